@@ -1,0 +1,458 @@
+"""Generate golden fixtures by importing the reference (/root/reference) in THIS container.
+
+TEST INFRASTRUCTURE.  Run once here (`python oracle/make_goldens.py`); the outputs
+under tests/golden/ are committed, the reference's Python never travels.  Each
+fixture holds inputs + the reference's outputs (and gradients) for one piece of
+the hot path.  Model weights are NOT stored: they
+are the analytic fill of oracle/analytic_weights.py applied through
+`named_parameters()`.
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = os.environ.get('STOVE_REFERENCE', '/root/reference')
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+
+import numpy as np
+import scipy
+import torch
+
+# ---- import-time stubs for packages the reference imports but the path never uses
+for name in ['spriteworld', 'spriteworld.renderers', 'spriteworld.sprite', 'imageio', 'setproctitle']:
+    if name not in sys.modules:
+        sys.modules[name] = types.ModuleType(name)
+sys.modules['spriteworld.sprite'].Sprite = object
+sys.modules['spriteworld'].renderers = sys.modules['spriteworld.renderers']
+sys.modules['setproctitle'].setproctitle = lambda *_: None
+if not hasattr(scipy, 'rand'):
+    scipy.rand = np.random.rand
+    scipy.randn = np.random.randn
+
+import warnings
+warnings.filterwarnings('ignore')
+
+from analytic_weights import analytic_tensor  # noqa: E402
+
+from model.video_prediction.config import StoveConfig  # noqa: E402
+from model.video_prediction.stove import Stove  # noqa: E402
+from model.video_prediction.supair import Supair  # noqa: E402
+from model.video_prediction.dynamics import Dynamics  # noqa: E402
+from model.spn import probabilistic_models as prob  # noqa: E402
+from model.spn import rat_torch  # noqa: E402
+from model.envs import envs as ref_envs  # noqa: E402
+import torch.distributions.normal as tdn  # noqa: E402
+
+
+def ref_config(dtype=torch.float64, **kw):
+    c = StoveConfig()
+    c.num_obj, c.width, c.height = 3, 32, 32
+    c.device = torch.device('cpu')
+    c.dtype = dtype
+    c.random_seed = 42
+    c.action_conditioned = False
+    c.action_space = None
+    c.skip = 2
+    c.r, c.coord_lim, c.num_frames = 1.2, 10, 100
+    for k, v in kw.items():
+        setattr(c, k, v)
+    torch.set_default_dtype(dtype)
+    return c
+
+
+def fill(module, prefix=''):
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            p.copy_(analytic_tensor(prefix + name, p.shape, p.dtype))
+
+
+def np_(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **{k: np_(v) for k, v in arrays.items()})
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+class EpsFeeder:
+    """Replaces torch.distributions.normal._standard_normal by a replay of a fixed list."""
+
+    def __init__(self, tensors):
+        self.tensors = list(tensors)
+        self.i = 0
+
+    def __call__(self, shape, dtype, device):
+        t = self.tensors[self.i]
+        self.i += 1
+        assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+        return t.to(dtype)
+
+
+# ------------------------------------------------------------------ G1 structure
+def spn_struct_json(spn):
+    layers = []
+    pos = {}
+    for li, layer in enumerate(spn.vector_list):
+        cur = []
+        for i, vec in enumerate(layer):
+            pos[id(vec)] = (li, i)
+            if isinstance(vec, rat_torch.GaussVector):
+                cur.append([int(s) for s in vec.scope])
+            elif isinstance(vec, rat_torch.ProductVector):
+                a, b = vec.inputs
+                cur.append([*pos[id(a)], *pos[id(b)]])
+            else:
+                cur.append([pos[id(p)][1] for p in vec.inputs])
+        layers.append(cur)
+    return {'layers': layers, 'root': list(pos[id(spn.output_vector)])}
+
+
+def g1_structures():
+    out = {}
+    for seed in (7, 42):
+        c = ref_config(random_seed=seed)
+        out[f'obj_{seed}'] = spn_struct_json(prob._get_obj_spn(c, seed))
+        out[f'bg_{seed}'] = spn_struct_json(prob._get_bg_spn(c, seed))
+    with open(os.path.join(OUT, 'g1_spn_structure.json'), 'w') as f:
+        json.dump(out, f)
+    print('wrote g1_spn_structure.json')
+
+
+# ------------------------------------------------------------------ G2 RatSpn.forward
+def g2_ratspn():
+    for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
+        c = ref_config(dtype)
+        g = torch.Generator().manual_seed(2)
+        for kind in ('obj', 'bg'):
+            spn = (prob._get_obj_spn if kind == 'obj' else prob._get_bg_spn)(c, 42)
+            fill(spn, f'sup.{kind}_spn.')
+            d = spn.num_dims
+            x = torch.rand(8, d, generator=g, dtype=torch.float64).to(dtype).requires_grad_()
+            m = torch.rand(8, d, generator=g, dtype=torch.float64).to(dtype)
+            m[0] = 0.0
+            m[1] = 1.0
+            m[2, ::3] = 1.3       # out of range on purpose (clamped by the leaf)
+            m[2, 1::3] = -0.2
+            m[3, : d // 2] = 0.0
+            m[3, d // 2:] = 1.0
+            m.requires_grad_()
+            out = spn.forward(x, m)
+            wsum = torch.linspace(0.5, 1.5, 8, dtype=dtype)
+            (out[:, 0] * wsum).sum().backward()
+            grads = {f'g_{n}': p.grad for n, p in spn.named_parameters()}
+            out_nomarg = spn.forward(x.detach(), None)
+            save(f'g2_ratspn_{kind}_{tag}', x=x, marg=m, out=out, out_nomarg=out_nomarg,
+                 gx=x.grad, gmarg=m.grad, wsum=wsum, **grads)
+
+
+# ------------------------------------------------------------------ G3/G4 scene pieces
+def crafted_z(n, n_obj, g, dtype):
+    z = torch.zeros(n, n_obj, 4, dtype=torch.float64)
+    z[..., 0] = 0.1 + 0.5 * torch.rand(n, n_obj, generator=g, dtype=torch.float64)
+    z[..., 1] = z[..., 0] * (0.75 + 0.5 * torch.rand(n, n_obj, generator=g, dtype=torch.float64))
+    z[..., 2:] = 1.8 * torch.rand(n, n_obj, 2, generator=g, dtype=torch.float64) - 0.9
+    z[0, 1, 2:] = z[0, 0, 2:] + 0.05               # overlapping pair
+    z[1, 0, 2:] = torch.tensor([0.95, -0.97])      # partly out of frame
+    z[2, :, 0] = 0.1                               # tiny boxes
+    z[2, :, 1] = 0.075
+    if n > 3:
+        z[3, :, 2:] = z[3, 0:1, 2:]                # all objects stacked
+    return z.to(dtype)
+
+
+def g3_masks_glimpses():
+    for n_obj in (3, 6):
+        c = ref_config(num_obj=n_obj)
+        sup = Supair(c)
+        g = torch.Generator().manual_seed(3)
+        n = 5
+        z = crafted_z(n, n_obj, g, c.dtype).requires_grad_()
+        x = torch.rand(n, 1, 32, 32, generator=g, dtype=torch.float64)
+        mp, bg, ov = sup.masks_from_z(z)
+        pat = sup.patches_from_z(x, z.flatten(end_dim=1))
+        wm = torch.rand(mp.shape, generator=g, dtype=torch.float64)
+        wb = torch.rand(bg.shape, generator=g, dtype=torch.float64)
+        wo = torch.rand(ov.shape, generator=g, dtype=torch.float64)
+        wp = torch.rand(pat.shape, generator=g, dtype=torch.float64)
+        ((mp * wm).sum() + (bg * wb).sum() + (ov * wo).sum() + (pat * wp).sum()).backward()
+        save(f'g3_scene_n{n_obj}', z=z, x=x, marg_patch=mp, bg_mask=bg, overlap=ov, patches=pat,
+             wm=wm, wb=wb, wo=wo, wp=wp, gz=z.grad)
+
+
+def g4_likelihood():
+    for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
+        for n_obj, extra in ((3, {}), (6, {'overlap_beta': 100.0, 'max_obj_scale': 0.22})):
+            c = ref_config(dtype, num_obj=n_obj, **extra)
+            c.debug = True
+            sup = Supair(c)
+            fill(sup, 'sup.')
+            g = torch.Generator().manual_seed(4)
+            n, t = 2, 4
+            x = (torch.rand(n, t, 1, 32, 32, generator=g, dtype=torch.float64) ** 3).to(dtype)
+            z = crafted_z(n * t, n_obj, g, dtype).flatten(end_dim=1).requires_grad_()
+            sup.step_counter = 0
+            lp, prop = sup.likelihood(x, z)
+            w = torch.linspace(0.5, 1.5, n * t, dtype=dtype)
+            (lp * w).sum().backward()
+            grads = {f'g_{k}': p.grad for k, p in sup.named_parameters() if p.grad is not None}
+            save(f'g4_likelihood_n{n_obj}_{tag}', x=x, z=z, log_p=lp, w=w, gz=z.grad,
+                 bg=prop['bg'], patch=prop['patch'], overlap=prop['overlap'], **grads)
+
+
+# ------------------------------------------------------------------ G5 dynamics
+def g5_dynamics():
+    variants = [
+        ('plain3', dict(num_obj=3), 2),
+        ('plain6', dict(num_obj=6), 2),
+        ('ac3', dict(num_obj=3, action_conditioned=True, action_space=9, debug_core_appearance=True), 2),
+        ('lim4', dict(num_obj=3), 4),
+    ]
+    for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
+        for name, kw, lim in variants:
+            c = ref_config(dtype, **kw)
+            dyn = Dynamics(c)
+            fill(dyn, 'dyn.')
+            g = torch.Generator().manual_seed(5)
+            b, n_obj = 6, c.num_obj
+            s = (torch.rand(b, n_obj, 16, generator=g, dtype=torch.float64) * 1.6 - 0.8).to(dtype).requires_grad_()
+            act = app = None
+            if c.action_conditioned:
+                act = torch.zeros(b, 9, dtype=dtype)
+                act[torch.arange(b), torch.arange(b) % 9] = 1.0
+                app = torch.rand(b, n_obj, 3, generator=g, dtype=torch.float64).to(dtype).requires_grad_()
+            res, rew = dyn.forward(s, 0, act, app, lim_enc=lim)
+            w = torch.rand(res.shape, generator=g, dtype=torch.float64).to(dtype)
+            loss = (res * w).sum()
+            if c.action_conditioned:
+                loss = loss + (rew * torch.linspace(1, 2, b, dtype=dtype).view(-1, 1)).sum()
+            loss.backward()
+            grads = {f'g_{k}': p.grad for k, p in dyn.named_parameters() if p.grad is not None}
+            extra = {}
+            if c.action_conditioned:
+                extra = dict(actions=act, app=app, reward=rew, gapp=app.grad)
+            save(f'g5_dynamics_{name}_{tag}', s=s, result=res, w=w, gs=s.grad, lim_enc=np.array(lim), **extra, **grads)
+
+
+# ------------------------------------------------------------------ G6 matchers + fix_supair, G10 units
+def g6_matchers():
+    g = torch.Generator().manual_seed(6)
+    # 3_only: mostly smooth tracks + injected swaps + an ambiguous (fault) case
+    c = ref_config()
+    st = Stove(c)
+    n, t = 6, 7
+    base = torch.rand(n, 1, 3, 4, generator=g, dtype=torch.float64) * 1.6 - 0.8
+    drift = torch.cumsum(0.03 * torch.randn(n, t, 3, 4, generator=g, dtype=torch.float64), 1)
+    z = base + drift
+    z[1, 3] = z[1, 3][[1, 0, 2]]
+    z[2, 2] = z[2, 2][[2, 0, 1]]
+    z[2, 5] = z[2, 5][[0, 2, 1]]
+    z[3, 1:, 0, 2:] = z[3, 1:, 1, 2:] + 1e-3       # two objects nearly on top of each other -> non-unique argmin
+    z[4, 4, :, 2:] = z[4, 3, 0:1, 2:]              # all current objects at prev object 0 -> fault repair
+    zstd = torch.rand(n, t, 3, 4, generator=g, dtype=torch.float64) * 0.3
+    zm, zsm, _ = st._3_only_match_objects(z.clone(), zstd.clone(), None)
+    app = torch.rand(n, t, 3, 3, generator=g, dtype=torch.float64)
+    c.debug_match_appearance = True
+    zm_a, zsm_a, app_m = st._3_only_match_objects(z.clone(), zstd.clone(), app.clone())
+    c.debug_match_appearance = False
+    save('g6_match_3only', z=z, zstd=zstd, z_matched=zm, zstd_matched=zsm,
+         app=app, z_matched_app=zm_a, zstd_matched_app=zsm_a, app_matched=app_m)
+
+    c6 = ref_config(num_obj=6, debug_match_objects='greedy')
+    st6 = Stove(c6)
+    base = torch.rand(n, 1, 6, 4, generator=g, dtype=torch.float64) * 1.6 - 0.8
+    z6 = base + torch.cumsum(0.03 * torch.randn(n, t, 6, 4, generator=g, dtype=torch.float64), 1)
+    for b in range(n):
+        for tt in range(1, t):
+            perm = torch.randperm(6, generator=g)
+            z6[b, tt] = z6[b, tt][perm]
+    z6std = torch.rand(n, t, 6, 4, generator=g, dtype=torch.float64) * 0.3
+    zm6, zsm6, _ = st6._greedy_match_objects(z6.clone(), z6std.clone(), None)
+    save('g6_match_greedy', z=z6, zstd=z6std, z_matched=zm6, zstd_matched=zsm6)
+
+    # fix_supair: glitches on scale dims (0,1) trigger, on position dims do not
+    zf = base[:, :, :3] + torch.cumsum(0.01 * torch.randn(n, t, 3, 4, generator=g, dtype=torch.float64), 1)
+    zf[0, 3, 1, 0] += 0.3
+    zf[1, 2, 0, 1] -= 0.25
+    zf[2, 4, 2, 2] += 0.5            # position glitch only: must not fire
+    zf[3, 0, 0, 0] += 0.4            # t=0 never fires
+    zf[3, t - 1, 1, 1] += 0.4        # t=T-1 never fires
+    zf[4, 2, 1, 0] += 0.3
+    zf[4, 3, 1, 0] += 0.3            # two in a row
+    zfs = torch.rand(n, t, 3, 4, generator=g, dtype=torch.float64) * 0.3
+    c = ref_config()
+    st = Stove(c)
+    a, b_ = st.fix_supair(zf.clone(), zfs.clone())
+    save('g6_fix_supair', z=zf, zstd=zfs, z_fixed=a, zstd_fixed=b_)
+
+
+def g10_units():
+    c = ref_config()
+    st = Stove(c)
+    g = torch.Generator().manual_seed(10)
+    zp = torch.randn(20, 8, generator=g, dtype=torch.float64) * 2
+    m, s = st.sup.constrain_zp(zp)
+    zd = torch.randn(4, 3, 16, generator=g, dtype=torch.float64) * 2
+    zds = torch.randn(4, 3, 16, generator=g, dtype=torch.float64) * 2
+    mc, sc = st.dyn.constrain_z_dyn(zd, zds)
+    zsup = torch.rand(4, 5, 3, 4, generator=g, dtype=torch.float64)
+    zsups = torch.rand(4, 5, 3, 4, generator=g, dtype=torch.float64) * 0.3
+    vf = st.v_from_state(zsup)
+    vs = st.v_std_from_pos(zsups)
+    xc = torch.rand(2, 3, 3, 32, 32, generator=g, dtype=torch.float64)
+    from model.utils.utils import bw_transform
+    bw = bw_transform(xc)
+    # full_state + transition_lik
+    eps = torch.randn(4, 3, 18, generator=g, dtype=torch.float64)
+    saved = tdn._standard_normal
+    tdn._standard_normal = EpsFeeder([eps])
+    zdyn = torch.rand(4, 3, 16, generator=g, dtype=torch.float64) - 0.5
+    sdyn = torch.rand(4, 3, 16, generator=g, dtype=torch.float64) * 0.3 + 0.01
+    zs6 = torch.rand(4, 3, 6, generator=g, dtype=torch.float64) - 0.5
+    ss6 = torch.rand(4, 3, 6, generator=g, dtype=torch.float64) * 0.3 + 0.01
+    z_s, log_q, mean, std = st.full_state(zdyn, sdyn, zs6, ss6)
+    tdn._standard_normal = saved
+    tl = st.transition_lik(zdyn, z_s[..., 2:])
+    save('g10_units', zp=zp, zp_mean=m, zp_std=s, zd=zd, zds=zds, zd_c=mc, zds_c=sc,
+         zsup=zsup, zsups=zsups, v_full=vf, vstd_full=vs, xc=xc, bw=bw,
+         eps=eps, zdyn=zdyn, sdyn=sdyn, zs6=zs6, ss6=ss6, fs_z=z_s, fs_logq=log_q, fs_mean=mean, fs_std=std,
+         translik=tl)
+
+
+# ------------------------------------------------------------------ G0 environments
+def g0_envs():
+    arrs = {}
+    for seed in range(4):
+        env = ref_envs.BillardsEnv(n=3, r=1.2, m=1., hw=10, granularity=10, res=32, t=1.,
+                                   friction_coefficient=0., seed=seed)
+        imgs, states = [], []
+        for _ in range(100):
+            img, st_, _ = env.step()
+            imgs.append(img.copy())
+            states.append(st_.copy())
+        arrs[f'bill3_img_{seed}'] = np.stack(imgs).astype(np.float32)
+        arrs[f'bill3_state_{seed}'] = np.stack(states)
+    for seed in range(2):
+        env = ref_envs.BillardsEnv(n=6, r=1., m=1., hw=10, granularity=10, res=32, t=1.,
+                                   friction_coefficient=0., seed=seed, use_colors=False)
+        imgs, states = [], []
+        for _ in range(30):
+            img, st_, _ = env.step()
+            imgs.append(img.copy())
+            states.append(st_.copy())
+        arrs[f'bill6_img_{seed}'] = np.stack(imgs).astype(np.float32)
+        arrs[f'bill6_state_{seed}'] = np.stack(states)
+    for seed in range(2):
+        env = ref_envs.GravityEnv(n=3, r=2, m=4., hw=30, granularity=50, res=32, t=1.,
+                                  init_v_factor=0.55, friction_coefficient=0., seed=seed)
+        imgs, states = [], []
+        for _ in range(30):
+            img, st_, _ = env.step()
+            imgs.append(img.copy())
+            states.append(st_.copy())
+        arrs[f'grav3_img_{seed}'] = np.stack(imgs).astype(np.float32)
+        arrs[f'grav3_state_{seed}'] = np.stack(states)
+    for seed in range(2):
+        base = ref_envs.BillardsEnv(n=3, r=1., m=1., hw=10, granularity=50, res=32, t=1.,
+                                    friction_coefficient=0., seed=seed)
+        task = ref_envs.AvoidanceTask(base, 4, greyscale=False, action_force=0.6)
+        p = np.random.uniform(0.2, 0.3)
+        pol = ref_envs.MonteCarloActionPolicy(action_space=9, prob_change=p)
+        imgs, states, acts, rews = [], [], [], []
+        for _ in range(30):
+            a = pol.next()
+            img, st_, rew, done = task.step(a)
+            imgs.append(np.asarray(img).copy())
+            states.append(np.asarray(st_).copy())
+            acts.append(a)
+            rews.append(rew)
+        arrs[f'avoid_img_{seed}'] = np.stack(imgs).astype(np.float32)
+        arrs[f'avoid_state_{seed}'] = np.stack(states)
+        arrs[f'avoid_action_{seed}'] = np.array(acts)
+        arrs[f'avoid_reward_{seed}'] = np.array(rews, dtype=np.float64)
+    save('g0_envs', **arrs)
+
+
+def billiards_frames(n_seq, t_len, n=3, r=1.2):
+    xs = []
+    for seed in range(n_seq):
+        env = ref_envs.BillardsEnv(n=n, r=r, m=1., hw=10, granularity=10, res=32, t=1.,
+                                   friction_coefficient=0., seed=seed, use_colors=None if n == 3 else False)
+        imgs = [env.step()[0].copy() for _ in range(t_len)]
+        xs.append(np.stack(imgs))
+    x = np.stack(xs)                                   # (B,T,res,res,3)
+    return np.transpose(x, (0, 1, 4, 2, 3))            # load_data.py:64
+
+
+# ------------------------------------------------------------------ G7/G8 full model
+def g7_g8_full():
+    cases = [
+        ('n3', dict(num_obj=3), 4, 8),
+        ('n6', dict(num_obj=6, debug_match_objects='greedy', overlap_beta=100.0, max_obj_scale=0.22), 2, 6),
+        ('ac3', dict(num_obj=3, action_conditioned=True, action_space=9, debug_core_appearance=True), 3, 6),
+    ]
+    for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
+        for name, kw, B, T in cases:
+            c = ref_config(dtype, **kw)
+            c.debug = True
+            N = c.num_obj
+            st = Stove(c)
+            fill(st)
+            x = torch.from_numpy(billiards_frames(B, T, n=N, r=1.2 if N == 3 else 1.0)).to(dtype)
+            g = torch.Generator().manual_seed(123)
+            lat = torch.randn(B, N, 12, 1, generator=g, dtype=torch.float64)
+            sd = torch.randn(B, N, 12, 1, generator=g, dtype=torch.float64)
+            steps = [torch.randn(B, N, 18, generator=g, dtype=torch.float64) for _ in range(2, T)]
+            actions = None
+            if c.action_conditioned:
+                actions = torch.zeros(B, T, 9, dtype=dtype)
+                ai = torch.randint(0, 9, (B, T), generator=g)
+                actions.scatter_(2, ai.unsqueeze(-1), 1.0)
+            saved = tdn._standard_normal
+            tdn._standard_normal = EpsFeeder([lat, sd] + steps)
+            elbo, prop, rewards = st(x, 0, actions)
+            tdn._standard_normal = saved
+            loss = -elbo
+            if c.action_conditioned:
+                loss = loss + 3.0 * (rewards ** 2).sum()
+            loss.backward()
+            gnorm = {f'gn_{k}': p.grad.norm() for k, p in st.named_parameters() if p.grad is not None}
+            small = {f'g_{k}': p.grad for k, p in st.named_parameters()
+                     if p.grad is not None and p.numel() <= 2100}
+            props = {f'p_{k}': v for k, v in prop.items() if v is not None and torch.is_tensor(v)}
+            extra = {}
+            if actions is not None:
+                extra['actions'] = actions
+                extra['rewards'] = rewards
+            # rollout from the last inferred state (G8)
+            with torch.no_grad():
+                z_last = prop['z'][:, -1]
+                fut = None
+                app = None
+                if c.action_conditioned:
+                    fut = actions[:, :5]
+                    app = prop['obj_appearances'][:, -1]
+                z_pred, r_pred = st.rollout(z_last, num=92 if name == 'n3' else 12, actions=fut, appearance=app)
+            extra['roll_z'] = z_pred
+            if c.action_conditioned:
+                extra['roll_rewards'] = r_pred
+            save(f'g7_stove_{name}_{tag}', x=x.to(torch.float32), eps_lat=lat, eps_std=sd, eps_steps=torch.stack(steps, 0),
+                 elbo=elbo, **props, **gnorm, **small, **extra)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7']
+    os.makedirs(OUT, exist_ok=True)
+    table = {'g0': g0_envs, 'g1': g1_structures, 'g2': g2_ratspn, 'g3': g3_masks_glimpses,
+             'g4': g4_likelihood, 'g5': g5_dynamics, 'g6': g6_matchers, 'g10': g10_units, 'g7': g7_g8_full}
+    for k in which:
+        torch.manual_seed(0)
+        np.random.seed(0)
+        table[k]()
