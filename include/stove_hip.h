@@ -1,0 +1,110 @@
+/* libstove_hip.so -- C ABI of the MI355X (gfx950) STOVE hot path.
+ *
+ * The reference (jlko/STOVE) has no FFI: the path sits behind Python modules whose work is a
+ * stream of ATen ops.  Each entry point below replaces one such op chain; the comment names
+ * the reference lines (relative to the reference repo root) it stands in for.  The Python
+ * modules in stove_amd/ (same names/signatures as the reference's) bind these with ctypes.
+ *
+ * Conventions:
+ *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch allocates), float32 unless noted; `stream` is a hipStream_t passed as void*.
+ *   - functions only enqueue work on `stream`: no allocation, no free, no synchronisation,
+ *     no global state; re-entrant and thread-safe; safe under hipGraph capture.
+ *   - workspaces are sized by the matching *_ws_bytes() query and need no initialisation.
+ *   - return value: 0 on success, otherwise the hipError_t of the failed launch
+ *     (stove_error_string() names it).
+ *   - all gradients are OVERWRITTEN, never accumulated.
+ */
+#ifndef STOVE_HIP_H
+#define STOVE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int stove_abi_version(void);
+const char* stove_error_string(int code);
+
+/* Baked parameter tables of the two random SPNs (built by stove_amd/spn/rat_spn.py from the
+ * reference-layout parameters: vector_list.L.i.{means,sigma_params,params}).
+ * Object SPN (probabilistic_models.py:8-22; R=6 replicas, 4 leaves x S=25 pixels, G=K=10):
+ *   obj_scope     int32 [R*4][S]        pixel index of leaf row i          (region_graph.py:54-95)
+ *   obj_leaf_slot int32 [R][100]        L*S+i of pixel p inside replica r
+ *   obj_coef      f32   [R*4][S][G][3]  (a,b,c): leaf log-density = sum_p w_p (a x^2 + b x + c)   (rat_torch.py:83-109)
+ *   obj_wsum      f32   [R*2][G*G][K]   softmax(params, 0) of the 12 inner sum nodes            (rat_torch.py:202-222)
+ *   obj_wroot     f32   [R][K*K]        softmax over all R*K*K root weights
+ * Background SPN (probabilistic_models.py:25-39; R=3, two 512-pixel leaves, G=6):
+ *   bg_side       int32 [R][1024]       0/1: which leaf of replica r owns pixel p
+ *   bg_coef       f32   [R][1024][G][3]
+ *   bg_wroot      f32   [R][G*G]        softmax over all R*G*G root weights, row j2*G+j1
+ */
+typedef struct StoveSpnTables {
+  const int32_t* obj_scope;
+  const int32_t* obj_leaf_slot;
+  const float* obj_coef;
+  const float* obj_wsum;
+  const float* obj_wroot;
+  const int32_t* bg_side;
+  const float* bg_coef;
+  const float* bg_wroot;
+} StoveSpnTables;
+
+/* Gradients w.r.t. the baked tables (same shapes as above). */
+typedef struct StoveSpnTableGrads {
+  float* obj_coef;
+  float* obj_wsum;
+  float* obj_wroot;
+  float* bg_coef;
+  float* bg_wroot;
+} StoveSpnTableGrads;
+
+/* ---- RatSpn.forward(inputs, marginalized) for the object SPN (rat_torch.py:354-357 as called
+ * at supair.py:76).  inputs/marg: (n,100) row-major, marg may be NULL.  out: (n,).
+ * `xw` is the saved activation for the backward: ceil(n/64)*100*2*64 floats. */
+size_t stove_objspn_tile_floats(int n);
+int stove_objspn_fwd(const StoveSpnTables* t, const float* inputs, const float* marg, float* xw, float* out,
+                     int n, void* stream);
+size_t stove_objspn_bwd_ws_bytes(int n);
+/* d_inputs/d_marg (n,100) may be NULL. */
+int stove_objspn_bwd(const StoveSpnTables* t, const float* marg, const float* xw, const float* out, const float* dout,
+                     float* d_inputs, float* d_marg, StoveSpnTableGrads* g, void* ws, int n, void* stream);
+
+/* ---- RatSpn.forward for the background SPN (supair.py:67).  inputs/marg: (n,1024).
+ * `ell` is the saved activation: stove_bgspn_saved_floats(n) floats. */
+size_t stove_bgspn_saved_floats(int n);
+int stove_bgspn_fwd(const StoveSpnTables* t, const float* inputs, const float* marg, float* ell, float* out,
+                    int n, void* stream);
+size_t stove_bgspn_bwd_ws_bytes(int n);
+int stove_bgspn_bwd(const StoveSpnTables* t, const float* inputs, const float* marg, const float* ell, const float* out,
+                    const float* dout, float* d_inputs, float* d_marg, StoveSpnTableGrads* g, void* ws, int n,
+                    void* stream);
+
+/* ---- Supair.likelihood (supair.py:44-110), fused: masks_from_z (:278-356), patches_from_z
+ * (:241-276), both SPN sweeps, patch scaling + Exponential(beta) overlap prior (:79-94).
+ * frames: (n_frames,1024) one-channel frames; z: (n_frames*n_obj,4) = [sx,sy,x,y].
+ * ll: (n_frames,) log p(x,z); parts: (n_frames,3) = bg, patches, overlap (may be NULL).
+ * saved: stove_scene_saved_floats() floats kept for the backward. */
+size_t stove_scene_saved_floats(int n_frames, int n_obj);
+int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
+                    float overlap_beta, float* ll, float* parts, float* saved, void* stream);
+size_t stove_scene_bwd_ws_bytes(int n_frames, int n_obj);
+/* dll: (n_frames,) -> dz: (n_frames*n_obj,4) and table gradients. */
+int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
+                    float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g,
+                    void* ws, void* stream);
+
+/* ---- glimpses + masks alone (supair.py:241-356), for the Supair.patches_from_z /
+ * masks_from_z API: patches, marg_patch: (n_frames*n_obj,100); overlap: (n_frames*n_obj,).
+ * `tile` is scratch of stove_objspn_tile_floats(n_frames*n_obj) floats. */
+int stove_scene_glimpses(const float* frames, const float* z, int n_frames, int n_obj, float* tile,
+                         float* patches, float* keep, void* stream);
+
+/* self-test hooks used by tests/ (wave reduction) */
+int stove_selftest_wave_sum(const float* in, float* out, int n_waves, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STOVE_HIP_H */

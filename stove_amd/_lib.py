@@ -1,0 +1,99 @@
+"""ctypes binding of libstove_hip.so (C ABI in include/stove_hip.h).  No fallback: a missing
+library or a non-GPU tensor is an error."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libstove_hip.so')
+_lib = None
+
+EXPORTS = [
+    'stove_abi_version', 'stove_error_string', 'stove_selftest_wave_sum',
+    'stove_objspn_tile_floats', 'stove_objspn_fwd', 'stove_objspn_bwd_ws_bytes', 'stove_objspn_bwd',
+    'stove_bgspn_saved_floats', 'stove_bgspn_fwd', 'stove_bgspn_bwd_ws_bytes', 'stove_bgspn_bwd',
+    'stove_scene_saved_floats', 'stove_scene_fwd', 'stove_scene_bwd_ws_bytes', 'stove_scene_bwd',
+    'stove_scene_glimpses',
+]
+
+
+class SpnTables(Structure):
+    _fields_ = [('obj_scope', c_void_p), ('obj_leaf_slot', c_void_p), ('obj_coef', c_void_p),
+                ('obj_wsum', c_void_p), ('obj_wroot', c_void_p),
+                ('bg_side', c_void_p), ('bg_coef', c_void_p), ('bg_wroot', c_void_p)]
+
+
+class SpnTableGrads(Structure):
+    _fields_ = [('obj_coef', c_void_p), ('obj_wsum', c_void_p), ('obj_wroot', c_void_p),
+                ('bg_coef', c_void_p), ('bg_wroot', c_void_p)]
+
+
+def _declare(lib):
+    P, I, F, S = c_void_p, c_int, c_float, c_size_t
+    T, G = POINTER(SpnTables), POINTER(SpnTableGrads)
+    sig = {
+        'stove_abi_version': (I, []),
+        'stove_error_string': (c_char_p, [I]),
+        'stove_selftest_wave_sum': (I, [P, P, I, P]),
+        'stove_objspn_tile_floats': (S, [I]),
+        'stove_objspn_fwd': (I, [T, P, P, P, P, I, P]),
+        'stove_objspn_bwd_ws_bytes': (S, [I]),
+        'stove_objspn_bwd': (I, [T, P, P, P, P, P, P, G, P, I, P]),
+        'stove_bgspn_saved_floats': (S, [I]),
+        'stove_bgspn_fwd': (I, [T, P, P, P, P, I, P]),
+        'stove_bgspn_bwd_ws_bytes': (S, [I]),
+        'stove_bgspn_bwd': (I, [T, P, P, P, P, P, P, P, G, P, I, P]),
+        'stove_scene_saved_floats': (S, [I, I]),
+        'stove_scene_fwd': (I, [T, P, P, I, I, F, P, P, P, P]),
+        'stove_scene_bwd_ws_bytes': (S, [I, I]),
+        'stove_scene_bwd': (I, [T, P, P, I, I, F, P, P, P, G, P, P]),
+        'stove_scene_glimpses': (I, [P, P, I, I, P, P, P, P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    for name in OPTIONAL_SIGS:
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = OPTIONAL_SIGS[name]
+
+
+OPTIONAL_SIGS = {}
+
+
+def load():
+    """Return the loaded library; raise if it has not been built (run `python -m stove_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `python -m stove_amd.build` '
+                '(hipcc --offload-arch=gfx950). stove_amd has no CPU fallback.')
+        lib = ctypes.CDLL(LIB_PATH)
+        _declare(lib)
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().stove_error_string(code)
+        raise RuntimeError(f'{what} failed: hipError {code} ({msg.decode() if msg else "?"})')
+
+
+def ptr(t):
+    """Device pointer of a contiguous float32/int32 CUDA(HIP) tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('stove_amd HIP ops need tensors on a GPU (cuda:N); there is no CPU path')
+    if not t.is_contiguous():
+        raise RuntimeError('stove_amd HIP ops need contiguous tensors')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

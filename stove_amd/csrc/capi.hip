@@ -1,0 +1,223 @@
+// C ABI of libstove_hip.so (see include/stove_hip.h).  Single translation unit: the kernel
+// files are included here so every launch sees its kernel without relocatable device code.
+#include "../../include/stove_hip.h"
+
+#include "common.h"
+#include "spn_obj.hip"
+#include "spn_bg.hip"
+#include "scene.hip"
+
+namespace stove {
+
+__global__ void wave_sum_test_k(const float* __restrict__ in, float* __restrict__ out) {
+  const int w = blockIdx.x * (blockDim.x >> 6) + wave_id();
+  const float v = in[(size_t)w * 64 + lane_id()];
+  const float s = wave_sum(v);
+  out[(size_t)w * 64 + lane_id()] = s;
+}
+
+// tile [nb][100][2][64] -> patches (n,100), keep (n,100)
+__global__ void tile_unpack_k(const float* __restrict__ tile, float* __restrict__ patches, float* __restrict__ keep,
+                              int n, int n_batches) {
+  const int total = n_batches * kPD * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63, p = (i >> 6) % kPD, b = i / (64 * kPD);
+    const int smp = b * 64 + lane;
+    if (smp >= n) continue;
+    const float* t = tile + ((size_t)b * kPD + p) * 2 * 64;
+    if (patches) patches[(size_t)smp * kPD + p] = t[lane];
+    if (keep) keep[(size_t)smp * kPD + p] = t[64 + lane];
+  }
+}
+
+template <int NMAX>
+static int scene_tile_fwd(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st) {
+  const int nb = (np + 63) / 64;
+  const int items = nb * kPD;
+  const int grid = items / 4 < 8192 ? (items + 3) / 4 : 8192;
+  hipLaunchKernelGGL((scene_tile_fwd_k<NMAX>), dim3(grid), dim3(256), 0, st, frames, z, xw, n_obj, np, nb);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+static int scene_tile_fwd_any(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st) {
+  if (n_obj <= 3) return scene_tile_fwd<3>(frames, z, xw, n_obj, np, st);
+  if (n_obj <= 6) return scene_tile_fwd<6>(frames, z, xw, n_obj, np, st);
+  if (n_obj <= 8) return scene_tile_fwd<8>(frames, z, xw, n_obj, np, st);
+  return (int)hipErrorInvalidValue;
+}
+
+static inline int nmax_of(int n_obj) { return n_obj <= 3 ? 3 : (n_obj <= 6 ? 6 : 8); }
+
+template <int NMAX>
+static int scene_bwd_tail(const float* frames, const float* z, const float* dxw, const float* d_ovl, float* dzc,
+                          const float* dll, const float* obj_ll, const float* dz_bg, float* dz, int n_obj, int np,
+                          hipStream_t st) {
+  const int nb = (np + 63) / 64;
+  hipLaunchKernelGGL((scene_tile_bwd_k<NMAX>), dim3(nb < 4096 ? nb : 4096), dim3(256), 0, st, frames, z, dxw, d_ovl, dzc, n_obj, np, nb);
+  STOVE_LAUNCH_CHECK();
+  hipLaunchKernelGGL((scene_finalize_bwd_k<NMAX>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, obj_ll, dz_bg, dzc, dz, n_obj, np);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
+
+}  // namespace stove
+
+using namespace stove;
+
+extern "C" {
+
+int stove_abi_version(void) { return 1; }
+
+const char* stove_error_string(int code) { return hipGetErrorString((hipError_t)code); }
+
+int stove_selftest_wave_sum(const float* in, float* out, int n_waves, void* stream) {
+  if (n_waves % 4) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(wave_sum_test_k, dim3(n_waves / 4), dim3(256), 0, (hipStream_t)stream, in, out);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- object SPN operator
+size_t stove_objspn_tile_floats(int n) { return (size_t)((n + 63) / 64) * kObjX; }
+
+int stove_objspn_fwd(const StoveSpnTables* t, const float* inputs, const float* marg, float* xw, float* out, int n,
+                     void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = objspn_tile_from_arrays(inputs, marg, xw, n, st);
+  if (rc) return rc;
+  return objspn_forward(xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, out, nullptr, n, st);
+}
+
+size_t stove_objspn_bwd_ws_bytes(int n) { return (objspn_bwd_ws_floats(n) + stove_objspn_tile_floats(n)) * sizeof(float); }
+
+int stove_objspn_bwd(const StoveSpnTables* t, const float* marg, const float* xw, const float* out, const float* dout,
+                     float* d_inputs, float* d_marg, StoveSpnTableGrads* g, void* ws, int n, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  float* dxw = (float*)ws;
+  float* rest = dxw + stove_objspn_tile_floats(n);
+  int rc = objspn_backward(xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot, out, dout, dxw,
+                           g->obj_coef, g->obj_wsum, g->obj_wroot, rest, n, st);
+  if (rc) return rc;
+  if (d_inputs == nullptr && d_marg == nullptr) return 0;
+  if (d_marg != nullptr && marg == nullptr) return (int)hipErrorInvalidValue;
+  return objspn_tile_to_arrays(dxw, marg, d_inputs, d_marg, n, st);
+}
+
+// ---------------------------------------------------------------- background SPN operator
+size_t stove_bgspn_saved_floats(int n) { return bgspn_fwd_ws_floats(n); }
+
+int stove_bgspn_fwd(const StoveSpnTables* t, const float* inputs, const float* marg, float* ell, float* out, int n,
+                    void* stream) {
+  return bgspn_forward(inputs, marg, nullptr, 0, t->bg_side, t->bg_coef, t->bg_wroot, ell, out, n, (hipStream_t)stream);
+}
+
+size_t stove_bgspn_bwd_ws_bytes(int n) { return bgspn_bwd_ws_floats(n) * sizeof(float); }
+
+int stove_bgspn_bwd(const StoveSpnTables* t, const float* inputs, const float* marg, const float* ell, const float* out,
+                    const float* dout, float* d_inputs, float* d_marg, StoveSpnTableGrads* g, void* ws, int n,
+                    void* stream) {
+  if (d_marg != nullptr && marg == nullptr) return (int)hipErrorInvalidValue;
+  return bgspn_backward(inputs, marg, nullptr, 0, t->bg_side, t->bg_coef, t->bg_wroot, ell, out, dout, d_inputs, d_marg,
+                        nullptr, g->bg_coef, g->bg_wroot, (float*)ws, n, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- fused scene likelihood
+// saved = [ xw tile | obj_ll (np) | ovl (np) | bg_out (nf) | bg_ell ]
+struct SceneSaved {
+  size_t xw, obj_ll, ovl, bg_out, bg_ell, total;
+};
+static SceneSaved scene_saved_layout(int nf, int n_obj) {
+  const size_t np = (size_t)nf * n_obj;
+  SceneSaved s;
+  s.xw = 0;
+  s.obj_ll = align64(stove_objspn_tile_floats((int)np));
+  s.ovl = s.obj_ll + align64(np);
+  s.bg_out = s.ovl + align64(np);
+  s.bg_ell = s.bg_out + align64(nf);
+  s.total = s.bg_ell + align64(bgspn_fwd_ws_floats(nf));
+  return s;
+}
+
+size_t stove_scene_saved_floats(int n_frames, int n_obj) { return scene_saved_layout(n_frames, n_obj).total; }
+
+int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
+                    float overlap_beta, float* ll, float* parts, float* saved, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_frames == 0) return 0;
+  const SceneSaved L = scene_saved_layout(n_frames, n_obj);
+  const int np = n_frames * n_obj;
+  int rc = scene_tile_fwd_any(frames, z, saved + L.xw, n_obj, np, st);
+  if (rc) return rc;
+  rc = objspn_forward(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl, np, st);
+  if (rc) return rc;
+  rc = bgspn_forward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(scene_assemble_fwd_k, dim3((n_frames + 255) / 256), dim3(256), 0, st, saved + L.bg_out, saved + L.obj_ll,
+                     saved + L.ovl, z, ll, parts, n_obj, n_frames, overlap_beta, logf(overlap_beta));
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ws = [ dxw tile | d_obj (np) | d_ovl (np) | dzc (np*NMAX*4) | dz_bg (np*4) | obj ws | bg ws ]
+struct SceneWs {
+  size_t dxw, d_obj, d_ovl, dzc, dz_bg, obj, bg, total;
+};
+static SceneWs scene_ws_layout(int nf, int n_obj) {
+  const size_t np = (size_t)nf * n_obj;
+  SceneWs s;
+  s.dxw = 0;
+  s.d_obj = align64(stove_objspn_tile_floats((int)np));
+  s.d_ovl = s.d_obj + align64(np);
+  s.dzc = s.d_ovl + align64(np);
+  s.dz_bg = s.dzc + align64(np * nmax_of(n_obj) * 4);
+  s.obj = s.dz_bg + align64(np * 4);
+  s.bg = s.obj + align64(objspn_bwd_ws_floats((int)np));
+  s.total = s.bg + align64(bgspn_bwd_ws_floats(nf));
+  return s;
+}
+
+size_t stove_scene_bwd_ws_bytes(int n_frames, int n_obj) { return scene_ws_layout(n_frames, n_obj).total * sizeof(float); }
+
+int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
+                    float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g, void* ws_,
+                    void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_frames == 0) return 0;
+  float* ws = (float*)ws_;
+  const SceneSaved L = scene_saved_layout(n_frames, n_obj);
+  const SceneWs W = scene_ws_layout(n_frames, n_obj);
+  const int np = n_frames * n_obj;
+  hipLaunchKernelGGL(scene_assemble_bwd_k, dim3((np + 255) / 256), dim3(256), 0, st, dll, z, ws + W.d_obj, ws + W.d_ovl, n_obj, np, overlap_beta);
+  STOVE_LAUNCH_CHECK();
+  int rc = objspn_backward(saved + L.xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot,
+                           saved + L.obj_ll, ws + W.d_obj, ws + W.dxw, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, st);
+  if (rc) return rc;
+  rc = bgspn_backward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, dll,
+                      nullptr, nullptr, ws + W.dz_bg, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, st);
+  if (rc) return rc;
+  if (n_obj <= 3)
+    return scene_bwd_tail<3>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st);
+  if (n_obj <= 6)
+    return scene_bwd_tail<6>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st);
+  if (n_obj <= 8)
+    return scene_bwd_tail<8>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st);
+  return (int)hipErrorInvalidValue;
+}
+
+int stove_scene_glimpses(const float* frames, const float* z, int n_frames, int n_obj, float* tile, float* patches,
+                         float* keep, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int np = n_frames * n_obj;
+  if (np == 0) return 0;
+  int rc = scene_tile_fwd_any(frames, z, tile, n_obj, np, st);
+  if (rc) return rc;
+  const int nb = (np + 63) / 64;
+  hipLaunchKernelGGL(tile_unpack_k, dim3(nb < 2048 ? nb * 25 : 2048 * 25), dim3(256), 0, st, tile, patches, keep, np, nb);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

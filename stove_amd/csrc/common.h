@@ -1,0 +1,62 @@
+// Shared device helpers for the STOVE gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace stove {
+
+constexpr int kWave = 64;
+constexpr float kLog2Pi = 1.8378770664093453f;
+
+// Wave-uniform value of the wave index inside the block (lets hipcc emit s_load for table reads).
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// Sum over the 64 lanes of a wave with DPP moves (VALU only, no LDS crossbar traffic).
+// The result is valid in lane 63; wave_sum() broadcasts it.
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, false));  // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, false));  // row_shr:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1,3
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2,3
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = wave_sum_lane63(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// One-dimensional bilinear tap pair of torch's grid_sample (align_corners=False, zero padding):
+// pixel coordinate q in an axis of `n` samples -> floor index i0, weights (1-t, t), in-bounds flags.
+struct Tap1 {
+  int i0;
+  float t;
+  float in0, in1;   // 1.0 / 0.0
+};
+__device__ __forceinline__ Tap1 make_tap(float q, int n) {
+  Tap1 r;
+  const float f = floorf(q);
+  r.i0 = (int)f;
+  r.t = q - f;
+  r.in0 = (r.i0 >= 0 && r.i0 < n) ? 1.0f : 0.0f;
+  r.in1 = (r.i0 + 1 >= 0 && r.i0 + 1 < n) ? 1.0f : 0.0f;
+  return r;
+}
+// Coverage of a ones-image sampled at q (zero padding): value and d/dq.
+__device__ __forceinline__ float cover(float q, int n, float* dq) {
+  const Tap1 t = make_tap(q, n);
+  *dq = t.in1 - t.in0;
+  return (1.0f - t.t) * t.in0 + t.t * t.in1;
+}
+
+}  // namespace stove
+
+#define STOVE_LAUNCH_CHECK()                          \
+  do {                                                \
+    hipError_t e__ = hipGetLastError();               \
+    if (e__ != hipSuccess) return (int)e__;           \
+  } while (0)

@@ -1,0 +1,304 @@
+// SuPAIR scene side of the likelihood: glimpses, occlusion masks, assembly (gfx950).
+//
+// Replaces, fused with the SPN sweeps, the reference's
+//   Supair.patches_from_z  (model/video_prediction/supair.py:241-276)  F.affine_grid + F.grid_sample
+//   Supair.masks_from_z    (supair.py:278-356)                        N sequential sample/paste rounds
+//   Supair.likelihood      (supair.py:79-94)                          scaling, overlap prior, sum
+// Semantics are those of torch >= 1.3 (align_corners=False), which is what the runnable
+// reference computes.
+//
+// The sequential mask recursion is removed algebraically: a pasted unit box is separable,
+// box_k[Y][X] = cover_x(X) * cover_y(Y), and clamp(clamp(a+b)+c) = min(1, a+b+c) for
+// non-negative terms, so the mask an object sees at a bilinear tap is a closed form of the
+// earlier objects' z.  Every (patch, pixel) is therefore independent: one lane per patch,
+// pixels looped, results written coalesced into the [batch][pixel][x|w][64] tile the
+// object-SPN kernels consume.
+#include "common.h"
+
+namespace stove {
+
+constexpr int kImg = 32;     // frame side
+constexpr int kPatch = 10;   // glimpse side
+constexpr int kPD = kPatch * kPatch;
+
+struct PatchPix {
+  Tap1 tx, ty;
+  float u, v;
+};
+__device__ __forceinline__ PatchPix patch_pix(const float* zk, int p) {
+  PatchPix q;
+  const int i = p / kPatch, j = p % kPatch;
+  q.u = (2.0f * j + 1.0f) * (1.0f / kPatch) - 1.0f;
+  q.v = (2.0f * i + 1.0f) * (1.0f / kPatch) - 1.0f;
+  const float gx = fmaf(zk[0], q.u, zk[2]);
+  const float gy = fmaf(zk[1], q.v, zk[3]);
+  q.tx = make_tap(((gx + 1.0f) * kImg - 1.0f) * 0.5f, kImg);
+  q.ty = make_tap(((gy + 1.0f) * kImg - 1.0f) * 0.5f, kImg);
+  return q;
+}
+
+__device__ __forceinline__ float inv_pix(float inv_s, float off, int idx) {
+  const float u = (2.0f * idx + 1.0f) * (1.0f / kImg) - 1.0f;
+  return ((fmaf(inv_s, u, off) + 1.0f) * kImg - 1.0f) * 0.5f;
+}
+
+// ---- tile forward: thread = (patch lane, pixel) -------------------------------------------
+// frames [n_frames][1024], z [n_frames*n_obj][4] = [sx, sy, x, y]; xw [n_batches][100][2][64]
+template <int NMAX>
+__global__ __launch_bounds__(256) void scene_tile_fwd_k(const float* __restrict__ frames, const float* __restrict__ z,
+                                                        float* __restrict__ xw, int n_obj, int n_patches, int n_batches) {
+  const int lane = lane_id();
+  const int total = n_batches * kPD;
+  for (int item = blockIdx.x * 4 + wave_id(); item < total; item += gridDim.x * 4) {
+    const int b = item / kPD, p = item % kPD;
+    const int patch = b * 64 + lane;
+    float xv = 0.0f, wv = 0.0f;
+    if (patch < n_patches) {
+      const int f = patch / n_obj, k = patch % n_obj;
+      const float* zf = z + (size_t)f * n_obj * 4;
+      const float zk[4] = {zf[k * 4], zf[k * 4 + 1], zf[k * 4 + 2], zf[k * 4 + 3]};
+      const PatchPix q = patch_pix(zk, p);
+      const float* img = frames + (size_t)f * kImg * kImg;
+      // earlier objects' coverage at the two tap columns / rows
+      float cx[NMAX][2], cy[NMAX][2];
+#pragma unroll
+      for (int j = 0; j < NMAX; ++j) {
+        if (j < k) {
+          const float isx = 1.0f / zf[j * 4], isy = 1.0f / zf[j * 4 + 1];
+          const float ox = -zf[j * 4 + 2] * isx, oy = -zf[j * 4 + 3] * isy;
+          float d;
+          cx[j][0] = cover(inv_pix(isx, ox, q.tx.i0), kImg, &d);
+          cx[j][1] = cover(inv_pix(isx, ox, q.tx.i0 + 1), kImg, &d);
+          cy[j][0] = cover(inv_pix(isy, oy, q.ty.i0), kImg, &d);
+          cy[j][1] = cover(inv_pix(isy, oy, q.ty.i0 + 1), kImg, &d);
+        }
+      }
+      float seen = 0.0f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float inb = (a ? q.ty.in1 : q.ty.in0) * (c ? q.tx.in1 : q.tx.in0);
+          if (inb != 0.0f) {
+            const float wt = (a ? q.ty.t : 1.0f - q.ty.t) * (c ? q.tx.t : 1.0f - q.tx.t);
+            xv = fmaf(wt, img[(q.ty.i0 + a) * kImg + q.tx.i0 + c], xv);
+            float run = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j)
+              if (j < k) run = fminf(run + cx[j][c] * cy[j][a], 1.0f);
+            seen = fmaf(wt, 1.0f - run, seen);
+          }
+        }
+      }
+      const float mg = 1.0f - seen;                               // supair.py:331
+      wv = 1.0f - fminf(fmaxf(mg, 0.0f), 1.0f);                   // rat_torch.py:104-106
+    }
+    float* t = xw + ((size_t)b * kPD + p) * 2 * 64;
+    t[lane] = xv;
+    t[64 + lane] = wv;
+  }
+}
+
+// ---- tile backward: dL/d(x,w) of the tile -> dL/dz of the patch's own object and of the
+// earlier objects of the same frame.  block = 64 patches x 4 pixel slots.
+// dzc[patch][NMAX][4]: slot k = own object, slots j<k = occluders.
+// d_ovl[patch] = dL/d overlap_k (overlap = mean over the patch of marg).
+template <int NMAX>
+__global__ __launch_bounds__(256) void scene_tile_bwd_k(const float* __restrict__ frames, const float* __restrict__ z,
+                                                        const float* __restrict__ dxw, const float* __restrict__ d_ovl,
+                                                        float* __restrict__ dzc, int n_obj, int n_patches, int n_batches) {
+  __shared__ float red[4][NMAX * 4][64];
+  const int lane = lane_id(), slot = wave_id();
+  for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
+    const int patch = b * 64 + lane;
+    const bool live = patch < n_patches;
+    const int f = live ? patch / n_obj : 0, k = live ? patch % n_obj : 0;
+    const float* zf = z + (size_t)f * n_obj * 4;
+    const float zk[4] = {zf[k * 4], zf[k * 4 + 1], zf[k * 4 + 2], zf[k * 4 + 3]};
+    const float* img = frames + (size_t)f * kImg * kImg;
+    const float govl = live ? d_ovl[patch] * (-1.0f / kPD) : 0.0f;   // d overlap / d seen = -1/100
+    float acc[NMAX][4];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
+    float isx[NMAX], isy[NMAX], ox[NMAX], oy[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+      if (j < k) {
+        isx[j] = 1.0f / zf[j * 4];
+        isy[j] = 1.0f / zf[j * 4 + 1];
+        ox[j] = -zf[j * 4 + 2] * isx[j];
+        oy[j] = -zf[j * 4 + 3] * isy[j];
+      }
+    }
+    float own[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (live) {
+      for (int p = slot; p < kPD; p += 4) {
+        const float* t = dxw + ((size_t)b * kPD + p) * 2 * 64;
+        const float gX = t[lane], gW = t[64 + lane];
+        const PatchPix q = patch_pix(zk, p);
+        float cx[NMAX][2], cy[NMAX][2], dcx[NMAX][2], dcy[NMAX][2];
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+          if (j < k) {
+            cx[j][0] = cover(inv_pix(isx[j], ox[j], q.tx.i0), kImg, &dcx[j][0]);
+            cx[j][1] = cover(inv_pix(isx[j], ox[j], q.tx.i0 + 1), kImg, &dcx[j][1]);
+            cy[j][0] = cover(inv_pix(isy[j], oy[j], q.ty.i0), kImg, &dcy[j][0]);
+            cy[j][1] = cover(inv_pix(isy[j], oy[j], q.ty.i0 + 1), kImg, &dcy[j][1]);
+          }
+        }
+        // forward pieces at the four taps
+        float im[2][2], vis[2][2];
+        bool pass[2][2];
+        float seen = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const float inb = (a ? q.ty.in1 : q.ty.in0) * (c ? q.tx.in1 : q.tx.in0);
+            im[a][c] = 0.0f;
+            vis[a][c] = 0.0f;
+            pass[a][c] = false;
+            if (inb != 0.0f) {
+              im[a][c] = img[(q.ty.i0 + a) * kImg + q.tx.i0 + c];
+              float run = 0.0f;
+              bool ok = true;
+#pragma unroll
+              for (int j = 0; j < NMAX; ++j) {
+                if (j < k) {
+                  run += cx[j][c] * cy[j][a];
+                  if (run > 1.0f) {
+                    run = 1.0f;
+                    ok = false;
+                  }
+                }
+              }
+              vis[a][c] = 1.0f - run;
+              pass[a][c] = ok;
+              const float wt = (a ? q.ty.t : 1.0f - q.ty.t) * (c ? q.tx.t : 1.0f - q.tx.t);
+              seen = fmaf(wt, vis[a][c], seen);
+            }
+          }
+        }
+        const float mg = 1.0f - seen;
+        // w = 1 - clamp(1 - seen): dw/dseen = 1 inside the clamp range (boundaries pass, as ATen)
+        const float dseen = ((mg >= 0.0f && mg <= 1.0f) ? gW : 0.0f) + govl;
+        // own object: through the sample location
+        const float wy0 = 1.0f - q.ty.t, wy1 = q.ty.t, wx0 = 1.0f - q.tx.t, wx1 = q.tx.t;
+        const float dpx = gX * (wy0 * (im[0][1] - im[0][0]) + wy1 * (im[1][1] - im[1][0])) +
+                          dseen * (wy0 * (vis[0][1] - vis[0][0]) + wy1 * (vis[1][1] - vis[1][0]));
+        const float dpy = gX * (wx0 * (im[1][0] - im[0][0]) + wx1 * (im[1][1] - im[0][1])) +
+                          dseen * (wx0 * (vis[1][0] - vis[0][0]) + wx1 * (vis[1][1] - vis[0][1]));
+        const float dgx = dpx * (0.5f * kImg), dgy = dpy * (0.5f * kImg);
+        own[0] = fmaf(dgx, q.u, own[0]);
+        own[1] = fmaf(dgy, q.v, own[1]);
+        own[2] += dgx;
+        own[3] += dgy;
+        // occluders: through the mask value at each tap
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            if (pass[a][c]) {
+              const float wt = (a ? wy1 : wy0) * (c ? wx1 : wx0);
+              const float dbox = -dseen * wt;   // vis = 1 - sum box
+              const int col = q.tx.i0 + c, row = q.ty.i0 + a;
+              const float uu = (2.0f * col + 1.0f) * (1.0f / kImg) - 1.0f;
+              const float vv = (2.0f * row + 1.0f) * (1.0f / kImg) - 1.0f;
+#pragma unroll
+              for (int j = 0; j < NMAX; ++j) {
+                if (j < k) {
+                  const float dqx = dbox * cy[j][a] * dcx[j][c] * (0.5f * kImg);
+                  const float dqy = dbox * cx[j][c] * dcy[j][a] * (0.5f * kImg);
+                  acc[j][0] = fmaf(-dqx * (uu - zf[j * 4 + 2]), isx[j] * isx[j], acc[j][0]);
+                  acc[j][1] = fmaf(-dqy * (vv - zf[j * 4 + 3]), isy[j] * isy[j], acc[j][1]);
+                  acc[j][2] = fmaf(-dqx, isx[j], acc[j][2]);
+                  acc[j][3] = fmaf(-dqy, isy[j], acc[j][3]);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    // own object goes to slot k
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+      const bool mine = (j == k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[slot][j * 4 + e][lane] = mine ? own[e] : ((j < k) ? acc[j][e] : 0.0f);
+    }
+    __syncthreads();
+    if (slot == 0 && live) {
+#pragma unroll
+      for (int j = 0; j < NMAX; ++j) {
+        if (j < n_obj) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float s = red[0][j * 4 + e][lane] + red[1][j * 4 + e][lane] + red[2][j * 4 + e][lane] + red[3][j * 4 + e][lane];
+            dzc[((size_t)patch * NMAX + j) * 4 + e] = s;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- assemble: log p(x, z) per frame (supair.py:79-94) -------------------------------------
+// parts[frame][3] = (bg, patches, overlap prior)
+__global__ void scene_assemble_fwd_k(const float* __restrict__ bg_ll, const float* __restrict__ obj_ll,
+                                     const float* __restrict__ ovl, const float* __restrict__ z,
+                                     float* __restrict__ ll, float* __restrict__ parts,
+                                     int n_obj, int n_frames, float beta, float log_beta) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  float pl = 0.0f, ol = 0.0f;
+  for (int k = 0; k < n_obj; ++k) {
+    const size_t i = (size_t)f * n_obj + k;
+    pl += obj_ll[i] * z[i * 4] * z[i * 4 + 1];
+    ol += log_beta - beta * ovl[i];
+  }
+  const float b = bg_ll[f];
+  ll[f] = (b + pl) + ol;
+  if (parts != nullptr) {
+    parts[f * 3] = b;
+    parts[f * 3 + 1] = pl;
+    parts[f * 3 + 2] = ol;
+  }
+}
+
+// per patch: d obj_ll, d overlap from d ll
+__global__ void scene_assemble_bwd_k(const float* __restrict__ dll, const float* __restrict__ z,
+                                     float* __restrict__ d_obj, float* __restrict__ d_ovl,
+                                     int n_obj, int n_patches, float beta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_patches) return;
+  const float g = dll[i / n_obj];
+  d_obj[i] = g * z[(size_t)i * 4] * z[(size_t)i * 4 + 1];
+  d_ovl[i] = -beta * g;
+}
+
+// dz[frame*n_obj + j][4] = bg part + sum_{k>=j} dzc[frame*n_obj+k][j] + direct scale terms
+template <int NMAX>
+__global__ void scene_finalize_bwd_k(const float* __restrict__ dll, const float* __restrict__ z,
+                                     const float* __restrict__ obj_ll, const float* __restrict__ dz_bg,
+                                     const float* __restrict__ dzc, float* __restrict__ dz, int n_obj, int n_patches) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_patches) return;
+  const int f = i / n_obj, j = i % n_obj;
+  float s[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s[e] = dz_bg[(size_t)i * 4 + e];
+  for (int k = j; k < n_obj; ++k) {
+    const float* c = dzc + (((size_t)f * n_obj + k) * NMAX + j) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += c[e];
+  }
+  const float g = dll[f] * obj_ll[i];
+  s[0] = fmaf(g, z[(size_t)i * 4 + 1], s[0]);
+  s[1] = fmaf(g, z[(size_t)i * 4], s[1]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dz[(size_t)i * 4 + e] = s[e];
+}
+
+}  // namespace stove

@@ -1,0 +1,466 @@
+// Background RAT-SPN (depth-1 random region graph over the 32x32 frame) -- gfx950 kernels.
+//
+// Replaces RatSpn.forward for the background SPN (model/spn/rat_torch.py:83-109, 147-163,
+// 202-222) as called from Supair.likelihood (model/video_prediction/supair.py:61-67), and, in
+// "scene" mode, the background half of Supair.masks_from_z (supair.py:304-344): the pasted
+// unit boxes are separable (coverage_x * coverage_y of the inverse affine grid), so the final
+// mask is a closed form of z and never touches memory.
+//
+// Mapping: one lane = one frame pixel (coalesced frame reads), the pixel's R*G leaf
+// coefficients live in registers for the whole persistent loop over frames; per-frame leaf
+// sums are reduced with DPP wave reductions + a small LDS stage.  A frame is split over
+// 1024/512 = 2 workgroups ("halves"); the tiny root kernels add the two partial leaf vectors.
+#include "common.h"
+
+namespace stove {
+
+constexpr int kBgPix = 1024;   // 32 x 32 x 1
+constexpr int kBgSide = 32;
+constexpr int kBgThreads = 512;
+constexpr int kBgHalves = kBgPix / kBgThreads;
+
+struct BoxGeom {
+  float inv_sx, inv_sy, off_x, off_y;   // invert_z, supair.py:233-237
+};
+__device__ __forceinline__ BoxGeom box_geom(const float* z) {
+  BoxGeom g;
+  g.inv_sx = 1.0f / z[0];
+  g.inv_sy = 1.0f / z[1];
+  g.off_x = -z[2] / z[0];
+  g.off_y = -z[3] / z[1];
+  return g;
+}
+// pixel-space coordinate of frame column/row `idx` under the inverse transform
+__device__ __forceinline__ float inv_coord(float inv_s, float off, int idx) {
+  const float u = (2.0f * idx + 1.0f) * (1.0f / kBgSide) - 1.0f;
+  const float gq = fmaf(inv_s, u, off);
+  return ((gq + 1.0f) * kBgSide - 1.0f) * 0.5f;
+}
+
+// ---- forward: partial leaf log-densities of every frame ------------------------------------
+// ell_part[frame][half][(r*2+side)*G+g]
+// SCENE: w = 1 - min(1, sum_k box_k) from z[frame][N][4];  else w = 1 - clamp(marg) (or 1).
+template <int R, int G, bool SCENE>
+__global__ __launch_bounds__(kBgThreads) void bgspn_fwd_k(
+    const float* __restrict__ frames, const float* __restrict__ marg, const float* __restrict__ z, int n_obj,
+    const int* __restrict__ side, const float* __restrict__ coef, float* __restrict__ ell_part, int n_frames) {
+  constexpr int NO = R * 2 * G;
+  constexpr int NW = kBgThreads / 64;
+  __shared__ float part[2][NW][NO];
+  const int half = blockIdx.x % kBgHalves;
+  const int p = half * kBgThreads + threadIdx.x;
+  const int lane = lane_id(), wv = wave_id();
+  float cf[R][G][3];
+  bool sd[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    sd[r] = side[r * kBgPix + p] != 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cf[r][g][k] = coef[((size_t)(r * kBgPix + p) * G + g) * 3 + k];
+  }
+  const int col = p % kBgSide, row = p / kBgSide;
+  int it = 0;
+  for (int f = blockIdx.x / kBgHalves; f < n_frames; f += gridDim.x / kBgHalves, ++it) {
+    const float x = frames[(size_t)f * kBgPix + p];
+    float w;
+    if (SCENE) {
+      float run = 0.0f;
+      for (int k = 0; k < n_obj; ++k) {
+        const BoxGeom bg = box_geom(z + ((size_t)f * n_obj + k) * 4);
+        float dq;
+        const float box = cover(inv_coord(bg.inv_sx, bg.off_x, col), kBgSide, &dq) *
+                          cover(inv_coord(bg.inv_sy, bg.off_y, row), kBgSide, &dq);
+        run = fminf(run + box, 1.0f);
+      }
+      w = 1.0f - run;
+    } else {
+      w = (marg != nullptr) ? 1.0f - fminf(fmaxf(marg[(size_t)f * kBgPix + p], 0.0f), 1.0f) : 1.0f;
+    }
+    const float wx = w * x, wxx = wx * x;
+    float* pp = part[it & 1][wv];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float val = fmaf(wxx, cf[r][g][0], fmaf(wx, cf[r][g][1], w * cf[r][g][2]));
+        const float v1 = sd[r] ? val : 0.0f;
+        const float s0 = wave_sum_lane63(val - v1);
+        const float s1 = wave_sum_lane63(v1);
+        if (lane == 63) {
+          pp[(r * 2) * G + g] = s0;
+          pp[(r * 2 + 1) * G + g] = s1;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < NO) {
+      float s = 0.0f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) s += part[it & 1][q][threadIdx.x];
+      ell_part[((size_t)f * kBgHalves + half) * NO + threadIdx.x] = s;
+    }
+  }
+}
+
+// ---- root: product (G x G per replica) + root sum over R*G*G, one thread per frame ----------
+template <int R, int G>
+__global__ void bgspn_root_fwd_k(const float* __restrict__ ell_part, const float* __restrict__ wroot,
+                                 float* __restrict__ out, int n_frames) {
+  constexpr int NO = R * 2 * G;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  float M[R], Sr[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float e1[G], e2[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float a = 0.0f, b = 0.0f;
+#pragma unroll
+      for (int h = 0; h < kBgHalves; ++h) {
+        a += ell_part[((size_t)f * kBgHalves + h) * NO + (r * 2) * G + g];
+        b += ell_part[((size_t)f * kBgHalves + h) * NO + (r * 2 + 1) * G + g];
+      }
+      e1[g] = a;
+      e2[g] = b;
+    }
+    float m1 = e1[0], m2 = e2[0];
+#pragma unroll
+    for (int g = 1; g < G; ++g) {
+      m1 = fmaxf(m1, e1[g]);
+      m2 = fmaxf(m2, e2[g]);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      e1[g] = __expf(e1[g] - m1);
+      e2[g] = __expf(e2[g] - m2);
+    }
+#pragma unroll
+    for (int j2 = 0; j2 < G; ++j2)
+#pragma unroll
+      for (int j1 = 0; j1 < G; ++j1) s = fmaf(e1[j1] * e2[j2], wroot[r * G * G + j2 * G + j1], s);
+    M[r] = m1 + m2;
+    Sr[r] = s;
+  }
+  float mm = M[0];
+#pragma unroll
+  for (int r = 1; r < R; ++r) mm = fmaxf(mm, M[r]);
+  float Z = 0.0f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) Z = fmaf(Sr[r], __expf(M[r] - mm), Z);
+  out[f] = mm + __logf(Z);
+}
+
+// dell[frame][(r*2+side)*G+g] = dL/d leaf ; rsc[frame][r][1+2G] = rho_r, E1[G], E2[G]
+template <int R, int G>
+__global__ void bgspn_root_bwd_k(const float* __restrict__ ell_part, const float* __restrict__ wroot,
+                                 const float* __restrict__ out, const float* __restrict__ dout,
+                                 float* __restrict__ dell, float* __restrict__ rsc, int n_frames) {
+  constexpr int NO = R * 2 * G;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  const float go = dout[f], ro = out[f];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float e1[G], e2[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float a = 0.0f, b = 0.0f;
+#pragma unroll
+      for (int h = 0; h < kBgHalves; ++h) {
+        a += ell_part[((size_t)f * kBgHalves + h) * NO + (r * 2) * G + g];
+        b += ell_part[((size_t)f * kBgHalves + h) * NO + (r * 2 + 1) * G + g];
+      }
+      e1[g] = a;
+      e2[g] = b;
+    }
+    float m1 = e1[0], m2 = e2[0];
+#pragma unroll
+    for (int g = 1; g < G; ++g) {
+      m1 = fmaxf(m1, e1[g]);
+      m2 = fmaxf(m2, e2[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      e1[g] = __expf(e1[g] - m1);
+      e2[g] = __expf(e2[g] - m2);
+    }
+    const float rho = go * __expf(m1 + m2 - ro);
+    float d1[G], d2[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) d1[g] = d2[g] = 0.0f;
+#pragma unroll
+    for (int j2 = 0; j2 < G; ++j2)
+#pragma unroll
+      for (int j1 = 0; j1 < G; ++j1) {
+        const float wk = wroot[r * G * G + j2 * G + j1];
+        d1[j1] = fmaf(e2[j2], wk, d1[j1]);
+        d2[j2] = fmaf(e1[j1], wk, d2[j2]);
+      }
+    float* rp = rsc + ((size_t)f * R + r) * (1 + 2 * G);
+    rp[0] = rho;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      dell[(size_t)f * NO + (r * 2) * G + g] = rho * e1[g] * d1[g];
+      dell[(size_t)f * NO + (r * 2 + 1) * G + g] = rho * e2[g] * d2[g];
+      rp[1 + g] = e1[g];
+      rp[1 + G + g] = e2[g];
+    }
+  }
+}
+
+// root weight grads (linear domain): part[c][r*G*G + j2*G + j1] = sum_frames rho_r E1[j1] E2[j2]
+template <int R, int G>
+__global__ void bgspn_rootgrad_k(const float* __restrict__ rsc, float* __restrict__ part, int n_frames, int n_chunks) {
+  const int k = threadIdx.x;
+  if (k >= R * G * G) return;
+  const int c = blockIdx.x;
+  const int r = k / (G * G), j2 = (k / G) % G, j1 = k % G;
+  float acc = 0.0f;
+  for (int f = c; f < n_frames; f += n_chunks) {
+    const float* rp = rsc + ((size_t)f * R + r) * (1 + 2 * G);
+    acc = fmaf(rp[0] * rp[1 + j1], rp[1 + G + j2], acc);
+  }
+  part[(size_t)c * R * G * G + k] = acc;
+}
+
+// ---- backward main: per-pixel dL/dw (-> marg or z) and leaf coefficient grads ----------------
+// SCENE: dz_part[frame][half][n_obj][4] (dsx, dsy, dx, dy of the pasted boxes)
+// else : d_marg[frame][p] (and d_inputs if non-null)
+// gcoef_part[block][r][p_local][g][3]
+template <int R, int G, bool SCENE, int NMAX>
+__global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
+    const float* __restrict__ frames, const float* __restrict__ marg, const float* __restrict__ z, int n_obj,
+    const int* __restrict__ side, const float* __restrict__ coef, const float* __restrict__ dell,
+    float* __restrict__ d_inputs, float* __restrict__ d_marg, float* __restrict__ dz_part,
+    float* __restrict__ gcoef_part, int n_frames) {
+  constexpr int NO = R * 2 * G;
+  constexpr int NW = kBgThreads / 64;
+  __shared__ float zred[2][NW][NMAX * 4];
+  const int half = blockIdx.x % kBgHalves;
+  const int p = half * kBgThreads + threadIdx.x;
+  const int lane = lane_id(), wv = wave_id();
+  float cf[R][G][3], gc[R][G][3];
+  bool sd[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    sd[r] = side[r * kBgPix + p] != 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        cf[r][g][k] = coef[((size_t)(r * kBgPix + p) * G + g) * 3 + k];
+        gc[r][g][k] = 0.0f;
+      }
+  }
+  const int col = p % kBgSide, row = p / kBgSide;
+  int it = 0;
+  for (int f = blockIdx.x / kBgHalves; f < n_frames; f += gridDim.x / kBgHalves, ++it) {
+    const float x = frames[(size_t)f * kBgPix + p];
+    float w, mraw = 0.0f;
+    // per-object box factors for the scene backward
+    float fx[NMAX], fy[NMAX], dfx[NMAX], dfy[NMAX];
+    bool pass = true;
+    if (SCENE) {
+      float run = 0.0f;
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        if (k < n_obj) {
+          const BoxGeom bg = box_geom(z + ((size_t)f * n_obj + k) * 4);
+          fx[k] = cover(inv_coord(bg.inv_sx, bg.off_x, col), kBgSide, &dfx[k]);
+          fy[k] = cover(inv_coord(bg.inv_sy, bg.off_y, row), kBgSide, &dfy[k]);
+          run += fx[k] * fy[k];
+          if (run > 1.0f) {
+            run = 1.0f;
+            pass = false;
+          }
+        }
+      }
+      w = 1.0f - run;
+    } else {
+      if (marg != nullptr) {
+        mraw = marg[(size_t)f * kBgPix + p];
+        w = 1.0f - fminf(fmaxf(mraw, 0.0f), 1.0f);
+      } else {
+        w = 1.0f;
+      }
+    }
+    const float wx = w * x, wxx = wx * x, x2 = x * x;
+    const float* de = dell + (size_t)f * NO;
+    float dw = 0.0f, dx = 0.0f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float d = sd[r] ? de[(r * 2 + 1) * G + g] : de[(r * 2) * G + g];
+        dw = fmaf(d, fmaf(cf[r][g][0], x2, fmaf(cf[r][g][1], x, cf[r][g][2])), dw);
+        dx = fmaf(d, fmaf(cf[r][g][0], x + x, cf[r][g][1]), dx);
+        gc[r][g][0] = fmaf(d, wxx, gc[r][g][0]);
+        gc[r][g][1] = fmaf(d, wx, gc[r][g][1]);
+        gc[r][g][2] = fmaf(d, w, gc[r][g][2]);
+      }
+    }
+    if (SCENE) {
+      // w = 1 - min(1, sum box): d box_k = -dw when no clamp fired
+      const float dbox = pass ? -dw : 0.0f;
+      float* zr = zred[it & 1][wv];
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        if (k < n_obj) {
+          const float* zk = z + ((size_t)f * n_obj + k) * 4;
+          const float isx = 1.0f / zk[0], isy = 1.0f / zk[1];
+          const float u = (2.0f * col + 1.0f) * (1.0f / kBgSide) - 1.0f;
+          const float v = (2.0f * row + 1.0f) * (1.0f / kBgSide) - 1.0f;
+          // q = ((u - x)/sx + 1) * 16 - 0.5
+          const float dqx = dbox * fy[k] * dfx[k] * (0.5f * kBgSide);
+          const float dqy = dbox * fx[k] * dfy[k] * (0.5f * kBgSide);
+          const float g_sx = wave_sum_lane63(-dqx * (u - zk[2]) * isx * isx);
+          const float g_sy = wave_sum_lane63(-dqy * (v - zk[3]) * isy * isy);
+          const float g_x = wave_sum_lane63(-dqx * isx);
+          const float g_y = wave_sum_lane63(-dqy * isy);
+          if (lane == 63) {
+            zr[k * 4] = g_sx;
+            zr[k * 4 + 1] = g_sy;
+            zr[k * 4 + 2] = g_x;
+            zr[k * 4 + 3] = g_y;
+          }
+        }
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < n_obj * 4) {
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) s += zred[it & 1][q][threadIdx.x];
+        dz_part[((size_t)f * kBgHalves + half) * n_obj * 4 + threadIdx.x] = s;
+      }
+    } else {
+      if (d_marg != nullptr) d_marg[(size_t)f * kBgPix + p] = (mraw >= 0.0f && mraw <= 1.0f) ? -dw : 0.0f;
+      if (d_inputs != nullptr) d_inputs[(size_t)f * kBgPix + p] = dx * w;
+    }
+  }
+  float* o = gcoef_part + ((size_t)blockIdx.x * R * kBgThreads) * G * 3;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) o[((size_t)(r * kBgThreads + threadIdx.x) * G + g) * 3 + k] = gc[r][g][k];
+}
+
+// g_coef[r][p][g][3] = sum over the blocks that own pixel-half(p) of gcoef_part
+template <int R, int G>
+__global__ void bgspn_coef_reduce_k(const float* __restrict__ gcoef_part, float* __restrict__ g_coef, int n_blocks) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;   // over R * 1024 * G * 3
+  if (j >= R * kBgPix * G * 3) return;
+  const int e = j % (G * 3);
+  const int p = (j / (G * 3)) % kBgPix;
+  const int r = j / (G * 3 * kBgPix);
+  const int half = p / kBgThreads, pl = p % kBgThreads;
+  float s = 0.0f;
+  for (int b = half; b < n_blocks; b += kBgHalves)
+    s += gcoef_part[(((size_t)b * R + r) * kBgThreads + pl) * G * 3 + e];
+  g_coef[j] = s;
+}
+
+// =============================================================================================
+constexpr int kBgR = 3, kBgG = 6, kBgNO = kBgR * 2 * kBgG;
+constexpr int kBgRootChunks = 64;
+
+static inline int bg_grid(int n_frames) {
+  int g = n_frames < 512 ? n_frames : 512;
+  if (g < 1) g = 1;
+  return g * kBgHalves;
+}
+
+size_t bgspn_fwd_ws_floats(int n_frames) { return (size_t)n_frames * kBgHalves * kBgNO; }
+
+// ell_part must stay alive until the backward (it is the saved activation).
+int bgspn_forward(const float* frames, const float* marg, const float* z, int n_obj, const int* side, const float* coef,
+                  const float* wroot, float* ell_part, float* out, int n_frames, hipStream_t st) {
+  if (n_frames == 0) return 0;
+  const int grid = bg_grid(n_frames);
+  if (z != nullptr)
+    hipLaunchKernelGGL((bgspn_fwd_k<kBgR, kBgG, true>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, ell_part, n_frames);
+  else
+    hipLaunchKernelGGL((bgspn_fwd_k<kBgR, kBgG, false>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, ell_part, n_frames);
+  STOVE_LAUNCH_CHECK();
+  hipLaunchKernelGGL((bgspn_root_fwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, n_frames);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t bgspn_bwd_ws_floats(int n_frames) {
+  const size_t grid = bg_grid(n_frames);
+  return (size_t)n_frames * (kBgNO + kBgR * (1 + 2 * kBgG)) + (size_t)n_frames * kBgHalves * 8 * 4 +
+         grid * kBgR * kBgThreads * kBgG * 3 + (size_t)kBgRootChunks * kBgR * kBgG * kBgG;
+}
+
+template <int NMAX>
+static int bg_bwd_launch(bool scene, int grid, hipStream_t st, const float* frames, const float* marg, const float* z,
+                         int n_obj, const int* side, const float* coef, const float* dell, float* d_inputs,
+                         float* d_marg, float* dz_part, float* gpart, int n_frames) {
+  if (scene)
+    hipLaunchKernelGGL((bgspn_bwd_k<kBgR, kBgG, true, NMAX>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
+  else
+    hipLaunchKernelGGL((bgspn_bwd_k<kBgR, kBgG, false, 1>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void bg_dz_halves_k(const float* __restrict__ dz_part, float* __restrict__ dz, int n_frames, int no4) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_frames * no4) return;
+  const int f = j / no4, e = j % no4;
+  float s = 0.0f;
+  for (int h = 0; h < kBgHalves; ++h) s += dz_part[((size_t)f * kBgHalves + h) * no4 + e];
+  dz[j] = s;
+}
+
+// dz (SCENE): [n_frames][n_obj][4] overwritten.  g_coef [R][1024][G][3], g_wroot [R*G*G] overwritten.
+int bgspn_backward(const float* frames, const float* marg, const float* z, int n_obj, const int* side, const float* coef,
+                   const float* wroot, const float* ell_part, const float* out, const float* dout,
+                   float* d_inputs, float* d_marg, float* dz, float* g_coef, float* g_wroot, float* ws,
+                   int n_frames, hipStream_t st) {
+  if (n_frames == 0) {
+    hipMemsetAsync(g_coef, 0, sizeof(float) * kBgR * kBgPix * kBgG * 3, st);
+    hipMemsetAsync(g_wroot, 0, sizeof(float) * kBgR * kBgG * kBgG, st);
+    return 0;
+  }
+  if (n_obj > 8) return (int)hipErrorInvalidValue;
+  const int grid = bg_grid(n_frames);
+  float* dell = ws;
+  float* rsc = dell + (size_t)n_frames * kBgNO;
+  float* dz_part = rsc + (size_t)n_frames * kBgR * (1 + 2 * kBgG);
+  float* gpart = dz_part + (size_t)n_frames * kBgHalves * 8 * 4;
+  float* rpart = gpart + (size_t)grid * kBgR * kBgThreads * kBgG * 3;
+  hipLaunchKernelGGL((bgspn_root_bwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, dout, dell, rsc, n_frames);
+  STOVE_LAUNCH_CHECK();
+  const bool scene = z != nullptr;
+  int rc;
+  if (!scene || n_obj <= 3)
+    rc = bg_bwd_launch<3>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
+  else if (n_obj <= 6)
+    rc = bg_bwd_launch<6>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
+  else
+    rc = bg_bwd_launch<8>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
+  if (rc) return rc;
+  if (scene) {
+    const int n = n_frames * n_obj * 4;
+    hipLaunchKernelGGL(bg_dz_halves_k, dim3((n + 255) / 256), dim3(256), 0, st, dz_part, dz, n_frames, n_obj * 4);
+    STOVE_LAUNCH_CHECK();
+  }
+  const int nc = kBgR * kBgPix * kBgG * 3;
+  hipLaunchKernelGGL((bgspn_coef_reduce_k<kBgR, kBgG>), dim3((nc + 255) / 256), dim3(256), 0, st, gpart, g_coef, grid);
+  STOVE_LAUNCH_CHECK();
+  const int chunks = n_frames < kBgRootChunks ? n_frames : kBgRootChunks;
+  hipLaunchKernelGGL((bgspn_rootgrad_k<kBgR, kBgG>), dim3(chunks), dim3(128), 0, st, rsc, rpart, n_frames, chunks);
+  STOVE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_chunks_k, dim3(1), dim3(256), 0, st, rpart, g_wroot, kBgR * kBgG * kBgG, chunks, 0);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace stove

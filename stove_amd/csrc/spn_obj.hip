@@ -1,0 +1,576 @@
+// Object RAT-SPN (depth-2 random region graph) -- forward / backward kernels for gfx950.
+//
+// Replaces the ATen op chains of the reference's RatSpn.forward for the object SPN
+// (model/spn/rat_torch.py:83-109 leaf, :147-163 product, :202-222 sum, :333-357 sweep)
+// as called from Supair.likelihood (model/video_prediction/supair.py:71-76).
+//
+// Mapping: one lane = one sample (glimpse patch), 64 samples per wave ("batch").  All
+// structure and parameter reads are wave-uniform, so hipcc serves them from the scalar
+// cache (s_load) and the VALU sees them as SGPR operands; per-lane data is only the
+// patch pixels, read coalesced from a [batch][pixel][x|w][64] tile.
+// A workgroup = 2R waves = (replica r, side) pairs of one batch; the two sides of a
+// replica meet through LDS for the root product, the R replicas for the root sum.
+//
+// Leaf in expanded form: sum_p w_p (a x_p^2 + b x_p + c),  a=-1/(2v), b=mu/v,
+// c=-mu^2/(2v) - 0.5 log(2 pi v)   (3 FMAs per pixel x gaussian).
+// Sum layer as a bilinear form on max-shifted exponentials with linear softmax weights:
+//   out_s = m1 + m2 + log sum_{j2,j1} E1[j1] E2[j2] W[j2*G+j1][s]   (20 exps instead of 1000).
+#include "common.h"
+
+namespace stove {
+
+template <int N>
+__device__ __forceinline__ float vmax(const float (&v)[N]) {
+  float m = v[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) m = fmaxf(m, v[i]);
+  return m;
+}
+
+// ---- shared piece: leaves + sum node of one (replica, side) -------------------------------
+template <int S, int G, int K>
+struct SideState {
+  float E1[G], E2[G];   // exp(leaf - max)
+  float acc[K];         // sum_k E1 E2 W[k][s]
+  float o[K];           // sum node outputs
+};
+
+template <int S, int G, int K>
+__device__ __forceinline__ void side_forward(const float* __restrict__ tile, int lane,
+                                             const int* __restrict__ scope, const float* __restrict__ coef,
+                                             const float* __restrict__ W, SideState<S, G, K>& st) {
+  float ell[2][G];
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    float acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0.0f;
+    const int* sc = scope + l * S;
+    const float* cf = coef + l * S * G * 3;
+    for (int i = 0; i < S; ++i) {
+      const int p = sc[i];
+      const float x = tile[(p * 2) * 64 + lane];
+      const float w = tile[(p * 2 + 1) * 64 + lane];
+      const float wx = w * x, wxx = wx * x;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float* c3 = cf + (i * G + g) * 3;
+        acc[g] = fmaf(wxx, c3[0], acc[g]);
+        acc[g] = fmaf(wx, c3[1], acc[g]);
+        acc[g] = fmaf(w, c3[2], acc[g]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) ell[l][g] = acc[g];
+  }
+  const float m1 = vmax<G>(ell[0]), m2 = vmax<G>(ell[1]);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    st.E1[g] = __expf(ell[0][g] - m1);
+    st.E2[g] = __expf(ell[1][g] - m2);
+  }
+#pragma unroll
+  for (int s = 0; s < K; ++s) st.acc[s] = 0.0f;
+#pragma unroll
+  for (int j2 = 0; j2 < G; ++j2) {
+#pragma unroll
+    for (int j1 = 0; j1 < G; ++j1) {
+      const float t = st.E1[j1] * st.E2[j2];
+      const float* wk = W + (j2 * G + j1) * K;
+#pragma unroll
+      for (int s = 0; s < K; ++s) st.acc[s] = fmaf(t, wk[s], st.acc[s]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < K; ++s) st.o[s] = m1 + m2 + __logf(st.acc[s]);
+}
+
+// ---- forward -------------------------------------------------------------------------------
+// out[sample] = root log-density; ovl[sample] = mean over pixels of (1 - w) (optional).
+template <int R, int S, int G, int K>
+__global__ __launch_bounds__(128 * R) void objspn_fwd_k(
+    const float* __restrict__ xw, const int* __restrict__ scope, const float* __restrict__ coef,
+    const float* __restrict__ wsum, const float* __restrict__ wroot,
+    float* __restrict__ out, float* __restrict__ ovl, int n_samples, int n_batches) {
+  constexpr int D = 4 * S;
+  __shared__ float xch[R * 2 * K * 64];
+  __shared__ float part[R * 2 * 64];
+  const int lane = lane_id();
+  const int wv = wave_id();
+  const int r = wv >> 1, side = wv & 1;
+  for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
+    const float* tile = xw + (size_t)b * (D * 2 * 64);
+    SideState<S, G, K> st;
+    side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3,
+                          wsum + (size_t)(r * 2 + side) * G * G * K, st);
+#pragma unroll
+    for (int s = 0; s < K; ++s) xch[((r * 2 + side) * K + s) * 64 + lane] = st.o[s];
+    __syncthreads();
+    if (side == 0) {
+      float oB[K];
+#pragma unroll
+      for (int s = 0; s < K; ++s) oB[s] = xch[((r * 2 + 1) * K + s) * 64 + lane];
+      const float mA = vmax<K>(st.o), mB = vmax<K>(oB);
+      float EA[K], EB[K];
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        EA[s] = __expf(st.o[s] - mA);
+        EB[s] = __expf(oB[s] - mB);
+      }
+      const float* wr = wroot + r * K * K;
+      float sr = 0.0f;
+#pragma unroll
+      for (int j2 = 0; j2 < K; ++j2)
+#pragma unroll
+        for (int j1 = 0; j1 < K; ++j1) sr = fmaf(EA[j1] * EB[j2], wr[j2 * K + j1], sr);
+      part[(r * 2) * 64 + lane] = mA + mB;
+      part[(r * 2 + 1) * 64 + lane] = sr;
+    } else if (wv == 1 && ovl != nullptr) {
+      float s1 = 0.0f;
+      for (int p = 0; p < D; ++p) s1 += 1.0f - tile[(p * 2 + 1) * 64 + lane];
+      const int smp = b * 64 + lane;
+      if (smp < n_samples) ovl[smp] = s1 * (1.0f / D);
+    }
+    __syncthreads();
+    if (wv == 0) {
+      float M = part[lane];
+#pragma unroll
+      for (int q = 1; q < R; ++q) M = fmaxf(M, part[(q * 2) * 64 + lane]);
+      float Z = 0.0f;
+#pragma unroll
+      for (int q = 0; q < R; ++q) Z = fmaf(part[(q * 2 + 1) * 64 + lane], __expf(part[(q * 2) * 64 + lane] - M), Z);
+      const int smp = b * 64 + lane;
+      if (smp < n_samples) out[smp] = M + __logf(Z);
+    }
+    // next iteration overwrites xch only after its own leaf sweep + barrier; part is re-read
+    // only by wave 0 before it reaches the next first barrier, so no extra barrier is needed
+    // for xch, but part needs one:
+    __syncthreads();
+  }
+}
+
+// ---- backward (main): recompute forward, back-propagate to the leaf outputs ---------------
+// dout[sample] = dL/d root, out[sample] = root value saved by the forward.
+// Writes   Dscr[batch][r][4][G][64]        dL/d leaf log-densities
+//          Sscr[batch][r*2+side][K+2G][64] gamma[s] = g_s / acc_s, E1[G], E2[G]   (sum-weight grads)
+//          Rscr[batch][r][1+2K][64]        rho_r, EA[K], EB[K]                     (root-weight grads)
+template <int R, int S, int G, int K>
+__global__ __launch_bounds__(128 * R) void objspn_bwd_k(
+    const float* __restrict__ xw, const int* __restrict__ scope, const float* __restrict__ coef,
+    const float* __restrict__ wsum, const float* __restrict__ wroot,
+    const float* __restrict__ out, const float* __restrict__ dout,
+    float* __restrict__ Dscr, float* __restrict__ Sscr, float* __restrict__ Rscr, int n_samples, int n_batches) {
+  constexpr int D = 4 * S;
+  __shared__ float xch[R * 2 * K * 64];
+  const int lane = lane_id();
+  const int wv = wave_id();
+  const int r = wv >> 1, side = wv & 1;
+  for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
+    const float* tile = xw + (size_t)b * (D * 2 * 64);
+    const float* W = wsum + (size_t)(r * 2 + side) * G * G * K;
+    SideState<S, G, K> st;
+    side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3, W, st);
+#pragma unroll
+    for (int s = 0; s < K; ++s) xch[((r * 2 + side) * K + s) * 64 + lane] = st.o[s];
+    __syncthreads();
+    float oP[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) oP[s] = xch[((r * 2 + (1 - side)) * K + s) * 64 + lane];
+    const float mO = vmax<K>(st.o), mP = vmax<K>(oP);
+    float EO[K], EP[K];   // own side, partner side
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      EO[s] = __expf(st.o[s] - mO);
+      EP[s] = __expf(oP[s] - mP);
+    }
+    const int smp = b * 64 + lane;
+    const bool live = smp < n_samples;
+    const float go = live ? dout[smp] : 0.0f;
+    const float ro = live ? out[smp] : 0.0f;
+    const float rho = go * __expf(mO + mP - ro);
+    const float* wr = wroot + r * K * K;
+    // g[s] = dL/d o[s] of this side
+    float g[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) g[s] = 0.0f;
+    if (side == 0) {
+#pragma unroll
+      for (int j2 = 0; j2 < K; ++j2)
+#pragma unroll
+        for (int j1 = 0; j1 < K; ++j1) g[j1] = fmaf(EP[j2], wr[j2 * K + j1], g[j1]);
+    } else {
+#pragma unroll
+      for (int j2 = 0; j2 < K; ++j2)
+#pragma unroll
+        for (int j1 = 0; j1 < K; ++j1) g[j2] = fmaf(EP[j1], wr[j2 * K + j1], g[j2]);
+    }
+    float gam[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      g[s] *= rho * EO[s];
+      gam[s] = g[s] / st.acc[s];
+    }
+    float d1[G], d2[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) d1[j] = d2[j] = 0.0f;
+#pragma unroll
+    for (int j2 = 0; j2 < G; ++j2) {
+#pragma unroll
+      for (int j1 = 0; j1 < G; ++j1) {
+        const float* wk = W + (j2 * G + j1) * K;
+        float t = 0.0f;
+#pragma unroll
+        for (int s = 0; s < K; ++s) t = fmaf(gam[s], wk[s], t);
+        d1[j1] = fmaf(st.E2[j2], t, d1[j1]);
+        d2[j2] = fmaf(st.E1[j1], t, d2[j2]);
+      }
+    }
+    float* Dp = Dscr + ((size_t)(b * R + r) * 4 + side * 2) * G * 64;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      Dp[j * 64 + lane] = d1[j] * st.E1[j];
+      Dp[(G + j) * 64 + lane] = d2[j] * st.E2[j];
+    }
+    float* Sp = Sscr + (size_t)(b * R * 2 + r * 2 + side) * (K + 2 * G) * 64;
+#pragma unroll
+    for (int s = 0; s < K; ++s) Sp[s * 64 + lane] = gam[s];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      Sp[(K + j) * 64 + lane] = st.E1[j];
+      Sp[(K + G + j) * 64 + lane] = st.E2[j];
+    }
+    if (side == 0) {
+      float* Rp = Rscr + (size_t)(b * R + r) * (1 + 2 * K) * 64;
+      Rp[lane] = rho;
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        Rp[(1 + s) * 64 + lane] = EO[s];
+        Rp[(1 + K + s) * 64 + lane] = EP[s];
+      }
+    }
+    __syncthreads();   // xch reuse
+  }
+}
+
+// ---- backward (pixels): dL/dx and dL/dw of every tile pixel --------------------------------
+// thread = (sample lane, pixel slot); the batch's leaf-gradient tile is staged in LDS.
+template <int R, int S, int G, int SLOTS>
+__global__ __launch_bounds__(64 * SLOTS) void objspn_pix_k(
+    const float* __restrict__ xw, const float* __restrict__ Dscr, const int* __restrict__ leaf_slot,
+    const float* __restrict__ coef, float* __restrict__ dxw, int n_batches) {
+  constexpr int D = 4 * S;
+  constexpr int DT = R * 4 * G * 64;
+  __shared__ float dl[DT];
+  const int lane = lane_id();
+  const int slot = wave_id();
+  for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
+    const float4* src = reinterpret_cast<const float4*>(Dscr + (size_t)b * DT);
+    float4* dst = reinterpret_cast<float4*>(dl);
+    for (int i = threadIdx.x; i < DT / 4; i += 64 * SLOTS) dst[i] = src[i];
+    __syncthreads();
+    const float* tile = xw + (size_t)b * (D * 2 * 64);
+    float* otile = dxw + (size_t)b * (D * 2 * 64);
+    for (int p = slot; p < D; p += SLOTS) {
+      const float x = tile[(p * 2) * 64 + lane];
+      const float w = tile[(p * 2 + 1) * 64 + lane];
+      const float x2 = x * x, tx = x + x;
+      float dx = 0.0f, dw = 0.0f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int ls = leaf_slot[r * D + p];          // L*S + i (wave-uniform)
+        const int L = ls / S;
+        const float* cf = coef + (size_t)(r * 4 * S + ls) * G * 3;
+        const float* dlp = dl + ((r * 4 + L) * G) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float d = dlp[g * 64];
+          const float a = cf[g * 3], bb = cf[g * 3 + 1], c = cf[g * 3 + 2];
+          dx = fmaf(d, fmaf(a, tx, bb), dx);
+          dw = fmaf(d, fmaf(a, x2, fmaf(bb, x, c)), dw);
+        }
+      }
+      otile[(p * 2) * 64 + lane] = dx * w;
+      otile[(p * 2 + 1) * 64 + lane] = dw;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- backward (leaf coefficient grads): partial sums over a chunk of batches --------------
+// block = replica r of chunk c; thread = (leaf L, pixel i) of that replica.
+// part[c][r][L*S+i][g][3] = sum_samples dl[g] * (w x^2, w x, w)
+template <int R, int S, int G>
+__global__ __launch_bounds__(128) void objspn_coefgrad_k(
+    const float* __restrict__ xw, const float* __restrict__ Dscr, const int* __restrict__ scope,
+    float* __restrict__ part, int n_batches, int n_chunks) {
+  constexpr int D = 4 * S;
+  const int r = blockIdx.x % R;
+  const int c = blockIdx.x / R;
+  const int t = threadIdx.x;
+  if (t >= D) return;
+  const int L = t / S;
+  const int p = scope[r * D + t];
+  float acc[G][3];
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0.0f;
+  for (int b = c; b < n_batches; b += n_chunks) {
+    const float4* xr = reinterpret_cast<const float4*>(xw + ((size_t)b * D + p) * 2 * 64);
+    const float4* dr = reinterpret_cast<const float4*>(Dscr + ((size_t)(b * R + r) * 4 + L) * G * 64);
+    for (int q = 0; q < 16; ++q) {
+      const float4 x4 = xr[q], w4 = xr[16 + q];
+      const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+      const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
+      float f0[4], f1[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f1[k] = ws[k] * xs[k];
+        f0[k] = f1[k] * xs[k];
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float4 d4 = dr[g * 16 + q];
+        const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[g][0] = fmaf(ds[k], f0[k], acc[g][0]);
+          acc[g][1] = fmaf(ds[k], f1[k], acc[g][1]);
+          acc[g][2] = fmaf(ds[k], ws[k], acc[g][2]);
+        }
+      }
+    }
+  }
+  float* o = part + ((size_t)(c * R + r) * D + t) * G * 3;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    o[g * 3] = acc[g][0];
+    o[g * 3 + 1] = acc[g][1];
+    o[g * 3 + 2] = acc[g][2];
+  }
+}
+
+// ---- backward (sum / root weight grads in the linear-weight domain) ------------------------
+// block = chunk c; threads 0 .. R*2*G*2-1 : (node, j2, half of j1) -> part_w[c][node][j2*G+j1][s]
+//                  next R*K threads       : (r, j2)                -> part_r[c][r][j2*K+j1]
+template <int R, int G, int K>
+__global__ __launch_bounds__(R * 2 * G * 2 + ((R * K + 63) / 64) * 64) void objspn_wgrad_k(
+    const float* __restrict__ Sscr, const float* __restrict__ Rscr,
+    float* __restrict__ part_w, float* __restrict__ part_r, int n_batches, int n_chunks) {
+  static_assert(G % 2 == 0, "G must be even");
+  constexpr int H = G / 2;
+  constexpr int NW = R * 2 * G * 2;
+  const int c = blockIdx.x;
+  const int t = threadIdx.x;
+  if (t < NW) {
+    const int node = t / (G * 2);
+    const int j2 = (t / 2) % G;
+    const int h = t % 2;
+    float acc[H][K];
+#pragma unroll
+    for (int a = 0; a < H; ++a)
+#pragma unroll
+      for (int s = 0; s < K; ++s) acc[a][s] = 0.0f;
+    for (int b = c; b < n_batches; b += n_chunks) {
+      const float4* sp = reinterpret_cast<const float4*>(Sscr + (size_t)(b * R * 2 + node) * (K + 2 * G) * 64);
+      for (int q = 0; q < 16; ++q) {
+        const float4 e2 = sp[(K + G + j2) * 16 + q];
+        const float e2s[4] = {e2.x, e2.y, e2.z, e2.w};
+        float gs[K][4];
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+          const float4 v = sp[s * 16 + q];
+          gs[s][0] = v.x; gs[s][1] = v.y; gs[s][2] = v.z; gs[s][3] = v.w;
+        }
+#pragma unroll
+        for (int a = 0; a < H; ++a) {
+          const float4 e1 = sp[(K + h * H + a) * 16 + q];
+          const float e1s[4] = {e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float pr = e1s[k] * e2s[k];
+#pragma unroll
+            for (int s = 0; s < K; ++s) acc[a][s] = fmaf(pr, gs[s][k], acc[a][s]);
+          }
+        }
+      }
+    }
+    float* o = part_w + ((size_t)(c * R * 2 + node) * G * G + j2 * G + h * H) * K;
+#pragma unroll
+    for (int a = 0; a < H; ++a)
+#pragma unroll
+      for (int s = 0; s < K; ++s) o[a * K + s] = acc[a][s];
+  } else if (t < NW + R * K) {
+    const int u = t - NW;
+    const int r = u / K, j2 = u % K;
+    float acc[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) acc[s] = 0.0f;
+    for (int b = c; b < n_batches; b += n_chunks) {
+      const float4* rp = reinterpret_cast<const float4*>(Rscr + (size_t)(b * R + r) * (1 + 2 * K) * 64);
+      for (int q = 0; q < 16; ++q) {
+        const float4 rho = rp[q];
+        const float4 eb = rp[(1 + K + j2) * 16 + q];
+        const float pr[4] = {rho.x * eb.x, rho.y * eb.y, rho.z * eb.z, rho.w * eb.w};
+#pragma unroll
+        for (int j1 = 0; j1 < K; ++j1) {
+          const float4 ea = rp[(1 + j1) * 16 + q];
+          acc[j1] = fmaf(pr[0], ea.x, acc[j1]);
+          acc[j1] = fmaf(pr[1], ea.y, acc[j1]);
+          acc[j1] = fmaf(pr[2], ea.z, acc[j1]);
+          acc[j1] = fmaf(pr[3], ea.w, acc[j1]);
+        }
+      }
+    }
+    float* o = part_r + ((size_t)(c * R + r) * K + j2) * K;
+#pragma unroll
+    for (int j1 = 0; j1 < K; ++j1) o[j1] = acc[j1];
+  }
+}
+
+// ---- tile staging for the stand-alone RatSpn.forward(inputs, marginalized) operator --------
+// inputs/marg are (n, D) row-major; w = 1 - clamp(marg, 0, 1) (rat_torch.py:104-106).
+__global__ void objspn_tile_from_arrays_k(const float* __restrict__ inputs, const float* __restrict__ marg,
+                                          float* __restrict__ xw, int n_samples, int n_batches, int D) {
+  extern __shared__ float lds[];   // [64][D+1] x then w
+  const int stride = D + 1;
+  for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
+    for (int i = threadIdx.x; i < 64 * D; i += blockDim.x) {
+      const int smp = i / D, p = i % D;
+      const size_t gi = (size_t)(b * 64 + smp) * D + p;
+      const bool live = (b * 64 + smp) < n_samples;
+      const float x = live ? inputs[gi] : 0.0f;
+      float w = 0.0f;
+      if (live) w = (marg != nullptr) ? 1.0f - fminf(fmaxf(marg[gi], 0.0f), 1.0f) : 1.0f;
+      lds[smp * stride + p] = x;
+      lds[64 * stride + smp * stride + p] = w;
+    }
+    __syncthreads();
+    float* tile = xw + (size_t)b * D * 2 * 64;
+    for (int i = threadIdx.x; i < 64 * D * 2; i += blockDim.x) {
+      const int lane = i & 63, pc = i >> 6;   // pc = p*2 + c
+      tile[i] = lds[(pc & 1) * 64 * stride + lane * stride + (pc >> 1)];
+    }
+    __syncthreads();
+  }
+}
+
+// d_inputs = dxw.x ; d_marg = -dxw.w where 0 <= marg <= 1 (clamp passes its boundary, as ATen does)
+__global__ void objspn_tile_to_arrays_k(const float* __restrict__ dxw, const float* __restrict__ marg,
+                                        float* __restrict__ d_inputs, float* __restrict__ d_marg,
+                                        int n_samples, int n_batches, int D) {
+  extern __shared__ float lds[];
+  const int stride = D + 1;
+  for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
+    const float* tile = dxw + (size_t)b * D * 2 * 64;
+    for (int i = threadIdx.x; i < 64 * D * 2; i += blockDim.x) {
+      const int lane = i & 63, pc = i >> 6;
+      lds[(pc & 1) * 64 * stride + lane * stride + (pc >> 1)] = tile[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * D; i += blockDim.x) {
+      const int smp = i / D, p = i % D;
+      if ((b * 64 + smp) >= n_samples) continue;
+      const size_t gi = (size_t)(b * 64 + smp) * D + p;
+      if (d_inputs != nullptr) d_inputs[gi] = lds[smp * stride + p];
+      if (d_marg != nullptr) {
+        const float m = marg[gi];
+        d_marg[gi] = (m >= 0.0f && m <= 1.0f) ? -lds[64 * stride + smp * stride + p] : 0.0f;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// out[j] = sum_c part[c][j]  (fixed order -> bitwise reproducible)
+__global__ void reduce_chunks_k(const float* __restrict__ part, float* __restrict__ out, int n, int n_chunks, int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.0f;
+  for (int c = 0; c < n_chunks; ++c) s += part[(size_t)c * n + j];
+  out[j] = accumulate ? out[j] + s : s;
+}
+
+}  // namespace stove
+
+// =============================================================================================
+// host-side launchers (C ABI lives in capi.hip)
+// =============================================================================================
+namespace stove {
+
+static inline int grid_for(int n_items, int cap) { return n_items < cap ? (n_items > 0 ? n_items : 1) : cap; }
+
+int objspn_tile_from_arrays(const float* inputs, const float* marg, float* xw, int n, hipStream_t st) {
+  const int nb = (n + 63) / 64;
+  if (nb == 0) return 0;
+  const int D = 100;
+  hipLaunchKernelGGL(objspn_tile_from_arrays_k, dim3(grid_for(nb, 2048)), dim3(256), 2 * 64 * (D + 1) * sizeof(float), st,
+                     inputs, marg, xw, n, nb, D);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int objspn_tile_to_arrays(const float* dxw, const float* marg, float* d_inputs, float* d_marg, int n, hipStream_t st) {
+  const int nb = (n + 63) / 64;
+  if (nb == 0) return 0;
+  const int D = 100;
+  hipLaunchKernelGGL(objspn_tile_to_arrays_k, dim3(grid_for(nb, 2048)), dim3(256), 2 * 64 * (D + 1) * sizeof(float), st,
+                     dxw, marg, d_inputs, d_marg, n, nb, D);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int objspn_forward(const float* xw, const int* scope, const float* coef, const float* wsum, const float* wroot,
+                   float* out, float* ovl, int n, hipStream_t st) {
+  const int nb = (n + 63) / 64;
+  if (nb == 0) return 0;
+  hipLaunchKernelGGL((objspn_fwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
+                     xw, scope, coef, wsum, wroot, out, ovl, n, nb);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+// workspace layout (floats) for the backward, per batch of 64 samples
+constexpr size_t kObjD = 6 * 4 * 10 * 64, kObjS = 12 * 30 * 64, kObjR = 6 * 21 * 64, kObjX = 100 * 2 * 64;
+constexpr int kObjChunks = 96;
+constexpr size_t kObjCoefN = 6 * 100 * 10 * 3, kObjWN = 12 * 100 * 10, kObjRootN = 6 * 100;
+
+size_t objspn_bwd_ws_floats(int n) {
+  const size_t nb = (n + 63) / 64;
+  return nb * (kObjD + kObjS + kObjR) + (size_t)kObjChunks * (kObjCoefN + kObjWN + kObjRootN);
+}
+
+// dxw: [nb][100][2][64] out.  g_coef/g_wsum/g_wroot: gradients w.r.t. the baked tables (overwritten).
+int objspn_backward(const float* xw, const int* scope, const int* leaf_slot, const float* coef, const float* wsum,
+                    const float* wroot, const float* out, const float* dout, float* dxw,
+                    float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n, hipStream_t st) {
+  const int nb = (n + 63) / 64;
+  if (nb == 0) {
+    hipMemsetAsync(g_coef, 0, kObjCoefN * 4, st);
+    hipMemsetAsync(g_wsum, 0, kObjWN * 4, st);
+    hipMemsetAsync(g_wroot, 0, kObjRootN * 4, st);
+    return 0;
+  }
+  float* Dscr = ws;
+  float* Sscr = Dscr + (size_t)nb * kObjD;
+  float* Rscr = Sscr + (size_t)nb * kObjS;
+  float* pc = Rscr + (size_t)nb * kObjR;
+  float* pw = pc + (size_t)kObjChunks * kObjCoefN;
+  float* pr = pw + (size_t)kObjChunks * kObjWN;
+  const int chunks = nb < kObjChunks ? nb : kObjChunks;
+  hipLaunchKernelGGL((objspn_bwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
+                     xw, scope, coef, wsum, wroot, out, dout, Dscr, Sscr, Rscr, n, nb);
+  STOVE_LAUNCH_CHECK();
+  hipLaunchKernelGGL((objspn_pix_k<6, 25, 10, 8>), dim3(grid_for(nb, 4096)), dim3(512), 0, st,
+                     xw, Dscr, leaf_slot, coef, dxw, nb);
+  STOVE_LAUNCH_CHECK();
+  hipLaunchKernelGGL((objspn_coefgrad_k<6, 25, 10>), dim3(6 * chunks), dim3(128), 0, st, xw, Dscr, scope, pc, nb, chunks);
+  STOVE_LAUNCH_CHECK();
+  hipLaunchKernelGGL((objspn_wgrad_k<6, 10, 10>), dim3(chunks), dim3(6 * 2 * 10 * 2 + 64), 0, st, Sscr, Rscr, pw, pr, nb, chunks);
+  STOVE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_chunks_k, dim3((kObjCoefN + 255) / 256), dim3(256), 0, st, pc, g_coef, (int)kObjCoefN, chunks, 0);
+  hipLaunchKernelGGL(reduce_chunks_k, dim3((kObjWN + 255) / 256), dim3(256), 0, st, pw, g_wsum, (int)kObjWN, chunks, 0);
+  hipLaunchKernelGGL(reduce_chunks_k, dim3((kObjRootN + 255) / 256), dim3(256), 0, st, pr, g_wroot, (int)kObjRootN, chunks, 0);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace stove

@@ -1,0 +1,294 @@
+"""Random sum-product networks (RAT-SPN) whose sweep runs as HIP kernels on gfx950.
+
+Module/API surface of the reference's model/spn/rat_torch.py (SpnArgs :21-35, GaussVector :64,
+ProductVector :138, SumVector :185, RatSpn :256): the same constructor arguments, the same
+`vector_list.L.i.{means,sigma_params,params}` / `output_vector.params` state-dict names and the
+same `RatSpn.forward(inputs, marginalized=None) -> (B, num_classes)` contract.  The node
+vectors only hold parameters and structure; evaluation is one fused kernel sweep
+(stove_amd/csrc/spn_obj.hip, spn_bg.hip) over tables baked from the parameters:
+
+  leaf      log N(x; mu, v) = a x^2 + b x + c,   v = vmin + (vmax - vmin) sigmoid(sigma_params)
+            (the reference's "sigma" is a variance, rat_torch.py:85-99)
+  sum       softmax(params, 0) in the linear domain; the kernel evaluates
+            log sum_k exp(child_k) w_k as a bilinear form of max-shifted exponentials.
+
+Two shapes have kernels, the two STOVE builds (probabilistic_models.py): the 100-dim object SPN
+(6 x random_split(2,2), 10 gaussians, 10 sums) and the 1024-dim background SPN
+(3 x random_split(2,1), 6 gaussians).  Other shapes raise NotImplementedError.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import region_graph
+
+
+def truncated_normal_(tensor, mean=0, std=0.1):
+    """Fill with N(mean, std) truncated to two standard deviations: of four candidate draws per
+    element keep the first that lies within (-2, 2)."""
+    with torch.no_grad():
+        cand = tensor.new_empty(tuple(tensor.shape) + (4,)).normal_()
+        ok = (cand > -2) & (cand < 2)
+        first = ok.max(-1, keepdim=True)[1]
+        tensor.copy_(cand.gather(-1, first).squeeze(-1))
+        tensor.mul_(std).add_(mean)
+    return tensor
+
+
+class BasicParamProvider:
+    def grab_sum_parameters(self, num_inputs, num_sums):
+        return nn.Parameter(torch.empty(num_inputs, num_sums))
+
+    def grab_leaf_parameters(self, scope, number, name=None):
+        return nn.Parameter(torch.empty(len(scope), number))
+
+
+class SpnArgs:
+    def __init__(self):
+        self.linear_sum_weights = False
+        self.normalized_sums = True
+        self.num_sums = 20
+        self.param_provider = BasicParamProvider()
+        self.gauss_min_sigma = 0.1
+        self.gauss_max_sigma = 1.0
+        self.gauss_mean_of_means = 0.0
+        self.dist = 'Gauss'
+        self.init_fn = truncated_normal_
+        self.gauss_min_mean = None
+        self.gauss_max_mean = None
+
+
+class NodeVector(nn.Module):
+    """A vector of SPN nodes over one region (parameter + structure holder)."""
+
+    def __init__(self, name):
+        super().__init__()
+        self.name = name
+
+    def __hash__(self):
+        return hash(self.name)
+
+    def __eq__(self, other):
+        return isinstance(other, NodeVector) and self.name == other.name
+
+    def init_params(self, init_fn=None):
+        pass
+
+    def num_params(self):
+        return 0
+
+
+class GaussVector(NodeVector):
+    def __init__(self, region, args, name, num_dims=0):
+        super().__init__(name)
+        self.args = args
+        self.scope = sorted(int(i) for i in region)
+        self.local_size = len(self.scope)
+        self.size = args.num_gauss
+        self.num_dims = num_dims
+        self.means = args.param_provider.grab_leaf_parameters(self.scope, args.num_gauss)
+        self.sigma_params = args.param_provider.grab_leaf_parameters(self.scope, args.num_gauss)
+
+    def init_params(self, init_fn=None):
+        init_fn = init_fn or truncated_normal_
+        init_fn(self.means, mean=self.args.gauss_mean_of_means, std=0.1)
+        init_fn(self.sigma_params, mean=0.0, std=0.1)
+
+    def num_params(self):
+        return self.means.numel() + self.sigma_params.numel()
+
+
+class ProductVector(NodeVector):
+    def __init__(self, vector1, vector2, name):
+        super().__init__(name)
+        self.inputs = [vector1, vector2]          # plain list: children are not sub-modules
+        assert not set(vector1.scope) & set(vector2.scope)
+        self.scope = sorted(set(vector1.scope) | set(vector2.scope))
+        self.size = vector1.size * vector2.size
+
+
+class SumVector(NodeVector):
+    def __init__(self, prod_vectors, num_sums, args, name=''):
+        super().__init__(name)
+        self.inputs = prod_vectors
+        self.size = num_sums
+        self.args = args
+        self.scope = self.inputs[0].scope
+        for v in self.inputs:
+            assert set(v.scope) == set(self.scope)
+        self.params = args.param_provider.grab_sum_parameters(sum(v.size for v in prod_vectors), num_sums)
+
+    def init_params(self, init_fn=None):
+        (init_fn or truncated_normal_)(self.params)
+
+    def num_params(self):
+        return self.params.numel()
+
+
+class RatSpn(nn.Module):
+    def __init__(self, num_classes, region_graph, args=None, name=None):
+        super().__init__()
+        self.args = args if args is not None else SpnArgs()
+        self.name = name if name is not None else str(id(self))
+        self._region_graph = region_graph
+        self.num_classes = num_classes
+        self.num_dims = region_graph.get_num_items()
+        self.vector_list = nn.ModuleList()
+        self.output_vector = None
+        self._build()
+        self.init_params(self.args.init_fn)
+        self._make_plan()
+
+    # ------------------------------------------------------------------ structure
+    def _build(self):
+        layers = self._region_graph.make_layers()
+        self.rg_layers = layers
+        dist_of = {}
+        leaf_layer = nn.ModuleList()
+        for i, region in enumerate(layers[0]):
+            if self.args.dist != 'Gauss':
+                raise NotImplementedError('only Gaussian leaves')
+            vec = GaussVector(region, self.args, '{}_gauss_{}'.format(self.name, i), num_dims=self.num_dims)
+            leaf_layer.append(vec)
+            dist_of[region] = vec
+        self.vector_list.append(leaf_layer)
+        products_of = {}
+        for li in range(1, len(layers)):
+            cur = nn.ModuleList()
+            if li % 2 == 1:
+                for i, partition in enumerate(layers[li]):
+                    a, b = partition[0], partition[1]
+                    vec = ProductVector(dist_of[a], dist_of[b], '{}_prod_{}_{}'.format(self.name, li, i))
+                    cur.append(vec)
+                    products_of.setdefault(tuple(sorted(a + b)), []).append(vec)
+            else:
+                n_out = self.num_classes if li == len(layers) - 1 else self.args.num_sums
+                for i, region in enumerate(layers[li]):
+                    vec = SumVector(products_of[region], n_out, self.args, name='{}_sum_{}_{}'.format(self.name, li, i))
+                    cur.append(vec)
+                    dist_of[region] = vec
+            self.vector_list.append(cur)
+        self.output_vector = dist_of[self._region_graph.get_root_region()]
+
+    def init_params(self, init_fn):
+        for layer in self.vector_list:
+            for vec in layer:
+                vec.init_params(init_fn)
+
+    def get_sum_params(self):
+        return {v: v.params for layer in self.vector_list for v in layer if isinstance(v, SumVector)}
+
+    def num_params(self):
+        return sum(v.num_params() for layer in self.vector_list for v in layer)
+
+    # ------------------------------------------------------------------ kernel plan
+    def _make_plan(self):
+        """Map the layered structure onto one of the two kernel shapes and precompute the
+        integer tables (registered as non-persistent buffers so they follow .to(device))."""
+        self._kind = None
+        vl = self.vector_list
+        a = self.args
+        if a.linear_sum_weights or not a.normalized_sums or a.gauss_min_mean is not None \
+                or a.gauss_max_mean is not None or not (a.gauss_min_sigma < a.gauss_max_sigma):
+            return
+        root = self.output_vector
+        if self.num_classes != 1 or not isinstance(root, SumVector):
+            return
+        leaves = list(vl[0])
+        leaf_idx = {id(v): i for i, v in enumerate(leaves)}
+        if len(vl) == 5 and self.num_dims == 100 and a.num_gauss == 10 and a.num_sums == 10:
+            sums = list(vl[2])
+            sum_idx = {id(v): i for i, v in enumerate(sums)}
+            R = len(root.inputs)
+            if R != 6 or len(leaves) != 4 * R or len(sums) != 2 * R:
+                return
+            leaf_order, sum_order = [], []
+            for prod in root.inputs:                       # replica r = r-th child of the root sum
+                for s in prod.inputs:                      # (in1, in2) = sides 0, 1
+                    if len(s.inputs) != 1:
+                        return
+                    sum_order.append(sum_idx[id(s)])
+                    for leaf in s.inputs[0].inputs:
+                        if len(leaf.scope) != 25:
+                            return
+                        leaf_order.append(leaf_idx[id(leaf)])
+            scope = torch.tensor([leaves[i].scope for i in leaf_order], dtype=torch.int32)      # (24,25)
+            slot = torch.zeros(R, 100, dtype=torch.int32)
+            for r in range(R):
+                for L in range(4):
+                    for i, p in enumerate(leaves[leaf_order[r * 4 + L]].scope):
+                        slot[r, p] = L * 25 + i
+            self.register_buffer('_scope', scope, persistent=False)
+            self.register_buffer('_leaf_slot', slot, persistent=False)
+            self.register_buffer('_leaf_order', torch.tensor(leaf_order), persistent=False)
+            self.register_buffer('_sum_order', torch.tensor(sum_order), persistent=False)
+            self._kind = 'obj'
+        elif len(vl) == 3 and self.num_dims == 1024 and a.num_gauss == 6:
+            R = len(root.inputs)
+            if R != 3 or len(leaves) != 2 * R:
+                return
+            side = torch.zeros(R, 1024, dtype=torch.int32)
+            gidx = torch.zeros(R, 1024, dtype=torch.long)
+            for r, prod in enumerate(root.inputs):
+                for s, leaf in enumerate(prod.inputs):
+                    if len(leaf.scope) != 512:
+                        return
+                    li = leaf_idx[id(leaf)]
+                    for i, p in enumerate(leaf.scope):
+                        side[r, p] = s
+                        gidx[r, p] = li * 512 + i
+            self.register_buffer('_side', side, persistent=False)
+            self.register_buffer('_gidx', gidx, persistent=False)
+            self._kind = 'bg'
+
+    def _leaf_coef(self):
+        """(n_leaves, S, G, 3) = (a, b, c) with leaf log-density sum_p w_p (a x^2 + b x + c)."""
+        a = self.args
+        mu = torch.stack([v.means for v in self.vector_list[0]])
+        rho = torch.stack([v.sigma_params for v in self.vector_list[0]])
+        var = a.gauss_min_sigma + (a.gauss_max_sigma - a.gauss_min_sigma) * torch.sigmoid(rho)
+        inv = 1.0 / var
+        return torch.stack([-0.5 * inv, mu * inv, -0.5 * mu * mu * inv - 0.5 * torch.log(2.0 * math.pi * var)], -1)
+
+    def tables(self):
+        """Baked float tables (differentiable functions of the parameters) + integer plan."""
+        if self._kind == 'obj':
+            coef = self._leaf_coef()[self._leaf_order]                                   # (24,25,10,3)
+            w = torch.stack([v.params for v in self.vector_list[2]])                      # (12,100,10)
+            wsum = torch.softmax(w, 1)[self._sum_order]
+            wroot = torch.softmax(self.output_vector.params, 0).view(6, 100)
+            return (coef.contiguous(), wsum.contiguous(), wroot.contiguous(), self._scope, self._leaf_slot)
+        if self._kind == 'bg':
+            coef = self._leaf_coef().reshape(6 * 512, 6, 3)[self._gidx]                   # (3,1024,6,3)
+            wroot = torch.softmax(self.output_vector.params, 0).view(3, 36)
+            return (coef.contiguous(), wroot.contiguous(), self._side)
+        raise NotImplementedError(
+            'RatSpn: no gfx950 kernel for this SPN shape (dims=%d); kernels exist for the STOVE '
+            'object (100-dim, 6x random_split(2,2)) and background (1024-dim, 3x random_split(2,1)) SPNs'
+            % self.num_dims)
+
+    # ------------------------------------------------------------------ evaluation
+    def forward(self, inputs, marginalized=None):
+        """Root log-density (B, 1); `marginalized` in [0,1] weighs each input's leaf term by
+        (1 - clamp(marginalized, 0, 1))."""
+        tabs = self.tables()
+        if self._kind == 'obj':
+            return ops.objspn_apply(inputs, marginalized, *tabs)
+        return ops.bgspn_apply(inputs, marginalized, *tabs)
+
+
+def _demo():
+    rg = region_graph.RegionGraph(range(100), seed=42)
+    for _ in range(6):
+        rg.random_split(2, 2)
+    args = SpnArgs()
+    args.num_sums = 10
+    args.num_gauss = 10
+    spn = RatSpn(1, region_graph=rg, name='spn', args=args)
+    print('parameters:', spn.num_params(), 'kernel:', spn._kind)
+
+
+if __name__ == '__main__':
+    _demo()

@@ -1,0 +1,43 @@
+"""LSTM recognition network of SuPAIR (host-side PyTorch-ROCm code).
+
+API and parameter names of the reference's model/video_prediction/encoder.py:7-57
+(`RnnStates`: LSTM(c*w*h -> 256) unrolled for num_obj steps on the SAME flattened frame, then
+256 -> 50 -> 8).  Because the input is identical at every step, its projection through
+W_ih is computed once (one (nT x 1024) @ (1024 x 1024) GEMM on rocBLAS/hipBLASLt) instead of
+num_obj times; the recurrent part is num_obj small GEMMs + gate math.
+"""
+import torch
+import torch.nn as nn
+
+
+class RnnStates(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.c = config
+        self.z_size = 4
+        self.lstm_size = 256
+        img_size = self.c.channels * self.c.width * self.c.height
+        self.rnn = nn.LSTM(img_size, self.lstm_size)
+        self.fc1 = nn.Linear(self.lstm_size, 50)
+        self.fc2 = nn.Linear(50, 2 * self.z_size)
+        nn.init.xavier_uniform_(self.fc1.weight)
+        nn.init.xavier_uniform_(self.fc2.weight)
+        nn.init.constant_(self.fc1.bias, 0.1)
+        nn.init.constant_(self.fc2.bias, 0.1)
+
+    def forward(self, frames):
+        """frames (-1, c, w, h) -> (-1, num_obj, 8): per-object (mean, std) codes of [sx, sy/sx, x, y]."""
+        x = frames.flatten(start_dim=1)
+        rnn = self.rnn
+        gates_x = torch.addmm(rnn.bias_ih_l0 + rnn.bias_hh_l0, x, rnn.weight_ih_l0.t())
+        h = x.new_zeros(x.shape[0], self.lstm_size)
+        cell = x.new_zeros(x.shape[0], self.lstm_size)
+        hs = []
+        for k in range(self.c.num_obj):
+            gates = gates_x if k == 0 else torch.addmm(gates_x, h, rnn.weight_hh_l0.t())
+            i, f, g, o = gates.chunk(4, 1)
+            cell = torch.sigmoid(f) * cell + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(cell)
+            hs.append(h)
+        out = torch.stack(hs, 1)
+        return self.fc2(torch.sigmoid(self.fc1(out)))

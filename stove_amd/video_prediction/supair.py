@@ -1,0 +1,143 @@
+"""SuPAIR scene model (sum-product attend-infer-repeat with a fixed number of objects).
+
+Module/API surface of the reference's model/video_prediction/supair.py (`Supair`, :14-551).
+`likelihood` -- 91-97 % of the reference's forward time -- is ONE fused HIP pipeline
+(stove_amd/csrc/scene.hip + spn_obj.hip + spn_bg.hip): glimpse extraction, occlusion masks,
+both SPN sweeps, patch scaling and the overlap prior, with an analytic backward to z and to
+every SPN parameter.  The stand-alone `patches_from_z` / `masks_from_z` API methods (debug
+plots, appearance embedding; not on the hot path) stay PyTorch-ROCm host code.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.distributions import Normal
+
+from .. import ops
+from ..spn import probabilistic_models as prob
+from . import encoder
+
+
+class Supair(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.c = config
+        self.step_counter = 0          # set by the calling trainer
+        self.prop_dict = {}            # exported metrics
+        self.encoder = encoder.RnnStates(self.c)
+        if self.c.debug_obj_spn or self.c.debug_bg_model:
+            raise NotImplementedError('the simple-Gaussian debug models have no gfx950 kernel')
+        self.obj_spn = prob._get_obj_spn(self.c, seed=self.c.random_seed)
+        self.bg_spn = prob._get_bg_spn(self.c, seed=self.c.random_seed)
+
+    # ------------------------------------------------------------------ likelihood
+    def likelihood(self, x, z_obj):
+        """log p(x, z) per frame.
+
+        x (n, T, c, w, h) frames; z_obj (n*T*O, 4) = [sx, sy, x, y] -> (n*T,), prop_dict.
+        log p = bgSPN(x | mask) + sum_k objSPN(glimpse_k | occlusion_k) sx_k sy_k
+                + sum_k log Exponential(overlap_beta)(overlap_k)      (reference supair.py:44-110)
+        """
+        if self.c.channels != 1 or x.shape[-1] != 32 or x.shape[-2] != 32 \
+                or self.c.patch_width != 10 or self.c.patch_height != 10:
+            raise NotImplementedError('scene kernels are built for 1x32x32 frames and 10x10 glimpses')
+        frames = x.flatten(end_dim=1).flatten(start_dim=1)
+        log_p_xz, parts = ops.scene_likelihood(
+            frames, z_obj.reshape(-1, 4), self.obj_spn.tables(), self.bg_spn.tables(),
+            self.c.num_obj, self.c.overlap_beta)
+        if ((self.step_counter % self.c.print_every == 0)
+                or (self.step_counter % self.c.plot_every == 0)):
+            if self.c.debug:
+                m = parts.mean(0)
+                self.prop_dict['bg'] = m[0]
+                self.prop_dict['patch'] = m[1]
+                self.prop_dict['overlap'] = m[2]
+        return log_p_xz, self.prop_dict
+
+    # ------------------------------------------------------------------ state codes
+    def constrain_zp(self, zp):
+        """(nTo, 8) raw codes -> mean, std (nTo, 4) of [sx, sy/sx, x, y] (reference supair.py:112-149)."""
+        c = self.c
+        sig = torch.sigmoid(zp)
+        span = zp.new_tensor([c.max_obj_scale - c.min_obj_scale, c.max_y_scale - c.min_y_scale,
+                              2 * c.obj_pos_bound, 2 * c.obj_pos_bound])
+        low = zp.new_tensor([c.min_obj_scale, c.min_y_scale, -c.obj_pos_bound, -c.obj_pos_bound])
+        zp_mean = sig[:, :4] * span + low
+        zp_std = sig[:, 4:] * zp.new_tensor([c.scale_var, c.scale_var, c.pos_var, c.pos_var])
+        return zp_mean, zp_std
+
+    @staticmethod
+    def sy_from_quotient(z):
+        """[sx, sy/sx, ...] -> [sx, sy, ...]."""
+        return torch.cat([z[..., 0:1], z[..., 0:1] * z[..., 1:2], z[..., 2:]], -1)
+
+    @staticmethod
+    def quotient_from_sy(z):
+        """[sx, sy, ...] -> [sx, sy/sx, ...]."""
+        return torch.cat([z[..., 0:1], z[..., 1:2] / z[..., 0:1], z[..., 2:]], -1)
+
+    def get_z_sup_sample(self, zp_mean, zp_std):
+        """Reparameterised sample of q(z|x) and its log-density summed over the 4 dims."""
+        dist = Normal(zp_mean, zp_std)
+        z = dist.rsample()
+        return self.sy_from_quotient(z), dist.log_prob(z).sum(-1)
+
+    # ------------------------------------------------------------------ spatial transformer API
+    @staticmethod
+    def expand_z(z):
+        """[sx, sy, x, y] -> affine matrices [[sx, 0, x], [0, sy, y]]  (nTo, 2, 3)."""
+        zero = torch.zeros_like(z[:, 0])
+        return torch.stack([z[:, 0], zero, z[:, 2], zero, z[:, 1], z[:, 3]], 1).view(-1, 2, 3)
+
+    @staticmethod
+    def invert_z(z):
+        """Parameters of the inverse transform: [1/sx, 1/sy, -x/sx, -y/sy]."""
+        return torch.stack([1.0 / z[:, 0], 1.0 / z[:, 1], -z[:, 2] / z[:, 0], -z[:, 3] / z[:, 1]], 1)
+
+    def _sample(self, img, theta, h_out, w_out):
+        ac = bool(getattr(self.c, 'align_corners', False))
+        grid = F.affine_grid(theta, (img.shape[0], img.shape[1], h_out, w_out), align_corners=ac)
+        return F.grid_sample(img, grid, mode='bilinear', padding_mode='zeros', align_corners=ac)
+
+    def patches_from_z(self, x_img, z_obj):
+        """(nT, c, w, h), (nT*o, 4) -> glimpses (nT*o, c, patch_w, patch_h)."""
+        o = z_obj.shape[0] // x_img.shape[0]
+        x_obj = x_img.unsqueeze(1).expand(-1, o, -1, -1, -1).reshape(-1, *x_img.shape[1:])
+        return self._sample(x_obj, self.expand_z(z_obj), self.c.patch_width, self.c.patch_height)
+
+    def masks_from_z(self, z_img):
+        """(nT, o, 4) -> marginalisation masks: per-glimpse (nT*o, c, pw, ph), background
+        (nT, c, w, h) and overlap ratios (nT, o).  Objects are processed in order; each sees the
+        boxes pasted by the earlier ones (and everything outside the frame) as marginalised."""
+        c = self.c
+        n = z_img.shape[0]
+        ones = z_img.new_ones(n, c.channels, c.width, c.height)
+        bg = z_img.new_zeros(n, c.channels, c.width, c.height)
+        per_obj = []
+        for k in range(z_img.shape[1]):
+            zk = z_img[:, k]
+            per_obj.append(1.0 - self._sample(1.0 - bg, self.expand_z(zk), c.patch_width, c.patch_height))
+            bg = torch.clamp(bg + self._sample(ones, self.expand_z(self.invert_z(zk)), c.width, c.height), 0, 1)
+        marg = torch.stack(per_obj, 1)
+        return marg.flatten(end_dim=1), bg, marg.flatten(start_dim=2).mean(dim=2)
+
+    def reconstruct_from_z(self, *args, **kwargs):
+        raise NotImplementedError('MPE rendering (reference supair.py:358-501) is visualisation code, '
+                                  'out of the hot-path scope of this build')
+
+    # ------------------------------------------------------------------ SuPAIR-only ELBO
+    def forward(self, x):
+        """ELBO of SuPAIR alone on (n, T, c, w, h) frames -> mean ELBO, prop_dict."""
+        codes = self.encoder(x.flatten(end_dim=1))
+        zp_mean, zp_std = self.constrain_zp(codes.flatten(end_dim=1))
+        z_obj, log_q = self.get_z_sup_sample(zp_mean, zp_std)
+        log_q = log_q.view(-1, self.c.num_obj).sum(-1)
+        log_p, _ = self.likelihood(x, z_obj)
+        elbo = log_p - log_q
+        average_elbo = torch.mean(elbo)
+        if ((self.step_counter % self.c.print_every == 0)
+                or (self.step_counter % self.c.plot_every == 0)):
+            self.prop_dict['z'] = z_obj.view(*x.shape[0:2], self.c.num_obj, 4).detach()
+            if self.c.debug:
+                self.prop_dict['log_q'] = log_q.mean().detach()
+                self.prop_dict['z_std'] = zp_std.mean(0).detach()
+        return average_elbo, self.prop_dict

@@ -1,0 +1,19 @@
+"""Helpers for the -m gpu parity tests: build product modules with the analytic weights."""
+import numpy as np
+import torch
+
+from analytic_weights import analytic_tensor
+
+
+def fill_analytic(module, prefix=''):
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            p.copy_(analytic_tensor(prefix + name, p.shape, torch.float64).to(p.dtype))
+    return module
+
+
+def err(a, b):
+    """max |a-b| / max |b| with both moved to float64 numpy."""
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().double().cpu().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))

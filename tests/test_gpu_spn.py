@@ -1,0 +1,199 @@
+"""GPU parity tests of the SPN / scene HIP kernels against the CPU oracle (fp64) and the
+reference-generated goldens.  Tolerances: forward values 1e-4 relative (the north_star bar),
+gradients 2e-3 relative to the largest entry (fp32 vs fp64; the reference's own fp32-vs-fp64
+gradient self-consistency is 3e-4)."""
+import numpy as np
+import pytest
+import torch
+
+import stove_oracle as O
+from gpu_helpers import err, fill_analytic
+from helpers import load_golden, oracle_setup, t_
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+FWD_TOL, GRAD_TOL = 1e-4, 2e-3
+
+
+def test_wave_sum_dpp():
+    from stove_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64 * 64, generator=g).to(DEV)
+    out = ops.wave_sum_selftest(x).view(64, 64).cpu()
+    ref = x.view(64, 64).double().sum(1, keepdim=True).expand(-1, 64).cpu()
+    assert err(out, ref) < 1e-5
+    # exact on small integers: every lane must carry the same total
+    xi = torch.randint(-8, 8, (16 * 64,), generator=g).float().to(DEV)
+    oi = ops.wave_sum_selftest(xi).view(16, 64).cpu()
+    assert torch.equal(oi, xi.view(16, 64).sum(1, keepdim=True).expand(-1, 64).cpu())
+
+
+def _spn_pair(kind):
+    from stove_amd.spn import probabilistic_models as prob
+    c, structs, params = oracle_setup(torch.float64)
+    spn = (prob._get_obj_spn if kind == 'obj' else prob._get_bg_spn)(c, 42)
+    fill_analytic(spn, f'sup.{kind}_spn.')
+    return c, structs, params, spn.to(DEV)
+
+
+def _oracle_spn(kind, c, structs, params, x, m):
+    if kind == 'obj':
+        args = (c.obj_spn_num_gauss, c.obj_spn_num_sums, c.obj_min_var, c.obj_max_var)
+    else:
+        args = (6, 3, c.bg_min_var, c.bg_max_var)
+    return O.spn_forward(structs[kind], params, f'sup.{kind}_spn.', x, m, *args)
+
+
+@pytest.mark.parametrize('kind', ['obj', 'bg'])
+@pytest.mark.parametrize('n', [8, 1, 64, 65, 200])
+def test_ratspn_operator(kind, n):
+    c, structs, params, spn = _spn_pair(kind)
+    d = spn.num_dims
+    g = torch.Generator().manual_seed(n)
+    if n == 8:
+        gold = load_golden(f'g2_ratspn_{kind}_f32')
+        x64, m64 = t_(gold['x']), t_(gold['marg'])
+    else:
+        x64 = torch.rand(n, d, generator=g, dtype=torch.float64)
+        m64 = torch.rand(n, d, generator=g, dtype=torch.float64) * 1.4 - 0.2
+        m64[0] = 0.0
+    wsum = torch.linspace(0.5, 1.5, n, dtype=torch.float64)
+    x_o, m_o = x64.clone().requires_grad_(), m64.clone().requires_grad_()
+    out_o = _oracle_spn(kind, c, structs, params, x_o, m_o)
+    (out_o[:, 0] * wsum).sum().backward()
+
+    x_d = x64.float().to(DEV).requires_grad_()
+    m_d = m64.float().to(DEV).requires_grad_()
+    out_d = spn(x_d, m_d)
+    assert out_d.shape == (n, 1)
+    assert err(out_d, out_o) < FWD_TOL
+    (out_d[:, 0] * wsum.float().to(DEV)).sum().backward()
+    assert err(x_d.grad, x_o.grad) < GRAD_TOL
+    assert err(m_d.grad, m_o.grad) < GRAD_TOL
+    for name, p in spn.named_parameters():
+        if name.startswith('output_vector'):
+            continue
+        assert err(p.grad, params[f'sup.{kind}_spn.' + name].grad) < GRAD_TOL, name
+    if n == 8:   # also against the reference's own fp32 outputs
+        assert err(out_d, gold['out']) < FWD_TOL
+        out_nm = spn(x_d.detach(), None)
+        assert err(out_nm, gold['out_nomarg']) < FWD_TOL
+
+
+def test_ratspn_operator_empty_batch():
+    c, structs, params, spn = _spn_pair('obj')
+    out = spn(torch.zeros(0, 100, device=DEV), None)
+    assert out.shape == (0, 1)
+
+
+def test_ratspn_bitwise_reproducible():
+    c, structs, params, spn = _spn_pair('obj')
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(300, 100, generator=g).to(DEV)
+    m = torch.rand(300, 100, generator=g).to(DEV)
+    outs, grads = [], []
+    for _ in range(2):
+        spn.zero_grad()
+        xx = x.clone().requires_grad_()
+        o = spn(xx, m)
+        o.sum().backward()
+        outs.append(o.detach().clone())
+        grads.append([p.grad.clone() for p in spn.parameters()] + [xx.grad.clone()])
+    assert torch.equal(outs[0], outs[1])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+
+
+def _supair_pair(n_obj, **extra):
+    from stove_amd.video_prediction.supair import Supair
+    from stove_amd.video_prediction.config import StoveConfig
+    c, structs, params = oracle_setup(torch.float64, num_obj=n_obj, **extra)
+    cfg = StoveConfig()
+    cfg.num_obj, cfg.width, cfg.height = n_obj, 32, 32
+    cfg.device, cfg.dtype, cfg.random_seed = torch.device(DEV), torch.float32, 42
+    cfg.action_conditioned, cfg.action_space = False, None
+    for k, v in extra.items():
+        setattr(cfg, k, v)
+    sup = fill_analytic(Supair(cfg), 'sup.').to(DEV)
+    return c, structs, params, sup
+
+
+@pytest.mark.parametrize('n_obj,extra', [(3, {}), (6, {'overlap_beta': 100.0, 'max_obj_scale': 0.22})])
+def test_scene_likelihood_vs_reference_golden(n_obj, extra):
+    gold = load_golden(f'g4_likelihood_n{n_obj}_f64')
+    c, structs, params, sup = _supair_pair(n_obj, **extra)
+    x = t_(gold['x']).float().to(DEV)
+    z = t_(gold['z']).float().to(DEV).requires_grad_()
+    sup.step_counter = 0
+    lp, prop = sup.likelihood(x, z)
+    assert err(lp, gold['log_p']) < FWD_TOL
+    for k in ('bg', 'patch', 'overlap'):
+        assert abs(float(prop[k]) - float(gold[k])) < FWD_TOL * abs(float(gold[k])) + 1e-6, k
+    (lp * t_(gold['w']).float().to(DEV)).sum().backward()
+    assert err(z.grad, gold['gz']) < GRAD_TOL
+    n = 0
+    for k, v in gold.items():
+        if k.startswith('g_') and 'encoder' not in k:
+            p = dict(sup.named_parameters())[k[2:]]
+            assert err(p.grad, v) < GRAD_TOL, k
+            n += 1
+    assert n > 60
+
+
+@pytest.mark.parametrize('n_obj', [3, 6, 1, 2])
+def test_scene_likelihood_vs_oracle_ragged(n_obj):
+    """n_frames not a multiple of the 64-sample tile, random and degenerate z."""
+    extra = {'debug_match_objects': 'greedy'} if n_obj != 3 else {}
+    c, structs, params, sup = _supair_pair(n_obj, **extra)
+    g = torch.Generator().manual_seed(11 + n_obj)
+    nb, t = 5, 9
+    x64 = torch.rand(nb, t, 1, 32, 32, generator=g, dtype=torch.float64) ** 2
+    z64 = torch.zeros(nb * t, n_obj, 4, dtype=torch.float64)
+    z64[..., 0] = 0.1 + 0.6 * torch.rand(nb * t, n_obj, generator=g, dtype=torch.float64)
+    z64[..., 1] = z64[..., 0] * (0.75 + 0.5 * torch.rand(nb * t, n_obj, generator=g, dtype=torch.float64))
+    z64[..., 2:] = 1.9 * torch.rand(nb * t, n_obj, 2, generator=g, dtype=torch.float64) - 0.95
+    z64[0, :, 2:] = z64[0, 0:1, 2:]                     # every object on top of the first
+    z64 = z64.flatten(0, 1)
+    w = torch.linspace(0.5, 1.5, nb * t, dtype=torch.float64)
+    z_o = z64.clone().requires_grad_()
+    lp_o, bg_o, pl_o, ov_o = O.scene_likelihood(c, params, structs, x64, z_o, parts=True)
+    (lp_o * w).sum().backward()
+    z_d = z64.float().to(DEV).requires_grad_()
+    sup.step_counter = 0
+    lp_d, prop = sup.likelihood(x64.float().to(DEV), z_d)
+    assert err(lp_d, lp_o) < FWD_TOL
+    assert abs(float(prop['bg']) - float(bg_o.mean())) < FWD_TOL * abs(float(bg_o.mean())) + 1e-6
+    (lp_d * w.float().to(DEV)).sum().backward()
+    assert err(z_d.grad, z_o.grad) < GRAD_TOL
+    for name, p in sup.named_parameters():
+        if 'encoder' in name or name.endswith('output_vector.params'):
+            continue
+        assert err(p.grad, params['sup.' + name].grad) < GRAD_TOL, name
+
+
+@pytest.mark.parametrize('n_obj', [3, 6])
+def test_glimpses_and_masks(n_obj):
+    gold = load_golden(f'g3_scene_n{n_obj}')
+    c, structs, params, sup = _supair_pair(n_obj, **({'debug_match_objects': 'greedy'} if n_obj == 6 else {}))
+    z = t_(gold['z']).float().to(DEV)
+    x = t_(gold['x']).float().to(DEV)
+    pat = sup.patches_from_z(x, z.flatten(0, 1))
+    assert pat.shape == gold['patches'].shape
+    assert err(pat, gold["patches"]) < 1e-4
+    mp, bgm, ov = sup.masks_from_z(z)
+    assert err(mp, gold["marg_patch"]) < 1e-4
+    assert err(bgm, gold["bg_mask"]) < 1e-4
+    assert err(ov, gold["overlap"]) < 1e-4
+
+
+@pytest.mark.parametrize('n_obj', [3, 6])
+def test_scene_glimpse_kernel(n_obj):
+    """The closed-form tile kernel (glimpse + occlusion mask) against the reference's sequential masks."""
+    from stove_amd import ops
+    gold = load_golden(f'g3_scene_n{n_obj}')
+    z = t_(gold['z']).float().to(DEV)
+    x = t_(gold['x']).float().to(DEV)
+    pat, keep = ops.scene_glimpses(x.flatten(1), z.flatten(0, 1), n_obj)
+    assert err(pat, gold['patches'].reshape(-1, 100)) < 1e-5
+    marg = np.clip(gold['marg_patch'].reshape(-1, 100), 0, 1)
+    assert err(1.0 - keep, marg) < 1e-5

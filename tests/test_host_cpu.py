@@ -1,0 +1,117 @@
+"""CPU-side checks (-m "not gpu"): the C ABI library loads and exports every declared symbol,
+the host-side structure code reproduces the reference's SPN structure, and the product path
+refuses to run without a GPU (no silent fallback)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import stove_oracle as O
+from helpers import GOLDEN, load_golden, t_
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from stove_amd import _lib, build
+    build.build_library()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    header = open(os.path.join(ROOT, 'include', 'stove_hip.h')).read()
+    declared = set(re.findall(r'\b(stove_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().stove_abi_version() >= 1
+    # size queries are pure host functions
+    assert _lib.load().stove_objspn_tile_floats(65) == 2 * 100 * 2 * 64
+    assert _lib.load().stove_scene_saved_floats(10, 3) > 0
+
+
+@pytest.mark.parametrize('seed', [7, 42])
+def test_region_graph_matches_reference_structure(seed):
+    from stove_amd.spn import probabilistic_models as prob
+    with open(os.path.join(GOLDEN, 'g1_spn_structure.json')) as f:
+        gold = json.load(f)
+    c = O.default_config(random_seed=seed)
+    for kind, spn in (('obj', prob._get_obj_spn(c, seed)), ('bg', prob._get_bg_spn(c, seed))):
+        g = gold[f'{kind}_{seed}']
+        pos = {}
+        for li, layer in enumerate(spn.vector_list):
+            assert len(layer) == len(g['layers'][li])
+            for i, vec in enumerate(layer):
+                pos[id(vec)] = (li, i)
+                ref = g['layers'][li][i]
+                if li == 0:
+                    assert list(vec.scope) == ref
+                elif li % 2 == 1:
+                    a, b = vec.inputs
+                    assert [*pos[id(a)], *pos[id(b)]] == ref
+                else:
+                    assert [pos[id(p)][1] for p in vec.inputs] == ref
+        assert list(pos[id(spn.output_vector)]) == g['root']
+        assert spn._kind == kind
+
+
+def test_state_dict_names_match_reference_inventory():
+    from stove_amd.video_prediction.stove import Stove
+    from stove_amd.video_prediction.config import StoveConfig
+    for extra in ({}, dict(action_conditioned=True, action_space=9, debug_core_appearance=True)):
+        c = O.default_config(**extra)
+        cfg = StoveConfig()
+        cfg.num_obj, cfg.width, cfg.height, cfg.random_seed = 3, 32, 32, 42
+        cfg.device, cfg.dtype = torch.device('cpu'), torch.float32
+        cfg.action_conditioned, cfg.action_space = c.action_conditioned, c.action_space
+        cfg.debug_core_appearance = c.debug_core_appearance
+        shapes = O.param_shapes(c, O.build_structs(c))
+        sd = Stove(cfg).state_dict()
+        for k, shp in shapes.items():
+            assert k in sd and tuple(sd[k].shape) == tuple(shp), k
+        extra_keys = set(sd) - set(shapes)
+        assert extra_keys == {'sup.obj_spn.output_vector.params', 'sup.bg_spn.output_vector.params'}
+
+
+def test_ops_refuse_cpu_tensors():
+    from stove_amd.spn import probabilistic_models as prob
+    c = O.default_config()
+    spn = prob._get_obj_spn(c, 42)
+    with pytest.raises(RuntimeError, match='GPU'):
+        spn(torch.rand(4, 100), None)
+
+
+def test_host_side_units_against_reference():
+    from stove_amd.video_prediction.stove import Stove
+    from stove_amd.video_prediction.config import StoveConfig
+    cfg = StoveConfig()
+    cfg.num_obj, cfg.width, cfg.height, cfg.random_seed = 3, 32, 32, 42
+    cfg.device, cfg.dtype, cfg.action_conditioned = torch.device('cpu'), torch.float64, False
+    torch.set_default_dtype(torch.float64)
+    try:
+        st = Stove(cfg)
+        g = load_golden('g10_units')
+        m, s = st.sup.constrain_zp(t_(g['zp']))
+        assert np.abs(m.numpy() - g['zp_mean']).max() < 1e-14 and np.abs(s.numpy() - g['zp_std']).max() < 1e-14
+        mc, sc = st.dyn.constrain_z_dyn(t_(g['zd']), t_(g['zds']))
+        assert np.abs(mc.numpy() - g['zd_c']).max() < 1e-14 and np.abs(sc.numpy() - g['zds_c']).max() < 1e-14
+        assert np.abs(st.v_from_state(t_(g['zsup'])).numpy() - g['v_full']).max() < 1e-14
+        assert np.abs(st.v_std_from_pos(t_(g['zsups'])).numpy() - g['vstd_full']).max() < 1e-14
+        g6 = load_golden('g6_match_3only')
+        zm, zs, _ = st._3_only_match_objects(t_(g6['z']), t_(g6['zstd']), None)
+        assert np.abs(zm.numpy() - g6['z_matched']).max() < 1e-15
+        assert np.abs(zs.numpy() - g6['zstd_matched']).max() < 1e-15
+        gf = load_golden('g6_fix_supair')
+        a, b = st.fix_supair(t_(gf['z']), t_(gf['zstd']))
+        assert np.abs(a.numpy() - gf['z_fixed']).max() < 1e-15 and np.abs(b.numpy() - gf['zstd_fixed']).max() < 1e-15
+        cfg6 = StoveConfig()
+        cfg6.num_obj, cfg6.width, cfg6.height, cfg6.random_seed = 6, 32, 32, 42
+        cfg6.device, cfg6.dtype, cfg6.action_conditioned = torch.device('cpu'), torch.float64, False
+        cfg6.debug_match_objects = 'greedy'
+        st6 = Stove(cfg6)
+        gg = load_golden('g6_match_greedy')
+        zm, zs, _ = st6._greedy_match_objects(t_(gg['z']), t_(gg['zstd']), None)
+        assert np.abs(zm.numpy() - gg['z_matched']).max() < 1e-15
+    finally:
+        torch.set_default_dtype(torch.float32)
