@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""Headline benchmark: frames/s of one STOVE training step on synthetic billiards video.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch: Stove.forward (encoder, matching, fused
+inference recursion, both fused scene likelihoods) + elbo.backward() + [N>1: one RCCL all-reduce
+of the flat gradient] + clip_grad_norm_(1) + Adam(amsgrad) step, i.e. the reference's training
+step (train.py:443-473).  Workload (BASELINE.json configs[1]): 3-object billiards, 32x32,
+T=100, batch 256 per GPU (weak scaling), frames from the build's numpy simulator, model with
+default initialisation; inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line (contract in the task statement); `roofline` is measured with HIP
+events around the dominant kernel, `cpu_baseline` times the CPU oracle on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=10)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--batch', type=int, default=256, help='sequences per GPU')
+    p.add_argument('--frames', type=int, default=100, help='T, frames per sequence')
+    p.add_argument('--workload', default='billiards', choices=['billiards', 'multibilliards', 'gravity', 'avoidance'])
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-batch', type=int, default=16)
+    p.add_argument('--cpu-iters', type=int, default=3)
+    p.add_argument('--profile-steps', type=int, default=3)
+    return p.parse_args()
+
+
+def build_config(workload, device):
+    from stove_amd.video_prediction.config import StoveConfig
+    c = StoveConfig()
+    c.width, c.height, c.channels = 32, 32, 1
+    c.device, c.dtype = device, torch.float32
+    c.random_seed = 42
+    c.skip = 2
+    c.print_every, c.plot_every = 10 ** 9, 1e19          # no logging side channel inside the timed region
+    c.num_obj, c.action_conditioned, c.action_space = 3, False, None
+    if workload == 'multibilliards':
+        c.num_obj, c.debug_match_objects, c.overlap_beta, c.max_obj_scale = 6, 'greedy', 100.0, 0.22
+    if workload == 'avoidance':
+        c.action_conditioned, c.action_space, c.debug_core_appearance = True, 9, True
+    return c
+
+
+def make_batch(workload, n_seq, T, seed0):
+    from stove_amd.envs import envs
+    cache = os.path.join('/tmp', f'stove_bench_{workload}_{n_seq}_{T}_{seed0}.npz')
+    if os.path.exists(cache):
+        d = dict(np.load(cache))
+    else:
+        d = envs.synth_sequences(workload, n_seq, T, seed0=seed0)
+        try:
+            np.savez(cache, **d)
+        except OSError:
+            pass
+    return d
+
+
+def cpu_baseline(workload, T, n_seq, iters):
+    """Time the CPU oracle (oracle/stove_oracle.py: the reference's ATen op sequence restated) on
+    the host cores: same workload shape, bounded batch."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import stove_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    kw = {}
+    if workload == 'multibilliards':
+        kw = dict(num_obj=6, debug_match_objects='greedy', overlap_beta=100.0, max_obj_scale=0.22)
+    c = O.default_config(**kw)
+    structs = O.build_structs(c)
+    torch.manual_seed(0)
+    params = {}
+    for k, shp in O.param_shapes(c, structs).items():
+        scale = 0.1 if k.endswith(('means', 'sigma_params', 'params')) else 1.0 / max(1.0, float(shp[-1])) ** 0.5
+        params[k] = (torch.randn(*shp) * scale).requires_grad_()
+    x = torch.from_numpy(make_batch(workload, n_seq, T, 10 ** 6)['X'])
+    g = torch.Generator().manual_seed(1)
+    times = []
+    for it in range(iters + 1):
+        eps = O.draw_eps(n_seq, c.num_obj, T, generator=g)
+        t0 = time.perf_counter()
+        elbo, _ = O.stove_forward(c, params, structs, x, eps)
+        (-elbo).backward()
+        dt = time.perf_counter() - t0
+        for p in params.values():
+            p.grad = None
+        if it > 0:
+            times.append(dt)
+    med = float(np.median(times))
+    return {'value': n_seq * T / med, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{workload} B={n_seq} T={T} fp32 fwd+bwd, median of {iters} after 1 warm-up, {med:.2f} s/step'}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the STOVE hot path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    from stove_amd import build as _build
+    if rank == 0 or world == 1:
+        _build.build_library()
+    if world > 1:
+        dist.barrier()
+    from stove_amd import _lib
+    from stove_amd.parallel import GradBucket
+    from stove_amd.video_prediction.stove import Stove
+
+    cfg = build_config(a.workload, dev)
+    torch.manual_seed(0)
+    model = Stove(cfg).to(dev)
+    bucket = GradBucket(model, world)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
+
+    data = make_batch(a.workload, a.batch, a.frames, rank * a.batch)
+    x = torch.from_numpy(data['X']).to(dev)
+    actions = torch.from_numpy(data['action']).float().to(dev) if 'action' in data else None
+    torch.manual_seed(1234 + rank)
+
+    def step(i):
+        opt.zero_grad(set_to_none=False)
+        elbo, _, rewards = model(x, i + 1, actions)
+        loss = -elbo
+        loss.backward()
+        bucket.all_reduce()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        return elbo
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        last = step(a.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    elbo_val = float(last)
+
+    # ---- per-kernel HIP-event timing of extra steps (profiling hooks off during the timed region)
+    roofline = None
+    lib = _lib.load()
+    if rank == 0 and a.profile_steps > 0:
+        lib.stove_profile_enable(1)
+        for i in range(a.profile_steps):
+            step(a.warmup + a.steps + i)
+        torch.cuda.synchronize()
+        prof = _lib.profile_report()
+        lib.stove_profile_enable(0)
+        if prof:
+            name, (total_ms, count) = max(prof.items(), key=lambda kv: kv[1][0])
+            n_obj = cfg.num_obj
+            frames_per_launch = a.batch * (a.frames - 2)             # the main likelihood call dominates the average
+            per_launch = {k: v for k, v in prof.items()}
+            avg_ms = total_ms / count
+            # algorithmic bytes of the SPN sweep per frame, fwd+bwd: 8200 + 32 N;
+            # the dominant kernel is one direction of it -> half of that per launch
+            alg_bytes = (8200 + 32 * n_obj) / 2 * frames_per_launch
+            roofline = {'bound': 'hbm', 'kernel': name, 'avg_ms': avg_ms, 'launches': count,
+                        'achieved': alg_bytes / (avg_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                        'frac': alg_bytes / (avg_ms * 1e-3) / 1e9 / 8000.0, 'traffic': None,
+                        'kernels_ms_per_step': {k: round(v[0] / a.profile_steps, 4) for k, v in sorted(
+                            per_launch.items(), key=lambda kv: -kv[1][0])[:12]}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.workload, a.frames, a.cpu_batch, a.cpu_iters)
+
+    if rank == 0:
+        frames = a.batch * a.frames * world * a.steps
+        out = {
+            'metric': 'frames/s (fwd+bwd) for 3-obj billiards 32x32 T=100, 1/2/4/8 GPU; ELBO delta vs ref',
+            'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{a.workload} 32x32 T={a.frames} batch={a.batch}/GPU (BASELINE.json configs[1])',
+                       'objects': cfg.num_obj, 'global_batch': a.batch * world,
+                       'step': 'forward+backward+allreduce+clip+adam(amsgrad)', 'parallelism': f'dp{world}',
+                       'elbo_last_step': elbo_val},
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

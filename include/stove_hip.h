@@ -101,6 +101,59 @@ int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z
 int stove_scene_glimpses(const float* frames, const float* z, int n_frames, int n_obj, float* tile,
                          float* patches, float* keep, void* stream);
 
+/* ---- Dynamics.forward / core (dynamics.py:181-265): one GNN step.
+ * params: the parameter image of stove_gnn_param_floats() floats built by
+ * stove_amd/video_prediction/dynamics.py (W | W^T | vectors; layout in csrc/gnn.hip).
+ * s_in (B,N,sin_dim): [state 16 | action embedding 4 | appearance 3] as configured (16 <= sin_dim <= 32);
+ * result (B,N,32) = means|stds (dynamics.py:216), pred (B,N,32) = dynamic_pred (:208), may be NULL.
+ * elu: 0 = leaky_relu(0.01) (the reference default, dynamics.py:109), 1 = elu. */
+size_t stove_gnn_param_floats(void);
+size_t stove_gnn_grad_floats(void);
+int stove_gnn_blocks(int B, int N);
+int stove_gnn_fwd(const float* s_in, const float* params, float* result, float* pred, int B, int N, int sin_dim,
+                  int lim_enc, int elu, void* stream);
+size_t stove_gnn_bwd_ws_bytes(int B, int N);
+/* g_params: gradient image of stove_gnn_grad_floats() floats (W layout + vectors). d_pred may be NULL. */
+int stove_gnn_bwd(const float* s_in, const float* params, const float* d_result, const float* d_pred, float* d_s_in,
+                  float* g_params, void* ws, int B, int N, int sin_dim, int lim_enc, int elu, void* stream);
+
+/* ---- the inference recursion of Stove.stove_forward (stove.py:696-713) with Dynamics.constrain_z_dyn
+ * (dynamics.py:147-179) and Stove.full_state (stove.py:103-170) fused, all Ts = T-skip steps in one launch.
+ * z1 (B,N,18) state at t=skip-1 [sx,sy/sx,x,y,vx,vy,latent]; zsup,zsstd (B,Ts,N,6) SuPAIR means/stds for
+ * t=skip..T-1; eps (B,Ts,N,18) standard-normal draws; extra (B,Ts,N,sin_dim-16) or NULL.
+ * outputs (B,Ts,N,.): z 18, zdyn 16, zdstd 16, mean 18, std 18, pred 32 (NULL to skip). */
+int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+                      const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred,
+                      int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
+                      void* stream);
+size_t stove_dynloop_bwd_ws_bytes(int B, int N);
+/* upstream gradients dz,dzdyn,dmean,dstd,dpred may each be NULL. */
+int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+                      const float* params, const float* z, const float* dz, const float* dzdyn, const float* dmean,
+                      const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd, float* dextra,
+                      float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var,
+                      float vel_std, float lat_std, void* stream);
+
+/* ---- Stove.rollout (stove.py:777-861), mean prediction: z_last (B,N,18) [sx,sy,...] ->
+ * z_pred (B,num,N,18); zstd (B,num,N,16) and pred (B,num,N,32) optional; extra (B,A,N,E) cycled (t % A). */
+int stove_rollout_fwd(const float* z_last, const float* extra, const float* params, float* z_pred, float* zstd, float* pred,
+                      int B, int num, int A, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std,
+                      float lat_std, void* stream);
+
+/* ---- Stove._3_only_match_objects / _greedy_match_objects / _volatile_match_objects
+ * (stove.py:200-329, 432-514, 331-430): the T-serial nearest-neighbour re-ordering of objects.
+ * feat (B,T,N,F) matching features in [-1,1] (positions [, appearance]); mode 0 = '3_only',
+ * 1 = 'greedy', 2 = 'volatile'.  idx (B,T,N) int64: current object assigned to slot a.
+ * perm (B,T,N,N) f32, pre-zeroed, only written in mode 2 (may be NULL otherwise). */
+int stove_match_objects(const float* feat, long long* idx, float* perm, int B, int T, int N, int F, int mode, void* stream);
+
+/* ---- measurement hooks (bench.py): when enabled, every kernel launch of this library is bracketed by
+ * two HIP events recorded on the launch stream.  stove_profile_report() synchronises them, writes
+ * "kernel\ttotal_ms\tcount\n" lines into buf and clears the records; returns the bytes needed.
+ * This is the only process-global state of the library and it is off by default. */
+void stove_profile_enable(int on);
+size_t stove_profile_report(char* buf, size_t cap);
+
 /* self-test hooks used by tests/ (wave reduction) */
 int stove_selftest_wave_sum(const float* in, float* out, int n_waves, void* stream);
 

@@ -16,6 +16,8 @@ EXPORTS = [
     'stove_bgspn_saved_floats', 'stove_bgspn_fwd', 'stove_bgspn_bwd_ws_bytes', 'stove_bgspn_bwd',
     'stove_scene_saved_floats', 'stove_scene_fwd', 'stove_scene_bwd_ws_bytes', 'stove_scene_bwd',
     'stove_scene_glimpses',
+    'stove_gnn_param_floats', 'stove_gnn_grad_floats', 'stove_gnn_blocks', 'stove_gnn_fwd', 'stove_gnn_bwd_ws_bytes',
+    'stove_gnn_bwd', 'stove_dynloop_fwd', 'stove_dynloop_bwd_ws_bytes', 'stove_dynloop_bwd', 'stove_rollout_fwd', 'stove_match_objects', 'stove_profile_enable', 'stove_profile_report',
 ]
 
 
@@ -50,6 +52,19 @@ def _declare(lib):
         'stove_scene_bwd_ws_bytes': (S, [I, I]),
         'stove_scene_bwd': (I, [T, P, P, I, I, F, P, P, P, G, P, P]),
         'stove_scene_glimpses': (I, [P, P, I, I, P, P, P, P]),
+        'stove_gnn_param_floats': (S, []),
+        'stove_gnn_grad_floats': (S, []),
+        'stove_gnn_blocks': (I, [I, I]),
+        'stove_gnn_fwd': (I, [P, P, P, P, I, I, I, I, I, P]),
+        'stove_gnn_bwd_ws_bytes': (S, [I, I]),
+        'stove_gnn_bwd': (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+        'stove_dynloop_fwd': (I, [P] * 12 + [I] * 6 + [F] * 3 + [P]),
+        'stove_dynloop_bwd_ws_bytes': (S, [I, I]),
+        'stove_dynloop_bwd': (I, [P] * 18 + [I] * 6 + [F] * 3 + [P]),
+        'stove_rollout_fwd': (I, [P] * 6 + [I] * 7 + [F] * 3 + [P]),
+        'stove_match_objects': (I, [P, P, P, I, I, I, I, I, P]),
+        'stove_profile_enable': (None, [I]),
+        'stove_profile_report': (S, [c_char_p, S]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -97,3 +112,17 @@ def ptr(t):
 
 def stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def profile_report():
+    """{kernel name: (total ms, launches)} recorded since stove_profile_enable(1); clears the records."""
+    lib = load()
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.stove_profile_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, ms, cnt = line.split('\t')
+        name = name.strip('()').split('<')[0].split('::')[-1]
+        tot, c = out.get(name, (0.0, 0))
+        out[name] = (tot + float(ms), c + int(cnt))
+    return out

@@ -3,9 +3,12 @@
 #include "../../include/stove_hip.h"
 
 #include "common.h"
+#include <string.h>
 #include "spn_obj.hip"
 #include "spn_bg.hip"
 #include "scene.hip"
+#include "gnn.hip"
+#include "match.hip"
 
 namespace stove {
 
@@ -35,7 +38,7 @@ static int scene_tile_fwd(const float* frames, const float* z, float* xw, int n_
   const int nb = (np + 63) / 64;
   const int items = nb * kPD;
   const int grid = items / 4 < 8192 ? (items + 3) / 4 : 8192;
-  hipLaunchKernelGGL((scene_tile_fwd_k<NMAX>), dim3(grid), dim3(256), 0, st, frames, z, xw, n_obj, np, nb);
+  STOVE_LAUNCH((scene_tile_fwd_k<NMAX>), dim3(grid), dim3(256), 0, st, frames, z, xw, n_obj, np, nb);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -54,9 +57,9 @@ static int scene_bwd_tail(const float* frames, const float* z, const float* dxw,
                           const float* dll, const float* obj_ll, const float* dz_bg, float* dz, int n_obj, int np,
                           hipStream_t st) {
   const int nb = (np + 63) / 64;
-  hipLaunchKernelGGL((scene_tile_bwd_k<NMAX>), dim3(nb < 4096 ? nb : 4096), dim3(256), 0, st, frames, z, dxw, d_ovl, dzc, n_obj, np, nb);
+  STOVE_LAUNCH((scene_tile_bwd_k<NMAX>), dim3(nb < 4096 ? nb : 4096), dim3(256), 0, st, frames, z, dxw, d_ovl, dzc, n_obj, np, nb);
   STOVE_LAUNCH_CHECK();
-  hipLaunchKernelGGL((scene_finalize_bwd_k<NMAX>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, obj_ll, dz_bg, dzc, dz, n_obj, np);
+  STOVE_LAUNCH((scene_finalize_bwd_k<NMAX>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, obj_ll, dz_bg, dzc, dz, n_obj, np);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -75,7 +78,7 @@ const char* stove_error_string(int code) { return hipGetErrorString((hipError_t)
 
 int stove_selftest_wave_sum(const float* in, float* out, int n_waves, void* stream) {
   if (n_waves % 4) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(wave_sum_test_k, dim3(n_waves / 4), dim3(256), 0, (hipStream_t)stream, in, out);
+  STOVE_LAUNCH(wave_sum_test_k, dim3(n_waves / 4), dim3(256), 0, (hipStream_t)stream, in, out);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -155,7 +158,7 @@ int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z
   if (rc) return rc;
   rc = bgspn_forward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(scene_assemble_fwd_k, dim3((n_frames + 255) / 256), dim3(256), 0, st, saved + L.bg_out, saved + L.obj_ll,
+  STOVE_LAUNCH(scene_assemble_fwd_k, dim3((n_frames + 255) / 256), dim3(256), 0, st, saved + L.bg_out, saved + L.obj_ll,
                      saved + L.ovl, z, ll, parts, n_obj, n_frames, overlap_beta, logf(overlap_beta));
   STOVE_LAUNCH_CHECK();
   return 0;
@@ -190,7 +193,7 @@ int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z
   const SceneSaved L = scene_saved_layout(n_frames, n_obj);
   const SceneWs W = scene_ws_layout(n_frames, n_obj);
   const int np = n_frames * n_obj;
-  hipLaunchKernelGGL(scene_assemble_bwd_k, dim3((np + 255) / 256), dim3(256), 0, st, dll, z, ws + W.d_obj, ws + W.d_ovl, n_obj, np, overlap_beta);
+  STOVE_LAUNCH(scene_assemble_bwd_k, dim3((np + 255) / 256), dim3(256), 0, st, dll, z, ws + W.d_obj, ws + W.d_ovl, n_obj, np, overlap_beta);
   STOVE_LAUNCH_CHECK();
   int rc = objspn_backward(saved + L.xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot,
                            saved + L.obj_ll, ws + W.d_obj, ws + W.dxw, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, st);
@@ -215,7 +218,151 @@ int stove_scene_glimpses(const float* frames, const float* z, int n_frames, int 
   int rc = scene_tile_fwd_any(frames, z, tile, n_obj, np, st);
   if (rc) return rc;
   const int nb = (np + 63) / 64;
-  hipLaunchKernelGGL(tile_unpack_k, dim3(nb < 2048 ? nb * 25 : 2048 * 25), dim3(256), 0, st, tile, patches, keep, np, nb);
+  STOVE_LAUNCH(tile_unpack_k, dim3(nb < 2048 ? nb * 25 : 2048 * 25), dim3(256), 0, st, tile, patches, keep, np, nb);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- GNN dynamics core
+static int gnn_lds_attr(const void* fn) {
+  return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGnnLdsFloats * sizeof(float)));
+}
+
+size_t stove_gnn_param_floats(void) { return kGnnParams; }
+size_t stove_gnn_grad_floats(void) { return kGnnGrads; }
+int stove_gnn_blocks(int B, int N) {
+  const int g = gnn_group(N);
+  return (B + g - 1) / g;
+}
+
+int stove_gnn_fwd(const float* s_in, const float* params, float* result, float* pred, int B, int N, int sin_dim,
+                  int lim_enc, int elu, void* stream) {
+  if (B == 0) return 0;
+  if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32) return (int)hipErrorInvalidValue;
+  int rc = gnn_lds_attr((const void*)gnn_step_fwd_k);
+  if (rc) return rc;
+  STOVE_LAUNCH(gnn_step_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
+                     s_in, params, result, pred, B, N, sin_dim, lim_enc, elu);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t stove_gnn_bwd_ws_bytes(int B, int N) { return (size_t)stove_gnn_blocks(B, N) * kGnnGrads * sizeof(float); }
+
+int stove_gnn_bwd(const float* s_in, const float* params, const float* d_result, const float* d_pred, float* d_s_in,
+                  float* g_params, void* ws, int B, int N, int sin_dim, int lim_enc, int elu, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    hipMemsetAsync(g_params, 0, kGnnGrads * sizeof(float), st);
+    return 0;
+  }
+  if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32) return (int)hipErrorInvalidValue;
+  int rc = gnn_lds_attr((const void*)gnn_step_bwd_k);
+  if (rc) return rc;
+  const int nb = stove_gnn_blocks(B, N);
+  STOVE_LAUNCH(gnn_step_bwd_k, dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, s_in, params, d_result, d_pred,
+                     d_s_in, (float*)ws, B, N, sin_dim, lim_enc, elu);
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 255) / 256), dim3(256), 0, st, (const float*)ws, g_params, kGnnGrads, nb, 0);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+                      const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred,
+                      int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
+                      void* stream) {
+  if (B == 0 || Ts == 0) return 0;
+  if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && extra == nullptr)) return (int)hipErrorInvalidValue;
+  int rc = gnn_lds_attr((const void*)dyn_loop_fwd_k);
+  if (rc) return rc;
+  LoopConst kc{pos_var, vel_std, lat_std};
+  STOVE_LAUNCH(dyn_loop_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
+                     z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, B, Ts, N, sin_dim, lim_enc, elu, kc);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t stove_dynloop_bwd_ws_bytes(int B, int N) { return stove_gnn_bwd_ws_bytes(B, N); }
+
+int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+                      const float* params, const float* z, const float* dz, const float* dzdyn, const float* dmean,
+                      const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd, float* dextra,
+                      float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var,
+                      float vel_std, float lat_std, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0 || Ts == 0) return (int)hipErrorInvalidValue;
+  if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && (extra == nullptr || dextra == nullptr)))
+    return (int)hipErrorInvalidValue;
+  int rc = gnn_lds_attr((const void*)dyn_loop_bwd_k);
+  if (rc) return rc;
+  LoopConst kc{pos_var, vel_std, lat_std};
+  const int nb = stove_gnn_blocks(B, N);
+  STOVE_LAUNCH(dyn_loop_bwd_k, dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, z1, zsup, zsstd, eps, extra, params, z,
+                     dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, (float*)ws, B, Ts, N, sin_dim, lim_enc, elu, kc);
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 255) / 256), dim3(256), 0, st, (const float*)ws, g_params, kGnnGrads, nb, 0);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_rollout_fwd(const float* z_last, const float* extra, const float* params, float* z_pred, float* zstd, float* pred,
+                      int B, int num, int A, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std,
+                      float lat_std, void* stream) {
+  if (B == 0 || num == 0) return 0;
+  if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && (extra == nullptr || A < 1))) return (int)hipErrorInvalidValue;
+  int rc = gnn_lds_attr((const void*)rollout_fwd_k);
+  if (rc) return rc;
+  LoopConst kc{pos_var, vel_std, lat_std};
+  STOVE_LAUNCH(rollout_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
+                     z_last, extra, params, z_pred, zstd, pred, B, num, A < 1 ? 1 : A, N, sin_dim, lim_enc, elu, kc);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- profiling hooks
+void stove_profile_enable(int on) {
+  std::lock_guard<std::mutex> g(prof_mu());
+  prof_on() = on != 0;
+}
+
+// Synchronises every recorded event pair, aggregates by kernel name and writes lines
+// "name\ttotal_ms\tcount\n" into buf (at most cap bytes); returns the number of bytes needed.
+size_t stove_profile_report(char* buf, size_t cap) {
+  std::lock_guard<std::mutex> g(prof_mu());
+  std::vector<std::pair<std::string, std::pair<double, long>>> agg;
+  for (auto& r : prof_recs()) {
+    (void)hipEventSynchronize(r.b);
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+    bool found = false;
+    for (auto& e : agg)
+      if (e.first == r.name) {
+        e.second.first += ms;
+        e.second.second += 1;
+        found = true;
+        break;
+      }
+    if (!found) agg.push_back({r.name, {ms, 1}});
+  }
+  prof_recs().clear();
+  std::string out;
+  for (auto& e : agg) out += e.first + "\t" + std::to_string(e.second.first) + "\t" + std::to_string(e.second.second) + "\n";
+  if (buf != nullptr && cap > 0) {
+    const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return out.size() + 1;
+}
+
+// ---------------------------------------------------------------- temporal object matching
+int stove_match_objects(const float* feat, long long* idx, float* perm, int B, int T, int N, int F, int mode, void* stream) {
+  if (B == 0 || T == 0) return 0;
+  if (N < 1 || N > kMatchN || F < 1 || F > kMatchF || mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
+  STOVE_LAUNCH(match_objects_k, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, feat, idx, perm, B, T, N, F, mode);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

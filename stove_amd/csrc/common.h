@@ -55,6 +55,56 @@ __device__ __forceinline__ float cover(float q, int n, float* dq) {
 
 }  // namespace stove
 
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py `roofline`) ----
+// Off by default (no overhead, no global state touched).  When enabled, every kernel launch is
+// bracketed by two events; stove_profile_report() synchronises them and aggregates by kernel.
+#include <mutex>
+#include <string>
+#include <vector>
+namespace stove {
+struct ProfRec {
+  const char* name;
+  hipEvent_t a, b;
+};
+inline bool& prof_on() {
+  static bool on = false;
+  return on;
+}
+inline std::vector<ProfRec>& prof_recs() {
+  static std::vector<ProfRec> v;
+  return v;
+}
+inline std::mutex& prof_mu() {
+  static std::mutex m;
+  return m;
+}
+struct ProfScope {
+  const char* name;
+  hipStream_t st;
+  hipEvent_t a, b;
+  bool live;
+  ProfScope(const char* n, hipStream_t s) : name(n), st(s), live(prof_on()) {
+    if (live) {
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, st);
+    }
+  }
+  ~ProfScope() {
+    if (live) {
+      (void)hipEventRecord(b, st);
+      std::lock_guard<std::mutex> g(prof_mu());
+      prof_recs().push_back({name, a, b});
+    }
+  }
+};
+}  // namespace stove
+#define STOVE_LAUNCH(kern, grid, block, lds, st, ...)                \
+  do {                                                               \
+    stove::ProfScope ps__(#kern, st);                                \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);     \
+  } while (0)
+
 #define STOVE_LAUNCH_CHECK()                          \
   do {                                                \
     hipError_t e__ = hipGetLastError();               \

@@ -1,0 +1,837 @@
+// Relational GNN dynamics core + the T-serial inference recursion, gfx950.
+//
+// Replaces the reference's
+//   Dynamics.forward / core      (model/video_prediction/dynamics.py:181-265)
+//   Dynamics.constrain_z_dyn     (dynamics.py:147-179)
+//   the loop body of stove_forward + Stove.full_state   (model/video_prediction/stove.py:696-713, 103-170)
+//   the loop body of Stove.rollout                      (stove.py:823-846)
+//
+// The recursion z[t] <- f(z[t-1], z_sup[t], eps[t]) is serial in t but independent across
+// sequences, so ONE persistent workgroup owns G = floor(16/N) sequences for the whole time loop:
+// no grid synchronisation, one launch for all T steps (the reference issues ~60 tiny ATen
+// launches per step).  All dense layers run on the f32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact f32, bit-for-bit an fma chain), 16 node rows (G*N padded) or
+// 16-row edge tiles (G*N*N) per MFMA tile; activations live in LDS, weights stream from L2.
+// The 65-wide edge input [s_i | s_j | d_ij] is never built: W0 [s_i|s_j|d] = W0a s_i + W0b s_j
+// + w_d d, so the first edge layer is one per-node GEMM (32 -> 256) plus an elementwise gather.
+// The backward recomputes the step's forward in LDS, then back-propagates; weight gradients
+// accumulate in MFMA accumulators (22 tiles of 16x16 per wave) across ALL time steps and are
+// written once per workgroup, then reduced in a fixed order (bitwise reproducible).
+#include "common.h"
+
+namespace stove {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- parameter image (floats) ----------------------------------------------------------------
+// P = [ W image | WT image | VEC ];  W: row-major [out][K];  WT: the transposes [K][out].
+constexpr int W_ENC = 0, W_S0 = 1024, W_S1 = 2048, W_EF = 3072, W_R1 = 11264, W_A1 = 13312, W_R2 = 15360,
+              W_F0 = 16384, W_F1 = 17408, W_F2 = 18432, W_O0 = 19456, W_O1 = 21504, W_END = 22528;
+constexpr int V_ENC = 0, V_S0 = 32, V_S1 = 64, V_BR0 = 96, V_WDR = 160, V_BA0 = 224, V_WDA = 288, V_BR1 = 352,
+              V_BA1 = 384, V_BR2 = 416, V_WA2 = 448, V_BA2 = 480, V_F0 = 512, V_F1 = 544, V_F2 = 576, V_O0 = 608,
+              V_O1 = 640, V_END = 672;
+constexpr int kGnnParams = 2 * W_END + V_END;      // forward image
+constexpr int kGnnGrads = W_END + V_END;           // gradient image (W layout + VEC)
+
+constexpr int LDN = 36, LDC = 68, LDP = 260, NEMAX = 80;
+
+struct GnnShape {
+  int N, G, NR, NE, ME;   // objects, sequences per workgroup, node rows, edge rows, edge tiles
+  int sin_dim, lim_enc, elu;
+};
+
+struct GnnLds {
+  float *SIN, *H1, *SD, *PRED, *F1, *F2, *O1, *RES, *DA, *DB, *DC;   // [16][LDN]
+  float *CAT, *DCAT;                                                  // [16][LDC]  CAT = [F3 | S]
+  float* P;                                                           // [16][LDP]
+  float *R1, *A1;                                                     // [NEMAX][LDC]
+  float *R2, *A2, *R3, *E32;                                          // [NEMAX][LDN]
+  float *ATT, *DIST, *DATT;                                           // [NEMAX]
+  float* DDIST;                                                       // [16][2]
+  float* PC;                                                          // [16][2] position carry of the time loop
+  float* DV;                                                          // [V_END] vector-gradient accumulators
+  float* X;                                                           // [16][40] epilogue scratch
+};
+constexpr int kGnnLdsFloats = 11 * 16 * LDN + 2 * 16 * LDC + 16 * LDP + 2 * NEMAX * LDC + 4 * NEMAX * LDN + 3 * NEMAX + 32 + 32 + V_END + 16 * 40;
+
+__device__ __forceinline__ GnnLds carve(float* base) {
+  GnnLds L;
+  float* p = base;
+  auto take = [&](int n) { float* q = p; p += n; return q; };
+  L.SIN = take(16 * LDN); L.H1 = take(16 * LDN); L.SD = take(16 * LDN); L.PRED = take(16 * LDN);
+  L.F1 = take(16 * LDN); L.F2 = take(16 * LDN); L.O1 = take(16 * LDN); L.RES = take(16 * LDN);
+  L.DA = take(16 * LDN); L.DB = take(16 * LDN); L.DC = take(16 * LDN);
+  L.CAT = take(16 * LDC); L.DCAT = take(16 * LDC);
+  L.P = take(16 * LDP);
+  L.R1 = take(NEMAX * LDC); L.A1 = take(NEMAX * LDC);
+  L.R2 = take(NEMAX * LDN); L.A2 = take(NEMAX * LDN); L.R3 = take(NEMAX * LDN); L.E32 = take(NEMAX * LDN);
+  L.ATT = take(NEMAX); L.DIST = take(NEMAX); L.DATT = take(NEMAX);
+  L.DDIST = take(32);
+  L.PC = take(32);
+  L.DV = take(V_END);
+  L.X = take(16 * 40);
+  return L;
+}
+
+__device__ __forceinline__ float act_phi(float x, int elu) { return x > 0.0f ? x : (elu ? expm1f(x) : 0.01f * x); }
+__device__ __forceinline__ float dphi_from_out(float y, int elu) { return y > 0.0f ? 1.0f : (elu ? y + 1.0f : 0.01f); }
+
+// ---- MFMA tiles --------------------------------------------------------------------------------
+// C(16x16) = A[16 x K] * B^T, A rows in LDS (lda floats), B rows = output columns, K contiguous.
+// The K order inside a 16-block is permuted identically on both operands (lane group kq feeds
+// k = 16 kb + 4 kq + m to MFMA m), so each lane reads one float4 per operand per 4 MFMAs.
+template <int K>
+__device__ __forceinline__ f32x4 tile_AB(const float* A, int lda, const float* __restrict__ B, int ldb) {
+  const int l = lane_id(), i = l & 15, kq = l >> 4;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int kb = 0; kb < K / 16; ++kb) {
+    const float4 a = *reinterpret_cast<const float4*>(A + i * lda + kb * 16 + 4 * kq);
+    const float4 b = *reinterpret_cast<const float4*>(B + i * ldb + kb * 16 + 4 * kq);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// acc[o][i] += sum_rows dO[row][o] * In[row][i]   (both operands row-strided in LDS)
+__device__ __forceinline__ f32x4 tile_dW(const float* dO, int ldo, const float* In, int ldi, int row_tiles, f32x4 acc) {
+  const int l = lane_id(), i = l & 15, kq = l >> 4;
+  for (int kb = 0; kb < row_tiles; ++kb) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int r = kb * 16 + 4 * kq + m;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dO[r * ldo + i], In[r * ldi + i], acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+// element (row, col) of an accumulator tile held by this lane: row = m0 + 4*(lane>>4) + reg, col = n0 + (lane&15)
+template <class F>
+__device__ __forceinline__ void tile_each(f32x4 acc, int m0, int n0, F f) {
+  const int l = lane_id();
+  const int col = n0 + (l & 15), r0 = m0 + 4 * (l >> 4);
+  f(r0, col, acc[0]);
+  f(r0 + 1, col, acc[1]);
+  f(r0 + 2, col, acc[2]);
+  f(r0 + 3, col, acc[3]);
+}
+
+// column sums of X[nrows][ncols] added into acc_vec[ncols]; threads t0 .. t0+ncols-1 do the work
+__device__ __forceinline__ void colsum_acc(float* acc_vec, const float* X, int ld, int nrows, int ncols, int t0) {
+  const int c = (int)threadIdx.x - t0;
+  if (c >= 0 && c < ncols) {
+    float s = 0.0f;
+    for (int r = 0; r < nrows; ++r) s += X[r * ld + c];
+    acc_vec[c] += s;
+  }
+}
+
+// =================================================================================================
+// forward of one GNN step; input L.SIN (rows < NR, cols < sin_dim, rest zero), output L.RES, L.PRED
+// =================================================================================================
+__device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh, const float* __restrict__ Wf, const float* __restrict__ V) {
+  const int wv = wave_id();
+  const int tid = threadIdx.x;
+  float* S = L.CAT + 32;   // S lives in CAT[:, 32:64]
+  // 1. state encoder; raw positions (first lim_enc dims) are kept for the distances (dynamics.py:250)
+  if (wv < 2) {
+    const f32x4 acc = tile_AB<32>(L.SIN, LDN, Wf + W_ENC + wv * 16 * 32, 32);
+    tile_each(acc, 0, wv * 16, [&](int r, int c, float v) {
+      S[r * LDC + c] = (c < sh.lim_enc) ? L.SIN[r * LDN + c] : v + V[V_ENC + c];
+    });
+  }
+  __syncthreads();
+  // 2. self-dynamics layer 0 and the factorised first edge layer (rel_i | rel_j | att_i | att_j)
+  for (int t = wv; t < 18; t += 4) {
+    if (t < 2) {
+      const f32x4 acc = tile_AB<32>(S, LDC, Wf + W_S0 + t * 16 * 32, 32);
+      tile_each(acc, 0, t * 16, [&](int r, int c, float v) { L.H1[r * LDN + c] = act_phi(v + V[V_S0 + c], sh.elu); });
+    } else {
+      const int n = t - 2;
+      const f32x4 acc = tile_AB<32>(S, LDC, Wf + W_EF + n * 16 * 32, 32);
+      tile_each(acc, 0, n * 16, [&](int r, int c, float v) { L.P[r * LDP + c] = v; });
+    }
+  }
+  __syncthreads();
+  // 3. edge pre-activations (gather) + self-dynamics layer 1
+  {
+    const int NN = sh.N * sh.N;
+    for (int idx = tid; idx < sh.ME * 16 * 64; idx += blockDim.x) {
+      const int e = idx >> 6, c = idx & 63;
+      float r1 = 0.0f, a1 = 0.0f;
+      if (e < sh.NE) {
+        const int g = e / NN, ij = e % NN, i = ij / sh.N, j = ij % sh.N;
+        const int ni = g * sh.N + i, nj = g * sh.N + j;
+        const float dx = S[ni * LDC] - S[nj * LDC], dy = S[ni * LDC + 1] - S[nj * LDC + 1];
+        const float d = dx * dx + dy * dy;
+        if (c == 0) L.DIST[e] = d;
+        r1 = act_phi(L.P[ni * LDP + c] + L.P[nj * LDP + 64 + c] + V[V_WDR + c] * d + V[V_BR0 + c], sh.elu);
+        a1 = act_phi(L.P[ni * LDP + 128 + c] + L.P[nj * LDP + 192 + c] + V[V_WDA + c] * d + V[V_BA0 + c], sh.elu);
+      }
+      L.R1[e * LDC + c] = r1;
+      L.A1[e * LDC + c] = a1;
+    }
+    if (wv < 2) {
+      const f32x4 acc = tile_AB<32>(L.H1, LDN, Wf + W_S1 + wv * 16 * 32, 32);
+      tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.SD[r * LDN + c] = v + V[V_S1 + c] + L.H1[r * LDN + c]; });
+    }
+  }
+  __syncthreads();
+  // 4. second edge layers (64 -> 32), relation and attention
+  for (int t = wv; t < sh.ME * 4; t += 4) {
+    const int m = t >> 2, n = (t >> 1) & 1, which = t & 1;
+    if (which == 0) {
+      const f32x4 acc = tile_AB<64>(L.R1 + m * 16 * LDC, LDC, Wf + W_R1 + n * 16 * 64, 64);
+      tile_each(acc, m * 16, n * 16, [&](int r, int c, float v) { L.R2[r * LDN + c] = act_phi(v + V[V_BR1 + c], sh.elu); });
+    } else {
+      const f32x4 acc = tile_AB<64>(L.A1 + m * 16 * LDC, LDC, Wf + W_A1 + n * 16 * 64, 64);
+      tile_each(acc, m * 16, n * 16, [&](int r, int c, float v) { L.A2[r * LDN + c] = act_phi(v + V[V_BA1 + c], sh.elu); });
+    }
+  }
+  __syncthreads();
+  // 5. third edge layers: relation 32 -> 32 (+skip), attention 32 -> 1 -> exp
+  if (tid < sh.ME * 16) {
+    float q = V[V_BA2];
+    for (int c = 0; c < 32; ++c) q = fmaf(L.A2[tid * LDN + c], V[V_WA2 + c], q);
+    L.ATT[tid] = (tid < sh.NE) ? __expf(q) : 0.0f;
+  }
+  for (int t = wv; t < sh.ME * 2; t += 4) {
+    const int m = t >> 1, n = t & 1;
+    const f32x4 acc = tile_AB<32>(L.R2 + m * 16 * LDN, LDN, Wf + W_R2 + n * 16 * 32, 32);
+    tile_each(acc, m * 16, n * 16, [&](int r, int c, float v) { L.R3[r * LDN + c] = v + V[V_BR2 + c] + L.R2[r * LDN + c]; });
+  }
+  __syncthreads();
+  // 6. masked, attention-weighted aggregation over the other objects
+  for (int idx = tid; idx < 16 * 32; idx += blockDim.x) {
+    const int r = idx >> 5, c = idx & 31;
+    float v = 0.0f;
+    if (r < sh.NR) {
+      const int g = r / sh.N, i = r % sh.N;
+      v = L.SD[r * LDN + c];
+      for (int j = 0; j < sh.N; ++j) {
+        if (j != i) {
+          const int e = (g * sh.N + i) * sh.N + j;
+          v = fmaf(L.R3[e * LDN + c], L.ATT[e], v);
+        }
+      }
+    }
+    L.PRED[r * LDN + c] = v;
+  }
+  __syncthreads();
+  // 7-9. affector MLP
+  if (wv < 2) {
+    const f32x4 acc = tile_AB<32>(L.PRED, LDN, Wf + W_F0 + wv * 16 * 32, 32);
+    tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.F1[r * LDN + c] = tanhf(v + V[V_F0 + c]); });
+  }
+  __syncthreads();
+  if (wv < 2) {
+    const f32x4 acc = tile_AB<32>(L.F1, LDN, Wf + W_F1 + wv * 16 * 32, 32);
+    tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.F2[r * LDN + c] = tanhf(v + V[V_F1 + c]) + L.F1[r * LDN + c]; });
+  }
+  __syncthreads();
+  if (wv < 2) {
+    const f32x4 acc = tile_AB<32>(L.F2, LDN, Wf + W_F2 + wv * 16 * 32, 32);
+    tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.CAT[r * LDC + c] = v + V[V_F2 + c]; });
+  }
+  __syncthreads();
+  // 10-11. output MLP on [affector | s]
+  if (wv < 2) {
+    const f32x4 acc = tile_AB<64>(L.CAT, LDC, Wf + W_O0 + wv * 16 * 64, 64);
+    tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.O1[r * LDN + c] = tanhf(v + V[V_O0 + c]); });
+  }
+  __syncthreads();
+  if (wv < 2) {
+    const f32x4 acc = tile_AB<32>(L.O1, LDN, Wf + W_O1 + wv * 16 * 32, 32);
+    tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.RES[r * LDN + c] = v + V[V_O1 + c] + L.O1[r * LDN + c]; });
+  }
+  __syncthreads();
+}
+
+// =================================================================================================
+// backward of one GNN step.  Requires the buffers left by gnn_forward of the same step.
+// in : L.DA = dL/dRES (rows >= NR zero);  dpred_up (global, may be null) = dL/dPRED from outside
+// out: L.DA = dL/dSIN;  weight gradients accumulate into acc[22] (MFMA tiles) and L.DV.
+// =================================================================================================
+template <int OUT, int IN, int SLOT0>
+__device__ __forceinline__ void dW_layer(f32x4* acc, const float* dO, int ldo, const float* In, int ldi, int row_tiles, int wv) {
+  constexpr int NT = (OUT / 16) * (IN / 16);
+  static_assert(NT % 4 == 0, "tiles per layer must be a multiple of the wave count");
+#pragma unroll
+  for (int k = 0; k < NT / 4; ++k) {
+    const int t = wv + 4 * k;
+    const int ot = t / (IN / 16), it = t % (IN / 16);
+    acc[SLOT0 + k] = tile_dW(dO + ot * 16, ldo, In + it * 16, ldi, row_tiles, acc[SLOT0 + k]);
+  }
+}
+template <int OUT, int IN, int SLOT0>
+__device__ __forceinline__ void dW_store(const f32x4* acc, float* __restrict__ img, int wv) {
+  constexpr int NT = (OUT / 16) * (IN / 16);
+#pragma unroll
+  for (int k = 0; k < NT / 4; ++k) {
+    const int t = wv + 4 * k;
+    const int ot = t / (IN / 16), it = t % (IN / 16);
+    tile_each(acc[SLOT0 + k], ot * 16, it * 16, [&](int r, int c, float v) { img[r * IN + c] = v; });
+  }
+}
+constexpr int SL_ENC = 0, SL_S0 = 1, SL_S1 = 2, SL_EF = 3, SL_R1 = 11, SL_A1 = 13, SL_R2 = 15, SL_F0 = 16, SL_F1 = 17,
+              SL_F2 = 18, SL_O0 = 19, SL_O1 = 21, SL_END = 22;
+
+__device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh, const float* __restrict__ WT, const float* __restrict__ V,
+                             f32x4* acc, const float* dpred_up /* global or null */, size_t dpred_seq_stride) {
+  const int wv = wave_id();
+  const int tid = threadIdx.x;
+  float* S = L.CAT + 32;
+  const int NN = sh.N * sh.N;
+  // b1. out.1:  RES = O1 W^T + b + O1
+  dW_layer<32, 32, SL_O1>(acc, L.DA, LDN, L.O1, LDN, 1, wv);
+  colsum_acc(L.DV + V_O1, L.DA, LDN, 16, 32, 128);
+  if (wv < 2) {
+    const f32x4 t = tile_AB<32>(L.DA, LDN, WT + W_O1 + wv * 16 * 32, 32);
+    tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
+      const float o = L.O1[r * LDN + c];
+      L.DB[r * LDN + c] = (v + L.DA[r * LDN + c]) * (1.0f - o * o);       // d pre-tanh of out.0
+    });
+  }
+  __syncthreads();
+  // b2. out.0 on CAT = [F3 | S]
+  dW_layer<32, 64, SL_O0>(acc, L.DB, LDN, L.CAT, LDC, 1, wv);
+  colsum_acc(L.DV + V_O0, L.DB, LDN, 16, 32, 128);
+  {
+    const f32x4 t = tile_AB<32>(L.DB, LDN, WT + W_O0 + wv * 16 * 32, 32);
+    tile_each(t, 0, wv * 16, [&](int r, int c, float v) { L.DCAT[r * LDC + c] = v; });
+  }
+  __syncthreads();
+  // b3. affector.2:  F3 = F2 W^T + b      (dF3 = DCAT[:, :32])
+  dW_layer<32, 32, SL_F2>(acc, L.DCAT, LDC, L.F2, LDN, 1, wv);
+  colsum_acc(L.DV + V_F2, L.DCAT, LDC, 16, 32, 128);
+  if (wv < 2) {
+    const f32x4 t = tile_AB<32>(L.DCAT, LDC, WT + W_F2 + wv * 16 * 32, 32);
+    tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
+      const float th = L.F2[r * LDN + c] - L.F1[r * LDN + c];              // tanh(u) of affector.1
+      L.DA[r * LDN + c] = v;                                               // dF2 (skip path)
+      L.DC[r * LDN + c] = v * (1.0f - th * th);                            // du
+    });
+  }
+  __syncthreads();
+  // b4. affector.1:  F2 = tanh(F1 W^T + b) + F1
+  dW_layer<32, 32, SL_F1>(acc, L.DC, LDN, L.F1, LDN, 1, wv);
+  colsum_acc(L.DV + V_F1, L.DC, LDN, 16, 32, 128);
+  if (wv < 2) {
+    const f32x4 t = tile_AB<32>(L.DC, LDN, WT + W_F1 + wv * 16 * 32, 32);
+    tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
+      const float f1 = L.F1[r * LDN + c];
+      L.DB[r * LDN + c] = (v + L.DA[r * LDN + c]) * (1.0f - f1 * f1);      // d pre-tanh of affector.0
+    });
+  }
+  __syncthreads();
+  // b5. affector.0:  F1 = tanh(PRED W^T + b)
+  dW_layer<32, 32, SL_F0>(acc, L.DB, LDN, L.PRED, LDN, 1, wv);
+  colsum_acc(L.DV + V_F0, L.DB, LDN, 16, 32, 128);
+  if (wv < 2) {
+    const f32x4 t = tile_AB<32>(L.DB, LDN, WT + W_F0 + wv * 16 * 32, 32);
+    tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
+      float up = 0.0f;
+      if (dpred_up != nullptr && r < sh.NR) up = dpred_up[(size_t)(r / sh.N) * dpred_seq_stride + (r % sh.N) * 32 + c];
+      L.DC[r * LDN + c] = v + up;                                          // dPRED = dSD
+    });
+  }
+  __syncthreads();
+  // b6a. d attention (per edge)
+  if (tid < sh.ME * 16) {
+    float dq = 0.0f;
+    if (tid < sh.NE) {
+      const int g = tid / NN, ij = tid % NN, i = ij / sh.N, j = ij % sh.N;
+      if (i != j) {
+        const int ni = g * sh.N + i;
+        float s = 0.0f;
+        for (int c = 0; c < 32; ++c) s = fmaf(L.DC[ni * LDN + c], L.R3[tid * LDN + c], s);
+        dq = s * L.ATT[tid];                                               // att = exp(q)
+      }
+    }
+    L.DATT[tid] = dq;
+  }
+  __syncthreads();
+  // b6b. dR3 in place; attention output layer grads
+  for (int idx = tid; idx < sh.ME * 16 * 32; idx += blockDim.x) {
+    const int e = idx >> 5, c = idx & 31;
+    float v = 0.0f;
+    if (e < sh.NE) {
+      const int g = e / NN, ij = e % NN, i = ij / sh.N, j = ij % sh.N;
+      if (i != j) v = L.DC[(g * sh.N + i) * LDN + c] * L.ATT[e];
+    }
+    L.R3[e * LDN + c] = v;
+  }
+  if (tid < 32) {
+    float s = 0.0f;
+    for (int e = 0; e < sh.NE; ++e) s = fmaf(L.DATT[e], L.A2[e * LDN + tid], s);
+    L.DV[V_WA2 + tid] += s;
+  } else if (tid == 32) {
+    float s = 0.0f;
+    for (int e = 0; e < sh.NE; ++e) s += L.DATT[e];
+    L.DV[V_BA2] += s;
+  }
+  __syncthreads();
+  // b7. rel.2:  R3 = R2 W^T + b + R2 ;  attention pre-activation grads in place in A2
+  dW_layer<32, 32, SL_R2>(acc, L.R3, LDN, L.R2, LDN, sh.ME, wv);
+  colsum_acc(L.DV + V_BR2, L.R3, LDN, sh.NE, 32, 128);
+  for (int t = wv; t < sh.ME * 2; t += 4) {
+    const int m = t >> 1, n = t & 1;
+    const f32x4 a = tile_AB<32>(L.R3 + m * 16 * LDN, LDN, WT + W_R2 + n * 16 * 32, 32);
+    tile_each(a, m * 16, n * 16, [&](int r, int c, float v) {
+      L.E32[r * LDN + c] = (v + L.R3[r * LDN + c]) * dphi_from_out(L.R2[r * LDN + c], sh.elu);
+    });
+  }
+  for (int idx = tid; idx < sh.ME * 16 * 32; idx += blockDim.x) {
+    const int e = idx >> 5, c = idx & 31;
+    const float y = L.A2[e * LDN + c];
+    L.A2[e * LDN + c] = L.DATT[e] * V[V_WA2 + c] * dphi_from_out(y, sh.elu);
+  }
+  __syncthreads();
+  // b8. rel.1 / att.1 weight grads (inputs R1 / A1 still intact)
+  dW_layer<32, 64, SL_R1>(acc, L.E32, LDN, L.R1, LDC, sh.ME, wv);
+  dW_layer<32, 64, SL_A1>(acc, L.A2, LDN, L.A1, LDC, sh.ME, wv);
+  colsum_acc(L.DV + V_BR1, L.E32, LDN, sh.NE, 32, 0);
+  colsum_acc(L.DV + V_BA1, L.A2, LDN, sh.NE, 32, 32);
+  __syncthreads();
+  // b9. rel.1 / att.1 data grads, multiplied by phi'(first-layer output), in place in R1 / A1
+  for (int t = wv; t < sh.ME * 8; t += 4) {
+    const int m = t >> 3, n = (t >> 1) & 3, which = t & 1;
+    if (which == 0) {
+      const f32x4 a = tile_AB<32>(L.E32 + m * 16 * LDN, LDN, WT + W_R1 + n * 16 * 32, 32);
+      tile_each(a, m * 16, n * 16, [&](int r, int c, float v) { L.R1[r * LDC + c] = v * dphi_from_out(L.R1[r * LDC + c], sh.elu); });
+    } else {
+      const f32x4 a = tile_AB<32>(L.A2 + m * 16 * LDN, LDN, WT + W_A1 + n * 16 * 32, 32);
+      tile_each(a, m * 16, n * 16, [&](int r, int c, float v) { L.A1[r * LDC + c] = v * dphi_from_out(L.A1[r * LDC + c], sh.elu); });
+    }
+  }
+  __syncthreads();
+  // b10. first edge layer: scatter (as a gather) into dP, vector grads, d distance
+  for (int idx = tid; idx < 16 * 256; idx += blockDim.x) {
+    const int r = idx >> 8, c = idx & 255;
+    float v = 0.0f;
+    if (r < sh.NR) {
+      const int g = r / sh.N, i = r % sh.N;
+      const int blk = c >> 6, cc = c & 63;
+      const float* src = (blk < 2) ? L.R1 : L.A1;
+      for (int j = 0; j < sh.N; ++j) {
+        const int e = (blk & 1) ? (g * sh.N + j) * sh.N + i : (g * sh.N + i) * sh.N + j;   // as s_j : as s_i
+        v += src[e * LDC + cc];
+      }
+    }
+    L.P[r * LDP + c] = v;
+  }
+  if (tid < 128) {
+    const int cc = tid & 63;
+    const float* src = (tid < 64) ? L.R1 : L.A1;
+    float sb = 0.0f, sd = 0.0f;
+    for (int e = 0; e < sh.NE; ++e) {
+      const float v = src[e * LDC + cc];
+      sb += v;
+      sd = fmaf(v, L.DIST[e], sd);
+    }
+    L.DV[(tid < 64 ? V_BR0 : V_BA0) + cc] += sb;
+    L.DV[(tid < 64 ? V_WDR : V_WDA) + cc] += sd;
+  } else if (tid - 128 < sh.ME * 16) {
+    const int e = tid - 128;
+    float s = 0.0f;
+    if (e < sh.NE)
+      for (int c = 0; c < 64; ++c) s = fmaf(L.R1[e * LDC + c], V[V_WDR + c], fmaf(L.A1[e * LDC + c], V[V_WDA + c], s));
+    L.DATT[e] = s;                                                          // dL/d dist_e
+  }
+  __syncthreads();
+  // b11. edge-first + self.1
+  dW_layer<256, 32, SL_EF>(acc, L.P, LDP, S, LDC, 1, wv);
+  dW_layer<32, 32, SL_S1>(acc, L.DC, LDN, L.H1, LDN, 1, wv);
+  colsum_acc(L.DV + V_S1, L.DC, LDN, 16, 32, 128);
+  if (wv < 2) {
+    const f32x4 t = tile_AB<32>(L.DC, LDN, WT + W_S1 + wv * 16 * 32, 32);
+    tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
+      L.DB[r * LDN + c] = (v + L.DC[r * LDN + c]) * dphi_from_out(L.H1[r * LDN + c], sh.elu);   // d pre-act of self.0
+    });
+  } else {
+    const int n = wv - 2;
+    const f32x4 t = tile_AB<256>(L.P, LDP, WT + W_EF + n * 16 * 256, 256);
+    tile_each(t, 0, n * 16, [&](int r, int c, float v) { L.DA[r * LDN + c] = v; });           // dS from the edge layers
+  }
+  if (tid < 32) {
+    const int r = tid >> 1, ax = tid & 1;
+    float s = 0.0f;
+    if (r < sh.NR) {
+      const int g = r / sh.N, i = r % sh.N;
+      for (int j = 0; j < sh.N; ++j) {
+        const int nj = g * sh.N + j;
+        const float diff = S[r * LDC + ax] - S[nj * LDC + ax];
+        s += 2.0f * diff * (L.DATT[(g * sh.N + i) * sh.N + j] + L.DATT[(g * sh.N + j) * sh.N + i]);
+      }
+    }
+    L.DDIST[tid] = s;
+  }
+  __syncthreads();
+  // b12. self.0 ; total dS ; split into the encoder output part and the pass-through part
+  dW_layer<32, 32, SL_S0>(acc, L.DB, LDN, S, LDC, 1, wv);
+  colsum_acc(L.DV + V_S0, L.DB, LDN, 16, 32, 128);
+  if (wv < 2) {
+    const f32x4 t = tile_AB<32>(L.DB, LDN, WT + W_S0 + wv * 16 * 32, 32);
+    tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
+      float tot = v + L.DA[r * LDN + c] + L.DCAT[r * LDC + 32 + c];
+      if (c < 2) tot += L.DDIST[r * 2 + c];
+      const bool raw = c < sh.lim_enc;
+      L.DC[r * LDN + c] = raw ? 0.0f : tot;      // d encoder output
+      L.F1[r * LDN + c] = raw ? tot : 0.0f;      // straight to SIN (F1 is dead by now)
+    });
+  }
+  __syncthreads();
+  // b13. encoder
+  dW_layer<32, 32, SL_ENC>(acc, L.DC, LDN, L.SIN, LDN, 1, wv);
+  colsum_acc(L.DV + V_ENC, L.DC, LDN, 16, 32, 128);
+  if (wv < 2) {
+    const f32x4 t = tile_AB<32>(L.DC, LDN, WT + W_ENC + wv * 16 * 32, 32);
+    tile_each(t, 0, wv * 16, [&](int r, int c, float v) { L.DA[r * LDN + c] = v + L.F1[r * LDN + c]; });
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void gnn_store_grads(const GnnLds& L, const f32x4* acc, float* __restrict__ gout) {
+  const int wv = wave_id();
+  dW_store<32, 32, SL_ENC>(acc, gout + W_ENC, wv);
+  dW_store<32, 32, SL_S0>(acc, gout + W_S0, wv);
+  dW_store<32, 32, SL_S1>(acc, gout + W_S1, wv);
+  dW_store<256, 32, SL_EF>(acc, gout + W_EF, wv);
+  dW_store<32, 64, SL_R1>(acc, gout + W_R1, wv);
+  dW_store<32, 64, SL_A1>(acc, gout + W_A1, wv);
+  dW_store<32, 32, SL_R2>(acc, gout + W_R2, wv);
+  dW_store<32, 32, SL_F0>(acc, gout + W_F0, wv);
+  dW_store<32, 32, SL_F1>(acc, gout + W_F1, wv);
+  dW_store<32, 32, SL_F2>(acc, gout + W_F2, wv);
+  dW_store<32, 64, SL_O0>(acc, gout + W_O0, wv);
+  dW_store<32, 32, SL_O1>(acc, gout + W_O1, wv);
+  __syncthreads();
+  for (int i = threadIdx.x; i < V_END; i += blockDim.x) gout[W_END + i] = L.DV[i];
+}
+
+// sequences per workgroup: node rows <= 16 and edge rows <= NEMAX
+__host__ __device__ inline int gnn_group(int N) {
+  const int a = 16 / N, b = NEMAX / (N * N);
+  const int g = a < b ? a : b;
+  return g < 1 ? 1 : g;
+}
+
+__device__ __forceinline__ GnnShape make_shape(int N, int b0, int B, int sin_dim, int lim_enc, int elu) {
+  GnnShape sh;
+  sh.N = N;
+  const int gmax = gnn_group(N);
+  sh.G = (B - b0) < gmax ? (B - b0) : gmax;
+  sh.NR = sh.G * N;
+  sh.NE = sh.G * N * N;
+  sh.ME = (sh.NE + 15) / 16;
+  sh.sin_dim = sin_dim;
+  sh.lim_enc = lim_enc;
+  sh.elu = elu;
+  return sh;
+}
+
+__device__ __forceinline__ void lds_zero(float* base, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) base[i] = 0.0f;
+}
+
+// =================================================================================================
+// single step: Dynamics.forward(s) -> result (B,N,32), dynamic_pred (B,N,32)
+// =================================================================================================
+__global__ __launch_bounds__(256) void gnn_step_fwd_k(const float* __restrict__ sin, const float* __restrict__ P,
+                                                      float* __restrict__ res, float* __restrict__ pred,
+                                                      int B, int N, int sin_dim, int lim_enc, int elu) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GnnLds L = carve(lds);
+  const int b0 = blockIdx.x * gnn_group(N);
+  const GnnShape sh = make_shape(N, b0, B, sin_dim, lim_enc, elu);
+  lds_zero(lds, kGnnLdsFloats);
+  __syncthreads();
+  for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
+    const int r = i / sin_dim, c = i % sin_dim;
+    L.SIN[r * LDN + c] = sin[((size_t)b0 * N + r) * sin_dim + c];
+  }
+  __syncthreads();
+  gnn_forward(L, sh, P, P + 2 * W_END);
+  for (int i = threadIdx.x; i < sh.NR * 32; i += blockDim.x) {
+    const int r = i >> 5, c = i & 31;
+    res[((size_t)b0 * N + r) * 32 + c] = L.RES[r * LDN + c];
+    if (pred != nullptr) pred[((size_t)b0 * N + r) * 32 + c] = L.PRED[r * LDN + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void gnn_step_bwd_k(const float* __restrict__ sin, const float* __restrict__ P,
+                                                      const float* __restrict__ dres, const float* __restrict__ dpred,
+                                                      float* __restrict__ dsin, float* __restrict__ gpart,
+                                                      int B, int N, int sin_dim, int lim_enc, int elu) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GnnLds L = carve(lds);
+  const int b0 = blockIdx.x * gnn_group(N);
+  const GnnShape sh = make_shape(N, b0, B, sin_dim, lim_enc, elu);
+  lds_zero(lds, kGnnLdsFloats);
+  __syncthreads();
+  for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
+    const int r = i / sin_dim, c = i % sin_dim;
+    L.SIN[r * LDN + c] = sin[((size_t)b0 * N + r) * sin_dim + c];
+  }
+  __syncthreads();
+  gnn_forward(L, sh, P, P + 2 * W_END);
+  for (int i = threadIdx.x; i < 16 * 32; i += blockDim.x) {
+    const int r = i >> 5, c = i & 31;
+    L.DA[r * LDN + c] = (r < sh.NR) ? dres[((size_t)b0 * N + r) * 32 + c] : 0.0f;
+  }
+  __syncthreads();
+  f32x4 acc[SL_END];
+#pragma unroll
+  for (int k = 0; k < SL_END; ++k) acc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  gnn_backward(L, sh, P + W_END, P + 2 * W_END, acc, dpred != nullptr ? dpred + (size_t)b0 * N * 32 : nullptr, (size_t)N * 32);
+  for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
+    const int r = i / sin_dim, c = i % sin_dim;
+    dsin[((size_t)b0 * N + r) * sin_dim + c] = L.DA[r * LDN + c];
+  }
+  gnn_store_grads(L, acc, gpart + (size_t)blockIdx.x * kGnnGrads);
+}
+
+// =================================================================================================
+// inference recursion (stove.py:696-713 + full_state :103-170 + constrain_z_dyn)
+//   z1      (B,N,18)      state at t = skip-1, layout [sx, sy/sx, x, y, vx, vy, latent 12]
+//   zsup    (B,Ts,N,6)    SuPAIR means   [sx, sy/sx, x, y, vx, vy]  for t = skip .. T-1 (Ts = T - skip)
+//   zsstd   (B,Ts,N,6)    SuPAIR stds
+//   eps     (B,Ts,N,18)   standard-normal draws
+//   extra   (B,Ts,N,E)    per-step extra core inputs (action embedding, appearance) of step t-1, E = sin_dim-16
+// outputs, all (B,Ts,N,.): z 18, zdyn 16, zdstd 16, mean 18, std 18, pred 32 (optional)
+// =================================================================================================
+struct LoopConst {
+  float pos_var, vel_std, lat_std;
+};
+
+__device__ __forceinline__ float std_scale(int d, const LoopConst& k) { return d < 2 ? k.pos_var : (d < 4 ? k.vel_std : k.lat_std); }
+
+// per (row, d<16) forward epilogue; writes z/zdyn/... and the next SIN
+__device__ __forceinline__ void loop_epilogue_fwd(const GnnLds& L, const GnnShape& sh, const LoopConst& kc, int b0, int Ts, int ts,
+                                                  const float* __restrict__ zsup, const float* __restrict__ zsstd,
+                                                  const float* __restrict__ eps, float* __restrict__ z,
+                                                  float* __restrict__ zdyn, float* __restrict__ zdstd,
+                                                  float* __restrict__ mean, float* __restrict__ stdv, float* Znew) {
+  for (int idx = threadIdx.x; idx < sh.NR * 18; idx += blockDim.x) {
+    const int r = idx / 18, q = idx % 18;                 // q: dim of the 18-vector
+    const int b = b0 + r / sh.N, n = r % sh.N;
+    const size_t o = ((size_t)b * Ts + ts) * sh.N + n;
+    float mu, sg;
+    if (q < 2) {
+      mu = zsup[o * 6 + q];
+      sg = zsstd[o * 6 + q];
+    } else {
+      const int d = q - 2;
+      const float m = 2.0f * sigmoidf_(L.RES[r * LDN + d]) - 1.0f;
+      const float sd = std_scale(d, kc) * sigmoidf_(L.RES[r * LDN + 16 + d]);
+      const float zd = m + (d < 2 ? L.SIN[r * LDN + d] : 0.0f);
+      zdyn[o * 16 + d] = zd;
+      zdstd[o * 16 + d] = sd;
+      if (d < 4) {
+        const float ms = zsup[o * 6 + 2 + d], ss = zsstd[o * 6 + 2 + d];
+        const float sd2 = sd * sd, ss2 = ss * ss, D = sd2 + ss2;
+        mu = (ss2 * zd + sd2 * ms) / D;
+        sg = sd * ss / sqrtf(D);
+      } else {
+        mu = zd;
+        sg = sd;
+      }
+    }
+    const float zv = fmaf(sg, eps[o * 18 + q], mu);
+    z[o * 18 + q] = zv;
+    mean[o * 18 + q] = mu;
+    stdv[o * 18 + q] = sg;
+    Znew[r * 20 + q] = zv;
+  }
+}
+
+__global__ __launch_bounds__(256) void dyn_loop_fwd_k(
+    const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
+    const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
+    float* __restrict__ z, float* __restrict__ zdyn, float* __restrict__ zdstd, float* __restrict__ mean,
+    float* __restrict__ stdv, float* __restrict__ pred,
+    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GnnLds L = carve(lds);
+  const int b0 = blockIdx.x * gnn_group(N);
+  const GnnShape sh = make_shape(N, b0, B, sin_dim, lim_enc, elu);
+  const int E = sin_dim - 16;
+  lds_zero(lds, kGnnLdsFloats);
+  __syncthreads();
+  float* Z = L.X;     // [16][20] current state z[t-1]
+  for (int i = threadIdx.x; i < sh.NR * 18; i += blockDim.x) Z[(i / 18) * 20 + i % 18] = z1[(size_t)b0 * N * 18 + i];
+  __syncthreads();
+  for (int ts = 0; ts < Ts; ++ts) {
+    for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
+      const int r = i / sin_dim, c = i % sin_dim;
+      float v;
+      if (c < 16) v = Z[r * 20 + 2 + c];
+      else v = extra[(((size_t)(b0 + r / N) * Ts + ts) * N + r % N) * E + (c - 16)];
+      L.SIN[r * LDN + c] = v;
+    }
+    __syncthreads();
+    gnn_forward(L, sh, P, P + 2 * W_END);
+    loop_epilogue_fwd(L, sh, kc, b0, Ts, ts, zsup, zsstd, eps, z, zdyn, zdstd, mean, stdv, Z);
+    if (pred != nullptr) {
+      for (int i = threadIdx.x; i < sh.NR * 32; i += blockDim.x) {
+        const int r = i >> 5, c = i & 31;
+        pred[(((size_t)(b0 + r / N) * Ts + ts) * N + r % N) * 32 + c] = L.PRED[r * LDN + c];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// backward of the recursion.  Upstream gradients (any may be null): dz, dzdyn, dmean, dstd (B,Ts,N,.), dpred.
+// Outputs: dz1 (B,N,18), dzsup, dzsstd (B,Ts,N,6), dextra (B,Ts,N,E), gpart[block][kGnnGrads].
+__global__ __launch_bounds__(256) void dyn_loop_bwd_k(
+    const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
+    const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
+    const float* __restrict__ z,
+    const float* __restrict__ dz, const float* __restrict__ dzdyn, const float* __restrict__ dmean,
+    const float* __restrict__ dstd, const float* __restrict__ dpred,
+    float* __restrict__ dz1, float* __restrict__ dzsup, float* __restrict__ dzsstd, float* __restrict__ dextra,
+    float* __restrict__ gpart,
+    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GnnLds L = carve(lds);
+  const int b0 = blockIdx.x * gnn_group(N);
+  const GnnShape sh = make_shape(N, b0, B, sin_dim, lim_enc, elu);
+  const int E = sin_dim - 16;
+  lds_zero(lds, kGnnLdsFloats);
+  f32x4 acc[SL_END];
+#pragma unroll
+  for (int k = 0; k < SL_END; ++k) acc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float* CAR = L.X;   // [16][20] gradient carried into z[t] from step t+1
+  __syncthreads();
+  for (int ts = Ts - 1; ts >= 0; --ts) {
+    // input state z[t-1]
+    for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
+      const int r = i / sin_dim, c = i % sin_dim;
+      const int b = b0 + r / N, n = r % N;
+      float v;
+      if (c < 16) v = (ts == 0) ? z1[((size_t)b * N + n) * 18 + 2 + c] : z[(((size_t)b * Ts + ts - 1) * N + n) * 18 + 2 + c];
+      else v = extra[(((size_t)b * Ts + ts) * N + n) * E + (c - 16)];
+      L.SIN[r * LDN + c] = v;
+    }
+    __syncthreads();
+    gnn_forward(L, sh, P, P + 2 * W_END);
+    // epilogue backward: per (row, d < 16) -> dRES in L.DA, SuPAIR grads, position carry in L.DDIST
+    for (int idx = threadIdx.x; idx < 16 * 18; idx += blockDim.x) {
+      const int r = idx / 18, q = idx % 18;
+      if (r >= sh.NR) {
+        if (q >= 2) {
+          L.DA[r * LDN + q - 2] = 0.0f;
+          L.DA[r * LDN + 16 + q - 2] = 0.0f;
+        }
+        continue;
+      }
+      const int b = b0 + r / N, n = r % N;
+      const size_t o = ((size_t)b * Ts + ts) * N + n;
+      const float ep = eps[o * 18 + q];
+      const float gz = (dz != nullptr ? dz[o * 18 + q] : 0.0f) + CAR[r * 20 + q];
+      const float gmu = gz + (dmean != nullptr ? dmean[o * 18 + q] : 0.0f);
+      const float gsg = gz * ep + (dstd != nullptr ? dstd[o * 18 + q] : 0.0f);
+      if (q < 2) {
+        dzsup[o * 6 + q] = gmu;
+        dzsstd[o * 6 + q] = gsg;
+        continue;
+      }
+      const int d = q - 2;
+      const float kd = std_scale(d, kc);
+      const float m = 2.0f * sigmoidf_(L.RES[r * LDN + d]) - 1.0f;
+      const float sd = kd * sigmoidf_(L.RES[r * LDN + 16 + d]);
+      const float zd = m + (d < 2 ? L.SIN[r * LDN + d] : 0.0f);
+      float gzd = (dzdyn != nullptr) ? dzdyn[o * 16 + d] : 0.0f;
+      float gsd;
+      if (d < 4) {
+        const float ms = zsup[o * 6 + 2 + d], ss = zsstd[o * 6 + 2 + d];
+        const float sd2 = sd * sd, ss2 = ss * ss, D = sd2 + ss2, iD = 1.0f / D;
+        const float mu = (ss2 * zd + sd2 * ms) * iD;
+        const float rD = rsqrtf(D);
+        gzd += gmu * ss2 * iD;
+        gsd = gmu * (ms - mu) * iD * 2.0f * sd + gsg * ss * ss2 * iD * rD;
+        dzsup[o * 6 + 2 + d] = gmu * sd2 * iD;
+        dzsstd[o * 6 + 2 + d] = gmu * (zd - mu) * iD * 2.0f * ss + gsg * sd * sd2 * iD * rD;
+      } else {
+        gzd += gmu;
+        gsd = gsg;
+      }
+      if (d < 2) L.PC[r * 2 + d] = gzd;                                    // z_dyn position = previous position + delta
+      L.DA[r * LDN + d] = gzd * 0.5f * (1.0f - m * m);                      // m = 2 sigmoid - 1
+      L.DA[r * LDN + 16 + d] = gsd * sd * (1.0f - sd / kd);                 // sd = k sigmoid
+    }
+    __syncthreads();
+    gnn_backward(L, sh, P + W_END, P + 2 * W_END, acc,
+                 dpred != nullptr ? dpred + ((size_t)b0 * Ts + ts) * N * 32 : nullptr, (size_t)Ts * N * 32);
+    // new carry into z[t-1]
+    for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
+      const int r = i / sin_dim, c = i % sin_dim;
+      const int b = b0 + r / N, n = r % N;
+      const float g = L.DA[r * LDN + c];
+      if (c < 16) CAR[r * 20 + 2 + c] = g + (c < 2 ? L.PC[r * 2 + c] : 0.0f);
+      else dextra[(((size_t)b * Ts + ts) * N + n) * E + (c - 16)] = g;
+    }
+    if (threadIdx.x < sh.NR * 2) CAR[(threadIdx.x >> 1) * 20 + (threadIdx.x & 1)] = 0.0f;
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < sh.NR * 18; i += blockDim.x) dz1[(size_t)b0 * N * 18 + i] = CAR[(i / 18) * 20 + i % 18];
+  gnn_store_grads(L, acc, gpart + (size_t)blockIdx.x * kGnnGrads);
+}
+
+// =================================================================================================
+// generative rollout (stove.py:823-846), mean prediction, forward only
+//   z_last (B,N,18) [sx, sy, x, y, vx, vy, latent]; extra (B,A,N,E) indexed (t-1) % A (A>=1) or null
+//   z_pred (B,num,N,18); zstd (B,num,N,16) optional; pred (B,num,N,32) optional
+// =================================================================================================
+__global__ __launch_bounds__(256) void rollout_fwd_k(const float* __restrict__ z_last, const float* __restrict__ extra,
+                                                     const float* __restrict__ P, float* __restrict__ z_pred,
+                                                     float* __restrict__ zstd, float* __restrict__ pred,
+                                                     int B, int num, int A, int N, int sin_dim, int lim_enc, int elu, LoopConst kc) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GnnLds L = carve(lds);
+  const int b0 = blockIdx.x * gnn_group(N);
+  const GnnShape sh = make_shape(N, b0, B, sin_dim, lim_enc, elu);
+  const int E = sin_dim - 16;
+  lds_zero(lds, kGnnLdsFloats);
+  __syncthreads();
+  float* Z = L.X;
+  for (int i = threadIdx.x; i < sh.NR * 18; i += blockDim.x) Z[(i / 18) * 20 + i % 18] = z_last[(size_t)b0 * N * 18 + i];
+  __syncthreads();
+  for (int t = 0; t < num; ++t) {
+    for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
+      const int r = i / sin_dim, c = i % sin_dim;
+      float v;
+      if (c < 16) v = Z[r * 20 + 2 + c];
+      else v = extra[(((size_t)(b0 + r / N) * A + (t % A)) * N + r % N) * E + (c - 16)];
+      L.SIN[r * LDN + c] = v;
+    }
+    __syncthreads();
+    gnn_forward(L, sh, P, P + 2 * W_END);
+    for (int idx = threadIdx.x; idx < sh.NR * 18; idx += blockDim.x) {
+      const int r = idx / 18, q = idx % 18;
+      const size_t o = ((size_t)(b0 + r / N) * num + t) * N + r % N;
+      float v;
+      if (q < 2) {
+        v = Z[r * 20 + q];                                  // scale stays constant
+      } else {
+        const int d = q - 2;
+        v = 2.0f * sigmoidf_(L.RES[r * LDN + d]) - 1.0f + (d < 2 ? L.SIN[r * LDN + d] : 0.0f);
+        if (zstd != nullptr) zstd[o * 16 + d] = std_scale(d, kc) * sigmoidf_(L.RES[r * LDN + 16 + d]);
+      }
+      z_pred[o * 18 + q] = v;
+      Z[r * 20 + q] = v;
+    }
+    if (pred != nullptr) {
+      for (int i = threadIdx.x; i < sh.NR * 32; i += blockDim.x) {
+        const int r = i >> 5, c = i & 31;
+        pred[(((size_t)(b0 + r / N) * num + t) * N + r % N) * 32 + c] = L.PRED[r * LDN + c];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace stove

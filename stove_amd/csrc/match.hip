@@ -1,0 +1,118 @@
+// Temporal object matching (index-only, no gradients), gfx950.
+//
+// Replaces the T-serial loops of Stove._3_only_match_objects (model/video_prediction/stove.py:200-329)
+// and Stove._greedy_match_objects (stove.py:432-514): ~15 tiny ATen launches and one host
+// synchronisation (`if num_faults > 0`) per frame in the reference, one launch here.
+// Sequences are independent, so one lane walks one sequence through time and emits the
+// permutation idx[b][t][a] = index of the current object assigned to slot a; the caller
+// applies it with a single differentiable gather.
+//   mode 0 ('3_only'): every slot takes its nearest current object; if that is not a
+//          permutation, slots are assigned greedily in slot order with column knock-out.
+//   mode 1 ('greedy'): N rounds of global arg-min over the N x N distance table with row and
+//          column knock-out.
+//   mode 2 ('volatile'): nearest previous slot per current object, no uniqueness (stove.py:331-430).
+// Distances are squared Euclidean on (v+1)/2-scaled features, ties resolve to the first index.
+#include "common.h"
+
+namespace stove {
+
+constexpr int kMatchN = 8, kMatchF = 8;
+
+__global__ void match_objects_k(const float* __restrict__ feat, long long* __restrict__ idx_out, float* __restrict__ perm_out,
+                                int B, int T, int N, int F, int mode) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float prev[kMatchN][kMatchF], cur[kMatchN][kMatchF], err[kMatchN][kMatchN];
+  const float* fb = feat + (size_t)b * T * N * F;
+  for (int a = 0; a < N; ++a) {
+    for (int f = 0; f < F; ++f) prev[a][f] = (fb[a * F + f] + 1.0f) * 0.5f;
+    idx_out[((size_t)b * T) * N + a] = a;
+  }
+  for (int t = 1; t < T; ++t) {
+    for (int j = 0; j < N; ++j)
+      for (int f = 0; f < F; ++f) cur[j][f] = (fb[((size_t)t * N + j) * F + f] + 1.0f) * 0.5f;
+    // err[a][j] = | prev_a - cur_j |^2
+    for (int a = 0; a < N; ++a)
+      for (int j = 0; j < N; ++j) {
+        float s = 0.0f;
+        for (int f = 0; f < F; ++f) {
+          const float d = prev[a][f] - cur[j][f];
+          s += d * d;
+        }
+        err[a][j] = s;
+      }
+    int idx[kMatchN];
+    if (mode == 0) {
+      for (int a = 0; a < N; ++a) {
+        int best = 0;
+        for (int j = 1; j < N; ++j)
+          if (err[a][j] < err[a][best]) best = j;
+        idx[a] = best;
+      }
+      bool ok = true;
+      for (int a = 0; a < N; ++a)
+        for (int c = a + 1; c < N; ++c)
+          if (idx[a] == idx[c]) ok = false;
+      if (!ok) {
+        for (int a = 0; a < N; ++a) {
+          int best = 0;
+          for (int j = 1; j < N; ++j)
+            if (err[a][j] < err[a][best]) best = j;
+          idx[a] = best;
+          for (int r = 0; r < N; ++r) err[r][best] = 1e12f;
+        }
+      }
+    } else if (mode == 1) {
+      for (int a = 0; a < N; ++a) idx[a] = 0;
+      for (int round = 0; round < N; ++round) {
+        int ba = 0, bj = 0;
+        float bv = err[0][0];
+        for (int a = 0; a < N; ++a)
+          for (int j = 0; j < N; ++j)
+            if (err[a][j] < bv) {
+              bv = err[a][j];
+              ba = a;
+              bj = j;
+            }
+        idx[ba] = bj;
+        for (int q = 0; q < N; ++q) {
+          err[ba][q] = 3.0e38f;
+          err[q][bj] = 3.0e38f;
+        }
+      }
+    } else {
+      // volatile: current object j goes to its nearest previous slot; slots may collide or stay empty.
+      // Reported through perm_out (a 0/1 matrix), idx gets -1 for empty slots.
+      for (int a = 0; a < N; ++a) idx[a] = -1;
+      for (int j = 0; j < N; ++j) {
+        int best = 0;
+        for (int a = 1; a < N; ++a)
+          if (err[a][j] < err[best][j]) best = a;
+        if (perm_out != nullptr) perm_out[(((size_t)b * T + t) * N + best) * N + j] = 1.0f;
+        idx[best] = j;
+      }
+    }
+    for (int a = 0; a < N; ++a) {
+      idx_out[((size_t)b * T + t) * N + a] = idx[a];
+      if (mode != 2) {
+        for (int f = 0; f < F; ++f) prev[a][f] = cur[idx[a]][f];
+      }
+    }
+    if (mode == 2) {
+      // matched state = perm @ current (sum of the assigned objects, zero if none)
+      float nxt[kMatchN][kMatchF];
+      for (int a = 0; a < N; ++a)
+        for (int f = 0; f < F; ++f) nxt[a][f] = 0.0f;
+      for (int j = 0; j < N; ++j) {
+        int best = 0;
+        for (int a = 1; a < N; ++a)
+          if (err[a][j] < err[best][j]) best = a;
+        for (int f = 0; f < F; ++f) nxt[best][f] += cur[j][f];
+      }
+      for (int a = 0; a < N; ++a)
+        for (int f = 0; f < F; ++f) prev[a][f] = nxt[a][f];
+    }
+  }
+}
+
+}  // namespace stove

@@ -383,11 +383,11 @@ int bgspn_forward(const float* frames, const float* marg, const float* z, int n_
   if (n_frames == 0) return 0;
   const int grid = bg_grid(n_frames);
   if (z != nullptr)
-    hipLaunchKernelGGL((bgspn_fwd_k<kBgR, kBgG, true>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, ell_part, n_frames);
+    STOVE_LAUNCH((bgspn_fwd_k<kBgR, kBgG, true>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, ell_part, n_frames);
   else
-    hipLaunchKernelGGL((bgspn_fwd_k<kBgR, kBgG, false>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, ell_part, n_frames);
+    STOVE_LAUNCH((bgspn_fwd_k<kBgR, kBgG, false>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, ell_part, n_frames);
   STOVE_LAUNCH_CHECK();
-  hipLaunchKernelGGL((bgspn_root_fwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, n_frames);
+  STOVE_LAUNCH((bgspn_root_fwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, n_frames);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -403,9 +403,9 @@ static int bg_bwd_launch(bool scene, int grid, hipStream_t st, const float* fram
                          int n_obj, const int* side, const float* coef, const float* dell, float* d_inputs,
                          float* d_marg, float* dz_part, float* gpart, int n_frames) {
   if (scene)
-    hipLaunchKernelGGL((bgspn_bwd_k<kBgR, kBgG, true, NMAX>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
+    STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, true, NMAX>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
   else
-    hipLaunchKernelGGL((bgspn_bwd_k<kBgR, kBgG, false, 1>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
+    STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, false, 1>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -436,7 +436,7 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
   float* dz_part = rsc + (size_t)n_frames * kBgR * (1 + 2 * kBgG);
   float* gpart = dz_part + (size_t)n_frames * kBgHalves * 8 * 4;
   float* rpart = gpart + (size_t)grid * kBgR * kBgThreads * kBgG * 3;
-  hipLaunchKernelGGL((bgspn_root_bwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, dout, dell, rsc, n_frames);
+  STOVE_LAUNCH((bgspn_root_bwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, dout, dell, rsc, n_frames);
   STOVE_LAUNCH_CHECK();
   const bool scene = z != nullptr;
   int rc;
@@ -449,16 +449,16 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
   if (rc) return rc;
   if (scene) {
     const int n = n_frames * n_obj * 4;
-    hipLaunchKernelGGL(bg_dz_halves_k, dim3((n + 255) / 256), dim3(256), 0, st, dz_part, dz, n_frames, n_obj * 4);
+    STOVE_LAUNCH(bg_dz_halves_k, dim3((n + 255) / 256), dim3(256), 0, st, dz_part, dz, n_frames, n_obj * 4);
     STOVE_LAUNCH_CHECK();
   }
   const int nc = kBgR * kBgPix * kBgG * 3;
-  hipLaunchKernelGGL((bgspn_coef_reduce_k<kBgR, kBgG>), dim3((nc + 255) / 256), dim3(256), 0, st, gpart, g_coef, grid);
+  STOVE_LAUNCH((bgspn_coef_reduce_k<kBgR, kBgG>), dim3((nc + 255) / 256), dim3(256), 0, st, gpart, g_coef, grid);
   STOVE_LAUNCH_CHECK();
   const int chunks = n_frames < kBgRootChunks ? n_frames : kBgRootChunks;
-  hipLaunchKernelGGL((bgspn_rootgrad_k<kBgR, kBgG>), dim3(chunks), dim3(128), 0, st, rsc, rpart, n_frames, chunks);
+  STOVE_LAUNCH((bgspn_rootgrad_k<kBgR, kBgG>), dim3(chunks), dim3(128), 0, st, rsc, rpart, n_frames, chunks);
   STOVE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_chunks_k, dim3(1), dim3(256), 0, st, rpart, g_wroot, kBgR * kBgG * kBgG, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3(1), dim3(256), 0, st, rpart, g_wroot, kBgR * kBgG * kBgG, chunks, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

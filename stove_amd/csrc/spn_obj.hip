@@ -502,7 +502,7 @@ int objspn_tile_from_arrays(const float* inputs, const float* marg, float* xw, i
   const int nb = (n + 63) / 64;
   if (nb == 0) return 0;
   const int D = 100;
-  hipLaunchKernelGGL(objspn_tile_from_arrays_k, dim3(grid_for(nb, 2048)), dim3(256), 2 * 64 * (D + 1) * sizeof(float), st,
+  STOVE_LAUNCH(objspn_tile_from_arrays_k, dim3(grid_for(nb, 2048)), dim3(256), 2 * 64 * (D + 1) * sizeof(float), st,
                      inputs, marg, xw, n, nb, D);
   STOVE_LAUNCH_CHECK();
   return 0;
@@ -512,7 +512,7 @@ int objspn_tile_to_arrays(const float* dxw, const float* marg, float* d_inputs, 
   const int nb = (n + 63) / 64;
   if (nb == 0) return 0;
   const int D = 100;
-  hipLaunchKernelGGL(objspn_tile_to_arrays_k, dim3(grid_for(nb, 2048)), dim3(256), 2 * 64 * (D + 1) * sizeof(float), st,
+  STOVE_LAUNCH(objspn_tile_to_arrays_k, dim3(grid_for(nb, 2048)), dim3(256), 2 * 64 * (D + 1) * sizeof(float), st,
                      dxw, marg, d_inputs, d_marg, n, nb, D);
   STOVE_LAUNCH_CHECK();
   return 0;
@@ -522,7 +522,7 @@ int objspn_forward(const float* xw, const int* scope, const float* coef, const f
                    float* out, float* ovl, int n, hipStream_t st) {
   const int nb = (n + 63) / 64;
   if (nb == 0) return 0;
-  hipLaunchKernelGGL((objspn_fwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
+  STOVE_LAUNCH((objspn_fwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
                      xw, scope, coef, wsum, wroot, out, ovl, n, nb);
   STOVE_LAUNCH_CHECK();
   return 0;
@@ -556,19 +556,19 @@ int objspn_backward(const float* xw, const int* scope, const int* leaf_slot, con
   float* pw = pc + (size_t)kObjChunks * kObjCoefN;
   float* pr = pw + (size_t)kObjChunks * kObjWN;
   const int chunks = nb < kObjChunks ? nb : kObjChunks;
-  hipLaunchKernelGGL((objspn_bwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
+  STOVE_LAUNCH((objspn_bwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
                      xw, scope, coef, wsum, wroot, out, dout, Dscr, Sscr, Rscr, n, nb);
   STOVE_LAUNCH_CHECK();
-  hipLaunchKernelGGL((objspn_pix_k<6, 25, 10, 8>), dim3(grid_for(nb, 4096)), dim3(512), 0, st,
+  STOVE_LAUNCH((objspn_pix_k<6, 25, 10, 8>), dim3(grid_for(nb, 4096)), dim3(512), 0, st,
                      xw, Dscr, leaf_slot, coef, dxw, nb);
   STOVE_LAUNCH_CHECK();
-  hipLaunchKernelGGL((objspn_coefgrad_k<6, 25, 10>), dim3(6 * chunks), dim3(128), 0, st, xw, Dscr, scope, pc, nb, chunks);
+  STOVE_LAUNCH((objspn_coefgrad_k<6, 25, 10>), dim3(6 * chunks), dim3(128), 0, st, xw, Dscr, scope, pc, nb, chunks);
   STOVE_LAUNCH_CHECK();
-  hipLaunchKernelGGL((objspn_wgrad_k<6, 10, 10>), dim3(chunks), dim3(6 * 2 * 10 * 2 + 64), 0, st, Sscr, Rscr, pw, pr, nb, chunks);
+  STOVE_LAUNCH((objspn_wgrad_k<6, 10, 10>), dim3(chunks), dim3(6 * 2 * 10 * 2 + 64), 0, st, Sscr, Rscr, pw, pr, nb, chunks);
   STOVE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_chunks_k, dim3((kObjCoefN + 255) / 256), dim3(256), 0, st, pc, g_coef, (int)kObjCoefN, chunks, 0);
-  hipLaunchKernelGGL(reduce_chunks_k, dim3((kObjWN + 255) / 256), dim3(256), 0, st, pw, g_wsum, (int)kObjWN, chunks, 0);
-  hipLaunchKernelGGL(reduce_chunks_k, dim3((kObjRootN + 255) / 256), dim3(256), 0, st, pr, g_wroot, (int)kObjRootN, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjCoefN + 255) / 256), dim3(256), 0, st, pc, g_coef, (int)kObjCoefN, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjWN + 255) / 256), dim3(256), 0, st, pw, g_wsum, (int)kObjWN, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjRootN + 255) / 256), dim3(256), 0, st, pr, g_wroot, (int)kObjRootN, chunks, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

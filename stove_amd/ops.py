@@ -16,6 +16,8 @@ from ._lib import SpnTableGrads, SpnTables, check, ptr, stream
 def _f32(t):
     if t is None:
         return None
+    if not t.is_cuda:
+        raise RuntimeError('stove_amd HIP ops need tensors on a GPU (cuda:N); there is no CPU path')
     if t.dtype != torch.float32:
         raise RuntimeError('stove_amd HIP kernels compute in float32; got %s' % t.dtype)
     return t.contiguous()
@@ -195,3 +197,151 @@ def wave_sum_selftest(x):
     out = torch.empty_like(x)
     check(lib.stove_selftest_wave_sum(ptr(x), ptr(out), x.numel() // 64, stream()), 'selftest')
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# GNN dynamics core and the fused inference recursion (csrc/gnn.hip)
+# ------------------------------------------------------------------------------------------------
+GNN_W_FLOATS = 22528
+GNN_V_FLOATS = 672
+
+
+def _gnn_image(w_img, v_img, wt_img):
+    return torch.cat([w_img, wt_img, v_img]).contiguous()
+
+
+class _GnnStepFn(torch.autograd.Function):
+    """Dynamics.forward core (reference dynamics.py:181-265): s_in (B,N,sin_dim) -> result, dynamic_pred (B,N,32)."""
+
+    @staticmethod
+    def forward(ctx, s_in, w_img, v_img, wt_img, lim_enc, elu):
+        lib = _lib.load()
+        s_in = _f32(s_in)
+        B, N, sd = s_in.shape
+        dev = s_in.device
+        params = _gnn_image(_f32(w_img), _f32(v_img), _f32(wt_img))
+        with torch.cuda.device(dev):
+            res = torch.empty(B, N, 32, dtype=torch.float32, device=dev)
+            pred = torch.empty(B, N, 32, dtype=torch.float32, device=dev)
+            check(lib.stove_gnn_fwd(ptr(s_in), ptr(params), ptr(res), ptr(pred), B, N, sd, int(lim_enc), int(elu), stream()),
+                  'stove_gnn_fwd')
+        ctx.save_for_backward(s_in, params)
+        ctx.cfg = (int(lim_enc), int(elu))
+        return res, pred
+
+    @staticmethod
+    def backward(ctx, dres, dpred):
+        lib = _lib.load()
+        s_in, params = ctx.saved_tensors
+        B, N, sd = s_in.shape
+        dev = s_in.device
+        lim_enc, elu = ctx.cfg
+        with torch.cuda.device(dev):
+            dres = _f32(dres) if dres is not None else torch.zeros(B, N, 32, device=dev)
+            dpred = _f32(dpred) if dpred is not None else None
+            d_s = torch.empty_like(s_in)
+            g = torch.empty(lib.stove_gnn_grad_floats(), dtype=torch.float32, device=dev)
+            ws = _ws(lib.stove_gnn_bwd_ws_bytes(B, N), dev)
+            check(lib.stove_gnn_bwd(ptr(s_in), ptr(params), ptr(dres), ptr(dpred), ptr(d_s), ptr(g), ptr(ws), B, N, sd,
+                                    lim_enc, elu, stream()), 'stove_gnn_bwd')
+        return d_s, g[:GNN_W_FLOATS], g[GNN_W_FLOATS:], None, None, None
+
+
+class _DynLoopFn(torch.autograd.Function):
+    """The T-serial inference recursion of Stove.stove_forward in one persistent kernel."""
+
+    @staticmethod
+    def forward(ctx, z1, zsup, zsstd, eps, extra, w_img, v_img, wt_img, lim_enc, elu, consts, want_pred):
+        lib = _lib.load()
+        z1, zsup, zsstd, eps = _f32(z1), _f32(zsup), _f32(zsstd), _f32(eps)
+        extra = _f32(extra)
+        B, Ts, N = zsup.shape[:3]
+        sd = 16 + (extra.shape[-1] if extra is not None else 0)
+        dev = z1.device
+        params = _gnn_image(_f32(w_img), _f32(v_img), _f32(wt_img))
+        with torch.cuda.device(dev):
+            def out(d):
+                return torch.empty(B, Ts, N, d, dtype=torch.float32, device=dev)
+            z, zdyn, zdstd, mean, std = out(18), out(16), out(16), out(18), out(18)
+            pred = out(32) if want_pred else None
+            check(lib.stove_dynloop_fwd(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z), ptr(zdyn),
+                                        ptr(zdstd), ptr(mean), ptr(std), ptr(pred), B, Ts, N, sd, int(lim_enc), int(elu),
+                                        *[float(c) for c in consts], stream()), 'stove_dynloop_fwd')
+        ctx.save_for_backward(z1, zsup, zsstd, eps, extra, params, z)
+        ctx.cfg = (int(lim_enc), int(elu), tuple(float(c) for c in consts), sd)
+        ctx.mark_non_differentiable(zdstd)
+        if pred is None:
+            pred = z.new_zeros(0)
+            ctx.mark_non_differentiable(pred)
+        return z, zdyn, zdstd, mean, std, pred
+
+    @staticmethod
+    def backward(ctx, dz, dzdyn, _dzdstd, dmean, dstd, dpred):
+        lib = _lib.load()
+        z1, zsup, zsstd, eps, extra, params, z = ctx.saved_tensors
+        lim_enc, elu, consts, sd = ctx.cfg
+        B, Ts, N = zsup.shape[:3]
+        dev = z1.device
+
+        def up(g, shape_like):
+            return None if g is None or g.numel() == 0 else _f32(g)
+        with torch.cuda.device(dev):
+            dz1 = torch.empty_like(z1)
+            dzsup, dzsstd = torch.empty_like(zsup), torch.empty_like(zsstd)
+            dextra = torch.empty_like(extra) if extra is not None else None
+            g = torch.empty(lib.stove_gnn_grad_floats(), dtype=torch.float32, device=dev)
+            ws = _ws(lib.stove_dynloop_bwd_ws_bytes(B, N), dev)
+            check(lib.stove_dynloop_bwd(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z),
+                                        ptr(up(dz, z)), ptr(up(dzdyn, z)), ptr(up(dmean, z)), ptr(up(dstd, z)),
+                                        ptr(up(dpred, z)), ptr(dz1), ptr(dzsup), ptr(dzsstd), ptr(dextra), ptr(g), ptr(ws),
+                                        B, Ts, N, sd, lim_enc, elu, *consts, stream()), 'stove_dynloop_bwd')
+        return (dz1, dzsup, dzsstd, None, dextra, g[:GNN_W_FLOATS], g[GNN_W_FLOATS:], None, None, None, None, None)
+
+
+def gnn_step(s_in, image, lim_enc=2, elu=False):
+    """image = (w_img, v_img, wt_img) from Dynamics.param_image()."""
+    return _GnnStepFn.apply(s_in, image[0], image[1], image[2], lim_enc, elu)
+
+
+def dyn_loop(z1, zsup, zsstd, eps, extra, image, lim_enc, elu, consts, want_pred=False):
+    return _DynLoopFn.apply(z1, zsup, zsstd, eps, extra, image[0], image[1], image[2], lim_enc, elu, consts, want_pred)
+
+
+@torch.no_grad()
+def rollout(z_last, extra, image, num, lim_enc, elu, consts, want_std=False, want_pred=False):
+    """Generative rollout (forward only): z_last (B,N,18), extra (B,A,N,E) or None -> z_pred (B,num,N,18)."""
+    lib = _lib.load()
+    z_last, extra = _f32(z_last), _f32(extra)
+    B, N = z_last.shape[:2]
+    A = extra.shape[1] if extra is not None else 1
+    sd = 16 + (extra.shape[-1] if extra is not None else 0)
+    dev = z_last.device
+    params = _gnn_image(_f32(image[0]), _f32(image[1]), _f32(image[2]))
+    with torch.cuda.device(dev):
+        z_pred = torch.empty(B, num, N, 18, dtype=torch.float32, device=dev)
+        zstd = torch.empty(B, num, N, 16, dtype=torch.float32, device=dev) if want_std else None
+        pred = torch.empty(B, num, N, 32, dtype=torch.float32, device=dev) if want_pred else None
+        check(lib.stove_rollout_fwd(ptr(z_last), ptr(extra), ptr(params), ptr(z_pred), ptr(zstd), ptr(pred), B, num, A, N, sd,
+                                    int(lim_enc), int(elu), *[float(c) for c in consts], stream()), 'stove_rollout_fwd')
+    return z_pred, zstd, pred
+
+
+MATCH_MODES = {'3_only': 0, 'greedy': 1, 'volatile': 2}
+
+
+@torch.no_grad()
+def match_objects(feat, mode):
+    """feat (B,T,N,F) matching features -> idx (B,T,N) int64 [, perm (B,T,N,N) for 'volatile']."""
+    lib = _lib.load()
+    feat = _f32(feat.detach())
+    B, T, N, Fd = feat.shape
+    dev = feat.device
+    with torch.cuda.device(dev):
+        idx = torch.empty(B, T, N, dtype=torch.int64, device=dev)
+        perm = None
+        if mode == 'volatile':
+            perm = torch.zeros(B, T, N, N, dtype=torch.float32, device=dev)
+            perm[:, 0] = torch.eye(N, device=dev)
+        check(lib.stove_match_objects(ptr(feat), ptr(idx), ptr(perm), B, T, N, Fd, MATCH_MODES[mode], stream()),
+              'stove_match_objects')
+    return idx, perm
