@@ -37,7 +37,7 @@ def parse():
     p.add_argument('--frames', type=int, default=100, help='T, frames per sequence')
     p.add_argument('--workload', default='billiards', choices=['billiards', 'multibilliards', 'gravity', 'avoidance'])
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-batch', type=int, default=16)
+    p.add_argument('--cpu-batch', type=int, default=8)
     p.add_argument('--cpu-iters', type=int, default=3)
     p.add_argument('--profile-steps', type=int, default=3)
     return p.parse_args()
@@ -78,7 +78,14 @@ def cpu_baseline(workload, T, n_seq, iters):
     the host cores: same workload shape, bounded batch."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import stove_oracle as O
-    cores = os.cpu_count() or 1
+    # the reference pins torch to config.max_threads = 8 (config.py:59, main.py:134); hundreds of
+    # OpenMP threads on these small ATen ops are far slower than 8, so the baseline uses the
+    # reference's own setting and reports it as `cores`
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = min(8, avail)
     torch.set_num_threads(cores)
     kw = {}
     if workload == 'multibilliards':
@@ -93,7 +100,10 @@ def cpu_baseline(workload, T, n_seq, iters):
     x = torch.from_numpy(make_batch(workload, n_seq, T, 10 ** 6)['X'])
     g = torch.Generator().manual_seed(1)
     times = []
+    t_start = time.perf_counter()
     for it in range(iters + 1):
+        if it > 1 and time.perf_counter() - t_start > 40.0:      # bounded: ~10-30 s of CPU work
+            break
         eps = O.draw_eps(n_seq, c.num_obj, T, generator=g)
         t0 = time.perf_counter()
         elbo, _ = O.stove_forward(c, params, structs, x, eps)
@@ -105,7 +115,15 @@ def cpu_baseline(workload, T, n_seq, iters):
             times.append(dt)
     med = float(np.median(times))
     return {'value': n_seq * T / med, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{workload} B={n_seq} T={T} fp32 fwd+bwd, median of {iters} after 1 warm-up, {med:.2f} s/step'}
+            'sample': f'{workload} B={n_seq} T={T} fp32 fwd+bwd, median of {len(times)} after 1 warm-up, {med:.2f} s/step'}
+
+
+def log(msg):
+    sys.stderr.write('[bench %.1fs] %s\n' % (time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
+
+
+_T0 = time.perf_counter()
 
 
 def main():
@@ -135,13 +153,15 @@ def main():
     bucket = GradBucket(model, world)
     opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
 
+    log('model built; generating data')
     data = make_batch(a.workload, a.batch, a.frames, rank * a.batch)
+    log('data ready')
     x = torch.from_numpy(data['X']).to(dev)
     actions = torch.from_numpy(data['action']).float().to(dev) if 'action' in data else None
     torch.manual_seed(1234 + rank)
 
     def step(i):
-        opt.zero_grad(set_to_none=False)
+        bucket.zero()
         elbo, _, rewards = model(x, i + 1, actions)
         loss = -elbo
         loss.backward()
@@ -153,6 +173,7 @@ def main():
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    log('warm-up done')
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -168,7 +189,8 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    elbo_val = float(last)
+    elbo_val = float(last.detach())
+    log('timed region done: %.1f ms/step' % (dt / a.steps * 1e3))
 
     # ---- per-kernel HIP-event timing of extra steps (profiling hooks off during the timed region)
     roofline = None
@@ -195,9 +217,11 @@ def main():
                         'kernels_ms_per_step': {k: round(v[0] / a.profile_steps, 4) for k, v in sorted(
                             per_launch.items(), key=lambda kv: -kv[1][0])[:12]}}
 
+    log('kernel profile done')
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.workload, a.frames, a.cpu_batch, a.cpu_iters)
+        log('cpu baseline done')
 
     if rank == 0:
         frames = a.batch * a.frames * world * a.steps
