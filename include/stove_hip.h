@@ -117,6 +117,11 @@ size_t stove_gnn_bwd_ws_bytes(int B, int N);
 int stove_gnn_bwd(const float* s_in, const float* params, const float* d_result, const float* d_pred, float* d_s_in,
                   float* g_params, void* ws, int B, int N, int sin_dim, int lim_enc, int elu, void* stream);
 
+/* debug/measurement: one forward+backward GNN step that also writes the cycle counter at every stage
+ * boundary of workgroup 0 into stamps[0..63] (int64, device). */
+int stove_gnn_debug_stamps(const float* s_in, const float* params, const float* d_result, float* d_s_in, void* ws,
+                           long long* stamps, int B, int N, int sin_dim, int lim_enc, int elu, void* stream);
+
 /* ---- the inference recursion of Stove.stove_forward (stove.py:696-713) with Dynamics.constrain_z_dyn
  * (dynamics.py:147-179) and Stove.full_state (stove.py:103-170) fused, all Ts = T-skip steps in one launch.
  * z1 (B,N,18) state at t=skip-1 [sx,sy/sx,x,y,vx,vy,latent]; zsup,zsstd (B,Ts,N,6) SuPAIR means/stds for

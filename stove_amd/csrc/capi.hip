@@ -231,7 +231,7 @@ static int gnn_lds_attr(const void* fn) {
 size_t stove_gnn_param_floats(void) { return kGnnParams; }
 size_t stove_gnn_grad_floats(void) { return kGnnGrads; }
 int stove_gnn_blocks(int B, int N) {
-  const int g = gnn_group(N);
+  const int g = gnn_group_for(B, N);
   return (B + g - 1) / g;
 }
 
@@ -242,7 +242,7 @@ int stove_gnn_fwd(const float* s_in, const float* params, float* result, float* 
   int rc = gnn_lds_attr((const void*)gnn_step_fwd_k);
   if (rc) return rc;
   STOVE_LAUNCH(gnn_step_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
-                     s_in, params, result, pred, B, N, sin_dim, lim_enc, elu);
+                     s_in, params, result, pred, B, N, gnn_group_for(B, N), sin_dim, lim_enc, elu);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -261,9 +261,20 @@ int stove_gnn_bwd(const float* s_in, const float* params, const float* d_result,
   if (rc) return rc;
   const int nb = stove_gnn_blocks(B, N);
   STOVE_LAUNCH(gnn_step_bwd_k, dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, s_in, params, d_result, d_pred,
-                     d_s_in, (float*)ws, B, N, sin_dim, lim_enc, elu);
+                     d_s_in, (float*)ws, B, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, (long long*)nullptr);
   STOVE_LAUNCH_CHECK();
   STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 255) / 256), dim3(256), 0, st, (const float*)ws, g_params, kGnnGrads, nb, 0);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+// debug: one fwd+bwd step with per-stage cycle stamps of block 0 (stamps: 64 int64 on the device)
+int stove_gnn_debug_stamps(const float* s_in, const float* params, const float* d_result, float* d_s_in, void* ws,
+                           long long* stamps, int B, int N, int sin_dim, int lim_enc, int elu, void* stream) {
+  int rc = gnn_lds_attr((const void*)gnn_step_bwd_k);
+  if (rc) return rc;
+  STOVE_LAUNCH(gnn_step_bwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream, s_in, params,
+               d_result, (const float*)nullptr, d_s_in, (float*)ws, B, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, stamps);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -278,7 +289,7 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
   if (rc) return rc;
   LoopConst kc{pos_var, vel_std, lat_std};
   STOVE_LAUNCH(dyn_loop_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
-                     z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, B, Ts, N, sin_dim, lim_enc, elu, kc);
+                     z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, B, Ts, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -299,7 +310,7 @@ int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, co
   LoopConst kc{pos_var, vel_std, lat_std};
   const int nb = stove_gnn_blocks(B, N);
   STOVE_LAUNCH(dyn_loop_bwd_k, dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, z1, zsup, zsstd, eps, extra, params, z,
-                     dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, (float*)ws, B, Ts, N, sin_dim, lim_enc, elu, kc);
+                     dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, (float*)ws, B, Ts, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
   STOVE_LAUNCH_CHECK();
   STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 255) / 256), dim3(256), 0, st, (const float*)ws, g_params, kGnnGrads, nb, 0);
   STOVE_LAUNCH_CHECK();
@@ -315,7 +326,7 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
   if (rc) return rc;
   LoopConst kc{pos_var, vel_std, lat_std};
   STOVE_LAUNCH(rollout_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
-                     z_last, extra, params, z_pred, zstd, pred, B, num, A < 1 ? 1 : A, N, sin_dim, lim_enc, elu, kc);
+                     z_last, extra, params, z_pred, zstd, pred, B, num, A < 1 ? 1 : A, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -362,7 +373,9 @@ size_t stove_profile_report(char* buf, size_t cap) {
 int stove_match_objects(const float* feat, long long* idx, float* perm, int B, int T, int N, int F, int mode, void* stream) {
   if (B == 0 || T == 0) return 0;
   if (N < 1 || N > kMatchN || F < 1 || F > kMatchF || mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
-  STOVE_LAUNCH(match_objects_k, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, feat, idx, perm, B, T, N, F, mode);
+  const size_t lds = (size_t)T * N * (F + 1) * sizeof(float);
+  if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+  STOVE_LAUNCH(match_objects_k, dim3(B), dim3(64), lds, (hipStream_t)stream, feat, idx, perm, B, T, N, F, mode);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

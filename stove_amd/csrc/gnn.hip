@@ -38,7 +38,11 @@ constexpr int LDN = 36, LDC = 68, LDP = 260, NEMAX = 80;
 struct GnnShape {
   int N, G, NR, NE, ME;   // objects, sequences per workgroup, node rows, edge rows, edge tiles
   int sin_dim, lim_enc, elu;
+  long long* stamps;      // debug: cycle stamps per stage (block 0, thread 0), normally null
 };
+__device__ __forceinline__ void gnn_stamp(const GnnShape& sh, int k) {
+  if (sh.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) sh.stamps[k] = (long long)__builtin_readcyclecounter();
+}
 
 struct GnnLds {
   float *SIN, *H1, *SD, *PRED, *F1, *F2, *O1, *RES, *DA, *DB, *DC;   // [16][LDN]
@@ -49,10 +53,14 @@ struct GnnLds {
   float *ATT, *DIST, *DATT;                                           // [NEMAX]
   float* DDIST;                                                       // [16][2]
   float* PC;                                                          // [16][2] position carry of the time loop
-  float* DV;                                                          // [V_END] vector-gradient accumulators
+  float* V;                                                           // [V_END] bias / vector parameters (copy of the VEC image)
+  float* AUXN;                                                        // [16][16]    col 0 = 1                        (bias grads ride the MFMAs)
+  float* AUXE;                                                        // [NEMAX][16] col 0 = 1, col 1 = dist_e, col 2 = dq_e
+  int *EI, *EJ;                                                       // [NEMAX] node rows of edge e = (g, i, j); -1 for padding
+  int *NG, *NI;                                                       // [16] first node row of the sequence of node r; object index of r
   float* X;                                                           // [16][40] epilogue scratch
 };
-constexpr int kGnnLdsFloats = 11 * 16 * LDN + 2 * 16 * LDC + 16 * LDP + 2 * NEMAX * LDC + 4 * NEMAX * LDN + 3 * NEMAX + 32 + 32 + V_END + 16 * 40;
+constexpr int kGnnLdsFloats = 11 * 16 * LDN + 2 * 16 * LDC + 16 * LDP + 2 * NEMAX * LDC + 4 * NEMAX * LDN + 3 * NEMAX + 32 + 32 + V_END + 16 * 16 + NEMAX * 16 + 2 * NEMAX + 32 + 16 * 40;
 
 __device__ __forceinline__ GnnLds carve(float* base) {
   GnnLds L;
@@ -68,7 +76,13 @@ __device__ __forceinline__ GnnLds carve(float* base) {
   L.ATT = take(NEMAX); L.DIST = take(NEMAX); L.DATT = take(NEMAX);
   L.DDIST = take(32);
   L.PC = take(32);
-  L.DV = take(V_END);
+  L.V = take(V_END);
+  L.AUXN = take(16 * 16);
+  L.AUXE = take(NEMAX * 16);
+  L.EI = reinterpret_cast<int*>(take(NEMAX));
+  L.EJ = reinterpret_cast<int*>(take(NEMAX));
+  L.NG = reinterpret_cast<int*>(take(16));
+  L.NI = reinterpret_cast<int*>(take(16));
   L.X = take(16 * 40);
   return L;
 }
@@ -118,23 +132,38 @@ __device__ __forceinline__ void tile_each(f32x4 acc, int m0, int n0, F f) {
   f(r0 + 3, col, acc[3]);
 }
 
-// column sums of X[nrows][ncols] added into acc_vec[ncols]; threads t0 .. t0+ncols-1 do the work
-__device__ __forceinline__ void colsum_acc(float* acc_vec, const float* X, int ld, int nrows, int ncols, int t0) {
-  const int c = (int)threadIdx.x - t0;
-  if (c >= 0 && c < ncols) {
-    float s = 0.0f;
-    for (int r = 0; r < nrows; ++r) s += X[r * ld + c];
-    acc_vec[c] += s;
+// one-time per-kernel setup: vector parameters and index tables into LDS (call after lds_zero + barrier)
+__device__ __forceinline__ void gnn_setup(const GnnLds& L, const GnnShape& sh, const float* __restrict__ Vg) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < V_END; i += blockDim.x) L.V[i] = Vg[i];
+  const int NN = sh.N * sh.N;
+  if (tid < NEMAX) {
+    int ei = -1, ej = -1;
+    if (tid < sh.NE) {
+      const int g = tid / NN, ij = tid % NN;
+      ei = g * sh.N + ij / sh.N;
+      ej = g * sh.N + ij % sh.N;
+    }
+    L.EI[tid] = ei;
+    L.EJ[tid] = ej;
+    L.AUXE[tid * 16] = tid < sh.NE ? 1.0f : 0.0f;
+  }
+  if (tid < 16) {
+    L.NG[tid] = (tid / sh.N) * sh.N;
+    L.NI[tid] = tid % sh.N;
+    L.AUXN[tid * 16] = 1.0f;
   }
 }
 
 // =================================================================================================
 // forward of one GNN step; input L.SIN (rows < NR, cols < sin_dim, rest zero), output L.RES, L.PRED
 // =================================================================================================
-__device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh, const float* __restrict__ Wf, const float* __restrict__ V) {
+__device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh, const float* __restrict__ Wf) {
   const int wv = wave_id();
   const int tid = threadIdx.x;
+  const float* V = L.V;
   float* S = L.CAT + 32;   // S lives in CAT[:, 32:64]
+  gnn_stamp(sh, 0);
   // 1. state encoder; raw positions (first lim_enc dims) are kept for the distances (dynamics.py:250)
   if (wv < 2) {
     const f32x4 acc = tile_AB<32>(L.SIN, LDN, Wf + W_ENC + wv * 16 * 32, 32);
@@ -143,6 +172,7 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
     });
   }
   __syncthreads();
+  gnn_stamp(sh, 1);
   // 2. self-dynamics layer 0 and the factorised first edge layer (rel_i | rel_j | att_i | att_j)
   for (int t = wv; t < 18; t += 4) {
     if (t < 2) {
@@ -154,19 +184,39 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
       tile_each(acc, 0, n * 16, [&](int r, int c, float v) { L.P[r * LDP + c] = v; });
     }
   }
+  if (tid >= 192 && tid - 192 < sh.ME * 16) {          // squared distances (wave 3 has the fewest tiles)
+    const int e = tid - 192;
+    float d = 0.0f;
+    if (L.EI[e] >= 0) {
+      const int ni = L.EI[e], nj = L.EJ[e];
+      const float dx = S[ni * LDC] - S[nj * LDC], dy = S[ni * LDC + 1] - S[nj * LDC + 1];
+      d = dx * dx + dy * dy;
+    }
+    L.DIST[e] = d;
+    L.AUXE[e * 16 + 1] = d;
+  }
+  if (tid >= 192 && sh.ME * 16 > 64 && tid - 192 + 64 < sh.ME * 16) {
+    const int e = tid - 192 + 64;
+    float d = 0.0f;
+    if (L.EI[e] >= 0) {
+      const int ni = L.EI[e], nj = L.EJ[e];
+      const float dx = S[ni * LDC] - S[nj * LDC], dy = S[ni * LDC + 1] - S[nj * LDC + 1];
+      d = dx * dx + dy * dy;
+    }
+    L.DIST[e] = d;
+    L.AUXE[e * 16 + 1] = d;
+  }
   __syncthreads();
+  gnn_stamp(sh, 2);
   // 3. edge pre-activations (gather) + self-dynamics layer 1
   {
-    const int NN = sh.N * sh.N;
     for (int idx = tid; idx < sh.ME * 16 * 64; idx += blockDim.x) {
       const int e = idx >> 6, c = idx & 63;
       float r1 = 0.0f, a1 = 0.0f;
-      if (e < sh.NE) {
-        const int g = e / NN, ij = e % NN, i = ij / sh.N, j = ij % sh.N;
-        const int ni = g * sh.N + i, nj = g * sh.N + j;
-        const float dx = S[ni * LDC] - S[nj * LDC], dy = S[ni * LDC + 1] - S[nj * LDC + 1];
-        const float d = dx * dx + dy * dy;
-        if (c == 0) L.DIST[e] = d;
+      const int ni = L.EI[e];
+      if (ni >= 0) {
+        const int nj = L.EJ[e];
+        const float d = L.DIST[e];
         r1 = act_phi(L.P[ni * LDP + c] + L.P[nj * LDP + 64 + c] + V[V_WDR + c] * d + V[V_BR0 + c], sh.elu);
         a1 = act_phi(L.P[ni * LDP + 128 + c] + L.P[nj * LDP + 192 + c] + V[V_WDA + c] * d + V[V_BA0 + c], sh.elu);
       }
@@ -179,6 +229,7 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
     }
   }
   __syncthreads();
+  gnn_stamp(sh, 3);
   // 4. second edge layers (64 -> 32), relation and attention
   for (int t = wv; t < sh.ME * 4; t += 4) {
     const int m = t >> 2, n = (t >> 1) & 1, which = t & 1;
@@ -191,6 +242,7 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
     }
   }
   __syncthreads();
+  gnn_stamp(sh, 4);
   // 5. third edge layers: relation 32 -> 32 (+skip), attention 32 -> 1 -> exp
   if (tid < sh.ME * 16) {
     float q = V[V_BA2];
@@ -203,50 +255,53 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
     tile_each(acc, m * 16, n * 16, [&](int r, int c, float v) { L.R3[r * LDN + c] = v + V[V_BR2 + c] + L.R2[r * LDN + c]; });
   }
   __syncthreads();
+  gnn_stamp(sh, 5);
   // 6. masked, attention-weighted aggregation over the other objects
   for (int idx = tid; idx < 16 * 32; idx += blockDim.x) {
     const int r = idx >> 5, c = idx & 31;
     float v = 0.0f;
     if (r < sh.NR) {
-      const int g = r / sh.N, i = r % sh.N;
+      const int i = L.NI[r], e0 = r * sh.N;                  // edges (r -> j) are rows e0 .. e0+N-1
       v = L.SD[r * LDN + c];
-      for (int j = 0; j < sh.N; ++j) {
-        if (j != i) {
-          const int e = (g * sh.N + i) * sh.N + j;
-          v = fmaf(L.R3[e * LDN + c], L.ATT[e], v);
-        }
-      }
+      for (int j = 0; j < sh.N; ++j)
+        if (j != i) v = fmaf(L.R3[(e0 + j) * LDN + c], L.ATT[e0 + j], v);
     }
     L.PRED[r * LDN + c] = v;
   }
   __syncthreads();
+  gnn_stamp(sh, 6);
   // 7-9. affector MLP
   if (wv < 2) {
     const f32x4 acc = tile_AB<32>(L.PRED, LDN, Wf + W_F0 + wv * 16 * 32, 32);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.F1[r * LDN + c] = tanhf(v + V[V_F0 + c]); });
   }
   __syncthreads();
+  gnn_stamp(sh, 7);
   if (wv < 2) {
     const f32x4 acc = tile_AB<32>(L.F1, LDN, Wf + W_F1 + wv * 16 * 32, 32);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.F2[r * LDN + c] = tanhf(v + V[V_F1 + c]) + L.F1[r * LDN + c]; });
   }
   __syncthreads();
+  gnn_stamp(sh, 8);
   if (wv < 2) {
     const f32x4 acc = tile_AB<32>(L.F2, LDN, Wf + W_F2 + wv * 16 * 32, 32);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.CAT[r * LDC + c] = v + V[V_F2 + c]; });
   }
   __syncthreads();
+  gnn_stamp(sh, 9);
   // 10-11. output MLP on [affector | s]
   if (wv < 2) {
     const f32x4 acc = tile_AB<64>(L.CAT, LDC, Wf + W_O0 + wv * 16 * 64, 64);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.O1[r * LDN + c] = tanhf(v + V[V_O0 + c]); });
   }
   __syncthreads();
+  gnn_stamp(sh, 10);
   if (wv < 2) {
     const f32x4 acc = tile_AB<32>(L.O1, LDN, Wf + W_O1 + wv * 16 * 32, 32);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.RES[r * LDN + c] = v + V[V_O1 + c] + L.O1[r * LDN + c]; });
   }
   __syncthreads();
+  gnn_stamp(sh, 11);
 }
 
 // =================================================================================================
@@ -278,15 +333,46 @@ __device__ __forceinline__ void dW_store(const f32x4* acc, float* __restrict__ i
 constexpr int SL_ENC = 0, SL_S0 = 1, SL_S1 = 2, SL_EF = 3, SL_R1 = 11, SL_A1 = 13, SL_R2 = 15, SL_F0 = 16, SL_F1 = 17,
               SL_F2 = 18, SL_O0 = 19, SL_O1 = 21, SL_END = 22;
 
-__device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh, const float* __restrict__ WT, const float* __restrict__ V,
-                             f32x4* acc, const float* dpred_up /* global or null */, size_t dpred_seq_stride) {
+// Bias / vector gradients ride the matrix cores too: with an auxiliary operand whose column 0 is 1
+// (column 1 the edge distance, column 2 dq), tile (o, j) of dO^T AUX holds sum_rows dO[row][o] * AUX[row][j].
+// Vector tiles are numbered globally; tile t belongs to wave t & 3 and accumulator slot t >> 2.
+constexpr int VT_ENC = 0, VT_S0 = 2, VT_S1 = 4, VT_F0 = 6, VT_F1 = 8, VT_F2 = 10, VT_O0 = 12, VT_O1 = 14,
+              VT_R0 = 16, VT_A0 = 20, VT_R1 = 24, VT_A1 = 26, VT_R2 = 28, VT_WA2 = 30, VT_BA2 = 32, VT_END = 33;
+constexpr int VSLOTS = (VT_END + 3) / 4;
+
+template <int T0, int NT>
+__device__ __forceinline__ void vec_layer(f32x4* vacc, const float* dO, int ldo, const float* aux, int row_tiles, int wv) {
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    if (((T0 + k) & 3) == wv) vacc[(T0 + k) >> 2] = tile_dW(dO + k * 16, ldo, aux, 16, row_tiles, vacc[(T0 + k) >> 2]);
+  }
+}
+// column `col` of vector tile t -> out[k*16 + o]
+template <int T0, int NT>
+__device__ __forceinline__ void vec_store(const f32x4* vacc, float* __restrict__ out, int col, int wv) {
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    if (((T0 + k) & 3) == wv) {
+      tile_each(vacc[(T0 + k) >> 2], k * 16, 0, [&](int r, int c, float v) {
+        if (c == col) out[r] = v;
+      });
+    }
+  }
+}
+
+__device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh, const float* __restrict__ WT,
+                             f32x4* acc, f32x4* vacc, const float* dpred_up /* global or null */, size_t dpred_seq_stride) {
   const int wv = wave_id();
   const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const float* V = L.V;
   float* S = L.CAT + 32;
-  const int NN = sh.N * sh.N;
+  gnn_stamp(sh, 20);
   // b1. out.1:  RES = O1 W^T + b + O1
   dW_layer<32, 32, SL_O1>(acc, L.DA, LDN, L.O1, LDN, 1, wv);
-  colsum_acc(L.DV + V_O1, L.DA, LDN, 16, 32, 128);
+  vec_layer<VT_O1, 2>(vacc, L.DA, LDN, L.AUXN, 1, wv);
   if (wv < 2) {
     const f32x4 t = tile_AB<32>(L.DA, LDN, WT + W_O1 + wv * 16 * 32, 32);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
@@ -295,17 +381,19 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     });
   }
   __syncthreads();
+  gnn_stamp(sh, 21);
   // b2. out.0 on CAT = [F3 | S]
   dW_layer<32, 64, SL_O0>(acc, L.DB, LDN, L.CAT, LDC, 1, wv);
-  colsum_acc(L.DV + V_O0, L.DB, LDN, 16, 32, 128);
+  vec_layer<VT_O0, 2>(vacc, L.DB, LDN, L.AUXN, 1, wv);
   {
     const f32x4 t = tile_AB<32>(L.DB, LDN, WT + W_O0 + wv * 16 * 32, 32);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) { L.DCAT[r * LDC + c] = v; });
   }
   __syncthreads();
+  gnn_stamp(sh, 22);
   // b3. affector.2:  F3 = F2 W^T + b      (dF3 = DCAT[:, :32])
   dW_layer<32, 32, SL_F2>(acc, L.DCAT, LDC, L.F2, LDN, 1, wv);
-  colsum_acc(L.DV + V_F2, L.DCAT, LDC, 16, 32, 128);
+  vec_layer<VT_F2, 2>(vacc, L.DCAT, LDC, L.AUXN, 1, wv);
   if (wv < 2) {
     const f32x4 t = tile_AB<32>(L.DCAT, LDC, WT + W_F2 + wv * 16 * 32, 32);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
@@ -315,9 +403,10 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     });
   }
   __syncthreads();
+  gnn_stamp(sh, 23);
   // b4. affector.1:  F2 = tanh(F1 W^T + b) + F1
   dW_layer<32, 32, SL_F1>(acc, L.DC, LDN, L.F1, LDN, 1, wv);
-  colsum_acc(L.DV + V_F1, L.DC, LDN, 16, 32, 128);
+  vec_layer<VT_F1, 2>(vacc, L.DC, LDN, L.AUXN, 1, wv);
   if (wv < 2) {
     const f32x4 t = tile_AB<32>(L.DC, LDN, WT + W_F1 + wv * 16 * 32, 32);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
@@ -326,9 +415,10 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     });
   }
   __syncthreads();
+  gnn_stamp(sh, 24);
   // b5. affector.0:  F1 = tanh(PRED W^T + b)
   dW_layer<32, 32, SL_F0>(acc, L.DB, LDN, L.PRED, LDN, 1, wv);
-  colsum_acc(L.DV + V_F0, L.DB, LDN, 16, 32, 128);
+  vec_layer<VT_F0, 2>(vacc, L.DB, LDN, L.AUXN, 1, wv);
   if (wv < 2) {
     const f32x4 t = tile_AB<32>(L.DB, LDN, WT + W_F0 + wv * 16 * 32, 32);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
@@ -338,44 +428,41 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     });
   }
   __syncthreads();
-  // b6a. d attention (per edge)
-  if (tid < sh.ME * 16) {
-    float dq = 0.0f;
-    if (tid < sh.NE) {
-      const int g = tid / NN, ij = tid % NN, i = ij / sh.N, j = ij % sh.N;
-      if (i != j) {
-        const int ni = g * sh.N + i;
-        float s = 0.0f;
-        for (int c = 0; c < 32; ++c) s = fmaf(L.DC[ni * LDN + c], L.R3[tid * LDN + c], s);
-        dq = s * L.ATT[tid];                                               // att = exp(q)
-      }
+  gnn_stamp(sh, 25);
+  // b6a. d attention: one wave-half (32 lanes = 32 channels) per edge
+  for (int e = wv * 2 + (lane >> 5); e < sh.ME * 16; e += 8) {
+    const int ni = L.EI[e], c = lane & 31;
+    float v = 0.0f;
+    if (ni >= 0 && ni != L.EJ[e]) v = L.DC[ni * LDN + c] * L.R3[e * LDN + c];
+    // sum over the 32 lanes of this half
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    if (c == 0) {
+      const float dq = v * L.ATT[e];                                       // att = exp(q)
+      L.DATT[e] = dq;
+      L.AUXE[e * 16 + 2] = dq;
     }
-    L.DATT[tid] = dq;
   }
   __syncthreads();
-  // b6b. dR3 in place; attention output layer grads
+  gnn_stamp(sh, 26);
+  // b6b. dR3 in place; attention output layer grads (A2 still holds the forward values)
+  vec_layer<VT_WA2, 2>(vacc, L.A2, LDN, L.AUXE, sh.ME, wv);
+  vec_layer<VT_BA2, 1>(vacc, L.AUXE, 16, L.AUXE, sh.ME, wv);
   for (int idx = tid; idx < sh.ME * 16 * 32; idx += blockDim.x) {
     const int e = idx >> 5, c = idx & 31;
+    const int ni = L.EI[e];
     float v = 0.0f;
-    if (e < sh.NE) {
-      const int g = e / NN, ij = e % NN, i = ij / sh.N, j = ij % sh.N;
-      if (i != j) v = L.DC[(g * sh.N + i) * LDN + c] * L.ATT[e];
-    }
+    if (ni >= 0 && ni != L.EJ[e]) v = L.DC[ni * LDN + c] * L.ATT[e];
     L.R3[e * LDN + c] = v;
   }
-  if (tid < 32) {
-    float s = 0.0f;
-    for (int e = 0; e < sh.NE; ++e) s = fmaf(L.DATT[e], L.A2[e * LDN + tid], s);
-    L.DV[V_WA2 + tid] += s;
-  } else if (tid == 32) {
-    float s = 0.0f;
-    for (int e = 0; e < sh.NE; ++e) s += L.DATT[e];
-    L.DV[V_BA2] += s;
-  }
   __syncthreads();
+  gnn_stamp(sh, 27);
   // b7. rel.2:  R3 = R2 W^T + b + R2 ;  attention pre-activation grads in place in A2
   dW_layer<32, 32, SL_R2>(acc, L.R3, LDN, L.R2, LDN, sh.ME, wv);
-  colsum_acc(L.DV + V_BR2, L.R3, LDN, sh.NE, 32, 128);
+  vec_layer<VT_R2, 2>(vacc, L.R3, LDN, L.AUXE, sh.ME, wv);
   for (int t = wv; t < sh.ME * 2; t += 4) {
     const int m = t >> 1, n = t & 1;
     const f32x4 a = tile_AB<32>(L.R3 + m * 16 * LDN, LDN, WT + W_R2 + n * 16 * 32, 32);
@@ -389,12 +476,14 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     L.A2[e * LDN + c] = L.DATT[e] * V[V_WA2 + c] * dphi_from_out(y, sh.elu);
   }
   __syncthreads();
+  gnn_stamp(sh, 28);
   // b8. rel.1 / att.1 weight grads (inputs R1 / A1 still intact)
   dW_layer<32, 64, SL_R1>(acc, L.E32, LDN, L.R1, LDC, sh.ME, wv);
   dW_layer<32, 64, SL_A1>(acc, L.A2, LDN, L.A1, LDC, sh.ME, wv);
-  colsum_acc(L.DV + V_BR1, L.E32, LDN, sh.NE, 32, 0);
-  colsum_acc(L.DV + V_BA1, L.A2, LDN, sh.NE, 32, 32);
+  vec_layer<VT_R1, 2>(vacc, L.E32, LDN, L.AUXE, sh.ME, wv);
+  vec_layer<VT_A1, 2>(vacc, L.A2, LDN, L.AUXE, sh.ME, wv);
   __syncthreads();
+  gnn_stamp(sh, 29);
   // b9. rel.1 / att.1 data grads, multiplied by phi'(first-layer output), in place in R1 / A1
   for (int t = wv; t < sh.ME * 8; t += 4) {
     const int m = t >> 3, n = (t >> 1) & 3, which = t & 1;
@@ -407,44 +496,36 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     }
   }
   __syncthreads();
-  // b10. first edge layer: scatter (as a gather) into dP, vector grads, d distance
+  gnn_stamp(sh, 30);
+  // b10. first edge layer: scatter (as a gather) into dP, bias / distance-weight grads, d distance
+  vec_layer<VT_R0, 4>(vacc, L.R1, LDC, L.AUXE, sh.ME, wv);
+  vec_layer<VT_A0, 4>(vacc, L.A1, LDC, L.AUXE, sh.ME, wv);
   for (int idx = tid; idx < 16 * 256; idx += blockDim.x) {
     const int r = idx >> 8, c = idx & 255;
     float v = 0.0f;
     if (r < sh.NR) {
-      const int g = r / sh.N, i = r % sh.N;
+      const int g0 = L.NG[r], i = L.NI[r];
       const int blk = c >> 6, cc = c & 63;
       const float* src = (blk < 2) ? L.R1 : L.A1;
-      for (int j = 0; j < sh.N; ++j) {
-        const int e = (blk & 1) ? (g * sh.N + j) * sh.N + i : (g * sh.N + i) * sh.N + j;   // as s_j : as s_i
-        v += src[e * LDC + cc];
+      if (blk & 1) {
+        for (int j = 0; j < sh.N; ++j) v += src[((g0 + j) * sh.N + i) * LDC + cc];      // r as the second argument s_j
+      } else {
+        for (int j = 0; j < sh.N; ++j) v += src[(r * sh.N + j) * LDC + cc];             // r as the first argument s_i
       }
     }
     L.P[r * LDP + c] = v;
   }
-  if (tid < 128) {
-    const int cc = tid & 63;
-    const float* src = (tid < 64) ? L.R1 : L.A1;
-    float sb = 0.0f, sd = 0.0f;
-    for (int e = 0; e < sh.NE; ++e) {
-      const float v = src[e * LDC + cc];
-      sb += v;
-      sd = fmaf(v, L.DIST[e], sd);
-    }
-    L.DV[(tid < 64 ? V_BR0 : V_BA0) + cc] += sb;
-    L.DV[(tid < 64 ? V_WDR : V_WDA) + cc] += sd;
-  } else if (tid - 128 < sh.ME * 16) {
-    const int e = tid - 128;
-    float s = 0.0f;
-    if (e < sh.NE)
-      for (int c = 0; c < 64; ++c) s = fmaf(L.R1[e * LDC + c], V[V_WDR + c], fmaf(L.A1[e * LDC + c], V[V_WDA + c], s));
-    L.DATT[e] = s;                                                          // dL/d dist_e
+  for (int e = wv; e < sh.ME * 16; e += 4) {             // dL/d dist_e: one wave per edge, lanes = channels
+    float v = L.R1[e * LDC + lane] * V[V_WDR + lane] + L.A1[e * LDC + lane] * V[V_WDA + lane];
+    v = wave_sum_lane63(v);
+    if (lane == 63) L.DATT[e] = v;
   }
   __syncthreads();
+  gnn_stamp(sh, 31);
   // b11. edge-first + self.1
   dW_layer<256, 32, SL_EF>(acc, L.P, LDP, S, LDC, 1, wv);
   dW_layer<32, 32, SL_S1>(acc, L.DC, LDN, L.H1, LDN, 1, wv);
-  colsum_acc(L.DV + V_S1, L.DC, LDN, 16, 32, 128);
+  vec_layer<VT_S1, 2>(vacc, L.DC, LDN, L.AUXN, 1, wv);
   if (wv < 2) {
     const f32x4 t = tile_AB<32>(L.DC, LDN, WT + W_S1 + wv * 16 * 32, 32);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
@@ -459,19 +540,19 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     const int r = tid >> 1, ax = tid & 1;
     float s = 0.0f;
     if (r < sh.NR) {
-      const int g = r / sh.N, i = r % sh.N;
+      const int g0 = L.NG[r], i = L.NI[r];
       for (int j = 0; j < sh.N; ++j) {
-        const int nj = g * sh.N + j;
-        const float diff = S[r * LDC + ax] - S[nj * LDC + ax];
-        s += 2.0f * diff * (L.DATT[(g * sh.N + i) * sh.N + j] + L.DATT[(g * sh.N + j) * sh.N + i]);
+        const float diff = S[r * LDC + ax] - S[(g0 + j) * LDC + ax];
+        s += 2.0f * diff * (L.DATT[r * sh.N + j] + L.DATT[(g0 + j) * sh.N + i]);
       }
     }
     L.DDIST[tid] = s;
   }
   __syncthreads();
+  gnn_stamp(sh, 32);
   // b12. self.0 ; total dS ; split into the encoder output part and the pass-through part
   dW_layer<32, 32, SL_S0>(acc, L.DB, LDN, S, LDC, 1, wv);
-  colsum_acc(L.DV + V_S0, L.DB, LDN, 16, 32, 128);
+  vec_layer<VT_S0, 2>(vacc, L.DB, LDN, L.AUXN, 1, wv);
   if (wv < 2) {
     const f32x4 t = tile_AB<32>(L.DB, LDN, WT + W_S0 + wv * 16 * 32, 32);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
@@ -483,17 +564,19 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     });
   }
   __syncthreads();
+  gnn_stamp(sh, 33);
   // b13. encoder
   dW_layer<32, 32, SL_ENC>(acc, L.DC, LDN, L.SIN, LDN, 1, wv);
-  colsum_acc(L.DV + V_ENC, L.DC, LDN, 16, 32, 128);
+  vec_layer<VT_ENC, 2>(vacc, L.DC, LDN, L.AUXN, 1, wv);
   if (wv < 2) {
     const f32x4 t = tile_AB<32>(L.DC, LDN, WT + W_ENC + wv * 16 * 32, 32);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) { L.DA[r * LDN + c] = v + L.F1[r * LDN + c]; });
   }
   __syncthreads();
+  gnn_stamp(sh, 34);
 }
 
-__device__ __forceinline__ void gnn_store_grads(const GnnLds& L, const f32x4* acc, float* __restrict__ gout) {
+__device__ __forceinline__ void gnn_store_grads(const f32x4* acc, const f32x4* vacc, float* __restrict__ gout) {
   const int wv = wave_id();
   dW_store<32, 32, SL_ENC>(acc, gout + W_ENC, wv);
   dW_store<32, 32, SL_S0>(acc, gout + W_S0, wv);
@@ -507,28 +590,60 @@ __device__ __forceinline__ void gnn_store_grads(const GnnLds& L, const f32x4* ac
   dW_store<32, 32, SL_F2>(acc, gout + W_F2, wv);
   dW_store<32, 64, SL_O0>(acc, gout + W_O0, wv);
   dW_store<32, 32, SL_O1>(acc, gout + W_O1, wv);
-  __syncthreads();
-  for (int i = threadIdx.x; i < V_END; i += blockDim.x) gout[W_END + i] = L.DV[i];
+  float* gv = gout + W_END;
+  vec_store<VT_ENC, 2>(vacc, gv + V_ENC, 0, wv);
+  vec_store<VT_S0, 2>(vacc, gv + V_S0, 0, wv);
+  vec_store<VT_S1, 2>(vacc, gv + V_S1, 0, wv);
+  vec_store<VT_F0, 2>(vacc, gv + V_F0, 0, wv);
+  vec_store<VT_F1, 2>(vacc, gv + V_F1, 0, wv);
+  vec_store<VT_F2, 2>(vacc, gv + V_F2, 0, wv);
+  vec_store<VT_O0, 2>(vacc, gv + V_O0, 0, wv);
+  vec_store<VT_O1, 2>(vacc, gv + V_O1, 0, wv);
+  vec_store<VT_R0, 4>(vacc, gv + V_BR0, 0, wv);
+  vec_store<VT_R0, 4>(vacc, gv + V_WDR, 1, wv);
+  vec_store<VT_A0, 4>(vacc, gv + V_BA0, 0, wv);
+  vec_store<VT_A0, 4>(vacc, gv + V_WDA, 1, wv);
+  vec_store<VT_R1, 2>(vacc, gv + V_BR1, 0, wv);
+  vec_store<VT_A1, 2>(vacc, gv + V_BA1, 0, wv);
+  vec_store<VT_R2, 2>(vacc, gv + V_BR2, 0, wv);
+  vec_store<VT_WA2, 2>(vacc, gv + V_WA2, 2, wv);
+  // ba2 = sum_e dq_e = element (row 0, col 2) of the AUXE^T AUXE tile; the rest of the 32-slot is padding
+  if (((VT_BA2)&3) == wv) {
+    tile_each(vacc[VT_BA2 >> 2], 0, 0, [&](int r, int c, float v) {
+      if (c == 2 && r < 16) gv[V_BA2 + r] = (r == 0) ? v : 0.0f;
+    });
+  }
+  if (wv == 1)
+    for (int i = lane_id(); i < 16; i += 64) gv[V_BA2 + 16 + i] = 0.0f;
 }
 
 // sequences per workgroup: node rows <= 16 and edge rows <= NEMAX
-__host__ __device__ inline int gnn_group(int N) {
+__host__ __device__ inline int gnn_group_max(int N) {
   const int a = 16 / N, b = NEMAX / (N * N);
   const int g = a < b ? a : b;
   return g < 1 ? 1 : g;
 }
+// The recursion is latency-bound (stage count x per-stage latency), not throughput-bound: as long as
+// there are CUs to spare, fewer sequences per workgroup means shorter elementwise loops and fewer
+// tiles per stage, hence a shorter step.  Use the smallest group that still fits one workgroup per CU.
+__host__ __device__ inline int gnn_group_for(int B, int N) {
+  const int gmax = gnn_group_max(N);
+  int g = (B + 255) / 256;
+  if (g < 1) g = 1;
+  return g > gmax ? gmax : g;
+}
 
-__device__ __forceinline__ GnnShape make_shape(int N, int b0, int B, int sin_dim, int lim_enc, int elu) {
+__device__ __forceinline__ GnnShape make_shape(int N, int G, int b0, int B, int sin_dim, int lim_enc, int elu) {
   GnnShape sh;
   sh.N = N;
-  const int gmax = gnn_group(N);
-  sh.G = (B - b0) < gmax ? (B - b0) : gmax;
+  sh.G = (B - b0) < G ? (B - b0) : G;
   sh.NR = sh.G * N;
   sh.NE = sh.G * N * N;
   sh.ME = (sh.NE + 15) / 16;
   sh.sin_dim = sin_dim;
   sh.lim_enc = lim_enc;
   sh.elu = elu;
+  sh.stamps = nullptr;
   return sh;
 }
 
@@ -541,19 +656,21 @@ __device__ __forceinline__ void lds_zero(float* base, int n) {
 // =================================================================================================
 __global__ __launch_bounds__(256) void gnn_step_fwd_k(const float* __restrict__ sin, const float* __restrict__ P,
                                                       float* __restrict__ res, float* __restrict__ pred,
-                                                      int B, int N, int sin_dim, int lim_enc, int elu) {
+                                                      int B, int N, int G, int sin_dim, int lim_enc, int elu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GnnLds L = carve(lds);
-  const int b0 = blockIdx.x * gnn_group(N);
-  const GnnShape sh = make_shape(N, b0, B, sin_dim, lim_enc, elu);
+  const int b0 = blockIdx.x * G;
+  const GnnShape sh = make_shape(N, G, b0, B, sin_dim, lim_enc, elu);
   lds_zero(lds, kGnnLdsFloats);
+  __syncthreads();
+  gnn_setup(L, sh, P + 2 * W_END);
   __syncthreads();
   for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
     const int r = i / sin_dim, c = i % sin_dim;
     L.SIN[r * LDN + c] = sin[((size_t)b0 * N + r) * sin_dim + c];
   }
   __syncthreads();
-  gnn_forward(L, sh, P, P + 2 * W_END);
+  gnn_forward(L, sh, P);
   for (int i = threadIdx.x; i < sh.NR * 32; i += blockDim.x) {
     const int r = i >> 5, c = i & 31;
     res[((size_t)b0 * N + r) * 32 + c] = L.RES[r * LDN + c];
@@ -564,33 +681,39 @@ __global__ __launch_bounds__(256) void gnn_step_fwd_k(const float* __restrict__ 
 __global__ __launch_bounds__(256) void gnn_step_bwd_k(const float* __restrict__ sin, const float* __restrict__ P,
                                                       const float* __restrict__ dres, const float* __restrict__ dpred,
                                                       float* __restrict__ dsin, float* __restrict__ gpart,
-                                                      int B, int N, int sin_dim, int lim_enc, int elu) {
+                                                      int B, int N, int G, int sin_dim, int lim_enc, int elu, long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GnnLds L = carve(lds);
-  const int b0 = blockIdx.x * gnn_group(N);
-  const GnnShape sh = make_shape(N, b0, B, sin_dim, lim_enc, elu);
+  const int b0 = blockIdx.x * G;
+  GnnShape sh = make_shape(N, G, b0, B, sin_dim, lim_enc, elu);
+  sh.stamps = stamps;
   lds_zero(lds, kGnnLdsFloats);
+  __syncthreads();
+  gnn_setup(L, sh, P + 2 * W_END);
   __syncthreads();
   for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
     const int r = i / sin_dim, c = i % sin_dim;
     L.SIN[r * LDN + c] = sin[((size_t)b0 * N + r) * sin_dim + c];
   }
   __syncthreads();
-  gnn_forward(L, sh, P, P + 2 * W_END);
+  gnn_forward(L, sh, P);
   for (int i = threadIdx.x; i < 16 * 32; i += blockDim.x) {
     const int r = i >> 5, c = i & 31;
     L.DA[r * LDN + c] = (r < sh.NR) ? dres[((size_t)b0 * N + r) * 32 + c] : 0.0f;
   }
   __syncthreads();
-  f32x4 acc[SL_END];
+  f32x4 acc[SL_END], vacc[VSLOTS];
 #pragma unroll
   for (int k = 0; k < SL_END; ++k) acc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  gnn_backward(L, sh, P + W_END, P + 2 * W_END, acc, dpred != nullptr ? dpred + (size_t)b0 * N * 32 : nullptr, (size_t)N * 32);
+#pragma unroll
+  for (int k = 0; k < VSLOTS; ++k) vacc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  gnn_backward(L, sh, P + W_END, acc, vacc, dpred != nullptr ? dpred + (size_t)b0 * N * 32 : nullptr, (size_t)N * 32);
   for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
     const int r = i / sin_dim, c = i % sin_dim;
     dsin[((size_t)b0 * N + r) * sin_dim + c] = L.DA[r * LDN + c];
   }
-  gnn_store_grads(L, acc, gpart + (size_t)blockIdx.x * kGnnGrads);
+  __syncthreads();
+  gnn_store_grads(acc, vacc, gpart + (size_t)blockIdx.x * kGnnGrads);
 }
 
 // =================================================================================================
@@ -652,13 +775,15 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_k(
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
     float* __restrict__ z, float* __restrict__ zdyn, float* __restrict__ zdstd, float* __restrict__ mean,
     float* __restrict__ stdv, float* __restrict__ pred,
-    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc) {
+    int B, int Ts, int N, int G, int sin_dim, int lim_enc, int elu, LoopConst kc) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GnnLds L = carve(lds);
-  const int b0 = blockIdx.x * gnn_group(N);
-  const GnnShape sh = make_shape(N, b0, B, sin_dim, lim_enc, elu);
+  const int b0 = blockIdx.x * G;
+  const GnnShape sh = make_shape(N, G, b0, B, sin_dim, lim_enc, elu);
   const int E = sin_dim - 16;
   lds_zero(lds, kGnnLdsFloats);
+  __syncthreads();
+  gnn_setup(L, sh, P + 2 * W_END);
   __syncthreads();
   float* Z = L.X;     // [16][20] current state z[t-1]
   for (int i = threadIdx.x; i < sh.NR * 18; i += blockDim.x) Z[(i / 18) * 20 + i % 18] = z1[(size_t)b0 * N * 18 + i];
@@ -672,7 +797,7 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_k(
       L.SIN[r * LDN + c] = v;
     }
     __syncthreads();
-    gnn_forward(L, sh, P, P + 2 * W_END);
+    gnn_forward(L, sh, P);
     loop_epilogue_fwd(L, sh, kc, b0, Ts, ts, zsup, zsstd, eps, z, zdyn, zdstd, mean, stdv, Z);
     if (pred != nullptr) {
       for (int i = threadIdx.x; i < sh.NR * 32; i += blockDim.x) {
@@ -694,17 +819,21 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
     const float* __restrict__ dstd, const float* __restrict__ dpred,
     float* __restrict__ dz1, float* __restrict__ dzsup, float* __restrict__ dzsstd, float* __restrict__ dextra,
     float* __restrict__ gpart,
-    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc) {
+    int B, int Ts, int N, int G, int sin_dim, int lim_enc, int elu, LoopConst kc) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GnnLds L = carve(lds);
-  const int b0 = blockIdx.x * gnn_group(N);
-  const GnnShape sh = make_shape(N, b0, B, sin_dim, lim_enc, elu);
+  const int b0 = blockIdx.x * G;
+  const GnnShape sh = make_shape(N, G, b0, B, sin_dim, lim_enc, elu);
   const int E = sin_dim - 16;
   lds_zero(lds, kGnnLdsFloats);
-  f32x4 acc[SL_END];
+  f32x4 acc[SL_END], vacc[VSLOTS];
 #pragma unroll
   for (int k = 0; k < SL_END; ++k) acc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < VSLOTS; ++k) vacc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   float* CAR = L.X;   // [16][20] gradient carried into z[t] from step t+1
+  __syncthreads();
+  gnn_setup(L, sh, P + 2 * W_END);
   __syncthreads();
   for (int ts = Ts - 1; ts >= 0; --ts) {
     // input state z[t-1]
@@ -717,7 +846,7 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
       L.SIN[r * LDN + c] = v;
     }
     __syncthreads();
-    gnn_forward(L, sh, P, P + 2 * W_END);
+    gnn_forward(L, sh, P);
     // epilogue backward: per (row, d < 16) -> dRES in L.DA, SuPAIR grads, position carry in L.DDIST
     for (int idx = threadIdx.x; idx < 16 * 18; idx += blockDim.x) {
       const int r = idx / 18, q = idx % 18;
@@ -764,7 +893,7 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
       L.DA[r * LDN + 16 + d] = gsd * sd * (1.0f - sd / kd);                 // sd = k sigmoid
     }
     __syncthreads();
-    gnn_backward(L, sh, P + W_END, P + 2 * W_END, acc,
+    gnn_backward(L, sh, P + W_END, acc, vacc,
                  dpred != nullptr ? dpred + ((size_t)b0 * Ts + ts) * N * 32 : nullptr, (size_t)Ts * N * 32);
     // new carry into z[t-1]
     for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
@@ -778,7 +907,8 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
     __syncthreads();
   }
   for (int i = threadIdx.x; i < sh.NR * 18; i += blockDim.x) dz1[(size_t)b0 * N * 18 + i] = CAR[(i / 18) * 20 + i % 18];
-  gnn_store_grads(L, acc, gpart + (size_t)blockIdx.x * kGnnGrads);
+  __syncthreads();
+  gnn_store_grads(acc, vacc, gpart + (size_t)blockIdx.x * kGnnGrads);
 }
 
 // =================================================================================================
@@ -789,13 +919,15 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
 __global__ __launch_bounds__(256) void rollout_fwd_k(const float* __restrict__ z_last, const float* __restrict__ extra,
                                                      const float* __restrict__ P, float* __restrict__ z_pred,
                                                      float* __restrict__ zstd, float* __restrict__ pred,
-                                                     int B, int num, int A, int N, int sin_dim, int lim_enc, int elu, LoopConst kc) {
+                                                     int B, int num, int A, int N, int G, int sin_dim, int lim_enc, int elu, LoopConst kc) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GnnLds L = carve(lds);
-  const int b0 = blockIdx.x * gnn_group(N);
-  const GnnShape sh = make_shape(N, b0, B, sin_dim, lim_enc, elu);
+  const int b0 = blockIdx.x * G;
+  const GnnShape sh = make_shape(N, G, b0, B, sin_dim, lim_enc, elu);
   const int E = sin_dim - 16;
   lds_zero(lds, kGnnLdsFloats);
+  __syncthreads();
+  gnn_setup(L, sh, P + 2 * W_END);
   __syncthreads();
   float* Z = L.X;
   for (int i = threadIdx.x; i < sh.NR * 18; i += blockDim.x) Z[(i / 18) * 20 + i % 18] = z_last[(size_t)b0 * N * 18 + i];
@@ -809,7 +941,7 @@ __global__ __launch_bounds__(256) void rollout_fwd_k(const float* __restrict__ z
       L.SIN[r * LDN + c] = v;
     }
     __syncthreads();
-    gnn_forward(L, sh, P, P + 2 * W_END);
+    gnn_forward(L, sh, P);
     for (int idx = threadIdx.x; idx < sh.NR * 18; idx += blockDim.x) {
       const int r = idx / 18, q = idx % 18;
       const size_t o = ((size_t)(b0 + r / N) * num + t) * N + r % N;

@@ -18,15 +18,23 @@ namespace stove {
 
 constexpr int kMatchN = 8, kMatchF = 8;
 
-__global__ void match_objects_k(const float* __restrict__ feat, long long* __restrict__ idx_out, float* __restrict__ perm_out,
-                                int B, int T, int N, int F, int mode) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// One wave per sequence: the 64 lanes stage the sequence's whole feature track into LDS with
+// coalesced loads (removing T dependent global-load latencies), lane 0 then walks it; the
+// permutations are buffered in LDS and written back coalesced.
+__global__ __launch_bounds__(64) void match_objects_k(const float* __restrict__ feat, long long* __restrict__ idx_out,
+                                                      float* __restrict__ perm_out, int B, int T, int N, int F, int mode) {
+  extern __shared__ float mlds[];                 // [T*N*F] features, then [T*N] int indices
+  const int b = blockIdx.x;
+  const int n_feat = T * N * F;
+  int* ibuf = reinterpret_cast<int*>(mlds + n_feat);
+  for (int i = threadIdx.x; i < n_feat; i += 64) mlds[i] = feat[(size_t)b * n_feat + i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
   float prev[kMatchN][kMatchF], cur[kMatchN][kMatchF], err[kMatchN][kMatchN];
-  const float* fb = feat + (size_t)b * T * N * F;
+  const float* fb = mlds;
   for (int a = 0; a < N; ++a) {
     for (int f = 0; f < F; ++f) prev[a][f] = (fb[a * F + f] + 1.0f) * 0.5f;
-    idx_out[((size_t)b * T) * N + a] = a;
+    ibuf[a] = a;
   }
   for (int t = 1; t < T; ++t) {
     for (int j = 0; j < N; ++j)
@@ -93,7 +101,7 @@ __global__ void match_objects_k(const float* __restrict__ feat, long long* __res
       }
     }
     for (int a = 0; a < N; ++a) {
-      idx_out[((size_t)b * T + t) * N + a] = idx[a];
+      ibuf[t * N + a] = idx[a];
       if (mode != 2) {
         for (int f = 0; f < F; ++f) prev[a][f] = cur[idx[a]][f];
       }
@@ -113,6 +121,9 @@ __global__ void match_objects_k(const float* __restrict__ feat, long long* __res
         for (int f = 0; f < F; ++f) prev[a][f] = nxt[a][f];
     }
   }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < T * N; i += 64) idx_out[(size_t)b * T * N + i] = ibuf[i];
 }
 
 }  // namespace stove

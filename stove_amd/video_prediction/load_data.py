@@ -1,0 +1,72 @@
+"""Dataset of sliding-window clips over simulated sequences (reference model/video_prediction/load_data.py:33-174).
+
+`data` dicts are what the simulators in stove_amd/envs produce (or the reference's pickles):
+X (episodes, frames, res, res, 3) or already channel-first, y (episodes, frames, n_obj, 4) and, for
+action-conditioned data, action / reward / done.  Labels are rescaled to the model's [-1, 1]
+frame; they only feed error metrics, never the loss.
+"""
+import pickle
+
+import numpy as np
+from torch.utils.data import Dataset
+
+
+def load(path):
+    ext = path.split('.')[-1]
+    if ext == 'pkl':
+        with open(path, 'rb') as f:
+            return pickle.load(f)
+    if ext == 'mat':
+        from scipy.io import loadmat
+        return loadmat(path)
+    raise ValueError('File format {} not recognized.'.format(ext))
+
+
+class StoveDataset(Dataset):
+    def __init__(self, config, test=False, data=None):
+        self.c = config
+        if data is None:
+            data = load(self.c.testdata if test else self.c.traindata)
+        self.rl = 'action' in data
+        action_space = data['action_space'] if self.rl else None
+        img = np.asarray(data['X'])[:self.c.num_episodes]
+        if img.shape[-1] == 3:                                   # (.., res, res, 3) -> (.., 3, res, res)
+            img = np.transpose(img, (0, 1, 4, 2, 3))
+        self.total_img = img
+        if (data['y'].shape[0] < self.c.num_episodes) and not test:
+            print('WARNING: Data shape smaller than num_episodes specified.')
+        self.total_data = np.array(data['y'][:self.c.num_episodes], dtype=np.float64)
+        if self.rl:
+            self.total_actions = data['action'][:self.c.num_episodes]
+            self.total_rewards = data['reward'][:self.c.num_episodes] + 1      # to [0, 1] for the BCE loss
+            self.total_dones = data['done'][:self.c.num_episodes] if 'done' in data else np.zeros_like(self.total_rewards)
+        coord_lim = data.get('coord_lim', data.get('hw', 10))
+        self.data_info = {
+            'width': img.shape[-1], 'height': img.shape[-2], 'r': data.get('r', 1.3), 'coord_lim': coord_lim,
+            'action_space': action_space, 'action_conditioned': self.rl,
+            'num_obj': self.total_data.shape[2], 'num_frames': self.total_data.shape[1]}
+        if self.c.debug_add_noise and not test:
+            self.total_data += 0.02 / 2 * coord_lim * np.random.normal(size=self.total_data.shape)
+        self.total_data *= 2 / coord_lim                         # positions and velocities to the [-1, 1] frame
+        self.total_data[..., :2] -= 1
+        n_eps, n_frames = self.total_img.shape[:2]
+        clip_len = (self.c.num_visible + self.c.num_rollout) * self.c.frame_step
+        starts = n_frames - clip_len + 1
+        ep, fr = np.meshgrid(np.arange(n_eps), np.arange(starts))
+        self.idxs = np.stack([ep, fr], 2).reshape(-1, 2)
+
+    def __len__(self):
+        return len(self.idxs)
+
+    def __getitem__(self, idx):
+        step = self.c.frame_step
+        i, j = self.idxs[idx]
+        mid = j + self.c.num_visible * step
+        end = mid + self.c.num_rollout * step
+        sample = {'present_images': self.total_img[i, j:mid:step], 'future_images': self.total_img[i, mid:end:step],
+                  'present_labels': self.total_data[i, j:mid:step], 'future_labels': self.total_data[i, mid:end:step]}
+        if self.rl:
+            for name, arr in (('actions', self.total_actions), ('rewards', self.total_rewards), ('dones', self.total_dones)):
+                sample['present_' + name] = arr[i, j:mid:step]
+                sample['future_' + name] = arr[i, mid:end:step]
+        return sample

@@ -1,0 +1,309 @@
+"""Training loop (reference model/video_prediction/train.py: AbstractTrainer :19-179, Trainer :182-848).
+
+Same public surface -- `Trainer(config, stove, train_dataset, test_dataset)` with `train`, `test`,
+`long_rollout`, `prediction_error`, `error_and_log`, `save`, `load`, `load_encoder` -- and the same
+optimisation recipe (Adam+amsgrad, exponential lr decay with a floor, global-norm clipping at 1,
+BCE reward term ramped in for action-conditioned data).  Additions for the MI355X build:
+one process per GPU with a single RCCL all-reduce of the flat gradient between backward and
+clipping (stove_amd/parallel.py), and frames/s in the log.  Plotting / GIF rendering of the
+reference (matplotlib, imageio) is visualisation and is not reproduced.
+"""
+import itertools
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.optim as optim
+from torch import nn
+from torch.utils.data import DataLoader
+
+from ..parallel import GradBucket
+from ..utils.utils import ExperimentLogger
+
+
+class AbstractTrainer:
+    def __init__(self, config, stove, train_dataset, test_dataset):
+        self.stove = stove
+        self.params = stove.parameters()
+        if config.debug_test_mode:
+            config.print_every = 1
+            config.plot_every = 1
+        self.c = config
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.dataloader = train_dataset
+        self.test_dataset = test_dataset
+        self.test_dataloader = DataLoader(test_dataset, batch_size=self.c.batch_size, shuffle=True,
+                                          num_workers=self.c.num_workers, drop_last=True)
+        self.optimizer = optim.Adam(self.stove.parameters(), lr=self.c.learning_rate, amsgrad=self.c.debug_amsgrad)
+        self.bucket = GradBucket(self.stove, self.world_size)
+        if self.c.load_encoder is not None:
+            self.load_encoder()
+        if not self.c.supair_grad:
+            self.disable_supair_grad()
+        self.epoch_start, self.step_start = 0, 0
+        if self.c.checkpoint_path is not None:
+            self.load()
+
+    @property
+    def dataloader(self):
+        return self._train_dataset
+
+    @dataloader.setter
+    def dataloader(self, train_dataset):
+        self._train_dataset = DataLoader(train_dataset, batch_size=self.c.batch_size, shuffle=True,
+                                         num_workers=self.c.num_workers, drop_last=True)
+
+    # ------------------------------------------------------------------ checkpoints
+    def _state(self, epoch, step):
+        return {'epoch': epoch, 'step': step, 'model_state_dict': self.stove.state_dict(),
+                'optimizer_state_dict': self.optimizer.state_dict()}
+
+    def save(self, epoch, step):
+        if self.rank != 0:
+            return
+        path = os.path.join(self.logger.checkpoint_dir, 'ckpt')
+        torch.save(self._state(epoch, step), path + '_{:05d}'.format(step))
+        torch.save(self._state(epoch, step), path)
+        print('Parameters saved to {}'.format(self.logger.exp_dir))
+
+    def load(self):
+        ckpt = torch.load(self.c.checkpoint_path, map_location=self.c.device)
+        if 'model_state_dict' in ckpt:
+            self.stove.load_state_dict(ckpt['model_state_dict'])
+            self.optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+            self.epoch_start, self.step_start = ckpt['epoch'], ckpt['step']
+        else:
+            self.stove.load_state_dict(ckpt)
+        print('Parameters loaded from {}.'.format(self.c.checkpoint_path))
+
+    def load_encoder(self):
+        pretrained = torch.load(self.c.load_encoder, map_location=self.c.device)['model_state_dict']
+        own = self.stove.state_dict()
+        picked = {k: v for k, v in pretrained.items() if k in own and 'encoder' in k}
+        own.update(picked)
+        self.stove.load_state_dict(own)
+        print('Loaded the following supair parameters from {}:'.format(self.c.load_encoder))
+        print(picked.keys())
+
+    def disable_supair_grad(self):
+        for p in self.stove.sup.parameters():
+            p.requires_grad = False
+
+    def init_t(self, tensor):
+        return tensor.type(self.c.dtype).to(device=self.c.device)
+
+    def adjust_learning_rate(self, optimizer, value, step):
+        lr = max(self.c.learning_rate * np.exp(-step / value), self.c.min_learning_rate)
+        for group in optimizer.param_groups:
+            group['lr'] = lr
+
+
+class Trainer(AbstractTrainer):
+    def __init__(self, config, stove, train_dataset, test_dataset):
+        super().__init__(config, stove, train_dataset, test_dataset)
+        self.logger = ExperimentLogger(self.c)
+        self.z_types = ['z', 'z_sup', 'z_dyn'] if not self.c.supair_only else ['z']
+        if self.c.action_conditioned:
+            self.reward_loss = nn.MSELoss() if self.c.debug_mse else nn.BCELoss()
+
+    # ------------------------------------------------------------------ metrics
+    def prediction_error(self, predicted, true, return_velocity=True, return_id_swaps=True,
+                         return_full=False, return_matched=False, level='sequence'):
+        """Position / velocity error of (n,T,o,4) predictions against the labels under the best
+        object permutation: one permutation per sequence (chosen on the first <=4 frames), or per
+        image for SuPAIR-only training.  Also the number of sequences without identity swaps."""
+        if self.c.supair_only:
+            return_velocity, level = False, 'image'
+        perms = list(itertools.permutations(range(self.c.num_obj)))
+        pos_p, pos_t = predicted[..., :2], true[..., :2]
+        t_fit = min(4, predicted.shape[1])
+        if level == 'sequence':
+            errs = torch.stack([torch.sqrt(((pos_p[:, :t_fit, list(p)] - pos_t[:, :t_fit]) ** 2).sum(-1)).mean((1, 2))
+                                for p in perms], 1)
+            best = errs.argmin(1).cpu().tolist()
+            pos_m = torch.stack([pos_p[i][:, list(perms[j])] for i, j in enumerate(best)], 0)
+        elif level == 'image':
+            pf, tf = pos_p.flatten(end_dim=1), pos_t.flatten(end_dim=1)
+            errs = torch.stack([torch.sqrt(((pf[:, list(p)] - tf) ** 2).sum(-1)).mean(1) for p in perms], 1)
+            best = errs.argmin(1).cpu().tolist()
+            pos_m = torch.stack([pf[i][list(perms[j])] for i, j in enumerate(best)], 0).reshape(pos_p.shape)
+        else:
+            raise ValueError
+        res = {}
+        dist_err = torch.sqrt(((pos_m - pos_t) ** 2).sum(-1))
+        if return_full:
+            per_t = dist_err.mean(-1)
+            res['error'], res['std_error'] = per_t.mean(0).cpu(), per_t.std(0).cpu()
+        else:
+            per_seq = dist_err.mean((1, 2))
+            res['error'], res['std_error'] = per_seq.mean().cpu(), per_seq.std().cpu()
+        if return_velocity:
+            vel_p = predicted[..., 2:4]
+            vel_m = torch.stack([vel_p[i][:, list(perms[j])] for i, j in enumerate(best)], 0)
+            v_err = torch.sqrt(((true[..., 2:] - vel_m) ** 2).sum(-1)).mean(-1)
+            if return_full:
+                res['v_error'], res['std_v_error'] = v_err.mean(0).cpu(), v_err.std(0).cpu()
+            else:
+                res['v_error'], res['std_v_error'] = v_err.mean().cpu(), v_err.std().cpu()
+            if return_matched:
+                res['vel_matched'] = vel_m
+        if return_matched:
+            res['pos_matched'] = pos_m
+        if return_id_swaps:
+            pf, tf = pos_p.flatten(end_dim=1), pos_t.flatten(end_dim=1)
+            per_img = torch.stack([torch.sqrt(((pf[:, list(p)] - tf) ** 2).sum(-1)) for p in perms], 1)
+            order = per_img.mean(-1).argmin(1).reshape(true.shape[:2])
+            stable = (order[:, 1:] == order[:, :-1]).all(1)
+            res['swaps'] = stable.sum().float().cpu() / true.shape[0]
+        return res
+
+    def error_and_log(self, elbo, reward, min_ll, prop_dict, data, step_counter, now, add=''):
+        skip = self.c.skip
+        perf = {'step': step_counter, 'time': now, 'elbo': elbo, 'reward': reward, 'min_ll': min_ll}
+        perf.update({k: v for k, v in prop_dict.items() if k[0] != 'z'})
+        z_true = self.init_t(data['present_labels'][:, skip:])
+        for z in self.z_types:
+            if z in ('z', 'z_sup'):
+                predicted = prop_dict[z][..., 2:]
+                scales = prop_dict[z].flatten(end_dim=2)[:, :2].mean(0)
+                perf['scale_x'], perf['scale_y'] = scales[0], scales[1]
+            else:
+                predicted = prop_dict[z]
+                perf['scale_x'] = perf['scale_y'] = float('nan')
+            perf.update(self.prediction_error(predicted, z_true))
+            for i, std in enumerate(prop_dict[z + '_std']):
+                perf['z_std_{}'.format(i)] = std
+            perf['type'] = z + add
+            if self.rank == 0:
+                self.logger.performance(perf)
+
+    def _reward_term(self, rewards, data, step_counter, key='present_rewards', skip=True):
+        target = self.init_t(data[key][:, self.c.skip:] if skip else data[key])
+        loss = self.reward_loss(rewards.flatten(), target.flatten())
+        ramp = self.c.debug_reward_rampup
+        weight = min(1, step_counter / ramp) if ramp is not False else 1
+        return loss, self.c.debug_reward_factor * weight * loss
+
+    # ------------------------------------------------------------------ training
+    def train_step(self, data, step_counter):
+        """One optimisation step on a batch dict (present_images [, present_actions, present_rewards])."""
+        images = self.init_t(data['present_images'])
+        actions = self.init_t(data['present_actions']) if self.c.action_conditioned else None
+        self.bucket.rebind()
+        self.bucket.zero()
+        elbo, prop_dict, rewards = self.stove(images, step_counter, actions, self.c.supair_only)
+        min_ll = -1.0 * elbo
+        mse_rewards = torch.zeros(1)
+        if self.c.action_conditioned:
+            mse_rewards, term = self._reward_term(rewards, data, step_counter)
+            min_ll = min_ll + term
+        min_ll.backward()
+        self.bucket.all_reduce()                     # [amd] one RCCL all-reduce of the flat gradient
+        if self.c.debug_gradient_clip:
+            torch.nn.utils.clip_grad_norm_(self.stove.parameters(), 1)
+        self.optimizer.step()
+        return elbo, prop_dict, rewards, min_ll, mse_rewards
+
+    def train(self, num_epochs=None):
+        print('Starting training for {}'.format(self.c.description))
+        print('Only pretraining.' if self.c.supair_only else 'Full inference.')
+        step_counter = self.step_start
+        start = time.time()
+        if not self.c.supair_only:
+            self.test(step_counter, start)
+        num_epochs = self.c.num_epochs if num_epochs is None else num_epochs
+        epoch = self.epoch_start
+        for epoch in range(self.epoch_start, num_epochs):
+            for data in self.dataloader:
+                now = time.time() - start
+                step_counter += 1
+                if self.c.debug_anneal_lr:
+                    self.adjust_learning_rate(self.optimizer, self.c.debug_anneal_lr, step_counter)
+                elbo, prop_dict, rewards, min_ll, mse_rewards = self.train_step(data, step_counter)
+                if step_counter % self.c.print_every == 0:
+                    self.error_and_log(elbo.item(), mse_rewards.item(), min_ll.item(), prop_dict, data, step_counter, now)
+                if step_counter % self.c.save_every == 0:
+                    self.save(epoch, step_counter)
+                if step_counter % self.c.long_rollout_every == 0:
+                    self.long_rollout(idx=[0, 1])
+                if self.c.debug_test_mode and not self.c.supair_only:
+                    self.save(0, 0)
+                    self.test(step_counter, now)
+                    break
+            if not self.c.supair_only:
+                self.test(step_counter, start)
+            print('Epoch: ', epoch, ' finished.')
+            if self.c.debug_test_mode:
+                break
+        if not self.c.debug_test_mode and not self.c.supair_only:
+            self.long_rollout(step_counter=step_counter)
+        if not self.c.nolog and self.rank == 0:
+            self.save(epoch, step_counter)
+            open(os.path.join(self.logger.exp_dir, 'success'), 'w').close()
+        print('Finished Training!')
+
+    @torch.no_grad()
+    def test(self, step_counter, start):
+        """ELBO + reconstruction errors on test clips, then rollout errors of the generative model."""
+        self.stove.eval()
+        for i, data in enumerate(self.test_dataloader):
+            now = time.time() - start
+            present = self.init_t(data['present_images'])
+            actions = future_actions = future_rewards = None
+            if self.c.action_conditioned:
+                actions = self.init_t(data['present_actions'])
+                future_actions = self.init_t(data['future_actions'])
+                future_rewards = self.init_t(data['future_rewards'])
+            elbo, prop_dict, rewards = self.stove(present, self.c.plot_every, actions, self.c.supair_only)
+            min_ll = -1.0 * elbo
+            mse_rewards = torch.zeros(1)
+            if self.c.action_conditioned:
+                mse_rewards, term = self._reward_term(rewards, data, step_counter)
+                min_ll = min_ll + term
+            self.error_and_log(elbo.item(), mse_rewards.item(), min_ll.item(), prop_dict, data, step_counter, now, add='_roll')
+            appearances = prop_dict['obj_appearances'][:, -1] if self.c.debug_core_appearance else None
+            z_pred, rewards_pred = self.stove.rollout(prop_dict['z'][:, -1], actions=future_actions, appearance=appearances)
+            future_reward_loss = 0
+            if self.c.action_conditioned:
+                future_reward_loss = self.reward_loss(rewards_pred.flatten(), future_rewards.flatten())
+            perf = {'step': step_counter, 'time': now, 'elbo': elbo, 'reward': future_reward_loss}
+            perf.update(self.prediction_error(z_pred[..., 2:], self.init_t(data['future_labels'])))
+            perf.update({k: v for k, v in prop_dict.items() if k[0] != 'z'})
+            perf['type'] = 'rollout'
+            if self.rank == 0:
+                self.logger.performance(perf)
+            if self.c.debug_test_mode or i > 7:
+                break
+        self.stove.train()
+
+    @torch.no_grad()
+    def long_rollout(self, idx=None, actions=None, step_counter=None, num=500):
+        """Roll the dynamics out for `num` frames from the first visible frames of a few test
+        sequences and log the position error over time (no GIF rendering in this build)."""
+        self.stove.eval()
+        idx = list(idx) if idx is not None else [0, 1]
+        ds = self.test_dataset
+        nv = self.c.num_visible
+        present = self.init_t(torch.from_numpy(np.stack([ds.total_img[i, :nv] for i in idx])))
+        act = self.init_t(torch.from_numpy(np.stack([ds.total_actions[i, :nv] for i in idx]))) \
+            if self.c.action_conditioned else None
+        elbo, prop_dict, _ = self.stove(present, self.c.plot_every, act, False)
+        app = prop_dict['obj_appearances'][:, -1] if self.c.debug_core_appearance else None
+        fut = None
+        if self.c.action_conditioned:
+            fut = self.init_t(torch.from_numpy(np.stack([ds.total_actions[i, nv:] for i in idx])))
+        z_pred, _ = self.stove.rollout(prop_dict['z'][:, -1], num=num, actions=fut, appearance=app)
+        avail = min(num, ds.total_data.shape[1] - nv)
+        out = {'z_pred': z_pred.cpu().numpy()}
+        if avail > 0:
+            true = self.init_t(torch.from_numpy(np.stack([ds.total_data[i, nv:nv + avail] for i in idx])))
+            err = self.prediction_error(z_pred[:, :avail, :, 2:], true, return_full=True, return_id_swaps=False)
+            out.update({k: v.numpy() for k, v in err.items()})
+        if self.rank == 0 and not self.c.nolog:
+            tag = 'final' if step_counter is None else '{:06d}'.format(step_counter)
+            np.save(os.path.join(self.logger.rollout_states_dir, 'rollout_states_{}.npy'.format(tag)), out['z_pred'])
+        self.stove.train()
+        return out
