@@ -375,7 +375,15 @@ int stove_match_objects(const float* feat, long long* idx, float* perm, int B, i
   if (N < 1 || N > kMatchN || F < 1 || F > kMatchF || mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
   const size_t lds = (size_t)T * N * (F + 1) * sizeof(float);
   if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
-  STOVE_LAUNCH(match_objects_k, dim3(B), dim3(64), lds, (hipStream_t)stream, feat, idx, perm, B, T, N, F, mode);
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 3 && F == 2)
+    STOVE_LAUNCH((match_objects_k<3, 2>), dim3(B), dim3(64), lds, st, feat, idx, perm, B, T, N, F, mode);
+  else if (N == 3 && F == 5)
+    STOVE_LAUNCH((match_objects_k<3, 5>), dim3(B), dim3(64), lds, st, feat, idx, perm, B, T, N, F, mode);
+  else if (N == 6 && F == 2)
+    STOVE_LAUNCH((match_objects_k<6, 2>), dim3(B), dim3(64), lds, st, feat, idx, perm, B, T, N, F, mode);
+  else
+    STOVE_LAUNCH((match_objects_k<0, 0>), dim3(B), dim3(64), lds, st, feat, idx, perm, B, T, N, F, mode);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

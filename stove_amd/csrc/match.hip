@@ -21,8 +21,12 @@ constexpr int kMatchN = 8, kMatchF = 8;
 // One wave per sequence: the 64 lanes stage the sequence's whole feature track into LDS with
 // coalesced loads (removing T dependent global-load latencies), lane 0 then walks it; the
 // permutations are buffered in LDS and written back coalesced.
+template <int TN, int TF>
 __global__ __launch_bounds__(64) void match_objects_k(const float* __restrict__ feat, long long* __restrict__ idx_out,
-                                                      float* __restrict__ perm_out, int B, int T, int N, int F, int mode) {
+                                                      float* __restrict__ perm_out, int B, int T, int Nrt, int Frt, int mode) {
+  // compile-time object / feature counts keep every table in registers (fully unrolled loops)
+  const int N = TN > 0 ? TN : Nrt;
+  const int F = TF > 0 ? TF : Frt;
   extern __shared__ float mlds[];                 // [T*N*F] features, then [T*N] int indices
   const int b = blockIdx.x;
   const int n_feat = T * N * F;
@@ -30,60 +34,61 @@ __global__ __launch_bounds__(64) void match_objects_k(const float* __restrict__ 
   for (int i = threadIdx.x; i < n_feat; i += 64) mlds[i] = feat[(size_t)b * n_feat + i];
   __syncthreads();
   if (threadIdx.x == 0) {
-  float prev[kMatchN][kMatchF], cur[kMatchN][kMatchF], err[kMatchN][kMatchN];
+  constexpr int MN = TN > 0 ? TN : kMatchN, MF = TF > 0 ? TF : kMatchF;
+  float prev[MN][MF], cur[MN][MF], err[MN][MN];
   const float* fb = mlds;
-  for (int a = 0; a < N; ++a) {
-    for (int f = 0; f < F; ++f) prev[a][f] = (fb[a * F + f] + 1.0f) * 0.5f;
+  _Pragma("unroll") for (int a = 0; a < N; ++a) {
+    _Pragma("unroll") for (int f = 0; f < F; ++f) prev[a][f] = (fb[a * F + f] + 1.0f) * 0.5f;
     ibuf[a] = a;
   }
   for (int t = 1; t < T; ++t) {
-    for (int j = 0; j < N; ++j)
-      for (int f = 0; f < F; ++f) cur[j][f] = (fb[((size_t)t * N + j) * F + f] + 1.0f) * 0.5f;
+    _Pragma("unroll") for (int j = 0; j < N; ++j)
+      _Pragma("unroll") for (int f = 0; f < F; ++f) cur[j][f] = (fb[((size_t)t * N + j) * F + f] + 1.0f) * 0.5f;
     // err[a][j] = | prev_a - cur_j |^2
-    for (int a = 0; a < N; ++a)
-      for (int j = 0; j < N; ++j) {
+    _Pragma("unroll") for (int a = 0; a < N; ++a)
+      _Pragma("unroll") for (int j = 0; j < N; ++j) {
         float s = 0.0f;
-        for (int f = 0; f < F; ++f) {
+        _Pragma("unroll") for (int f = 0; f < F; ++f) {
           const float d = prev[a][f] - cur[j][f];
           s += d * d;
         }
         err[a][j] = s;
       }
-    int idx[kMatchN];
+    int idx[MN];
     if (mode == 0) {
-      for (int a = 0; a < N; ++a) {
+      _Pragma("unroll") for (int a = 0; a < N; ++a) {
         int best = 0;
-        for (int j = 1; j < N; ++j)
+        _Pragma("unroll") for (int j = 1; j < N; ++j)
           if (err[a][j] < err[a][best]) best = j;
         idx[a] = best;
       }
       bool ok = true;
-      for (int a = 0; a < N; ++a)
-        for (int c = a + 1; c < N; ++c)
+      _Pragma("unroll") for (int a = 0; a < N; ++a)
+        _Pragma("unroll") for (int c = a + 1; c < N; ++c)
           if (idx[a] == idx[c]) ok = false;
       if (!ok) {
-        for (int a = 0; a < N; ++a) {
+        _Pragma("unroll") for (int a = 0; a < N; ++a) {
           int best = 0;
-          for (int j = 1; j < N; ++j)
+          _Pragma("unroll") for (int j = 1; j < N; ++j)
             if (err[a][j] < err[a][best]) best = j;
           idx[a] = best;
-          for (int r = 0; r < N; ++r) err[r][best] = 1e12f;
+          _Pragma("unroll") for (int r = 0; r < N; ++r) err[r][best] = 1e12f;
         }
       }
     } else if (mode == 1) {
-      for (int a = 0; a < N; ++a) idx[a] = 0;
-      for (int round = 0; round < N; ++round) {
+      _Pragma("unroll") for (int a = 0; a < N; ++a) idx[a] = 0;
+      _Pragma("unroll") for (int round = 0; round < N; ++round) {
         int ba = 0, bj = 0;
         float bv = err[0][0];
-        for (int a = 0; a < N; ++a)
-          for (int j = 0; j < N; ++j)
+        _Pragma("unroll") for (int a = 0; a < N; ++a)
+          _Pragma("unroll") for (int j = 0; j < N; ++j)
             if (err[a][j] < bv) {
               bv = err[a][j];
               ba = a;
               bj = j;
             }
         idx[ba] = bj;
-        for (int q = 0; q < N; ++q) {
+        _Pragma("unroll") for (int q = 0; q < N; ++q) {
           err[ba][q] = 3.0e38f;
           err[q][bj] = 3.0e38f;
         }
@@ -91,34 +96,34 @@ __global__ __launch_bounds__(64) void match_objects_k(const float* __restrict__ 
     } else {
       // volatile: current object j goes to its nearest previous slot; slots may collide or stay empty.
       // Reported through perm_out (a 0/1 matrix), idx gets -1 for empty slots.
-      for (int a = 0; a < N; ++a) idx[a] = -1;
-      for (int j = 0; j < N; ++j) {
+      _Pragma("unroll") for (int a = 0; a < N; ++a) idx[a] = -1;
+      _Pragma("unroll") for (int j = 0; j < N; ++j) {
         int best = 0;
-        for (int a = 1; a < N; ++a)
+        _Pragma("unroll") for (int a = 1; a < N; ++a)
           if (err[a][j] < err[best][j]) best = a;
         if (perm_out != nullptr) perm_out[(((size_t)b * T + t) * N + best) * N + j] = 1.0f;
         idx[best] = j;
       }
     }
-    for (int a = 0; a < N; ++a) {
+    _Pragma("unroll") for (int a = 0; a < N; ++a) {
       ibuf[t * N + a] = idx[a];
       if (mode != 2) {
-        for (int f = 0; f < F; ++f) prev[a][f] = cur[idx[a]][f];
+        _Pragma("unroll") for (int f = 0; f < F; ++f) prev[a][f] = cur[idx[a]][f];
       }
     }
     if (mode == 2) {
       // matched state = perm @ current (sum of the assigned objects, zero if none)
-      float nxt[kMatchN][kMatchF];
-      for (int a = 0; a < N; ++a)
-        for (int f = 0; f < F; ++f) nxt[a][f] = 0.0f;
-      for (int j = 0; j < N; ++j) {
+      float nxt[MN][MF];
+      _Pragma("unroll") for (int a = 0; a < N; ++a)
+        _Pragma("unroll") for (int f = 0; f < F; ++f) nxt[a][f] = 0.0f;
+      _Pragma("unroll") for (int j = 0; j < N; ++j) {
         int best = 0;
-        for (int a = 1; a < N; ++a)
+        _Pragma("unroll") for (int a = 1; a < N; ++a)
           if (err[a][j] < err[best][j]) best = a;
-        for (int f = 0; f < F; ++f) nxt[best][f] += cur[j][f];
+        _Pragma("unroll") for (int f = 0; f < F; ++f) nxt[best][f] += cur[j][f];
       }
-      for (int a = 0; a < N; ++a)
-        for (int f = 0; f < F; ++f) prev[a][f] = nxt[a][f];
+      _Pragma("unroll") for (int a = 0; a < N; ++a)
+        _Pragma("unroll") for (int f = 0; f < F; ++f) prev[a][f] = nxt[a][f];
     }
   }
   }

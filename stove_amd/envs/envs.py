@@ -106,11 +106,12 @@ class BillardsEnv(PhysicsEnv):
         for i in range(self.n):                      # walls
             for ax in range(2):
                 nxt = self.x[i, ax] + v[i, ax] * dt
-                if nxt < self.r[i]:
-                    self.x[i, ax] = self.r[i]
+                ri = float(np.ravel(self.r[i])[0])
+                if nxt < ri:
+                    self.x[i, ax] = ri
                     v[i, ax] = -v[i, ax]
-                elif nxt > self.hw - self.r[i]:
-                    self.x[i, ax] = self.hw - self.r[i]
+                elif nxt > self.hw - ri:
+                    self.x[i, ax] = self.hw - ri
                     v[i, ax] = -v[i, ax]
         if self.drift:
             return v

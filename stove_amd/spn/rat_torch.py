@@ -186,8 +186,10 @@ class RatSpn(nn.Module):
     # ------------------------------------------------------------------ kernel plan
     def _make_plan(self):
         """Map the layered structure onto one of the two kernel shapes and precompute the
-        integer tables (registered as non-persistent buffers so they follow .to(device))."""
+        integer tables.  They are plain attributes (not buffers: `Module.type(dtype)` would cast
+        them to float), cached per device on first use."""
         self._kind = None
+        self._plan_cpu, self._plan_dev = {}, {}
         vl = self.vector_list
         a = self.args
         if a.linear_sum_weights or not a.normalized_sums or a.gauss_min_mean is not None \
@@ -220,10 +222,8 @@ class RatSpn(nn.Module):
                 for L in range(4):
                     for i, p in enumerate(leaves[leaf_order[r * 4 + L]].scope):
                         slot[r, p] = L * 25 + i
-            self.register_buffer('_scope', scope, persistent=False)
-            self.register_buffer('_leaf_slot', slot, persistent=False)
-            self.register_buffer('_leaf_order', torch.tensor(leaf_order), persistent=False)
-            self.register_buffer('_sum_order', torch.tensor(sum_order), persistent=False)
+            self._plan_cpu = {'scope': scope, 'leaf_slot': slot, 'leaf_order': torch.tensor(leaf_order),
+                              'sum_order': torch.tensor(sum_order)}
             self._kind = 'obj'
         elif len(vl) == 3 and self.num_dims == 1024 and a.num_gauss == 6:
             R = len(root.inputs)
@@ -239,8 +239,7 @@ class RatSpn(nn.Module):
                     for i, p in enumerate(leaf.scope):
                         side[r, p] = s
                         gidx[r, p] = li * 512 + i
-            self.register_buffer('_side', side, persistent=False)
-            self.register_buffer('_gidx', gidx, persistent=False)
+            self._plan_cpu = {'side': side, 'gidx': gidx}
             self._kind = 'bg'
 
     def _leaf_coef(self):
@@ -252,18 +251,26 @@ class RatSpn(nn.Module):
         inv = 1.0 / var
         return torch.stack([-0.5 * inv, mu * inv, -0.5 * mu * mu * inv - 0.5 * torch.log(2.0 * math.pi * var)], -1)
 
+    def _plan(self, device):
+        key = str(device)
+        if key not in self._plan_dev:
+            self._plan_dev[key] = {k: v.to(device) for k, v in self._plan_cpu.items()}
+        return self._plan_dev[key]
+
     def tables(self):
         """Baked float tables (differentiable functions of the parameters) + integer plan."""
         if self._kind == 'obj':
-            coef = self._leaf_coef()[self._leaf_order]                                   # (24,25,10,3)
+            pl = self._plan(self.output_vector.params.device)
+            coef = self._leaf_coef()[pl['leaf_order']]                                    # (24,25,10,3)
             w = torch.stack([v.params for v in self.vector_list[2]])                      # (12,100,10)
-            wsum = torch.softmax(w, 1)[self._sum_order]
+            wsum = torch.softmax(w, 1)[pl['sum_order']]
             wroot = torch.softmax(self.output_vector.params, 0).view(6, 100)
-            return (coef.contiguous(), wsum.contiguous(), wroot.contiguous(), self._scope, self._leaf_slot)
+            return (coef.contiguous(), wsum.contiguous(), wroot.contiguous(), pl['scope'], pl['leaf_slot'])
         if self._kind == 'bg':
-            coef = self._leaf_coef().reshape(6 * 512, 6, 3)[self._gidx]                   # (3,1024,6,3)
+            pl = self._plan(self.output_vector.params.device)
+            coef = self._leaf_coef().reshape(6 * 512, 6, 3)[pl['gidx']]                   # (3,1024,6,3)
             wroot = torch.softmax(self.output_vector.params, 0).view(3, 36)
-            return (coef.contiguous(), wroot.contiguous(), self._side)
+            return (coef.contiguous(), wroot.contiguous(), pl['side'])
         raise NotImplementedError(
             'RatSpn: no gfx950 kernel for this SPN shape (dims=%d); kernels exist for the STOVE '
             'object (100-dim, 6x random_split(2,2)) and background (1024-dim, 3x random_split(2,1)) SPNs'
