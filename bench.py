@@ -205,18 +205,29 @@ def main():
         if prof:
             name, (total_ms, count) = max(prof.items(), key=lambda kv: kv[1][0])
             n_obj = cfg.num_obj
-            frames_per_launch = a.batch * (a.frames - 2)             # the main likelihood call dominates the average
-            per_launch = {k: v for k, v in prof.items()}
             avg_ms = total_ms / count
-            # algorithmic bytes of the SPN sweep per frame, fwd+bwd: 8200 + 32 N;
-            # the dominant kernel is one direction of it -> half of that per launch
-            alg_bytes = (8200 + 32 * n_obj) / 2 * frames_per_launch
-            roofline = {'bound': 'hbm', 'kernel': name, 'avg_ms': avg_ms, 'launches': count,
-                        'achieved': alg_bytes / (avg_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
-                        'frac': alg_bytes / (avg_ms * 1e-3) / 1e9 / 8000.0, 'traffic': None,
-                        'kernels_ms_per_step': {k: round(v[0] / a.profile_steps, 4) for k, v in sorted(
-                            per_launch.items(), key=lambda kv: -kv[1][0])[:12]}}
-
+            per_step = {k: round(v[0] / a.profile_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:14]}
+            if name.startswith(('dyn_loop', 'gnn_step', 'rollout')):
+                # GNN recursion: dense contraction -> fp32 MFMA peak (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s).
+                # Algorithmic flops per (sequence, step), SURVEY.md section 8d: F = 17408 N + 26944 N (N-1)
+                # forward, 2F for the backward math (the in-kernel recompute is overhead, not counted).
+                F = 17408 * n_obj + 26944 * n_obj * (n_obj - 1)
+                units = a.batch * (a.frames - 2)
+                flops = (2 * F if 'bwd' in name else F) * units
+                ach = flops / (avg_ms * 1e-3) / 1e12
+                roofline = {'bound': 'mfma', 'kernel': name, 'avg_ms': avg_ms, 'launches': count, 'achieved': ach,
+                            'peak': 157.3, 'unit': 'TFLOP/s', 'frac': ach / 157.3, 'traffic': None,
+                            'note': 'latency-bound: %d dependent time steps per launch' % (a.frames - 2),
+                            'kernels_ms_per_step': per_step}
+            else:
+                # SPN / scene sweep: scan-shaped -> HBM 8 TB/s.  Algorithmic bytes per frame fwd+bwd =
+                # 8200 + 32 N; one direction of it per launch.
+                frames_per_launch = a.batch * (a.frames - 1)
+                alg_bytes = (8200 + 32 * n_obj) / 2 * frames_per_launch
+                ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+                roofline = {'bound': 'hbm', 'kernel': name, 'avg_ms': avg_ms, 'launches': count, 'achieved': ach,
+                            'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0, 'traffic': None,
+                            'note': 'VALU-bound sweep (~120 flop/B, ridge ~20 flop/B)', 'kernels_ms_per_step': per_step}
     log('kernel profile done')
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

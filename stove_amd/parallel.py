@@ -13,46 +13,46 @@ import torch.distributed as dist
 
 
 class GradBucket:
-    """Makes every `p.grad` of `module` a view into one flat fp32 buffer and all-reduces that buffer."""
+    """Flat fp32 gradient bucket of a module.
+
+    Autograd writes `p.grad` as usual (no extra accumulate kernels).  `all_reduce()` packs the
+    gradients into ONE contiguous buffer with a single `torch.cat`, all-reduces that buffer, and
+    re-points every `p.grad` at its slice (views, no unflatten copies).  Parameters that never
+    receive a gradient (the unused dynamics cores 1-2, reference stove.py:698-699) are left out,
+    identically on every rank.  With a single rank nothing is done at all.
+    """
 
     def __init__(self, module, world_size=None):
         self.params = [p for p in module.parameters() if p.requires_grad]
         if world_size is None:
             world_size = dist.get_world_size() if dist.is_initialized() else 1
         self.world_size = world_size
-        total = sum(p.numel() for p in self.params)
-        ref = self.params[0]
-        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
-        off = 0
+        self.flat = None
+
+    def rebind(self):
+        """Kept for API symmetry: nothing to do, gradients are packed lazily in all_reduce()."""
+
+    def zero(self):
         for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        live = [p for p in self.params if p.grad is not None]
+        self.flat = torch.cat([p.grad.reshape(-1) for p in live])
+        off = 0
+        for p in live:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
-
-    def rebind(self):
-        """Re-attach the views if something replaced p.grad (e.g. zero_grad(set_to_none=True))."""
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            view = self.flat[off:off + n].view_as(p)
-            if p.grad is None:
-                view.zero_()
-                p.grad = view
-            elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
-                p.grad = view
-            off += n
-
-    def zero(self):
-        self.flat.zero_()
+        return self.flat
 
     def all_reduce(self):
         """Average the gradients over the ranks (no-op for a single rank)."""
         if self.world_size <= 1:
             return
-        self.rebind()
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(self.world_size)
+        flat = self.pack()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(self.world_size)
 
 
 def shard_batch(tensor, rank, world_size):

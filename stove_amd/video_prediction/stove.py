@@ -208,15 +208,16 @@ class Stove(nn.Module):
             log_z_s, z_std_s = torch.stack(lq, 1), torch.stack(zst, 1)
             rewards = torch.stack(rew, 1) if c.action_conditioned else torch.zeros(Ts)
 
-        # 3. ELBO: image likelihood (SPNs), q(z|x) and the generative transition likelihood
-        z_f = self.sup.sy_from_quotient(z_s.flatten(end_dim=2))
-        img_lik, sup_prop = self.sup.likelihood(x[:, skip:], z_f[..., :4])
+        # 3. ELBO: image likelihood (SPNs), q(z|x) and the generative transition likelihood.
+        # The reference scores frames skip..T-1 (sampled z) and frame 1..skip-1 (SuPAIR mean) in two
+        # likelihood calls (stove.py:731-736); here both go through ONE fused scene launch.
+        z_all = torch.cat([z_sup[:, 1:skip], z_s[..., :4]], 1)                 # (n, T-1, o, 4) [sx, sy/sx, x, y]
+        z_all = self.sup.sy_from_quotient(z_all.flatten(end_dim=2))
+        lik_all, sup_prop = self.sup.likelihood(x[:, 1:], z_all, log_from=skip - 1)
         self.prop_dict.update(sup_prop)
-        z_sup_tmp = self.sup.sy_from_quotient(z_sup[:, 1:skip])
-        saved_step = self.sup.step_counter
-        self.sup.step_counter = 1                            # the t = 1 term is not logged (reference discards its prop)
-        img_lik_sup, _ = self.sup.likelihood(x[:, 1:skip], z_sup_tmp.flatten(end_dim=2))
-        self.sup.step_counter = saved_step
+        lik_all = lik_all.view(n, T - 1)
+        img_lik = lik_all[:, skip - 1:].reshape(-1)
+        img_lik_sup = lik_all[:, :skip - 1].reshape(-1)
         log_z_f = log_z_s.sum((-2, -1)).flatten()
         trans_lik = self.transition_lik(means=z_dyn_s, results=z_s[..., 2:]).sum((-2, -1)).flatten(end_dim=1)
         elbo = trans_lik + img_lik - log_z_f

@@ -30,12 +30,13 @@ class Supair(nn.Module):
         self.bg_spn = prob._get_bg_spn(self.c, seed=self.c.random_seed)
 
     # ------------------------------------------------------------------ likelihood
-    def likelihood(self, x, z_obj):
+    def likelihood(self, x, z_obj, log_from=0):
         """log p(x, z) per frame.
 
         x (n, T, c, w, h) frames; z_obj (n*T*O, 4) = [sx, sy, x, y] -> (n*T,), prop_dict.
         log p = bgSPN(x | mask) + sum_k objSPN(glimpse_k | occlusion_k) sx_k sy_k
                 + sum_k log Exponential(overlap_beta)(overlap_k)      (reference supair.py:44-110)
+        `log_from` (build addition) restricts the logged part means to frames x[:, log_from:].
         """
         if self.c.channels != 1 or x.shape[-1] != 32 or x.shape[-2] != 32 \
                 or self.c.patch_width != 10 or self.c.patch_height != 10:
@@ -47,7 +48,8 @@ class Supair(nn.Module):
         if ((self.step_counter % self.c.print_every == 0)
                 or (self.step_counter % self.c.plot_every == 0)):
             if self.c.debug:
-                m = parts.mean(0)
+                # `log_from`: first time index whose frames enter the logged bg/patch/overlap means
+                m = parts.view(x.shape[0], x.shape[1], 3)[:, log_from:].mean((0, 1))
                 self.prop_dict['bg'] = m[0]
                 self.prop_dict['patch'] = m[1]
                 self.prop_dict['overlap'] = m[2]

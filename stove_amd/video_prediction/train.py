@@ -192,7 +192,6 @@ class Trainer(AbstractTrainer):
         """One optimisation step on a batch dict (present_images [, present_actions, present_rewards])."""
         images = self.init_t(data['present_images'])
         actions = self.init_t(data['present_actions']) if self.c.action_conditioned else None
-        self.bucket.rebind()
         self.bucket.zero()
         elbo, prop_dict, rewards = self.stove(images, step_counter, actions, self.c.supair_only)
         min_ll = -1.0 * elbo

@@ -41,17 +41,14 @@ def _worker(rank, world, port, out):
     x = torch.randn(8, 6, dtype=torch.float64)
     xs = shard_batch(x, rank, world)
     assert xs.shape[0] == 4
-    for _ in range(2):                      # second pass: views must survive zero + backward
+    for _ in range(2):                      # two steps: the bucket is re-packed every step
         bucket.zero()
         _loss(model, xs).backward()
-        ptrs = [p.grad.data_ptr() for p in bucket.params]
         bucket.all_reduce()
-        assert ptrs == [p.grad.data_ptr() for p in bucket.params]
-    # zero_grad(set_to_none=True) detaches the views; rebind must restore them
-    model.zero_grad(set_to_none=True)
-    bucket.rebind()
-    _loss(model, xs).backward()
-    bucket.all_reduce()
+        off = 0
+        for p in bucket.params:             # after the exchange every grad is a view into the one flat buffer
+            assert p.grad.data_ptr() == bucket.flat[off:].data_ptr()
+            off += p.numel()
     torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)       # after the reduce, as train.py:471-472
     if rank == 0:
         torch.save(bucket.flat.clone(), out)
@@ -75,11 +72,14 @@ def test_gloo_allreduce_matches_single_process(tmp_path):
 def test_bucket_is_one_contiguous_buffer_single_rank():
     model = _make_model()
     b = GradBucket(model, 1)
-    assert b.flat.numel() == sum(p.numel() for p in model.parameters())
     _loss(model, torch.randn(4, 6, dtype=torch.float64)).backward()
+    b.all_reduce()        # no-op for a single rank
+    flat = b.pack()
+    assert flat.numel() == sum(p.numel() for p in model.parameters())
     off = 0
     for p in model.parameters():
-        assert p.grad.data_ptr() == b.flat[off:].data_ptr()
+        assert p.grad.data_ptr() == flat[off:].data_ptr()
         off += p.numel()
-    b.all_reduce()        # no-op without a process group
-    assert float(b.flat.abs().sum()) > 0
+    assert float(flat.abs().sum()) > 0
+    b.zero()
+    assert all(p.grad is None for p in model.parameters())
