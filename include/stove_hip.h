@@ -127,15 +127,18 @@ int stove_gnn_debug_stamps(const float* s_in, const float* params, const float* 
  * z1 (B,N,18) state at t=skip-1 [sx,sy/sx,x,y,vx,vy,latent]; zsup,zsstd (B,Ts,N,6) SuPAIR means/stds for
  * t=skip..T-1; eps (B,Ts,N,18) standard-normal draws; extra (B,Ts,N,sin_dim-16) or NULL.
  * outputs (B,Ts,N,.): z 18, zdyn 16, zdstd 16, mean 18, std 18, pred 32 (NULL to skip). */
+/* act: optional saved activations (stove_dynloop_act_floats() floats, ~11.6 KB per sequence-step at N=3)
+ * that let the backward skip its recompute; pass NULL to both calls to recompute instead. */
+size_t stove_dynloop_act_floats(int B, int Ts, int N);
 int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                       const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred,
-                      int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
+                      float* act, int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
                       void* stream);
 size_t stove_dynloop_bwd_ws_bytes(int B, int N);
 /* upstream gradients dz,dzdyn,dmean,dstd,dpred may each be NULL. */
 int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
-                      const float* params, const float* z, const float* dz, const float* dzdyn, const float* dmean,
-                      const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd, float* dextra,
+                      const float* params, const float* z, const float* act, const float* dz, const float* dzdyn,
+                      const float* dmean, const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd, float* dextra,
                       float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var,
                       float vel_std, float lat_std, void* stream);
 

@@ -279,8 +279,13 @@ int stove_gnn_debug_stamps(const float* s_in, const float* params, const float* 
   return 0;
 }
 
+size_t stove_dynloop_act_floats(int B, int Ts, int N) {
+  const int g = gnn_group_for(B, N);
+  return (size_t)stove_gnn_blocks(B, N) * Ts * gnn_act_floats(N, g);
+}
+
 int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
-                      const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred,
+                      const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred, float* act,
                       int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
                       void* stream) {
   if (B == 0 || Ts == 0) return 0;
@@ -289,7 +294,7 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
   if (rc) return rc;
   LoopConst kc{pos_var, vel_std, lat_std};
   STOVE_LAUNCH(dyn_loop_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
-                     z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, B, Ts, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
+                     z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -297,7 +302,7 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
 size_t stove_dynloop_bwd_ws_bytes(int B, int N) { return stove_gnn_bwd_ws_bytes(B, N); }
 
 int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
-                      const float* params, const float* z, const float* dz, const float* dzdyn, const float* dmean,
+                      const float* params, const float* z, const float* act, const float* dz, const float* dzdyn, const float* dmean,
                       const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd, float* dextra,
                       float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var,
                       float vel_std, float lat_std, void* stream) {
@@ -309,7 +314,7 @@ int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, co
   if (rc) return rc;
   LoopConst kc{pos_var, vel_std, lat_std};
   const int nb = stove_gnn_blocks(B, N);
-  STOVE_LAUNCH(dyn_loop_bwd_k, dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, z1, zsup, zsstd, eps, extra, params, z,
+  STOVE_LAUNCH(dyn_loop_bwd_k, dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, z1, zsup, zsstd, eps, extra, params, z, act,
                      dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, (float*)ws, B, Ts, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
   STOVE_LAUNCH_CHECK();
   STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 255) / 256), dim3(256), 0, st, (const float*)ws, g_params, kGnnGrads, nb, 0);

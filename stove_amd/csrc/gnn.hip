@@ -23,6 +23,12 @@ namespace stove {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
+// global store/load of the wave (vmcnt(0)); inside the time loop that would put the latency of the
+// streaming output / activation stores on the critical path of every stage.  Nothing in these kernels
+// hands global data from one wave to another inside a launch, so LDS ordering is all that is needed.
+#define WG_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 // ---- parameter image (floats) ----------------------------------------------------------------
 // P = [ W image | WT image | VEC ];  W: row-major [out][K];  WT: the transposes [K][out].
 constexpr int W_ENC = 0, W_S0 = 1024, W_S1 = 2048, W_EF = 3072, W_R1 = 11264, W_A1 = 13312, W_R2 = 15360,
@@ -171,7 +177,7 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
       S[r * LDC + c] = (c < sh.lim_enc) ? L.SIN[r * LDN + c] : v + V[V_ENC + c];
     });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 1);
   // 2. self-dynamics layer 0 and the factorised first edge layer (rel_i | rel_j | att_i | att_j)
   for (int t = wv; t < 18; t += 4) {
@@ -206,7 +212,7 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
     L.DIST[e] = d;
     L.AUXE[e * 16 + 1] = d;
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 2);
   // 3. edge pre-activations (gather) + self-dynamics layer 1
   {
@@ -228,7 +234,7 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
       tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.SD[r * LDN + c] = v + V[V_S1 + c] + L.H1[r * LDN + c]; });
     }
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 3);
   // 4. second edge layers (64 -> 32), relation and attention
   for (int t = wv; t < sh.ME * 4; t += 4) {
@@ -241,7 +247,7 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
       tile_each(acc, m * 16, n * 16, [&](int r, int c, float v) { L.A2[r * LDN + c] = act_phi(v + V[V_BA1 + c], sh.elu); });
     }
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 4);
   // 5. third edge layers: relation 32 -> 32 (+skip), attention 32 -> 1 -> exp
   if (tid < sh.ME * 16) {
@@ -254,7 +260,7 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
     const f32x4 acc = tile_AB<32>(L.R2 + m * 16 * LDN, LDN, Wf + W_R2 + n * 16 * 32, 32);
     tile_each(acc, m * 16, n * 16, [&](int r, int c, float v) { L.R3[r * LDN + c] = v + V[V_BR2 + c] + L.R2[r * LDN + c]; });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 5);
   // 6. masked, attention-weighted aggregation over the other objects
   for (int idx = tid; idx < 16 * 32; idx += blockDim.x) {
@@ -268,39 +274,39 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
     }
     L.PRED[r * LDN + c] = v;
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 6);
   // 7-9. affector MLP
   if (wv < 2) {
     const f32x4 acc = tile_AB<32>(L.PRED, LDN, Wf + W_F0 + wv * 16 * 32, 32);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.F1[r * LDN + c] = tanhf(v + V[V_F0 + c]); });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 7);
   if (wv < 2) {
     const f32x4 acc = tile_AB<32>(L.F1, LDN, Wf + W_F1 + wv * 16 * 32, 32);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.F2[r * LDN + c] = tanhf(v + V[V_F1 + c]) + L.F1[r * LDN + c]; });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 8);
   if (wv < 2) {
     const f32x4 acc = tile_AB<32>(L.F2, LDN, Wf + W_F2 + wv * 16 * 32, 32);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.CAT[r * LDC + c] = v + V[V_F2 + c]; });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 9);
   // 10-11. output MLP on [affector | s]
   if (wv < 2) {
     const f32x4 acc = tile_AB<64>(L.CAT, LDC, Wf + W_O0 + wv * 16 * 64, 64);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.O1[r * LDN + c] = tanhf(v + V[V_O0 + c]); });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 10);
   if (wv < 2) {
     const f32x4 acc = tile_AB<32>(L.O1, LDN, Wf + W_O1 + wv * 16 * 32, 32);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.RES[r * LDN + c] = v + V[V_O1 + c] + L.O1[r * LDN + c]; });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 11);
 }
 
@@ -380,7 +386,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
       L.DB[r * LDN + c] = (v + L.DA[r * LDN + c]) * (1.0f - o * o);       // d pre-tanh of out.0
     });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 21);
   // b2. out.0 on CAT = [F3 | S]
   dW_layer<32, 64, SL_O0>(acc, L.DB, LDN, L.CAT, LDC, 1, wv);
@@ -389,7 +395,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     const f32x4 t = tile_AB<32>(L.DB, LDN, WT + W_O0 + wv * 16 * 32, 32);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) { L.DCAT[r * LDC + c] = v; });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 22);
   // b3. affector.2:  F3 = F2 W^T + b      (dF3 = DCAT[:, :32])
   dW_layer<32, 32, SL_F2>(acc, L.DCAT, LDC, L.F2, LDN, 1, wv);
@@ -402,7 +408,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
       L.DC[r * LDN + c] = v * (1.0f - th * th);                            // du
     });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 23);
   // b4. affector.1:  F2 = tanh(F1 W^T + b) + F1
   dW_layer<32, 32, SL_F1>(acc, L.DC, LDN, L.F1, LDN, 1, wv);
@@ -414,7 +420,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
       L.DB[r * LDN + c] = (v + L.DA[r * LDN + c]) * (1.0f - f1 * f1);      // d pre-tanh of affector.0
     });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 24);
   // b5. affector.0:  F1 = tanh(PRED W^T + b)
   dW_layer<32, 32, SL_F0>(acc, L.DB, LDN, L.PRED, LDN, 1, wv);
@@ -427,7 +433,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
       L.DC[r * LDN + c] = v + up;                                          // dPRED = dSD
     });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 25);
   // b6a. d attention: one wave-half (32 lanes = 32 channels) per edge
   for (int e = wv * 2 + (lane >> 5); e < sh.ME * 16; e += 8) {
@@ -446,7 +452,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
       L.AUXE[e * 16 + 2] = dq;
     }
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 26);
   // b6b. dR3 in place; attention output layer grads (A2 still holds the forward values)
   vec_layer<VT_WA2, 2>(vacc, L.A2, LDN, L.AUXE, sh.ME, wv);
@@ -458,7 +464,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     if (ni >= 0 && ni != L.EJ[e]) v = L.DC[ni * LDN + c] * L.ATT[e];
     L.R3[e * LDN + c] = v;
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 27);
   // b7. rel.2:  R3 = R2 W^T + b + R2 ;  attention pre-activation grads in place in A2
   dW_layer<32, 32, SL_R2>(acc, L.R3, LDN, L.R2, LDN, sh.ME, wv);
@@ -475,14 +481,14 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     const float y = L.A2[e * LDN + c];
     L.A2[e * LDN + c] = L.DATT[e] * V[V_WA2 + c] * dphi_from_out(y, sh.elu);
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 28);
   // b8. rel.1 / att.1 weight grads (inputs R1 / A1 still intact)
   dW_layer<32, 64, SL_R1>(acc, L.E32, LDN, L.R1, LDC, sh.ME, wv);
   dW_layer<32, 64, SL_A1>(acc, L.A2, LDN, L.A1, LDC, sh.ME, wv);
   vec_layer<VT_R1, 2>(vacc, L.E32, LDN, L.AUXE, sh.ME, wv);
   vec_layer<VT_A1, 2>(vacc, L.A2, LDN, L.AUXE, sh.ME, wv);
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 29);
   // b9. rel.1 / att.1 data grads, multiplied by phi'(first-layer output), in place in R1 / A1
   for (int t = wv; t < sh.ME * 8; t += 4) {
@@ -495,7 +501,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
       tile_each(a, m * 16, n * 16, [&](int r, int c, float v) { L.A1[r * LDC + c] = v * dphi_from_out(L.A1[r * LDC + c], sh.elu); });
     }
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 30);
   // b10. first edge layer: scatter (as a gather) into dP, bias / distance-weight grads, d distance
   vec_layer<VT_R0, 4>(vacc, L.R1, LDC, L.AUXE, sh.ME, wv);
@@ -520,7 +526,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     v = wave_sum_lane63(v);
     if (lane == 63) L.DATT[e] = v;
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 31);
   // b11. edge-first + self.1
   dW_layer<256, 32, SL_EF>(acc, L.P, LDP, S, LDC, 1, wv);
@@ -548,7 +554,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     }
     L.DDIST[tid] = s;
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 32);
   // b12. self.0 ; total dS ; split into the encoder output part and the pass-through part
   dW_layer<32, 32, SL_S0>(acc, L.DB, LDN, S, LDC, 1, wv);
@@ -563,7 +569,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
       L.F1[r * LDN + c] = raw ? tot : 0.0f;      // straight to SIN (F1 is dead by now)
     });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 33);
   // b13. encoder
   dW_layer<32, 32, SL_ENC>(acc, L.DC, LDN, L.SIN, LDN, 1, wv);
@@ -572,7 +578,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     const f32x4 t = tile_AB<32>(L.DC, LDN, WT + W_ENC + wv * 16 * 32, 32);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) { L.DA[r * LDN + c] = v + L.F1[r * LDN + c]; });
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_stamp(sh, 34);
 }
 
@@ -662,14 +668,14 @@ __global__ __launch_bounds__(256) void gnn_step_fwd_k(const float* __restrict__ 
   const int b0 = blockIdx.x * G;
   const GnnShape sh = make_shape(N, G, b0, B, sin_dim, lim_enc, elu);
   lds_zero(lds, kGnnLdsFloats);
-  __syncthreads();
+  WG_SYNC();
   gnn_setup(L, sh, P + 2 * W_END);
-  __syncthreads();
+  WG_SYNC();
   for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
     const int r = i / sin_dim, c = i % sin_dim;
     L.SIN[r * LDN + c] = sin[((size_t)b0 * N + r) * sin_dim + c];
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_forward(L, sh, P);
   for (int i = threadIdx.x; i < sh.NR * 32; i += blockDim.x) {
     const int r = i >> 5, c = i & 31;
@@ -688,20 +694,20 @@ __global__ __launch_bounds__(256) void gnn_step_bwd_k(const float* __restrict__ 
   GnnShape sh = make_shape(N, G, b0, B, sin_dim, lim_enc, elu);
   sh.stamps = stamps;
   lds_zero(lds, kGnnLdsFloats);
-  __syncthreads();
+  WG_SYNC();
   gnn_setup(L, sh, P + 2 * W_END);
-  __syncthreads();
+  WG_SYNC();
   for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
     const int r = i / sin_dim, c = i % sin_dim;
     L.SIN[r * LDN + c] = sin[((size_t)b0 * N + r) * sin_dim + c];
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_forward(L, sh, P);
   for (int i = threadIdx.x; i < 16 * 32; i += blockDim.x) {
     const int r = i >> 5, c = i & 31;
     L.DA[r * LDN + c] = (r < sh.NR) ? dres[((size_t)b0 * N + r) * 32 + c] : 0.0f;
   }
-  __syncthreads();
+  WG_SYNC();
   f32x4 acc[SL_END], vacc[VSLOTS];
 #pragma unroll
   for (int k = 0; k < SL_END; ++k) acc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(256) void gnn_step_bwd_k(const float* __restrict__ 
     const int r = i / sin_dim, c = i % sin_dim;
     dsin[((size_t)b0 * N + r) * sin_dim + c] = L.DA[r * LDN + c];
   }
-  __syncthreads();
+  WG_SYNC();
   gnn_store_grads(acc, vacc, gpart + (size_t)blockIdx.x * kGnnGrads);
 }
 
@@ -725,6 +731,93 @@ __global__ __launch_bounds__(256) void gnn_step_bwd_k(const float* __restrict__ 
 //   extra   (B,Ts,N,E)    per-step extra core inputs (action embedding, appearance) of step t-1, E = sin_dim-16
 // outputs, all (B,Ts,N,.): z 18, zdyn 16, zdstd 16, mean 18, std 18, pred 32 (optional)
 // =================================================================================================
+
+// ---- saved activations of one step (what gnn_backward + the epilogue backward read) ---------------
+// dense block per (workgroup, step): 7 node buffers [NRmax][32] (SIN,H1,PRED,F1,F2,O1,RES), CAT [NRmax][64],
+// R1,A1 [NEmax][64], R2,A2,R3 [NEmax][32], ATT, DIST [NEmax]  with NRmax = G N, NEmax = G N N.
+__host__ __device__ inline size_t gnn_act_floats(int N, int G) {
+  const size_t nr = (size_t)G * N, ne = (size_t)G * N * N;
+  return nr * (7 * 32 + 64) + ne * (2 * 64 + 3 * 32 + 2);
+}
+template <int Q, bool FROM_G>
+__device__ __forceinline__ void seg_get(float* v, const float* lds, int ld, int shift, int n, const float* __restrict__ g) {
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int i = (int)threadIdx.x + q * 256;
+    float x = 0.0f;
+    if (i < n) x = FROM_G ? g[i] : lds[(i >> shift) * ld + (i & ((1 << shift) - 1))];
+    v[q] = x;
+  }
+}
+template <int Q, bool TO_G>
+__device__ __forceinline__ void seg_put(const float* v, float* lds, int ld, int shift, int n, float* __restrict__ g) {
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int i = (int)threadIdx.x + q * 256;
+    if (i < n) {
+      if (TO_G) g[i] = v[q];
+      else lds[(i >> shift) * ld + (i & ((1 << shift) - 1))] = v[q];
+    }
+  }
+}
+// Two-phase transfer: every source read (global loads for a restore, LDS reads for a save) is issued
+// before the first dependent write, so a restore costs ONE memory latency instead of one per buffer.
+// Q* = elements per thread of each buffer class (256 threads).
+template <bool STORE, int QN, int QC, int Q64, int Q32>
+__device__ __forceinline__ void gnn_act_xfer(const GnnLds& L, const GnnShape& sh, float* __restrict__ g, int nr_max, int ne_max) {
+  constexpr int NV = 7 * QN + QC + 2 * Q64 + 3 * Q32 + 2;
+  float v[NV];
+  float* node32[7] = {L.SIN, L.H1, L.PRED, L.F1, L.F2, L.O1, L.RES};
+  float* edge64[2] = {L.R1, L.A1};
+  float* edge32[3] = {L.R2, L.A2, L.R3};
+  float* edge1[2] = {L.ATT, L.DIST};
+  const int n32 = sh.NR * 32, n64 = sh.NR * 64, e64 = sh.NE * 64, e32 = sh.NE * 32, e1 = sh.NE;
+  {
+    const float* gg = g;
+    int o = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { seg_get<QN, !STORE>(v + o, node32[k], LDN, 5, n32, gg); o += QN; gg += nr_max * 32; }
+    seg_get<QC, !STORE>(v + o, L.CAT, LDC, 6, n64, gg); o += QC; gg += nr_max * 64;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { seg_get<Q64, !STORE>(v + o, edge64[k], LDC, 6, e64, gg); o += Q64; gg += ne_max * 64; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { seg_get<Q32, !STORE>(v + o, edge32[k], LDN, 5, e32, gg); o += Q32; gg += ne_max * 32; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { seg_get<1, !STORE>(v + o, edge1[k], 1, 0, e1, gg); o += 1; gg += ne_max; }
+  }
+  {
+    float* gg = g;
+    int o = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { seg_put<QN, STORE>(v + o, node32[k], LDN, 5, n32, gg); o += QN; gg += nr_max * 32; }
+    seg_put<QC, STORE>(v + o, L.CAT, LDC, 6, n64, gg); o += QC; gg += nr_max * 64;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { seg_put<Q64, STORE>(v + o, edge64[k], LDC, 6, e64, gg); o += Q64; gg += ne_max * 64; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { seg_put<Q32, STORE>(v + o, edge32[k], LDN, 5, e32, gg); o += Q32; gg += ne_max * 32; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      seg_put<1, STORE>(v + o, edge1[k], 1, 0, e1, gg);
+      if (!STORE && k == 1 && (int)threadIdx.x < e1) L.AUXE[threadIdx.x * 16 + 1] = v[o];   // dist also feeds the aux MFMA operand
+      o += 1;
+      gg += ne_max;
+    }
+  }
+}
+// shape classes with a register-resident transfer: 0: N<=3-ish, 1: up to G*N = 8 nodes / 36 edges, 2: none (recompute)
+__device__ __forceinline__ int gnn_act_class(const GnnShape& sh) {
+  if (sh.NR * 64 <= 256 && sh.NE * 64 <= 768) return 0;
+  if (sh.NR * 64 <= 512 && sh.NE * 64 <= 2304) return 1;
+  return 2;
+}
+template <bool STORE>
+__device__ __forceinline__ bool gnn_act_any(const GnnLds& L, const GnnShape& sh, float* g, int nr_max, int ne_max) {
+  const int cls = gnn_act_class(sh);
+  if (cls == 0) gnn_act_xfer<STORE, 1, 1, 3, 2>(L, sh, g, nr_max, ne_max);
+  else if (cls == 1) gnn_act_xfer<STORE, 1, 2, 9, 5>(L, sh, g, nr_max, ne_max);
+  return cls < 2;
+}
+
 struct LoopConst {
   float pos_var, vel_std, lat_std;
 };
@@ -774,20 +867,21 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_k(
     const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
     float* __restrict__ z, float* __restrict__ zdyn, float* __restrict__ zdstd, float* __restrict__ mean,
-    float* __restrict__ stdv, float* __restrict__ pred,
+    float* __restrict__ stdv, float* __restrict__ pred, float* __restrict__ act,
     int B, int Ts, int N, int G, int sin_dim, int lim_enc, int elu, LoopConst kc) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GnnLds L = carve(lds);
   const int b0 = blockIdx.x * G;
   const GnnShape sh = make_shape(N, G, b0, B, sin_dim, lim_enc, elu);
   const int E = sin_dim - 16;
+  const size_t act_stride = gnn_act_floats(N, G);
   lds_zero(lds, kGnnLdsFloats);
-  __syncthreads();
+  WG_SYNC();
   gnn_setup(L, sh, P + 2 * W_END);
-  __syncthreads();
+  WG_SYNC();
   float* Z = L.X;     // [16][20] current state z[t-1]
   for (int i = threadIdx.x; i < sh.NR * 18; i += blockDim.x) Z[(i / 18) * 20 + i % 18] = z1[(size_t)b0 * N * 18 + i];
-  __syncthreads();
+  WG_SYNC();
   for (int ts = 0; ts < Ts; ++ts) {
     for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
       const int r = i / sin_dim, c = i % sin_dim;
@@ -796,8 +890,10 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_k(
       else v = extra[(((size_t)(b0 + r / N) * Ts + ts) * N + r % N) * E + (c - 16)];
       L.SIN[r * LDN + c] = v;
     }
-    __syncthreads();
+    WG_SYNC();
     gnn_forward(L, sh, P);
+    if (act != nullptr)      // keep this step's activations for the backward (instead of recomputing them there)
+      gnn_act_any<true>(L, sh, act + ((size_t)blockIdx.x * Ts + ts) * act_stride, G * N, G * N * N);
     loop_epilogue_fwd(L, sh, kc, b0, Ts, ts, zsup, zsstd, eps, z, zdyn, zdstd, mean, stdv, Z);
     if (pred != nullptr) {
       for (int i = threadIdx.x; i < sh.NR * 32; i += blockDim.x) {
@@ -805,7 +901,7 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_k(
         pred[(((size_t)(b0 + r / N) * Ts + ts) * N + r % N) * 32 + c] = L.PRED[r * LDN + c];
       }
     }
-    __syncthreads();
+    WG_SYNC();
   }
 }
 
@@ -814,7 +910,7 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_k(
 __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
     const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
-    const float* __restrict__ z,
+    const float* __restrict__ z, const float* __restrict__ act,
     const float* __restrict__ dz, const float* __restrict__ dzdyn, const float* __restrict__ dmean,
     const float* __restrict__ dstd, const float* __restrict__ dpred,
     float* __restrict__ dz1, float* __restrict__ dzsup, float* __restrict__ dzsstd, float* __restrict__ dextra,
@@ -832,21 +928,29 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
 #pragma unroll
   for (int k = 0; k < VSLOTS; ++k) vacc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   float* CAR = L.X;   // [16][20] gradient carried into z[t] from step t+1
-  __syncthreads();
+  WG_SYNC();
   gnn_setup(L, sh, P + 2 * W_END);
-  __syncthreads();
+  WG_SYNC();
   for (int ts = Ts - 1; ts >= 0; --ts) {
-    // input state z[t-1]
-    for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
-      const int r = i / sin_dim, c = i % sin_dim;
-      const int b = b0 + r / N, n = r % N;
-      float v;
-      if (c < 16) v = (ts == 0) ? z1[((size_t)b * N + n) * 18 + 2 + c] : z[(((size_t)b * Ts + ts - 1) * N + n) * 18 + 2 + c];
-      else v = extra[(((size_t)b * Ts + ts) * N + n) * E + (c - 16)];
-      L.SIN[r * LDN + c] = v;
+    bool restored = false;
+    if (act != nullptr) {
+      // forward activations of this step, saved by dyn_loop_fwd_k
+      restored = gnn_act_any<false>(L, sh, const_cast<float*>(act) + ((size_t)blockIdx.x * Ts + ts) * gnn_act_floats(N, G), G * N, G * N * N);
+      if (restored) WG_SYNC();
     }
-    __syncthreads();
-    gnn_forward(L, sh, P);
+    if (!restored) {
+      // recompute them from the input state z[t-1]
+      for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
+        const int r = i / sin_dim, c = i % sin_dim;
+        const int b = b0 + r / N, n = r % N;
+        float v;
+        if (c < 16) v = (ts == 0) ? z1[((size_t)b * N + n) * 18 + 2 + c] : z[(((size_t)b * Ts + ts - 1) * N + n) * 18 + 2 + c];
+        else v = extra[(((size_t)b * Ts + ts) * N + n) * E + (c - 16)];
+        L.SIN[r * LDN + c] = v;
+      }
+      WG_SYNC();
+      gnn_forward(L, sh, P);
+    }
     // epilogue backward: per (row, d < 16) -> dRES in L.DA, SuPAIR grads, position carry in L.DDIST
     for (int idx = threadIdx.x; idx < 16 * 18; idx += blockDim.x) {
       const int r = idx / 18, q = idx % 18;
@@ -892,7 +996,7 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
       L.DA[r * LDN + d] = gzd * 0.5f * (1.0f - m * m);                      // m = 2 sigmoid - 1
       L.DA[r * LDN + 16 + d] = gsd * sd * (1.0f - sd / kd);                 // sd = k sigmoid
     }
-    __syncthreads();
+    WG_SYNC();
     gnn_backward(L, sh, P + W_END, acc, vacc,
                  dpred != nullptr ? dpred + ((size_t)b0 * Ts + ts) * N * 32 : nullptr, (size_t)Ts * N * 32);
     // new carry into z[t-1]
@@ -904,10 +1008,10 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
       else dextra[(((size_t)b * Ts + ts) * N + n) * E + (c - 16)] = g;
     }
     if (threadIdx.x < sh.NR * 2) CAR[(threadIdx.x >> 1) * 20 + (threadIdx.x & 1)] = 0.0f;
-    __syncthreads();
+    WG_SYNC();
   }
   for (int i = threadIdx.x; i < sh.NR * 18; i += blockDim.x) dz1[(size_t)b0 * N * 18 + i] = CAR[(i / 18) * 20 + i % 18];
-  __syncthreads();
+  WG_SYNC();
   gnn_store_grads(acc, vacc, gpart + (size_t)blockIdx.x * kGnnGrads);
 }
 
@@ -926,12 +1030,12 @@ __global__ __launch_bounds__(256) void rollout_fwd_k(const float* __restrict__ z
   const GnnShape sh = make_shape(N, G, b0, B, sin_dim, lim_enc, elu);
   const int E = sin_dim - 16;
   lds_zero(lds, kGnnLdsFloats);
-  __syncthreads();
+  WG_SYNC();
   gnn_setup(L, sh, P + 2 * W_END);
-  __syncthreads();
+  WG_SYNC();
   float* Z = L.X;
   for (int i = threadIdx.x; i < sh.NR * 18; i += blockDim.x) Z[(i / 18) * 20 + i % 18] = z_last[(size_t)b0 * N * 18 + i];
-  __syncthreads();
+  WG_SYNC();
   for (int t = 0; t < num; ++t) {
     for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
       const int r = i / sin_dim, c = i % sin_dim;
@@ -940,7 +1044,7 @@ __global__ __launch_bounds__(256) void rollout_fwd_k(const float* __restrict__ z
       else v = extra[(((size_t)(b0 + r / N) * A + (t % A)) * N + r % N) * E + (c - 16)];
       L.SIN[r * LDN + c] = v;
     }
-    __syncthreads();
+    WG_SYNC();
     gnn_forward(L, sh, P);
     for (int idx = threadIdx.x; idx < sh.NR * 18; idx += blockDim.x) {
       const int r = idx / 18, q = idx % 18;
@@ -962,7 +1066,7 @@ __global__ __launch_bounds__(256) void rollout_fwd_k(const float* __restrict__ z
         pred[(((size_t)(b0 + r / N) * num + t) * N + r % N) * 32 + c] = L.PRED[r * LDN + c];
       }
     }
-    __syncthreads();
+    WG_SYNC();
   }
 }
 

@@ -264,10 +264,14 @@ class _DynLoopFn(torch.autograd.Function):
                 return torch.empty(B, Ts, N, d, dtype=torch.float32, device=dev)
             z, zdyn, zdstd, mean, std = out(18), out(16), out(16), out(18), out(18)
             pred = out(32) if want_pred else None
+            # saved activations (291 MB at B=256, T=100, N=3) so the backward does not recompute the forward
+            act = None
+            if any(ctx.needs_input_grad):
+                act = torch.empty(lib.stove_dynloop_act_floats(B, Ts, N) + 1, dtype=torch.float32, device=dev)
             check(lib.stove_dynloop_fwd(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z), ptr(zdyn),
-                                        ptr(zdstd), ptr(mean), ptr(std), ptr(pred), B, Ts, N, sd, int(lim_enc), int(elu),
-                                        *[float(c) for c in consts], stream()), 'stove_dynloop_fwd')
-        ctx.save_for_backward(z1, zsup, zsstd, eps, extra, params, z)
+                                        ptr(zdstd), ptr(mean), ptr(std), ptr(pred), ptr(act), B, Ts, N, sd, int(lim_enc),
+                                        int(elu), *[float(c) for c in consts], stream()), 'stove_dynloop_fwd')
+        ctx.save_for_backward(z1, zsup, zsstd, eps, extra, params, z, act)
         ctx.cfg = (int(lim_enc), int(elu), tuple(float(c) for c in consts), sd)
         ctx.mark_non_differentiable(zdstd)
         if pred is None:
@@ -278,7 +282,7 @@ class _DynLoopFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz, dzdyn, _dzdstd, dmean, dstd, dpred):
         lib = _lib.load()
-        z1, zsup, zsstd, eps, extra, params, z = ctx.saved_tensors
+        z1, zsup, zsstd, eps, extra, params, z, act = ctx.saved_tensors
         lim_enc, elu, consts, sd = ctx.cfg
         B, Ts, N = zsup.shape[:3]
         dev = z1.device
@@ -291,7 +295,7 @@ class _DynLoopFn(torch.autograd.Function):
             dextra = torch.empty_like(extra) if extra is not None else None
             g = torch.empty(lib.stove_gnn_grad_floats(), dtype=torch.float32, device=dev)
             ws = _ws(lib.stove_dynloop_bwd_ws_bytes(B, N), dev)
-            check(lib.stove_dynloop_bwd(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z),
+            check(lib.stove_dynloop_bwd(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z), ptr(act),
                                         ptr(up(dz, z)), ptr(up(dzdyn, z)), ptr(up(dmean, z)), ptr(up(dstd, z)),
                                         ptr(up(dpred, z)), ptr(dz1), ptr(dzsup), ptr(dzsstd), ptr(dextra), ptr(g), ptr(ws),
                                         B, Ts, N, sd, lim_enc, elu, *consts, stream()), 'stove_dynloop_bwd')
