@@ -228,6 +228,17 @@ def main():
                 roofline = {'bound': 'hbm', 'kernel': name, 'avg_ms': avg_ms, 'launches': count, 'achieved': ach,
                             'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0, 'traffic': None,
                             'note': 'VALU-bound sweep (~120 flop/B, ridge ~20 flop/B)', 'kernels_ms_per_step': per_step}
+    if roofline is not None:
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (if present)
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_traffic.json')))[-1:]:
+            try:
+                tr = json.load(open(path)).get(roofline['kernel'])
+                if tr and a.workload == 'billiards' and a.batch == 256 and a.frames == 100:
+                    roofline['traffic'] = tr['hbm_bytes_per_launch']
+                    roofline['traffic_source'] = os.path.basename(path)
+            except (OSError, ValueError):
+                pass
     log('kernel profile done')
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -241,7 +252,7 @@ def main():
             'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{a.workload} 32x32 T={a.frames} batch={a.batch}/GPU (BASELINE.json configs[1])',
+            'config': {'workload': f'{a.workload} {cfg.num_obj}-object 32x32 T={a.frames} batch={a.batch}/GPU' + (' (BASELINE.json configs[1])' if a.workload == 'billiards' and a.batch == 256 and a.frames == 100 else ''),
                        'objects': cfg.num_obj, 'global_batch': a.batch * world,
                        'step': 'forward+backward+allreduce+clip+adam(amsgrad)', 'parallelism': f'dp{world}',
                        'elbo_last_step': elbo_val},

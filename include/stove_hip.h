@@ -155,6 +155,14 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
  * perm (B,T,N,N) f32, pre-zeroed, only written in mode 2 (may be NULL otherwise). */
 int stove_match_objects(const float* feat, long long* idx, float* perm, int B, int T, int N, int F, int mode, void* stream);
 
+/* ---- gate math of RnnStates' LSTM (encoder.py:43-51, torch.nn.LSTM cell, gate order i,f,g,o); the GEMMs
+ * around it stay on rocBLAS.  gx (n,4H): x W_ih^T + b_ih + b_hh; gh (n,4H): h_prev W_hh^T or NULL; c_prev
+ * (n,H) or NULL (zero state).  bwd: dh, dc_in (NULL = 0) -> dg (n,4H), dc_out (n,H); dgx_acc (n,4H) gets
+ * dg added (first != 0: overwritten), the running sum over the unrolled steps that feeds dW_ih. */
+int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, float* c, float* h, int n, int H, void* stream);
+int stove_lstm_cell_bwd(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
+                        const float* dc_in, float* dg, float* dc_out, float* dgx_acc, int first, int n, int H, void* stream);
+
 /* ---- measurement hooks (bench.py): when enabled, every kernel launch of this library is bracketed by
  * two HIP events recorded on the launch stream.  stove_profile_report() synchronises them, writes
  * "kernel\ttotal_ms\tcount\n" lines into buf and clears the records; returns the bytes needed.

@@ -17,7 +17,7 @@ EXPORTS = [
     'stove_scene_saved_floats', 'stove_scene_fwd', 'stove_scene_bwd_ws_bytes', 'stove_scene_bwd',
     'stove_scene_glimpses',
     'stove_gnn_param_floats', 'stove_gnn_grad_floats', 'stove_gnn_blocks', 'stove_gnn_fwd', 'stove_gnn_bwd_ws_bytes',
-    'stove_gnn_bwd', 'stove_dynloop_act_floats', 'stove_dynloop_fwd', 'stove_dynloop_bwd_ws_bytes', 'stove_dynloop_bwd', 'stove_rollout_fwd', 'stove_match_objects', 'stove_profile_enable', 'stove_profile_report', 'stove_gnn_debug_stamps',
+    'stove_gnn_bwd', 'stove_dynloop_act_floats', 'stove_dynloop_fwd', 'stove_dynloop_bwd_ws_bytes', 'stove_dynloop_bwd', 'stove_rollout_fwd', 'stove_match_objects', 'stove_profile_enable', 'stove_profile_report', 'stove_gnn_debug_stamps', 'stove_lstm_cell_fwd', 'stove_lstm_cell_bwd',
 ]
 
 
@@ -65,6 +65,8 @@ def _declare(lib):
         'stove_rollout_fwd': (I, [P] * 6 + [I] * 7 + [F] * 3 + [P]),
         'stove_match_objects': (I, [P, P, P, I, I, I, I, I, P]),
         'stove_profile_enable': (None, [I]),
+        'stove_lstm_cell_fwd': (I, [P, P, P, P, P, I, I, P]),
+        'stove_lstm_cell_bwd': (I, [P] * 9 + [I, I, I, P]),
         'stove_gnn_debug_stamps': (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
         'stove_profile_report': (S, [c_char_p, S]),
     }

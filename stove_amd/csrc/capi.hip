@@ -9,6 +9,7 @@
 #include "scene.hip"
 #include "gnn.hip"
 #include "match.hip"
+#include "lstm.hip"
 
 namespace stove {
 
@@ -332,6 +333,28 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
   LoopConst kc{pos_var, vel_std, lat_std};
   STOVE_LAUNCH(rollout_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
                      z_last, extra, params, z_pred, zstd, pred, B, num, A < 1 ? 1 : A, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- LSTM cell (recognition network)
+int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, float* c, float* h, int n, int H, void* stream) {
+  if (n == 0) return 0;
+  if (H % 4) return (int)hipErrorInvalidValue;
+  const size_t total = (size_t)n * (H / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  STOVE_LAUNCH(lstm_cell_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, gx, gh, c_prev, c, h, n, H);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_lstm_cell_bwd(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
+                        const float* dc_in, float* dg, float* dc_out, float* dgx_acc, int first, int n, int H, void* stream) {
+  if (n == 0) return 0;
+  if (H % 4) return (int)hipErrorInvalidValue;
+  const size_t total = (size_t)n * (H / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  STOVE_LAUNCH(lstm_cell_bwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, gx, gh, c_prev, c, dh, dc_in, dg, dc_out, dgx_acc, first, n, H);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -349,3 +349,62 @@ def match_objects(feat, mode):
         check(lib.stove_match_objects(ptr(feat), ptr(idx), ptr(perm), B, T, N, Fd, MATCH_MODES[mode], stream()),
               'stove_match_objects')
     return idx, perm
+
+
+class _EncoderLstmFn(torch.autograd.Function):
+    """num_steps LSTM steps on the SAME input x (reference encoder.py:43-51): hs (n, num_steps, H).
+
+    rocBLAS GEMMs + the fused gate kernels of csrc/lstm.hip.  The input projection x W_ih^T is
+    computed once; its gradient is the sum of the per-step gate gradients (accumulated in-kernel),
+    so dW_ih is ONE (4H x n) @ (n x D) GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, num_steps):
+        lib = _lib.load()
+        x, w_ih, w_hh = _f32(x), _f32(w_ih), _f32(w_hh)
+        n, H = x.shape[0], w_hh.shape[1]
+        dev = x.device
+        with torch.cuda.device(dev):
+            gx = torch.addmm(b_ih + b_hh, x, w_ih.t())
+            hs = torch.empty(num_steps, n, H, dtype=torch.float32, device=dev)
+            cs = torch.empty(num_steps, n, H, dtype=torch.float32, device=dev)
+            ghs = []
+            for k in range(num_steps):
+                gh = torch.mm(hs[k - 1], w_hh.t()) if k > 0 else None
+                ghs.append(gh)
+                check(lib.stove_lstm_cell_fwd(ptr(gx), ptr(gh), ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(hs[k]),
+                                              n, H, stream()), 'stove_lstm_cell_fwd')
+        ctx.save_for_backward(x, w_ih, w_hh, gx, hs, cs, *[g for g in ghs if g is not None])
+        ctx.num_steps = num_steps
+        return hs.transpose(0, 1)
+
+    @staticmethod
+    def backward(ctx, dhs):
+        lib = _lib.load()
+        x, w_ih, w_hh, gx, hs, cs = ctx.saved_tensors[:6]
+        ghs = [None] + list(ctx.saved_tensors[6:])
+        K = ctx.num_steps
+        n, H = x.shape[0], w_hh.shape[1]
+        dev = x.device
+        dhs = _f32(dhs.transpose(0, 1))                       # (K, n, H)
+        with torch.cuda.device(dev):
+            dgx = torch.empty_like(gx)
+            dg = torch.empty_like(gx)
+            dc = [torch.empty(n, H, dtype=torch.float32, device=dev) for _ in range(2)]
+            d_whh = torch.zeros_like(w_hh)
+            dh = dhs[K - 1]
+            for k in range(K - 1, -1, -1):
+                check(lib.stove_lstm_cell_bwd(ptr(gx), ptr(ghs[k]), ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(dh),
+                                              ptr(dc[(k + 1) % 2]) if k < K - 1 else None, ptr(dg), ptr(dc[k % 2]), ptr(dgx),
+                                              1 if k == K - 1 else 0, n, H, stream()), 'stove_lstm_cell_bwd')
+                if k > 0:
+                    d_whh.addmm_(dg.t(), hs[k - 1])
+                    dh = torch.addmm(dhs[k - 1], dg, w_hh)
+            d_wih = torch.mm(dgx.t(), x)
+            d_b = dgx.sum(0)
+        dx = torch.mm(dgx, w_ih) if ctx.needs_input_grad[0] else None
+        return dx, d_wih, d_whh, d_b, d_b, None
+
+
+def encoder_lstm(x, w_ih, w_hh, b_ih, b_hh, num_steps):
+    return _EncoderLstmFn.apply(x, w_ih, w_hh, b_ih, b_hh, num_steps)

@@ -4,10 +4,13 @@ API and parameter names of the reference's model/video_prediction/encoder.py:7-5
 (`RnnStates`: LSTM(c*w*h -> 256) unrolled for num_obj steps on the SAME flattened frame, then
 256 -> 50 -> 8).  Because the input is identical at every step, its projection through
 W_ih is computed once (one (nT x 1024) @ (1024 x 1024) GEMM on rocBLAS/hipBLASLt) instead of
-num_obj times; the recurrent part is num_obj small GEMMs + gate math.
+num_obj times; the recurrent part is num_obj small GEMMs, and all gate math between the GEMMs is
+the fused HIP cell of csrc/lstm.hip (`ops.encoder_lstm`), forward and backward.
 """
 import torch
 import torch.nn as nn
+
+from .. import ops
 
 
 class RnnStates(nn.Module):
@@ -29,15 +32,5 @@ class RnnStates(nn.Module):
         """frames (-1, c, w, h) -> (-1, num_obj, 8): per-object (mean, std) codes of [sx, sy/sx, x, y]."""
         x = frames.flatten(start_dim=1)
         rnn = self.rnn
-        gates_x = torch.addmm(rnn.bias_ih_l0 + rnn.bias_hh_l0, x, rnn.weight_ih_l0.t())
-        h = x.new_zeros(x.shape[0], self.lstm_size)
-        cell = x.new_zeros(x.shape[0], self.lstm_size)
-        hs = []
-        for k in range(self.c.num_obj):
-            gates = gates_x if k == 0 else torch.addmm(gates_x, h, rnn.weight_hh_l0.t())
-            i, f, g, o = gates.chunk(4, 1)
-            cell = torch.sigmoid(f) * cell + torch.sigmoid(i) * torch.tanh(g)
-            h = torch.sigmoid(o) * torch.tanh(cell)
-            hs.append(h)
-        out = torch.stack(hs, 1)
-        return self.fc2(torch.sigmoid(self.fc1(out)))
+        hs = ops.encoder_lstm(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, self.c.num_obj)
+        return self.fc2(torch.sigmoid(self.fc1(hs)))

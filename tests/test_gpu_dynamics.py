@@ -183,3 +183,21 @@ def test_rollout_std_and_sampling_api():
         assert err(zf[:, t], z) < 1e-5
     zsamp, lq, _ = st.rollout(z_last, num=3, sample=True)
     assert zsamp.shape == (7, 3, 3, 18) and lq.shape == (7, 3, 3, 16)
+
+
+def test_encoder_lstm_against_oracle():
+    """Fused LSTM cell (csrc/lstm.hip) + rocBLAS GEMMs against the oracle's restatement of RnnStates."""
+    from stove_amd.video_prediction.encoder import RnnStates
+    c, structs, params = oracle_setup(torch.float64)
+    enc = fill_analytic(RnnStates(make_cfg()), 'sup.encoder.').to(DEV)
+    g = torch.Generator().manual_seed(9)
+    x64 = torch.rand(37, 1, 32, 32, generator=g, dtype=torch.float64)
+    w64 = torch.rand(37, 3, 8, generator=g, dtype=torch.float64)
+    out_o = O.encoder_forward(c, params, x64)
+    (out_o * w64).sum().backward()
+    out_d = enc(x64.float().to(DEV))
+    assert out_d.shape == (37, 3, 8)
+    assert err(out_d, out_o) < 1e-5
+    (out_d * w64.float().to(DEV)).sum().backward()
+    for name, p in enc.named_parameters():
+        assert err(p.grad, params['sup.encoder.' + name].grad) < 1e-3, name
