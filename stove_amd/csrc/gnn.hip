@@ -180,15 +180,63 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
   WG_SYNC();
   gnn_stamp(sh, 1);
   // 2. self-dynamics layer 0 and the factorised first edge layer (rel_i | rel_j | att_i | att_j)
-  for (int t = wv; t < 18; t += 4) {
-    if (t < 2) {
-      const f32x4 acc = tile_AB<32>(S, LDC, Wf + W_S0 + t * 16 * 32, 32);
-      tile_each(acc, 0, t * 16, [&](int r, int c, float v) { L.H1[r * LDN + c] = act_phi(v + V[V_S0 + c], sh.elu); });
-    } else {
-      const int n = t - 2;
-      const f32x4 acc = tile_AB<32>(S, LDC, Wf + W_EF + n * 16 * 32, 32);
-      tile_each(acc, 0, n * 16, [&](int r, int c, float v) { L.P[r * LDP + c] = v; });
+  {
+    // every tile of this stage multiplies the same 16 x 32 activation block S: read its fragment once,
+    // issue all weight loads of the wave's tiles up front, then run the independent MFMA chains interleaved
+    // (wave w: edge-first column tiles w, w+4, w+8, w+12; waves 0/1 additionally self.0 tile w)
+    const int i = lane_id() & 15, kq = lane_id() >> 4;
+    const float4 a0 = *reinterpret_cast<const float4*>(S + i * LDC + 4 * kq);
+    const float4 a1 = *reinterpret_cast<const float4*>(S + i * LDC + 16 + 4 * kq);
+    float4 b0[5], b1[5];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* w = Wf + W_EF + (wv + 4 * q) * 16 * 32 + i * 32 + 4 * kq;
+      b0[q] = *reinterpret_cast<const float4*>(w);
+      b1[q] = *reinterpret_cast<const float4*>(w + 16);
     }
+    {
+      const float* w = Wf + W_S0 + (wv & 1) * 16 * 32 + i * 32 + 4 * kq;
+      b0[4] = *reinterpret_cast<const float4*>(w);
+      b1[4] = *reinterpret_cast<const float4*>(w + 16);
+    }
+    f32x4 c[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) c[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#define STOVE_MMA_STEP(AV, BV)                                                          \
+    _Pragma("unroll") for (int q = 0; q < 5; ++q)                                       \
+      if (q < 4 || wv < 2) c[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, BV[q], c[q], 0, 0, 0);
+    float bx[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) bx[q] = b0[q].x;
+    STOVE_MMA_STEP(a0.x, bx)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) bx[q] = b0[q].y;
+    STOVE_MMA_STEP(a0.y, bx)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) bx[q] = b0[q].z;
+    STOVE_MMA_STEP(a0.z, bx)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) bx[q] = b0[q].w;
+    STOVE_MMA_STEP(a0.w, bx)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) bx[q] = b1[q].x;
+    STOVE_MMA_STEP(a1.x, bx)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) bx[q] = b1[q].y;
+    STOVE_MMA_STEP(a1.y, bx)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) bx[q] = b1[q].z;
+    STOVE_MMA_STEP(a1.z, bx)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) bx[q] = b1[q].w;
+    STOVE_MMA_STEP(a1.w, bx)
+#undef STOVE_MMA_STEP
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = wv + 4 * q;
+      tile_each(c[q], 0, n * 16, [&](int r, int cc, float v) { L.P[r * LDP + cc] = v; });
+    }
+    if (wv < 2) tile_each(c[4], 0, wv * 16, [&](int r, int cc, float v) { L.H1[r * LDN + cc] = act_phi(v + V[V_S0 + cc], sh.elu); });
   }
   if (tid >= 192 && tid - 192 < sh.ME * 16) {          // squared distances (wave 3 has the fewest tiles)
     const int e = tid - 192;
@@ -532,15 +580,20 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   dW_layer<256, 32, SL_EF>(acc, L.P, LDP, S, LDC, 1, wv);
   dW_layer<32, 32, SL_S1>(acc, L.DC, LDN, L.H1, LDN, 1, wv);
   vec_layer<VT_S1, 2>(vacc, L.DC, LDN, L.AUXN, 1, wv);
+  {
+    // dS from the edge layers: dP (16 x 256) Wef (256 x 32).  Each wave contracts one quarter of K for both
+    // column tiles (two interleaved chains of 16 MFMAs instead of one chain of 64); b12 adds the 4 partials.
+    float* part = (wv == 0) ? L.DA : (wv == 1) ? L.SD : (wv == 2) ? L.RES : L.O1;     // SD, RES, O1 are dead here
+    const f32x4 t0 = tile_AB<64>(L.P + wv * 64, LDP, WT + W_EF + wv * 64, 256);
+    const f32x4 t1 = tile_AB<64>(L.P + wv * 64, LDP, WT + W_EF + 16 * 256 + wv * 64, 256);
+    tile_each(t0, 0, 0, [&](int r, int c, float v) { part[r * LDN + c] = v; });
+    tile_each(t1, 0, 16, [&](int r, int c, float v) { part[r * LDN + c] = v; });
+  }
   if (wv < 2) {
     const f32x4 t = tile_AB<32>(L.DC, LDN, WT + W_S1 + wv * 16 * 32, 32);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
       L.DB[r * LDN + c] = (v + L.DC[r * LDN + c]) * dphi_from_out(L.H1[r * LDN + c], sh.elu);   // d pre-act of self.0
     });
-  } else {
-    const int n = wv - 2;
-    const f32x4 t = tile_AB<256>(L.P, LDP, WT + W_EF + n * 16 * 256, 256);
-    tile_each(t, 0, n * 16, [&](int r, int c, float v) { L.DA[r * LDN + c] = v; });           // dS from the edge layers
   }
   if (tid < 32) {
     const int r = tid >> 1, ax = tid & 1;
@@ -562,7 +615,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   if (wv < 2) {
     const f32x4 t = tile_AB<32>(L.DB, LDN, WT + W_S0 + wv * 16 * 32, 32);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
-      float tot = v + L.DA[r * LDN + c] + L.DCAT[r * LDC + 32 + c];
+      float tot = v + ((L.DA[r * LDN + c] + L.SD[r * LDN + c]) + (L.RES[r * LDN + c] + L.O1[r * LDN + c])) + L.DCAT[r * LDC + 32 + c];
       if (c < 2) tot += L.DDIST[r * 2 + c];
       const bool raw = c < sh.lim_enc;
       L.DC[r * LDN + c] = raw ? 0.0f : tot;      // d encoder output
