@@ -133,10 +133,17 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the STOVE hot path has no CPU fallback')
+    # one process per GPU; STOVE_DIST_BACKEND=gloo lets the multi-process path be exercised on a
+    # single-GPU box (ranks then share cuda:0) -- the driver's runs use RCCL ('nccl')
+    backend = os.environ.get('STOVE_DIST_BACKEND', 'nccl')
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from stove_amd import build as _build
     if rank == 0 or world == 1:
@@ -195,13 +202,18 @@ def main():
     # ---- per-kernel HIP-event timing of extra steps (profiling hooks off during the timed region)
     roofline = None
     lib = _lib.load()
-    if rank == 0 and a.profile_steps > 0:
-        lib.stove_profile_enable(1)
+    prof = None
+    if a.profile_steps > 0:
+        # every rank runs the extra steps (they contain the collective); only rank 0 records events
+        if rank == 0:
+            lib.stove_profile_enable(1)
         for i in range(a.profile_steps):
             step(a.warmup + a.steps + i)
         torch.cuda.synchronize()
-        prof = _lib.profile_report()
-        lib.stove_profile_enable(0)
+        if rank == 0:
+            prof = _lib.profile_report()
+            lib.stove_profile_enable(0)
+    if rank == 0 and a.profile_steps > 0:
         if prof:
             name, (total_ms, count) = max(prof.items(), key=lambda kv: kv[1][0])
             n_obj = cfg.num_obj
