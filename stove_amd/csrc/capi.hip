@@ -264,7 +264,7 @@ int stove_gnn_bwd(const float* s_in, const float* params, const float* d_result,
   STOVE_LAUNCH(gnn_step_bwd_k, dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, s_in, params, d_result, d_pred,
                      d_s_in, (float*)ws, B, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, (long long*)nullptr);
   STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 255) / 256), dim3(256), 0, st, (const float*)ws, g_params, kGnnGrads, nb, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 31) / 32), dim3(256), 0, st, (const float*)ws, g_params, kGnnGrads, nb, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -318,7 +318,7 @@ int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, co
   STOVE_LAUNCH(dyn_loop_bwd_k, dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, z1, zsup, zsstd, eps, extra, params, z, act,
                      dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, (float*)ws, B, Ts, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
   STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 255) / 256), dim3(256), 0, st, (const float*)ws, g_params, kGnnGrads, nb, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 31) / 32), dim3(256), 0, st, (const float*)ws, g_params, kGnnGrads, nb, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -23,6 +23,15 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2,3
   return v;
 }
+// Sum within each 16-lane row only (4 fused DPP adds); the row totals end up in lanes 15, 31, 47, 63.
+// Cheaper than a full wave sum when the four row totals can be combined later (e.g. by an LDS stage).
+__device__ __forceinline__ float row_sum_lane15(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, false));
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
   v = wave_sum_lane63(v);
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));

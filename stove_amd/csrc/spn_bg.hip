@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_fwd_k(
     const int* __restrict__ side, const float* __restrict__ coef, float* __restrict__ ell_part, int n_frames) {
   constexpr int NO = R * 2 * G;
   constexpr int NW = kBgThreads / 64;
-  __shared__ float part[2][NW][NO];
+  __shared__ float part[2][NW * 4][NO];     // one partial per 16-lane row of every wave
   const int half = blockIdx.x % kBgHalves;
   const int p = half * kBgThreads + threadIdx.x;
   const int lane = lane_id(), wv = wave_id();
@@ -79,16 +79,17 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_fwd_k(
       w = (marg != nullptr) ? 1.0f - fminf(fmaxf(marg[(size_t)f * kBgPix + p], 0.0f), 1.0f) : 1.0f;
     }
     const float wx = w * x, wxx = wx * x;
-    float* pp = part[it & 1][wv];
+    float* pp = part[it & 1][wv * 4 + (lane >> 4)];
+    const bool row_last = (lane & 15) == 15;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const float val = fmaf(wxx, cf[r][g][0], fmaf(wx, cf[r][g][1], w * cf[r][g][2]));
         const float v1 = sd[r] ? val : 0.0f;
-        const float s0 = wave_sum_lane63(val - v1);
-        const float s1 = wave_sum_lane63(v1);
-        if (lane == 63) {
+        const float s0 = row_sum_lane15(val - v1);
+        const float s1 = row_sum_lane15(v1);
+        if (row_last) {
           pp[(r * 2) * G + g] = s0;
           pp[(r * 2 + 1) * G + g] = s1;
         }
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_fwd_k(
     if (threadIdx.x < NO) {
       float s = 0.0f;
 #pragma unroll
-      for (int q = 0; q < NW; ++q) s += part[it & 1][q][threadIdx.x];
+      for (int q = 0; q < NW * 4; ++q) s += part[it & 1][q][threadIdx.x];
       ell_part[((size_t)f * kBgHalves + half) * NO + threadIdx.x] = s;
     }
   }
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
     float* __restrict__ gcoef_part, int n_frames) {
   constexpr int NO = R * 2 * G;
   constexpr int NW = kBgThreads / 64;
-  __shared__ float zred[2][NW][NMAX * 4];
+  __shared__ float zred[2][NW * 4][NMAX * 4];
   const int half = blockIdx.x % kBgHalves;
   const int p = half * kBgThreads + threadIdx.x;
   const int lane = lane_id(), wv = wave_id();
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
       for (int g = 0; g < G; ++g) {
         const float d = sd[r] ? de[(r * 2 + 1) * G + g] : de[(r * 2) * G + g];
         dw = fmaf(d, fmaf(cf[r][g][0], x2, fmaf(cf[r][g][1], x, cf[r][g][2])), dw);
-        dx = fmaf(d, fmaf(cf[r][g][0], x + x, cf[r][g][1]), dx);
+        if (!SCENE) dx = fmaf(d, fmaf(cf[r][g][0], x + x, cf[r][g][1]), dx);
         gc[r][g][0] = fmaf(d, wxx, gc[r][g][0]);
         gc[r][g][1] = fmaf(d, wx, gc[r][g][1]);
         gc[r][g][2] = fmaf(d, w, gc[r][g][2]);
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
     if (SCENE) {
       // w = 1 - min(1, sum box): d box_k = -dw when no clamp fired
       const float dbox = pass ? -dw : 0.0f;
-      float* zr = zred[it & 1][wv];
+      float* zr = zred[it & 1][wv * 4 + (lane >> 4)];
+      const bool row_last = (lane & 15) == 15;
 #pragma unroll
       for (int k = 0; k < NMAX; ++k) {
         if (k < n_obj) {
@@ -317,11 +319,11 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
           // q = ((u - x)/sx + 1) * 16 - 0.5
           const float dqx = dbox * fy[k] * dfx[k] * (0.5f * kBgSide);
           const float dqy = dbox * fx[k] * dfy[k] * (0.5f * kBgSide);
-          const float g_sx = wave_sum_lane63(-dqx * (u - zk[2]) * isx * isx);
-          const float g_sy = wave_sum_lane63(-dqy * (v - zk[3]) * isy * isy);
-          const float g_x = wave_sum_lane63(-dqx * isx);
-          const float g_y = wave_sum_lane63(-dqy * isy);
-          if (lane == 63) {
+          const float g_sx = row_sum_lane15(-dqx * (u - zk[2]) * isx * isx);
+          const float g_sy = row_sum_lane15(-dqy * (v - zk[3]) * isy * isy);
+          const float g_x = row_sum_lane15(-dqx * isx);
+          const float g_y = row_sum_lane15(-dqy * isy);
+          if (row_last) {
             zr[k * 4] = g_sx;
             zr[k * 4 + 1] = g_sy;
             zr[k * 4 + 2] = g_x;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
       if ((int)threadIdx.x < n_obj * 4) {
         float s = 0.0f;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) s += zred[it & 1][q][threadIdx.x];
+        for (int q = 0; q < NW * 4; ++q) s += zred[it & 1][q][threadIdx.x];
         dz_part[((size_t)f * kBgHalves + half) * n_obj * 4 + threadIdx.x] = s;
       }
     } else {
@@ -458,7 +460,7 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
   const int chunks = n_frames < kBgRootChunks ? n_frames : kBgRootChunks;
   STOVE_LAUNCH((bgspn_rootgrad_k<kBgR, kBgG>), dim3(chunks), dim3(128), 0, st, rsc, rpart, n_frames, chunks);
   STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH(reduce_chunks_k, dim3(1), dim3(256), 0, st, rpart, g_wroot, kBgR * kBgG * kBgG, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kBgR * kBgG * kBgG + 31) / 32), dim3(256), 0, st, rpart, g_wroot, kBgR * kBgG * kBgG, chunks, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

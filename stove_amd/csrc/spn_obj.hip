@@ -480,13 +480,24 @@ __global__ void objspn_tile_to_arrays_k(const float* __restrict__ dxw, const flo
   }
 }
 
-// out[j] = sum_c part[c][j]  (fixed order -> bitwise reproducible)
-__global__ void reduce_chunks_k(const float* __restrict__ part, float* __restrict__ out, int n, int n_chunks, int accumulate) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+// out[j] = sum_c part[c][j]  (fixed order -> bitwise reproducible).
+// 256 threads = 32 elements x 8 chunk slices: slice q adds chunks q, q+8, ...; the 8 slice sums are then
+// added in slice order.  (One thread per element walking all chunks serially was latency-bound.)
+__global__ __launch_bounds__(256) void reduce_chunks_k(const float* __restrict__ part, float* __restrict__ out, int n, int n_chunks, int accumulate) {
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + e;
   float s = 0.0f;
-  for (int c = 0; c < n_chunks; ++c) s += part[(size_t)c * n + j];
-  out[j] = accumulate ? out[j] + s : s;
+  if (j < n)
+    for (int c = q; c < n_chunks; c += 8) s += part[(size_t)c * n + j];
+  red[q][e] = s;
+  __syncthreads();
+  if (q == 0 && j < n) {
+    float t = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][e];
+    out[j] = accumulate ? out[j] + t : t;
+  }
 }
 
 }  // namespace stove
@@ -530,7 +541,7 @@ int objspn_forward(const float* xw, const int* scope, const float* coef, const f
 
 // workspace layout (floats) for the backward, per batch of 64 samples
 constexpr size_t kObjD = 6 * 4 * 10 * 64, kObjS = 12 * 30 * 64, kObjR = 6 * 21 * 64, kObjX = 100 * 2 * 64;
-constexpr int kObjChunks = 96;
+constexpr int kObjChunks = 288;
 constexpr size_t kObjCoefN = 6 * 100 * 10 * 3, kObjWN = 12 * 100 * 10, kObjRootN = 6 * 100;
 
 size_t objspn_bwd_ws_floats(int n) {
@@ -566,9 +577,9 @@ int objspn_backward(const float* xw, const int* scope, const int* leaf_slot, con
   STOVE_LAUNCH_CHECK();
   STOVE_LAUNCH((objspn_wgrad_k<6, 10, 10>), dim3(chunks), dim3(6 * 2 * 10 * 2 + 64), 0, st, Sscr, Rscr, pw, pr, nb, chunks);
   STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjCoefN + 255) / 256), dim3(256), 0, st, pc, g_coef, (int)kObjCoefN, chunks, 0);
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjWN + 255) / 256), dim3(256), 0, st, pw, g_wsum, (int)kObjWN, chunks, 0);
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjRootN + 255) / 256), dim3(256), 0, st, pr, g_wroot, (int)kObjRootN, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjCoefN + 31) / 32), dim3(256), 0, st, pc, g_coef, (int)kObjCoefN, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjWN + 31) / 32), dim3(256), 0, st, pw, g_wsum, (int)kObjWN, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjRootN + 31) / 32), dim3(256), 0, st, pr, g_wroot, (int)kObjRootN, chunks, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
