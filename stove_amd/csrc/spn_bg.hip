@@ -221,6 +221,7 @@ __global__ void bgspn_rootgrad_k(const float* __restrict__ rsc, float* __restric
   const int c = blockIdx.x;
   const int r = k / (G * G), j2 = (k / G) % G, j1 = k % G;
   float acc = 0.0f;
+#pragma unroll 4
   for (int f = c; f < n_frames; f += n_chunks) {
     const float* rp = rsc + ((size_t)f * R + r) * (1 + 2 * G);
     acc = fmaf(rp[0] * rp[1 + j1], rp[1 + G + j2], acc);
@@ -352,24 +353,36 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
       for (int k = 0; k < 3; ++k) o[((size_t)(r * kBgThreads + threadIdx.x) * G + g) * 3 + k] = gc[r][g][k];
 }
 
-// g_coef[r][p][g][3] = sum over the blocks that own pixel-half(p) of gcoef_part
+// g_coef[r][p][g][3] = sum over the blocks that own pixel-half(p) of gcoef_part (fixed order).
+// 256 threads = 32 elements x 8 slices of the partial blocks, as reduce_chunks_k.
 template <int R, int G>
-__global__ void bgspn_coef_reduce_k(const float* __restrict__ gcoef_part, float* __restrict__ g_coef, int n_blocks) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;   // over R * 1024 * G * 3
-  if (j >= R * kBgPix * G * 3) return;
-  const int e = j % (G * 3);
-  const int p = (j / (G * 3)) % kBgPix;
-  const int r = j / (G * 3 * kBgPix);
-  const int half = p / kBgThreads, pl = p % kBgThreads;
+__global__ __launch_bounds__(256) void bgspn_coef_reduce_k(const float* __restrict__ gcoef_part, float* __restrict__ g_coef, int n_blocks) {
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + el;               // over R * 1024 * G * 3
   float s = 0.0f;
-  for (int b = half; b < n_blocks; b += kBgHalves)
-    s += gcoef_part[(((size_t)b * R + r) * kBgThreads + pl) * G * 3 + e];
-  g_coef[j] = s;
+  const bool live = j < R * kBgPix * G * 3;
+  if (live) {
+    const int e = j % (G * 3);
+    const int p = (j / (G * 3)) % kBgPix;
+    const int r = j / (G * 3 * kBgPix);
+    const int half = p / kBgThreads, pl = p % kBgThreads;
+    for (int b = half + q * kBgHalves; b < n_blocks; b += 8 * kBgHalves)
+      s += gcoef_part[(((size_t)b * R + r) * kBgThreads + pl) * G * 3 + e];
+  }
+  red[q][el] = s;
+  __syncthreads();
+  if (q == 0 && live) {
+    float t = red[0][el];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][el];
+    g_coef[j] = t;
+  }
 }
 
 // =============================================================================================
 constexpr int kBgR = 3, kBgG = 6, kBgNO = kBgR * 2 * kBgG;
-constexpr int kBgRootChunks = 64;
+constexpr int kBgRootChunks = 256;
 
 static inline int bg_grid(int n_frames) {
   int g = n_frames < 512 ? n_frames : 512;
@@ -455,7 +468,7 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
     STOVE_LAUNCH_CHECK();
   }
   const int nc = kBgR * kBgPix * kBgG * 3;
-  STOVE_LAUNCH((bgspn_coef_reduce_k<kBgR, kBgG>), dim3((nc + 255) / 256), dim3(256), 0, st, gpart, g_coef, grid);
+  STOVE_LAUNCH((bgspn_coef_reduce_k<kBgR, kBgG>), dim3((nc + 31) / 32), dim3(256), 0, st, gpart, g_coef, grid);
   STOVE_LAUNCH_CHECK();
   const int chunks = n_frames < kBgRootChunks ? n_frames : kBgRootChunks;
   STOVE_LAUNCH((bgspn_rootgrad_k<kBgR, kBgG>), dim3(chunks), dim3(128), 0, st, rsc, rpart, n_frames, chunks);
