@@ -93,6 +93,9 @@ __device__ __forceinline__ GnnLds carve(float* base) {
   return L;
 }
 
+// tanh through one v_exp_f32 and one v_rcp_f32 (absolute error ~2e-7); ocml's tanhf costs several hundred
+// cycles of dependent latency per stage of the T-serial chain.
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 __device__ __forceinline__ float act_phi(float x, int elu) { return x > 0.0f ? x : (elu ? expm1f(x) : 0.01f * x); }
 __device__ __forceinline__ float dphi_from_out(float y, int elu) { return y > 0.0f ? 1.0f : (elu ? y + 1.0f : 0.01f); }
 
@@ -112,6 +115,34 @@ __device__ __forceinline__ f32x4 tile_AB(const float* A, int lda, const float* _
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// The same tile with the weight fragment fetched ahead of time: wfrag_load is issued one stage early (the
+// weights do not depend on anything), so its L2 latency is off the critical path of the stage that uses it.
+template <int K>
+struct WFrag {
+  float4 b[K / 16];
+};
+template <int K>
+__device__ __forceinline__ WFrag<K> wfrag_load(const float* __restrict__ B, int ldb) {
+  const int l = lane_id(), i = l & 15, kq = l >> 4;
+  WFrag<K> f;
+#pragma unroll
+  for (int kb = 0; kb < K / 16; ++kb) f.b[kb] = *reinterpret_cast<const float4*>(B + i * ldb + kb * 16 + 4 * kq);
+  return f;
+}
+template <int K>
+__device__ __forceinline__ f32x4 tile_AW(const float* A, int lda, const WFrag<K>& w) {
+  const int l = lane_id(), i = l & 15, kq = l >> 4;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int kb = 0; kb < K / 16; ++kb) {
+    const float4 a = *reinterpret_cast<const float4*>(A + i * lda + kb * 16 + 4 * kq);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.b[kb].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.b[kb].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.b[kb].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.b[kb].w, acc, 0, 0, 0);
   }
   return acc;
 }
@@ -324,34 +355,43 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
   }
   WG_SYNC();
   gnn_stamp(sh, 6);
-  // 7-9. affector MLP
+  // 7-11. affector and output MLPs: a chain of five small layers on waves 0/1; each stage fetches the NEXT
+  // layer's weight fragment before it starts computing.
+  const int w01 = wv & 1;
+  WFrag<32> wf0 = wfrag_load<32>(Wf + W_F0 + w01 * 16 * 32, 32);
   if (wv < 2) {
-    const f32x4 acc = tile_AB<32>(L.PRED, LDN, Wf + W_F0 + wv * 16 * 32, 32);
-    tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.F1[r * LDN + c] = tanhf(v + V[V_F0 + c]); });
+    const WFrag<32> wf1 = wfrag_load<32>(Wf + W_F1 + w01 * 16 * 32, 32);
+    const f32x4 acc = tile_AW<32>(L.PRED, LDN, wf0);
+    tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.F1[r * LDN + c] = fast_tanh(v + V[V_F0 + c]); });
+    wf0 = wf1;
   }
   WG_SYNC();
   gnn_stamp(sh, 7);
+  WFrag<64> wo0;
   if (wv < 2) {
-    const f32x4 acc = tile_AB<32>(L.F1, LDN, Wf + W_F1 + wv * 16 * 32, 32);
-    tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.F2[r * LDN + c] = tanhf(v + V[V_F1 + c]) + L.F1[r * LDN + c]; });
+    const WFrag<32> wf2 = wfrag_load<32>(Wf + W_F2 + w01 * 16 * 32, 32);
+    const f32x4 acc = tile_AW<32>(L.F1, LDN, wf0);
+    tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.F2[r * LDN + c] = fast_tanh(v + V[V_F1 + c]) + L.F1[r * LDN + c]; });
+    wf0 = wf2;
   }
   WG_SYNC();
   gnn_stamp(sh, 8);
   if (wv < 2) {
-    const f32x4 acc = tile_AB<32>(L.F2, LDN, Wf + W_F2 + wv * 16 * 32, 32);
+    wo0 = wfrag_load<64>(Wf + W_O0 + w01 * 16 * 64, 64);
+    const f32x4 acc = tile_AW<32>(L.F2, LDN, wf0);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.CAT[r * LDC + c] = v + V[V_F2 + c]; });
   }
   WG_SYNC();
   gnn_stamp(sh, 9);
-  // 10-11. output MLP on [affector | s]
   if (wv < 2) {
-    const f32x4 acc = tile_AB<64>(L.CAT, LDC, Wf + W_O0 + wv * 16 * 64, 64);
-    tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.O1[r * LDN + c] = tanhf(v + V[V_O0 + c]); });
+    wf0 = wfrag_load<32>(Wf + W_O1 + w01 * 16 * 32, 32);
+    const f32x4 acc = tile_AW<64>(L.CAT, LDC, wo0);
+    tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.O1[r * LDN + c] = fast_tanh(v + V[V_O0 + c]); });
   }
   WG_SYNC();
   gnn_stamp(sh, 10);
   if (wv < 2) {
-    const f32x4 acc = tile_AB<32>(L.O1, LDN, Wf + W_O1 + wv * 16 * 32, 32);
+    const f32x4 acc = tile_AW<32>(L.O1, LDN, wf0);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.RES[r * LDN + c] = v + V[V_O1 + c] + L.O1[r * LDN + c]; });
   }
   WG_SYNC();

@@ -59,13 +59,17 @@ class Supair(nn.Module):
     def constrain_zp(self, zp):
         """(nTo, 8) raw codes -> mean, std (nTo, 4) of [sx, sy/sx, x, y] (reference supair.py:112-149)."""
         c = self.c
-        sig = torch.sigmoid(zp)
-        span = zp.new_tensor([c.max_obj_scale - c.min_obj_scale, c.max_y_scale - c.min_y_scale,
-                              2 * c.obj_pos_bound, 2 * c.obj_pos_bound])
-        low = zp.new_tensor([c.min_obj_scale, c.min_y_scale, -c.obj_pos_bound, -c.obj_pos_bound])
-        zp_mean = sig[:, :4] * span + low
-        zp_std = sig[:, 4:] * zp.new_tensor([c.scale_var, c.scale_var, c.pos_var, c.pos_var])
-        return zp_mean, zp_std
+        key = (str(zp.device), zp.dtype, c.max_obj_scale, c.min_obj_scale, c.max_y_scale, c.min_y_scale,
+               c.obj_pos_bound, c.scale_var, c.pos_var)
+        if getattr(self, '_zp_consts_key', None) != key:          # constants live on the device, built once
+            span = [c.max_obj_scale - c.min_obj_scale, c.max_y_scale - c.min_y_scale,
+                    2 * c.obj_pos_bound, 2 * c.obj_pos_bound, c.scale_var, c.scale_var, c.pos_var, c.pos_var]
+            low = [c.min_obj_scale, c.min_y_scale, -c.obj_pos_bound, -c.obj_pos_bound, 0.0, 0.0, 0.0, 0.0]
+            self._zp_consts = (zp.new_tensor(span), zp.new_tensor(low))
+            self._zp_consts_key = key
+        span, low = self._zp_consts
+        out = torch.addcmul(low, torch.sigmoid(zp), span)
+        return out[:, :4], out[:, 4:]
 
     @staticmethod
     def sy_from_quotient(z):
