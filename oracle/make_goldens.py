@@ -447,11 +447,82 @@ def g7_g8_full():
                  elbo=elbo, **props, **gnorm, **small, **extra)
 
 
+# ------------------------------------------------------------------ G6b volatile matcher, G11 SuPAIR-only ELBO, G9 optimiser steps
+def g6b_volatile():
+    g = torch.Generator().manual_seed(66)
+    c = ref_config(debug_match_objects='volatile')
+    st = Stove(c)
+    n, t = 6, 7
+    base = torch.rand(n, 1, 3, 4, generator=g, dtype=torch.float64) * 1.6 - 0.8
+    z = base + torch.cumsum(0.03 * torch.randn(n, t, 3, 4, generator=g, dtype=torch.float64), 1)
+    z[1, 3] = z[1, 3][[1, 0, 2]]
+    z[2, 2] = z[2, 2][[2, 0, 1]]
+    z[4, 4, :, 2:] = z[4, 3, 0:1, 2:]              # all current objects collapse onto one previous slot
+    zstd = torch.rand(n, t, 3, 4, generator=g, dtype=torch.float64) * 0.3
+    zm, zsm, _ = st._volatile_match_objects(z.clone(), zstd.clone(), None)
+    save('g6_match_volatile', z=z, zstd=zstd, z_matched=zm, zstd_matched=zsm)
+
+
+def g11_supair_only():
+    for dtype, tag in ((torch.float64, 'f64'),):
+        c = ref_config(dtype)
+        c.debug = True
+        st = Stove(c)
+        fill(st)
+        B, T = 3, 4
+        x = torch.from_numpy(billiards_frames(B, T)).to(dtype)
+        g = torch.Generator().manual_seed(11)
+        eps = torch.randn(B * T * 3, 4, generator=g, dtype=torch.float64)
+        saved = tdn._standard_normal
+        tdn._standard_normal = EpsFeeder([eps])
+        elbo, prop, _ = st(x, 0, None, True)
+        tdn._standard_normal = saved
+        (-elbo).backward()
+        gn = {f'gn_{k}': p.grad.norm() for k, p in st.named_parameters() if p.grad is not None}
+        save(f'g11_supair_only_{tag}', x=x.to(torch.float32), eps=eps, elbo=elbo, z=prop['z'], log_q=prop['log_q'], **gn)
+
+
+def g9_optimiser_steps():
+    """Three steps of the reference's optimisation recipe (train.py:431-473) on one fixed batch."""
+    c = ref_config(torch.float32)
+    st = Stove(c)
+    fill(st)
+    B, T = 4, 8
+    x = torch.from_numpy(billiards_frames(B, T)).to(torch.float32)
+    opt = torch.optim.Adam(st.parameters(), lr=c.learning_rate, amsgrad=c.debug_amsgrad)
+    g = torch.Generator().manual_seed(9)
+    elbos, all_eps = [], []
+    for step in range(1, 4):
+        lat = torch.randn(B, 3, 12, 1, generator=g, dtype=torch.float64)
+        sd = torch.randn(B, 3, 12, 1, generator=g, dtype=torch.float64)
+        steps = [torch.randn(B, 3, 18, generator=g, dtype=torch.float64) for _ in range(2, T)]
+        all_eps.append((lat, sd, torch.stack(steps, 0)))
+        lr = max(c.learning_rate * np.exp(-step / c.debug_anneal_lr), c.min_learning_rate)
+        for grp in opt.param_groups:
+            grp['lr'] = lr
+        opt.zero_grad()
+        saved = tdn._standard_normal
+        tdn._standard_normal = EpsFeeder([lat, sd] + steps)
+        elbo, _, _ = st(x, step, None)
+        tdn._standard_normal = saved
+        (-elbo).backward()
+        torch.nn.utils.clip_grad_norm_(st.parameters(), 1)
+        opt.step()
+        elbos.append(float(elbo))
+    checks = {f'p_{k}': p.detach().double().sum() for k, p in st.named_parameters()
+              if k in ('dyn.out.0.1.weight', 'sup.encoder.fc2.weight', 'sup.obj_spn.vector_list.4.0.params',
+                       'sup.bg_spn.vector_list.0.0.means', 'dyn.rel_cores.0.0.weight')}
+    save('g9_optimiser_steps', x=x, elbos=np.array(elbos),
+         eps_lat=torch.stack([e[0] for e in all_eps]), eps_std=torch.stack([e[1] for e in all_eps]),
+         eps_steps=torch.stack([e[2] for e in all_eps]), **checks)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7']
+    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7', 'g6b', 'g11', 'g9']
     os.makedirs(OUT, exist_ok=True)
     table = {'g0': g0_envs, 'g1': g1_structures, 'g2': g2_ratspn, 'g3': g3_masks_glimpses,
-             'g4': g4_likelihood, 'g5': g5_dynamics, 'g6': g6_matchers, 'g10': g10_units, 'g7': g7_g8_full}
+             'g4': g4_likelihood, 'g5': g5_dynamics, 'g6': g6_matchers, 'g10': g10_units, 'g7': g7_g8_full,
+             'g6b': g6b_volatile, 'g11': g11_supair_only, 'g9': g9_optimiser_steps}
     for k in which:
         torch.manual_seed(0)
         np.random.seed(0)

@@ -670,3 +670,34 @@ def param_shapes(c, structs):
 
 def build_structs(c):
     return {'obj': obj_spn_structure(c), 'bg': bg_spn_structure(c)}
+
+
+# --------------------------------------------------------------------------
+# remaining entry points of the path: the non-permutation matcher and the SuPAIR-only ELBO
+# --------------------------------------------------------------------------
+def match_volatile(c, z_sup, z_sup_std=None, app=None):
+    """_volatile_match_objects, stove.py:331-430: every current object goes to its nearest previous slot."""
+    z, cols = _match_features(c, z_sup, z_sup_std, app)
+    out = [z[:, 0]]
+    n_obj = z.shape[2]
+    for t in range(1, z.shape[1]):
+        cur = z[:, t][..., cols].detach()
+        prev = out[-1][..., cols].detach()
+        # err[n, j, a] = |prev_a - cur_j|^2 ; column j (current object) picks its row-wise minimum over a
+        err = ((prev.unsqueeze(1) - cur.unsqueeze(2)) ** 2).sum(-1)
+        col_idx = err.argmin(-2).flatten()
+        flat = torch.arange(col_idx.shape[0]) * n_obj + col_idx
+        perm = torch.zeros(z.shape[0] * n_obj * n_obj, dtype=z.dtype)
+        perm[flat] = 1
+        out.append(perm.view(z.shape[0], n_obj, n_obj) @ z[:, t])
+    return _split_matched(torch.stack(out, 1), z_sup_std, app)
+
+
+def supair_forward(c, params, structs, x, eps):
+    """Supair.forward, supair.py:504-551: ELBO of SuPAIR alone; eps (n*T*N, 4) standard-normal draws."""
+    code = encoder_forward(c, params, x.flatten(0, 1))
+    mean, std = constrain_zp(c, code.flatten(0, 1))
+    z = mean + std * eps
+    log_q = normal_log_prob(z, mean, std).sum(-1).view(-1, c.num_obj).sum(-1)
+    log_p = scene_likelihood(c, params, structs, x, sy_from_quotient(z))
+    return torch.mean(log_p - log_q), sy_from_quotient(z).view(*x.shape[:2], c.num_obj, 4), log_q.mean()

@@ -10,7 +10,7 @@
 //          permutation, slots are assigned greedily in slot order with column knock-out.
 //   mode 1 ('greedy'): N rounds of global arg-min over the N x N distance table with row and
 //          column knock-out.
-//   mode 2 ('volatile'): nearest previous slot per current object, no uniqueness (stove.py:331-430).
+//   mode 2 ('volatile'): nearest current object per slot, no uniqueness, no repair (stove.py:331-430).
 // Distances are squared Euclidean on (v+1)/2-scaled features, ties resolve to the first index.
 #include "common.h"
 
@@ -94,36 +94,18 @@ __global__ __launch_bounds__(64) void match_objects_k(const float* __restrict__ 
         }
       }
     } else {
-      // volatile: current object j goes to its nearest previous slot; slots may collide or stay empty.
-      // Reported through perm_out (a 0/1 matrix), idx gets -1 for empty slots.
-      _Pragma("unroll") for (int a = 0; a < N; ++a) idx[a] = -1;
-      _Pragma("unroll") for (int j = 0; j < N; ++j) {
+      // volatile (stove.py:331-430): every slot takes its nearest current object, duplicates allowed
+      // (errors.min(-2) there runs over the CURRENT objects, so it is mode 0 without the repair)
+      _Pragma("unroll") for (int a = 0; a < N; ++a) {
         int best = 0;
-        _Pragma("unroll") for (int a = 1; a < N; ++a)
-          if (err[a][j] < err[best][j]) best = a;
-        if (perm_out != nullptr) perm_out[(((size_t)b * T + t) * N + best) * N + j] = 1.0f;
-        idx[best] = j;
+        _Pragma("unroll") for (int j = 1; j < N; ++j)
+          if (err[a][j] < err[a][best]) best = j;
+        idx[a] = best;
       }
     }
     _Pragma("unroll") for (int a = 0; a < N; ++a) {
       ibuf[t * N + a] = idx[a];
-      if (mode != 2) {
-        _Pragma("unroll") for (int f = 0; f < F; ++f) prev[a][f] = cur[idx[a]][f];
-      }
-    }
-    if (mode == 2) {
-      // matched state = perm @ current (sum of the assigned objects, zero if none)
-      float nxt[MN][MF];
-      _Pragma("unroll") for (int a = 0; a < N; ++a)
-        _Pragma("unroll") for (int f = 0; f < F; ++f) nxt[a][f] = 0.0f;
-      _Pragma("unroll") for (int j = 0; j < N; ++j) {
-        int best = 0;
-        _Pragma("unroll") for (int a = 1; a < N; ++a)
-          if (err[a][j] < err[best][j]) best = a;
-        _Pragma("unroll") for (int f = 0; f < F; ++f) nxt[best][f] += cur[j][f];
-      }
-      _Pragma("unroll") for (int a = 0; a < N; ++a)
-        _Pragma("unroll") for (int f = 0; f < F; ++f) prev[a][f] = nxt[a][f];
+      _Pragma("unroll") for (int f = 0; f < F; ++f) prev[a][f] = cur[idx[a]][f];
     }
   }
   }

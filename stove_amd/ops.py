@@ -343,9 +343,6 @@ def match_objects(feat, mode):
     with torch.cuda.device(dev):
         idx = torch.empty(B, T, N, dtype=torch.int64, device=dev)
         perm = None
-        if mode == 'volatile':
-            perm = torch.zeros(B, T, N, N, dtype=torch.float32, device=dev)
-            perm[:, 0] = torch.eye(N, device=dev)
         check(lib.stove_match_objects(ptr(feat), ptr(idx), ptr(perm), B, T, N, Fd, MATCH_MODES[mode], stream()),
               'stove_match_objects')
     return idx, perm

@@ -201,3 +201,64 @@ def test_encoder_lstm_against_oracle():
     (out_d * w64.float().to(DEV)).sum().backward()
     for name, p in enc.named_parameters():
         assert err(p.grad, params['sup.encoder.' + name].grad) < 1e-3, name
+
+
+def test_match_volatile():
+    from stove_amd.video_prediction.stove import Stove
+    g = load_golden('g6_match_volatile')
+    st = Stove(make_cfg(debug_match_objects='volatile'))
+    zm, zsm, _ = st._volatile_match_objects(t_(g['z']).float().to(DEV), t_(g['zstd']).float().to(DEV), None)
+    assert err(zm, g['z_matched']) < 1e-6 and err(zsm, g['zstd_matched']) < 1e-6
+
+
+def test_supair_only_elbo():
+    """Stove.forward(..., pretrain=True): the SuPAIR-only ELBO (reference supair.py:504-551)."""
+    import torch.distributions.normal as tdn
+    from stove_amd.video_prediction.stove import Stove
+    g = load_golden('g11_supair_only_f64')
+    st = fill_analytic(Stove(make_cfg())).to(DEV)
+    eps = t_(g['eps']).float().to(DEV)
+    saved = tdn._standard_normal
+    tdn._standard_normal = lambda shape, dtype, device: eps.reshape(shape).to(dtype)
+    try:
+        elbo, prop, _ = st(t_(g['x']).float().to(DEV), 0, None, True)
+    finally:
+        tdn._standard_normal = saved
+    assert abs(float(elbo.detach()) - float(g['elbo'])) < 1e-4 * abs(float(g['elbo']))
+    assert err(prop['z'], g['z']) < 1e-4
+    (-elbo).backward()
+    params = dict(st.named_parameters())
+    for k, v in g.items():
+        if k.startswith('gn_'):
+            assert abs(float(params[k[3:]].grad.norm()) - float(v)) <= 5e-3 * float(v) + 1e-9, k
+
+
+def test_three_optimiser_steps_track_the_reference():
+    """Adam(amsgrad) + lr schedule + clip_grad_norm_(1) on one batch (reference train.py:431-473, fp32):
+    the ELBO sequence and parameter checksums after three steps."""
+    from stove_amd.video_prediction.stove import Stove
+    g = load_golden('g9_optimiser_steps')
+    cfg = make_cfg()
+    st = fill_analytic(Stove(cfg)).to(DEV)
+    opt = torch.optim.Adam(st.parameters(), lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
+    x = t_(g['x']).float().to(DEV)
+    for step in range(1, 4):
+        lat = t_(g['eps_lat'])[step - 1][..., 0].float()
+        sd = t_(g['eps_std'])[step - 1][..., 0].float()
+        steps = t_(g['eps_steps'])[step - 1].float().permute(1, 0, 2, 3).contiguous()
+        table = {'latent': lat, 'std': sd, 'steps': steps}
+        st.noise_fn = lambda kind, shape, _t=table: _t[kind].reshape(shape)
+        for grp in opt.param_groups:
+            grp['lr'] = max(cfg.learning_rate * np.exp(-step / cfg.debug_anneal_lr), cfg.min_learning_rate)
+        opt.zero_grad()
+        elbo, _, _ = st(x, step, None)
+        (-elbo).backward()
+        torch.nn.utils.clip_grad_norm_(st.parameters(), 1)
+        opt.step()
+        ref = float(g['elbos'][step - 1])
+        assert abs(float(elbo.detach()) - ref) < 2e-4 * abs(ref), (step, float(elbo.detach()), ref)
+    params = dict(st.named_parameters())
+    for k, v in g.items():
+        if k.startswith('p_'):
+            got = float(params[k[2:]].detach().double().sum())
+            assert abs(got - float(v)) < 2e-4 * abs(float(v)) + 1e-4, (k, got, float(v))

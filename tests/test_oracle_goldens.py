@@ -213,3 +213,27 @@ def test_stove_forward_and_rollout(name, tag, dtype, tol):
     assert rel_err(zp, g['roll_z']) < tol * 100
     if actions is not None:
         assert rel_err(rp, g['roll_rewards']) < tol * 100
+
+
+def test_match_volatile():
+    g = load_golden('g6_match_volatile')
+    c = O.default_config(debug_match_objects='volatile')
+    zm, zs, _ = O.match_volatile(c, t_(g['z']), t_(g['zstd']), None)
+    assert rel_err(zm, g['z_matched']) < 1e-14 and rel_err(zs, g['zstd_matched']) < 1e-14
+
+
+def test_supair_only_elbo():
+    g = load_golden('g11_supair_only_f64')
+    c, structs, params = oracle_setup(torch.float64)
+    elbo, z, log_q = O.supair_forward(c, params, structs, O.bw_transform(t_(g['x'])), t_(g['eps']))
+    # the fixture stores the frames as float32, the reference ran on their float64 originals
+    assert abs(float(elbo) - float(g['elbo'])) < 1e-6 * abs(float(g['elbo']))
+    assert rel_err(z.detach(), g['z']) < 1e-6
+    assert abs(float(log_q) - float(g['log_q'])) < 1e-6 * abs(float(g['log_q']))
+    (-elbo).backward()
+    n = 0
+    for k, v in g.items():
+        if k.startswith('gn_'):
+            assert abs(float(params[k[3:]].grad.norm()) - float(v)) <= 1e-4 * float(v) + 1e-12, k
+            n += 1
+    assert n > 60
