@@ -151,13 +151,13 @@ def main():
     if world > 1:
         dist.barrier()
     from stove_amd import _lib
-    from stove_amd.parallel import GradBucket
+    from stove_amd.arena import ParamArena
     from stove_amd.video_prediction.stove import Stove
 
     cfg = build_config(a.workload, dev)
     torch.manual_seed(0)
     model = Stove(cfg).to(dev)
-    bucket = GradBucket(model, world)
+    bucket = ParamArena(model, world)          # parameters / gradients flat; grad buffer == all-reduce bucket
     opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
 
     log('model built; generating data')
@@ -173,7 +173,7 @@ def main():
         loss = -elbo
         loss.backward()
         bucket.all_reduce()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        bucket.clip_grad_norm_(1.0)
         opt.step()
         return elbo
 

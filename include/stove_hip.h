@@ -155,6 +155,30 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
  * perm (B,T,N,N) f32, pre-zeroed, only written in mode 2 (may be NULL otherwise). */
 int stove_match_objects(const float* feat, long long* idx, float* perm, int B, int T, int N, int F, int mode, void* stream);
 
+/* ---- flat parameter arena.  When all model parameters are views into ONE fp32 buffer (and their gradients
+ * into one gradient buffer, which is also the data-parallel all-reduce bucket), the SPN tables and the GNN
+ * parameter image are baked from / their gradients pushed into those buffers directly:
+ *   stove_spn_bake      leaf (a,b,c) from means / sigma_params (rat_torch.py:85-99), softmax of the sum
+ *                       weights (rat_torch.py:210), permuted into the kernel order
+ *   stove_spn_bake_bwd  the chain rule of the same, ACCUMULATED into grad_arena
+ *   stove_arena_gather / _scatter_add   image[i] = arena[src[i]] (src < 0: zero padding) and its adjoint.
+ * Offsets are float offsets into the arena; obj_* follow the kernel's leaf / sum order. */
+typedef struct StoveSpnArenaPlan {
+  const int32_t* obj_mu;    /* [24] */
+  const int32_t* obj_rho;   /* [24] */
+  const int32_t* obj_sum;   /* [12] */
+  const int32_t* bg_mu;     /* [6]  */
+  const int32_t* bg_rho;    /* [6]  */
+  const int32_t* bg_gidx;   /* [3*1024] leaf*512 + row of pixel p in replica r */
+  int32_t obj_root, bg_root;
+  float obj_vmin, obj_vmax, bg_vmin, bg_vmax;
+} StoveSpnArenaPlan;
+int stove_spn_bake(const float* arena, const StoveSpnArenaPlan* plan, float* obj_coef, float* obj_wsum, float* obj_wroot,
+                   float* bg_coef, float* bg_wroot, void* stream);
+int stove_spn_bake_bwd(const float* arena, const StoveSpnArenaPlan* plan, const StoveSpnTableGrads* g, float* grad_arena, void* stream);
+int stove_arena_gather(const float* arena, const int32_t* src, float* image, int n, void* stream);
+int stove_arena_scatter_add(const float* gimage, const int32_t* src, float* grad_arena, int n, void* stream);
+
 /* ---- gate math of RnnStates' LSTM (encoder.py:43-51, torch.nn.LSTM cell, gate order i,f,g,o); the GEMMs
  * around it stay on rocBLAS.  gx (n,4H): x W_ih^T + b_ih + b_hh; gh (n,4H): h_prev W_hh^T or NULL; c_prev
  * (n,H) or NULL (zero state).  bwd: dh, dc_in (NULL = 0) -> dg (n,4H), dc_out (n,H); dgx_acc (n,4H) gets

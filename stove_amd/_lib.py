@@ -18,6 +18,7 @@ EXPORTS = [
     'stove_scene_glimpses',
     'stove_gnn_param_floats', 'stove_gnn_grad_floats', 'stove_gnn_blocks', 'stove_gnn_fwd', 'stove_gnn_bwd_ws_bytes',
     'stove_gnn_bwd', 'stove_dynloop_act_floats', 'stove_dynloop_fwd', 'stove_dynloop_bwd_ws_bytes', 'stove_dynloop_bwd', 'stove_rollout_fwd', 'stove_match_objects', 'stove_profile_enable', 'stove_profile_report', 'stove_gnn_debug_stamps', 'stove_lstm_cell_fwd', 'stove_lstm_cell_bwd',
+    'stove_spn_bake', 'stove_spn_bake_bwd', 'stove_arena_gather', 'stove_arena_scatter_add',
 ]
 
 
@@ -32,9 +33,17 @@ class SpnTableGrads(Structure):
                 ('bg_coef', c_void_p), ('bg_wroot', c_void_p)]
 
 
+class SpnArenaPlan(Structure):
+    _fields_ = [('obj_mu', c_void_p), ('obj_rho', c_void_p), ('obj_sum', c_void_p),
+                ('bg_mu', c_void_p), ('bg_rho', c_void_p), ('bg_gidx', c_void_p),
+                ('obj_root', c_int), ('bg_root', c_int),
+                ('obj_vmin', c_float), ('obj_vmax', c_float), ('bg_vmin', c_float), ('bg_vmax', c_float)]
+
+
 def _declare(lib):
     P, I, F, S = c_void_p, c_int, c_float, c_size_t
     T, G = POINTER(SpnTables), POINTER(SpnTableGrads)
+    A = POINTER(SpnArenaPlan)
     sig = {
         'stove_abi_version': (I, []),
         'stove_error_string': (c_char_p, [I]),
@@ -69,6 +78,10 @@ def _declare(lib):
         'stove_lstm_cell_bwd': (I, [P] * 9 + [I, I, I, P]),
         'stove_gnn_debug_stamps': (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
         'stove_profile_report': (S, [c_char_p, S]),
+        'stove_spn_bake': (I, [P, A, P, P, P, P, P, P]),
+        'stove_spn_bake_bwd': (I, [P, A, G, P, P]),
+        'stove_arena_gather': (I, [P, P, P, I, P]),
+        'stove_arena_scatter_add': (I, [P, P, P, I, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -1,0 +1,160 @@
+// Flat parameter arena support: bake the SPN tables and the GNN parameter image straight from the
+// flat fp32 parameter buffer, and push table / image gradients straight back into the flat gradient
+// buffer (which is also the data-parallel all-reduce bucket).
+//
+// With the reference-layout parameters (162 separate tensors: vector_list.L.i.means ..., dyn.*.weight)
+// as views into one arena, this replaces ~250 small ATen launches per training step (stack / index /
+// sigmoid / softmax and their backward, the gradient clones of AccumulateGrad) by four launches.
+#include "common.h"
+
+namespace stove {
+
+// plan of the SPN part (all int32, device): offsets are float offsets into the arena
+//   obj_mu[24], obj_rho[24] (kernel leaf order), obj_sum[12] (kernel order), obj_root
+//   bg_mu[6], bg_rho[6] (reference leaf order), bg_root, bg_gidx[3*1024] = leaf*512 + row
+struct SpnArenaPlan {
+  const int* obj_mu;
+  const int* obj_rho;
+  const int* obj_sum;
+  const int* bg_mu;
+  const int* bg_rho;
+  const int* bg_gidx;
+  int obj_root, bg_root;
+  float obj_vmin, obj_vmax, bg_vmin, bg_vmax;
+};
+
+__device__ __forceinline__ void leaf_coef(float mu, float rho, float vmin, float vmax, float* abc) {
+  const float v = vmin + (vmax - vmin) * (1.0f / (1.0f + expf(-rho)));
+  const float iv = 1.0f / v;
+  abc[0] = -0.5f * iv;
+  abc[1] = mu * iv;
+  abc[2] = -0.5f * mu * mu * iv - 0.5f * logf(6.283185307179586f * v);
+}
+__device__ __forceinline__ void leaf_coef_bwd(float mu, float rho, float vmin, float vmax, const float* g, float* dmu, float* drho) {
+  const float s = 1.0f / (1.0f + expf(-rho));
+  const float v = vmin + (vmax - vmin) * s;
+  const float iv = 1.0f / v;
+  *dmu = g[1] * iv - g[2] * mu * iv;
+  const float dv = g[0] * 0.5f * iv * iv - g[1] * mu * iv * iv + g[2] * (0.5f * mu * mu * iv * iv - 0.5f * iv);
+  *drho = dv * (vmax - vmin) * s * (1.0f - s);
+}
+
+constexpr int kAObjLeaves = 24, kAObjS = 25, kAObjG = 10, kAObjSums = 12, kAObjK = 10;
+constexpr int kABgR = 3, kABgPix = 1024, kABgG = 6;
+constexpr int kAObjCoef = kAObjLeaves * kAObjS * kAObjG;    // 6000 (x3)
+constexpr int kABgCoef = kABgR * kABgPix * kABgG;           // 18432 (x3)
+constexpr int kASoftBlocks = (kAObjSums * kAObjK + 2 + 3) / 4;
+
+// column softmax over n rows with row stride ld: one 64-lane wave per column
+__device__ __forceinline__ void softmax_col(const float* __restrict__ p, float* __restrict__ w, int n, int ld) {
+  const int lane = lane_id();
+  float m = -3.0e38f;
+  for (int k = lane; k < n; k += 64) m = fmaxf(m, p[k * ld]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float s = 0.0f;
+  for (int k = lane; k < n; k += 64) s += expf(p[k * ld] - m);
+  s = wave_sum(s);
+  const float inv = 1.0f / s;
+  for (int k = lane; k < n; k += 64) w[k * ld] = expf(p[k * ld] - m) * inv;
+}
+// dp_k += w_k (g_k - sum_j w_j g_j)
+__device__ __forceinline__ void softmax_col_bwd(const float* __restrict__ p, const float* __restrict__ g, float* __restrict__ dp, int n, int ld) {
+  const int lane = lane_id();
+  float m = -3.0e38f;
+  for (int k = lane; k < n; k += 64) m = fmaxf(m, p[k * ld]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float s = 0.0f, d = 0.0f;
+  for (int k = lane; k < n; k += 64) {
+    const float e = expf(p[k * ld] - m);
+    s += e;
+    d = fmaf(e, g[k * ld], d);
+  }
+  s = wave_sum(s);
+  d = wave_sum(d);
+  const float inv = 1.0f / s, dot = d * inv;
+  for (int k = lane; k < n; k += 64) dp[k * ld] += expf(p[k * ld] - m) * inv * (g[k * ld] - dot);
+}
+
+// grid: ceil((6000 + 18432) / 256) element blocks, then 31 blocks of 4 waves, one wave per softmax column
+// (120 sum-node columns + the two roots)
+__global__ __launch_bounds__(256) void spn_bake_k(const float* __restrict__ arena, SpnArenaPlan pl, float* __restrict__ obj_coef,
+                                                  float* __restrict__ obj_wsum, float* __restrict__ obj_wroot,
+                                                  float* __restrict__ bg_coef, float* __restrict__ bg_wroot, int n_elem_blocks) {
+  if ((int)blockIdx.x < n_elem_blocks) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < kAObjCoef) {
+      const int q = t / (kAObjS * kAObjG), rem = t % (kAObjS * kAObjG);
+      leaf_coef(arena[pl.obj_mu[q] + rem], arena[pl.obj_rho[q] + rem], pl.obj_vmin, pl.obj_vmax, obj_coef + (size_t)t * 3);
+    } else if (t < kAObjCoef + kABgCoef) {
+      const int u = t - kAObjCoef;
+      const int rp = u / kABgG, g = u % kABgG;
+      const int gi = pl.bg_gidx[rp];
+      const int leaf = gi >> 9, row = gi & 511;
+      leaf_coef(arena[pl.bg_mu[leaf] + row * kABgG + g], arena[pl.bg_rho[leaf] + row * kABgG + g], pl.bg_vmin, pl.bg_vmax,
+                bg_coef + (size_t)u * 3);
+    }
+    return;
+  }
+  const int col = ((int)blockIdx.x - n_elem_blocks) * 4 + wave_id();
+  if (col < kAObjSums * kAObjK + 2) {
+    if (col < kAObjSums * kAObjK) {
+      const int node = col / kAObjK, s = col % kAObjK;
+      softmax_col(arena + pl.obj_sum[node] + s, obj_wsum + (size_t)node * 100 * kAObjK + s, 100, kAObjK);
+    } else if (col == kAObjSums * kAObjK) {
+      softmax_col(arena + pl.obj_root, obj_wroot, 600, 1);
+    } else {
+      softmax_col(arena + pl.bg_root, bg_wroot, kABgR * kABgG * kABgG, 1);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void spn_bake_bwd_k(const float* __restrict__ arena, SpnArenaPlan pl,
+                                                      const float* __restrict__ g_obj_coef, const float* __restrict__ g_obj_wsum,
+                                                      const float* __restrict__ g_obj_wroot, const float* __restrict__ g_bg_coef,
+                                                      const float* __restrict__ g_bg_wroot, float* __restrict__ garena,
+                                                      int n_elem_blocks) {
+  if ((int)blockIdx.x < n_elem_blocks) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < kAObjCoef) {
+      const int q = t / (kAObjS * kAObjG), rem = t % (kAObjS * kAObjG);
+      float dmu, drho;
+      leaf_coef_bwd(arena[pl.obj_mu[q] + rem], arena[pl.obj_rho[q] + rem], pl.obj_vmin, pl.obj_vmax, g_obj_coef + (size_t)t * 3, &dmu, &drho);
+      garena[pl.obj_mu[q] + rem] += dmu;
+      garena[pl.obj_rho[q] + rem] += drho;
+    } else if (t < kAObjCoef + kABgCoef) {
+      const int u = t - kAObjCoef;
+      const int rp = u / kABgG, g = u % kABgG;
+      const int gi = pl.bg_gidx[rp];
+      const int leaf = gi >> 9, row = gi & 511;
+      const int om = pl.bg_mu[leaf] + row * kABgG + g, orh = pl.bg_rho[leaf] + row * kABgG + g;
+      float dmu, drho;
+      leaf_coef_bwd(arena[om], arena[orh], pl.bg_vmin, pl.bg_vmax, g_bg_coef + (size_t)u * 3, &dmu, &drho);
+      garena[om] += dmu;
+      garena[orh] += drho;
+    }
+    return;
+  }
+  const int col = ((int)blockIdx.x - n_elem_blocks) * 4 + wave_id();
+  if (col < kAObjSums * kAObjK + 2) {
+    if (col < kAObjSums * kAObjK) {
+      const int node = col / kAObjK, s = col % kAObjK;
+      softmax_col_bwd(arena + pl.obj_sum[node] + s, g_obj_wsum + (size_t)node * 100 * kAObjK + s, garena + pl.obj_sum[node] + s, 100, kAObjK);
+    } else if (col == kAObjSums * kAObjK) {
+      softmax_col_bwd(arena + pl.obj_root, g_obj_wroot, garena + pl.obj_root, 600, 1);
+    } else {
+      softmax_col_bwd(arena + pl.bg_root, g_bg_wroot, garena + pl.bg_root, kABgR * kABgG * kABgG, 1);
+    }
+  }
+}
+
+// image[i] = src[i] >= 0 ? arena[src[i]] : 0      /      garena[src[i]] += gimage[i]
+__global__ void arena_gather_k(const float* __restrict__ arena, const int* __restrict__ src, float* __restrict__ image, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) image[i] = src[i] >= 0 ? arena[src[i]] : 0.0f;
+}
+__global__ void arena_scatter_add_k(const float* __restrict__ gimage, const int* __restrict__ src, float* __restrict__ garena, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && src[i] >= 0) garena[src[i]] += gimage[i];
+}
+
+}  // namespace stove

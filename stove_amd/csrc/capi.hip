@@ -10,6 +10,7 @@
 #include "gnn.hip"
 #include "match.hip"
 #include "lstm.hip"
+#include "arena.hip"
 
 namespace stove {
 
@@ -333,6 +334,47 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
   LoopConst kc{pos_var, vel_std, lat_std};
   STOVE_LAUNCH(rollout_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
                      z_last, extra, params, z_pred, zstd, pred, B, num, A < 1 ? 1 : A, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- flat parameter arena
+static SpnArenaPlan arena_plan(const StoveSpnArenaPlan* p) {
+  SpnArenaPlan q;
+  q.obj_mu = p->obj_mu; q.obj_rho = p->obj_rho; q.obj_sum = p->obj_sum;
+  q.bg_mu = p->bg_mu; q.bg_rho = p->bg_rho; q.bg_gidx = p->bg_gidx;
+  q.obj_root = p->obj_root; q.bg_root = p->bg_root;
+  q.obj_vmin = p->obj_vmin; q.obj_vmax = p->obj_vmax; q.bg_vmin = p->bg_vmin; q.bg_vmax = p->bg_vmax;
+  return q;
+}
+
+int stove_spn_bake(const float* arena, const StoveSpnArenaPlan* plan, float* obj_coef, float* obj_wsum, float* obj_wroot,
+                   float* bg_coef, float* bg_wroot, void* stream) {
+  const int nb = (kAObjCoef + kABgCoef + 255) / 256;
+  STOVE_LAUNCH(spn_bake_k, dim3(nb + kASoftBlocks), dim3(256), 0, (hipStream_t)stream, arena, arena_plan(plan), obj_coef, obj_wsum, obj_wroot,
+               bg_coef, bg_wroot, nb);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_spn_bake_bwd(const float* arena, const StoveSpnArenaPlan* plan, const StoveSpnTableGrads* g, float* grad_arena, void* stream) {
+  const int nb = (kAObjCoef + kABgCoef + 255) / 256;
+  STOVE_LAUNCH(spn_bake_bwd_k, dim3(nb + kASoftBlocks), dim3(256), 0, (hipStream_t)stream, arena, arena_plan(plan), (const float*)g->obj_coef,
+               (const float*)g->obj_wsum, (const float*)g->obj_wroot, (const float*)g->bg_coef, (const float*)g->bg_wroot, grad_arena, nb);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_arena_gather(const float* arena, const int32_t* src, float* image, int n, void* stream) {
+  if (n == 0) return 0;
+  STOVE_LAUNCH(arena_gather_k, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, arena, src, image, n);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_arena_scatter_add(const float* gimage, const int32_t* src, float* grad_arena, int n, void* stream) {
+  if (n == 0) return 0;
+  STOVE_LAUNCH(arena_scatter_add_k, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gimage, src, grad_arena, n);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

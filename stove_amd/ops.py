@@ -122,7 +122,7 @@ class _SceneFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, frames, z, obj_coef, obj_wsum, obj_wroot, bg_coef, bg_wroot,
-                obj_scope, obj_leaf_slot, bg_side, n_obj, beta):
+                obj_scope, obj_leaf_slot, bg_side, n_obj, beta, sink=None):
         lib = _lib.load()
         frames, z = _f32(frames), _f32(z)
         tabs = [_f32(x) for x in (obj_coef, obj_wsum, obj_wroot, bg_coef, bg_wroot)]
@@ -136,7 +136,7 @@ class _SceneFn(torch.autograd.Function):
             check(lib.stove_scene_fwd(ctypes.byref(t), ptr(frames), ptr(z), nf, n_obj, float(beta), ptr(ll), ptr(parts),
                                       ptr(saved), stream()), 'stove_scene_fwd')
         ctx.save_for_backward(frames, z, *tabs, obj_scope, obj_leaf_slot, bg_side, saved)
-        ctx.n_obj, ctx.beta = n_obj, float(beta)
+        ctx.n_obj, ctx.beta, ctx.sink = n_obj, float(beta), sink
         ctx.mark_non_differentiable(parts)
         return ll, parts
 
@@ -156,7 +156,10 @@ class _SceneFn(torch.autograd.Function):
             t = _tables(obj=(obj_scope, obj_leaf_slot, oc, ow, orr), bg=(bg_side, bc, bw))
             check(lib.stove_scene_bwd(ctypes.byref(t), ptr(frames), ptr(z), nf, n_obj, ctx.beta, ptr(saved), ptr(dll),
                                       ptr(dz), ctypes.byref(g), ptr(ws), stream()), 'stove_scene_bwd')
-        return (None, dz, *grads, None, None, None, None, None)
+        if ctx.sink is not None:               # flat parameter arena: table gradients go straight into the bucket
+            ctx.sink(grads)
+            grads = [None] * 5
+        return (None, dz, *grads, None, None, None, None, None, None)
 
 
 def objspn_apply(inputs, marg, coef, wsum, wroot, scope, leaf_slot):
@@ -167,12 +170,15 @@ def bgspn_apply(inputs, marg, coef, wroot, side):
     return _BgSpnFn.apply(inputs, marg, coef, wroot, side)
 
 
-def scene_likelihood(frames, z, obj_tabs, bg_tabs, n_obj, beta):
+def scene_likelihood(frames, z, obj_tabs, bg_tabs, n_obj, beta, sink=None):
     """frames (nf,1024), z (nf*n_obj,4)=[sx,sy,x,y]; obj_tabs=(coef,wsum,wroot,scope,leaf_slot),
-    bg_tabs=(coef,wroot,side) -> ll (nf,), parts (nf,3)=(bg, patches, overlap)."""
+    bg_tabs=(coef,wroot,side) -> ll (nf,), parts (nf,3)=(bg, patches, overlap).
+    `sink(table_grads)`: receives the five table gradients in backward instead of autograd (ParamArena)."""
     oc, ow, orr, osc, ols = obj_tabs
     bc, bw, bs = bg_tabs
-    return _SceneFn.apply(frames, z, oc, ow, orr, bc, bw, osc, ols, bs, int(n_obj), float(beta))
+    if sink is not None and not z.requires_grad and torch.is_grad_enabled():
+        z = z.detach().requires_grad_()        # the sink needs the backward to run
+    return _SceneFn.apply(frames, z, oc, ow, orr, bc, bw, osc, ols, bs, int(n_obj), float(beta), sink)
 
 
 def scene_glimpses(frames, z, n_obj):
@@ -207,6 +213,8 @@ GNN_V_FLOATS = 672
 
 
 def _gnn_image(w_img, v_img, wt_img):
+    if v_img is None:                          # prebuilt [W | W^T | vectors] image (ParamArena.gnn_image)
+        return w_img
     return torch.cat([w_img, wt_img, v_img]).contiguous()
 
 
@@ -214,12 +222,13 @@ class _GnnStepFn(torch.autograd.Function):
     """Dynamics.forward core (reference dynamics.py:181-265): s_in (B,N,sin_dim) -> result, dynamic_pred (B,N,32)."""
 
     @staticmethod
-    def forward(ctx, s_in, w_img, v_img, wt_img, lim_enc, elu):
+    def forward(ctx, s_in, w_img, v_img, wt_img, lim_enc, elu, sink=None):
         lib = _lib.load()
         s_in = _f32(s_in)
         B, N, sd = s_in.shape
         dev = s_in.device
         params = _gnn_image(_f32(w_img), _f32(v_img), _f32(wt_img))
+        ctx.sink = sink
         with torch.cuda.device(dev):
             res = torch.empty(B, N, 32, dtype=torch.float32, device=dev)
             pred = torch.empty(B, N, 32, dtype=torch.float32, device=dev)
@@ -244,14 +253,17 @@ class _GnnStepFn(torch.autograd.Function):
             ws = _ws(lib.stove_gnn_bwd_ws_bytes(B, N), dev)
             check(lib.stove_gnn_bwd(ptr(s_in), ptr(params), ptr(dres), ptr(dpred), ptr(d_s), ptr(g), ptr(ws), B, N, sd,
                                     lim_enc, elu, stream()), 'stove_gnn_bwd')
-        return d_s, g[:GNN_W_FLOATS], g[GNN_W_FLOATS:], None, None, None
+        if ctx.sink is not None:
+            ctx.sink(g)
+            return d_s, None, None, None, None, None, None
+        return d_s, g[:GNN_W_FLOATS], g[GNN_W_FLOATS:], None, None, None, None
 
 
 class _DynLoopFn(torch.autograd.Function):
     """The T-serial inference recursion of Stove.stove_forward in one persistent kernel."""
 
     @staticmethod
-    def forward(ctx, z1, zsup, zsstd, eps, extra, w_img, v_img, wt_img, lim_enc, elu, consts, want_pred):
+    def forward(ctx, z1, zsup, zsstd, eps, extra, w_img, v_img, wt_img, lim_enc, elu, consts, want_pred, sink=None):
         lib = _lib.load()
         z1, zsup, zsstd, eps = _f32(z1), _f32(zsup), _f32(zsstd), _f32(eps)
         extra = _f32(extra)
@@ -273,6 +285,7 @@ class _DynLoopFn(torch.autograd.Function):
                                         int(elu), *[float(c) for c in consts], stream()), 'stove_dynloop_fwd')
         ctx.save_for_backward(z1, zsup, zsstd, eps, extra, params, z, act)
         ctx.cfg = (int(lim_enc), int(elu), tuple(float(c) for c in consts), sd)
+        ctx.sink = sink
         ctx.mark_non_differentiable(zdstd)
         if pred is None:
             pred = z.new_zeros(0)
@@ -299,16 +312,27 @@ class _DynLoopFn(torch.autograd.Function):
                                         ptr(up(dz, z)), ptr(up(dzdyn, z)), ptr(up(dmean, z)), ptr(up(dstd, z)),
                                         ptr(up(dpred, z)), ptr(dz1), ptr(dzsup), ptr(dzsstd), ptr(dextra), ptr(g), ptr(ws),
                                         B, Ts, N, sd, lim_enc, elu, *consts, stream()), 'stove_dynloop_bwd')
-        return (dz1, dzsup, dzsstd, None, dextra, g[:GNN_W_FLOATS], g[GNN_W_FLOATS:], None, None, None, None, None)
+        if ctx.sink is not None:
+            ctx.sink(g)
+            return (dz1, dzsup, dzsstd, None, dextra) + (None,) * 8
+        return (dz1, dzsup, dzsstd, None, dextra, g[:GNN_W_FLOATS], g[GNN_W_FLOATS:], None, None, None, None, None, None)
 
 
-def gnn_step(s_in, image, lim_enc=2, elu=False):
-    """image = (w_img, v_img, wt_img) from Dynamics.param_image()."""
-    return _GnnStepFn.apply(s_in, image[0], image[1], image[2], lim_enc, elu)
+def _sunk(t, sink):
+    """With a gradient sink the parameters are not autograd inputs: make sure the backward still runs."""
+    if sink is not None and not t.requires_grad and torch.is_grad_enabled():
+        return t.detach().requires_grad_()
+    return t
 
 
-def dyn_loop(z1, zsup, zsstd, eps, extra, image, lim_enc, elu, consts, want_pred=False):
-    return _DynLoopFn.apply(z1, zsup, zsstd, eps, extra, image[0], image[1], image[2], lim_enc, elu, consts, want_pred)
+def gnn_step(s_in, image, lim_enc=2, elu=False, sink=None):
+    """image = (w_img, v_img, wt_img) from Dynamics.param_image(), or (flat image, None, None) + a gradient sink."""
+    return _GnnStepFn.apply(_sunk(s_in, sink), image[0], image[1], image[2], lim_enc, elu, sink)
+
+
+def dyn_loop(z1, zsup, zsstd, eps, extra, image, lim_enc, elu, consts, want_pred=False, sink=None):
+    return _DynLoopFn.apply(_sunk(z1, sink), zsup, zsstd, eps, extra, image[0], image[1], image[2], lim_enc, elu, consts,
+                            want_pred, sink)
 
 
 @torch.no_grad()

@@ -66,12 +66,28 @@ class Dynamics(nn.Module):
         self.transition_lik_std = torch.tensor([[std]], dtype=torch.float32, device=self.c.device)
 
     # ------------------------------------------------------------------ kernel parameter image
-    def param_image(self, core_idx=0):
-        """(W image, vector image, W^T image) of one core as flat float32 tensors."""
+    def param_image(self, core_idx=0, leaf=None, pad_value=0.0):
+        """(W image, vector image, W^T image) of one core as flat float32 tensors.
+
+        `leaf(p)` substitutes every parameter (ParamArena passes arena indices through the same
+        packing code to get the gather table of its one-launch image; pads are then `pad_value`)."""
         k = core_idx
-        r0, a0 = self.rel_cores[k][0], self.att_net[k][0]
         cl = self.c.cl
-        enc_w = F.pad(self.state_enc.weight, (0, cl - self.enc_input_size))
+        if leaf is not None:
+            class _L:                                   # a Linear whose weight / bias went through leaf()
+                def __init__(self, lin):
+                    self.weight, self.bias = leaf(lin.weight), leaf(lin.bias)
+            wrap = lambda lin: _L(lin)                  # noqa: E731
+        else:
+            wrap = lambda lin: lin                      # noqa: E731
+        this = self
+        self = type('_View', (), {})()                  # same packing code on wrapped layers
+        self.state_enc = wrap(this.state_enc)
+        for name in ('self_cores', 'rel_cores', 'att_net', 'affector', 'out'):
+            setattr(self, name, {k: [wrap(lin) for lin in getattr(this, name)[k]]})
+        self.enc_input_size = this.enc_input_size
+        r0, a0 = self.rel_cores[k][0], self.att_net[k][0]
+        enc_w = F.pad(self.state_enc.weight, (0, cl - self.enc_input_size), value=pad_value)
         ef = torch.cat([r0.weight[:, :cl], r0.weight[:, cl:2 * cl], a0.weight[:, :cl], a0.weight[:, cl:2 * cl]], 0)
         mats = [enc_w, self.self_cores[k][0].weight, self.self_cores[k][1].weight, ef,
                 self.rel_cores[k][1].weight, self.att_net[k][1].weight, self.rel_cores[k][2].weight,
@@ -84,11 +100,19 @@ class Dynamics(nn.Module):
         vecs = [self.state_enc.bias, self.self_cores[k][0].bias, self.self_cores[k][1].bias,
                 r0.bias, r0.weight[:, 2 * cl], a0.bias, a0.weight[:, 2 * cl],
                 self.rel_cores[k][1].bias, self.att_net[k][1].bias, self.rel_cores[k][2].bias,
-                a2.weight.reshape(-1), F.pad(a2.bias, (0, cl - 1)),
+                a2.weight.reshape(-1), F.pad(a2.bias, (0, cl - 1), value=pad_value),
                 self.affector[k][0].bias, self.affector[k][1].bias, self.affector[k][2].bias,
                 self.out[k][0].bias, self.out[k][1].bias]
         v_img = torch.cat(vecs)
         return w_img, v_img, wt_img
+
+    def kernel_params(self, core_idx=0):
+        """-> (image tuple for ops.gnn_step / dyn_loop / rollout, gradient sink or None).  With a ParamArena the
+        image is one gather launch and the gradient image is scattered straight into the flat gradient buffer."""
+        arena = getattr(self, '_arena', None)
+        if arena is not None and arena.has_gnn:
+            return (arena.gnn_image(core_idx), None, None), (lambda g: arena.gnn_sink(g, core_idx))
+        return self.param_image(core_idx), None
 
     def loop_consts(self):
         """(pos std bound, velocity std bound, latent std bound) of constrain_z_dyn."""
@@ -124,7 +148,8 @@ class Dynamics(nn.Module):
         s = self.core_inputs(s, actions, obj_appearances)
         if s.shape[-1] != self.enc_input_size:
             raise ValueError('core input has %d dims, the encoder expects %d' % (s.shape[-1], self.enc_input_size))
-        result, dynamic_pred = ops.gnn_step(s, self.param_image(core_idx), lim_enc, self.use_elu)
+        image, sink = self.kernel_params(core_idx)
+        result, dynamic_pred = ops.gnn_step(s, image, lim_enc, self.use_elu, sink)
         if self.c.action_conditioned:
             return result, self.reward_from_pred(dynamic_pred).view(-1, 1)
         return result, 0

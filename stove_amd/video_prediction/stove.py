@@ -185,9 +185,10 @@ class Stove(nn.Module):
                 extra.append(obj_appearances[:, skip - 1:T - 1])
             extra = torch.cat(extra, -1) if extra else None
             eps = self._noise('steps', (n, Ts, o, cl // 2 + 2), z_sup)
+            image, sink = self.dyn.kernel_params(0)
             z_s, z_dyn_s, z_dyn_std_s, mean_s, z_std_s, pred = ops.dyn_loop(
-                init_z, z_sup_full[:, skip:], z_sup_std_full[:, skip:], eps, extra, self.dyn.param_image(0),
-                2, self.dyn.use_elu, self.dyn.loop_consts(), want_pred=bool(c.action_conditioned))
+                init_z, z_sup_full[:, skip:], z_sup_std_full[:, skip:], eps, extra, image,
+                2, self.dyn.use_elu, self.dyn.loop_consts(), want_pred=bool(c.action_conditioned), sink=sink)
             log_z_s = _normal_log_prob(z_s, mean_s, z_std_s)
             rewards = self.dyn.reward_from_pred(pred) if c.action_conditioned else torch.zeros(Ts)
         else:
@@ -255,7 +256,7 @@ class Stove(nn.Module):
                 a_len = actions.shape[1] if actions is not None else 1
                 extra.append(appearance.unsqueeze(1).expand(-1, a_len, -1, -1))
             extra = torch.cat(extra, -1).contiguous() if extra else None
-            z_full, z_stds, pred = ops.rollout(z_last, extra, self.dyn.param_image(0), num, 2, self.dyn.use_elu,
+            z_full, z_stds, pred = ops.rollout(z_last, extra, self.dyn.kernel_params(0)[0], num, 2, self.dyn.use_elu,
                                               self.dyn.loop_consts(), want_std=return_std,
                                               want_pred=bool(c.action_conditioned))
             rewards = self.dyn.reward_from_pred(pred) if c.action_conditioned else torch.zeros(num)

@@ -42,9 +42,14 @@ class Supair(nn.Module):
                 or self.c.patch_width != 10 or self.c.patch_height != 10:
             raise NotImplementedError('scene kernels are built for 1x32x32 frames and 10x10 glimpses')
         frames = x.flatten(end_dim=1).flatten(start_dim=1)
+        arena = getattr(self, '_arena', None)
+        if arena is not None and arena.has_spn:         # flat parameter arena: one bake launch, gradients sunk
+            obj_tabs, bg_tabs = arena.spn_tables()
+            sink = arena.spn_sink
+        else:
+            obj_tabs, bg_tabs, sink = self.obj_spn.tables(), self.bg_spn.tables(), None
         log_p_xz, parts = ops.scene_likelihood(
-            frames, z_obj.reshape(-1, 4), self.obj_spn.tables(), self.bg_spn.tables(),
-            self.c.num_obj, self.c.overlap_beta)
+            frames, z_obj.reshape(-1, 4), obj_tabs, bg_tabs, self.c.num_obj, self.c.overlap_beta, sink)
         if ((self.step_counter % self.c.print_every == 0)
                 or (self.step_counter % self.c.plot_every == 0)):
             if self.c.debug:

@@ -19,6 +19,7 @@ import torch.optim as optim
 from torch import nn
 from torch.utils.data import DataLoader
 
+from ..arena import ParamArena
 from ..parallel import GradBucket
 from ..utils.utils import ExperimentLogger
 
@@ -38,11 +39,17 @@ class AbstractTrainer:
         self.test_dataloader = DataLoader(test_dataset, batch_size=self.c.batch_size, shuffle=True,
                                           num_workers=self.c.num_workers, drop_last=True)
         self.optimizer = optim.Adam(self.stove.parameters(), lr=self.c.learning_rate, amsgrad=self.c.debug_amsgrad)
-        self.bucket = GradBucket(self.stove, self.world_size)
         if self.c.load_encoder is not None:
             self.load_encoder()
         if not self.c.supair_grad:
             self.disable_supair_grad()
+        # [amd] flat parameter / gradient arena (one-launch table baking, gradient bucket == all-reduce buffer);
+        # the per-tensor GradBucket is the fallback for models that are not fp32 on a GPU
+        p0 = next(self.stove.parameters())
+        if getattr(self.c, 'param_arena', True) and p0.is_cuda and p0.dtype == torch.float32:
+            self.bucket = ParamArena(self.stove, self.world_size)
+        else:
+            self.bucket = GradBucket(self.stove, self.world_size)
         self.epoch_start, self.step_start = 0, 0
         if self.c.checkpoint_path is not None:
             self.load()
@@ -202,7 +209,10 @@ class Trainer(AbstractTrainer):
         min_ll.backward()
         self.bucket.all_reduce()                     # [amd] one RCCL all-reduce of the flat gradient
         if self.c.debug_gradient_clip:
-            torch.nn.utils.clip_grad_norm_(self.stove.parameters(), 1)
+            if isinstance(self.bucket, ParamArena):
+                self.bucket.clip_grad_norm_(1)
+            else:
+                torch.nn.utils.clip_grad_norm_(self.stove.parameters(), 1)
         self.optimizer.step()
         return elbo, prop_dict, rewards, min_ll, mse_rewards
 

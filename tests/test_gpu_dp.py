@@ -39,11 +39,11 @@ def _worker(rank, world, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from stove_amd.parallel import GradBucket
+    from stove_amd.arena import ParamArena
     from stove_amd.video_prediction.stove import Stove
     gold = load_golden('g7_stove_n3_f32')
     model = fill_analytic(Stove(_cfg())).to('cuda:0')
-    bucket = GradBucket(model, world)
+    bucket = ParamArena(model, world)
     x = t_(gold['x']).float()
     per = x.shape[0] // world
     elbo = _run(model, x, gold, rank * per, (rank + 1) * per)
@@ -51,8 +51,8 @@ def _worker(rank, world, port, out):
     e = torch.tensor([elbo], dtype=torch.float64)
     dist.all_reduce(e)
     if rank == 0:
-        torch.save({'flat': bucket.flat.cpu(), 'elbo': float(e) / world,
-                    'names': [n for n, p in model.named_parameters() if p.grad is not None]}, out)
+        torch.save({'grads': {n: p.grad.cpu() for n, p in model.named_parameters()}, 'elbo': float(e) / world,
+                    'bucket_numel': bucket.grad.numel()}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -70,9 +70,14 @@ def test_two_rank_gradients_equal_single_process(tmp_path):
     model = fill_analytic(Stove(_cfg())).to('cuda:0')
     x = t_(gold['x']).float()
     elbo = _run(model, x, gold, 0, x.shape[0])
+    used = [n for n, p in model.named_parameters() if p.grad is not None]
     ref = torch.cat([p.grad.reshape(-1) for n, p in model.named_parameters() if p.grad is not None]).cpu()
-    assert got['names'] == [n for n, p in model.named_parameters() if p.grad is not None]
+    flat = torch.cat([got['grads'][n].reshape(-1) for n in used])
     assert abs(got['elbo'] - elbo) < 1e-5 * abs(elbo)
-    rel = float((got['flat'] - ref).abs().max() / ref.abs().max())
+    rel = float((flat - ref).abs().max() / ref.abs().max())
     assert rel < 2e-4, rel
-    assert got['flat'].numel() == 1410255          # the parameters that receive a gradient
+    assert flat.numel() == 1410255                 # the parameters that receive a gradient
+    for n, g in got['grads'].items():              # the unused dynamics cores 1-2 stay exactly zero in the bucket
+        if n not in used:
+            assert float(g.abs().max()) == 0.0, n
+    assert got['bucket_numel'] >= 1410255          # exchanged as ONE flat buffer (all parameters, 16-byte aligned)

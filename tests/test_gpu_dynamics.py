@@ -32,10 +32,14 @@ VARIANTS = {
 
 
 @pytest.mark.parametrize('name', list(VARIANTS))
-def test_dynamics_step(name):
+@pytest.mark.parametrize('arena', [False, True])
+def test_dynamics_step(name, arena):
+    from stove_amd.arena import ParamArena
     from stove_amd.video_prediction.dynamics import Dynamics
     gold = load_golden(f'g5_dynamics_{name}_f64')
     dyn = fill_analytic(Dynamics(make_cfg(**VARIANTS[name])), 'dyn.').to(DEV)
+    if arena:
+        assert ParamArena(dyn).has_gnn
     s = t_(gold['s']).float().to(DEV).requires_grad_()
     act = t_(gold['actions']).float().to(DEV) if 'actions' in gold else None
     app = t_(gold['app']).float().to(DEV).requires_grad_() if 'app' in gold else None
@@ -125,10 +129,17 @@ def _golden_noise(gold):
 
 @pytest.mark.parametrize('name', list(CASES))
 @pytest.mark.parametrize('fused', [True, False])
-def test_stove_forward_elbo_and_grads(name, fused):
+@pytest.mark.parametrize('arena', [False, True])
+def test_stove_forward_elbo_and_grads(name, fused, arena):
+    """`arena`: parameters / gradients as views into the flat ParamArena buffers, tables baked and gradients sunk
+    by the arena kernels -- must give the same numbers as the per-tensor autograd path."""
+    from stove_amd.arena import ParamArena
     from stove_amd.video_prediction.stove import Stove
     gold = load_golden(f'g7_stove_{name}_f64')
     st = fill_analytic(Stove(make_cfg(fused_dynamics=fused, **CASES[name]))).to(DEV)
+    if arena:
+        ar = ParamArena(st)
+        assert ar.has_spn and ar.has_gnn
     st.noise_fn = _golden_noise(gold)
     x = t_(gold['x']).float().to(DEV)
     actions = t_(gold['actions']).float().to(DEV) if 'actions' in gold else None
@@ -154,6 +165,9 @@ def test_stove_forward_elbo_and_grads(name, fused):
         elif k.startswith('g_'):
             assert err(params[k[2:]].grad, v) < 5e-3, k
     assert n > 50
+    if arena:                                                  # cores 1-2 are never used: their gradients stay zero
+        assert float(params['dyn.self_cores.1.0.weight'].grad.abs().max()) == 0.0
+        ar.check()
     # rollout from the last inferred state (G8)
     with torch.no_grad():
         z_last = prop['z'][:, -1]
@@ -233,13 +247,16 @@ def test_supair_only_elbo():
             assert abs(float(params[k[3:]].grad.norm()) - float(v)) <= 5e-3 * float(v) + 1e-9, k
 
 
-def test_three_optimiser_steps_track_the_reference():
+@pytest.mark.parametrize('arena', [False, True])
+def test_three_optimiser_steps_track_the_reference(arena):
     """Adam(amsgrad) + lr schedule + clip_grad_norm_(1) on one batch (reference train.py:431-473, fp32):
     the ELBO sequence and parameter checksums after three steps."""
+    from stove_amd.arena import ParamArena
     from stove_amd.video_prediction.stove import Stove
     g = load_golden('g9_optimiser_steps')
     cfg = make_cfg()
     st = fill_analytic(Stove(cfg)).to(DEV)
+    ar = ParamArena(st) if arena else None
     opt = torch.optim.Adam(st.parameters(), lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
     x = t_(g['x']).float().to(DEV)
     for step in range(1, 4):
@@ -250,10 +267,16 @@ def test_three_optimiser_steps_track_the_reference():
         st.noise_fn = lambda kind, shape, _t=table: _t[kind].reshape(shape)
         for grp in opt.param_groups:
             grp['lr'] = max(cfg.learning_rate * np.exp(-step / cfg.debug_anneal_lr), cfg.min_learning_rate)
-        opt.zero_grad()
+        if arena:
+            ar.zero_grad()
+        else:
+            opt.zero_grad()
         elbo, _, _ = st(x, step, None)
         (-elbo).backward()
-        torch.nn.utils.clip_grad_norm_(st.parameters(), 1)
+        if arena:
+            ar.clip_grad_norm_(1)
+        else:
+            torch.nn.utils.clip_grad_norm_(st.parameters(), 1)
         opt.step()
         ref = float(g['elbos'][step - 1])
         assert abs(float(elbo.detach()) - ref) < 2e-4 * abs(ref), (step, float(elbo.detach()), ref)

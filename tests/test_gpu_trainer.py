@@ -40,8 +40,9 @@ def test_main_train_test_rollout(tmp_path, preset):
         elbos.append(float(elbo))
     changed = sum(int(not torch.equal(a, b)) for a, b in zip(before, trainer.stove.parameters()))
     assert changed > 100                         # every used parameter moved
-    flat = trainer.bucket.pack()                 # the DP exchange buffer: one contiguous 1.41 M-float tensor
-    assert flat.numel() == sum(p.numel() for p in trainer.stove.parameters() if p.grad is not None)
+    flat = trainer.bucket.pack()                 # the DP exchange buffer: one contiguous tensor holding every gradient
+    assert flat.is_contiguous() and flat.numel() >= sum(p.numel() for p in trainer.stove.parameters())
+    assert flat.numel() < sum(p.numel() + 4 for p in trainer.stove.parameters())      # 16-byte alignment pads only
     trainer.test(3, 0.0)                         # ELBO + 4-frame rollout errors through the logger
     out = trainer.long_rollout(idx=[0, 1], num=12)
     assert out['z_pred'].shape == (2, 12, 3, 18) and np.isfinite(out['z_pred']).all()
