@@ -372,6 +372,22 @@ def match_objects(feat, mode):
     return idx, perm
 
 
+def _splitk_tn(a, b):
+    """a^T @ b for tall a (K, M), b (K, N) with K >> M, N (weight gradients over all frames).
+
+    rocBLAS picks a low-occupancy kernel for this shape (40 TFLOP/s fp32 on MI355X for 1024 x 256 x 25 600);
+    the same product as a batched GEMM over S chunks of K plus a sum runs at 120-140 TFLOP/s (tools/gemm_probe3.py)."""
+    K = a.shape[0]
+    S = 1
+    for cand in (16, 8, 4, 2) if a.shape[1] * b.shape[1] <= (1 << 19) else ():      # a 1024 x 1024 output already fills the chip
+        if K % cand == 0 and K // cand >= 1024:
+            S = cand
+            break
+    if S == 1:
+        return torch.mm(a.t(), b)
+    return torch.bmm(a.view(S, K // S, -1).transpose(1, 2), b.view(S, K // S, -1)).sum(0)
+
+
 class _EncoderLstmFn(torch.autograd.Function):
     """num_steps LSTM steps on the SAME input x (reference encoder.py:43-51): hs (n, num_steps, H).
 
@@ -410,18 +426,24 @@ class _EncoderLstmFn(torch.autograd.Function):
         dhs = _f32(dhs.transpose(0, 1))                       # (K, n, H)
         with torch.cuda.device(dev):
             dgx = torch.empty_like(gx)
-            dg = torch.empty_like(gx)
+            # gate gradients of steps 1..K-1 are kept ((K-1) x 105 MB at 25 600 frames) so that dW_hh is ONE
+            # GEMM over all steps; step 0 (h_{-1} = 0) only feeds dgx and uses slot 0 as scratch at the end
+            dg_all = torch.empty(max(K - 1, 1), n, 4 * H, dtype=torch.float32, device=dev)
             dc = [torch.empty(n, H, dtype=torch.float32, device=dev) for _ in range(2)]
-            d_whh = torch.zeros_like(w_hh)
             dh = dhs[K - 1]
+            d_whh = None
             for k in range(K - 1, -1, -1):
+                if k == 0 and K > 1:
+                    d_whh = _splitk_tn(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H))       # before slot 0 is reused
+                dg = dg_all[max(k - 1, 0)]
                 check(lib.stove_lstm_cell_bwd(ptr(gx), ptr(ghs[k]), ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(dh),
                                               ptr(dc[(k + 1) % 2]) if k < K - 1 else None, ptr(dg), ptr(dc[k % 2]), ptr(dgx),
                                               1 if k == K - 1 else 0, n, H, stream()), 'stove_lstm_cell_bwd')
                 if k > 0:
-                    d_whh.addmm_(dg.t(), hs[k - 1])
                     dh = torch.addmm(dhs[k - 1], dg, w_hh)
-            d_wih = torch.mm(dgx.t(), x)
+            if d_whh is None:
+                d_whh = torch.zeros_like(w_hh)
+            d_wih = _splitk_tn(dgx, x)
             d_b = dgx.sum(0)
         dx = torch.mm(dgx, w_ih) if ctx.needs_input_grad[0] else None
         return dx, d_wih, d_whh, d_b, d_b, None
