@@ -192,24 +192,52 @@ __device__ __forceinline__ void gnn_setup(const GnnLds& L, const GnnShape& sh, c
   }
 }
 
+// Weight fragments of the first two stages, which every step of the time loop starts with: loaded ONCE per
+// kernel and kept in registers (48 VGPRs), so the step never waits on L2 before its first MFMA.  All later
+// stages fetch their fragments one or two stages ahead (WFrag prefetch), for the same reason.
+struct FwdW {
+  WFrag<32> enc;          // encoder tile (wave & 1)
+  float4 ef0[4], ef1[4];  // edge-first column tiles wave + 4 q
+  float4 s00, s01;        // self.0 tile (wave & 1)
+};
+__device__ __forceinline__ FwdW gnn_fwdw_load(const float* __restrict__ Wf) {
+  const int wv = wave_id(), i = lane_id() & 15, kq = lane_id() >> 4;
+  FwdW f;
+  f.enc = wfrag_load<32>(Wf + W_ENC + (wv & 1) * 16 * 32, 32);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float* w = Wf + W_EF + (wv + 4 * q) * 16 * 32 + i * 32 + 4 * kq;
+    f.ef0[q] = *reinterpret_cast<const float4*>(w);
+    f.ef1[q] = *reinterpret_cast<const float4*>(w + 16);
+  }
+  const float* w = Wf + W_S0 + (wv & 1) * 16 * 32 + i * 32 + 4 * kq;
+  f.s00 = *reinterpret_cast<const float4*>(w);
+  f.s01 = *reinterpret_cast<const float4*>(w + 16);
+  return f;
+}
+
 // =================================================================================================
 // forward of one GNN step; input L.SIN (rows < NR, cols < sin_dim, rest zero), output L.RES, L.PRED
 // =================================================================================================
-__device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh, const float* __restrict__ Wf) {
+__device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh, const float* __restrict__ Wf, const FwdW& fw) {
   const int wv = wave_id();
   const int tid = threadIdx.x;
+  const int w01 = wv & 1;
   const float* V = L.V;
   float* S = L.CAT + 32;   // S lives in CAT[:, 32:64]
   gnn_stamp(sh, 0);
   // 1. state encoder; raw positions (first lim_enc dims) are kept for the distances (dynamics.py:250)
   if (wv < 2) {
-    const f32x4 acc = tile_AB<32>(L.SIN, LDN, Wf + W_ENC + wv * 16 * 32, 32);
+    const f32x4 acc = tile_AW<32>(L.SIN, LDN, fw.enc);
     tile_each(acc, 0, wv * 16, [&](int r, int c, float v) {
       S[r * LDC + c] = (c < sh.lim_enc) ? L.SIN[r * LDN + c] : v + V[V_ENC + c];
     });
   }
   WG_SYNC();
   gnn_stamp(sh, 1);
+  // fragments of stages 3 and 4, in flight while stage 2 computes
+  const WFrag<32> ws1 = wfrag_load<32>(Wf + W_S1 + w01 * 16 * 32, 32);
+  const WFrag<64> w4 = wfrag_load<64>(Wf + (w01 ? W_A1 : W_R1) + ((wv >> 1) & 1) * 16 * 64, 64);
   // 2. self-dynamics layer 0 and the factorised first edge layer (rel_i | rel_j | att_i | att_j)
   {
     // every tile of this stage multiplies the same 16 x 32 activation block S: read its fragment once,
@@ -221,15 +249,11 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
     float4 b0[5], b1[5];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float* w = Wf + W_EF + (wv + 4 * q) * 16 * 32 + i * 32 + 4 * kq;
-      b0[q] = *reinterpret_cast<const float4*>(w);
-      b1[q] = *reinterpret_cast<const float4*>(w + 16);
+      b0[q] = fw.ef0[q];
+      b1[q] = fw.ef1[q];
     }
-    {
-      const float* w = Wf + W_S0 + (wv & 1) * 16 * 32 + i * 32 + 4 * kq;
-      b0[4] = *reinterpret_cast<const float4*>(w);
-      b1[4] = *reinterpret_cast<const float4*>(w + 16);
-    }
+    b0[4] = fw.s00;
+    b1[4] = fw.s01;
     f32x4 c[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) c[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -294,6 +318,7 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
   WG_SYNC();
   gnn_stamp(sh, 2);
   // 3. edge pre-activations (gather) + self-dynamics layer 1
+  const WFrag<32> w5 = wfrag_load<32>(Wf + W_R2 + w01 * 16 * 32, 32);
   {
     for (int idx = tid; idx < sh.ME * 16 * 64; idx += blockDim.x) {
       const int e = idx >> 6, c = idx & 63;
@@ -309,20 +334,21 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
       L.A1[e * LDC + c] = a1;
     }
     if (wv < 2) {
-      const f32x4 acc = tile_AB<32>(L.H1, LDN, Wf + W_S1 + wv * 16 * 32, 32);
+      const f32x4 acc = tile_AW<32>(L.H1, LDN, ws1);
       tile_each(acc, 0, wv * 16, [&](int r, int c, float v) { L.SD[r * LDN + c] = v + V[V_S1 + c] + L.H1[r * LDN + c]; });
     }
   }
   WG_SYNC();
   gnn_stamp(sh, 3);
-  // 4. second edge layers (64 -> 32), relation and attention
+  // 4. second edge layers (64 -> 32), relation and attention: wave w owns (column tile (w>>1)&1, which = w&1)
+  WFrag<32> wf0 = wfrag_load<32>(Wf + W_F0 + w01 * 16 * 32, 32);      // stage 7's fragment
   for (int t = wv; t < sh.ME * 4; t += 4) {
     const int m = t >> 2, n = (t >> 1) & 1, which = t & 1;
     if (which == 0) {
-      const f32x4 acc = tile_AB<64>(L.R1 + m * 16 * LDC, LDC, Wf + W_R1 + n * 16 * 64, 64);
+      const f32x4 acc = tile_AW<64>(L.R1 + m * 16 * LDC, LDC, w4);
       tile_each(acc, m * 16, n * 16, [&](int r, int c, float v) { L.R2[r * LDN + c] = act_phi(v + V[V_BR1 + c], sh.elu); });
     } else {
-      const f32x4 acc = tile_AB<64>(L.A1 + m * 16 * LDC, LDC, Wf + W_A1 + n * 16 * 64, 64);
+      const f32x4 acc = tile_AW<64>(L.A1 + m * 16 * LDC, LDC, w4);
       tile_each(acc, m * 16, n * 16, [&](int r, int c, float v) { L.A2[r * LDN + c] = act_phi(v + V[V_BA1 + c], sh.elu); });
     }
   }
@@ -336,7 +362,7 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
   }
   for (int t = wv; t < sh.ME * 2; t += 4) {
     const int m = t >> 1, n = t & 1;
-    const f32x4 acc = tile_AB<32>(L.R2 + m * 16 * LDN, LDN, Wf + W_R2 + n * 16 * 32, 32);
+    const f32x4 acc = tile_AW<32>(L.R2 + m * 16 * LDN, LDN, w5);       // n = t & 1 = wave & 1
     tile_each(acc, m * 16, n * 16, [&](int r, int c, float v) { L.R3[r * LDN + c] = v + V[V_BR2 + c] + L.R2[r * LDN + c]; });
   }
   WG_SYNC();
@@ -357,8 +383,6 @@ __device__ __forceinline__ void gnn_forward(const GnnLds& L, const GnnShape& sh,
   gnn_stamp(sh, 6);
   // 7-11. affector and output MLPs: a chain of five small layers on waves 0/1; each stage fetches the NEXT
   // layer's weight fragment before it starts computing.
-  const int w01 = wv & 1;
-  WFrag<32> wf0 = wfrag_load<32>(Wf + W_F0 + w01 * 16 * 32, 32);
   if (wv < 2) {
     const WFrag<32> wf1 = wfrag_load<32>(Wf + W_F1 + w01 * 16 * 32, 32);
     const f32x4 acc = tile_AW<32>(L.PRED, LDN, wf0);
@@ -456,19 +480,23 @@ __device__ __forceinline__ void vec_store(const f32x4* vacc, float* __restrict__
   }
 }
 
-__device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh, const float* __restrict__ WT,
+// `o1t`: the W^T fragment of the first backward stage (out.1, tile wave & 1), loaded once per kernel by the caller.
+// Every other stage's fragment is fetched one stage ahead, so no stage waits on L2 before its first MFMA.
+__device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh, const float* __restrict__ WT, const WFrag<32>& o1t,
                              f32x4* acc, f32x4* vacc, const float* dpred_up /* global or null */, size_t dpred_seq_stride) {
   const int wv = wave_id();
   const int tid = threadIdx.x;
   const int lane = lane_id();
+  const int w01 = wv & 1;
   const float* V = L.V;
   float* S = L.CAT + 32;
   gnn_stamp(sh, 20);
   // b1. out.1:  RES = O1 W^T + b + O1
+  const WFrag<32> o0t = wfrag_load<32>(WT + W_O0 + wv * 16 * 32, 32);
   dW_layer<32, 32, SL_O1>(acc, L.DA, LDN, L.O1, LDN, 1, wv);
   vec_layer<VT_O1, 2>(vacc, L.DA, LDN, L.AUXN, 1, wv);
   if (wv < 2) {
-    const f32x4 t = tile_AB<32>(L.DA, LDN, WT + W_O1 + wv * 16 * 32, 32);
+    const f32x4 t = tile_AW<32>(L.DA, LDN, o1t);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
       const float o = L.O1[r * LDN + c];
       L.DB[r * LDN + c] = (v + L.DA[r * LDN + c]) * (1.0f - o * o);       // d pre-tanh of out.0
@@ -477,19 +505,21 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   WG_SYNC();
   gnn_stamp(sh, 21);
   // b2. out.0 on CAT = [F3 | S]
+  const WFrag<32> f2t = wfrag_load<32>(WT + W_F2 + w01 * 16 * 32, 32);
   dW_layer<32, 64, SL_O0>(acc, L.DB, LDN, L.CAT, LDC, 1, wv);
   vec_layer<VT_O0, 2>(vacc, L.DB, LDN, L.AUXN, 1, wv);
   {
-    const f32x4 t = tile_AB<32>(L.DB, LDN, WT + W_O0 + wv * 16 * 32, 32);
+    const f32x4 t = tile_AW<32>(L.DB, LDN, o0t);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) { L.DCAT[r * LDC + c] = v; });
   }
   WG_SYNC();
   gnn_stamp(sh, 22);
   // b3. affector.2:  F3 = F2 W^T + b      (dF3 = DCAT[:, :32])
+  const WFrag<32> f1t = wfrag_load<32>(WT + W_F1 + w01 * 16 * 32, 32);
   dW_layer<32, 32, SL_F2>(acc, L.DCAT, LDC, L.F2, LDN, 1, wv);
   vec_layer<VT_F2, 2>(vacc, L.DCAT, LDC, L.AUXN, 1, wv);
   if (wv < 2) {
-    const f32x4 t = tile_AB<32>(L.DCAT, LDC, WT + W_F2 + wv * 16 * 32, 32);
+    const f32x4 t = tile_AW<32>(L.DCAT, LDC, f2t);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
       const float th = L.F2[r * LDN + c] - L.F1[r * LDN + c];              // tanh(u) of affector.1
       L.DA[r * LDN + c] = v;                                               // dF2 (skip path)
@@ -499,10 +529,11 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   WG_SYNC();
   gnn_stamp(sh, 23);
   // b4. affector.1:  F2 = tanh(F1 W^T + b) + F1
+  const WFrag<32> f0t = wfrag_load<32>(WT + W_F0 + w01 * 16 * 32, 32);
   dW_layer<32, 32, SL_F1>(acc, L.DC, LDN, L.F1, LDN, 1, wv);
   vec_layer<VT_F1, 2>(vacc, L.DC, LDN, L.AUXN, 1, wv);
   if (wv < 2) {
-    const f32x4 t = tile_AB<32>(L.DC, LDN, WT + W_F1 + wv * 16 * 32, 32);
+    const f32x4 t = tile_AW<32>(L.DC, LDN, f1t);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
       const float f1 = L.F1[r * LDN + c];
       L.DB[r * LDN + c] = (v + L.DA[r * LDN + c]) * (1.0f - f1 * f1);      // d pre-tanh of affector.0
@@ -511,10 +542,11 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   WG_SYNC();
   gnn_stamp(sh, 24);
   // b5. affector.0:  F1 = tanh(PRED W^T + b)
+  const WFrag<32> r2t = wfrag_load<32>(WT + W_R2 + w01 * 16 * 32, 32);
   dW_layer<32, 32, SL_F0>(acc, L.DB, LDN, L.PRED, LDN, 1, wv);
   vec_layer<VT_F0, 2>(vacc, L.DB, LDN, L.AUXN, 1, wv);
   if (wv < 2) {
-    const f32x4 t = tile_AB<32>(L.DB, LDN, WT + W_F0 + wv * 16 * 32, 32);
+    const f32x4 t = tile_AW<32>(L.DB, LDN, f0t);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
       float up = 0.0f;
       if (dpred_up != nullptr && r < sh.NR) up = dpred_up[(size_t)(r / sh.N) * dpred_seq_stride + (r % sh.N) * 32 + c];
@@ -555,11 +587,15 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   WG_SYNC();
   gnn_stamp(sh, 27);
   // b7. rel.2:  R3 = R2 W^T + b + R2 ;  attention pre-activation grads in place in A2
+  // b9's fragments: tile t = wave + 4k has which = wave & 1 and column tile (wave >> 1) + 2 (k & 1)
+  const float* w9 = WT + (w01 ? W_A1 : W_R1) + (wv >> 1) * 16 * 32;
+  const WFrag<32> r1ta = wfrag_load<32>(w9, 32);
+  const WFrag<32> r1tb = wfrag_load<32>(w9 + 2 * 16 * 32, 32);
   dW_layer<32, 32, SL_R2>(acc, L.R3, LDN, L.R2, LDN, sh.ME, wv);
   vec_layer<VT_R2, 2>(vacc, L.R3, LDN, L.AUXE, sh.ME, wv);
   for (int t = wv; t < sh.ME * 2; t += 4) {
     const int m = t >> 1, n = t & 1;
-    const f32x4 a = tile_AB<32>(L.R3 + m * 16 * LDN, LDN, WT + W_R2 + n * 16 * 32, 32);
+    const f32x4 a = tile_AW<32>(L.R3 + m * 16 * LDN, LDN, r2t);            // n = wave & 1
     tile_each(a, m * 16, n * 16, [&](int r, int c, float v) {
       L.E32[r * LDN + c] = (v + L.R3[r * LDN + c]) * dphi_from_out(L.R2[r * LDN + c], sh.elu);
     });
@@ -572,6 +608,9 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   WG_SYNC();
   gnn_stamp(sh, 28);
   // b8. rel.1 / att.1 weight grads (inputs R1 / A1 still intact)
+  const WFrag<64> eft0 = wfrag_load<64>(WT + W_EF + wv * 64, 256);        // b11's fragments
+  const WFrag<64> eft1 = wfrag_load<64>(WT + W_EF + 16 * 256 + wv * 64, 256);
+  const WFrag<32> s1t = wfrag_load<32>(WT + W_S1 + w01 * 16 * 32, 32);
   dW_layer<32, 64, SL_R1>(acc, L.E32, LDN, L.R1, LDC, sh.ME, wv);
   dW_layer<32, 64, SL_A1>(acc, L.A2, LDN, L.A1, LDC, sh.ME, wv);
   vec_layer<VT_R1, 2>(vacc, L.E32, LDN, L.AUXE, sh.ME, wv);
@@ -581,11 +620,12 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   // b9. rel.1 / att.1 data grads, multiplied by phi'(first-layer output), in place in R1 / A1
   for (int t = wv; t < sh.ME * 8; t += 4) {
     const int m = t >> 3, n = (t >> 1) & 3, which = t & 1;
+    const WFrag<32>& w = (n & 2) ? r1tb : r1ta;
     if (which == 0) {
-      const f32x4 a = tile_AB<32>(L.E32 + m * 16 * LDN, LDN, WT + W_R1 + n * 16 * 32, 32);
+      const f32x4 a = tile_AW<32>(L.E32 + m * 16 * LDN, LDN, w);
       tile_each(a, m * 16, n * 16, [&](int r, int c, float v) { L.R1[r * LDC + c] = v * dphi_from_out(L.R1[r * LDC + c], sh.elu); });
     } else {
-      const f32x4 a = tile_AB<32>(L.A2 + m * 16 * LDN, LDN, WT + W_A1 + n * 16 * 32, 32);
+      const f32x4 a = tile_AW<32>(L.A2 + m * 16 * LDN, LDN, w);
       tile_each(a, m * 16, n * 16, [&](int r, int c, float v) { L.A1[r * LDC + c] = v * dphi_from_out(L.A1[r * LDC + c], sh.elu); });
     }
   }
@@ -617,6 +657,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   WG_SYNC();
   gnn_stamp(sh, 31);
   // b11. edge-first + self.1
+  const WFrag<32> s0t = wfrag_load<32>(WT + W_S0 + w01 * 16 * 32, 32);
   dW_layer<256, 32, SL_EF>(acc, L.P, LDP, S, LDC, 1, wv);
   dW_layer<32, 32, SL_S1>(acc, L.DC, LDN, L.H1, LDN, 1, wv);
   vec_layer<VT_S1, 2>(vacc, L.DC, LDN, L.AUXN, 1, wv);
@@ -624,13 +665,13 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
     // dS from the edge layers: dP (16 x 256) Wef (256 x 32).  Each wave contracts one quarter of K for both
     // column tiles (two interleaved chains of 16 MFMAs instead of one chain of 64); b12 adds the 4 partials.
     float* part = (wv == 0) ? L.DA : (wv == 1) ? L.SD : (wv == 2) ? L.RES : L.O1;     // SD, RES, O1 are dead here
-    const f32x4 t0 = tile_AB<64>(L.P + wv * 64, LDP, WT + W_EF + wv * 64, 256);
-    const f32x4 t1 = tile_AB<64>(L.P + wv * 64, LDP, WT + W_EF + 16 * 256 + wv * 64, 256);
+    const f32x4 t0 = tile_AW<64>(L.P + wv * 64, LDP, eft0);
+    const f32x4 t1 = tile_AW<64>(L.P + wv * 64, LDP, eft1);
     tile_each(t0, 0, 0, [&](int r, int c, float v) { part[r * LDN + c] = v; });
     tile_each(t1, 0, 16, [&](int r, int c, float v) { part[r * LDN + c] = v; });
   }
   if (wv < 2) {
-    const f32x4 t = tile_AB<32>(L.DC, LDN, WT + W_S1 + wv * 16 * 32, 32);
+    const f32x4 t = tile_AW<32>(L.DC, LDN, s1t);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
       L.DB[r * LDN + c] = (v + L.DC[r * LDN + c]) * dphi_from_out(L.H1[r * LDN + c], sh.elu);   // d pre-act of self.0
     });
@@ -650,10 +691,11 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   WG_SYNC();
   gnn_stamp(sh, 32);
   // b12. self.0 ; total dS ; split into the encoder output part and the pass-through part
+  const WFrag<32> enct = wfrag_load<32>(WT + W_ENC + w01 * 16 * 32, 32);
   dW_layer<32, 32, SL_S0>(acc, L.DB, LDN, S, LDC, 1, wv);
   vec_layer<VT_S0, 2>(vacc, L.DB, LDN, L.AUXN, 1, wv);
   if (wv < 2) {
-    const f32x4 t = tile_AB<32>(L.DB, LDN, WT + W_S0 + wv * 16 * 32, 32);
+    const f32x4 t = tile_AW<32>(L.DB, LDN, s0t);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) {
       float tot = v + ((L.DA[r * LDN + c] + L.SD[r * LDN + c]) + (L.RES[r * LDN + c] + L.O1[r * LDN + c])) + L.DCAT[r * LDC + 32 + c];
       if (c < 2) tot += L.DDIST[r * 2 + c];
@@ -668,7 +710,7 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   dW_layer<32, 32, SL_ENC>(acc, L.DC, LDN, L.SIN, LDN, 1, wv);
   vec_layer<VT_ENC, 2>(vacc, L.DC, LDN, L.AUXN, 1, wv);
   if (wv < 2) {
-    const f32x4 t = tile_AB<32>(L.DC, LDN, WT + W_ENC + wv * 16 * 32, 32);
+    const f32x4 t = tile_AW<32>(L.DC, LDN, enct);
     tile_each(t, 0, wv * 16, [&](int r, int c, float v) { L.DA[r * LDN + c] = v + L.F1[r * LDN + c]; });
   }
   WG_SYNC();
@@ -768,8 +810,9 @@ __global__ __launch_bounds__(256) void gnn_step_fwd_k(const float* __restrict__ 
     const int r = i / sin_dim, c = i % sin_dim;
     L.SIN[r * LDN + c] = sin[((size_t)b0 * N + r) * sin_dim + c];
   }
+  const FwdW fw = gnn_fwdw_load(P);
   WG_SYNC();
-  gnn_forward(L, sh, P);
+  gnn_forward(L, sh, P, fw);
   for (int i = threadIdx.x; i < sh.NR * 32; i += blockDim.x) {
     const int r = i >> 5, c = i & 31;
     res[((size_t)b0 * N + r) * 32 + c] = L.RES[r * LDN + c];
@@ -794,8 +837,11 @@ __global__ __launch_bounds__(256) void gnn_step_bwd_k(const float* __restrict__ 
     const int r = i / sin_dim, c = i % sin_dim;
     L.SIN[r * LDN + c] = sin[((size_t)b0 * N + r) * sin_dim + c];
   }
-  WG_SYNC();
-  gnn_forward(L, sh, P);
+  {
+    const FwdW fw = gnn_fwdw_load(P);
+    WG_SYNC();
+    gnn_forward(L, sh, P, fw);
+  }
   for (int i = threadIdx.x; i < 16 * 32; i += blockDim.x) {
     const int r = i >> 5, c = i & 31;
     L.DA[r * LDN + c] = (r < sh.NR) ? dres[((size_t)b0 * N + r) * 32 + c] : 0.0f;
@@ -806,7 +852,8 @@ __global__ __launch_bounds__(256) void gnn_step_bwd_k(const float* __restrict__ 
   for (int k = 0; k < SL_END; ++k) acc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int k = 0; k < VSLOTS; ++k) vacc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  gnn_backward(L, sh, P + W_END, acc, vacc, dpred != nullptr ? dpred + (size_t)b0 * N * 32 : nullptr, (size_t)N * 32);
+  const WFrag<32> o1t = wfrag_load<32>(P + W_END + W_O1 + (wave_id() & 1) * 16 * 32, 32);
+  gnn_backward(L, sh, P + W_END, o1t, acc, vacc, dpred != nullptr ? dpred + (size_t)b0 * N * 32 : nullptr, (size_t)N * 32);
   for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
     const int r = i / sin_dim, c = i % sin_dim;
     dsin[((size_t)b0 * N + r) * sin_dim + c] = L.DA[r * LDN + c];
@@ -974,6 +1021,7 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_k(
   WG_SYNC();
   float* Z = L.X;     // [16][20] current state z[t-1]
   for (int i = threadIdx.x; i < sh.NR * 18; i += blockDim.x) Z[(i / 18) * 20 + i % 18] = z1[(size_t)b0 * N * 18 + i];
+  const FwdW fw = gnn_fwdw_load(P);
   WG_SYNC();
   for (int ts = 0; ts < Ts; ++ts) {
     for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
@@ -984,7 +1032,7 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_k(
       L.SIN[r * LDN + c] = v;
     }
     WG_SYNC();
-    gnn_forward(L, sh, P);
+    gnn_forward(L, sh, P, fw);
     if (act != nullptr)      // keep this step's activations for the backward (instead of recomputing them there)
       gnn_act_any<true>(L, sh, act + ((size_t)blockIdx.x * Ts + ts) * act_stride, G * N, G * N * N);
     loop_epilogue_fwd(L, sh, kc, b0, Ts, ts, zsup, zsstd, eps, z, zdyn, zdstd, mean, stdv, Z);
@@ -1021,6 +1069,7 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
 #pragma unroll
   for (int k = 0; k < VSLOTS; ++k) vacc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   float* CAR = L.X;   // [16][20] gradient carried into z[t] from step t+1
+  const WFrag<32> o1t = wfrag_load<32>(P + W_END + W_O1 + (wave_id() & 1) * 16 * 32, 32);
   WG_SYNC();
   gnn_setup(L, sh, P + 2 * W_END);
   WG_SYNC();
@@ -1041,8 +1090,9 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
         else v = extra[(((size_t)b * Ts + ts) * N + n) * E + (c - 16)];
         L.SIN[r * LDN + c] = v;
       }
+      const FwdW fw = gnn_fwdw_load(P);
       WG_SYNC();
-      gnn_forward(L, sh, P);
+      gnn_forward(L, sh, P, fw);
     }
     // epilogue backward: per (row, d < 16) -> dRES in L.DA, SuPAIR grads, position carry in L.DDIST
     for (int idx = threadIdx.x; idx < 16 * 18; idx += blockDim.x) {
@@ -1090,7 +1140,7 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
       L.DA[r * LDN + 16 + d] = gsd * sd * (1.0f - sd / kd);                 // sd = k sigmoid
     }
     WG_SYNC();
-    gnn_backward(L, sh, P + W_END, acc, vacc,
+    gnn_backward(L, sh, P + W_END, o1t, acc, vacc,
                  dpred != nullptr ? dpred + ((size_t)b0 * Ts + ts) * N * 32 : nullptr, (size_t)Ts * N * 32);
     // new carry into z[t-1]
     for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
@@ -1128,6 +1178,7 @@ __global__ __launch_bounds__(256) void rollout_fwd_k(const float* __restrict__ z
   WG_SYNC();
   float* Z = L.X;
   for (int i = threadIdx.x; i < sh.NR * 18; i += blockDim.x) Z[(i / 18) * 20 + i % 18] = z_last[(size_t)b0 * N * 18 + i];
+  const FwdW fw = gnn_fwdw_load(P);
   WG_SYNC();
   for (int t = 0; t < num; ++t) {
     for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
@@ -1138,7 +1189,7 @@ __global__ __launch_bounds__(256) void rollout_fwd_k(const float* __restrict__ z
       L.SIN[r * LDN + c] = v;
     }
     WG_SYNC();
-    gnn_forward(L, sh, P);
+    gnn_forward(L, sh, P, fw);
     for (int idx = threadIdx.x; idx < sh.NR * 18; idx += blockDim.x) {
       const int r = idx / 18, q = idx % 18;
       const size_t o = ((size_t)(b0 + r / N) * num + t) * N + r % N;
