@@ -9,6 +9,7 @@
 #include "scene.hip"
 #include "gnn.hip"
 #include "match.hip"
+#include "gnn_small.hip"
 #include "lstm.hip"
 #include "arena.hip"
 
@@ -292,9 +293,23 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
                       void* stream) {
   if (B == 0 || Ts == 0) return 0;
   if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && extra == nullptr)) return (int)hipErrorInvalidValue;
+  LoopConst kc{pos_var, vel_std, lat_std};
+  if (N <= 4 && N >= 2) {      // small graphs: row-per-wave VALU formulation, two barriers per step (gnn_small.hip)
+    const void* fn = act != nullptr ? (const void*)dyn_loop_fwd_small_k<true> : (const void*)dyn_loop_fwd_small_k<false>;
+    int rc = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSmLdsFloats * sizeof(float)));
+    if (rc) return rc;
+    if (act != nullptr) {
+      STOVE_LAUNCH(dyn_loop_fwd_small_k<true>, dim3(B), dim3(256), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
+                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc);
+    } else {
+      STOVE_LAUNCH(dyn_loop_fwd_small_k<false>, dim3(B), dim3(256), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
+                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc);
+    }
+    STOVE_LAUNCH_CHECK();
+    return 0;
+  }
   int rc = gnn_lds_attr((const void*)dyn_loop_fwd_k);
   if (rc) return rc;
-  LoopConst kc{pos_var, vel_std, lat_std};
   STOVE_LAUNCH(dyn_loop_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
                      z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
   STOVE_LAUNCH_CHECK();
@@ -329,9 +344,18 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
                       float lat_std, void* stream) {
   if (B == 0 || num == 0) return 0;
   if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && (extra == nullptr || A < 1))) return (int)hipErrorInvalidValue;
+  LoopConst kc{pos_var, vel_std, lat_std};
+  if (N <= 4 && N >= 2) {
+    int rc = (int)hipFuncSetAttribute((const void*)rollout_fwd_small_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(kSmLdsFloats * sizeof(float)));
+    if (rc) return rc;
+    STOVE_LAUNCH(rollout_fwd_small_k, dim3(B), dim3(256), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
+                 z_last, extra, params, z_pred, zstd, pred, B, num, A < 1 ? 1 : A, N, sin_dim, lim_enc, elu, kc);
+    STOVE_LAUNCH_CHECK();
+    return 0;
+  }
   int rc = gnn_lds_attr((const void*)rollout_fwd_k);
   if (rc) return rc;
-  LoopConst kc{pos_var, vel_std, lat_std};
   STOVE_LAUNCH(rollout_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
                      z_last, extra, params, z_pred, zstd, pred, B, num, A < 1 ? 1 : A, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
   STOVE_LAUNCH_CHECK();

@@ -768,6 +768,7 @@ __host__ __device__ inline int gnn_group_max(int N) {
 // there are CUs to spare, fewer sequences per workgroup means shorter elementwise loops and fewer
 // tiles per stage, hence a shorter step.  Use the smallest group that still fits one workgroup per CU.
 __host__ __device__ inline int gnn_group_for(int B, int N) {
+  if (N <= 4) return 1;      // the small-graph time loop (gnn_small.hip) is one sequence per workgroup
   const int gmax = gnn_group_max(N);
   int g = (B + 255) / 256;
   if (g < 1) g = 1;
@@ -828,7 +829,6 @@ __global__ __launch_bounds__(256) void gnn_step_bwd_k(const float* __restrict__ 
   const GnnLds L = carve(lds);
   const int b0 = blockIdx.x * G;
   GnnShape sh = make_shape(N, G, b0, B, sin_dim, lim_enc, elu);
-  sh.stamps = stamps;
   lds_zero(lds, kGnnLdsFloats);
   WG_SYNC();
   gnn_setup(L, sh, P + 2 * W_END);
@@ -837,23 +837,32 @@ __global__ __launch_bounds__(256) void gnn_step_bwd_k(const float* __restrict__ 
     const int r = i / sin_dim, c = i % sin_dim;
     L.SIN[r * LDN + c] = sin[((size_t)b0 * N + r) * sin_dim + c];
   }
-  {
-    const FwdW fw = gnn_fwdw_load(P);
-    WG_SYNC();
-    gnn_forward(L, sh, P, fw);
-  }
-  for (int i = threadIdx.x; i < 16 * 32; i += blockDim.x) {
-    const int r = i >> 5, c = i & 31;
-    L.DA[r * LDN + c] = (r < sh.NR) ? dres[((size_t)b0 * N + r) * 32 + c] : 0.0f;
-  }
-  WG_SYNC();
   f32x4 acc[SL_END], vacc[VSLOTS];
 #pragma unroll
   for (int k = 0; k < SL_END; ++k) acc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int k = 0; k < VSLOTS; ++k) vacc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   const WFrag<32> o1t = wfrag_load<32>(P + W_END + W_O1 + (wave_id() & 1) * 16 * 32, 32);
-  gnn_backward(L, sh, P + W_END, o1t, acc, vacc, dpred != nullptr ? dpred + (size_t)b0 * N * 32 : nullptr, (size_t)N * 32);
+  // debug stamps: time the THIRD pass (weights L2-warm, as every step of the time loop sees them); the extra
+  // passes only happen with stamps != null (their weight gradients are then 3x, nobody reads them)
+  const int reps = (stamps != nullptr) ? 3 : 1;
+  for (int rep = 0; rep < reps; ++rep) {
+    sh.stamps = (rep == reps - 1) ? stamps : nullptr;
+    {
+      const FwdW fw = gnn_fwdw_load(P);
+      WG_SYNC();
+      gnn_forward(L, sh, P, fw);
+    }
+    for (int i = threadIdx.x; i < 16 * 32; i += blockDim.x) {
+      const int r = i >> 5, c = i & 31;
+      L.DA[r * LDN + c] = (r < sh.NR) ? dres[((size_t)b0 * N + r) * 32 + c] : 0.0f;
+    }
+    WG_SYNC();
+    gnn_backward(L, sh, P + W_END, o1t, acc, vacc, dpred != nullptr ? dpred + (size_t)b0 * N * 32 : nullptr, (size_t)N * 32);
+    if (rep + 1 < reps) {        // restore the input for the next pass (DA aliases nothing the forward reads, SIN is intact)
+      WG_SYNC();
+    }
+  }
   for (int i = threadIdx.x; i < sh.NR * sin_dim; i += blockDim.x) {
     const int r = i / sin_dim, c = i % sin_dim;
     dsin[((size_t)b0 * N + r) * sin_dim + c] = L.DA[r * LDN + c];

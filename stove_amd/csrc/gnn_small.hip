@@ -1,0 +1,367 @@
+// Small-graph variant of the GNN time loop (N <= 4 objects, one sequence per workgroup), gfx950.
+//
+// Why a second formulation.  With N = 3 the MFMA path (gnn.hip) fills 3 of the 16 rows of every node tile and
+// 9 of 16 of every edge tile, and -- what actually bounds the T-serial recursion -- every dense layer is a
+// workgroup-wide stage: LDS write, barrier, LDS read, MFMA chain, epilogue; 11 such stages per step.  But the
+// node MLPs (encoder, self-dynamics, affector, output) act on every node row independently, and the edge MLPs
+// on every edge independently; rows only mix at the edge gather and at the aggregation.  So here
+//   * one WAVE owns one node row for the whole step (and 1-3 edges in the edge phase);
+//   * a 32-wide activation vector lives in ONE VGPR (lane k holds x[k]); a dense layer is 32 v_readlane
+//     (x[k] -> SGPR, wave-uniform) + 32 v_fmac with the lane's weight row streamed from LDS as float4
+//     ([K/4][OUT][4] layout, conflict-free), i.e. layers chain register-to-register with no LDS round trip
+//     and no barrier;
+//   * the workgroup synchronises exactly twice per step (before the edge phase, before the aggregation).
+// All forward weights (90 KB) sit in LDS for the whole launch.
+// The kernel writes the same saved-activation block as dyn_loop_fwd_k, so dyn_loop_bwd_k consumes it unchanged.
+#include "common.h"
+
+namespace stove {
+
+constexpr int kSmW = W_END;                                   // [layer][K/4][OUT][4]
+constexpr int kSmLdsFloats = kSmW + V_END + 4 * 256 + 16 + 4 * 128 + 16 * 32 + 16;
+
+struct SmLds {
+  float *W, *V, *PR, *POS, *X1, *R3, *ATT;
+};
+__device__ __forceinline__ SmLds sm_carve(float* base) {
+  SmLds L;
+  L.W = base;
+  L.V = L.W + kSmW;
+  L.PR = L.V + V_END;        // [4][256]  W_a s_i | W_b s_j | A_a s_i | A_b s_j of every node
+  L.POS = L.PR + 4 * 256;    // [4][4]    encoder outputs 0, 1 (the positions the distances use)
+  L.X1 = L.POS + 16;         // [4 waves][R1 act 64 | A1 act 64] of the edge a wave is working on
+  L.R3 = L.X1 + 4 * 128;     // [16][32]  relation outputs by edge row i*N + j
+  L.ATT = L.R3 + 16 * 32;    // [16]
+  return L;
+}
+
+// one layer of the W image -> [K/4][OUT][4]
+__device__ __forceinline__ void sm_repack(float* dst, const float* __restrict__ src, int OUT, int K) {
+  for (int idx = threadIdx.x; idx < OUT * K; idx += blockDim.x) {
+    const int o = idx / K, k = idx % K;
+    dst[((k >> 2) * OUT + o) * 4 + (k & 3)] = src[idx];
+  }
+}
+__device__ __forceinline__ void sm_setup(const SmLds& L, const float* __restrict__ P) {
+  sm_repack(L.W + W_ENC, P + W_ENC, 32, 32);
+  sm_repack(L.W + W_S0, P + W_S0, 32, 32);
+  sm_repack(L.W + W_S1, P + W_S1, 32, 32);
+  sm_repack(L.W + W_EF, P + W_EF, 256, 32);
+  sm_repack(L.W + W_R1, P + W_R1, 32, 64);
+  sm_repack(L.W + W_A1, P + W_A1, 32, 64);
+  sm_repack(L.W + W_R2, P + W_R2, 32, 32);
+  sm_repack(L.W + W_F0, P + W_F0, 32, 32);
+  sm_repack(L.W + W_F1, P + W_F1, 32, 32);
+  sm_repack(L.W + W_F2, P + W_F2, 32, 32);
+  sm_repack(L.W + W_O0, P + W_O0, 32, 64);
+  sm_repack(L.W + W_O1, P + W_O1, 32, 32);
+  for (int i = threadIdx.x; i < V_END; i += blockDim.x) L.V[i] = P[2 * W_END + i];
+}
+
+__device__ __forceinline__ float sm_rl(float v, int k) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+// y[o] = sum_{k < 4 K4} W[o][k] x[k], x[k] held by lane k (< 32) of this wave; Wl = layer base, k4-major with OUT rows
+template <int K4>
+__device__ __forceinline__ float sm_dot(const float* Wl, int OUT, int o, float x, int k4_0 = 0) {
+  float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+  for (int k4 = 0; k4 < K4; ++k4) {
+    const float4 w = *reinterpret_cast<const float4*>(Wl + ((k4_0 + k4) * OUT + o) * 4);
+    a0 = fmaf(w.x, sm_rl(x, 4 * k4), a0);
+    a1 = fmaf(w.y, sm_rl(x, 4 * k4 + 1), a1);
+    a0 = fmaf(w.z, sm_rl(x, 4 * k4 + 2), a0);
+    a1 = fmaf(w.w, sm_rl(x, 4 * k4 + 3), a1);
+  }
+  return a0 + a1;
+}
+
+struct SmCfg {
+  int N, sin_dim, lim_enc, elu;
+};
+// pointers into the saved-activation block of one (sequence, step); layout of gnn_act_floats(N, 1)
+struct SmAct {
+  float *SIN, *H1, *PRED, *F1, *F2, *O1, *RES, *CAT, *R1, *A1, *R2, *A2, *R3, *ATT, *DIST;
+};
+__device__ __forceinline__ SmAct sm_act(float* g, int N) {
+  SmAct a;
+  const int nr = N, ne = N * N;
+  a.SIN = g; a.H1 = g + nr * 32; a.PRED = g + 2 * nr * 32; a.F1 = g + 3 * nr * 32; a.F2 = g + 4 * nr * 32;
+  a.O1 = g + 5 * nr * 32; a.RES = g + 6 * nr * 32; a.CAT = g + 7 * nr * 32;
+  a.R1 = a.CAT + nr * 64; a.A1 = a.R1 + ne * 64; a.R2 = a.A1 + ne * 64; a.A2 = a.R2 + ne * 32; a.R3 = a.A2 + ne * 32;
+  a.ATT = a.R3 + ne * 32; a.DIST = a.ATT + ne;
+  return a;
+}
+
+// One GNN step.  Node wave r (< N): `sinv` = input row (lane k and k+32 hold s_in[r][k], zero beyond sin_dim);
+// returns RES[o] / PRED[o] in lane o (and o+32).  SAVE: write the activation block (act.* valid).
+template <bool SAVE>
+__device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float sinv, const SmAct& act, float& res_out, float& pred_out) {
+  const int wv = wave_id();
+  const int lane = lane_id();
+  const int o = lane & 31, h = lane >> 5;
+  const int N = cf.N;
+  const float* V = L.V;
+  float S = 0.0f, SD = 0.0f;
+  // ---- P1: node rows: encoder, self-dynamics, factorised first edge layer -------------------------------------
+  if (wv < N) {
+    const int r = wv;
+    float e;
+    if (cf.sin_dim <= 16) e = sm_dot<4>(L.W + W_ENC, 32, o, sinv);
+    else e = sm_dot<8>(L.W + W_ENC, 32, o, sinv);
+    S = (o < cf.lim_enc) ? sinv : e + V[V_ENC + o];
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      const float* w = L.W + W_EF + (k4 * 256 + lane) * 4;
+      const float4 w0 = *reinterpret_cast<const float4*>(w);
+      const float4 w1 = *reinterpret_cast<const float4*>(w + 64 * 4);
+      const float4 w2 = *reinterpret_cast<const float4*>(w + 128 * 4);
+      const float4 w3 = *reinterpret_cast<const float4*>(w + 192 * 4);
+      const float x0 = sm_rl(S, 4 * k4), x1 = sm_rl(S, 4 * k4 + 1), x2 = sm_rl(S, 4 * k4 + 2), x3 = sm_rl(S, 4 * k4 + 3);
+      p0 = fmaf(w0.w, x3, fmaf(w0.z, x2, fmaf(w0.y, x1, fmaf(w0.x, x0, p0))));
+      p1 = fmaf(w1.w, x3, fmaf(w1.z, x2, fmaf(w1.y, x1, fmaf(w1.x, x0, p1))));
+      p2 = fmaf(w2.w, x3, fmaf(w2.z, x2, fmaf(w2.y, x1, fmaf(w2.x, x0, p2))));
+      p3 = fmaf(w3.w, x3, fmaf(w3.z, x2, fmaf(w3.y, x1, fmaf(w3.x, x0, p3))));
+    }
+    float* pr = L.PR + r * 256 + lane;
+    pr[0] = p0;
+    pr[64] = p1;
+    pr[128] = p2;
+    pr[192] = p3;
+    if (lane < 2) L.POS[r * 4 + lane] = S;
+  }
+  WG_SYNC();
+  // self-dynamics of the node rows is independent of the edges: issue it after the barrier so the edge phase of
+  // the other waves is not held up by it (node waves do it before their own edges)
+  float H1 = 0.0f;
+  if (wv < N) {
+    H1 = act_phi(sm_dot<8>(L.W + W_S0, 32, o, S) + V[V_S0 + o], cf.elu);
+    SD = sm_dot<8>(L.W + W_S1, 32, o, H1) + V[V_S1 + o] + H1;
+    if (SAVE && lane < 32) {
+      act.SIN[wv * 32 + o] = sinv;
+      act.H1[wv * 32 + o] = H1;
+      act.CAT[wv * 64 + 32 + o] = S;
+    }
+  }
+  // ---- P3: edges (i -> j, i != j), round-robin over the four waves; half 0 = relation chain, half 1 = attention -----
+  const int NEo = N * (N - 1);
+  for (int q = 3 - wv; q < NEo; q += 4) {      // wave 3 (no node row when N = 3) takes edges first
+    const int i = q / (N - 1), jj = q % (N - 1), j = jj + (jj >= i ? 1 : 0);
+    const int e = i * N + j;
+    const float dx = L.POS[i * 4] - L.POS[j * 4], dy = L.POS[i * 4 + 1] - L.POS[j * 4 + 1];
+    const float d = dx * dx + dy * dy;
+    const float* pi = L.PR + i * 256 + 128 * h;
+    const float* pj = L.PR + j * 256 + 128 * h + 64;
+    const int vwd = h ? V_WDA : V_WDR, vb0 = h ? V_BA0 : V_BR0;
+    const float a_lo = act_phi(pi[o] + pj[o] + V[vwd + o] * d + V[vb0 + o], cf.elu);
+    const float a_hi = act_phi(pi[o + 32] + pj[o + 32] + V[vwd + o + 32] * d + V[vb0 + o + 32], cf.elu);
+    float* x1 = L.X1 + wv * 128 + 64 * h;
+    x1[o] = a_lo;
+    x1[o + 32] = a_hi;
+    if (SAVE) {
+      float* g1 = (h ? act.A1 : act.R1) + e * 64;
+      g1[o] = a_lo;
+      g1[o + 32] = a_hi;
+    }
+    // second layer 64 -> 32: the activation row comes back as LDS broadcast reads (one address per half)
+    const float* Wl = L.W + (h ? W_A1 : W_R1);
+    float y0 = 0.0f, y1 = 0.0f;
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+      const float4 w = *reinterpret_cast<const float4*>(Wl + (k4 * 32 + o) * 4);
+      const float4 x = *reinterpret_cast<const float4*>(x1 + 4 * k4);
+      y0 = fmaf(w.y, x.y, fmaf(w.x, x.x, y0));
+      y1 = fmaf(w.w, x.w, fmaf(w.z, x.z, y1));
+    }
+    const float a2 = act_phi(y0 + y1 + V[(h ? V_BA1 : V_BR1) + o], cf.elu);
+    if (SAVE) ((h ? act.A2 : act.R2) + e * 32)[o] = a2;
+    // third layer: relation 32 -> 32 + skip (x = lanes 0..31 of a2); attention 32 -> 1 -> exp
+    const float r3 = sm_dot<8>(L.W + W_R2, 32, o, a2) + V[V_BR2 + o] + a2;
+    const float att = __expf(wave_sum(h ? a2 * V[V_WA2 + o] : 0.0f) + V[V_BA2]);
+    if (h == 0) L.R3[e * 32 + o] = r3;
+    if (lane == 0) L.ATT[e] = att;
+    if (SAVE) {
+      if (h == 0) act.R3[e * 32 + o] = r3;
+      if (lane == 0) {
+        act.ATT[e] = att;
+        act.DIST[e] = d;
+      }
+    }
+  }
+  if (SAVE && wv < N) {             // self-edge rows (masked out of the model): finite zeros for the backward's restore
+    const int e = wv * N + wv;
+    act.R1[e * 64 + lane] = 0.0f;
+    act.A1[e * 64 + lane] = 0.0f;
+    (h ? act.A2 : act.R2)[e * 32 + o] = 0.0f;
+    if (h == 0) act.R3[e * 32 + o] = 0.0f;
+    if (lane == 0) {
+      act.ATT[e] = 0.0f;
+      act.DIST[e] = 0.0f;
+    }
+  }
+  WG_SYNC();
+  // ---- P4: node rows: aggregation, affector, output ------------------------------------------------------------------
+  if (wv < N) {
+    const int r = wv;
+    float pred = SD;
+    for (int j = 0; j < N; ++j)
+      if (j != r) pred = fmaf(L.R3[(r * N + j) * 32 + o], L.ATT[r * N + j], pred);
+    const float F1 = fast_tanh(sm_dot<8>(L.W + W_F0, 32, o, pred) + V[V_F0 + o]);
+    const float F2 = fast_tanh(sm_dot<8>(L.W + W_F1, 32, o, F1) + V[V_F1 + o]) + F1;
+    const float F3 = sm_dot<8>(L.W + W_F2, 32, o, F2) + V[V_F2 + o];
+    const float O1 = fast_tanh(sm_dot<8>(L.W + W_O0, 32, o, F3) + sm_dot<8>(L.W + W_O0, 32, o, S, 8) + V[V_O0 + o]);
+    const float RES = sm_dot<8>(L.W + W_O1, 32, o, O1) + V[V_O1 + o] + O1;
+    if (SAVE && lane < 32) {
+      act.PRED[r * 32 + o] = pred;
+      act.F1[r * 32 + o] = F1;
+      act.F2[r * 32 + o] = F2;
+      act.CAT[r * 64 + o] = F3;
+      act.O1[r * 32 + o] = O1;
+      act.RES[r * 32 + o] = RES;
+    }
+    res_out = RES;
+    pred_out = pred;
+  }
+}
+
+__device__ __forceinline__ float sm_from_lane(float v, int src_lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, v)));
+}
+
+// =================================================================================================
+// inference recursion, same contract as dyn_loop_fwd_k (gnn.hip) with G = 1: grid = B sequences
+// =================================================================================================
+template <bool SAVE>
+__global__ __launch_bounds__(256) void dyn_loop_fwd_small_k(
+    const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
+    const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
+    float* __restrict__ z, float* __restrict__ zdyn, float* __restrict__ zdstd, float* __restrict__ mean,
+    float* __restrict__ stdv, float* __restrict__ pred, float* __restrict__ act,
+    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const SmLds L = sm_carve(lds);
+  const int b = blockIdx.x;
+  const int wv = wave_id(), lane = lane_id(), l = lane & 31;
+  const SmCfg cf{N, sin_dim, lim_enc, elu};
+  const int E = sin_dim - 16;
+  const size_t act_stride = gnn_act_floats(N, 1);
+  sm_setup(L, P);
+  // node wave r: lane l (and l+32) holds s_in[l]; dims 0..15 come from the running state z[t-1][2..17]
+  float sinv = 0.0f;
+  const int r = wv;
+  if (wv < N) {
+    if (l < 16) sinv = z1[((size_t)b * N + r) * 18 + 2 + l];
+    else if (l < sin_dim) sinv = extra[(((size_t)b * Ts + 0) * N + r) * E + (l - 16)];
+  }
+  WG_SYNC();
+  for (int ts = 0; ts < Ts; ++ts) {
+    const size_t o = ((size_t)b * Ts + ts) * N + r;
+    // this step's epilogue inputs and the next step's extra inputs: issued now, consumed ~2 us later
+    float ep = 0.0f, ms = 0.0f, ss = 1.0f, xnext = 0.0f;
+    if (wv < N) {
+      if (l < 16) ep = eps[o * 18 + 2 + l];
+      else if (l < 18) ep = eps[o * 18 + (l - 16)];
+      if (l < 4) {
+        ms = zsup[o * 6 + 2 + l];
+        ss = zsstd[o * 6 + 2 + l];
+      } else if (l >= 16 && l < 18) {
+        ms = zsup[o * 6 + (l - 16)];
+        ss = zsstd[o * 6 + (l - 16)];
+      }
+      if (l >= 16 && l < sin_dim && ts + 1 < Ts) xnext = extra[(((size_t)b * Ts + ts + 1) * N + r) * E + (l - 16)];
+    }
+    SmAct a{};
+    if (SAVE) a = sm_act(act + ((size_t)b * Ts + ts) * act_stride, N);
+    float res = 0.0f, prd = 0.0f;
+    sm_step<SAVE>(L, cf, sinv, a, res, prd);
+    if (wv < N) {
+      // epilogue (stove.py:103-170 + constrain_z_dyn): lane d < 16 owns state dim d, lanes 16/17 the two scale dims
+      const float res_s = sm_from_lane(res, (lane & 32) + ((l + 16) & 31));      // RES[16 + d] for d < 16
+      float zv;
+      if (l < 16) {
+        const int d = l;
+        const float m = 2.0f * sigmoidf_(res) - 1.0f;
+        const float sd = std_scale(d, kc) * sigmoidf_(res_s);
+        const float zd = m + (d < 2 ? sinv : 0.0f);
+        float mu, sg;
+        if (d < 4) {
+          const float sd2 = sd * sd, ss2 = ss * ss, D = sd2 + ss2;
+          mu = (ss2 * zd + sd2 * ms) / D;
+          sg = sd * ss / sqrtf(D);
+        } else {
+          mu = zd;
+          sg = sd;
+        }
+        zv = fmaf(sg, ep, mu);
+        if (lane < 32) {
+          zdyn[o * 16 + d] = zd;
+          zdstd[o * 16 + d] = sd;
+          z[o * 18 + 2 + d] = zv;
+          mean[o * 18 + 2 + d] = mu;
+          stdv[o * 18 + 2 + d] = sg;
+        }
+      } else {
+        zv = xnext;                                   // becomes s_in[l] of the next step (0 beyond sin_dim)
+        if (l < 18 && lane < 32) {
+          const int q = l - 16;
+          z[o * 18 + q] = fmaf(ss, ep, ms);
+          mean[o * 18 + q] = ms;
+          stdv[o * 18 + q] = ss;
+        }
+      }
+      if (pred != nullptr && lane < 32) pred[o * 32 + l] = prd;
+      sinv = zv;
+    }
+  }
+}
+
+// =================================================================================================
+// generative rollout, same contract as rollout_fwd_k (gnn.hip) with G = 1
+// =================================================================================================
+__global__ __launch_bounds__(256) void rollout_fwd_small_k(const float* __restrict__ z_last, const float* __restrict__ extra,
+                                                           const float* __restrict__ P, float* __restrict__ z_pred,
+                                                           float* __restrict__ zstd, float* __restrict__ pred,
+                                                           int B, int num, int A, int N, int sin_dim, int lim_enc, int elu, LoopConst kc) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const SmLds L = sm_carve(lds);
+  const int b = blockIdx.x;
+  const int wv = wave_id(), lane = lane_id(), l = lane & 31;
+  const SmCfg cf{N, sin_dim, lim_enc, elu};
+  const int E = sin_dim - 16;
+  sm_setup(L, P);
+  float sinv = 0.0f, scale = 0.0f;
+  const int r = wv;
+  if (wv < N) {
+    if (l < 16) sinv = z_last[((size_t)b * N + r) * 18 + 2 + l];
+    else if (l < sin_dim) sinv = extra[(((size_t)b * A + 0) * N + r) * E + (l - 16)];
+    if (l >= 16 && l < 18) scale = z_last[((size_t)b * N + r) * 18 + (l - 16)];       // sx, sy stay constant
+  }
+  WG_SYNC();
+  for (int t = 0; t < num; ++t) {
+    const size_t o = ((size_t)b * num + t) * N + r;
+    float xnext = 0.0f;
+    if (wv < N && l >= 16 && l < sin_dim && t + 1 < num) xnext = extra[(((size_t)b * A + ((t + 1) % A)) * N + r) * E + (l - 16)];
+    const SmAct a{};
+    float res = 0.0f, prd = 0.0f;
+    sm_step<false>(L, cf, sinv, a, res, prd);
+    if (wv < N) {
+      const float res_s = sm_from_lane(res, (lane & 32) + ((l + 16) & 31));
+      float zv;
+      if (l < 16) {
+        zv = 2.0f * sigmoidf_(res) - 1.0f + (l < 2 ? sinv : 0.0f);
+        if (lane < 32) {
+          z_pred[o * 18 + 2 + l] = zv;
+          if (zstd != nullptr) zstd[o * 16 + l] = std_scale(l, kc) * sigmoidf_(res_s);
+        }
+      } else {
+        zv = xnext;
+        if (l < 18 && lane < 32) z_pred[o * 18 + (l - 16)] = scale;
+      }
+      if (pred != nullptr && lane < 32) pred[o * 32 + l] = prd;
+      sinv = zv;
+    }
+  }
+}
+
+}  // namespace stove
