@@ -155,6 +155,10 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
  * perm (B,T,N,N) f32, pre-zeroed, only written in mode 2 (may be NULL otherwise). */
 int stove_match_objects(const float* feat, long long* idx, float* perm, int B, int T, int N, int F, int mode, void* stream);
 
+/* debug aid of the measurement tools: device buffer of 64 int64 cycle stamps ([4 waves][16 phases]) written by
+ * workgroup 0 of the small-graph time loops in their last step; NULL (default) switches it off. */
+void stove_debug_set_stamps(long long* device_buffer);
+
 /* ---- flat parameter arena.  When all model parameters are views into ONE fp32 buffer (and their gradients
  * into one gradient buffer, which is also the data-parallel all-reduce bucket), the SPN tables and the GNN
  * parameter image are baked from / their gradients pushed into those buffers directly:

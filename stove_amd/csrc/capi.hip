@@ -282,6 +282,11 @@ int stove_gnn_debug_stamps(const float* s_in, const float* params, const float* 
   return 0;
 }
 
+// debug: device buffer ([4 waves][16] int64) that the small-graph time loops stamp their phases into (last step,
+// workgroup 0); null = off.  Set by the measurement tools only.
+static long long* g_sm_stamps = nullptr;
+void stove_debug_set_stamps(long long* device_buffer) { g_sm_stamps = device_buffer; }
+
 size_t stove_dynloop_act_floats(int B, int Ts, int N) {
   const int g = gnn_group_for(B, N);
   return (size_t)stove_gnn_blocks(B, N) * Ts * gnn_act_floats(N, g);
@@ -300,10 +305,10 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
     if (rc) return rc;
     if (act != nullptr) {
       STOVE_LAUNCH(dyn_loop_fwd_small_k<true>, dim3(B), dim3(256), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
-                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc);
+                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps);
     } else {
       STOVE_LAUNCH(dyn_loop_fwd_small_k<false>, dim3(B), dim3(256), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
-                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc);
+                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps);
     }
     STOVE_LAUNCH_CHECK();
     return 0;

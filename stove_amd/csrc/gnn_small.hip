@@ -78,7 +78,29 @@ __device__ __forceinline__ float sm_dot(const float* Wl, int OUT, int o, float x
 
 struct SmCfg {
   int N, sin_dim, lim_enc, elu;
+  int ne;                // edges of this wave (<= 3), ei/ej their node rows -- constant over the time loop
+  int ei[3], ej[3];
+  long long* stamps;     // debug: [4 waves][16] cycle stamps of workgroup 0 (normally null)
 };
+// edges (i -> j, i != j) q = 0 .. N(N-1)-1 are dealt out as wave 3 - (q & 3): wave 3, which has no node row when N = 3,
+// gets the first one
+__device__ __forceinline__ void sm_edges(SmCfg& cf) {
+  const int wv = wave_id();
+  cf.ne = 0;
+  for (int k = 0; k < 3; ++k) {
+    const int q = 3 - wv + 4 * k;
+    cf.ei[k] = cf.ej[k] = 0;
+    if (q < cf.N * (cf.N - 1)) {
+      const int i = q / (cf.N - 1), jj = q % (cf.N - 1);
+      cf.ei[k] = i;
+      cf.ej[k] = jj + (jj >= i ? 1 : 0);
+      cf.ne = k + 1;
+    }
+  }
+}
+__device__ __forceinline__ void sm_stamp(const SmCfg& cf, int k) {
+  if (cf.stamps != nullptr && blockIdx.x == 0 && lane_id() == 0) cf.stamps[wave_id() * 16 + k] = (long long)__builtin_readcyclecounter();
+}
 // pointers into the saved-activation block of one (sequence, step); layout of gnn_act_floats(N, 1)
 struct SmAct {
   float *SIN, *H1, *PRED, *F1, *F2, *O1, *RES, *CAT, *R1, *A1, *R2, *A2, *R3, *ATT, *DIST;
@@ -93,6 +115,38 @@ __device__ __forceinline__ SmAct sm_act(float* g, int N) {
   return a;
 }
 
+// A layer's weight rows for this lane, fetched from LDS ahead of use: the weights never depend on the data, so
+// every layer's fetch is issued while the previous layer still computes and the LDS latency (~100+ cycles per
+// read, which dominated the first version of this kernel) disappears from the serial chain.
+template <int K4>
+struct SmW {
+  float4 w[K4];
+};
+template <int K4>
+__device__ __forceinline__ SmW<K4> sm_wload(const float* Wl, int OUT, int o, int k4_0 = 0) {
+  SmW<K4> r;
+#pragma unroll
+  for (int k4 = 0; k4 < K4; ++k4) r.w[k4] = *reinterpret_cast<const float4*>(Wl + ((k4_0 + k4) * OUT + o) * 4);
+  return r;
+}
+// Packed fp32 FMA (v_pk_fma_f32: two lanes of fp32 per VGPR pair, full rate on CDNA3/4).  The operands are laid out
+// so that every packed operand is a natural register pair -- (w.x, w.y) and (w.z, w.w) of a float4, an SGPR pair
+// of consecutive readlanes -- otherwise the compiler pays two v_mov per packed instruction.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int K4>
+__device__ __forceinline__ float sm_dotw(const SmW<K4>& W, float x) {
+  v2f a = {0.0f, 0.0f}, b = {0.0f, 0.0f};       // two independent chains
+#pragma unroll
+  for (int k4 = 0; k4 < K4; ++k4) {
+    a = pk_fma(v2f{W.w[k4].x, W.w[k4].y}, v2f{sm_rl(x, 4 * k4), sm_rl(x, 4 * k4 + 1)}, a);
+    b = pk_fma(v2f{W.w[k4].z, W.w[k4].w}, v2f{sm_rl(x, 4 * k4 + 2), sm_rl(x, 4 * k4 + 3)}, b);
+  }
+  a += b;
+  return a.x + a.y;
+}
+
 // One GNN step.  Node wave r (< N): `sinv` = input row (lane k and k+32 hold s_in[r][k], zero beyond sin_dim);
 // returns RES[o] / PRED[o] in lane o (and o+32).  SAVE: write the activation block (act.* valid).
 template <bool SAVE>
@@ -102,86 +156,144 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
   const int o = lane & 31, h = lane >> 5;
   const int N = cf.N;
   const float* V = L.V;
-  float S = 0.0f, SD = 0.0f;
-  // ---- P1: node rows: encoder, self-dynamics, factorised first edge layer -------------------------------------
+  float S = 0.0f, SD = 0.0f, H1 = 0.0f;
+  SmW<8> wa, wb;
+  sm_stamp(cf, 0);
+  // ---- P1: node rows: encoder, factorised first edge layer ------------------------------------------------------
   if (wv < N) {
     const int r = wv;
-    float e;
-    if (cf.sin_dim <= 16) e = sm_dot<4>(L.W + W_ENC, 32, o, sinv);
-    else e = sm_dot<8>(L.W + W_ENC, 32, o, sinv);
-    S = (o < cf.lim_enc) ? sinv : e + V[V_ENC + o];
-    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+    wa = sm_wload<8>(L.W + W_ENC, 32, o);
+    const float benc = V[V_ENC + o];
+    // first half of the edge-first weights (k4 = 0..3, four column groups of 64) while the encoder computes
+    float4 ef[4][4];
 #pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4) {
-      const float* w = L.W + W_EF + (k4 * 256 + lane) * 4;
-      const float4 w0 = *reinterpret_cast<const float4*>(w);
-      const float4 w1 = *reinterpret_cast<const float4*>(w + 64 * 4);
-      const float4 w2 = *reinterpret_cast<const float4*>(w + 128 * 4);
-      const float4 w3 = *reinterpret_cast<const float4*>(w + 192 * 4);
-      const float x0 = sm_rl(S, 4 * k4), x1 = sm_rl(S, 4 * k4 + 1), x2 = sm_rl(S, 4 * k4 + 2), x3 = sm_rl(S, 4 * k4 + 3);
-      p0 = fmaf(w0.w, x3, fmaf(w0.z, x2, fmaf(w0.y, x1, fmaf(w0.x, x0, p0))));
-      p1 = fmaf(w1.w, x3, fmaf(w1.z, x2, fmaf(w1.y, x1, fmaf(w1.x, x0, p1))));
-      p2 = fmaf(w2.w, x3, fmaf(w2.z, x2, fmaf(w2.y, x1, fmaf(w2.x, x0, p2))));
-      p3 = fmaf(w3.w, x3, fmaf(w3.z, x2, fmaf(w3.y, x1, fmaf(w3.x, x0, p3))));
+    for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) ef[k4][g] = *reinterpret_cast<const float4*>(L.W + W_EF + (k4 * 256 + g * 64 + lane) * 4);
+    float e;
+    if (cf.sin_dim <= 16) {
+      SmW<4> w4;
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) w4.w[k4] = wa.w[k4];
+      e = sm_dotw<4>(w4, sinv);
+    } else {
+      e = sm_dotw<8>(wa, sinv);
+    }
+    S = (o < cf.lim_enc) ? sinv : e + benc;
+    v2f p[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float4 nx[4][4];
+      if (half == 0) {
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) nx[k4][g] = *reinterpret_cast<const float4*>(L.W + W_EF + ((4 + k4) * 256 + g * 64 + lane) * 4);
+      } else {
+        wb = sm_wload<8>(L.W + W_S0, 32, o);        // self-dynamics layer 0, used right after the barrier
+      }
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int kk = 16 * half + 4 * k4;
+        const v2f x01 = {sm_rl(S, kk), sm_rl(S, kk + 1)}, x23 = {sm_rl(S, kk + 2), sm_rl(S, kk + 3)};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          p[g] = pk_fma(v2f{ef[k4][g].x, ef[k4][g].y}, x01, p[g]);
+          p[g] = pk_fma(v2f{ef[k4][g].z, ef[k4][g].w}, x23, p[g]);
+        }
+      }
+      if (half == 0) {
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) ef[k4][g] = nx[k4][g];
+      }
     }
     float* pr = L.PR + r * 256 + lane;
-    pr[0] = p0;
-    pr[64] = p1;
-    pr[128] = p2;
-    pr[192] = p3;
+    pr[0] = p[0].x + p[0].y;
+    pr[64] = p[1].x + p[1].y;
+    pr[128] = p[2].x + p[2].y;
+    pr[192] = p[3].x + p[3].y;
     if (lane < 2) L.POS[r * 4 + lane] = S;
   }
+  sm_stamp(cf, 1);
   WG_SYNC();
-  // self-dynamics of the node rows is independent of the edges: issue it after the barrier so the edge phase of
-  // the other waves is not held up by it (node waves do it before their own edges)
-  float H1 = 0.0f;
-  if (wv < N) {
-    H1 = act_phi(sm_dot<8>(L.W + W_S0, 32, o, S) + V[V_S0 + o], cf.elu);
-    SD = sm_dot<8>(L.W + W_S1, 32, o, H1) + V[V_S1 + o] + H1;
-    if (SAVE && lane < 32) {
-      act.SIN[wv * 32 + o] = sinv;
-      act.H1[wv * 32 + o] = H1;
-      act.CAT[wv * 64 + 32 + o] = S;
-    }
-  }
-  // ---- P3: edges (i -> j, i != j), round-robin over the four waves; half 0 = relation chain, half 1 = attention -----
-  const int NEo = N * (N - 1);
-  for (int q = 3 - wv; q < NEo; q += 4) {      // wave 3 (no node row when N = 3) takes edges first
-    const int i = q / (N - 1), jj = q % (N - 1), j = jj + (jj >= i ? 1 : 0);
-    const int e = i * N + j;
-    const float dx = L.POS[i * 4] - L.POS[j * 4], dy = L.POS[i * 4 + 1] - L.POS[j * 4 + 1];
-    const float d = dx * dx + dy * dy;
-    const float* pi = L.PR + i * 256 + 128 * h;
-    const float* pj = L.PR + j * 256 + 128 * h + 64;
-    const int vwd = h ? V_WDA : V_WDR, vb0 = h ? V_BA0 : V_BR0;
-    const float a_lo = act_phi(pi[o] + pj[o] + V[vwd + o] * d + V[vb0 + o], cf.elu);
-    const float a_hi = act_phi(pi[o + 32] + pj[o + 32] + V[vwd + o + 32] * d + V[vb0 + o + 32], cf.elu);
+  sm_stamp(cf, 2);
+  // ---- P3: edges (i -> j, i != j); half 0 = relation chain, half 1 = attention chain ----------------------------------
+  // Wave 3 (no node row when N = 3) takes edges first.  Node waves interleave their self-dynamics layers (independent
+  // of the edges) with the LDS round trip of their first edge's activation row.
+  bool self_done = !(wv < N);
+  const int vwd = h ? V_WDA : V_WDR, vb0 = h ? V_BA0 : V_BR0;
+  const float wd_lo = V[vwd + o], wd_hi = V[vwd + o + 32], b0_lo = V[vb0 + o], b0_hi = V[vb0 + o + 32];
+  const float b1 = V[(h ? V_BA1 : V_BR1) + o], br2 = V[V_BR2 + o], wa2 = V[V_WA2 + o], ba2 = V[V_BA2];
+  const float* Wl2 = L.W + (h ? W_A1 : W_R1);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    if (it >= cf.ne && self_done) break;
+    const bool has_edge = it < cf.ne;
+    int e = 0;
+    float d = 0.0f, a_lo = 0.0f, a_hi = 0.0f;
     float* x1 = L.X1 + wv * 128 + 64 * h;
-    x1[o] = a_lo;
-    x1[o + 32] = a_hi;
+    SmW<16> w2;
+    if (has_edge) {
+      const int i = cf.ei[it], j = cf.ej[it];
+      e = i * N + j;
+      w2 = sm_wload<16>(Wl2, 32, o);
+      const float dx = L.POS[i * 4] - L.POS[j * 4], dy = L.POS[i * 4 + 1] - L.POS[j * 4 + 1];
+      d = dx * dx + dy * dy;
+      const float* pi = L.PR + i * 256 + 128 * h;
+      const float* pj = L.PR + j * 256 + 128 * h + 64;
+      a_lo = act_phi(pi[o] + pj[o] + wd_lo * d + b0_lo, cf.elu);
+      a_hi = act_phi(pi[o + 32] + pj[o + 32] + wd_hi * d + b0_hi, cf.elu);
+      x1[o] = a_lo;
+      x1[o + 32] = a_hi;
+    }
+    sm_stamp(cf, 8);
+    if (!self_done) {            // node wave: self-dynamics (wb = W_S0 from before the barrier)
+      wa = sm_wload<8>(L.W + W_S1, 32, o);
+      const float bs0 = V[V_S0 + o], bs1 = V[V_S1 + o];
+      H1 = act_phi(sm_dotw<8>(wb, S) + bs0, cf.elu);
+      SD = sm_dotw<8>(wa, H1) + bs1 + H1;
+      if (SAVE && lane < 32) {
+        act.SIN[wv * 32 + o] = sinv;
+        act.H1[wv * 32 + o] = H1;
+        act.CAT[wv * 64 + 32 + o] = S;
+      }
+      self_done = true;
+    }
+    sm_stamp(cf, 9);
+    if (!has_edge) break;
+    // second layer 64 -> 32: the activation row comes back as LDS broadcast reads (one address per half)
+    float4 xr[16];
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) xr[k4] = *reinterpret_cast<const float4*>(x1 + 4 * k4);
+    wb = sm_wload<8>(L.W + W_R2, 32, o);
     if (SAVE) {
       float* g1 = (h ? act.A1 : act.R1) + e * 64;
       g1[o] = a_lo;
       g1[o + 32] = a_hi;
     }
-    // second layer 64 -> 32: the activation row comes back as LDS broadcast reads (one address per half)
-    const float* Wl = L.W + (h ? W_A1 : W_R1);
-    float y0 = 0.0f, y1 = 0.0f;
+    v2f y0 = {0.0f, 0.0f}, y1 = {0.0f, 0.0f}, y2 = {0.0f, 0.0f}, y3 = {0.0f, 0.0f};      // four independent chains
 #pragma unroll
-    for (int k4 = 0; k4 < 16; ++k4) {
-      const float4 w = *reinterpret_cast<const float4*>(Wl + (k4 * 32 + o) * 4);
-      const float4 x = *reinterpret_cast<const float4*>(x1 + 4 * k4);
-      y0 = fmaf(w.y, x.y, fmaf(w.x, x.x, y0));
-      y1 = fmaf(w.w, x.w, fmaf(w.z, x.z, y1));
+    for (int k4 = 0; k4 < 16; k4 += 2) {
+      y0 = pk_fma(v2f{w2.w[k4].x, w2.w[k4].y}, v2f{xr[k4].x, xr[k4].y}, y0);
+      y1 = pk_fma(v2f{w2.w[k4].z, w2.w[k4].w}, v2f{xr[k4].z, xr[k4].w}, y1);
+      y2 = pk_fma(v2f{w2.w[k4 + 1].x, w2.w[k4 + 1].y}, v2f{xr[k4 + 1].x, xr[k4 + 1].y}, y2);
+      y3 = pk_fma(v2f{w2.w[k4 + 1].z, w2.w[k4 + 1].w}, v2f{xr[k4 + 1].z, xr[k4 + 1].w}, y3);
     }
-    const float a2 = act_phi(y0 + y1 + V[(h ? V_BA1 : V_BR1) + o], cf.elu);
-    if (SAVE) ((h ? act.A2 : act.R2) + e * 32)[o] = a2;
+    y0 += y1;
+    y2 += y3;
+    y0 += y2;
+    const float a2 = act_phi(y0.x + y0.y + b1, cf.elu);
+    sm_stamp(cf, 10);
     // third layer: relation 32 -> 32 + skip (x = lanes 0..31 of a2); attention 32 -> 1 -> exp
-    const float r3 = sm_dot<8>(L.W + W_R2, 32, o, a2) + V[V_BR2 + o] + a2;
-    const float att = __expf(wave_sum(h ? a2 * V[V_WA2 + o] : 0.0f) + V[V_BA2]);
+    const float r3 = sm_dotw<8>(wb, a2) + br2 + a2;
+    const float att = __expf(wave_sum(h ? a2 * wa2 : 0.0f) + ba2);
+    sm_stamp(cf, 11);
     if (h == 0) L.R3[e * 32 + o] = r3;
     if (lane == 0) L.ATT[e] = att;
     if (SAVE) {
+      ((h ? act.A2 : act.R2) + e * 32)[o] = a2;
       if (h == 0) act.R3[e * 32 + o] = r3;
       if (lane == 0) {
         act.ATT[e] = att;
@@ -200,18 +312,33 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
       act.DIST[e] = 0.0f;
     }
   }
+  if (wv < N) wa = sm_wload<8>(L.W + W_F0, 32, o);        // affector.0, in flight across the barrier
+  sm_stamp(cf, 4);
   WG_SYNC();
+  sm_stamp(cf, 5);
   // ---- P4: node rows: aggregation, affector, output ------------------------------------------------------------------
   if (wv < N) {
     const int r = wv;
+    wb = sm_wload<8>(L.W + W_F1, 32, o);
+    const float bf0 = V[V_F0 + o], bf1 = V[V_F1 + o], bf2 = V[V_F2 + o], bo0 = V[V_O0 + o], bo1 = V[V_O1 + o];
     float pred = SD;
     for (int j = 0; j < N; ++j)
       if (j != r) pred = fmaf(L.R3[(r * N + j) * 32 + o], L.ATT[r * N + j], pred);
-    const float F1 = fast_tanh(sm_dot<8>(L.W + W_F0, 32, o, pred) + V[V_F0 + o]);
-    const float F2 = fast_tanh(sm_dot<8>(L.W + W_F1, 32, o, F1) + V[V_F1 + o]) + F1;
-    const float F3 = sm_dot<8>(L.W + W_F2, 32, o, F2) + V[V_F2 + o];
-    const float O1 = fast_tanh(sm_dot<8>(L.W + W_O0, 32, o, F3) + sm_dot<8>(L.W + W_O0, 32, o, S, 8) + V[V_O0 + o]);
-    const float RES = sm_dot<8>(L.W + W_O1, 32, o, O1) + V[V_O1 + o] + O1;
+    sm_stamp(cf, 12);
+    const float F1 = fast_tanh(sm_dotw<8>(wa, pred) + bf0);
+    sm_stamp(cf, 13);
+    wa = sm_wload<8>(L.W + W_F2, 32, o);
+    const float F2 = fast_tanh(sm_dotw<8>(wb, F1) + bf1) + F1;
+    wb = sm_wload<8>(L.W + W_O0, 32, o);
+    const float F3 = sm_dotw<8>(wa, F2) + bf2;
+    wa = sm_wload<8>(L.W + W_O0, 32, o, 8);
+    float t = sm_dotw<8>(wb, F3);
+    wb = sm_wload<8>(L.W + W_O1, 32, o);
+    t += sm_dotw<8>(wa, S);
+    const float O1 = fast_tanh(t + bo0);
+    sm_stamp(cf, 14);
+    const float RES = sm_dotw<8>(wb, O1) + bo1 + O1;
+    sm_stamp(cf, 15);
     if (SAVE && lane < 32) {
       act.PRED[r * 32 + o] = pred;
       act.F1[r * 32 + o] = F1;
@@ -223,6 +350,7 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
     res_out = RES;
     pred_out = pred;
   }
+  sm_stamp(cf, 6);
 }
 
 __device__ __forceinline__ float sm_from_lane(float v, int src_lane) {
@@ -238,12 +366,14 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_small_k(
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
     float* __restrict__ z, float* __restrict__ zdyn, float* __restrict__ zdstd, float* __restrict__ mean,
     float* __restrict__ stdv, float* __restrict__ pred, float* __restrict__ act,
-    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc) {
+    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc, long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const SmLds L = sm_carve(lds);
   const int b = blockIdx.x;
   const int wv = wave_id(), lane = lane_id(), l = lane & 31;
-  const SmCfg cf{N, sin_dim, lim_enc, elu};
+  SmCfg cf{N, sin_dim, lim_enc, elu};
+  cf.stamps = nullptr;
+  sm_edges(cf);
   const int E = sin_dim - 16;
   const size_t act_stride = gnn_act_floats(N, 1);
   sm_setup(L, P);
@@ -273,6 +403,7 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_small_k(
     }
     SmAct a{};
     if (SAVE) a = sm_act(act + ((size_t)b * Ts + ts) * act_stride, N);
+    cf.stamps = (ts == Ts - 1) ? stamps : nullptr;
     float res = 0.0f, prd = 0.0f;
     sm_step<SAVE>(L, cf, sinv, a, res, prd);
     if (wv < N) {
@@ -313,6 +444,7 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_small_k(
       if (pred != nullptr && lane < 32) pred[o * 32 + l] = prd;
       sinv = zv;
     }
+    sm_stamp(cf, 7);
   }
 }
 
@@ -327,7 +459,9 @@ __global__ __launch_bounds__(256) void rollout_fwd_small_k(const float* __restri
   const SmLds L = sm_carve(lds);
   const int b = blockIdx.x;
   const int wv = wave_id(), lane = lane_id(), l = lane & 31;
-  const SmCfg cf{N, sin_dim, lim_enc, elu};
+  SmCfg cf{N, sin_dim, lim_enc, elu};
+  cf.stamps = nullptr;
+  sm_edges(cf);
   const int E = sin_dim - 16;
   sm_setup(L, P);
   float sinv = 0.0f, scale = 0.0f;

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     build.build_library()
     lib = ctypes.CDLL(_lib.LIB_PATH)
     header = open(os.path.join(ROOT, 'include', 'stove_hip.h')).read()
-    declared = set(re.findall(r'^(?:int|size_t|const char\*)\s+(stove_[a-z0-9_]+)\s*\(', header, flags=re.M))
+    declared = set(re.findall(r'^(?:int|size_t|void|const char\*)\s+(stove_[a-z0-9_]+)\s*\(', header, flags=re.M))
     assert len(declared) >= 15
     for name in declared:
         assert hasattr(lib, name), name
