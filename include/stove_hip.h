@@ -155,6 +155,33 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
  * perm (B,T,N,N) f32, pre-zeroed, only written in mode 2 (may be NULL otherwise). */
 int stove_match_objects(const float* feat, long long* idx, float* perm, int B, int T, int N, int F, int mode, void* stream);
 
+/* ---- SuPAIR state pipeline and ELBO assembly (elementwise / short stencils in t; replaces ~180 ATen launches per step).
+ * stove_supair_state_fwd: raw codes (n*T*o, 8) of the recognition LSTM ->
+ *     zc (n,T,o,8) = constrain_zp (supair.py:112-149; span_low = 8 spans then 8 lows, HOST floats),
+ *     idx (n,T,o) = object matching on the positions (mode as stove_match_objects; pos (n,T,o,2) is scratch),
+ *     zfix (n,T,o,8) = gathered + fix_supair-smoothed [mean 4 | std 4] (stove.py:516-563; hits (n,T,o) u8 = its mask),
+ *     zl / sl (n,T-skip,o,6) = z_sup_full / z_sup_std_full[:, skip:] with finite-difference velocities
+ *     (stove.py:172-198), init6 (n,o,6) = z_sup_full[:, skip-1].
+ * stove_supair_state_bwd: gradients of zfix / zl / sl / init6 (any may be NULL) -> g_codes; gfix_ws: n*T*o*8 floats.
+ * stove_zall_fwd/bwd: z of the scene likelihood, frames 1..T-1: SuPAIR means before `skip`, sampled states after,
+ *     [sx, sy/sx, x, y] -> [sx, sy, x, y] (stove.py:731-736); bwd writes every element of g_zfix and g_zs (n,T-skip,o,18).
+ * stove_elbo_fwd: out3 = { mean_t,b(trans_lik + img_lik - log_q) + mean(img_lik_sup), mean trans_lik, mean log_q }
+ *     (stove.py:738-748); lik (n,T-1); trans_std16 HOST floats; part_ws n*4 floats.  stove_elbo_bwd: g_out = device
+ *     scalar dL/d out3[0]. */
+int stove_supair_state_fwd(const float* codes, const float* span_low, float* zc, float* pos, long long* idx, float* zfix,
+                           unsigned char* hits, float* zl, float* sl, float* init6, int n, int T, int o, int skip, int fix,
+                           int mode, void* stream);
+int stove_supair_state_bwd(const float* zc, const long long* idx, const unsigned char* hits, const float* zfix, const float* g_zfix,
+                           const float* g_zl, const float* g_sl, const float* g_init6, const float* span_low, float* gfix_ws,
+                           float* g_codes, int n, int T, int o, int skip, void* stream);
+int stove_zall_fwd(const float* zfix, const float* zs, float* zall, int n, int T, int o, int skip, void* stream);
+int stove_zall_bwd(const float* zfix, const float* zs, const float* g_zall, float* g_zfix, float* g_zs, int n, int T, int o, int skip,
+                   void* stream);
+int stove_elbo_fwd(const float* zs, const float* mean, const float* std_, const float* zdyn, const float* lik, const float* trans_std16,
+                   float* part_ws, float* out3, int n, int T, int o, int skip, void* stream);
+int stove_elbo_bwd(const float* zs, const float* mean, const float* std_, const float* zdyn, const float* trans_std16, const float* g_out,
+                   float* g_zs, float* g_mean, float* g_std, float* g_zdyn, float* g_lik, int n, int T, int o, int skip, void* stream);
+
 /* debug aid of the measurement tools: device buffer of 64 int64 cycle stamps ([4 waves][16 phases]) written by
  * workgroup 0 of the small-graph time loops in their last step; NULL (default) switches it off. */
 void stove_debug_set_stamps(long long* device_buffer);

@@ -12,6 +12,7 @@
 #include "gnn_small.hip"
 #include "lstm.hip"
 #include "arena.hip"
+#include "state.hip"
 
 namespace stove {
 
@@ -404,6 +405,91 @@ int stove_arena_gather(const float* arena, const int32_t* src, float* image, int
 int stove_arena_scatter_add(const float* gimage, const int32_t* src, float* grad_arena, int n, void* stream) {
   if (n == 0) return 0;
   STOVE_LAUNCH(arena_scatter_add_k, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gimage, src, grad_arena, n);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- SuPAIR state pipeline / ELBO assembly
+static ZpConst zp_const(const float* span_low) {
+  ZpConst k;
+  for (int d = 0; d < 8; ++d) {
+    k.span[d] = span_low[d];
+    k.low[d] = span_low[8 + d];
+  }
+  return k;
+}
+
+int stove_supair_state_fwd(const float* codes, const float* span_low, float* zc, float* pos, long long* idx, float* zfix,
+                           unsigned char* hits, float* zl, float* sl, float* init6, int n, int T, int o, int skip, int fix,
+                           int mode, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return 0;
+  if (T < 2 || skip < 1 || skip >= T || o < 1 || o > kMatchN) return (int)hipErrorInvalidValue;
+  const int M = n * T * o;
+  STOVE_LAUNCH(zp_constrain_k, dim3((M * 8 + 255) / 256), dim3(256), 0, st, codes, zp_const(span_low), zc, pos, M);
+  STOVE_LAUNCH_CHECK();
+  int rc = stove_match_objects(pos, idx, nullptr, n, T, o, 2, mode, stream);
+  if (rc) return rc;
+  STOVE_LAUNCH(supair_state_fwd_k, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)zc, (const long long*)idx, zfix, hits, zl, sl,
+               init6, n, T, o, skip, fix);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_supair_state_bwd(const float* zc, const long long* idx, const unsigned char* hits, const float* zfix, const float* g_zfix,
+                           const float* g_zl, const float* g_sl, const float* g_init6, const float* span_low, float* gfix_ws,
+                           float* g_codes, int n, int T, int o, int skip, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return 0;
+  const int M = n * T * o;
+  STOVE_LAUNCH(supair_state_bwd1_k, dim3((M + 255) / 256), dim3(256), 0, st, zfix, g_zfix, g_zl, g_sl, g_init6, gfix_ws, n, T, o, skip);
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH(supair_state_bwd2_k, dim3((M + 255) / 256), dim3(256), 0, st, zc, idx, hits, (const float*)gfix_ws, zp_const(span_low),
+               g_codes, n, T, o);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_zall_fwd(const float* zfix, const float* zs, float* zall, int n, int T, int o, int skip, void* stream) {
+  if (n == 0) return 0;
+  const int M = n * (T - 1) * o;
+  STOVE_LAUNCH(zall_fwd_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, zfix, zs, zall, n, T, o, skip);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_zall_bwd(const float* zfix, const float* zs, const float* g_zall, float* g_zfix, float* g_zs, int n, int T, int o, int skip,
+                   void* stream) {
+  if (n == 0) return 0;
+  const int M = n * T * o + n * (T - skip) * o;
+  STOVE_LAUNCH(zall_bwd_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, zfix, zs, g_zall, g_zfix, g_zs, n, T, o, skip);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+static TransStd trans_std(const float* s16) {
+  TransStd t;
+  for (int d = 0; d < 16; ++d) t.s[d] = s16[d];
+  return t;
+}
+
+int stove_elbo_fwd(const float* zs, const float* mean, const float* std_, const float* zdyn, const float* lik, const float* trans_std16,
+                   float* part_ws, float* out3, int n, int T, int o, int skip, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0 || skip < 1 || skip >= T) return (int)hipErrorInvalidValue;
+  STOVE_LAUNCH(elbo_part_k, dim3(n), dim3(256), 0, st, zs, mean, std_, zdyn, lik, trans_std(trans_std16), part_ws, T, o, skip);
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH(elbo_final_k, dim3(1), dim3(256), 0, st, (const float*)part_ws, out3, n, T, skip);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_elbo_bwd(const float* zs, const float* mean, const float* std_, const float* zdyn, const float* trans_std16, const float* g_out,
+                   float* g_zs, float* g_mean, float* g_std, float* g_zdyn, float* g_lik, int n, int T, int o, int skip, void* stream) {
+  if (n == 0) return 0;
+  const int M = n * (T - skip) * o + n * (T - 1);
+  STOVE_LAUNCH(elbo_bwd_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, zs, mean, std_, zdyn, trans_std(trans_std16), g_out,
+               g_zs, g_mean, g_std, g_zdyn, g_lik, n, T, o, skip);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

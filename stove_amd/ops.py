@@ -372,6 +372,134 @@ def match_objects(feat, mode):
     return idx, perm
 
 
+# ------------------------------------------------------------------------------------------------
+# SuPAIR state pipeline and ELBO assembly (csrc/state.hip)
+# ------------------------------------------------------------------------------------------------
+def _host_floats(vals, n):
+    vals = [float(v) for v in vals]
+    if len(vals) != n:
+        raise ValueError('expected %d floats, got %d' % (n, len(vals)))
+    return (ctypes.c_float * n)(*vals)
+
+
+class _SupairStateFn(torch.autograd.Function):
+    """constrain_zp + object matching + gather + fix_supair + velocities (reference supair.py:112-149,
+    stove.py:172-198, 200-563): raw codes -> zfix (n,T,o,8), zl, sl (n,T-skip,o,6), init6 (n,o,6), idx."""
+
+    @staticmethod
+    def forward(ctx, codes, span_low, n, T, o, skip, fix, mode):
+        lib = _lib.load()
+        codes = _f32(codes)
+        dev = codes.device
+        Ts = T - skip
+        kc = _host_floats(span_low, 16)
+        with torch.cuda.device(dev):
+            def f(*shape):
+                return torch.empty(*shape, dtype=torch.float32, device=dev)
+            zc, pos, zfix = f(n, T, o, 8), f(n, T, o, 2), f(n, T, o, 8)
+            idx = torch.empty(n, T, o, dtype=torch.int64, device=dev)
+            hits = torch.empty(n, T, o, dtype=torch.uint8, device=dev)
+            zl, sl, init6 = f(n, Ts, o, 6), f(n, Ts, o, 6), f(n, o, 6)
+            check(lib.stove_supair_state_fwd(ptr(codes), kc, ptr(zc), ptr(pos), ptr(idx), ptr(zfix), ptr(hits), ptr(zl), ptr(sl),
+                                             ptr(init6), n, T, o, skip, int(bool(fix)), MATCH_MODES[mode], stream()),
+                  'stove_supair_state_fwd')
+        ctx.save_for_backward(zc, idx, hits, zfix)
+        ctx.cfg = (tuple(span_low), n, T, o, skip, codes.shape)
+        ctx.mark_non_differentiable(idx)
+        return zfix, zl, sl, init6, idx
+
+    @staticmethod
+    def backward(ctx, g_zfix, g_zl, g_sl, g_init6, _g_idx):
+        lib = _lib.load()
+        zc, idx, hits, zfix = ctx.saved_tensors
+        span_low, n, T, o, skip, shape = ctx.cfg
+        dev = zc.device
+        kc = _host_floats(span_low, 16)
+        gs = [None if g is None else _f32(g) for g in (g_zfix, g_zl, g_sl, g_init6)]
+        with torch.cuda.device(dev):
+            ws = torch.empty(n * T * o * 8, dtype=torch.float32, device=dev)
+            g_codes = torch.empty(shape, dtype=torch.float32, device=dev)
+            check(lib.stove_supair_state_bwd(ptr(zc), ptr(idx), ptr(hits), ptr(zfix), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]),
+                                             kc, ptr(ws), ptr(g_codes), n, T, o, skip, stream()), 'stove_supair_state_bwd')
+        return g_codes, None, None, None, None, None, None, None
+
+
+class _ZallFn(torch.autograd.Function):
+    """z of the scene likelihood for frames 1..T-1 (reference stove.py:731-736 + sy_from_quotient) -> (n*(T-1)*o, 4)."""
+
+    @staticmethod
+    def forward(ctx, zfix, zs, n, T, o, skip):
+        lib = _lib.load()
+        zfix, zs = _f32(zfix), _f32(zs)
+        dev = zfix.device
+        with torch.cuda.device(dev):
+            zall = torch.empty(n * (T - 1) * o, 4, dtype=torch.float32, device=dev)
+            check(lib.stove_zall_fwd(ptr(zfix), ptr(zs), ptr(zall), n, T, o, skip, stream()), 'stove_zall_fwd')
+        ctx.save_for_backward(zfix, zs)
+        ctx.cfg = (n, T, o, skip)
+        return zall
+
+    @staticmethod
+    def backward(ctx, g_zall):
+        lib = _lib.load()
+        zfix, zs = ctx.saved_tensors
+        n, T, o, skip = ctx.cfg
+        with torch.cuda.device(zfix.device):
+            g_zfix, g_zs = torch.empty_like(zfix), torch.empty_like(zs)
+            check(lib.stove_zall_bwd(ptr(zfix), ptr(zs), ptr(_f32(g_zall)), ptr(g_zfix), ptr(g_zs), n, T, o, skip, stream()),
+                  'stove_zall_bwd')
+        return g_zfix, g_zs, None, None, None, None
+
+
+class _ElboFn(torch.autograd.Function):
+    """mean(trans_lik + img_lik - log_q) + mean(img_lik_sup) (reference stove.py:738-748) -> elbo (), stats (2,) =
+    (mean trans_lik, mean log_q)."""
+
+    @staticmethod
+    def forward(ctx, zs, mean, std, zdyn, lik, trans_std, n, T, o, skip):
+        lib = _lib.load()
+        zs, mean, std, zdyn, lik = _f32(zs), _f32(mean), _f32(std), _f32(zdyn), _f32(lik)
+        dev = zs.device
+        ts = _host_floats(trans_std, 16)
+        with torch.cuda.device(dev):
+            part = torch.empty(n * 4, dtype=torch.float32, device=dev)
+            out3 = torch.empty(3, dtype=torch.float32, device=dev)
+            check(lib.stove_elbo_fwd(ptr(zs), ptr(mean), ptr(std), ptr(zdyn), ptr(lik), ts, ptr(part), ptr(out3), n, T, o, skip, stream()),
+                  'stove_elbo_fwd')
+        ctx.save_for_backward(zs, mean, std, zdyn)
+        ctx.cfg = (tuple(trans_std), n, T, o, skip, lik.shape)
+        stats = out3[1:]
+        ctx.mark_non_differentiable(stats)
+        return out3[0], stats
+
+    @staticmethod
+    def backward(ctx, g_elbo, _g_stats):
+        lib = _lib.load()
+        zs, mean, std, zdyn = ctx.saved_tensors
+        trans_std, n, T, o, skip, lik_shape = ctx.cfg
+        ts = _host_floats(trans_std, 16)
+        dev = zs.device
+        with torch.cuda.device(dev):
+            g = _f32(g_elbo).reshape(1)
+            g_zs, g_mean, g_std, g_zdyn = (torch.empty_like(t) for t in (zs, mean, std, zdyn))
+            g_lik = torch.empty(lik_shape, dtype=torch.float32, device=dev)
+            check(lib.stove_elbo_bwd(ptr(zs), ptr(mean), ptr(std), ptr(zdyn), ts, ptr(g), ptr(g_zs), ptr(g_mean), ptr(g_std), ptr(g_zdyn),
+                                     ptr(g_lik), n, T, o, skip, stream()), 'stove_elbo_bwd')
+        return g_zs, g_mean, g_std, g_zdyn, g_lik, None, None, None, None, None
+
+
+def supair_state(codes, span_low, n, T, o, skip, fix, mode):
+    return _SupairStateFn.apply(codes, tuple(float(v) for v in span_low), int(n), int(T), int(o), int(skip), bool(fix), mode)
+
+
+def zall(zfix, zs, n, T, o, skip):
+    return _ZallFn.apply(zfix, zs, int(n), int(T), int(o), int(skip))
+
+
+def elbo(zs, mean, std, zdyn, lik, trans_std, n, T, o, skip):
+    return _ElboFn.apply(zs, mean, std, zdyn, lik, tuple(float(v) for v in trans_std), int(n), int(T), int(o), int(skip))
+
+
 def _splitk_tn(a, b):
     """a^T @ b for tall a (K, M), b (K, N) with K >> M, N (weight gradients over all frames).
 

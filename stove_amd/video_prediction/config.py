@@ -44,6 +44,8 @@ _DEFAULTS = dict(
     world_size=1,            # data-parallel ranks (one process per GPU, RCCL all-reduce of the flat gradient)
     align_corners=False,     # spatial-transformer convention; False = what the runnable reference computes
     fused_dynamics=True,     # run the inference recursion in the persistent HIP time-loop kernel
+    fused_state=True,        # constrain_zp / matching / fix_supair / velocities as the fused state pipeline (csrc/state.hip)
+    fused_elbo=True,         # log q, transition likelihood and the ELBO means in two launches
     param_arena=True,        # Trainer: parameters / gradients as views into one flat buffer (stove_amd/arena.py)
 )
 

@@ -64,6 +64,7 @@ class Dynamics(nn.Module):
         elif len(std) != cl // 2:
             raise ValueError('Specify valid transition_lik_std.')
         self.transition_lik_std = torch.tensor([[std]], dtype=torch.float32, device=self.c.device)
+        self.transition_lik_std_host = [float(v) for v in std]     # the fused ELBO kernel takes them as launch constants
 
     # ------------------------------------------------------------------ kernel parameter image
     def param_image(self, core_idx=0, leaf=None, pad_value=0.0):

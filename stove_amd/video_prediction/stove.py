@@ -157,23 +157,33 @@ class Stove(nn.Module):
         n, T = x.shape[:2]
         o, skip, cl = c.num_obj, c.skip, c.cl
 
-        # 1. SuPAIR states for every frame, consistent object order, smoothing, velocities
+        # 1. SuPAIR states for every frame, consistent object order, smoothing, velocities.
+        # Without appearance features the whole chain (constrain_zp, matching, gather, fix_supair, velocities) is the
+        # fused state pipeline (csrc/state.hip); the PyTorch chain below it is the same computation op by op.
         codes = self.sup.encoder(x.flatten(end_dim=1))
-        z_sup, z_sup_std = self.sup.constrain_zp(codes.flatten(end_dim=1))
-        z_sup, z_sup_std = z_sup.view(n, T, o, 4), z_sup_std.view(n, T, o, 4)
-        app = None
-        if c.debug_core_appearance or c.debug_match_appearance:
-            app = self.object_embedding(z_sup, x_color)
-        z_sup, z_sup_std, obj_appearances = self.match_objects(z_sup, z_sup_std, app)
-        if c.debug_fix_supair:
-            z_sup, z_sup_std = self.fix_supair(z_sup, z_sup_std)
-        z_sup_full = self.v_from_state(z_sup)
-        z_sup_std_full = self.v_std_from_pos(z_sup_std)
+        fused_state = bool(getattr(c, 'fused_state', True)) and not (c.debug_core_appearance or c.debug_match_appearance)
+        if fused_state:
+            zfix, zsup_loop, zsstd_loop, init6, _ = ops.supair_state(
+                codes.flatten(end_dim=1), self.sup.zp_span_low(), n, T, o, skip, c.debug_fix_supair, c.debug_match_objects)
+            z_sup = zfix[..., :4]
+            obj_appearances = None
+        else:
+            z_sup, z_sup_std = self.sup.constrain_zp(codes.flatten(end_dim=1))
+            z_sup, z_sup_std = z_sup.view(n, T, o, 4), z_sup_std.view(n, T, o, 4)
+            app = None
+            if c.debug_core_appearance or c.debug_match_appearance:
+                app = self.object_embedding(z_sup, x_color)
+            z_sup, z_sup_std, obj_appearances = self.match_objects(z_sup, z_sup_std, app)
+            if c.debug_fix_supair:
+                z_sup, z_sup_std = self.fix_supair(z_sup, z_sup_std)
+            z_sup_full = self.v_from_state(z_sup)
+            z_sup_std_full = self.v_std_from_pos(z_sup_std)
+            zsup_loop, zsstd_loop, init6 = z_sup_full[:, skip:], z_sup_std_full[:, skip:], z_sup_full[:, skip - 1]
 
         # 2. initial state at t = skip-1 and the inference recursion
         lat0 = 0.01 * self._noise('latent', (n, o, cl // 2 - 4), z_sup)
         _ = 0.1 + 0.01 * self._noise('std', (n, o, cl // 2 - 4), z_sup)     # drawn as in the reference, unused
-        init_z = torch.cat([z_sup_full[:, skip - 1], lat0], -1)
+        init_z = torch.cat([init6, lat0], -1)
         Ts = T - skip
         use_app = bool(c.debug_core_appearance)
         if getattr(c, 'fused_dynamics', True):
@@ -187,12 +197,11 @@ class Stove(nn.Module):
             eps = self._noise('steps', (n, Ts, o, cl // 2 + 2), z_sup)
             image, sink = self.dyn.kernel_params(0)
             z_s, z_dyn_s, z_dyn_std_s, mean_s, z_std_s, pred = ops.dyn_loop(
-                init_z, z_sup_full[:, skip:], z_sup_std_full[:, skip:], eps, extra, image,
+                init_z, zsup_loop, zsstd_loop, eps, extra, image,
                 2, self.dyn.use_elu, self.dyn.loop_consts(), want_pred=bool(c.action_conditioned), sink=sink)
-            log_z_s = _normal_log_prob(z_s, mean_s, z_std_s)
             rewards = self.dyn.reward_from_pred(pred) if c.action_conditioned else torch.zeros(Ts)
         else:
-            z_prev, zs, zd, zds, lq, zst, rew = init_z, [], [], [], [], [], []
+            z_prev, zs, zd, zds, zm, zst, rew = init_z, [], [], [], [], [], []
             eps_all = self._noise('steps', (n, Ts, o, cl // 2 + 2), z_sup)
             saved_fn = self.noise_fn
             for t in range(skip, T):
@@ -201,40 +210,51 @@ class Stove(nn.Module):
                 m, sd = self.dyn.constrain_z_dyn(tmp[..., :cl // 2], tmp[..., cl // 2:])
                 z_dyn_t = torch.cat([z_prev[..., 2:4] + m[..., :2], m[..., 2:]], -1)
                 self.noise_fn = lambda kind, shape, _e=eps_all[:, t - skip]: _e
-                z_t, log_q, _, std_t = self.full_state(z_dyn_t, sd, z_sup_full[:, t], z_sup_std_full[:, t])
+                z_t, _, mean_t, std_t = self.full_state(z_dyn_t, sd, zsup_loop[:, t - skip], zsstd_loop[:, t - skip])
                 self.noise_fn = saved_fn
-                zs.append(z_t); zd.append(z_dyn_t); zds.append(sd); lq.append(log_q); zst.append(std_t); rew.append(reward)
+                zs.append(z_t); zd.append(z_dyn_t); zds.append(sd); zm.append(mean_t); zst.append(std_t); rew.append(reward)
                 z_prev = z_t
             z_s, z_dyn_s, z_dyn_std_s = torch.stack(zs, 1), torch.stack(zd, 1), torch.stack(zds, 1)
-            log_z_s, z_std_s = torch.stack(lq, 1), torch.stack(zst, 1)
+            mean_s, z_std_s = torch.stack(zm, 1), torch.stack(zst, 1)
             rewards = torch.stack(rew, 1) if c.action_conditioned else torch.zeros(Ts)
 
         # 3. ELBO: image likelihood (SPNs), q(z|x) and the generative transition likelihood.
         # The reference scores frames skip..T-1 (sampled z) and frame 1..skip-1 (SuPAIR mean) in two
         # likelihood calls (stove.py:731-736); here both go through ONE fused scene launch.
-        z_all = torch.cat([z_sup[:, 1:skip], z_s[..., :4]], 1)                 # (n, T-1, o, 4) [sx, sy/sx, x, y]
-        z_all = self.sup.sy_from_quotient(z_all.flatten(end_dim=2))
+        if fused_state:
+            z_all = ops.zall(zfix, z_s, n, T, o, skip)
+        else:
+            z_all = torch.cat([z_sup[:, 1:skip], z_s[..., :4]], 1)             # (n, T-1, o, 4) [sx, sy/sx, x, y]
+            z_all = self.sup.sy_from_quotient(z_all.flatten(end_dim=2))
         lik_all, sup_prop = self.sup.likelihood(x[:, 1:], z_all, log_from=skip - 1)
         self.prop_dict.update(sup_prop)
         lik_all = lik_all.view(n, T - 1)
-        img_lik = lik_all[:, skip - 1:].reshape(-1)
-        img_lik_sup = lik_all[:, :skip - 1].reshape(-1)
-        log_z_f = log_z_s.sum((-2, -1)).flatten()
-        trans_lik = self.transition_lik(means=z_dyn_s, results=z_s[..., 2:]).sum((-2, -1)).flatten(end_dim=1)
-        elbo = trans_lik + img_lik - log_z_f
-        average_elbo = torch.mean(elbo) + torch.mean(img_lik_sup)
+        if getattr(c, 'fused_elbo', True):
+            # log q(z), the transition likelihood and all the means in two launches (csrc/state.hip)
+            average_elbo, stats = ops.elbo(z_s, mean_s, z_std_s, z_dyn_s, lik_all,
+                                           self.dyn.transition_lik_std_host, n, T, o, skip)
+            trans_mean, logq_mean = stats[0], stats[1]
+        else:
+            log_z_s = _normal_log_prob(z_s, mean_s, z_std_s)
+            img_lik = lik_all[:, skip - 1:].reshape(-1)
+            img_lik_sup = lik_all[:, :skip - 1].reshape(-1)
+            log_z_f = log_z_s.sum((-2, -1)).flatten()
+            trans_lik = self.transition_lik(means=z_dyn_s, results=z_s[..., 2:]).sum((-2, -1)).flatten(end_dim=1)
+            elbo = trans_lik + img_lik - log_z_f
+            average_elbo = torch.mean(elbo) + torch.mean(img_lik_sup)
+            trans_mean, logq_mean = trans_lik.mean(), log_z_f.mean()
 
         if (self.step_counter % c.print_every == 0) or (self.step_counter % c.plot_every == 0):
             pd = self.prop_dict
             pd['z'] = self.sup.sy_from_quotient(z_s).detach()
             pd['z_dyn'] = z_dyn_s.detach()
-            pd['z_sup'] = self.sup.sy_from_quotient(z_sup_full[:, skip:]).detach()
+            pd['z_sup'] = self.sup.sy_from_quotient(zsup_loop).detach()
             pd['z_std'] = z_std_s.mean((0, 1, 2)).detach()
             nan2 = torch.full((2,), float('nan'), device=z_s.device, dtype=z_s.dtype)
             pd['z_dyn_std'] = torch.cat([nan2, z_dyn_std_s[..., :4].mean((0, 1, 2)).detach()])
-            pd['z_sup_std'] = z_sup_std_full[:, skip:].mean((0, 1, 2)).detach()
-            pd['log_q'] = log_z_f.mean().detach()
-            pd['translik'] = trans_lik.mean().detach()
+            pd['z_sup_std'] = zsstd_loop.mean((0, 1, 2)).detach()
+            pd['log_q'] = logq_mean.detach()
+            pd['translik'] = trans_mean.detach()
             pd['obj_appearances'] = obj_appearances[:, skip:].detach() if obj_appearances is not None else None
         return average_elbo, self.prop_dict, rewards
 

@@ -76,6 +76,14 @@ class Supair(nn.Module):
         out = torch.addcmul(low, torch.sigmoid(zp), span)
         return out[:, :4], out[:, 4:]
 
+    def zp_span_low(self):
+        """The 8 spans and 8 lows of constrain_zp as host floats (the fused state pipeline's constants)."""
+        c = self.c
+        span = [c.max_obj_scale - c.min_obj_scale, c.max_y_scale - c.min_y_scale,
+                2 * c.obj_pos_bound, 2 * c.obj_pos_bound, c.scale_var, c.scale_var, c.pos_var, c.pos_var]
+        low = [c.min_obj_scale, c.min_y_scale, -c.obj_pos_bound, -c.obj_pos_bound, 0.0, 0.0, 0.0, 0.0]
+        return span + low
+
     @staticmethod
     def sy_from_quotient(z):
         """[sx, sy/sx, ...] -> [sx, sy, ...]."""

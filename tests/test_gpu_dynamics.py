@@ -136,7 +136,8 @@ def test_stove_forward_elbo_and_grads(name, fused, arena):
     from stove_amd.arena import ParamArena
     from stove_amd.video_prediction.stove import Stove
     gold = load_golden(f'g7_stove_{name}_f64')
-    st = fill_analytic(Stove(make_cfg(fused_dynamics=fused, **CASES[name]))).to(DEV)
+    # fused=False: host time loop, PyTorch state chain and PyTorch ELBO assembly (the op-by-op restatement)
+    st = fill_analytic(Stove(make_cfg(fused_dynamics=fused, fused_state=fused, fused_elbo=fused, **CASES[name]))).to(DEV)
     if arena:
         ar = ParamArena(st)
         assert ar.has_spn and ar.has_gnn
