@@ -286,3 +286,60 @@ def test_three_optimiser_steps_track_the_reference(arena):
         if k.startswith('p_'):
             got = float(params[k[2:]].detach().double().sum())
             assert abs(got - float(v)) < 2e-4 * abs(float(v)) + 1e-4, (k, got, float(v))
+
+
+@pytest.mark.parametrize('mode', ['3_only', 'greedy', 'volatile'])
+def test_state_pipeline_against_torch_chain(mode):
+    """Fused state pipeline (csrc/state.hip) == constrain_zp -> match -> gather -> fix_supair -> velocities done op by
+    op in PyTorch, values and gradients; random codes make the smoothing stencil fire and 'volatile' pick duplicates."""
+    from stove_amd import ops
+    from stove_amd.video_prediction.stove import Stove
+    st = Stove(make_cfg(debug_match_objects=mode)).to(DEV)
+    n, T, o, skip = 6, 11, 3, 2
+    g = torch.Generator(device='cpu').manual_seed(3)
+    codes = (2.0 * torch.randn(n * T * o, 8, generator=g)).to(DEV).requires_grad_()
+    ws = [torch.randn(*s, generator=g).to(DEV) for s in ((n, T, o, 8), (n, T - skip, o, 6), (n, T - skip, o, 6), (n, o, 6))]
+    zfix, zl, sl, init6, idx = ops.supair_state(codes, st.sup.zp_span_low(), n, T, o, skip, True, mode)
+    ((zfix * ws[0]).sum() + (zl * ws[1]).sum() + (sl * ws[2]).sum() + (init6 * ws[3]).sum()).backward()
+    ref = codes.detach().clone().requires_grad_()
+    z, zs = st.sup.constrain_zp(ref)
+    z, zs, _ = st.match_objects(z.view(n, T, o, 4), zs.view(n, T, o, 4), None)
+    raw = torch.cat([z, zs], -1).detach()
+    z, zs = st.fix_supair(z, zs)
+    full, sfull = st.v_from_state(z), st.v_std_from_pos(zs)
+    fixed = torch.cat([z, zs], -1)
+    assert float((fixed.detach() - raw).abs().max()) > 0.01            # the stencil did replace something
+    if mode == 'volatile':
+        assert any(len(set(r)) < o for r in idx.view(-1, o).tolist())   # ... and volatile is not a permutation here
+    ((fixed * ws[0]).sum() + (full[:, skip:] * ws[1]).sum() + (sfull[:, skip:] * ws[2]).sum()
+     + (full[:, skip - 1] * ws[3]).sum()).backward()
+    assert err(zfix, fixed) < 1e-6 and err(zl, full[:, skip:]) < 1e-6 and err(sl, sfull[:, skip:]) < 1e-6
+    assert err(init6, full[:, skip - 1]) < 1e-6
+    assert err(codes.grad, ref.grad) < 1e-5
+
+
+def test_elbo_assembly_against_torch():
+    from stove_amd import ops
+    n, T, o, skip = 4, 7, 3, 2
+    g = torch.Generator(device='cpu').manual_seed(5)
+    Ts = T - skip
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    zs, mean, zd = mk(n, Ts, o, 18).requires_grad_(), mk(n, Ts, o, 18).requires_grad_(), mk(n, Ts, o, 16).requires_grad_()
+    std = (0.05 + torch.rand(n, Ts, o, 18, generator=g)).to(DEV).requires_grad_()
+    lik = mk(n, T - 1).requires_grad_()
+    tstd = [0.01] * 4 + [0.02] * 12
+    elbo, stats = ops.elbo(zs, mean, std, zd, lik, tstd, n, T, o, skip)
+    (3.0 * elbo).backward()
+    got = [t.grad.clone() for t in (zs, mean, std, zd, lik)]
+    for t in (zs, mean, std, zd, lik):
+        t.grad = None
+    lp = lambda x, m, s: -0.5 * ((x - m) / s) ** 2 - torch.log(s) - 0.5 * float(np.log(2 * np.pi))
+    logq = lp(zs, mean, std).sum((-2, -1)).flatten()
+    trans = lp(zs[..., 2:], zd, torch.tensor(tstd, device=DEV)).sum((-2, -1)).flatten()
+    ref = torch.mean(trans + lik[:, skip - 1:].reshape(-1) - logq) + torch.mean(lik[:, :skip - 1])
+    (3.0 * ref).backward()
+    assert abs(float(elbo) - float(ref)) < 1e-5 * abs(float(ref))
+    assert abs(float(stats[0]) - float(trans.mean())) < 1e-5 * abs(float(trans.mean()))
+    assert abs(float(stats[1]) - float(logq.mean())) < 1e-5 * abs(float(logq.mean()))
+    for a, t in zip(got, (zs, mean, std, zd, lik)):
+        assert err(a, t.grad) < 1e-5
