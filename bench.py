@@ -158,7 +158,8 @@ def main():
     torch.manual_seed(0)
     model = Stove(cfg).to(dev)
     bucket = ParamArena(model, world)          # parameters / gradients flat; grad buffer == all-reduce bucket
-    opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
+    from stove_amd.optim import FlatAdam
+    opt = FlatAdam(bucket, lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)       # torch.optim.Adam's update as one launch
 
     log('model built; generating data')
     data = make_batch(a.workload, a.batch, a.frames, rank * a.batch)
@@ -173,8 +174,7 @@ def main():
         loss = -elbo
         loss.backward()
         bucket.all_reduce()
-        bucket.clip_grad_norm_(1.0)
-        opt.step()
+        opt.step(max_norm=1.0)                                    # clip_grad_norm_(1) folded into the Adam launch
         return elbo
 
     for i in range(a.warmup):

@@ -210,6 +210,16 @@ int stove_spn_bake_bwd(const float* arena, const StoveSpnArenaPlan* plan, const 
 int stove_arena_gather(const float* arena, const int32_t* src, float* image, int n, void* stream);
 int stove_arena_scatter_add(const float* gimage, const int32_t* src, float* grad_arena, int n, void* stream);
 
+/* out[j] = sum_c parts[c][j] in chunk order (n a multiple of 4): the split-K partials of the weight-gradient GEMMs. */
+int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void* stream);
+
+/* One Adam / AMSGrad step of torch.optim.Adam (weight_decay 0; reference train.py:431-473) over the flat arena, with
+ * clip_grad_norm_(max_norm) folded in: gradients are scaled by min(1, max_norm / (*grad_norm + 1e-6)) on the fly
+ * (grad_norm = device scalar holding the L2 norm of grads, NULL = no clipping).  max_exp_avg_sq NULL = plain Adam.
+ * numel must be a multiple of 4 (the arena pads to 16 bytes); step counts from 1. */
+int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad_norm,
+                    size_t numel, float lr, float beta1, float beta2, float eps, int step, float max_norm, void* stream);
+
 /* ---- gate math of RnnStates' LSTM (encoder.py:43-51, torch.nn.LSTM cell, gate order i,f,g,o); the GEMMs
  * around it stay on rocBLAS.  gx (n,4H): x W_ih^T + b_ih + b_hh; gh (n,4H): h_prev W_hh^T or NULL; c_prev
  * (n,H) or NULL (zero state).  bwd: dh, dc_in (NULL = 0) -> dg (n,4H), dc_out (n,H); dgx_acc (n,4H) gets

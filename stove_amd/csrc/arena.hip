@@ -158,3 +158,52 @@ __global__ void arena_scatter_add_k(const float* __restrict__ gimage, const int*
 }
 
 }  // namespace stove
+
+namespace stove {
+
+// Adam / AMSGrad step of torch.optim.Adam (weight_decay = 0) over the flat arena, with clip_grad_norm_ folded in:
+//   g' = g * min(1, max_norm / (norm + 1e-6))        (norm: device scalar, null = no clipping)
+//   m = b1 m + (1 - b1) g' ; v = b2 v + (1 - b2) g'^2 ; vmax = max(vmax, v)   (vmax null = plain Adam)
+//   p -= (lr / bc1) * m / (sqrt(vmax or v) / sqrt(bc2) + eps)
+struct AdamConst {
+  float lr, b1, b2, eps, bc1, sqrt_bc2, max_norm;
+};
+__global__ void flat_adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            float* __restrict__ vmax, const float* __restrict__ norm, AdamConst k, int n4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float coef = 1.0f;
+  if (norm != nullptr) coef = fminf(1.0f, k.max_norm / (norm[0] + 1e-6f));
+  const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+  float4 p4 = reinterpret_cast<float4*>(p)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+  float4 x4 = vmax != nullptr ? reinterpret_cast<float4*>(vmax)[i] : v4;
+  const float step = k.lr / k.bc1;
+#define STOVE_ADAM1(c)                                           \
+  {                                                              \
+    const float gg = g4.c * coef;                                \
+    m4.c = m4.c + (1.0f - k.b1) * (gg - m4.c);                   \
+    v4.c = k.b2 * v4.c + (1.0f - k.b2) * gg * gg;                \
+    x4.c = vmax != nullptr ? fmaxf(x4.c, v4.c) : v4.c;           \
+    p4.c -= step * m4.c / (sqrtf(x4.c) / k.sqrt_bc2 + k.eps);    \
+  }
+  STOVE_ADAM1(x) STOVE_ADAM1(y) STOVE_ADAM1(z) STOVE_ADAM1(w)
+#undef STOVE_ADAM1
+  reinterpret_cast<float4*>(p)[i] = p4;
+  reinterpret_cast<float4*>(m)[i] = m4;
+  reinterpret_cast<float4*>(v)[i] = v4;
+  if (vmax != nullptr) reinterpret_cast<float4*>(vmax)[i] = x4;
+}
+
+// out[j] = sum_c part[c][j], fixed order; n4 = n / 4 (split-K partials of the batched weight-gradient GEMMs)
+__global__ void sum_chunks4_k(const float* __restrict__ part, float* __restrict__ out, int n4, int chunks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = reinterpret_cast<const float4*>(part)[i];
+  for (int c = 1; c < chunks; ++c) {
+    const float4 b = reinterpret_cast<const float4*>(part)[(size_t)c * n4 + i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = a;
+}
+
+}  // namespace stove

@@ -4,6 +4,7 @@
 
 #include "common.h"
 #include <string.h>
+#include <math.h>
 #include "spn_obj.hip"
 #include "spn_bg.hip"
 #include "scene.hip"
@@ -405,6 +406,30 @@ int stove_arena_gather(const float* arena, const int32_t* src, float* image, int
 int stove_arena_scatter_add(const float* gimage, const int32_t* src, float* grad_arena, int n, void* stream) {
   if (n == 0) return 0;
   STOVE_LAUNCH(arena_scatter_add_k, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gimage, src, grad_arena, n);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void* stream) {
+  if (n == 0) return 0;
+  if (n % 4 != 0 || chunks < 1) return (int)hipErrorInvalidValue;
+  const int n4 = (int)(n / 4);
+  STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, parts, out, n4, chunks);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad_norm,
+                    size_t numel, float lr, float beta1, float beta2, float eps, int step, float max_norm, void* stream) {
+  if (numel == 0) return 0;
+  if (numel % 4 != 0 || step < 1) return (int)hipErrorInvalidValue;
+  AdamConst k;
+  k.lr = lr; k.b1 = beta1; k.b2 = beta2; k.eps = eps; k.max_norm = max_norm;
+  k.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  k.sqrt_bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  const int n4 = (int)(numel / 4);
+  STOVE_LAUNCH(flat_adam_k, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq,
+               grad_norm, k, n4);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

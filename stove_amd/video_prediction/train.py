@@ -20,6 +20,7 @@ from torch import nn
 from torch.utils.data import DataLoader
 
 from ..arena import ParamArena
+from ..optim import FlatAdam
 from ..parallel import GradBucket
 from ..utils.utils import ExperimentLogger
 
@@ -48,6 +49,8 @@ class AbstractTrainer:
         p0 = next(self.stove.parameters())
         if getattr(self.c, 'param_arena', True) and p0.is_cuda and p0.dtype == torch.float32:
             self.bucket = ParamArena(self.stove, self.world_size)
+            # same update rule and state-dict layout as the Adam above, one launch over the flat buffers
+            self.optimizer = FlatAdam(self.bucket, lr=self.c.learning_rate, amsgrad=self.c.debug_amsgrad)
         else:
             self.bucket = GradBucket(self.stove, self.world_size)
         self.epoch_start, self.step_start = 0, 0
@@ -208,12 +211,12 @@ class Trainer(AbstractTrainer):
             min_ll = min_ll + term
         min_ll.backward()
         self.bucket.all_reduce()                     # [amd] one RCCL all-reduce of the flat gradient
-        if self.c.debug_gradient_clip:
-            if isinstance(self.bucket, ParamArena):
-                self.bucket.clip_grad_norm_(1)
-            else:
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.step(max_norm=1 if self.c.debug_gradient_clip else None)      # clipping folded into the step
+        else:
+            if self.c.debug_gradient_clip:
                 torch.nn.utils.clip_grad_norm_(self.stove.parameters(), 1)
-        self.optimizer.step()
+            self.optimizer.step()
         return elbo, prop_dict, rewards, min_ll, mse_rewards
 
     def train(self, num_epochs=None):

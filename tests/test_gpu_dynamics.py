@@ -248,7 +248,7 @@ def test_supair_only_elbo():
             assert abs(float(params[k[3:]].grad.norm()) - float(v)) <= 5e-3 * float(v) + 1e-9, k
 
 
-@pytest.mark.parametrize('arena', [False, True])
+@pytest.mark.parametrize('arena', [False, True, 'flat_adam'])
 def test_three_optimiser_steps_track_the_reference(arena):
     """Adam(amsgrad) + lr schedule + clip_grad_norm_(1) on one batch (reference train.py:431-473, fp32):
     the ELBO sequence and parameter checksums after three steps."""
@@ -258,7 +258,11 @@ def test_three_optimiser_steps_track_the_reference(arena):
     cfg = make_cfg()
     st = fill_analytic(Stove(cfg)).to(DEV)
     ar = ParamArena(st) if arena else None
-    opt = torch.optim.Adam(st.parameters(), lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
+    if arena == 'flat_adam':       # the one-launch Adam + clip over the flat buffers
+        from stove_amd.optim import FlatAdam
+        opt = FlatAdam(ar, lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
+    else:
+        opt = torch.optim.Adam(st.parameters(), lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
     x = t_(g['x']).float().to(DEV)
     for step in range(1, 4):
         lat = t_(g['eps_lat'])[step - 1][..., 0].float()
@@ -274,11 +278,14 @@ def test_three_optimiser_steps_track_the_reference(arena):
             opt.zero_grad()
         elbo, _, _ = st(x, step, None)
         (-elbo).backward()
-        if arena:
+        if arena == 'flat_adam':
+            opt.step(max_norm=1)
+        elif arena:
             ar.clip_grad_norm_(1)
+            opt.step()
         else:
             torch.nn.utils.clip_grad_norm_(st.parameters(), 1)
-        opt.step()
+            opt.step()
         ref = float(g['elbos'][step - 1])
         assert abs(float(elbo.detach()) - ref) < 2e-4 * abs(ref), (step, float(elbo.detach()), ref)
     params = dict(st.named_parameters())
@@ -286,6 +293,15 @@ def test_three_optimiser_steps_track_the_reference(arena):
         if k.startswith('p_'):
             got = float(params[k[2:]].detach().double().sum())
             assert abs(got - float(v)) < 2e-4 * abs(float(v)) + 1e-4, (k, got, float(v))
+    if arena == 'flat_adam':       # checkpoint layout of torch.optim.Adam: state per parameter index, reloadable
+        sd = opt.state_dict()
+        assert set(sd['state'][0]) >= {'step', 'exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'} and float(sd['state'][0]['step']) == 3
+        ref = torch.optim.Adam(st.parameters(), lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
+        ref.load_state_dict(sd)
+        m0 = opt.state[ar.params[5]]['exp_avg'].clone()
+        opt2 = FlatAdam(ar, lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
+        opt2.load_state_dict(sd)
+        assert opt2._steps == 3 and torch.equal(opt2.state[ar.params[5]]['exp_avg'], m0)
 
 
 @pytest.mark.parametrize('mode', ['3_only', 'greedy', 'volatile'])
