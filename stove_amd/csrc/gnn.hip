@@ -431,6 +431,29 @@ template <int OUT, int IN, int SLOT0>
 __device__ __forceinline__ void dW_layer(f32x4* acc, const float* dO, int ldo, const float* In, int ldi, int row_tiles, int wv) {
   constexpr int NT = (OUT / 16) * (IN / 16);
   static_assert(NT % 4 == 0, "tiles per layer must be a multiple of the wave count");
+  if (row_tiles == 1) {
+    // one 16-row block (every node layer; edge layers of small graphs): fetch the operands of ALL the wave's tiles
+    // first, then issue the MFMAs step-major, so consecutive MFMAs hit different accumulators and the LDS latency is
+    // paid once instead of once per tile (the tile-by-tile order made dW of the 256 x 32 edge-first layer cost 2.4k
+    // cycles for 1k cycles of MFMA)
+    const int l = lane_id(), i = l & 15, kq = l >> 4;
+    float a[NT / 4][4], b[NT / 4][4];
+#pragma unroll
+    for (int k = 0; k < NT / 4; ++k) {
+      const int t = wv + 4 * k;
+      const int ot = t / (IN / 16), it = t % (IN / 16);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        a[k][m] = dO[(4 * kq + m) * ldo + ot * 16 + i];
+        b[k][m] = In[(4 * kq + m) * ldi + it * 16 + i];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int k = 0; k < NT / 4; ++k) acc[SLOT0 + k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][m], b[k][m], acc[SLOT0 + k], 0, 0, 0);
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < NT / 4; ++k) {
     const int t = wv + 4 * k;
@@ -608,9 +631,6 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   WG_SYNC();
   gnn_stamp(sh, 28);
   // b8. rel.1 / att.1 weight grads (inputs R1 / A1 still intact)
-  const WFrag<64> eft0 = wfrag_load<64>(WT + W_EF + wv * 64, 256);        // b11's fragments
-  const WFrag<64> eft1 = wfrag_load<64>(WT + W_EF + 16 * 256 + wv * 64, 256);
-  const WFrag<32> s1t = wfrag_load<32>(WT + W_S1 + w01 * 16 * 32, 32);
   dW_layer<32, 64, SL_R1>(acc, L.E32, LDN, L.R1, LDC, sh.ME, wv);
   dW_layer<32, 64, SL_A1>(acc, L.A2, LDN, L.A1, LDC, sh.ME, wv);
   vec_layer<VT_R1, 2>(vacc, L.E32, LDN, L.AUXE, sh.ME, wv);
@@ -632,27 +652,36 @@ __device__ __forceinline__ void gnn_backward(const GnnLds& L, const GnnShape& sh
   WG_SYNC();
   gnn_stamp(sh, 30);
   // b10. first edge layer: scatter (as a gather) into dP, bias / distance-weight grads, d distance
+  const WFrag<64> eft0 = wfrag_load<64>(WT + W_EF + wv * 64, 256);        // b11's fragments
+  const WFrag<64> eft1 = wfrag_load<64>(WT + W_EF + 16 * 256 + wv * 64, 256);
+  const WFrag<32> s1t = wfrag_load<32>(WT + W_S1 + w01 * 16 * 32, 32);
   vec_layer<VT_R0, 4>(vacc, L.R1, LDC, L.AUXE, sh.ME, wv);
   vec_layer<VT_A0, 4>(vacc, L.A1, LDC, L.AUXE, sh.ME, wv);
-  for (int idx = tid; idx < 16 * 256; idx += blockDim.x) {
-    const int r = idx >> 8, c = idx & 255;
-    float v = 0.0f;
-    if (r < sh.NR) {
+  {
+    // dP[r][c] for the real node rows only (thread = column c), padded rows cleared with vector stores
+    const int c = tid, blk = c >> 6, cc = c & 63;
+    const float* src = (blk < 2) ? L.R1 : L.A1;
+    for (int r = 0; r < sh.NR; ++r) {
       const int g0 = L.NG[r], i = L.NI[r];
-      const int blk = c >> 6, cc = c & 63;
-      const float* src = (blk < 2) ? L.R1 : L.A1;
+      float v = 0.0f;
       if (blk & 1) {
         for (int j = 0; j < sh.N; ++j) v += src[((g0 + j) * sh.N + i) * LDC + cc];      // r as the second argument s_j
       } else {
         for (int j = 0; j < sh.N; ++j) v += src[(r * sh.N + j) * LDC + cc];             // r as the first argument s_i
       }
+      L.P[r * LDP + c] = v;
     }
-    L.P[r * LDP + c] = v;
+    for (int q = tid; q < (16 - sh.NR) * 64; q += blockDim.x)
+      *reinterpret_cast<float4*>(L.P + (sh.NR + (q >> 6)) * LDP + (q & 63) * 4) = float4{0.0f, 0.0f, 0.0f, 0.0f};
   }
-  for (int e = wv; e < sh.ME * 16; e += 4) {             // dL/d dist_e: one wave per edge, lanes = channels
-    float v = L.R1[e * LDC + lane] * V[V_WDR + lane] + L.A1[e * LDC + lane] * V[V_WDA + lane];
-    v = wave_sum_lane63(v);
-    if (lane == 63) L.DATT[e] = v;
+  // dL/d dist_e: 16 lanes per edge, 4 channels each, row reduction
+  for (int e0 = 0; e0 < sh.ME * 16; e0 += 16) {
+    const int e = e0 + (tid >> 4), c4 = (tid & 15) * 4;
+    const float4 r1 = *reinterpret_cast<const float4*>(L.R1 + e * LDC + c4), a1 = *reinterpret_cast<const float4*>(L.A1 + e * LDC + c4);
+    const float4 wr = *reinterpret_cast<const float4*>(V + V_WDR + c4), wa = *reinterpret_cast<const float4*>(V + V_WDA + c4);
+    float v = r1.x * wr.x + r1.y * wr.y + r1.z * wr.z + r1.w * wr.w + a1.x * wa.x + a1.y * wa.y + a1.z * wa.z + a1.w * wa.w;
+    v = row_sum_lane15(v);
+    if ((tid & 15) == 15) L.DATT[e] = v;
   }
   WG_SYNC();
   gnn_stamp(sh, 31);
