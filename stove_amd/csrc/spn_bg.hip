@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_fwd_k(
 // ---- root: product (G x G per replica) + root sum over R*G*G, one thread per frame ----------
 template <int R, int G>
 __global__ void bgspn_root_fwd_k(const float* __restrict__ ell_part, const float* __restrict__ wroot,
-                                 float* __restrict__ out, int n_frames) {
+                                 float* __restrict__ out, int n_frames, int halves) {
   constexpr int NO = R * 2 * G;
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_frames) return;
@@ -119,10 +119,9 @@ __global__ void bgspn_root_fwd_k(const float* __restrict__ ell_part, const float
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       float a = 0.0f, b = 0.0f;
-#pragma unroll
-      for (int h = 0; h < kBgHalves; ++h) {
-        a += ell_part[((size_t)f * kBgHalves + h) * NO + (r * 2) * G + g];
-        b += ell_part[((size_t)f * kBgHalves + h) * NO + (r * 2 + 1) * G + g];
+      for (int h = 0; h < halves; ++h) {
+        a += ell_part[((size_t)f * halves + h) * NO + (r * 2) * G + g];
+        b += ell_part[((size_t)f * halves + h) * NO + (r * 2 + 1) * G + g];
       }
       e1[g] = a;
       e2[g] = b;
@@ -159,7 +158,7 @@ __global__ void bgspn_root_fwd_k(const float* __restrict__ ell_part, const float
 template <int R, int G>
 __global__ void bgspn_root_bwd_k(const float* __restrict__ ell_part, const float* __restrict__ wroot,
                                  const float* __restrict__ out, const float* __restrict__ dout,
-                                 float* __restrict__ dell, float* __restrict__ rsc, int n_frames) {
+                                 float* __restrict__ dell, float* __restrict__ rsc, int n_frames, int halves) {
   constexpr int NO = R * 2 * G;
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_frames) return;
@@ -170,10 +169,9 @@ __global__ void bgspn_root_bwd_k(const float* __restrict__ ell_part, const float
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       float a = 0.0f, b = 0.0f;
-#pragma unroll
-      for (int h = 0; h < kBgHalves; ++h) {
-        a += ell_part[((size_t)f * kBgHalves + h) * NO + (r * 2) * G + g];
-        b += ell_part[((size_t)f * kBgHalves + h) * NO + (r * 2 + 1) * G + g];
+      for (int h = 0; h < halves; ++h) {
+        a += ell_part[((size_t)f * halves + h) * NO + (r * 2) * G + g];
+        b += ell_part[((size_t)f * halves + h) * NO + (r * 2 + 1) * G + g];
       }
       e1[g] = a;
       e2[g] = b;
@@ -380,6 +378,10 @@ __global__ __launch_bounds__(256) void bgspn_coef_reduce_k(const float* __restri
   }
 }
 
+}  // namespace stove
+#include "spn_bg_mfma.hip"
+namespace stove {
+
 // =============================================================================================
 constexpr int kBgR = 3, kBgG = 6, kBgNO = kBgR * 2 * kBgG;
 constexpr int kBgRootChunks = 256;
@@ -390,19 +392,48 @@ static inline int bg_grid(int n_frames) {
   return g * kBgHalves;
 }
 
-size_t bgspn_fwd_ws_floats(int n_frames) { return (size_t)n_frames * kBgHalves * kBgNO; }
+// [ell: n * halves * 36][dense coefficient image of the MFMA path (scene mode)]
+size_t bgspn_fwd_ws_floats(int n_frames) { return (size_t)n_frames * kBgHalves * kBgNO + kBgDenseF; }
+static inline float* bg_dense_of(float* ell_part, int n_frames) { return ell_part + (size_t)n_frames * kBgHalves * kBgNO; }
 
 // ell_part must stay alive until the backward (it is the saved activation).
 int bgspn_forward(const float* frames, const float* marg, const float* z, int n_obj, const int* side, const float* coef,
                   const float* wroot, float* ell_part, float* out, int n_frames, hipStream_t st) {
   if (n_frames == 0) return 0;
   const int grid = bg_grid(n_frames);
-  if (z != nullptr)
+  int halves = kBgHalves;
+  if (z != nullptr && n_obj >= 1 && n_obj <= 8) {
+    // scene mode: leaf layer as a GEMM on the matrix cores (spn_bg_mfma.hip); ell is (n, 36), one "half"
+    float* Cf = bg_dense_of(ell_part, n_frames);
+    STOVE_LAUNCH(bg_dense_fwd_k, dim3((kBgDenseF + 255) / 256), dim3(256), 0, st, side, coef, Cf);
+    STOVE_LAUNCH_CHECK();
+    constexpr int TPW = 2;
+    const int waves = n_obj <= 4 ? 4 : 2;                                    // coverage tables: waves * 32 * n_obj * 64 floats of LDS
+    const size_t lds = (size_t)waves * TPW * 16 * (n_obj * 64 + 4) * sizeof(float);
+    const int per_block = waves * TPW * 16;
+    const dim3 grid_m((n_frames + per_block - 1) / per_block), block_m(waves * 64);
+#define STOVE_BG_FWD(NOBJ)                                                                                                        \
+  {                                                                                                                               \
+    int rc = (int)hipFuncSetAttribute((const void*)bgspn_mfma_fwd_k<TPW, NOBJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    if (rc) return rc;                                                                                                            \
+    STOVE_LAUNCH((bgspn_mfma_fwd_k<TPW, NOBJ>), grid_m, block_m, lds, st, frames, z, n_obj, (const float*)Cf, ell_part, n_frames);  \
+  }
+    if (n_obj == 3) STOVE_BG_FWD(3)
+    else if (n_obj == 6) STOVE_BG_FWD(6)
+    else if (n_obj == 2) STOVE_BG_FWD(2)
+    else if (n_obj == 4) STOVE_BG_FWD(4)
+    else STOVE_BG_FWD(0)
+#undef STOVE_BG_FWD
+    STOVE_LAUNCH_CHECK();
+    halves = 1;
+  } else if (z != nullptr) {
     STOVE_LAUNCH((bgspn_fwd_k<kBgR, kBgG, true>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, ell_part, n_frames);
-  else
+    STOVE_LAUNCH_CHECK();
+  } else {
     STOVE_LAUNCH((bgspn_fwd_k<kBgR, kBgG, false>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, ell_part, n_frames);
-  STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH((bgspn_root_fwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, n_frames);
+    STOVE_LAUNCH_CHECK();
+  }
+  STOVE_LAUNCH((bgspn_root_fwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, n_frames, halves);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -451,7 +482,8 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
   float* dz_part = rsc + (size_t)n_frames * kBgR * (1 + 2 * kBgG);
   float* gpart = dz_part + (size_t)n_frames * kBgHalves * 8 * 4;
   float* rpart = gpart + (size_t)grid * kBgR * kBgThreads * kBgG * 3;
-  STOVE_LAUNCH((bgspn_root_bwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, dout, dell, rsc, n_frames);
+  const int halves = (z != nullptr && n_obj >= 1 && n_obj <= 8) ? 1 : kBgHalves;      // as written by bgspn_forward
+  STOVE_LAUNCH((bgspn_root_bwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, dout, dell, rsc, n_frames, halves);
   STOVE_LAUNCH_CHECK();
   const bool scene = z != nullptr;
   int rc;
