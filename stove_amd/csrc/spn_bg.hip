@@ -409,7 +409,7 @@ int bgspn_forward(const float* frames, const float* marg, const float* z, int n_
     STOVE_LAUNCH_CHECK();
     constexpr int TPW = 2;
     const int waves = n_obj <= 4 ? 4 : 2;                                    // coverage tables: waves * 32 * n_obj * 64 floats of LDS
-    const size_t lds = (size_t)waves * TPW * 16 * (n_obj * 64 + 4) * sizeof(float);
+    const size_t lds = (size_t)waves * TPW * 16 * (n_obj * 64 + 4 + n_obj * 4) * sizeof(float);
     const int per_block = waves * TPW * 16;
     const dim3 grid_m((n_frames + per_block - 1) / per_block), block_m(waves * 64);
 #define STOVE_BG_FWD(NOBJ)                                                                                                        \

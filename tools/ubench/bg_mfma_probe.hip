@@ -1,45 +1,20 @@
-// Background SPN leaf layer on the matrix cores (scene mode), gfx950.
-//
-// The leaf log-densities of a frame are 36 masked sums over its 1024 pixels,
-//     ell[f][(r, side, g)] = sum_{p : side_r(p) = side} w_p (a_{r,p,g} x_p^2 + b_{r,p,g} x_p + c_{r,p,g}),
-// i.e. one GEMM   ell (F x 36) = Phi (F x 3072) . C (3072 x 36)   with the per-frame features
-// Phi = [w x^2 | w x | w] and a fixed coefficient matrix C (zero where the pixel is on the other side of the
-// replica's split).  The lane-per-pixel kernel of spn_bg.hip spends its time in 36 cross-lane reductions per
-// frame (144 DPP adds per lane and frame); as a GEMM on v_mfma_f32_16x16x4_f32 (exact fp32) the reductions
-// are the matrix cores' contraction and the kernel is bounded by 2 304 MFMAs per 16 frames.
-// The occlusion weight w comes from the closed-form separable box coverage (cover_x(col) cover_y(row), see
-// spn_bg.hip): the 64 coverage values per (frame, object) are tabulated once per tile in LDS, so a pixel's
-// weight costs n_obj multiply-adds instead of 2 n_obj coverage evaluations.
-#include "common.h"
-
+// Probe: where does bgspn_mfma_fwd_k spend its time?  Variants of the kernel with one ingredient removed.
+#include "../../stove_amd/csrc/common.h"
 namespace stove {
-
-constexpr int kBgNC = 48;                                   // 36 leaf outputs padded to three 16-column tiles
-constexpr int kBgDenseF = 3 * 3 * 64 * 4 * 16 * 4;          // forward image floats: [feat][tile][kb][kq][j][m]
+constexpr int kBgPix = 1024, kBgSide = 32;
+constexpr int kBgDenseF = 3 * 3 * 64 * 4 * 16 * 4;
 typedef float bgf4 __attribute__((ext_vector_type(4)));
-
-// Cf[feat][t][kb][kq][j][m] = C[(pixel 16 kb + 4 kq + m, feat)][col 16 t + j]: the B fragment of MFMA m of pixel
-// block kb is one coalesced float4 per lane (lane = (j, kq)); the K order inside a block is the same permutation
-// on both operands (slot kq of MFMA m <-> pixel 4 kq + m).
-__global__ void bg_dense_fwd_k(const int* __restrict__ side, const float* __restrict__ coef, float* __restrict__ Cf) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= kBgDenseF) return;
-  const int m = idx & 3, j = (idx >> 2) & 15, kq = (idx >> 6) & 3, kb = (idx >> 8) & 63, t = (idx >> 14) % 3, feat = idx / (3 << 14);
-  const int p = 16 * kb + 4 * kq + m, col = 16 * t + j;
-  float v = 0.0f;
-  if (col < 36) {
-    const int r = col / 12, sd = (col / 6) & 1, g = col % 6;
-    if ((side[r * kBgPix + p] != 0) == (sd != 0)) v = coef[((size_t)(r * kBgPix + p) * 6 + g) * 3 + feat];
-  }
-  Cf[idx] = v;
+struct BoxGeom { float inv_sx, inv_sy, off_x, off_y; };
+__device__ __forceinline__ BoxGeom box_geom(const float* z) { BoxGeom g; g.inv_sx = 1.0f / z[0]; g.inv_sy = 1.0f / z[1]; g.off_x = -z[2] / z[0]; g.off_y = -z[3] / z[1]; return g; }
+__device__ __forceinline__ float inv_coord(float inv_s, float off, int idx) {
+  const float u = (2.0f * idx + 1.0f) * (1.0f / kBgSide) - 1.0f;
+  const float gq = fmaf(inv_s, u, off);
+  return ((gq + 1.0f) * kBgSide - 1.0f) * 0.5f;
 }
-
-// One wave = TPW tiles of 16 frames; per 16-pixel block: 9 B fragments (3 features x 3 column tiles) shared by the
-// wave's tiles, 36 MFMAs per tile.  ell (F, 36).  Dynamic LDS: waves * TPW * 16 * n_obj * 64 floats of coverage tables.
 // NOBJ > 0: compile-time object count (the per-object loop unrolls and the whole pixel block becomes one basic block,
 // so the scheduler overlaps one tile's mask / feature VALU work with the other tile's MFMAs); NOBJ = 0: runtime n_obj.
-template <int TPW, int NOBJ>
-__global__ __launch_bounds__(256) void bgspn_mfma_fwd_k(const float* __restrict__ frames, const float* __restrict__ z, int n_obj_rt,
+template <int TPW, int NOBJ, int MODE>
+__global__ __launch_bounds__(256) void probe_k(const float* __restrict__ frames, const float* __restrict__ z, int n_obj_rt,
                                                        const float* __restrict__ Cf, float* __restrict__ ell, int F) {
   const int n_obj = NOBJ > 0 ? NOBJ : n_obj_rt;
   extern __shared__ __attribute__((aligned(16))) float bg_lds[];
@@ -62,8 +37,7 @@ __global__ __launch_bounds__(256) void bgspn_mfma_fwd_k(const float* __restrict_
     }
     *reinterpret_cast<float4*>(geo + q * 4) = g4;
   }
-#pragma unroll 4
-  for (int idx = lane; idx < TPW * 16 * n_obj * 64; idx += 64) {      // unrolled: four independent coverage chains in flight
+  for (int idx = lane; idx < TPW * 16 * n_obj * 64; idx += 64) {
     const int c = idx & 63, q = idx >> 6, k = q % n_obj, fr = q / n_obj;
     float v = 0.0f;
     if (f0 + fr < F) {
@@ -97,19 +71,7 @@ __global__ __launch_bounds__(256) void bgspn_mfma_fwd_k(const float* __restrict_
 #pragma unroll
     for (int u = 0; u < GRP; ++u) xc[u][tl] = *reinterpret_cast<const float4*>(fptr[tl] + 16 * ((kofs + u) & 63));
   }
-  // a lane only ever touches columns 4 kq .. 4 kq + 3 of the two 16-column halves of a row: its x-coverage values are
-  // loop invariants (kept in registers when the object count is a compile-time constant)
-  constexpr int NK = NOBJ > 0 ? NOBJ : 1;
-  float4 cxr[TPW][2][NK];
-  if (NOBJ > 0) {
-#pragma unroll
-    for (int tl = 0; tl < TPW; ++tl)
-#pragma unroll
-      for (int hp = 0; hp < 2; ++hp)
-#pragma unroll
-        for (int k = 0; k < NK; ++k) cxr[tl][hp][k] = *reinterpret_cast<const float4*>(tab + (tl * 16 + i) * fstride + k * 64 + 16 * hp + 4 * kq);
-  }
-  for (int kg = 0; kg < 64; kg += GRP) {
+  for (int kg = 0; kg < (MODE == 4 ? 0 : 64); kg += GRP) {
     if (kg + GRP < 64) {
 #pragma unroll
       for (int u = 0; u < GRP; ++u)
@@ -121,19 +83,19 @@ __global__ __launch_bounds__(256) void bgspn_mfma_fwd_k(const float* __restrict_
       const int kb = (kofs + kg + u) & 63;
       if (kg + u + 1 < 64) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) bn[q] = Cq[(size_t)(q * 64 + ((kb + 1) & 63)) * 64];
+        for (int q = 0; q < 9; ++q) bn[q] = (MODE == 3) ? bq[q] : Cq[(size_t)(q * 64 + ((kb + 1) & 63)) * 64];
       }
       const int row = kb >> 1, c0 = 16 * (kb & 1) + 4 * kq;
 #pragma unroll
       for (int tl = 0; tl < TPW; ++tl) {
         const int fr = tl * 16 + i, f = f0 + fr;
-        const float4 x = xc[u][tl];
+        const float4 x = (MODE == 2) ? float4{0.5f, 0.25f, 0.125f, 0.75f} : xc[u][tl];
         float4 run = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < n_obj; ++k) {
+        for (int k = 0; k < (MODE == 2 ? 0 : n_obj); ++k) {
           const float* tk = tab + fr * fstride + k * 64;
           const float cy = tk[32 + row];
-          const float4 cx = (NOBJ > 0) ? cxr[tl][u & 1][k < NK ? k : 0] : *reinterpret_cast<const float4*>(tk + c0);
+          const float4 cx = *reinterpret_cast<const float4*>(tk + c0);
           run.x = fmaf(cx.x, cy, run.x);
           run.y = fmaf(cx.y, cy, run.y);
           run.z = fmaf(cx.z, cy, run.z);
@@ -148,9 +110,13 @@ __global__ __launch_bounds__(256) void bgspn_mfma_fwd_k(const float* __restrict_
           const float wx = wm * xs[m], wxx = wx * xs[m];
 #pragma unroll
           for (int t = 0; t < 3; ++t) {
-            acc[tl][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxx, bq[0 * 3 + t][m], acc[tl][t], 0, 0, 0);
-            acc[tl][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx, bq[1 * 3 + t][m], acc[tl][t], 0, 0, 0);
-            acc[tl][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm, bq[2 * 3 + t][m], acc[tl][t], 0, 0, 0);
+            if (MODE == 1) {
+              acc[tl][t][0] += wxx * bq[0 * 3 + t][m] + wx * bq[1 * 3 + t][m] + wm * bq[2 * 3 + t][m];
+            } else {
+              acc[tl][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxx, bq[0 * 3 + t][m], acc[tl][t], 0, 0, 0);
+              acc[tl][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx, bq[1 * 3 + t][m], acc[tl][t], 0, 0, 0);
+              acc[tl][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm, bq[2 * 3 + t][m], acc[tl][t], 0, 0, 0);
+            }
           }
         }
       }
@@ -174,3 +140,35 @@ __global__ __launch_bounds__(256) void bgspn_mfma_fwd_k(const float* __restrict_
 }
 
 }  // namespace stove
+#include <stdio.h>
+using namespace stove;
+template <int MODE> float run(const float* frames, const float* z, const float* Cf, float* ell, int F) {
+  const int waves = 4, TPW = 2, n_obj = 3;
+  const size_t lds = (size_t)waves * TPW * 16 * (n_obj * 64 + 4 + n_obj * 4) * sizeof(float);
+  hipFuncSetAttribute((const void*)probe_k<2, 3, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const int per_block = waves * TPW * 16;
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  float best = 1e9;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipEventRecord(a, 0);
+    hipLaunchKernelGGL((probe_k<2, 3, MODE>), dim3((F + per_block - 1) / per_block), dim3(256), lds, 0, frames, z, n_obj, Cf, ell, F);
+    hipEventRecord(b, 0); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+  }
+  return best;
+}
+int main() {
+  const int F = 25344;
+  float *frames, *z, *Cf, *ell;
+  hipMalloc(&frames, (size_t)F * 1024 * 4); hipMalloc(&z, (size_t)F * 3 * 4 * 4); hipMalloc(&Cf, kBgDenseF * 4); hipMalloc(&ell, (size_t)F * 36 * 4);
+  hipMemset(frames, 0, (size_t)F * 1024 * 4); hipMemset(Cf, 0, kBgDenseF * 4);
+  float* hz = (float*)malloc((size_t)F * 12 * 4);
+  for (int i = 0; i < F * 3; ++i) { hz[i * 4] = 0.2f; hz[i * 4 + 1] = 0.2f; hz[i * 4 + 2] = 0.1f * (i % 7) - 0.3f; hz[i * 4 + 3] = 0.05f * (i % 11) - 0.2f; }
+  hipMemcpy(z, hz, (size_t)F * 12 * 4, hipMemcpyHostToDevice);
+  printf("full            %.3f ms\n", run<0>(frames, z, Cf, ell, F));
+  printf("no MFMA         %.3f ms\n", run<1>(frames, z, Cf, ell, F));
+  printf("no frames/mask  %.3f ms\n", run<2>(frames, z, Cf, ell, F));
+  printf("no B loads      %.3f ms\n", run<3>(frames, z, Cf, ell, F));
+  printf("tables only     %.3f ms\n", run<4>(frames, z, Cf, ell, F));
+  return 0;
+}
