@@ -183,7 +183,7 @@ static SceneWs scene_ws_layout(int nf, int n_obj) {
   s.dz_bg = s.dzc + align64(np * nmax_of(n_obj) * 4);
   s.obj = s.dz_bg + align64(np * 4);
   s.bg = s.obj + align64(objspn_bwd_ws_floats((int)np));
-  s.total = s.bg + align64(bgspn_bwd_ws_floats(nf));
+  s.total = s.bg + align64(bgspn_bwd_ws_floats(nf, n_obj));
   return s;
 }
 

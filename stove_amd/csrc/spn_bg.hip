@@ -227,6 +227,26 @@ __global__ void bgspn_rootgrad_k(const float* __restrict__ rsc, float* __restric
   part[(size_t)c * R * G * G + k] = acc;
 }
 
+// ---- per (frame, object) box coverage tables for the scene backward -----------------------------------------
+// T[(f * n_obj + k) * kBgTab + ..] = [cover_x(col) 32 | d cover_x 32 | cover_y(row) 32 | d cover_y 32 | 1/sx, 1/sy, x, y]
+// Every pixel lane of bgspn_bwd_k needs these for all objects of every frame; evaluated in place they cost four IEEE
+// divisions and two coverage evaluations per (pixel, frame, object) -- 40 % of that kernel's instructions.
+constexpr int kBgTab = 132;
+__global__ void bg_cover_tables_k(const float* __restrict__ z, float* __restrict__ T, int n_pairs) {
+  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (q >= n_pairs) return;
+  const int c = threadIdx.x & 63;
+  const float* zk = z + (size_t)q * 4;
+  const BoxGeom bg = box_geom(zk);
+  float dq;
+  const float v = (c < 32) ? cover(inv_coord(bg.inv_sx, bg.off_x, c), kBgSide, &dq) : cover(inv_coord(bg.inv_sy, bg.off_y, c - 32), kBgSide, &dq);
+  float* t = T + (size_t)q * kBgTab;
+  const int o = (c < 32) ? c : 64 + (c - 32);
+  t[o] = v;
+  t[o + 32] = dq;
+  if (c < 4) t[128 + c] = (c == 0) ? bg.inv_sx : (c == 1) ? bg.inv_sy : zk[c];
+}
+
 // ---- backward main: per-pixel dL/dw (-> marg or z) and leaf coefficient grads ----------------
 // SCENE: dz_part[frame][half][n_obj][4] (dsx, dsy, dx, dy of the pasted boxes)
 // else : d_marg[frame][p] (and d_inputs if non-null)
@@ -236,7 +256,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
     const float* __restrict__ frames, const float* __restrict__ marg, const float* __restrict__ z, int n_obj,
     const int* __restrict__ side, const float* __restrict__ coef, const float* __restrict__ dell,
     float* __restrict__ d_inputs, float* __restrict__ d_marg, float* __restrict__ dz_part,
-    float* __restrict__ gcoef_part, int n_frames) {
+    float* __restrict__ gcoef_part, int n_frames, const float* __restrict__ T) {
   constexpr int NO = R * 2 * G;
   constexpr int NW = kBgThreads / 64;
   __shared__ float zred[2][NW * 4][NMAX * 4];
@@ -269,9 +289,11 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
 #pragma unroll
       for (int k = 0; k < NMAX; ++k) {
         if (k < n_obj) {
-          const BoxGeom bg = box_geom(z + ((size_t)f * n_obj + k) * 4);
-          fx[k] = cover(inv_coord(bg.inv_sx, bg.off_x, col), kBgSide, &dfx[k]);
-          fy[k] = cover(inv_coord(bg.inv_sy, bg.off_y, row), kBgSide, &dfy[k]);
+          const float* tk = T + ((size_t)f * n_obj + k) * kBgTab;
+          fx[k] = tk[col];
+          dfx[k] = tk[32 + col];
+          fy[k] = tk[64 + row];
+          dfy[k] = tk[96 + row];
           run += fx[k] * fy[k];
           if (run > 1.0f) {
             run = 1.0f;
@@ -311,8 +333,9 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
 #pragma unroll
       for (int k = 0; k < NMAX; ++k) {
         if (k < n_obj) {
-          const float* zk = z + ((size_t)f * n_obj + k) * 4;
-          const float isx = 1.0f / zk[0], isy = 1.0f / zk[1];
+          const float* gk = T + ((size_t)f * n_obj + k) * kBgTab + 128;       // 1/sx, 1/sy, x, y
+          const float isx = gk[0], isy = gk[1];
+          const float zk[4] = {0.0f, 0.0f, gk[2], gk[3]};
           const float u = (2.0f * col + 1.0f) * (1.0f / kBgSide) - 1.0f;
           const float v = (2.0f * row + 1.0f) * (1.0f / kBgSide) - 1.0f;
           // q = ((u - x)/sx + 1) * 16 - 0.5
@@ -438,20 +461,20 @@ int bgspn_forward(const float* frames, const float* marg, const float* z, int n_
   return 0;
 }
 
-size_t bgspn_bwd_ws_floats(int n_frames) {
+size_t bgspn_bwd_ws_floats(int n_frames, int n_obj = 0) {
   const size_t grid = bg_grid(n_frames);
   return (size_t)n_frames * (kBgNO + kBgR * (1 + 2 * kBgG)) + (size_t)n_frames * kBgHalves * 8 * 4 +
-         grid * kBgR * kBgThreads * kBgG * 3 + (size_t)kBgRootChunks * kBgR * kBgG * kBgG;
+         grid * kBgR * kBgThreads * kBgG * 3 + (size_t)kBgRootChunks * kBgR * kBgG * kBgG + (size_t)n_frames * n_obj * kBgTab;
 }
 
 template <int NMAX>
 static int bg_bwd_launch(bool scene, int grid, hipStream_t st, const float* frames, const float* marg, const float* z,
                          int n_obj, const int* side, const float* coef, const float* dell, float* d_inputs,
-                         float* d_marg, float* dz_part, float* gpart, int n_frames) {
+                         float* d_marg, float* dz_part, float* gpart, int n_frames, const float* T) {
   if (scene)
-    STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, true, NMAX>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
+    STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, true, NMAX>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T);
   else
-    STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, false, 1>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
+    STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, false, 1>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -482,17 +505,23 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
   float* dz_part = rsc + (size_t)n_frames * kBgR * (1 + 2 * kBgG);
   float* gpart = dz_part + (size_t)n_frames * kBgHalves * 8 * 4;
   float* rpart = gpart + (size_t)grid * kBgR * kBgThreads * kBgG * 3;
+  float* T = rpart + (size_t)kBgRootChunks * kBgR * kBgG * kBgG;            // scene mode only (ws sized with n_obj)
   const int halves = (z != nullptr && n_obj >= 1 && n_obj <= 8) ? 1 : kBgHalves;      // as written by bgspn_forward
   STOVE_LAUNCH((bgspn_root_bwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, dout, dell, rsc, n_frames, halves);
   STOVE_LAUNCH_CHECK();
   const bool scene = z != nullptr;
+  if (scene) {
+    const int pairs = n_frames * n_obj;
+    STOVE_LAUNCH(bg_cover_tables_k, dim3((pairs + 3) / 4), dim3(256), 0, st, z, T, pairs);
+    STOVE_LAUNCH_CHECK();
+  }
   int rc;
   if (!scene || n_obj <= 3)
-    rc = bg_bwd_launch<3>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
+    rc = bg_bwd_launch<3>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T);
   else if (n_obj <= 6)
-    rc = bg_bwd_launch<6>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
+    rc = bg_bwd_launch<6>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T);
   else
-    rc = bg_bwd_launch<8>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames);
+    rc = bg_bwd_launch<8>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T);
   if (rc) return rc;
   if (scene) {
     const int n = n_frames * n_obj * 4;
