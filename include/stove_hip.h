@@ -213,6 +213,14 @@ int stove_arena_scatter_add(const float* gimage, const int32_t* src, float* grad
 /* out[j] = sum_c parts[c][j] in chunk order (n a multiple of 4): the split-K partials of the weight-gradient GEMMs. */
 int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void* stream);
 
+/* bw_transform (reference utils.py): x (n_frames, channels, pixels) -> out (n_frames, pixels) = clamp(sum over channels, 0, 1). */
+int stove_bw_transform(const float* x, float* out, int n_frames, int channels, int pixels, void* stream);
+
+/* out[c] = sum_r a[r][c] of a row-major (rows, cols) matrix, cols a multiple of 4 or <= 64 (bias gradients of the
+ * recognition network: 25 600 x 1024, 76 800 x 50, 76 800 x 8); ws: stove_colsum_ws_floats(rows, cols) floats.  Fixed summation order. */
+size_t stove_colsum_ws_floats(int rows, int cols);
+int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void* stream);
+
 /* One Adam / AMSGrad step of torch.optim.Adam (weight_decay 0; reference train.py:431-473) over the flat arena, with
  * clip_grad_norm_(max_norm) folded in: gradients are scaled by min(1, max_norm / (*grad_norm + 1e-6)) on the fly
  * (grad_norm = device scalar holding the L2 norm of grads, NULL = no clipping).  max_exp_avg_sq NULL = plain Adam.

@@ -419,6 +419,44 @@ int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void*
   return 0;
 }
 
+int stove_bw_transform(const float* x, float* out, int n_frames, int channels, int pixels, void* stream) {
+  if (n_frames == 0) return 0;
+  if (pixels % 4 != 0 || channels < 1) return (int)hipErrorInvalidValue;
+  const long long total = (long long)n_frames * (pixels / 4);
+  if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  STOVE_LAUNCH(bw_transform_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, n_frames, channels, pixels / 4);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t stove_colsum_ws_floats(int rows, int cols) {
+  const int chunks = rows < 512 ? (rows < 1 ? 1 : rows) : 512;
+  return (size_t)chunks * cols;
+}
+
+int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (cols <= 0 || (cols % 4 != 0 && cols > 64)) return (int)hipErrorInvalidValue;
+  if (rows == 0) {
+    hipMemsetAsync(out, 0, sizeof(float) * cols, st);
+    return 0;
+  }
+  const int chunks = rows < 512 ? rows : 512;
+  const int per = (rows + chunks - 1) / chunks;
+  const int used = (rows + per - 1) / per;
+  if (cols <= 64) {
+    int cpad = 1;
+    while (cpad < cols) cpad <<= 1;
+    STOVE_LAUNCH(colsum_narrow_part_k, dim3(used), dim3(256), 0, st, a, ws, rows, cols, cpad, per);
+  } else {
+    STOVE_LAUNCH(colsum_part_k, dim3(used, (cols / 4 + 255) / 256), dim3(256), 0, st, a, ws, rows, cols / 4, per);
+  }
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, (const float*)ws, out, cols, used, 0);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
 int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad_norm,
                     size_t numel, float lr, float beta1, float beta2, float eps, int step, float max_norm, void* stream) {
   if (numel == 0) return 0;

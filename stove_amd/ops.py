@@ -500,6 +500,57 @@ def elbo(zs, mean, std, zdyn, lik, trans_std, n, T, o, skip):
     return _ElboFn.apply(zs, mean, std, zdyn, lik, tuple(float(v) for v in trans_std), int(n), int(T), int(o), int(skip))
 
 
+@torch.no_grad()
+def bw_transform(x):
+    """(n, T, C, w, h) frames -> (n, T, 1, w, h): channel sum clamped to [0, 1], one pass (reads 3 channels once)."""
+    lib = _lib.load()
+    x = _f32(x)
+    n, T, C, w, h = x.shape
+    with torch.cuda.device(x.device):
+        out = torch.empty(n, T, 1, w, h, dtype=torch.float32, device=x.device)
+        check(lib.stove_bw_transform(ptr(x), ptr(out), n * T, C, w * h, stream()), 'stove_bw_transform')
+    return out
+
+
+def colsum(a):
+    """a.sum(0) of a contiguous (rows, cols) fp32 matrix (cols % 4 == 0) at HBM speed, fixed order."""
+    lib = _lib.load()
+    rows, cols = a.shape
+    if cols % 4 != 0 and cols > 64:
+        return a.sum(0)
+    with torch.cuda.device(a.device):
+        out = torch.empty(cols, dtype=torch.float32, device=a.device)
+        ws = torch.empty(lib.stove_colsum_ws_floats(rows, cols) + 1, dtype=torch.float32, device=a.device)
+        check(lib.stove_colsum(ptr(a), ptr(out), ptr(ws), rows, cols, stream()), 'stove_colsum')
+    return out
+
+
+class _LinearFn(torch.autograd.Function):
+    """torch.nn.functional.linear on a 2-D fp32 input with the bias gradient as a chunked column sum: ATen reduces the
+    (76 800, 50) head gradients of the recognition network at 0.07 TB/s (226 us per step), csrc/arena.hip takes ~10 us."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.mm(g, weight) if ctx.needs_input_grad[0] else None
+        gw = torch.mm(g.t(), x) if ctx.needs_input_grad[1] else None
+        gb = colsum(g) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def linear(x, weight, bias):
+    """F.linear for (..., in) fp32 GPU inputs with a fast bias gradient."""
+    shape = x.shape
+    out = _LinearFn.apply(_f32(x.reshape(-1, shape[-1])), weight, bias)
+    return out.view(*shape[:-1], weight.shape[0])
+
+
 def _splitk_tn(a, b):
     """a^T @ b for tall a (K, M), b (K, N) with K >> M, N (weight gradients over all frames).
 
@@ -578,7 +629,7 @@ class _EncoderLstmFn(torch.autograd.Function):
             if d_whh is None:
                 d_whh = torch.zeros_like(w_hh)
             d_wih = _splitk_tn(dgx, x)
-            d_b = dgx.sum(0)
+            d_b = colsum(dgx)
         dx = torch.mm(dgx, w_ih) if ctx.needs_input_grad[0] else None
         return dx, d_wih, d_whh, d_b, d_b, None
 

@@ -13,6 +13,9 @@ import torch
 
 def bw_transform(x):
     """(n, T, 3, w, h) one-ball-per-channel frames -> (n, T, 1, w, h): channel sum clamped to [0, 1]."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and (x.shape[-1] * x.shape[-2]) % 4 == 0 and not x.requires_grad:
+        from .. import ops
+        return ops.bw_transform(x)               # one fused pass on the GPU (the training input path)
     return torch.clamp(x.sum(2), 0, 1).unsqueeze(2)
 
 

@@ -33,4 +33,5 @@ class RnnStates(nn.Module):
         x = frames.flatten(start_dim=1)
         rnn = self.rnn
         hs = ops.encoder_lstm(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, self.c.num_obj)
-        return self.fc2(torch.sigmoid(self.fc1(hs)))
+        fc1, fc2 = self.fc1, self.fc2
+        return ops.linear(torch.sigmoid(ops.linear(hs, fc1.weight, fc1.bias)), fc2.weight, fc2.bias)
