@@ -164,7 +164,7 @@ def main():
     log('model built; generating data')
     data = make_batch(a.workload, a.batch, a.frames, rank * a.batch)
     log('data ready')
-    x = torch.from_numpy(data['X']).to(dev)
+    x = torch.from_numpy(data['X']).to(dev).contiguous()       # a batch as the DataLoader collates it (contiguous n,T,C,w,h)
     actions = torch.from_numpy(data['action']).float().to(dev) if 'action' in data else None
     torch.manual_seed(1234 + rank)
 

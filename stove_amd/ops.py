@@ -539,7 +539,7 @@ class _LinearFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
         gx = torch.mm(g, weight) if ctx.needs_input_grad[0] else None
-        gw = torch.mm(g.t(), x) if ctx.needs_input_grad[1] else None
+        gw = _splitk_tn(g, x) if ctx.needs_input_grad[1] else None          # (out, in) = g^T x over all rows: split-K
         gb = colsum(g) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
 

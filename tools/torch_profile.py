@@ -16,7 +16,7 @@ bucket = ParamArena(model, 1)
 from stove_amd.optim import FlatAdam
 opt = FlatAdam(bucket, lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
 data = bench.make_batch(workload, 256, 100, 0)
-x = torch.from_numpy(data['X']).to(dev)
+x = torch.from_numpy(data['X']).to(dev).contiguous()
 actions = torch.from_numpy(data['action']).float().to(dev) if 'action' in data else None
 
 def step(i):
