@@ -37,8 +37,8 @@ def parse():
     p.add_argument('--frames', type=int, default=100, help='T, frames per sequence')
     p.add_argument('--workload', default='billiards', choices=['billiards', 'multibilliards', 'gravity', 'avoidance'])
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-batch', type=int, default=8)
-    p.add_argument('--cpu-iters', type=int, default=3)
+    p.add_argument('--cpu-batch', type=int, default=32)
+    p.add_argument('--cpu-iters', type=int, default=8)
     p.add_argument('--profile-steps', type=int, default=3)
     return p.parse_args()
 
