@@ -304,8 +304,20 @@ __global__ __launch_bounds__(128) void objspn_coefgrad_k(
     const float* __restrict__ xw, const float* __restrict__ Dscr, const int* __restrict__ scope,
     float* __restrict__ part, int n_batches, int n_chunks) {
   constexpr int D = 4 * S;
-  const int r = blockIdx.x % R;
-  const int c = blockIdx.x / R;
+  // XCD-aware block -> (replica, chunk) map.  The R replica blocks of a chunk read the same (x, w) tiles; consecutive
+  // block ids go round-robin over the 8 XCDs (each with its own L2), so with the plain map r = id % R every tile was
+  // fetched from HBM once per replica (880 MB per launch for 134 MB of input, rocprofv3 FETCH_SIZE, at the HBM
+  // roofline).  With chunks a multiple of 8, blocks id, id + 8, ..., id + 8 (R - 1) -- same XCD, dispatched together
+  // -- are the R replicas of one chunk, and five of the six reads hit that XCD's L2.
+  int r, c;
+  if (n_chunks % 8 == 0) {
+    const int grp = blockIdx.x / (8 * R), in = blockIdx.x % (8 * R);
+    c = grp * 8 + (in & 7);
+    r = in >> 3;
+  } else {
+    r = blockIdx.x % R;
+    c = blockIdx.x / R;
+  }
   const int t = threadIdx.x;
   if (t >= D) return;
   const int L = t / S;
