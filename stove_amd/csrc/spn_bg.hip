@@ -410,7 +410,7 @@ constexpr int kBgR = 3, kBgG = 6, kBgNO = kBgR * 2 * kBgG;
 constexpr int kBgRootChunks = 256;
 
 static inline int bg_grid(int n_frames) {
-  int g = n_frames < 512 ? n_frames : 512;
+  int g = n_frames < 256 ? n_frames : 256;
   if (g < 1) g = 1;
   return g * kBgHalves;
 }
