@@ -135,6 +135,7 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
                       float* act, int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
                       void* stream);
 size_t stove_dynloop_bwd_ws_bytes(int B, int N);
+size_t stove_dynloop_bwd_ws_bytes_ts(int B, int Ts, int N);   /* the one to use: the small-graph backward streams per-step gradients through ws */
 /* upstream gradients dz,dzdyn,dmean,dstd,dpred may each be NULL. */
 int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                       const float* params, const float* z, const float* act, const float* dz, const float* dzdyn,

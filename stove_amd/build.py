@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libstove_hip.so')
 SOURCES = ['capi.hip']
-DEPS = ['capi.hip', 'common.h', 'spn_obj.hip', 'spn_bg.hip', 'spn_bg_mfma.hip', 'scene.hip', 'gnn.hip', 'match.hip', 'gnn_small.hip', 'lstm.hip', 'arena.hip', 'state.hip',
+DEPS = ['capi.hip', 'common.h', 'spn_obj.hip', 'spn_bg.hip', 'spn_bg_mfma.hip', 'scene.hip', 'gnn.hip', 'match.hip', 'gnn_small.hip', 'gnn_small_bwd.hip', 'lstm.hip', 'arena.hip', 'state.hip',
         os.path.join('..', '..', 'include', 'stove_hip.h')]
 
 

@@ -4,6 +4,7 @@
 
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 #include <math.h>
 #include "spn_obj.hip"
 #include "spn_bg.hip"
@@ -11,6 +12,7 @@
 #include "gnn.hip"
 #include "match.hip"
 #include "gnn_small.hip"
+#include "gnn_small_bwd.hip"
 #include "lstm.hip"
 #include "arena.hip"
 #include "state.hip"
@@ -289,9 +291,24 @@ int stove_gnn_debug_stamps(const float* s_in, const float* params, const float* 
 static long long* g_sm_stamps = nullptr;
 void stove_debug_set_stamps(long long* device_buffer) { g_sm_stamps = device_buffer; }
 
+// STOVE_SMALL_BWD=0 keeps the MFMA backward of gnn.hip for small graphs too (A/B switch of the small-graph backward)
+static int small_bwd_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("STOVE_SMALL_BWD");
+    v = (e != nullptr && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 size_t stove_dynloop_act_floats(int B, int Ts, int N) {
   const int g = gnn_group_for(B, N);
-  return (size_t)stove_gnn_blocks(B, N) * Ts * gnn_act_floats(N, g);
+  const size_t blockwise = (size_t)stove_gnn_blocks(B, N) * Ts * gnn_act_floats(N, g);
+  if (N >= 2 && N <= 4) {
+    const size_t streams = (size_t)B * sm_act2_floats(N, Ts);
+    return streams > blockwise ? streams : blockwise;
+  }
+  return blockwise;
 }
 
 int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
@@ -307,10 +324,10 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
     if (rc) return rc;
     if (act != nullptr) {
       STOVE_LAUNCH(dyn_loop_fwd_small_k<true>, dim3(B), dim3(256), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
-                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps);
+                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps, small_bwd_enabled());
     } else {
       STOVE_LAUNCH(dyn_loop_fwd_small_k<false>, dim3(B), dim3(256), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
-                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps);
+                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps, 0);
     }
     STOVE_LAUNCH_CHECK();
     return 0;
@@ -325,6 +342,15 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
 
 size_t stove_dynloop_bwd_ws_bytes(int B, int N) { return stove_gnn_bwd_ws_bytes(B, N); }
 
+static bool small_bwd_path(int N, const float* act) { return N >= 2 && N <= 4 && act != nullptr && small_bwd_enabled(); }
+
+// workspace of stove_dynloop_bwd for Ts steps: per-workgroup partial weight gradients, plus (small-graph path) the dY streams
+size_t stove_dynloop_bwd_ws_bytes_ts(int B, int Ts, int N) {
+  size_t f = stove_gnn_bwd_ws_bytes(B, N) / sizeof(float);
+  if (N >= 2 && N <= 4 && small_bwd_enabled()) f = (size_t)B * kGnnGrads + (size_t)B * sm_dy_floats(N, Ts);
+  return f * sizeof(float);
+}
+
 int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                       const float* params, const float* z, const float* act, const float* dz, const float* dzdyn, const float* dmean,
                       const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd, float* dextra,
@@ -334,9 +360,27 @@ int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, co
   if (B == 0 || Ts == 0) return (int)hipErrorInvalidValue;
   if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && (extra == nullptr || dextra == nullptr)))
     return (int)hipErrorInvalidValue;
+  LoopConst kc{pos_var, vel_std, lat_std};
+  if (small_bwd_path(N, act)) {
+    // small graphs: T-serial data-gradient chain (gnn_small_bwd.hip), then the weight gradients as a throughput pass
+    float* gpart = (float*)ws;
+    float* dy = gpart + (size_t)B * kGnnGrads;
+    int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_bwd_small_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(kSmBLdsFloats * sizeof(float)));
+    if (rc) return rc;
+    STOVE_LAUNCH(dyn_loop_bwd_small_k, dim3(B), dim3(256), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, params,
+                 const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim, lim_enc, elu, kc);
+    STOVE_LAUNCH_CHECK();
+    rc = (int)hipFuncSetAttribute((const void*)gnn_dw_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDwLdsFloats * sizeof(float)));
+    if (rc) return rc;
+    STOVE_LAUNCH(gnn_dw_small_k, dim3(B), dim3(256), kDwLdsFloats * sizeof(float), st, act, (const float*)dy, gpart, B, Ts, N);
+    STOVE_LAUNCH_CHECK();
+    STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 31) / 32), dim3(256), 0, st, (const float*)gpart, g_params, kGnnGrads, B, 0);
+    STOVE_LAUNCH_CHECK();
+    return 0;
+  }
   int rc = gnn_lds_attr((const void*)dyn_loop_bwd_k);
   if (rc) return rc;
-  LoopConst kc{pos_var, vel_std, lat_std};
   const int nb = stove_gnn_blocks(B, N);
   STOVE_LAUNCH(dyn_loop_bwd_k, dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, z1, zsup, zsstd, eps, extra, params, z, act,
                      dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, (float*)ws, B, Ts, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);

@@ -101,17 +101,49 @@ __device__ __forceinline__ void sm_edges(SmCfg& cf) {
 __device__ __forceinline__ void sm_stamp(const SmCfg& cf, int k) {
   if (cf.stamps != nullptr && blockIdx.x == 0 && lane_id() == 0) cf.stamps[wave_id() * 16 + k] = (long long)__builtin_readcyclecounter();
 }
-// pointers into the saved-activation block of one (sequence, step); layout of gnn_act_floats(N, 1)
+// Saved activations.  Two layouts behind the same per-step pointer set:
+//  * "block" (gnn_act_floats(N, 1), what dyn_loop_bwd_k of gnn.hip restores): dense block per (sequence, step), edge
+//    rows e = i N + j including the (zeroed) self edges, CAT = [F3 | S] 64 wide;
+//  * "streams" (sm_act2_floats, what the small-graph backward and its weight-gradient pass read): per sequence one
+//    stream per buffer over all steps -- row (t N + r) of a node buffer, row (t N(N-1) + q) of an edge buffer -- so that
+//    16 consecutive rows of any layer input are one contiguous tile for the weight-gradient MFMAs.
 struct SmAct {
-  float *SIN, *H1, *PRED, *F1, *F2, *O1, *RES, *CAT, *R1, *A1, *R2, *A2, *R3, *ATT, *DIST;
+  float *SIN, *H1, *PRED, *F1, *F2, *O1, *RES, *S, *F3, *R1, *A1, *R2, *A2, *R3, *ATT, *DIST;
+  int cat_ld;        // 64 (block: S = CAT + 32) or 32 (streams)
+  int compact;       // edge rows indexed by q (streams) or by e = i N + j (block)
 };
 __device__ __forceinline__ SmAct sm_act(float* g, int N) {
   SmAct a;
   const int nr = N, ne = N * N;
   a.SIN = g; a.H1 = g + nr * 32; a.PRED = g + 2 * nr * 32; a.F1 = g + 3 * nr * 32; a.F2 = g + 4 * nr * 32;
-  a.O1 = g + 5 * nr * 32; a.RES = g + 6 * nr * 32; a.CAT = g + 7 * nr * 32;
-  a.R1 = a.CAT + nr * 64; a.A1 = a.R1 + ne * 64; a.R2 = a.A1 + ne * 64; a.A2 = a.R2 + ne * 32; a.R3 = a.A2 + ne * 32;
+  a.O1 = g + 5 * nr * 32; a.RES = g + 6 * nr * 32; a.F3 = g + 7 * nr * 32; a.S = a.F3 + 32;
+  a.R1 = a.F3 + nr * 64; a.A1 = a.R1 + ne * 64; a.R2 = a.A1 + ne * 64; a.A2 = a.R2 + ne * 32; a.R3 = a.A2 + ne * 32;
   a.ATT = a.R3 + ne * 32; a.DIST = a.ATT + ne;
+  a.cat_ld = 64;
+  a.compact = 0;
+  return a;
+}
+constexpr int kSmNodeBufs = 9;      // SIN, S, H1, PRED, F1, F2, F3, O1, RES
+__host__ __device__ inline size_t sm_act2_floats(int N, int Ts) {
+  const size_t f = (size_t)Ts * ((size_t)N * kSmNodeBufs * 32 + (size_t)N * (N - 1) * (64 + 64 + 32 + 32 + 32 + 2));
+  return (f + 3) & ~(size_t)3;       // every sequence's streams start 16-byte aligned
+}
+// stream pointers of one sequence, advanced to step ts
+__device__ __forceinline__ SmAct sm_act2(float* seq, int N, int Ts, int ts) {
+  SmAct a;
+  const size_t nrows = (size_t)Ts * N, erows = (size_t)Ts * N * (N - 1);
+  float* nb = seq + (size_t)ts * N * 32;
+  a.SIN = nb; a.S = nb + nrows * 32; a.H1 = nb + 2 * nrows * 32; a.PRED = nb + 3 * nrows * 32; a.F1 = nb + 4 * nrows * 32;
+  a.F2 = nb + 5 * nrows * 32; a.F3 = nb + 6 * nrows * 32; a.O1 = nb + 7 * nrows * 32; a.RES = nb + 8 * nrows * 32;
+  float* eb = seq + nrows * kSmNodeBufs * 32;
+  const size_t eo = (size_t)ts * N * (N - 1);
+  a.R1 = eb + eo * 64; a.A1 = eb + erows * 64 + eo * 64;
+  float* e32 = eb + erows * 128;
+  a.R2 = e32 + eo * 32; a.A2 = e32 + erows * 32 + eo * 32; a.R3 = e32 + 2 * erows * 32 + eo * 32;
+  float* e1 = e32 + 3 * erows * 32;
+  a.ATT = e1 + eo; a.DIST = e1 + erows + eo;
+  a.cat_ld = 32;
+  a.compact = 1;
   return a;
 }
 
@@ -231,13 +263,14 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
   for (int it = 0; it < 3; ++it) {
     if (it >= cf.ne && self_done) break;
     const bool has_edge = it < cf.ne;
-    int e = 0;
+    int e = 0, eg = 0;          // LDS edge row (i N + j); row in the saved-activation buffers
     float d = 0.0f, a_lo = 0.0f, a_hi = 0.0f;
     float* x1 = L.X1 + wv * 128 + 64 * h;
     SmW<16> w2;
     if (has_edge) {
       const int i = cf.ei[it], j = cf.ej[it];
       e = i * N + j;
+      eg = (SAVE && act.compact) ? 3 - wv + 4 * it : e;
       w2 = sm_wload<16>(Wl2, 32, o);
       const float dx = L.POS[i * 4] - L.POS[j * 4], dy = L.POS[i * 4 + 1] - L.POS[j * 4 + 1];
       d = dx * dx + dy * dy;
@@ -257,7 +290,7 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
       if (SAVE && lane < 32) {
         act.SIN[wv * 32 + o] = sinv;
         act.H1[wv * 32 + o] = H1;
-        act.CAT[wv * 64 + 32 + o] = S;
+        act.S[wv * act.cat_ld + o] = S;
       }
       self_done = true;
     }
@@ -269,7 +302,7 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
     for (int k4 = 0; k4 < 16; ++k4) xr[k4] = *reinterpret_cast<const float4*>(x1 + 4 * k4);
     wb = sm_wload<8>(L.W + W_R2, 32, o);
     if (SAVE) {
-      float* g1 = (h ? act.A1 : act.R1) + e * 64;
+      float* g1 = (h ? act.A1 : act.R1) + eg * 64;
       g1[o] = a_lo;
       g1[o + 32] = a_hi;
     }
@@ -293,15 +326,15 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
     if (h == 0) L.R3[e * 32 + o] = r3;
     if (lane == 0) L.ATT[e] = att;
     if (SAVE) {
-      ((h ? act.A2 : act.R2) + e * 32)[o] = a2;
-      if (h == 0) act.R3[e * 32 + o] = r3;
+      ((h ? act.A2 : act.R2) + eg * 32)[o] = a2;
+      if (h == 0) act.R3[eg * 32 + o] = r3;
       if (lane == 0) {
-        act.ATT[e] = att;
-        act.DIST[e] = d;
+        act.ATT[eg] = att;
+        act.DIST[eg] = d;
       }
     }
   }
-  if (SAVE && wv < N) {             // self-edge rows (masked out of the model): finite zeros for the backward's restore
+  if (SAVE && wv < N && !act.compact) {             // self-edge rows (masked out of the model): finite zeros for the backward's restore
     const int e = wv * N + wv;
     act.R1[e * 64 + lane] = 0.0f;
     act.A1[e * 64 + lane] = 0.0f;
@@ -343,7 +376,7 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
       act.PRED[r * 32 + o] = pred;
       act.F1[r * 32 + o] = F1;
       act.F2[r * 32 + o] = F2;
-      act.CAT[r * 64 + o] = F3;
+      act.F3[r * act.cat_ld + o] = F3;
       act.O1[r * 32 + o] = O1;
       act.RES[r * 32 + o] = RES;
     }
@@ -366,7 +399,7 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_small_k(
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
     float* __restrict__ z, float* __restrict__ zdyn, float* __restrict__ zdstd, float* __restrict__ mean,
     float* __restrict__ stdv, float* __restrict__ pred, float* __restrict__ act,
-    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc, long long* stamps) {
+    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc, long long* stamps, int streams) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const SmLds L = sm_carve(lds);
   const int b = blockIdx.x;
@@ -402,7 +435,7 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_small_k(
       if (l >= 16 && l < sin_dim && ts + 1 < Ts) xnext = extra[(((size_t)b * Ts + ts + 1) * N + r) * E + (l - 16)];
     }
     SmAct a{};
-    if (SAVE) a = sm_act(act + ((size_t)b * Ts + ts) * act_stride, N);
+    if (SAVE) a = streams ? sm_act2(act + (size_t)b * sm_act2_floats(N, Ts), N, Ts, ts) : sm_act(act + ((size_t)b * Ts + ts) * act_stride, N);
     cf.stamps = (ts == Ts - 1) ? stamps : nullptr;
     float res = 0.0f, prd = 0.0f;
     sm_step<SAVE>(L, cf, sinv, a, res, prd);
@@ -476,7 +509,7 @@ __global__ __launch_bounds__(256) void rollout_fwd_small_k(const float* __restri
     const size_t o = ((size_t)b * num + t) * N + r;
     float xnext = 0.0f;
     if (wv < N && l >= 16 && l < sin_dim && t + 1 < num) xnext = extra[(((size_t)b * A + ((t + 1) % A)) * N + r) * E + (l - 16)];
-    const SmAct a{};
+    SmAct a{};
     float res = 0.0f, prd = 0.0f;
     sm_step<false>(L, cf, sinv, a, res, prd);
     if (wv < N) {

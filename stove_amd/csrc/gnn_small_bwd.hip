@@ -1,0 +1,502 @@
+// Backward of the small-graph time loop (N <= 4 objects), gfx950: the adjoint of gnn_small.hip in the same
+// wave-per-node-row, register-chained form, split in two launches:
+//   dyn_loop_bwd_small_k  walks the T-serial chain backwards (data gradients only: dz1, dzsup, dzsstd, dextra) and
+//                         streams every layer's pre-activation gradient ("dY") to HBM;
+//   gnn_dw_small_k        turns the saved layer inputs and the dY streams into weight gradients as a throughput
+//                         GEMM: 16 consecutive (time, row) rows per MFMA tile, i.e. full tiles instead of the 3 useful
+//                         rows of 16 the in-loop accumulation of gnn.hip had, and off the latency-critical chain.
+// Formulas follow gnn_backward (gnn.hip, stages b1-b13), which is validated against the reference goldens.
+#include "common.h"
+
+namespace stove {
+
+// ---- dY streams of one sequence (same row indexing as the activation streams, sm_act2) ----------------------
+struct SmDy {
+  float *dRES, *dO1, *dF3, *duF1, *dF1p, *dSD, *dH1p, *dEnc, *dP, *dR3, *E32, *dA2p, *dR1p, *dA1p, *dq;
+};
+__host__ __device__ inline size_t sm_dy_floats(int N, int Ts) {
+  const size_t f = (size_t)Ts * ((size_t)N * (8 * 32 + 256) + (size_t)N * (N - 1) * (3 * 32 + 2 * 64 + 1));
+  return (f + 3) & ~(size_t)3;       // every sequence's streams start 16-byte aligned
+}
+__device__ __forceinline__ SmDy sm_dy(float* seq, int N, int Ts, int ts) {
+  SmDy d;
+  const size_t nrows = (size_t)Ts * N, erows = (size_t)Ts * N * (N - 1);
+  float* nb = seq + (size_t)ts * N * 32;
+  d.dRES = nb; d.dO1 = nb + nrows * 32; d.dF3 = nb + 2 * nrows * 32; d.duF1 = nb + 3 * nrows * 32; d.dF1p = nb + 4 * nrows * 32;
+  d.dSD = nb + 5 * nrows * 32; d.dH1p = nb + 6 * nrows * 32; d.dEnc = nb + 7 * nrows * 32;
+  d.dP = seq + nrows * 8 * 32 + (size_t)ts * N * 256;
+  float* eb = seq + nrows * (8 * 32 + 256);
+  const size_t eo = (size_t)ts * N * (N - 1);
+  d.dR3 = eb + eo * 32; d.E32 = eb + erows * 32 + eo * 32; d.dA2p = eb + 2 * erows * 32 + eo * 32;
+  float* e64 = eb + 3 * erows * 32;
+  d.dR1p = e64 + eo * 64; d.dA1p = e64 + erows * 64 + eo * 64;
+  d.dq = e64 + 2 * erows * 64 + eo;
+  return d;
+}
+
+// LDS of the backward kernel (floats): W^T images repacked for row-per-lane dots, vectors, exchange buffers
+struct SmBLds {
+  float *W, *V, *DSD, *EG, *DD, *POS, *X1, *DP;
+};
+constexpr int kSmBLdsFloats = W_END + V_END + 4 * 32 + 16 * 128 + 16 + 2 * 16 + 4 * 64 + 4 * 256;
+__device__ __forceinline__ SmBLds smb_carve(float* base) {
+  SmBLds L;
+  L.W = base;
+  L.V = L.W + W_END;
+  L.DSD = L.V + V_END;        // [4][32]   dL/dPRED of every node row
+  L.EG = L.DSD + 4 * 32;      // [16][dR1pre 64 | dA1pre 64] by edge row i*N + j
+  L.DD = L.EG + 16 * 128;     // [16]      dL/d dist of every edge
+  L.POS = L.DD + 16;          // [2][4][4] positions (two parities: a fast wave may already write the next step's)
+  L.X1 = L.POS + 32;          // [4 waves][E32 32 | dA2pre 32]
+  L.DP = L.X1 + 4 * 64;       // [4][256]  dP rows for the edge-first transpose product
+  return L;
+}
+// transposed layer image (rows = layer inputs, K = layer outputs) -> [K/4][rows][4]
+__device__ __forceinline__ void smb_setup(const SmBLds& L, const float* __restrict__ P) {
+  const float* WT = P + W_END;
+  sm_repack(L.W + W_ENC, WT + W_ENC, 32, 32);
+  sm_repack(L.W + W_S0, WT + W_S0, 32, 32);
+  sm_repack(L.W + W_S1, WT + W_S1, 32, 32);
+  sm_repack(L.W + W_EF, WT + W_EF, 32, 256);
+  sm_repack(L.W + W_R1, WT + W_R1, 64, 32);
+  sm_repack(L.W + W_A1, WT + W_A1, 64, 32);
+  sm_repack(L.W + W_R2, WT + W_R2, 32, 32);
+  sm_repack(L.W + W_F0, WT + W_F0, 32, 32);
+  sm_repack(L.W + W_F1, WT + W_F1, 32, 32);
+  sm_repack(L.W + W_F2, WT + W_F2, 32, 32);
+  sm_repack(L.W + W_O0, WT + W_O0, 64, 32);
+  sm_repack(L.W + W_O1, WT + W_O1, 32, 32);
+  for (int i = threadIdx.x; i < V_END; i += blockDim.x) L.V[i] = P[2 * W_END + i];
+}
+
+// what a node wave needs of step ts, fetched one step ahead
+struct SmBNodeIn {
+  float RES, SIN, O1, F1, F2, H1, S;         // lane l (and l + 32): element l of the row
+  float ep, ms, ss, gz, gmu_in, gsg_in, gzd_in, dpred;
+};
+__device__ __forceinline__ SmBNodeIn smb_node_load(const SmAct& a, int r, int l, size_t o, const float* __restrict__ eps,
+                                                   const float* __restrict__ zsup, const float* __restrict__ zsstd,
+                                                   const float* __restrict__ dz, const float* __restrict__ dzdyn,
+                                                   const float* __restrict__ dmean, const float* __restrict__ dstd,
+                                                   const float* __restrict__ dpred) {
+  SmBNodeIn n;
+  n.RES = a.RES[r * 32 + l];
+  n.SIN = a.SIN[r * 32 + l];
+  n.O1 = a.O1[r * 32 + l];
+  n.F1 = a.F1[r * 32 + l];
+  n.F2 = a.F2[r * 32 + l];
+  n.H1 = a.H1[r * 32 + l];
+  n.S = a.S[r * a.cat_ld + l];
+  n.ep = n.gz = n.gmu_in = n.gsg_in = n.gzd_in = 0.0f;
+  n.ms = 0.0f;
+  n.ss = 1.0f;
+  const int q = l < 16 ? l + 2 : l - 16;          // dim of the 18-vector owned by this lane (lanes 0..17)
+  if (l < 18) {
+    n.ep = eps[o * 18 + q];
+    if (dz != nullptr) n.gz = dz[o * 18 + q];
+    if (dmean != nullptr) n.gmu_in = dmean[o * 18 + q];
+    if (dstd != nullptr) n.gsg_in = dstd[o * 18 + q];
+    if (l < 4 || l >= 16) {
+      n.ms = zsup[o * 6 + (l < 4 ? 2 + l : l - 16)];
+      n.ss = zsstd[o * 6 + (l < 4 ? 2 + l : l - 16)];
+    }
+    if (l < 16 && dzdyn != nullptr) n.gzd_in = dzdyn[o * 16 + l];
+  }
+  n.dpred = dpred != nullptr ? dpred[o * 32 + l] : 0.0f;
+  return n;
+}
+
+__global__ __launch_bounds__(256) void dyn_loop_bwd_small_k(
+    const float* __restrict__ zsup, const float* __restrict__ zsstd, const float* __restrict__ eps, const float* __restrict__ P,
+    float* __restrict__ act, const float* __restrict__ dz, const float* __restrict__ dzdyn, const float* __restrict__ dmean,
+    const float* __restrict__ dstd, const float* __restrict__ dpred, float* __restrict__ dz1, float* __restrict__ dzsup,
+    float* __restrict__ dzsstd, float* __restrict__ dextra, float* __restrict__ dy, int B, int Ts, int N, int sin_dim, int lim_enc,
+    int elu, LoopConst kc) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const SmBLds L = smb_carve(lds);
+  const int b = blockIdx.x;
+  const int wv = wave_id(), lane = lane_id(), l = lane & 31, h = lane >> 5;
+  SmCfg cf{N, sin_dim, lim_enc, elu};
+  cf.stamps = nullptr;
+  sm_edges(cf);
+  const int E = sin_dim - 16;
+  const int NEo = N * (N - 1);
+  const float* V = L.V;
+  smb_setup(L, P);
+  float* aseq = act + (size_t)b * sm_act2_floats(N, Ts);
+  float* dseq = dy + (size_t)b * sm_dy_floats(N, Ts);
+  const int r = wv;
+  const bool node = wv < N;
+  float car = 0.0f;                                   // lane d < 16: gradient carried into z[t][2 + d] from step t + 1
+  SmBNodeIn nin{};
+  if (node) {
+    const SmAct a = sm_act2(aseq, N, Ts, Ts - 1);
+    nin = smb_node_load(a, r, l, ((size_t)b * Ts + Ts - 1) * N + r, eps, zsup, zsstd, dz, dzdyn, dmean, dstd, dpred);
+  }
+  WG_SYNC();
+  for (int ts = Ts - 1; ts >= 0; --ts) {
+    const SmAct a = sm_act2(aseq, N, Ts, ts);
+    const SmDy g = sm_dy(dseq, N, Ts, ts);
+    const size_t o = ((size_t)b * Ts + ts) * N + r;
+    const SmBNodeIn cur = nin;
+    if (node && ts > 0) {
+      const SmAct an = sm_act2(aseq, N, Ts, ts - 1);
+      nin = smb_node_load(an, r, l, o - N, eps, zsup, zsstd, dz, dzdyn, dmean, dstd, dpred);
+    }
+    // this wave's edges of the step: saved forward values, in flight across the node phase
+    float eR3[3], eATT[3], eR2[3], eA2[3], eX_lo[3], eX_hi[3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      eR3[it] = eATT[it] = eR2[it] = eA2[it] = eX_lo[it] = eX_hi[it] = 0.0f;
+      if (it < cf.ne) {
+        const int q = 3 - wv + 4 * it;
+        eR3[it] = a.R3[q * 32 + l];
+        eATT[it] = a.ATT[q];
+        eR2[it] = a.R2[q * 32 + l];
+        eA2[it] = a.A2[q * 32 + l];
+        const float* x1 = (h ? a.A1 : a.R1) + q * 64;
+        eX_lo[it] = x1[l];
+        eX_hi[it] = x1[l + 32];
+      }
+    }
+    float* pos = L.POS + (ts & 1) * 16;
+    float dS_o0 = 0.0f, dSD = 0.0f, pc = 0.0f;
+    // ---- Q4: node rows: epilogue, output and affector MLPs backwards ----------------------------------------------
+    if (node) {
+      SmW<8> wa = sm_wload<8>(L.W + W_O1, 32, l), wb;
+      if (l < 2) pos[r * 4 + l] = cur.S;
+      // epilogue backward (dyn_loop_bwd_k of gnn.hip, per (row, q)): lane d < 16 owns q = d + 2, lanes 16/17 q = 0/1
+      const float res_hi = sm_from_lane(cur.RES, (lane & 32) + ((l + 16) & 31));
+      const float gz = cur.gz + (l < 16 ? car : 0.0f);
+      const float gmu = gz + cur.gmu_in, gsg = gz * cur.ep + cur.gsg_in;
+      float lo = 0.0f, hi = 0.0f;
+      if (l < 16) {
+        const int d = l;
+        const float kd = std_scale(d, kc);
+        const float m = 2.0f * sigmoidf_(cur.RES) - 1.0f;
+        const float sd = kd * sigmoidf_(res_hi);
+        const float zd = m + (d < 2 ? cur.SIN : 0.0f);
+        float gzd = cur.gzd_in, gsd;
+        if (d < 4) {
+          const float ms = cur.ms, ss = cur.ss;
+          const float sd2 = sd * sd, ss2 = ss * ss, D = sd2 + ss2, iD = 1.0f / D;
+          const float mu = (ss2 * zd + sd2 * ms) * iD;
+          const float rD = rsqrtf(D);
+          gzd += gmu * ss2 * iD;
+          gsd = gmu * (ms - mu) * iD * 2.0f * sd + gsg * ss * ss2 * iD * rD;
+          if (lane < 32) {
+            dzsup[o * 6 + 2 + d] = gmu * sd2 * iD;
+            dzsstd[o * 6 + 2 + d] = gmu * (zd - mu) * iD * 2.0f * ss + gsg * sd * sd2 * iD * rD;
+          }
+        } else {
+          gzd += gmu;
+          gsd = gsg;
+        }
+        if (d < 2) pc = gzd;                              // z_dyn position = previous position + delta
+        lo = gzd * 0.5f * (1.0f - m * m);
+        hi = gsd * sd * (1.0f - sd / kd);
+      } else if (l < 18 && lane < 32) {
+        dzsup[o * 6 + (l - 16)] = gmu;
+        dzsstd[o * 6 + (l - 16)] = gsg;
+      }
+      const float hi_from = sm_from_lane(hi, (lane & 32) + ((l + 16) & 31));      // lane l >= 16 takes hi of lane l - 16
+      const float dres = l < 16 ? lo : hi_from;
+      // b1. out.1
+      wb = sm_wload<8>(L.W + W_O0, 64, l);
+      const float db = (sm_dotw<8>(wa, dres) + dres) * (1.0f - cur.O1 * cur.O1);
+      // b2. out.0 on [F3 | S]
+      wa = sm_wload<8>(L.W + W_O0, 64, 32 + l);
+      const float dF3 = sm_dotw<8>(wb, db);
+      wb = sm_wload<8>(L.W + W_F2, 32, l);
+      dS_o0 = sm_dotw<8>(wa, db);
+      // b3. affector.2
+      wa = sm_wload<8>(L.W + W_F1, 32, l);
+      const float dF2 = sm_dotw<8>(wb, dF3);
+      const float th = cur.F2 - cur.F1;
+      const float du = dF2 * (1.0f - th * th);
+      // b4. affector.1
+      wb = sm_wload<8>(L.W + W_F0, 32, l);
+      const float dbf = (sm_dotw<8>(wa, du) + dF2) * (1.0f - cur.F1 * cur.F1);
+      // b5. affector.0
+      dSD = sm_dotw<8>(wb, dbf) + cur.dpred;
+      if (lane < 32) {
+        L.DSD[r * 32 + l] = dSD;
+        g.dRES[r * 32 + l] = dres;
+        g.dO1[r * 32 + l] = db;
+        g.dF3[r * 32 + l] = dF3;
+        g.duF1[r * 32 + l] = du;
+        g.dF1p[r * 32 + l] = dbf;
+        g.dSD[r * 32 + l] = dSD;
+      }
+    }
+    WG_SYNC();
+    // ---- Q3: edges: half 0 = relation chain, half 1 = attention chain -----------------------------------------------
+    {
+      const float wa2 = V[V_WA2 + l];
+      const int vwd = h ? V_WDA : V_WDR;
+      const float wd_lo = V[vwd + l], wd_hi = V[vwd + l + 32];
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        if (it >= cf.ne) break;
+        const int i = cf.ei[it], j = cf.ej[it], e = i * N + j, q = 3 - wv + 4 * it;
+        SmW<8> w2 = sm_wload<8>(L.W + W_R2, 32, l);
+        const float* Wl = L.W + (h ? W_A1 : W_R1);
+        SmW<8> wlo = sm_wload<8>(Wl, 64, l), whi = sm_wload<8>(Wl, 64, l + 32);
+        const float dsd_i = L.DSD[i * 32 + l];
+        const float att = eATT[it];
+        const float dq = wave_sum(h == 0 ? dsd_i * eR3[it] : 0.0f) * att;
+        const float dR3 = dsd_i * att;
+        const float e32 = (sm_dotw<8>(w2, dR3) + dR3) * dphi_from_out(eR2[it], elu);
+        const float dA2p = dq * wa2 * dphi_from_out(eA2[it], elu);
+        float* x1 = L.X1 + wv * 64 + 32 * h;
+        x1[l] = h ? dA2p : e32;
+        float4 xr[8];
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) xr[k4] = *reinterpret_cast<const float4*>(x1 + 4 * k4);
+        v2f y0 = {0.0f, 0.0f}, y1 = {0.0f, 0.0f}, y2 = {0.0f, 0.0f}, y3 = {0.0f, 0.0f};
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+          y0 = pk_fma(v2f{wlo.w[k4].x, wlo.w[k4].y}, v2f{xr[k4].x, xr[k4].y}, y0);
+          y1 = pk_fma(v2f{wlo.w[k4].z, wlo.w[k4].w}, v2f{xr[k4].z, xr[k4].w}, y1);
+          y2 = pk_fma(v2f{whi.w[k4].x, whi.w[k4].y}, v2f{xr[k4].x, xr[k4].y}, y2);
+          y3 = pk_fma(v2f{whi.w[k4].z, whi.w[k4].w}, v2f{xr[k4].z, xr[k4].w}, y3);
+        }
+        y0 += y1;
+        y2 += y3;
+        const float d1_lo = (y0.x + y0.y) * dphi_from_out(eX_lo[it], elu);
+        const float d1_hi = (y2.x + y2.y) * dphi_from_out(eX_hi[it], elu);
+        const float dd = wave_sum(d1_lo * wd_lo + d1_hi * wd_hi);
+        float* eg = L.EG + e * 128 + 64 * h;
+        eg[l] = d1_lo;
+        eg[l + 32] = d1_hi;
+        if (lane == 0) L.DD[e] = dd;
+        float* g1 = (h ? g.dA1p : g.dR1p) + q * 64;
+        g1[l] = d1_lo;
+        g1[l + 32] = d1_hi;
+        if (h == 0) {
+          g.dR3[q * 32 + l] = dR3;
+          g.E32[q * 32 + l] = e32;
+        } else {
+          g.dA2p[q * 32 + l] = dA2p;
+        }
+        if (lane == 0) g.dq[q] = dq;
+      }
+    }
+    WG_SYNC();
+    // ---- Q2: node rows: first edge layer, self-dynamics, encoder backwards ------------------------------------------
+    if (node) {
+      // dP[r][c], c = lane + 64 g: relation / attention, r as first (s_i) or second (s_j) argument
+      float dp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int j = 0; j < N; ++j) {
+        if (j == r) continue;
+        const float* e1 = L.EG + (r * N + j) * 128;
+        const float* e2 = L.EG + (j * N + r) * 128;
+        dp[0] += e1[lane];
+        dp[1] += e2[lane];
+        dp[2] += e1[64 + lane];
+        dp[3] += e2[64 + lane];
+      }
+      float* dpr = L.DP + r * 256;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        dpr[lane + 64 * gq] = dp[gq];
+        g.dP[r * 256 + lane + 64 * gq] = dp[gq];
+      }
+      SmW<8> wa = sm_wload<8>(L.W + W_S1, 32, l);
+      // dS from the edge layers: dP (256) W_ef (256 x 32); the two half-waves split the 256 terms
+      v2f s0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f};
+#pragma unroll 4
+      for (int k4 = 0; k4 < 32; ++k4) {
+        const float4 w = *reinterpret_cast<const float4*>(L.W + W_EF + ((32 * h + k4) * 32 + l) * 4);
+        const float4 x = *reinterpret_cast<const float4*>(dpr + 128 * h + 4 * k4);
+        s0 = pk_fma(v2f{w.x, w.y}, v2f{x.x, x.y}, s0);
+        s1 = pk_fma(v2f{w.z, w.w}, v2f{x.z, x.w}, s1);
+      }
+      s0 += s1;
+      float dS_edge = s0.x + s0.y;
+      dS_edge += sm_from_lane(dS_edge, lane ^ 32);
+      // b11. self.1:  SD = H1 W^T + b + H1
+      SmW<8> wb = sm_wload<8>(L.W + W_S0, 32, l);
+      const float dH1p = (sm_dotw<8>(wa, dSD) + dSD) * dphi_from_out(cur.H1, elu);
+      // b12. self.0 ; total dS ; split into the encoder output part and the pass-through part
+      wa = sm_wload<8>(L.W + W_ENC, 32, l);
+      float tot = sm_dotw<8>(wb, dH1p) + dS_edge + dS_o0;
+      if (l < 2) {
+        float dd = 0.0f;
+        for (int j = 0; j < N; ++j)
+          if (j != r) dd += 2.0f * (pos[r * 4 + l] - pos[j * 4 + l]) * (L.DD[r * N + j] + L.DD[j * N + r]);
+        tot += dd;
+      }
+      const bool raw = l < lim_enc;
+      const float dEnc = raw ? 0.0f : tot;
+      // b13. encoder
+      const float dsin = sm_dotw<8>(wa, dEnc) + (raw ? tot : 0.0f);
+      if (lane < 32) {
+        g.dH1p[r * 32 + l] = dH1p;
+        g.dEnc[r * 32 + l] = dEnc;
+        if (l >= 16 && l < sin_dim) dextra[o * E + (l - 16)] = dsin;
+      }
+      car = (l < 16) ? dsin + (l < 2 ? pc : 0.0f) : 0.0f;
+    }
+  }
+  if (node) {
+    const float shifted = sm_from_lane(car, (lane + 62) & 63);      // all lanes take part: a bpermute reads 0 from inactive source lanes
+    if (lane < 18) dz1[((size_t)b * N + r) * 18 + lane] = lane < 2 ? 0.0f : shifted;
+  }
+}
+
+// =================================================================================================
+// weight gradients from the streams: one workgroup per sequence (the partial images are reduced by reduce_chunks_k)
+// =================================================================================================
+// 16 consecutive rows of every stream form one MFMA K-block.  A row block is fetched with coalesced float4 loads into
+// registers while the previous block's MFMAs run, then dropped into padded LDS buffers, from which the validated
+// dW_layer / vec_layer of gnn.hip (step-major interleaved MFMAs) accumulate -- full 16-row tiles instead of the 3 useful
+// rows of 16 the in-loop accumulation has, and no per-tile global-load latency (a first version that fed the MFMAs
+// straight from global memory spent 1 us per tile waiting: 0.98 ms per launch).
+struct DwLds {
+  float *SIN, *H1, *PRED, *F1, *F2, *O1, *CAT;                          // layer inputs, [16][LDN] ([16][LDC] for CAT = [F3 | S])
+  float *dEnc, *dH1p, *dSD, *dF1p, *duF1, *dF3, *dO1, *dRES, *dP;       // dY, [16][LDN] ([16][LDP] for dP)
+  float *R1, *A1, *dR1p, *dA1p;                                         // edge pass, [16][LDC]
+  float *R2, *A2, *E32, *dA2p, *dR3;                                    // edge pass, [16][LDN]
+  float *AUXN, *AUXE;                                                   // [16][16]
+};
+constexpr int kDwLdsFloats = 14 * 16 * LDN + 16 * LDC + 16 * LDP + 4 * 16 * LDC + 5 * 16 * LDN + 2 * 256;
+__device__ __forceinline__ DwLds dw_carve(float* p) {
+  DwLds L;
+  auto take = [&](int n) { float* q = p; p += n; return q; };
+  L.SIN = take(16 * LDN); L.H1 = take(16 * LDN); L.PRED = take(16 * LDN); L.F1 = take(16 * LDN); L.F2 = take(16 * LDN);
+  L.O1 = take(16 * LDN); L.CAT = take(16 * LDC);
+  L.dEnc = take(16 * LDN); L.dH1p = take(16 * LDN); L.dSD = take(16 * LDN); L.dF1p = take(16 * LDN); L.duF1 = take(16 * LDN);
+  L.dF3 = take(16 * LDN); L.dO1 = take(16 * LDN); L.dRES = take(16 * LDN); L.dP = take(16 * LDP);
+  L.R1 = take(16 * LDC); L.A1 = take(16 * LDC); L.dR1p = take(16 * LDC); L.dA1p = take(16 * LDC);
+  L.R2 = take(16 * LDN); L.A2 = take(16 * LDN); L.E32 = take(16 * LDN); L.dA2p = take(16 * LDN); L.dR3 = take(16 * LDN);
+  L.AUXN = take(256); L.AUXE = take(256);
+  return L;
+}
+// float4 number `idx` of the 16-row block starting at row r0 of a row-major stream of width W (zero beyond nrows)
+template <int W>
+__device__ __forceinline__ float4 dw_fetch(const float* __restrict__ src, int r0, int nrows, int idx) {
+  const int row = idx / (W / 4);
+  if (r0 + row >= nrows) return float4{0.0f, 0.0f, 0.0f, 0.0f};
+  return reinterpret_cast<const float4*>(src + (size_t)r0 * W)[idx];
+}
+template <int W>
+__device__ __forceinline__ void dw_drop(float* dst, int ld, int col0, int idx, float4 v) {
+  const int row = idx / (W / 4), c4 = idx % (W / 4);
+  *reinterpret_cast<float4*>(dst + row * ld + col0 + c4 * 4) = v;
+}
+
+__global__ __launch_bounds__(256) void gnn_dw_small_k(const float* __restrict__ act, const float* __restrict__ dy, float* __restrict__ gpart,
+                                                      int B, int Ts, int N) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const DwLds L = dw_carve(lds);
+  const int b = blockIdx.x, wv = wave_id(), tid = threadIdx.x;
+  const SmAct a = sm_act2(const_cast<float*>(act) + (size_t)b * sm_act2_floats(N, Ts), N, Ts, 0);
+  const SmDy g = sm_dy(const_cast<float*>(dy) + (size_t)b * sm_dy_floats(N, Ts), N, Ts, 0);
+  f32x4 acc[SL_END], vacc[VSLOTS];
+#pragma unroll
+  for (int k = 0; k < SL_END; ++k) acc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < VSLOTS; ++k) vacc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i = tid; i < 256; i += 256) {
+    L.AUXN[i] = (i & 15) == 0 ? 1.0f : 0.0f;
+    L.AUXE[i] = (i & 15) == 0 ? 1.0f : 0.0f;
+  }
+  const int nrows = Ts * N, erows = Ts * N * (N - 1);
+  // ---- node rows: 16 streams of width 32 (two per thread half: threads 0..127 the first, 128..255 the second) + dP (256)
+  const float* n32[16] = {a.SIN, a.H1, a.PRED, a.F1, a.F2, a.O1, a.F3, a.S, g.dEnc, g.dH1p, g.dSD, g.dF1p, g.duF1, g.dF3, g.dO1, g.dRES};
+  float* d32[16] = {L.SIN, L.H1, L.PRED, L.F1, L.F2, L.O1, L.CAT, L.CAT, L.dEnc, L.dH1p, L.dSD, L.dF1p, L.duF1, L.dF3, L.dO1, L.dRES};
+  const int half = tid >> 7, t7 = tid & 127;
+  float4 rg[12];
+  auto node_fetch = [&](int r0) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) rg[p] = dw_fetch<32>(n32[2 * p + half], r0, nrows, t7);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rg[8 + q] = dw_fetch<256>(g.dP, r0, nrows, tid + 256 * q);
+  };
+  auto node_drop = [&]() {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int sidx = 2 * p + half;
+      const int ld = (sidx == 6 || sidx == 7) ? LDC : LDN;
+      dw_drop<32>(d32[sidx], ld, sidx == 7 ? 32 : 0, t7, rg[p]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dw_drop<256>(L.dP, LDP, 0, tid + 256 * q, rg[8 + q]);
+  };
+  node_fetch(0);
+  WG_SYNC();
+  for (int r0 = 0; r0 < nrows; r0 += 16) {
+    node_drop();
+    WG_SYNC();
+    if (r0 + 16 < nrows) node_fetch(r0 + 16);
+    const float* S = L.CAT + 32;
+    dW_layer<32, 32, SL_ENC>(acc, L.dEnc, LDN, L.SIN, LDN, 1, wv);
+    dW_layer<32, 32, SL_S0>(acc, L.dH1p, LDN, S, LDC, 1, wv);
+    dW_layer<32, 32, SL_S1>(acc, L.dSD, LDN, L.H1, LDN, 1, wv);
+    dW_layer<256, 32, SL_EF>(acc, L.dP, LDP, S, LDC, 1, wv);
+    dW_layer<32, 32, SL_F0>(acc, L.dF1p, LDN, L.PRED, LDN, 1, wv);
+    dW_layer<32, 32, SL_F1>(acc, L.duF1, LDN, L.F1, LDN, 1, wv);
+    dW_layer<32, 32, SL_F2>(acc, L.dF3, LDN, L.F2, LDN, 1, wv);
+    dW_layer<32, 64, SL_O0>(acc, L.dO1, LDN, L.CAT, LDC, 1, wv);
+    dW_layer<32, 32, SL_O1>(acc, L.dRES, LDN, L.O1, LDN, 1, wv);
+    vec_layer<VT_ENC, 2>(vacc, L.dEnc, LDN, L.AUXN, 1, wv);
+    vec_layer<VT_S0, 2>(vacc, L.dH1p, LDN, L.AUXN, 1, wv);
+    vec_layer<VT_S1, 2>(vacc, L.dSD, LDN, L.AUXN, 1, wv);
+    vec_layer<VT_F0, 2>(vacc, L.dF1p, LDN, L.AUXN, 1, wv);
+    vec_layer<VT_F1, 2>(vacc, L.duF1, LDN, L.AUXN, 1, wv);
+    vec_layer<VT_F2, 2>(vacc, L.dF3, LDN, L.AUXN, 1, wv);
+    vec_layer<VT_O0, 2>(vacc, L.dO1, LDN, L.AUXN, 1, wv);
+    vec_layer<VT_O1, 2>(vacc, L.dRES, LDN, L.AUXN, 1, wv);
+    WG_SYNC();
+  }
+  // ---- edge rows: four 64-wide streams (one float4 per thread each), five 32-wide (threads 0..127 / 128..255), dist and dq
+  const float* e32[6] = {a.R2, a.A2, g.E32, g.dA2p, g.dR3, g.dR3};
+  float* f32d[6] = {L.R2, L.A2, L.E32, L.dA2p, L.dR3, L.dR3};
+  float aux1 = 0.0f, aux2 = 0.0f;
+  auto edge_fetch = [&](int r0) {
+    rg[0] = dw_fetch<64>(a.R1, r0, erows, tid);
+    rg[1] = dw_fetch<64>(a.A1, r0, erows, tid);
+    rg[2] = dw_fetch<64>(g.dR1p, r0, erows, tid);
+    rg[3] = dw_fetch<64>(g.dA1p, r0, erows, tid);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) rg[4 + p] = dw_fetch<32>(e32[2 * p + half], r0, erows, t7);
+    if (tid < 16) {
+      aux1 = (r0 + tid < erows) ? a.DIST[r0 + tid] : 0.0f;
+      aux2 = (r0 + tid < erows) ? g.dq[r0 + tid] : 0.0f;
+    }
+  };
+  auto edge_drop = [&]() {
+    dw_drop<64>(L.R1, LDC, 0, tid, rg[0]);
+    dw_drop<64>(L.A1, LDC, 0, tid, rg[1]);
+    dw_drop<64>(L.dR1p, LDC, 0, tid, rg[2]);
+    dw_drop<64>(L.dA1p, LDC, 0, tid, rg[3]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      if (!(p == 2 && half == 1)) dw_drop<32>(f32d[2 * p + half], LDN, 0, t7, rg[4 + p]);
+    if (tid < 16) {
+      L.AUXE[tid * 16 + 1] = aux1;
+      L.AUXE[tid * 16 + 2] = aux2;
+    }
+  };
+  edge_fetch(0);
+  for (int r0 = 0; r0 < erows; r0 += 16) {
+    edge_drop();
+    WG_SYNC();
+    if (r0 + 16 < erows) edge_fetch(r0 + 16);
+    dW_layer<32, 64, SL_R1>(acc, L.E32, LDN, L.R1, LDC, 1, wv);
+    dW_layer<32, 64, SL_A1>(acc, L.dA2p, LDN, L.A1, LDC, 1, wv);
+    dW_layer<32, 32, SL_R2>(acc, L.dR3, LDN, L.R2, LDN, 1, wv);
+    vec_layer<VT_R0, 4>(vacc, L.dR1p, LDC, L.AUXE, 1, wv);
+    vec_layer<VT_A0, 4>(vacc, L.dA1p, LDC, L.AUXE, 1, wv);
+    vec_layer<VT_R1, 2>(vacc, L.E32, LDN, L.AUXE, 1, wv);
+    vec_layer<VT_A1, 2>(vacc, L.dA2p, LDN, L.AUXE, 1, wv);
+    vec_layer<VT_R2, 2>(vacc, L.dR3, LDN, L.AUXE, 1, wv);
+    vec_layer<VT_WA2, 2>(vacc, L.A2, LDN, L.AUXE, 1, wv);
+    vec_layer<VT_BA2, 1>(vacc, L.AUXE, 16, L.AUXE, 1, wv);
+    WG_SYNC();
+  }
+  gnn_store_grads(acc, vacc, gpart + (size_t)blockIdx.x * kGnnGrads);
+}
+
+}  // namespace stove

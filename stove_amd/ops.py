@@ -307,7 +307,7 @@ class _DynLoopFn(torch.autograd.Function):
             dzsup, dzsstd = torch.empty_like(zsup), torch.empty_like(zsstd)
             dextra = torch.empty_like(extra) if extra is not None else None
             g = torch.empty(lib.stove_gnn_grad_floats(), dtype=torch.float32, device=dev)
-            ws = _ws(lib.stove_dynloop_bwd_ws_bytes(B, N), dev)
+            ws = _ws(lib.stove_dynloop_bwd_ws_bytes_ts(B, Ts, N), dev)
             check(lib.stove_dynloop_bwd(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z), ptr(act),
                                         ptr(up(dz, z)), ptr(up(dzdyn, z)), ptr(up(dmean, z)), ptr(up(dstd, z)),
                                         ptr(up(dpred, z)), ptr(dz1), ptr(dzsup), ptr(dzsstd), ptr(dextra), ptr(g), ptr(ws),
