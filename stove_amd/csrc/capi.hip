@@ -475,7 +475,22 @@ int stove_bw_transform(const float* x, float* out, int n_frames, int channels, i
 
 size_t stove_colsum_ws_floats(int rows, int cols) {
   const int chunks = rows < 512 ? (rows < 1 ? 1 : rows) : 512;
-  return (size_t)chunks * cols;
+  return (size_t)(chunks + 16) * cols;
+}
+
+// one level: `rows` rows -> `used` partial rows (returned), each the sum of `per` consecutive rows
+static int colsum_level(const float* a, float* part, int rows, int cols, int max_chunks, hipStream_t st) {
+  const int chunks = rows < max_chunks ? rows : max_chunks;
+  const int per = (rows + chunks - 1) / chunks;
+  const int used = (rows + per - 1) / per;
+  if (cols <= 64) {
+    int cpad = 1;
+    while (cpad < cols) cpad <<= 1;
+    STOVE_LAUNCH(colsum_narrow_part_k, dim3(used), dim3(256), 0, st, a, part, rows, cols, cpad, per);
+  } else {
+    STOVE_LAUNCH(colsum_part_k, dim3(used, (cols / 4 + 255) / 256), dim3(256), 0, st, a, part, rows, cols / 4, per);
+  }
+  return used;
 }
 
 int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void* stream) {
@@ -485,18 +500,18 @@ int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void
     hipMemsetAsync(out, 0, sizeof(float) * cols, st);
     return 0;
   }
-  const int chunks = rows < 512 ? rows : 512;
-  const int per = (rows + chunks - 1) / chunks;
-  const int used = (rows + per - 1) / per;
-  if (cols <= 64) {
-    int cpad = 1;
-    while (cpad < cols) cpad <<= 1;
-    STOVE_LAUNCH(colsum_narrow_part_k, dim3(used), dim3(256), 0, st, a, ws, rows, cols, cpad, per);
-  } else {
-    STOVE_LAUNCH(colsum_part_k, dim3(used, (cols / 4 + 255) / 256), dim3(256), 0, st, a, ws, rows, cols / 4, per);
-  }
+  // 512 row chunks keep the first pass at HBM speed; a second pass folds them to <= 16 so that the final fixed-order
+  // sum is short (a single 512-way pass over 1024 columns has only 32 workgroups and is latency-bound: 30 us)
+  int used = colsum_level(a, ws, rows, cols, 512, st);
   STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, (const float*)ws, out, cols, used, 0);
+  const float* src = ws;
+  if (used > 16) {
+    float* ws2 = ws + (size_t)(rows < 512 ? rows : 512) * cols;
+    used = colsum_level(ws, ws2, used, cols, 16, st);
+    STOVE_LAUNCH_CHECK();
+    src = ws2;
+  }
+  STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, src, out, cols, used, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
