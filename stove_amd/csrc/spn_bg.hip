@@ -278,22 +278,45 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
   }
   const int col = p % kBgSide, row = p / kBgSide;
   int it = 0;
-  for (int f = blockIdx.x / kBgHalves; f < n_frames; f += gridDim.x / kBgHalves, ++it) {
-    const float x = frames[(size_t)f * kBgPix + p];
+  // the pixel and the coverage-table entries of the NEXT frame are fetched while the current one is processed: with
+  // ~100 frames per block and a dependent global load at the top of every iteration, the load latency was the kernel
+  const int fstep = gridDim.x / kBgHalves;
+  float xn = 0.0f, fxn[NMAX], fyn[NMAX], dfxn[NMAX], dfyn[NMAX];
+  auto prefetch = [&](int f) {
+    xn = frames[(size_t)f * kBgPix + p];
+    if (SCENE) {
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        if (k < n_obj) {
+          const float* tk = T + ((size_t)f * n_obj + k) * kBgTab;
+          fxn[k] = tk[col];
+          dfxn[k] = tk[32 + col];
+          fyn[k] = tk[64 + row];
+          dfyn[k] = tk[96 + row];
+        }
+      }
+    }
+  };
+  if ((int)(blockIdx.x / kBgHalves) < n_frames) prefetch(blockIdx.x / kBgHalves);
+  for (int f = blockIdx.x / kBgHalves; f < n_frames; f += fstep, ++it) {
+    const float x = xn;
     float w, mraw = 0.0f;
     // per-object box factors for the scene backward
     float fx[NMAX], fy[NMAX], dfx[NMAX], dfy[NMAX];
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      fx[k] = fxn[k];
+      fy[k] = fyn[k];
+      dfx[k] = dfxn[k];
+      dfy[k] = dfyn[k];
+    }
+    if (f + fstep < n_frames) prefetch(f + fstep);
     bool pass = true;
     if (SCENE) {
       float run = 0.0f;
 #pragma unroll
       for (int k = 0; k < NMAX; ++k) {
         if (k < n_obj) {
-          const float* tk = T + ((size_t)f * n_obj + k) * kBgTab;
-          fx[k] = tk[col];
-          dfx[k] = tk[32 + col];
-          fy[k] = tk[64 + row];
-          dfy[k] = tk[96 + row];
           run += fx[k] * fy[k];
           if (run > 1.0f) {
             run = 1.0f;
