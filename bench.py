@@ -219,17 +219,20 @@ def main():
             n_obj = cfg.num_obj
             avg_ms = total_ms / count
             per_step = {k: round(v[0] / a.profile_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:14]}
-            if name.startswith(('dyn_loop', 'gnn_step', 'rollout')):
-                # GNN recursion: dense contraction -> fp32 MFMA peak (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s).
-                # Algorithmic flops per (sequence, step), SURVEY.md section 8d: F = 17408 N + 26944 N (N-1)
-                # forward, 2F for the backward math (the in-kernel recompute is overhead, not counted).
+            if name.startswith(('dyn_loop', 'gnn_step', 'rollout', 'gnn_dw')):
+                # GNN recursion: dense fp32 contraction -> 157.3 TFLOP/s (v_mfma_f32_16x16x4_f32; the packed-fp32 VALU
+                # path of the small-graph kernels, v_pk_fma_f32, has the same peak on MI355X).
+                # Algorithmic flops per (sequence, step), SURVEY.md section 8d: F = 17408 N + 26944 N (N-1) forward;
+                # the backward is 2F: F of data gradients (dyn_loop_bwd_small_k) + F of weight gradients
+                # (gnn_dw_small_k); the MFMA kernel of gnn.hip (N > 4) does both in one launch.
                 F = 17408 * n_obj + 26944 * n_obj * (n_obj - 1)
                 units = a.batch * (a.frames - 2)
-                flops = (2 * F if 'bwd' in name else F) * units
+                both = 'bwd' in name and 'small' not in name
+                flops = (2 * F if both else F) * units
                 ach = flops / (avg_ms * 1e-3) / 1e12
                 roofline = {'bound': 'mfma', 'kernel': name, 'avg_ms': avg_ms, 'launches': count, 'achieved': ach,
                             'peak': 157.3, 'unit': 'TFLOP/s', 'frac': ach / 157.3, 'traffic': None,
-                            'note': 'latency-bound: %d dependent time steps per launch' % (a.frames - 2),
+                            'note': 'latency-bound: %d dependent time steps per launch, one sequence per CU' % (a.frames - 2),
                             'kernels_ms_per_step': per_step}
             else:
                 # SPN / scene sweep: scan-shaped -> HBM 8 TB/s.  Algorithmic bytes per frame fwd+bwd =
