@@ -6,10 +6,10 @@
 // node MLPs (encoder, self-dynamics, affector, output) act on every node row independently, and the edge MLPs
 // on every edge independently; rows only mix at the edge gather and at the aggregation.  So here
 //   * one WAVE owns one node row for the whole step (and 1-3 edges in the edge phase);
-//   * a 32-wide activation vector lives in ONE VGPR (lane k holds x[k]); a dense layer is 32 v_readlane
-//     (x[k] -> SGPR, wave-uniform) + 32 v_fmac with the lane's weight row streamed from LDS as float4
-//     ([K/4][OUT][4] layout, conflict-free), i.e. layers chain register-to-register with no LDS round trip
-//     and no barrier;
+//   * a 32-wide activation vector lives in ONE VGPR (lane k holds x[k]); a dense layer sends it through a per-wave
+//     LDS scratch, reads it back as 8 broadcast float4 and runs 16 v_pk_fma_f32 against the lane's weight row, which
+//     streams from LDS as float4 ([K/4][OUT][4] layout, conflict-free) one layer ahead; layers chain inside the
+//     wave with no workgroup barrier (a first version broadcast x with 32 v_readlane per layer: 391 vs 255 cycles);
 //   * the workgroup synchronises exactly twice per step (before the edge phase, before the aggregation).
 // All forward weights (90 KB) sit in LDS for the whole launch.
 // The kernel writes the same saved-activation block as dyn_loop_fwd_k, so dyn_loop_bwd_k consumes it unchanged.
@@ -56,24 +56,6 @@ __device__ __forceinline__ void sm_setup(const SmLds& L, const float* __restrict
   sm_repack(L.W + W_O0, P + W_O0, 32, 64);
   sm_repack(L.W + W_O1, P + W_O1, 32, 32);
   for (int i = threadIdx.x; i < V_END; i += blockDim.x) L.V[i] = P[2 * W_END + i];
-}
-
-__device__ __forceinline__ float sm_rl(float v, int k) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
-}
-// y[o] = sum_{k < 4 K4} W[o][k] x[k], x[k] held by lane k (< 32) of this wave; Wl = layer base, k4-major with OUT rows
-template <int K4>
-__device__ __forceinline__ float sm_dot(const float* Wl, int OUT, int o, float x, int k4_0 = 0) {
-  float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-  for (int k4 = 0; k4 < K4; ++k4) {
-    const float4 w = *reinterpret_cast<const float4*>(Wl + ((k4_0 + k4) * OUT + o) * 4);
-    a0 = fmaf(w.x, sm_rl(x, 4 * k4), a0);
-    a1 = fmaf(w.y, sm_rl(x, 4 * k4 + 1), a1);
-    a0 = fmaf(w.z, sm_rl(x, 4 * k4 + 2), a0);
-    a1 = fmaf(w.w, sm_rl(x, 4 * k4 + 3), a1);
-  }
-  return a0 + a1;
 }
 
 struct SmCfg {
@@ -167,15 +149,29 @@ __device__ __forceinline__ SmW<K4> sm_wload(const float* Wl, int OUT, int o, int
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
+// y[o] = sum_k W[o][k] x[k].  The activation vector goes through a per-wave LDS scratch and comes back as K/4 broadcast
+// float4 reads (every lane reads the same address: one LDS pass), then K/2 packed FMAs on four independent chains.
+// Measured per 32 x 32 layer on one wave per SIMD (tools/ubench/dot_variants.hip): 255 cycles, against 391 for
+// 32 v_readlane feeding the FMAs through SGPRs (every FMA then waits on the SGPR its readlane has just written).
 template <int K4>
 __device__ __forceinline__ float sm_dotw(const SmW<K4>& W, float x) {
-  v2f a = {0.0f, 0.0f}, b = {0.0f, 0.0f};       // two independent chains
+  __shared__ __attribute__((aligned(16))) float xb[4][32];
+  float* p = xb[wave_id()];
+  if (lane_id() < 32) p[lane_id()] = x;        // x[k] is lane k's value (the upper half-wave may hold something else)
+  float4 xv[K4];
 #pragma unroll
-  for (int k4 = 0; k4 < K4; ++k4) {
-    a = pk_fma(v2f{W.w[k4].x, W.w[k4].y}, v2f{sm_rl(x, 4 * k4), sm_rl(x, 4 * k4 + 1)}, a);
-    b = pk_fma(v2f{W.w[k4].z, W.w[k4].w}, v2f{sm_rl(x, 4 * k4 + 2), sm_rl(x, 4 * k4 + 3)}, b);
+  for (int k4 = 0; k4 < K4; ++k4) xv[k4] = *reinterpret_cast<const float4*>(p + 4 * k4);
+  v2f a = {0.0f, 0.0f}, b = {0.0f, 0.0f}, c = {0.0f, 0.0f}, d = {0.0f, 0.0f};
+#pragma unroll
+  for (int k4 = 0; k4 < K4; k4 += 2) {
+    a = pk_fma(v2f{W.w[k4].x, W.w[k4].y}, v2f{xv[k4].x, xv[k4].y}, a);
+    b = pk_fma(v2f{W.w[k4].z, W.w[k4].w}, v2f{xv[k4].z, xv[k4].w}, b);
+    c = pk_fma(v2f{W.w[k4 + 1].x, W.w[k4 + 1].y}, v2f{xv[k4 + 1].x, xv[k4 + 1].y}, c);
+    d = pk_fma(v2f{W.w[k4 + 1].z, W.w[k4 + 1].w}, v2f{xv[k4 + 1].z, xv[k4 + 1].w}, d);
   }
   a += b;
+  c += d;
+  a += c;
   return a.x + a.y;
 }
 
@@ -212,6 +208,11 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
       e = sm_dotw<8>(wa, sinv);
     }
     S = (o < cf.lim_enc) ? sinv : e + benc;
+    __shared__ __attribute__((aligned(16))) float sbuf[4][32];       // S back as broadcast float4 reads (see sm_dotw)
+    if (lane < 32) sbuf[wv][lane] = S;
+    float4 sx[8];
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) sx[k4] = *reinterpret_cast<const float4*>(&sbuf[wv][4 * k4]);
     v2f p[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -226,8 +227,8 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
       }
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) {
-        const int kk = 16 * half + 4 * k4;
-        const v2f x01 = {sm_rl(S, kk), sm_rl(S, kk + 1)}, x23 = {sm_rl(S, kk + 2), sm_rl(S, kk + 3)};
+        const float4 xq = sx[4 * half + k4];
+        const v2f x01 = {xq.x, xq.y}, x23 = {xq.z, xq.w};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           p[g] = pk_fma(v2f{ef[k4][g].x, ef[k4][g].y}, x01, p[g]);
