@@ -602,7 +602,7 @@ class _EncoderLstmFn(torch.autograd.Function):
     so dW_ih is ONE (4H x n) @ (n x D) GEMM."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, num_steps):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major=False):
         lib = _lib.load()
         x, w_ih, w_hh = _f32(x), _f32(w_ih), _f32(w_hh)
         n, H = x.shape[0], w_hh.shape[1]
@@ -621,7 +621,8 @@ class _EncoderLstmFn(torch.autograd.Function):
                                               n, H, stream()), 'stove_lstm_cell_fwd')
         ctx.save_for_backward(x, w_ih, w_hh, gx, hs, cs, *[g for g in ghs if g is not None])
         ctx.num_steps = num_steps
-        return hs.transpose(0, 1)
+        ctx.time_major = bool(time_major)
+        return hs if time_major else hs.transpose(0, 1)
 
     @staticmethod
     def backward(ctx, dhs):
@@ -631,7 +632,7 @@ class _EncoderLstmFn(torch.autograd.Function):
         K = ctx.num_steps
         n, H = x.shape[0], w_hh.shape[1]
         dev = x.device
-        dhs = _f32(dhs.transpose(0, 1))                       # (K, n, H)
+        dhs = _f32(dhs if ctx.time_major else dhs.transpose(0, 1))                       # (K, n, H)
         with torch.cuda.device(dev):
             dgx = torch.empty_like(gx)
             # gate gradients of steps 1..K-1 are kept ((K-1) x 105 MB at 25 600 frames) so that dW_hh is ONE
@@ -654,8 +655,10 @@ class _EncoderLstmFn(torch.autograd.Function):
             d_wih = _splitk_tn(dgx, x)
             d_b = colsum(dgx)
         dx = torch.mm(dgx, w_ih) if ctx.needs_input_grad[0] else None
-        return dx, d_wih, d_whh, d_b, d_b, None
+        return dx, d_wih, d_whh, d_b, d_b, None, None
 
 
-def encoder_lstm(x, w_ih, w_hh, b_ih, b_hh, num_steps):
-    return _EncoderLstmFn.apply(x, w_ih, w_hh, b_ih, b_hh, num_steps)
+def encoder_lstm(x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major=False):
+    """-> hs (n, num_steps, H), or (num_steps, n, H) with time_major=True: the layout the kernels produce; the row-wise
+    head can run on it directly, which saves two 78 MB transposes per step (only its 8-wide output is permuted)."""
+    return _EncoderLstmFn.apply(x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major)

@@ -32,6 +32,8 @@ class RnnStates(nn.Module):
         """frames (-1, c, w, h) -> (-1, num_obj, 8): per-object (mean, std) codes of [sx, sy/sx, x, y]."""
         x = frames.flatten(start_dim=1)
         rnn = self.rnn
-        hs = ops.encoder_lstm(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, self.c.num_obj)
+        hs = ops.encoder_lstm(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, self.c.num_obj,
+                              time_major=True)                       # (num_obj, n, 256), as the LSTM kernels write it
         fc1, fc2 = self.fc1, self.fc2
-        return ops.linear(torch.sigmoid(ops.linear(hs, fc1.weight, fc1.bias)), fc2.weight, fc2.bias)
+        codes = ops.linear(torch.sigmoid(ops.linear(hs, fc1.weight, fc1.bias)), fc2.weight, fc2.bias)
+        return codes.transpose(0, 1)                                 # (n, num_obj, 8): only the small output is permuted
