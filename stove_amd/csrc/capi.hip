@@ -135,9 +135,9 @@ int stove_bgspn_bwd(const StoveSpnTables* t, const float* inputs, const float* m
 }
 
 // ---------------------------------------------------------------- fused scene likelihood
-// saved = [ xw tile | obj_ll (np) | ovl (np) | bg_out (nf) | bg_ell ]
+// saved = [ xw tile | obj_ll (np) | ovl (np) | bg_out (nf) | bg_ell | object-SPN forward state ]
 struct SceneSaved {
-  size_t xw, obj_ll, ovl, bg_out, bg_ell, total;
+  size_t xw, obj_ll, ovl, bg_out, bg_ell, obj_state, total;
 };
 static SceneSaved scene_saved_layout(int nf, int n_obj) {
   const size_t np = (size_t)nf * n_obj;
@@ -147,7 +147,8 @@ static SceneSaved scene_saved_layout(int nf, int n_obj) {
   s.ovl = s.obj_ll + align64(np);
   s.bg_out = s.ovl + align64(np);
   s.bg_ell = s.bg_out + align64(nf);
-  s.total = s.bg_ell + align64(bgspn_fwd_ws_floats(nf));
+  s.obj_state = s.bg_ell + align64(bgspn_fwd_ws_floats(nf));
+  s.total = s.obj_state + align64(objspn_state_floats((int)np));
   return s;
 }
 
@@ -161,7 +162,8 @@ int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z
   const int np = n_frames * n_obj;
   int rc = scene_tile_fwd_any(frames, z, saved + L.xw, n_obj, np, st);
   if (rc) return rc;
-  rc = objspn_forward(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl, np, st);
+  rc = objspn_forward(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl, np, st,
+                      saved + L.obj_state);
   if (rc) return rc;
   rc = bgspn_forward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, st);
   if (rc) return rc;
@@ -203,7 +205,8 @@ int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z
   STOVE_LAUNCH(scene_assemble_bwd_k, dim3((np + 255) / 256), dim3(256), 0, st, dll, z, ws + W.d_obj, ws + W.d_ovl, n_obj, np, overlap_beta);
   STOVE_LAUNCH_CHECK();
   int rc = objspn_backward(saved + L.xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot,
-                           saved + L.obj_ll, ws + W.d_obj, ws + W.dxw, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, st);
+                           saved + L.obj_ll, ws + W.d_obj, ws + W.dxw, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, st,
+                           saved + L.obj_state);
   if (rc) return rc;
   rc = bgspn_backward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, dll,
                       nullptr, nullptr, ws + W.dz_bg, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, st);

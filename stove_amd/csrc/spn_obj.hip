@@ -91,7 +91,7 @@ template <int R, int S, int G, int K>
 __global__ __launch_bounds__(128 * R) void objspn_fwd_k(
     const float* __restrict__ xw, const int* __restrict__ scope, const float* __restrict__ coef,
     const float* __restrict__ wsum, const float* __restrict__ wroot,
-    float* __restrict__ out, float* __restrict__ ovl, int n_samples, int n_batches) {
+    float* __restrict__ out, float* __restrict__ ovl, int n_samples, int n_batches, float* __restrict__ st_save) {
   constexpr int D = 4 * S;
   __shared__ float xch[R * 2 * K * 64];
   __shared__ float part[R * 2 * 64];
@@ -103,6 +103,19 @@ __global__ __launch_bounds__(128 * R) void objspn_fwd_k(
     SideState<S, G, K> st;
     side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3,
                           wsum + (size_t)(r * 2 + side) * G * G * K, st);
+    if (st_save != nullptr) {      // (replica, side) state for the backward: [batch][wave][E1 G | E2 G | acc K | o K][64]
+      float* sp = st_save + ((size_t)b * (R * 2) + wv) * (2 * G + 2 * K) * 64 + lane;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        sp[g * 64] = st.E1[g];
+        sp[(G + g) * 64] = st.E2[g];
+      }
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        sp[(2 * G + s) * 64] = st.acc[s];
+        sp[(2 * G + K + s) * 64] = st.o[s];
+      }
+    }
 #pragma unroll
     for (int s = 0; s < K; ++s) xch[((r * 2 + side) * K + s) * 64 + lane] = st.o[s];
     __syncthreads();
@@ -159,7 +172,8 @@ __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
     const float* __restrict__ xw, const int* __restrict__ scope, const float* __restrict__ coef,
     const float* __restrict__ wsum, const float* __restrict__ wroot,
     const float* __restrict__ out, const float* __restrict__ dout,
-    float* __restrict__ Dscr, float* __restrict__ Sscr, float* __restrict__ Rscr, int n_samples, int n_batches) {
+    float* __restrict__ Dscr, float* __restrict__ Sscr, float* __restrict__ Rscr, int n_samples, int n_batches,
+    const float* __restrict__ st_save) {
   constexpr int D = 4 * S;
   __shared__ float xch[R * 2 * K * 64];
   const int lane = lane_id();
@@ -169,7 +183,21 @@ __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
     const float* tile = xw + (size_t)b * (D * 2 * 64);
     const float* W = wsum + (size_t)(r * 2 + side) * G * G * K;
     SideState<S, G, K> st;
-    side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3, W, st);
+    if (st_save != nullptr) {      // written by objspn_fwd_k: 10 KB per wave instead of re-running leaves + sum node
+      const float* sp = st_save + ((size_t)b * (R * 2) + wv) * (2 * G + 2 * K) * 64 + lane;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        st.E1[g] = sp[g * 64];
+        st.E2[g] = sp[(G + g) * 64];
+      }
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        st.acc[s] = sp[(2 * G + s) * 64];
+        st.o[s] = sp[(2 * G + K + s) * 64];
+      }
+    } else {
+      side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3, W, st);
+    }
 #pragma unroll
     for (int s = 0; s < K; ++s) xch[((r * 2 + side) * K + s) * 64 + lane] = st.o[s];
     __syncthreads();
@@ -541,12 +569,15 @@ int objspn_tile_to_arrays(const float* dxw, const float* marg, float* d_inputs, 
   return 0;
 }
 
+// floats of the optional forward-state dump (per 64-sample batch: 12 waves x 40 values x 64 lanes)
+size_t objspn_state_floats(int n) { return (size_t)((n + 63) / 64) * 12 * 40 * 64; }
+
 int objspn_forward(const float* xw, const int* scope, const float* coef, const float* wsum, const float* wroot,
-                   float* out, float* ovl, int n, hipStream_t st) {
+                   float* out, float* ovl, int n, hipStream_t st, float* st_save = nullptr) {
   const int nb = (n + 63) / 64;
   if (nb == 0) return 0;
   STOVE_LAUNCH((objspn_fwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
-                     xw, scope, coef, wsum, wroot, out, ovl, n, nb);
+                     xw, scope, coef, wsum, wroot, out, ovl, n, nb, st_save);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -564,7 +595,7 @@ size_t objspn_bwd_ws_floats(int n) {
 // dxw: [nb][100][2][64] out.  g_coef/g_wsum/g_wroot: gradients w.r.t. the baked tables (overwritten).
 int objspn_backward(const float* xw, const int* scope, const int* leaf_slot, const float* coef, const float* wsum,
                     const float* wroot, const float* out, const float* dout, float* dxw,
-                    float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n, hipStream_t st) {
+                    float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n, hipStream_t st, const float* st_save = nullptr) {
   const int nb = (n + 63) / 64;
   if (nb == 0) {
     hipMemsetAsync(g_coef, 0, kObjCoefN * 4, st);
@@ -580,7 +611,7 @@ int objspn_backward(const float* xw, const int* scope, const int* leaf_slot, con
   float* pr = pw + (size_t)kObjChunks * kObjWN;
   const int chunks = nb < kObjChunks ? nb : kObjChunks;
   STOVE_LAUNCH((objspn_bwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
-                     xw, scope, coef, wsum, wroot, out, dout, Dscr, Sscr, Rscr, n, nb);
+                     xw, scope, coef, wsum, wroot, out, dout, Dscr, Sscr, Rscr, n, nb, st_save);
   STOVE_LAUNCH_CHECK();
   STOVE_LAUNCH((objspn_pix_k<6, 25, 10, 8>), dim3(grid_for(nb, 4096)), dim3(512), 0, st,
                      xw, Dscr, leaf_slot, coef, dxw, nb);
