@@ -326,10 +326,10 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
     int rc = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSmLdsFloats * sizeof(float)));
     if (rc) return rc;
     if (act != nullptr) {
-      STOVE_LAUNCH(dyn_loop_fwd_small_k<true>, dim3(B), dim3(256), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
+      STOVE_LAUNCH(dyn_loop_fwd_small_k<true>, dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
                    z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps, small_bwd_enabled());
     } else {
-      STOVE_LAUNCH(dyn_loop_fwd_small_k<false>, dim3(B), dim3(256), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
+      STOVE_LAUNCH(dyn_loop_fwd_small_k<false>, dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
                    z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps, 0);
     }
     STOVE_LAUNCH_CHECK();
@@ -371,7 +371,7 @@ int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, co
     int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_bwd_small_k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(kSmBLdsFloats * sizeof(float)));
     if (rc) return rc;
-    STOVE_LAUNCH(dyn_loop_bwd_small_k, dim3(B), dim3(256), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, params,
+    STOVE_LAUNCH(dyn_loop_bwd_small_k, dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, params,
                  const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim, lim_enc, elu, kc);
     STOVE_LAUNCH_CHECK();
     rc = (int)hipFuncSetAttribute((const void*)gnn_dw_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDwLdsFloats * sizeof(float)));
@@ -403,7 +403,7 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
     int rc = (int)hipFuncSetAttribute((const void*)rollout_fwd_small_k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(kSmLdsFloats * sizeof(float)));
     if (rc) return rc;
-    STOVE_LAUNCH(rollout_fwd_small_k, dim3(B), dim3(256), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
+    STOVE_LAUNCH(rollout_fwd_small_k, dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
                  z_last, extra, params, z_pred, zstd, pred, B, num, A < 1 ? 1 : A, N, sin_dim, lim_enc, elu, kc);
     STOVE_LAUNCH_CHECK();
     return 0;

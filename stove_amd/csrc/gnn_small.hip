@@ -18,7 +18,8 @@
 namespace stove {
 
 constexpr int kSmW = W_END;                                   // [layer][K/4][OUT][4]
-constexpr int kSmLdsFloats = kSmW + V_END + 4 * 256 + 16 + 4 * 128 + 16 * 32 + 16;
+constexpr int kSmWaves = 4;     // waves per workgroup; more than 4 halves the register budget (2 waves per SIMD) and the kernels spill
+constexpr int kSmLdsFloats = kSmW + V_END + 4 * 256 + 16 + kSmWaves * 128 + 16 * 32 + 16;
 
 struct SmLds {
   float *W, *V, *PR, *POS, *X1, *R3, *ATT;
@@ -29,8 +30,8 @@ __device__ __forceinline__ SmLds sm_carve(float* base) {
   L.V = L.W + kSmW;
   L.PR = L.V + V_END;        // [4][256]  W_a s_i | W_b s_j | A_a s_i | A_b s_j of every node
   L.POS = L.PR + 4 * 256;    // [4][4]    encoder outputs 0, 1 (the positions the distances use)
-  L.X1 = L.POS + 16;         // [4 waves][R1 act 64 | A1 act 64] of the edge a wave is working on
-  L.R3 = L.X1 + 4 * 128;     // [16][32]  relation outputs by edge row i*N + j
+  L.X1 = L.POS + 16;         // [waves][R1 act 64 | A1 act 64] of the edge a wave is working on
+  L.R3 = L.X1 + kSmWaves * 128;     // [16][32]  relation outputs by edge row i*N + j
   L.ATT = L.R3 + 16 * 32;    // [16]
   return L;
 }
@@ -61,17 +62,18 @@ __device__ __forceinline__ void sm_setup(const SmLds& L, const float* __restrict
 struct SmCfg {
   int N, sin_dim, lim_enc, elu;
   int ne;                // edges of this wave (<= 3), ei/ej their node rows -- constant over the time loop
-  int ei[3], ej[3];
+  int ei[3], ej[3], eq[3];     // eq: index q of the edge (row in the compact saved streams)
   long long* stamps;     // debug: [4 waves][16] cycle stamps of workgroup 0 (normally null)
 };
-// edges (i -> j, i != j) q = 0 .. N(N-1)-1 are dealt out as wave 3 - (q & 3): wave 3, which has no node row when N = 3,
-// gets the first one
+// edges (i -> j, i != j) q = 0 .. N(N-1)-1 are dealt out round-robin from the LAST wave down: the waves without a node
+// row (waves N .. kSmWaves-1) get theirs first, so with N = 3 all six edges run concurrently, one per wave
 __device__ __forceinline__ void sm_edges(SmCfg& cf) {
   const int wv = wave_id();
   cf.ne = 0;
   for (int k = 0; k < 3; ++k) {
-    const int q = 3 - wv + 4 * k;
+    const int q = kSmWaves - 1 - wv + kSmWaves * k;
     cf.ei[k] = cf.ej[k] = 0;
+    cf.eq[k] = q;
     if (q < cf.N * (cf.N - 1)) {
       const int i = q / (cf.N - 1), jj = q % (cf.N - 1);
       cf.ei[k] = i;
@@ -155,7 +157,7 @@ __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_el
 // 32 v_readlane feeding the FMAs through SGPRs (every FMA then waits on the SGPR its readlane has just written).
 template <int K4>
 __device__ __forceinline__ float sm_dotw(const SmW<K4>& W, float x) {
-  __shared__ __attribute__((aligned(16))) float xb[4][32];
+  __shared__ __attribute__((aligned(16))) float xb[kSmWaves][32];
   float* p = xb[wave_id()];
   if (lane_id() < 32) p[lane_id()] = x;        // x[k] is lane k's value (the upper half-wave may hold something else)
   float4 xv[K4];
@@ -271,7 +273,7 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
     if (has_edge) {
       const int i = cf.ei[it], j = cf.ej[it];
       e = i * N + j;
-      eg = (SAVE && act.compact) ? 3 - wv + 4 * it : e;
+      eg = (SAVE && act.compact) ? cf.eq[it] : e;
       w2 = sm_wload<16>(Wl2, 32, o);
       const float dx = L.POS[i * 4] - L.POS[j * 4], dy = L.POS[i * 4 + 1] - L.POS[j * 4 + 1];
       d = dx * dx + dy * dy;
@@ -395,7 +397,7 @@ __device__ __forceinline__ float sm_from_lane(float v, int src_lane) {
 // inference recursion, same contract as dyn_loop_fwd_k (gnn.hip) with G = 1: grid = B sequences
 // =================================================================================================
 template <bool SAVE>
-__global__ __launch_bounds__(256) void dyn_loop_fwd_small_k(
+__global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
     float* __restrict__ z, float* __restrict__ zdyn, float* __restrict__ zdstd, float* __restrict__ mean,
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_small_k(
 // =================================================================================================
 // generative rollout, same contract as rollout_fwd_k (gnn.hip) with G = 1
 // =================================================================================================
-__global__ __launch_bounds__(256) void rollout_fwd_small_k(const float* __restrict__ z_last, const float* __restrict__ extra,
+__global__ __launch_bounds__(64 * kSmWaves) void rollout_fwd_small_k(const float* __restrict__ z_last, const float* __restrict__ extra,
                                                            const float* __restrict__ P, float* __restrict__ z_pred,
                                                            float* __restrict__ zstd, float* __restrict__ pred,
                                                            int B, int num, int A, int N, int sin_dim, int lim_enc, int elu, LoopConst kc) {

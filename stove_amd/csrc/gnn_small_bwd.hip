@@ -38,7 +38,7 @@ __device__ __forceinline__ SmDy sm_dy(float* seq, int N, int Ts, int ts) {
 struct SmBLds {
   float *W, *V, *DSD, *EG, *DD, *POS, *X1, *DP;
 };
-constexpr int kSmBLdsFloats = W_END + V_END + 4 * 32 + 16 * 128 + 16 + 2 * 16 + 4 * 64 + 4 * 256;
+constexpr int kSmBLdsFloats = W_END + V_END + 4 * 32 + 16 * 128 + 16 + 2 * 16 + kSmWaves * 64 + 4 * 256;
 __device__ __forceinline__ SmBLds smb_carve(float* base) {
   SmBLds L;
   L.W = base;
@@ -48,7 +48,7 @@ __device__ __forceinline__ SmBLds smb_carve(float* base) {
   L.DD = L.EG + 16 * 128;     // [16]      dL/d dist of every edge
   L.POS = L.DD + 16;          // [2][4][4] positions (two parities: a fast wave may already write the next step's)
   L.X1 = L.POS + 32;          // [4 waves][E32 32 | dA2pre 32]
-  L.DP = L.X1 + 4 * 64;       // [4][256]  dP rows for the edge-first transpose product
+  L.DP = L.X1 + kSmWaves * 64;       // [4][256]  dP rows for the edge-first transpose product
   return L;
 }
 // transposed layer image (rows = layer inputs, K = layer outputs) -> [K/4][rows][4]
@@ -106,7 +106,7 @@ __device__ __forceinline__ SmBNodeIn smb_node_load(const SmAct& a, int r, int l,
   return n;
 }
 
-__global__ __launch_bounds__(256) void dyn_loop_bwd_small_k(
+__global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     const float* __restrict__ zsup, const float* __restrict__ zsstd, const float* __restrict__ eps, const float* __restrict__ P,
     float* __restrict__ act, const float* __restrict__ dz, const float* __restrict__ dzdyn, const float* __restrict__ dmean,
     const float* __restrict__ dstd, const float* __restrict__ dpred, float* __restrict__ dz1, float* __restrict__ dzsup,
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_small_k(
     for (int it = 0; it < 3; ++it) {
       eR3[it] = eATT[it] = eR2[it] = eA2[it] = eX_lo[it] = eX_hi[it] = 0.0f;
       if (it < cf.ne) {
-        const int q = 3 - wv + 4 * it;
+        const int q = cf.eq[it];
         eR3[it] = a.R3[q * 32 + l];
         eATT[it] = a.ATT[q];
         eR2[it] = a.R2[q * 32 + l];
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_small_k(
 #pragma unroll
       for (int it = 0; it < 3; ++it) {
         if (it >= cf.ne) break;
-        const int i = cf.ei[it], j = cf.ej[it], e = i * N + j, q = 3 - wv + 4 * it;
+        const int i = cf.ei[it], j = cf.ej[it], e = i * N + j, q = cf.eq[it];
         SmW<8> w2 = sm_wload<8>(L.W + W_R2, 32, l);
         const float* Wl = L.W + (h ? W_A1 : W_R1);
         SmW<8> wlo = sm_wload<8>(Wl, 64, l), whi = sm_wload<8>(Wl, 64, l + 32);

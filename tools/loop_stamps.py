@@ -23,7 +23,7 @@ for it in range(3):
     lib.stove_debug_set_stamps(stamps.data_ptr())
     out = ops.dyn_loop(z1, zsup, zsstd, eps, None, image, 2, False, dyn.loop_consts())
     torch.cuda.synchronize()
-    fw = stamps.cpu().view(2, 4, 16).clone()
+    fw = stamps.cpu().view(2, 4, 16).clone()      # [fwd | bwd][wave][phase]
     (out[0].sum() + out[3].sum()).backward()
     torch.cuda.synchronize()
     bw = stamps.cpu().view(2, 4, 16).clone()
