@@ -127,15 +127,19 @@ int stove_gnn_debug_stamps(const float* s_in, const float* params, const float* 
  * z1 (B,N,18) state at t=skip-1 [sx,sy/sx,x,y,vx,vy,latent]; zsup,zsstd (B,Ts,N,6) SuPAIR means/stds for
  * t=skip..T-1; eps (B,Ts,N,18) standard-normal draws; extra (B,Ts,N,sin_dim-16) or NULL.
  * outputs (B,Ts,N,.): z 18, zdyn 16, zdstd 16, mean 18, std 18, pred 32 (NULL to skip). */
-/* act: optional saved activations (stove_dynloop_act_floats() floats, ~11.6 KB per sequence-step at N=3)
- * that let the backward skip its recompute; pass NULL to both calls to recompute instead. */
+/* act: saved activations (stove_dynloop_act_floats() floats, ~9 KB per sequence-step at N=3), written by the forward and
+ * read by the backward.  With 2 <= N <= 4 objects the small-graph kernels run (one wave per node row, csrc/gnn_small*.hip):
+ * act is then REQUIRED by the backward (the layout is a set of per-sequence streams), and the backward consists of a
+ * T-serial data-gradient launch plus a weight-gradient launch over the streams; its workspace is sized by
+ * stove_dynloop_bwd_ws_bytes_ts.  For N > 4 (MFMA kernels of csrc/gnn.hip) act may be NULL in both calls: the backward
+ * then recomputes each step.  STOVE_SMALL_BWD=0 in the environment selects the MFMA backward for small graphs too. */
 size_t stove_dynloop_act_floats(int B, int Ts, int N);
 int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                       const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred,
                       float* act, int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
                       void* stream);
 size_t stove_dynloop_bwd_ws_bytes(int B, int N);
-size_t stove_dynloop_bwd_ws_bytes_ts(int B, int Ts, int N);   /* the one to use: the small-graph backward streams per-step gradients through ws */
+size_t stove_dynloop_bwd_ws_bytes_ts(int B, int Ts, int N);   /* the one to use (covers the streamed per-step gradients) */
 /* upstream gradients dz,dzdyn,dmean,dstd,dpred may each be NULL. */
 int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                       const float* params, const float* z, const float* act, const float* dz, const float* dzdyn,
