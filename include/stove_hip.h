@@ -94,6 +94,13 @@ size_t stove_scene_bwd_ws_bytes(int n_frames, int n_obj);
 int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
                     float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g,
                     void* ws, void* stream);
+/* The same with the parameter-gradient passes (leaf / sum / root table gradients: they only feed the optimiser) on a
+ * second stream, so that they overlap with what the caller enqueues on `stream` next -- in STOVE the latency-bound
+ * backward of the recursion, which leaves most of every CU idle.  dz is complete in `stream` order when the call
+ * returns; *g is complete in `param_stream` order.  param_stream NULL or == stream: identical to stove_scene_bwd. */
+int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
+                    float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g,
+                    void* ws, void* stream, void* param_stream);
 
 /* ---- glimpses + masks alone (supair.py:241-356), for the Supair.patches_from_z /
  * masks_from_z API: patches, marg_patch: (n_frames*n_obj,100); overlap: (n_frames*n_obj,).

@@ -196,7 +196,14 @@ size_t stove_scene_bwd_ws_bytes(int n_frames, int n_obj) { return scene_ws_layou
 int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
                     float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g, void* ws_,
                     void* stream) {
+  return stove_scene_bwd_overlap(t, frames, z, n_frames, n_obj, overlap_beta, saved, dll, dz, g, ws_, stream, stream);
+}
+
+int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
+                            float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g, void* ws_,
+                            void* stream, void* param_stream) {
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t sp = param_stream != nullptr ? (hipStream_t)param_stream : st;
   if (n_frames == 0) return 0;
   float* ws = (float*)ws_;
   const SceneSaved L = scene_saved_layout(n_frames, n_obj);
@@ -206,10 +213,10 @@ int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z
   STOVE_LAUNCH_CHECK();
   int rc = objspn_backward(saved + L.xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot,
                            saved + L.obj_ll, ws + W.d_obj, ws + W.dxw, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, st,
-                           saved + L.obj_state);
+                           saved + L.obj_state, sp);
   if (rc) return rc;
   rc = bgspn_backward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, dll,
-                      nullptr, nullptr, ws + W.dz_bg, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, st);
+                      nullptr, nullptr, ws + W.dz_bg, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, st, sp);
   if (rc) return rc;
   if (n_obj <= 3)
     return scene_bwd_tail<3>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st);

@@ -64,6 +64,18 @@ __device__ __forceinline__ float cover(float q, int n, float* dq) {
 
 }  // namespace stove
 
+// make stream `to` wait for everything enqueued on `from` so far (no-op when they are the same stream)
+namespace stove {
+inline void stream_after(hipStream_t to, hipStream_t from) {
+  if (to == from) return;
+  hipEvent_t ev;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return;
+  hipEventRecord(ev, from);
+  hipStreamWaitEvent(to, ev, 0);
+  hipEventDestroy(ev);          // released by the runtime once the wait has been satisfied
+}
+}  // namespace stove
+
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py `roofline`) ----
 // Off by default (no overhead, no global state touched).  When enabled, every kernel launch is
 // bracketed by two events; stove_profile_report() synchronises them and aggregates by kernel.

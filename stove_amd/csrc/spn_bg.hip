@@ -515,7 +515,8 @@ __global__ void bg_dz_halves_k(const float* __restrict__ dz_part, float* __restr
 int bgspn_backward(const float* frames, const float* marg, const float* z, int n_obj, const int* side, const float* coef,
                    const float* wroot, const float* ell_part, const float* out, const float* dout,
                    float* d_inputs, float* d_marg, float* dz, float* g_coef, float* g_wroot, float* ws,
-                   int n_frames, hipStream_t st) {
+                   int n_frames, hipStream_t st, hipStream_t st_par = nullptr) {
+  if (st_par == nullptr) st_par = st;          // stream of the parameter-gradient reductions (see objspn_backward)
   if (n_frames == 0) {
     hipMemsetAsync(g_coef, 0, sizeof(float) * kBgR * kBgPix * kBgG * 3, st);
     hipMemsetAsync(g_wroot, 0, sizeof(float) * kBgR * kBgG * kBgG, st);
@@ -546,18 +547,19 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
   else
     rc = bg_bwd_launch<8>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T);
   if (rc) return rc;
+  stream_after(st_par, st);                    // gcoef_part of bgspn_bwd_k, rsc of bgspn_root_bwd_k
   if (scene) {
     const int n = n_frames * n_obj * 4;
     STOVE_LAUNCH(bg_dz_halves_k, dim3((n + 255) / 256), dim3(256), 0, st, dz_part, dz, n_frames, n_obj * 4);
     STOVE_LAUNCH_CHECK();
   }
   const int nc = kBgR * kBgPix * kBgG * 3;
-  STOVE_LAUNCH((bgspn_coef_reduce_k<kBgR, kBgG>), dim3((nc + 31) / 32), dim3(256), 0, st, gpart, g_coef, grid);
+  STOVE_LAUNCH((bgspn_coef_reduce_k<kBgR, kBgG>), dim3((nc + 31) / 32), dim3(256), 0, st_par, gpart, g_coef, grid);
   STOVE_LAUNCH_CHECK();
   const int chunks = n_frames < kBgRootChunks ? n_frames : kBgRootChunks;
-  STOVE_LAUNCH((bgspn_rootgrad_k<kBgR, kBgG>), dim3(chunks), dim3(128), 0, st, rsc, rpart, n_frames, chunks);
+  STOVE_LAUNCH((bgspn_rootgrad_k<kBgR, kBgG>), dim3(chunks), dim3(128), 0, st_par, rsc, rpart, n_frames, chunks);
   STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kBgR * kBgG * kBgG + 31) / 32), dim3(256), 0, st, rpart, g_wroot, kBgR * kBgG * kBgG, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kBgR * kBgG * kBgG + 31) / 32), dim3(256), 0, st_par, rpart, g_wroot, kBgR * kBgG * kBgG, chunks, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -595,7 +595,11 @@ size_t objspn_bwd_ws_floats(int n) {
 // dxw: [nb][100][2][64] out.  g_coef/g_wsum/g_wroot: gradients w.r.t. the baked tables (overwritten).
 int objspn_backward(const float* xw, const int* scope, const int* leaf_slot, const float* coef, const float* wsum,
                     const float* wroot, const float* out, const float* dout, float* dxw,
-                    float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n, hipStream_t st, const float* st_save = nullptr) {
+                    float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n, hipStream_t st, const float* st_save = nullptr,
+                    hipStream_t st_par = nullptr) {
+  // st_par: stream of the parameter-gradient passes (default: st).  They only feed the optimiser, so on a second
+  // stream they overlap with whatever the caller enqueues on `st` next (the latency-bound recursion backward).
+  if (st_par == nullptr) st_par = st;
   const int nb = (n + 63) / 64;
   if (nb == 0) {
     hipMemsetAsync(g_coef, 0, kObjCoefN * 4, st);
@@ -613,16 +617,17 @@ int objspn_backward(const float* xw, const int* scope, const int* leaf_slot, con
   STOVE_LAUNCH((objspn_bwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
                      xw, scope, coef, wsum, wroot, out, dout, Dscr, Sscr, Rscr, n, nb, st_save);
   STOVE_LAUNCH_CHECK();
+  stream_after(st_par, st);                    // the parameter passes read Dscr / Sscr / Rscr of objspn_bwd_k
   STOVE_LAUNCH((objspn_pix_k<6, 25, 10, 8>), dim3(grid_for(nb, 4096)), dim3(512), 0, st,
                      xw, Dscr, leaf_slot, coef, dxw, nb);
   STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH((objspn_coefgrad_k<6, 25, 10>), dim3(6 * chunks), dim3(128), 0, st, xw, Dscr, scope, pc, nb, chunks);
+  STOVE_LAUNCH((objspn_coefgrad_k<6, 25, 10>), dim3(6 * chunks), dim3(128), 0, st_par, xw, Dscr, scope, pc, nb, chunks);
   STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH((objspn_wgrad_k<6, 10, 10>), dim3(chunks), dim3(6 * 2 * 10 * 2 + 64), 0, st, Sscr, Rscr, pw, pr, nb, chunks);
+  STOVE_LAUNCH((objspn_wgrad_k<6, 10, 10>), dim3(chunks), dim3(6 * 2 * 10 * 2 + 64), 0, st_par, Sscr, Rscr, pw, pr, nb, chunks);
   STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjCoefN + 31) / 32), dim3(256), 0, st, pc, g_coef, (int)kObjCoefN, chunks, 0);
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjWN + 31) / 32), dim3(256), 0, st, pw, g_wsum, (int)kObjWN, chunks, 0);
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjRootN + 31) / 32), dim3(256), 0, st, pr, g_wroot, (int)kObjRootN, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjCoefN + 31) / 32), dim3(256), 0, st_par, pc, g_coef, (int)kObjCoefN, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjWN + 31) / 32), dim3(256), 0, st_par, pw, g_wsum, (int)kObjWN, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjRootN + 31) / 32), dim3(256), 0, st_par, pr, g_wroot, (int)kObjRootN, chunks, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -5,6 +5,7 @@ workspaces through PyTorch's caching allocator, and raises if the library is mis
 tensors are not on a GPU -- there is no CPU or eager fallback.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -117,6 +118,17 @@ class _BgSpnFn(torch.autograd.Function):
         return d_in, d_m, g_coef, g_wroot, None
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One extra stream per device for work that only feeds the optimiser (parameter-gradient passes)."""
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class _SceneFn(torch.autograd.Function):
     """Supair.likelihood fused (reference supair.py:44-110)."""
 
@@ -154,6 +166,20 @@ class _SceneFn(torch.autograd.Function):
             g.obj_coef, g.obj_wsum, g.obj_wroot, g.bg_coef, g.bg_wroot = [ptr(x) for x in grads]
             ws = _ws(lib.stove_scene_bwd_ws_bytes(nf, n_obj), dev)
             t = _tables(obj=(obj_scope, obj_leaf_slot, oc, ow, orr), bg=(bg_side, bc, bw))
+            if ctx.sink is not None and os.environ.get('STOVE_NO_OVERLAP', '0') != '1':
+                # Flat-arena path: the table gradients only feed the optimiser.  Their passes (and the arena sink) go to a
+                # second stream and overlap with what autograd enqueues next on this one: the recursion's backward,
+                # latency-bound with one sequence per CU.  The main stream waits for them at the end of the backward pass.
+                main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+                check(lib.stove_scene_bwd_overlap(ctypes.byref(t), ptr(frames), ptr(z), nf, n_obj, ctx.beta, ptr(saved), ptr(dll),
+                                                  ptr(dz), ctypes.byref(g), ptr(ws), main.cuda_stream, side.cuda_stream),
+                      'stove_scene_bwd_overlap')
+                with torch.cuda.stream(side):
+                    ctx.sink(grads)
+                for buf in (ws, saved, *grads):
+                    buf.record_stream(side)          # the caching allocator must not hand these out before `side` is done
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_stream(side))
+                return (None, dz, None, None, None, None, None, None, None, None, None, None, None)
             check(lib.stove_scene_bwd(ctypes.byref(t), ptr(frames), ptr(z), nf, n_obj, ctx.beta, ptr(saved), ptr(dll),
                                       ptr(dz), ctypes.byref(g), ptr(ws), stream()), 'stove_scene_bwd')
         if ctx.sink is not None:               # flat parameter arena: table gradients go straight into the bucket
