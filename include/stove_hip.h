@@ -154,6 +154,14 @@ int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, co
                       float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var,
                       float vel_std, float lat_std, void* stream);
 
+/* The same with the weight-gradient work (g_params) on a second stream; the data gradients (dz1, dzsup, dzsstd, dextra) are
+ * complete in `stream` order, g_params in `param_stream` order (see stove_scene_bwd_overlap). */
+int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+                              const float* params, const float* z, const float* act, const float* dz, const float* dzdyn,
+                              const float* dmean, const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd,
+                              float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
+                              float pos_var, float vel_std, float lat_std, void* stream, void* param_stream);
+
 /* ---- Stove.rollout (stove.py:777-861), mean prediction: z_last (B,N,18) [sx,sy,...] ->
  * z_pred (B,num,N,18); zstd (B,num,N,16) and pred (B,num,N,32) optional; extra (B,A,N,E) cycled (t % A). */
 int stove_rollout_fwd(const float* z_last, const float* extra, const float* params, float* z_pred, float* zstd, float* pred,

@@ -366,7 +366,17 @@ int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, co
                       const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd, float* dextra,
                       float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var,
                       float vel_std, float lat_std, void* stream) {
+  return stove_dynloop_bwd_overlap(z1, zsup, zsstd, eps, extra, params, z, act, dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd,
+                                   dextra, g_params, ws, B, Ts, N, sin_dim, lim_enc, elu, pos_var, vel_std, lat_std, stream, stream);
+}
+
+int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+                              const float* params, const float* z, const float* act, const float* dz, const float* dzdyn,
+                              const float* dmean, const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd,
+                              float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
+                              float pos_var, float vel_std, float lat_std, void* stream, void* param_stream) {
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t sp = param_stream != nullptr ? (hipStream_t)param_stream : st;
   if (B == 0 || Ts == 0) return (int)hipErrorInvalidValue;
   if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && (extra == nullptr || dextra == nullptr)))
     return (int)hipErrorInvalidValue;
@@ -383,9 +393,10 @@ int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, co
     STOVE_LAUNCH_CHECK();
     rc = (int)hipFuncSetAttribute((const void*)gnn_dw_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDwLdsFloats * sizeof(float)));
     if (rc) return rc;
-    STOVE_LAUNCH(gnn_dw_small_k, dim3(B), dim3(256), kDwLdsFloats * sizeof(float), st, act, (const float*)dy, gpart, B, Ts, N);
+    stream_after(sp, st);        // the weight-gradient pass reads the dY streams; it only feeds the optimiser (second stream)
+    STOVE_LAUNCH(gnn_dw_small_k, dim3(B), dim3(256), kDwLdsFloats * sizeof(float), sp, act, (const float*)dy, gpart, B, Ts, N);
     STOVE_LAUNCH_CHECK();
-    STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 31) / 32), dim3(256), 0, st, (const float*)gpart, g_params, kGnnGrads, B, 0);
+    STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 31) / 32), dim3(256), 0, sp, (const float*)gpart, g_params, kGnnGrads, B, 0);
     STOVE_LAUNCH_CHECK();
     return 0;
   }
@@ -395,7 +406,8 @@ int stove_dynloop_bwd(const float* z1, const float* zsup, const float* zsstd, co
   STOVE_LAUNCH(dyn_loop_bwd_k, dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, z1, zsup, zsstd, eps, extra, params, z, act,
                      dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, (float*)ws, B, Ts, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
   STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 31) / 32), dim3(256), 0, st, (const float*)ws, g_params, kGnnGrads, nb, 0);
+  stream_after(sp, st);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 31) / 32), dim3(256), 0, sp, (const float*)ws, g_params, kGnnGrads, nb, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -334,6 +334,21 @@ class _DynLoopFn(torch.autograd.Function):
             dextra = torch.empty_like(extra) if extra is not None else None
             g = torch.empty(lib.stove_gnn_grad_floats(), dtype=torch.float32, device=dev)
             ws = _ws(lib.stove_dynloop_bwd_ws_bytes_ts(B, Ts, N), dev)
+            if ctx.sink is not None and os.environ.get('STOVE_NO_OVERLAP', '0') != '1':
+                # weight gradients (only the optimiser reads them) on the second stream, under the encoder's backward GEMMs
+                main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+                check(lib.stove_dynloop_bwd_overlap(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z), ptr(act),
+                                                    ptr(up(dz, z)), ptr(up(dzdyn, z)), ptr(up(dmean, z)), ptr(up(dstd, z)),
+                                                    ptr(up(dpred, z)), ptr(dz1), ptr(dzsup), ptr(dzsstd), ptr(dextra), ptr(g), ptr(ws),
+                                                    B, Ts, N, sd, lim_enc, elu, *consts, main.cuda_stream, side.cuda_stream),
+                      'stove_dynloop_bwd_overlap')
+                with torch.cuda.stream(side):
+                    ctx.sink(g)
+                for buf in (ws, g, act):
+                    if buf is not None:
+                        buf.record_stream(side)
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_stream(side))
+                return (dz1, dzsup, dzsstd, None, dextra) + (None,) * 8
             check(lib.stove_dynloop_bwd(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z), ptr(act),
                                         ptr(up(dz, z)), ptr(up(dzdyn, z)), ptr(up(dmean, z)), ptr(up(dstd, z)),
                                         ptr(up(dpred, z)), ptr(dz1), ptr(dzsup), ptr(dzsstd), ptr(dextra), ptr(g), ptr(ws),
