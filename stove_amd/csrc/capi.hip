@@ -154,19 +154,39 @@ static SceneSaved scene_saved_layout(int nf, int n_obj) {
 
 size_t stove_scene_saved_floats(int n_frames, int n_obj) { return scene_saved_layout(n_frames, n_obj).total; }
 
+// Internal fork stream (one per device, created on first use): the background-SPN chain of a scene call runs on it next
+// to the object-SPN chain -- they are independent until the assemble / tail kernels -- and is joined back before the call
+// returns, so callers see plain single-stream semantics.  STOVE_NO_OVERLAP=1 keeps everything on the caller's stream.
+static hipStream_t scene_fork_stream(hipStream_t st) {
+  static hipStream_t side[16] = {nullptr};
+  static int off = -1;
+  if (off < 0) {
+    const char* e = getenv("STOVE_NO_OVERLAP");
+    off = (e != nullptr && e[0] == '1') ? 1 : 0;
+  }
+  if (off) return st;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return st;
+  if (side[dev] == nullptr && hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking) != hipSuccess) return st;
+  return side[dev];
+}
+
 int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
                     float overlap_beta, float* ll, float* parts, float* saved, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n_frames == 0) return 0;
   const SceneSaved L = scene_saved_layout(n_frames, n_obj);
   const int np = n_frames * n_obj;
+  hipStream_t sb = scene_fork_stream(st);       // background chain (MFMA-bound) next to the object chain (VALU-bound)
+  stream_after(sb, st);                         // fork: inputs are ready in `st` order
   int rc = scene_tile_fwd_any(frames, z, saved + L.xw, n_obj, np, st);
   if (rc) return rc;
   rc = objspn_forward(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl, np, st,
                       saved + L.obj_state);
   if (rc) return rc;
-  rc = bgspn_forward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, st);
+  rc = bgspn_forward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, sb);
   if (rc) return rc;
+  stream_after(st, sb);                         // join
   STOVE_LAUNCH(scene_assemble_fwd_k, dim3((n_frames + 255) / 256), dim3(256), 0, st, saved + L.bg_out, saved + L.obj_ll,
                      saved + L.ovl, z, ll, parts, n_obj, n_frames, overlap_beta, logf(overlap_beta));
   STOVE_LAUNCH_CHECK();
@@ -211,13 +231,16 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
   const int np = n_frames * n_obj;
   STOVE_LAUNCH(scene_assemble_bwd_k, dim3((np + 255) / 256), dim3(256), 0, st, dll, z, ws + W.d_obj, ws + W.d_ovl, n_obj, np, overlap_beta);
   STOVE_LAUNCH_CHECK();
+  hipStream_t sb = scene_fork_stream(st);       // background chain next to the object chain, joined before the tail
+  stream_after(sb, st);
   int rc = objspn_backward(saved + L.xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot,
                            saved + L.obj_ll, ws + W.d_obj, ws + W.dxw, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, st,
                            saved + L.obj_state, sp);
   if (rc) return rc;
   rc = bgspn_backward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, dll,
-                      nullptr, nullptr, ws + W.dz_bg, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, st, sp);
+                      nullptr, nullptr, ws + W.dz_bg, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, sb, sp == st ? sb : sp);
   if (rc) return rc;
+  stream_after(st, sb);                         // join: the tail needs dz_bg (and, without a parameter stream, the bg table grads)
   if (n_obj <= 3)
     return scene_bwd_tail<3>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st);
   if (n_obj <= 6)
