@@ -728,12 +728,14 @@ int stove_match_objects(const float* feat, long long* idx, float* perm, int B, i
   const size_t lds = (size_t)T * N * (F + 1) * sizeof(float);
   if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
-  if (N == 3 && F == 2)
+  // the lane-parallel kernel wins where the serial walk of lane 0 has real work per frame (the greedy matcher, more than
+  // three objects: 580 -> 170 us for six); for three objects and the nearest-slot rules the serial walk is shorter
+  if (mode == 1 || N > 3)
+    STOVE_LAUNCH(match_objects_par_k, dim3(B), dim3(64), lds, st, feat, idx, B, T, N, F, mode);
+  else if (N == 3 && F == 2)
     STOVE_LAUNCH((match_objects_k<3, 2>), dim3(B), dim3(64), lds, st, feat, idx, perm, B, T, N, F, mode);
   else if (N == 3 && F == 5)
     STOVE_LAUNCH((match_objects_k<3, 5>), dim3(B), dim3(64), lds, st, feat, idx, perm, B, T, N, F, mode);
-  else if (N == 6 && F == 2)
-    STOVE_LAUNCH((match_objects_k<6, 2>), dim3(B), dim3(64), lds, st, feat, idx, perm, B, T, N, F, mode);
   else
     STOVE_LAUNCH((match_objects_k<0, 0>), dim3(B), dim3(64), lds, st, feat, idx, perm, B, T, N, F, mode);
   STOVE_LAUNCH_CHECK();
