@@ -161,12 +161,17 @@ class Stove(nn.Module):
         # Without appearance features the whole chain (constrain_zp, matching, gather, fix_supair, velocities) is the
         # fused state pipeline (csrc/state.hip); the PyTorch chain below it is the same computation op by op.
         codes = self.sup.encoder(x.flatten(end_dim=1))
-        fused_state = bool(getattr(c, 'fused_state', True)) and not (c.debug_core_appearance or c.debug_match_appearance)
+        fused_state = bool(getattr(c, 'fused_state', True)) and not c.debug_match_appearance
         if fused_state:
-            zfix, zsup_loop, zsstd_loop, init6, _ = ops.supair_state(
+            zfix, zsup_loop, zsstd_loop, init6, idx = ops.supair_state(
                 codes.flatten(end_dim=1), self.sup.zp_span_low(), n, T, o, skip, c.debug_fix_supair, c.debug_match_objects)
             z_sup = zfix[..., :4]
             obj_appearances = None
+            if c.debug_core_appearance:
+                # appearance embedding of the UNMATCHED slots (as the reference computes it), permuted like the states
+                z_pre, _ = self.sup.constrain_zp(codes.flatten(end_dim=1).detach())
+                app = self.object_embedding(z_pre.view(n, T, o, 4), x_color)
+                obj_appearances = torch.gather(app, 2, idx.unsqueeze(-1).expand(-1, -1, -1, app.shape[-1]))
         else:
             z_sup, z_sup_std = self.sup.constrain_zp(codes.flatten(end_dim=1))
             z_sup, z_sup_std = z_sup.view(n, T, o, 4), z_sup_std.view(n, T, o, 4)
