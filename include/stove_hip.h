@@ -102,6 +102,10 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
                     float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g,
                     void* ws, void* stream, void* param_stream);
 
+/* Stove.object_embedding (stove.py:565-590): emb (n_frames*n_obj, channels) = mean over the 10x10 glimpse of object k of
+ * colour frame x_color (n_frames, channels, 32, 32); z (n_frames*n_obj, 4) = [sx, sy, x, y].  No gradients. */
+int stove_glimpse_mean(const float* x_color, const float* z, float* emb, int n_frames, int n_obj, int channels, void* stream);
+
 /* ---- glimpses + masks alone (supair.py:241-356), for the Supair.patches_from_z /
  * masks_from_z API: patches, marg_patch: (n_frames*n_obj,100); overlap: (n_frames*n_obj,).
  * `tile` is scratch of stove_objspn_tile_floats(n_frames*n_obj) floats. */

@@ -301,4 +301,30 @@ __global__ void scene_finalize_bwd_k(const float* __restrict__ dll, const float*
   for (int e = 0; e < 4; ++e) dz[(size_t)i * 4 + e] = s[e];
 }
 
+// ---- object appearance embedding (Stove.object_embedding, stove.py:565-590): mean colour of every object's glimpse of
+// the colour frame.  thread = (glimpse, channel); the 100 bilinear samples of patches_from_z are taken on the fly, so the
+// (frames x objects x channels x 32 x 32) expansion and the glimpse tensor of the PyTorch path never exist.
+// x_color [n_frames][C][1024], z [n_frames*n_obj][4] = [sx, sy, x, y] -> emb [n_frames*n_obj][C]
+__global__ void glimpse_mean_k(const float* __restrict__ x_color, const float* __restrict__ z, float* __restrict__ emb, int n_patches,
+                               int n_obj, int C) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_patches * C) return;
+  const int patch = t / C, c = t % C;
+  const int f = patch / n_obj;
+  const float zk[4] = {z[(size_t)patch * 4], z[(size_t)patch * 4 + 1], z[(size_t)patch * 4 + 2], z[(size_t)patch * 4 + 3]};
+  const float* img = x_color + ((size_t)f * C + c) * kImg * kImg;
+  float acc = 0.0f;
+  for (int p = 0; p < kPD; ++p) {
+    const PatchPix q = patch_pix(zk, p);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float inb = (a ? q.ty.in1 : q.ty.in0) * (b ? q.tx.in1 : q.tx.in0);
+        if (inb != 0.0f) acc = fmaf((a ? q.ty.t : 1.0f - q.ty.t) * (b ? q.tx.t : 1.0f - q.tx.t), img[(q.ty.i0 + a) * kImg + q.tx.i0 + b], acc);
+      }
+  }
+  emb[t] = acc * (1.0f / kPD);
+}
+
 }  // namespace stove

@@ -223,6 +223,18 @@ def scene_glimpses(frames, z, n_obj):
     return patches, keep
 
 
+@torch.no_grad()
+def glimpse_mean(x_color, z, n_obj):
+    """x_color (nf, C, 32, 32), z (nf*n_obj, 4)=[sx,sy,x,y] -> (nf*n_obj, C): mean colour of every object's glimpse."""
+    lib = _lib.load()
+    x_color, z = _f32(x_color), _f32(z)
+    nf, C = x_color.shape[0], x_color.shape[1]
+    with torch.cuda.device(x_color.device):
+        emb = torch.empty(nf * n_obj, C, dtype=torch.float32, device=x_color.device)
+        check(lib.stove_glimpse_mean(ptr(x_color), ptr(z), ptr(emb), nf, n_obj, C, stream()), 'stove_glimpse_mean')
+    return emb
+
+
 def wave_sum_selftest(x):
     lib = _lib.load()
     x = _f32(x)

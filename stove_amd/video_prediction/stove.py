@@ -148,6 +148,11 @@ class Stove(nn.Module):
     def object_embedding(self, z, x_color):
         """Mean colour of each object's glimpse of the colour frame: (n,T,o,3)."""
         z_patch = self.sup.sy_from_quotient(z[..., :4].detach())
+        c = self.c
+        if x_color.is_cuda and x_color.dtype == torch.float32 and x_color.shape[-1] == 32 and x_color.shape[-2] == 32 \
+                and c.patch_width == 10 and c.patch_height == 10 and not bool(getattr(c, 'align_corners', False)):
+            emb = ops.glimpse_mean(x_color.flatten(end_dim=1), z_patch.flatten(end_dim=2), z.shape[-2])     # one launch
+            return emb.view(*z.shape[:-1], x_color.shape[2])
         patches = self.sup.patches_from_z(x_color.flatten(end_dim=1), z_patch.flatten(end_dim=2))
         return patches.mean((-1, -2)).view(*z.shape[:-1], 3)
 

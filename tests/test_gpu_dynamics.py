@@ -391,3 +391,17 @@ def test_small_graph_recursion_matches_step_kernels(n_obj):
     for k in g1:
         assert err(g1[k], g2[k]) < 2e-3 or float(g2[k].abs().max()) < 1e-9, k
     assert err(z1, z2) < 1e-4
+
+
+def test_object_embedding_kernel_against_grid_sample():
+    """stove_glimpse_mean == mean over patches_from_z (PyTorch affine_grid / grid_sample) of the colour frame."""
+    from stove_amd import ops
+    from stove_amd.video_prediction.stove import Stove
+    st = Stove(make_cfg()).to(DEV)
+    g = torch.Generator(device='cpu').manual_seed(4)
+    nf, o = 37, 3
+    x = torch.rand(nf, 3, 32, 32, generator=g).to(DEV)
+    z = torch.cat([0.1 + 0.5 * torch.rand(nf * o, 2, generator=g), 1.6 * torch.rand(nf * o, 2, generator=g) - 0.8], 1).to(DEV)
+    want = st.sup.patches_from_z(x, z).mean((-1, -2))
+    got = ops.glimpse_mean(x, z, o)
+    assert err(got, want) < 1e-5
