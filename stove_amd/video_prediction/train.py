@@ -20,6 +20,7 @@ from torch import nn
 from torch.utils.data import DataLoader
 
 from ..arena import ParamArena
+from .load_data import DeviceClipLoader
 from ..optim import FlatAdam
 from ..parallel import GradBucket
 from ..utils.utils import ExperimentLogger
@@ -63,8 +64,16 @@ class AbstractTrainer:
 
     @dataloader.setter
     def dataloader(self, train_dataset):
-        self._train_dataset = DataLoader(train_dataset, batch_size=self.c.batch_size, shuffle=True,
-                                         num_workers=self.c.num_workers, drop_last=True)
+        # [amd] the training set lives on the GPU and batches are gathered there (no per-step host collate / PCIe copy)
+        # when it fits the budget; otherwise the reference's DataLoader
+        dev = torch.device(self.c.device)
+        budget = float(getattr(self.c, 'device_dataset_gb', 64.0)) * 2 ** 30
+        if dev.type == 'cuda' and getattr(self.c, 'device_dataset', True) \
+                and DeviceClipLoader.nbytes(train_dataset, self.c.dtype) <= budget:
+            self._train_dataset = DeviceClipLoader(train_dataset, self.c.batch_size, dev, self.c.dtype, shuffle=True, drop_last=True)
+        else:
+            self._train_dataset = DataLoader(train_dataset, batch_size=self.c.batch_size, shuffle=True,
+                                             num_workers=self.c.num_workers, drop_last=True)
 
     # ------------------------------------------------------------------ checkpoints
     def _state(self, epoch, step):

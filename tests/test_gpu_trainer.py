@@ -87,3 +87,29 @@ def test_full_size_properties():
     assert abs(np.mean(es) - e1) < 2e-6 * abs(e1), (np.mean(es), e1)
     gm = torch.stack(gs).mean(0)
     assert float((gm - g1).abs().max()) < 2e-4 * float(g1.abs().max())
+
+
+def test_device_clip_loader_equals_dataloader(tmp_path):
+    """Batches gathered on the GPU from the device-resident dataset == the reference-style host DataLoader's batches."""
+    from torch.utils.data import DataLoader
+    from stove_amd.envs import envs
+    from stove_amd.video_prediction.config import StoveConfig
+    from stove_amd.video_prediction.load_data import DeviceClipLoader, StoveDataset
+    cfg = StoveConfig()
+    cfg.num_episodes, cfg.num_visible, cfg.num_rollout, cfg.frame_step = 5, 6, 3, 2
+    d = envs.synth_sequences('avoidance', 5, 30)
+    data = {'X': np.transpose(d['X'], (0, 1, 3, 4, 2)).astype(np.float64), 'y': d['y'], 'coord_lim': 10, 'r': 1.2,
+            'action': d['action'], 'reward': d['reward'], 'done': np.zeros_like(d['reward']), 'action_space': 9}
+    ds = StoveDataset(cfg, data=data)
+    dev = torch.device('cuda:0')
+    ours = DeviceClipLoader(ds, 7, dev, torch.float32, shuffle=False)
+    ref = DataLoader(ds, batch_size=7, shuffle=False, drop_last=True)
+    assert len(ours) == len(ref)
+    n = 0
+    for a, b in zip(ours, ref):
+        assert set(a) == set(b)
+        for k in a:
+            assert a[k].shape == b[k].shape and a[k].is_cuda
+            assert torch.equal(a[k].cpu(), b[k].float()), k
+        n += 1
+    assert n == len(ref) and n > 3
