@@ -106,6 +106,21 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
  * colour frame x_color (n_frames, channels, 32, 32); z (n_frames*n_obj, 4) = [sx, sy, x, y].  No gradients. */
 int stove_glimpse_mean(const float* x_color, const float* z, float* emb, int n_frames, int n_obj, int channels, void* stream);
 
+/* ---- MPE reconstruction of glimpses by the object SPN (Supair.spn_mpe, supair.py:382-424, with RatSpn.reconstruct,
+ * rat_torch.py:359-372): inputs (n,100) glimpses, no marginalisation.  Every sum node keeps its best child
+ * (argmax_k child_k + log w_k, first on ties); the walk from the root selects one replica and one Gaussian per leaf;
+ * out (n,100) = those components' means on their scopes, clamped to [0,1].  leaf_means: f32 [R*4][25][10], leaf order of
+ * obj_scope.  pick (n,5) int32 = (replica, component of each of its 4 leaves), may be NULL.  `xw`: scratch of
+ * stove_objspn_tile_floats(n) floats.  No gradients. */
+int stove_objspn_mpe(const StoveSpnTables* t, const float* leaf_means, const float* inputs, float* xw, float* out,
+                     int32_t* pick, int n, void* stream);
+
+/* ---- frame rendering (Supair.reconstruct_from_z, supair.py:484-498): out (n_frames,1024) =
+ * clamp(bg + sum_k grid_sample(patch_k, inverse transform of z_k), 0, 1).  bg (1024,), z (n_frames*n_obj,4) = [sx,sy,x,y],
+ * patches (.,100): row (f / frames_per_patch) * n_obj + k; frames_per_patch == 0: the single row 0 for every object. */
+int stove_render_frames(const float* bg, const float* patches, int frames_per_patch, const float* z, float* out, int n_frames,
+                        int n_obj, void* stream);
+
 /* ---- glimpses + masks alone (supair.py:241-356), for the Supair.patches_from_z /
  * masks_from_z API: patches, marg_patch: (n_frames*n_obj,100); overlap: (n_frames*n_obj,).
  * `tile` is scratch of stove_objspn_tile_floats(n_frames*n_obj) floats. */

@@ -482,6 +482,25 @@ def g11_supair_only():
         save(f'g11_supair_only_{tag}', x=x.to(torch.float32), eps=eps, elbo=elbo, z=prop['z'], log_q=prop['log_q'], **gn)
 
 
+def g12_reconstruct():
+    """MPE rendering, supair.py:357-498: max-activation images, per-glimpse MPE patches, rendered frames."""
+    for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
+        c = ref_config(dtype)
+        sup = Supair(c)
+        fill(sup, 'sup.')
+        g = torch.Generator().manual_seed(12)
+        n, t = 2, 3
+        x = (torch.rand(n, t, 1, 32, 32, generator=g, dtype=torch.float64) ** 3).to(dtype)
+        z = crafted_z(n * t, 3, g, dtype).view(n, t, 3, 4)
+        with torch.no_grad():
+            save(f'g12_reconstruct_{tag}', x=x, z=z,
+                 bg_max=sup.spn_max_activation(sup.bg_spn), obj_max=sup.spn_max_activation(sup.obj_spn),
+                 mpe_patches=sup.spn_mpe(z.flatten(end_dim=1), x.flatten(end_dim=1)),
+                 recon_max=sup.reconstruct_from_z(z),
+                 recon_mpe=sup.reconstruct_from_z(z, x, max_activation=False, single_image=False),
+                 recon_mpe_single=sup.reconstruct_from_z(z, x[:, 0], max_activation=False, single_image=True))
+
+
 def g9_optimiser_steps():
     """Three steps of the reference's optimisation recipe (train.py:431-473) on one fixed batch."""
     c = ref_config(torch.float32)
@@ -518,11 +537,11 @@ def g9_optimiser_steps():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7', 'g6b', 'g11', 'g9']
+    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7', 'g6b', 'g11', 'g9', 'g12']
     os.makedirs(OUT, exist_ok=True)
     table = {'g0': g0_envs, 'g1': g1_structures, 'g2': g2_ratspn, 'g3': g3_masks_glimpses,
              'g4': g4_likelihood, 'g5': g5_dynamics, 'g6': g6_matchers, 'g10': g10_units, 'g7': g7_g8_full,
-             'g6b': g6b_volatile, 'g11': g11_supair_only, 'g9': g9_optimiser_steps}
+             'g6b': g6b_volatile, 'g11': g11_supair_only, 'g9': g9_optimiser_steps, 'g12': g12_reconstruct}
     for k in which:
         torch.manual_seed(0)
         np.random.seed(0)

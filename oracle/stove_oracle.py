@@ -148,15 +148,16 @@ def spn_structure(num_dims, seed, num_splits, depth):
             'root': where[root]}
 
 
-def spn_forward(struct, params, prefix, x, marg, num_gauss, num_sums, vmin, vmax):
-    """RatSpn.forward (rat_torch.py:354-357) -> (B, 1).
+def spn_forward(struct, params, prefix, x, marg, num_gauss, num_sums, vmin, vmax, child_values=False):
+    """RatSpn.forward (rat_torch.py:354-357) -> (B, 1); with child_values also the per-sum-vector
+    `child + log w` tensors (B, children, sums) of compute_activations(get_sum_child_acts=True), :333-352.
 
     params[prefix + 'vector_list.L.i.{means,sigma_params,params}'] as in the
     reference state dict.  Leaf: rat_torch.py:83-109 (the 'sigma' is a variance);
     product: :147-163; sum: :202-222.
     """
     layers = struct['layers']
-    acts = {}
+    acts, kept = {}, {}
     if marg is not None:
         keep = 1.0 - torch.clamp(marg, 0.0, 1.0)
     for i, scope in enumerate(layers[0]):
@@ -179,8 +180,91 @@ def spn_forward(struct, params, prefix, x, marg, num_gauss, num_sums, vmin, vmax
                 w = params[f'{prefix}vector_list.{li}.{i}.params']
                 logw = torch.log_softmax(w, 0)
                 child = torch.cat([acts[(li - 1, k)] for k in kids], 1)
-                acts[(li, i)] = torch.logsumexp(child.unsqueeze(-1) + logw, 1)
+                kept[(li, i)] = child.unsqueeze(-1) + logw
+                acts[(li, i)] = torch.logsumexp(kept[(li, i)], 1)
+    if child_values:
+        return acts[struct['root']], kept
     return acts[struct['root']]
+
+
+def spn_decode(struct, params, prefix, pick, node=0):
+    """RatSpn.reconstruct(idxs, node, sample=False), rat_torch.py:359-372 with the per-node walks of
+    :126-135 (leaf: component means on its scope), :177-183 (product: node = row * size1 + col, input 0 takes
+    col, input 1 takes row), :224-229 (sum: child index -> walk the concatenated product vectors).
+    `pick[(layer, i)]` = chosen child per sum node of that vector.  Returns the (num_dims,) float64 array."""
+    layers = struct['layers']
+    out = np.zeros(struct['num_dims'])
+
+    def size(li, i):
+        if li == 0:
+            return params[f'{prefix}vector_list.0.{i}.means'].shape[1]
+        if li % 2 == 1:
+            la, ia, lb, ib = layers[li][i]
+            return size(la, ia) * size(lb, ib)
+        return params[f'{prefix}vector_list.{li}.{i}.params'].shape[1]
+
+    def walk(li, i, n):
+        if li == 0:
+            out[list(layers[0][i])] = params[f'{prefix}vector_list.0.{i}.means'][:, n].detach().double().numpy()
+        elif li % 2 == 1:
+            la, ia, lb, ib = layers[li][i]
+            s1 = size(la, ia)
+            walk(la, ia, n % s1)
+            walk(lb, ib, n // s1)
+        else:
+            k = int(pick[(li, i)][n])
+            for pi in layers[li][i]:
+                sz = size(li - 1, pi)
+                if k < sz:
+                    return walk(li - 1, pi, k)
+                k -= sz
+    walk(*struct['root'], node)
+    return out
+
+
+def spn_max_activation(struct, params, prefix, dtype):
+    """Supair.spn_max_activation, supair.py:357-380: walk along the largest sum weights; clip to [0, 1]."""
+    pick = {}
+    for li in range(2, len(struct['layers']), 2):
+        for i in range(len(struct['layers'][li])):
+            pick[(li, i)] = np.argmax(params[f'{prefix}vector_list.{li}.{i}.params'].detach().numpy(), 0)
+    return torch.as_tensor(np.clip(spn_decode(struct, params, prefix, pick), 0.0, 1.0)).to(dtype)
+
+
+def spn_mpe(c, params, structs, z, x):
+    """Supair.spn_mpe for the object SPN, supair.py:382-424.  z (nT, o, 4), x (nT, ch, H, W) -> (nT, o, ph*pw):
+    per glimpse, the walk along argmax_k (child_k + log w_k) of every sum node (no marginalisation), clipped."""
+    patches = glimpses(c, x, z.flatten(0, 1))
+    _, kept = spn_forward(structs['obj'], params, 'sup.obj_spn.', patches.flatten(1), None,
+                          c.obj_spn_num_gauss, c.obj_spn_num_sums, c.obj_min_var, c.obj_max_var, child_values=True)
+    rec = []
+    for j in range(patches.shape[0]):
+        pick = {k: np.argmax(v[j].detach().numpy(), 0) for k, v in kept.items()}
+        rec.append(spn_decode(structs['obj'], params, 'sup.obj_spn.', pick))
+    rec = torch.as_tensor(np.clip(np.stack(rec), 0.0, 1.0)).to(z.dtype)
+    return rec.view(x.shape[0], c.num_obj, -1)
+
+
+def reconstruct_from_z(c, params, structs, z, x=None, max_activation=True, single_image=True):
+    """Supair.reconstruct_from_z, supair.py:426-498.  z (n, T, o, >=4) -> frames (n, T, ch, W, H): the background
+    SPN's max-activation image plus every object's patch (max-activation, or the MPE reconstruction of its glimpse
+    of x) pasted through the inverse transform, clamped to [0, 1]."""
+    z = z[..., :4]
+    n, T, o = z.shape[:3]
+    bg = spn_max_activation(structs['bg'], params, 'sup.bg_spn.', z.dtype).view(c.width, c.height)
+    rec = bg.unsqueeze(0).repeat(n * T, 1, 1).unsqueeze(1)
+    if max_activation:
+        patch = spn_max_activation(structs['obj'], params, 'sup.obj_spn.', z.dtype).view(c.patch_width, c.patch_height)
+        patches = patch.expand(n * T, o, c.channels, c.patch_width, c.patch_height)
+    else:
+        z_in, x_in = (z[:, 0], x) if single_image else (z.flatten(0, 1), x.flatten(0, 1))
+        patches = spn_mpe(c, params, structs, z_in, x_in).view(z_in.shape[0], o, c.channels, c.patch_width, c.patch_height)
+        if single_image:
+            patches = patches.unsqueeze(1).repeat(1, T, 1, 1, 1, 1).flatten(0, 1)
+    z_img = z.flatten(0, 1)
+    for k in range(o):
+        rec = rec + _sample(patches[:, k].contiguous(), _theta(_z_inverse(z_img[:, k])), c.width, c.height)
+    return torch.clamp(rec.view(n, T, c.channels, c.width, c.height), 0, 1)
 
 
 def obj_spn_structure(c):

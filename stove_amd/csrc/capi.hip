@@ -260,6 +260,25 @@ int stove_glimpse_mean(const float* x_color, const float* z, float* emb, int n_f
   return 0;
 }
 
+int stove_objspn_mpe(const StoveSpnTables* t, const float* leaf_means, const float* inputs, float* xw, float* out,
+                     int32_t* pick, int n, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = objspn_tile_from_arrays(inputs, nullptr, xw, n, st);
+  if (rc) return rc;
+  return objspn_mpe(xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, leaf_means, out, pick, n, st);
+}
+
+int stove_render_frames(const float* bg, const float* patches, int frames_per_patch, const float* z, float* out, int n_frames,
+                        int n_obj, void* stream) {
+  const long long total = (long long)n_frames * 1024;
+  if (total == 0) return 0;
+  if (frames_per_patch < 0 || n_obj < 0 || (total + 255) / 256 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  STOVE_LAUNCH(render_frames_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bg, patches,
+               frames_per_patch, z, out, n_frames, n_obj);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
 int stove_scene_glimpses(const float* frames, const float* z, int n_frames, int n_obj, float* tile, float* patches,
                          float* keep, void* stream) {
   hipStream_t st = (hipStream_t)stream;

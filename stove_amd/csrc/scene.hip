@@ -327,4 +327,37 @@ __global__ void glimpse_mean_k(const float* __restrict__ x_color, const float* _
   emb[t] = acc * (1.0f / kPD);
 }
 
+// ---- frame rendering (Supair.reconstruct_from_z, supair.py:484-498): out = clamp(bg + sum_k paste(patch_k; z_k), 0, 1) with
+// paste = grid_sample of the 10x10 patch through the inverse transform [[1/sx, 0, -x/sx], [0, 1/sy, -y/sy]] onto the frame.
+// thread = one pixel of one frame.  patches [.][100]: row (f / frames_per_patch) * n_obj + k, or the single row 0 shared by all
+// objects when frames_per_patch == 0 (max-activation rendering).  bg [1024], z [n_frames*n_obj][4], out [n_frames][1024].
+__global__ __launch_bounds__(256) void render_frames_k(const float* __restrict__ bg, const float* __restrict__ patches,
+                                                       int frames_per_patch, const float* __restrict__ z, float* __restrict__ out,
+                                                       int n_frames, int n_obj) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n_frames * kImg * kImg) return;
+  const int f = (int)(t / (kImg * kImg)), pix = (int)(t % (kImg * kImg));
+  const int Y = pix / kImg, X = pix % kImg;
+  const float u = (2.0f * X + 1.0f) * (1.0f / kImg) - 1.0f, v = (2.0f * Y + 1.0f) * (1.0f / kImg) - 1.0f;
+  float acc = bg[pix];
+  for (int k = 0; k < n_obj; ++k) {
+    const float* zk = z + ((size_t)f * n_obj + k) * 4;
+    const float* pt = patches + (frames_per_patch > 0 ? ((size_t)(f / frames_per_patch) * n_obj + k) * kPD : 0);
+    const float gx = (1.0f / zk[0]) * u + (-zk[2] / zk[0]);
+    const float gy = (1.0f / zk[1]) * v + (-zk[3] / zk[1]);
+    const Tap1 tx = make_tap(((gx + 1.0f) * kPatch - 1.0f) * 0.5f, kPatch);
+    const Tap1 ty = make_tap(((gy + 1.0f) * kPatch - 1.0f) * 0.5f, kPatch);
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float inb = (a ? ty.in1 : ty.in0) * (b ? tx.in1 : tx.in0);
+        if (inb != 0.0f) s = fmaf((a ? ty.t : 1.0f - ty.t) * (b ? tx.t : 1.0f - tx.t), pt[(ty.i0 + a) * kPatch + tx.i0 + b], s);
+      }
+    acc += s;
+  }
+  out[t] = fminf(fmaxf(acc, 0.0f), 1.0f);
+}
+
 }  // namespace stove

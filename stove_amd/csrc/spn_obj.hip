@@ -162,6 +162,100 @@ __global__ __launch_bounds__(128 * R) void objspn_fwd_k(
   }
 }
 
+// ---- MPE walk (Supair.spn_mpe, supair.py:382-424; RatSpn.reconstruct, rat_torch.py:359-372 with the node walks of
+// :126-135, :177-183, :224-229).  Per sample: every sum node takes argmax_k(child_k + log w_k) -- taken here on the
+// max-shifted linear products E1 E2 W, which order the same way -- then the walk from the root picks one replica, one sum
+// node per side and one Gaussian per leaf; the output is those components' means on the leaf scopes, clamped to [0, 1].
+// Ties resolve to the first child in the reference's concatenation order (np.argmax): replica-major, then j2*n1 + j1.
+// mu [R*4][S][G] leaf means in the order of `scope`; out [n][4S]; pick [n][5] = (replica, comps of the 4 leaves) or null.
+template <int R, int S, int G, int K>
+__global__ __launch_bounds__(128 * R) void objspn_mpe_k(
+    const float* __restrict__ xw, const int* __restrict__ scope, const float* __restrict__ coef,
+    const float* __restrict__ wsum, const float* __restrict__ wroot, const float* __restrict__ mu,
+    float* __restrict__ out, int* __restrict__ pick, int n_samples, int n_batches) {
+  constexpr int D = 4 * S;
+  __shared__ float xch[R * 2 * K * 64];
+  __shared__ unsigned char best_pair[R * 2 * K * 64];   // per (replica, side) sum node: winning j2*G+j1
+  __shared__ float root_val[R * 64];
+  __shared__ int root_arg[R * 64];
+  __shared__ int chosen[64];                            // r*K*K + j2*K + j1 of the root's winner
+  const int lane = lane_id();
+  const int wv = wave_id();
+  const int r = wv >> 1, side = wv & 1;
+  for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
+    const float* tile = xw + (size_t)b * (D * 2 * 64);
+    SideState<S, G, K> st;
+    const float* W = wsum + (size_t)(r * 2 + side) * G * G * K;
+    side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3, W, st);
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      float bv = -1.0f;
+      int bk = 0;
+#pragma unroll
+      for (int j2 = 0; j2 < G; ++j2)
+#pragma unroll
+        for (int j1 = 0; j1 < G; ++j1) {
+          const float t = st.E1[j1] * st.E2[j2] * W[(j2 * G + j1) * K + s];
+          if (t > bv) { bv = t; bk = j2 * G + j1; }
+        }
+      best_pair[((r * 2 + side) * K + s) * 64 + lane] = (unsigned char)bk;
+      xch[((r * 2 + side) * K + s) * 64 + lane] = st.o[s];
+    }
+    __syncthreads();
+    if (side == 0) {
+      float oB[K];
+#pragma unroll
+      for (int s = 0; s < K; ++s) oB[s] = xch[((r * 2 + 1) * K + s) * 64 + lane];
+      const float mA = vmax<K>(st.o), mB = vmax<K>(oB);
+      const float* wr = wroot + r * K * K;
+      float bv = -1.0f;
+      int bk = 0;
+#pragma unroll
+      for (int j2 = 0; j2 < K; ++j2) {
+        const float eb = __expf(oB[j2] - mB);
+#pragma unroll
+        for (int j1 = 0; j1 < K; ++j1) {
+          const float t = __expf(st.o[j1] - mA) * eb * wr[j2 * K + j1];
+          if (t > bv) { bv = t; bk = j2 * K + j1; }
+        }
+      }
+      root_val[r * 64 + lane] = mA + mB + __logf(bv);
+      root_arg[r * 64 + lane] = bk;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      float bv = root_val[lane];
+      int br = 0;
+#pragma unroll
+      for (int q = 1; q < R; ++q) {
+        const float v = root_val[q * 64 + lane];
+        if (v > bv) { bv = v; br = q; }
+      }
+      chosen[lane] = br * K * K + root_arg[br * 64 + lane];
+    }
+    __syncthreads();
+    const int smp = b * 64 + lane;
+    const int ch = chosen[lane];
+    const int rs = ch / (K * K), nB = (ch % (K * K)) / K, nA = ch % K;     // replica, side-B node (row), side-A node (col)
+    const int pA = best_pair[((rs * 2) * K + nA) * 64 + lane], pB = best_pair[((rs * 2 + 1) * K + nB) * 64 + lane];
+    const int comp[4] = {pA % G, pA / G, pB % G, pB / G};                    // leaf = side * 2 + (0: in1 = col, 1: in2 = row)
+    if (smp < n_samples) {
+      for (int q = wv; q < D; q += 2 * R) {
+        const int L = q / S, i = q % S;
+        const int g = L == 0 ? comp[0] : L == 1 ? comp[1] : L == 2 ? comp[2] : comp[3];
+        const int cell = (rs * 4 + L) * S + i;
+        out[(size_t)smp * D + scope[cell]] = fminf(fmaxf(mu[(size_t)cell * G + g], 0.0f), 1.0f);
+      }
+      if (wv == 0 && pick != nullptr) {
+        int* pk = pick + (size_t)smp * 5;
+        pk[0] = rs;
+        pk[1] = comp[0], pk[2] = comp[1], pk[3] = comp[2], pk[4] = comp[3];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- backward (main): recompute forward, back-propagate to the leaf outputs ---------------
 // dout[sample] = dL/d root, out[sample] = root value saved by the forward.
 // Writes   Dscr[batch][r][4][G][64]        dL/d leaf log-densities
@@ -578,6 +672,16 @@ int objspn_forward(const float* xw, const int* scope, const float* coef, const f
   if (nb == 0) return 0;
   STOVE_LAUNCH((objspn_fwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
                      xw, scope, coef, wsum, wroot, out, ovl, n, nb, st_save);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int objspn_mpe(const float* xw, const int* scope, const float* coef, const float* wsum, const float* wroot, const float* mu,
+               float* out, int* pick, int n, hipStream_t st) {
+  const int nb = (n + 63) / 64;
+  if (nb == 0) return 0;
+  STOVE_LAUNCH((objspn_mpe_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
+                     xw, scope, coef, wsum, wroot, mu, out, pick, n, nb);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -196,6 +196,40 @@ def bgspn_apply(inputs, marg, coef, wroot, side):
     return _BgSpnFn.apply(inputs, marg, coef, wroot, side)
 
 
+@torch.no_grad()
+def objspn_mpe(inputs, leaf_means, coef, wsum, wroot, scope, leaf_slot, return_pick=False):
+    """inputs (n,100) -> MPE reconstructions (n,100) [, pick (n,5) int32 = replica + its 4 leaf components]."""
+    lib = _lib.load()
+    inputs, leaf_means, coef, wsum, wroot = _f32(inputs), _f32(leaf_means), _f32(coef), _f32(wsum), _f32(wroot)
+    n, dev = inputs.shape[0], inputs.device
+    with torch.cuda.device(dev):
+        xw = torch.empty(lib.stove_objspn_tile_floats(n) + 1, dtype=torch.float32, device=dev)
+        out = torch.empty(n, 100, dtype=torch.float32, device=dev)
+        pick = torch.empty(n, 5, dtype=torch.int32, device=dev) if return_pick else None
+        t = _tables(obj=(scope, leaf_slot, coef, wsum, wroot))
+        check(lib.stove_objspn_mpe(ctypes.byref(t), ptr(leaf_means), ptr(inputs), ptr(xw), ptr(out), ptr(pick), n, stream()),
+              'stove_objspn_mpe')
+    return (out, pick) if return_pick else out
+
+
+@torch.no_grad()
+def render_frames(bg, patches, frames_per_patch, z, n_obj):
+    """bg (1024,), patches (., 100), z (nf*n_obj, 4)=[sx,sy,x,y] -> (nf, 1024) = clamp(bg + pasted patches, 0, 1);
+    patch row of (frame f, object k) = (f // frames_per_patch) * n_obj + k, or row 0 for all when frames_per_patch == 0."""
+    lib = _lib.load()
+    bg, patches, z = _f32(bg), _f32(patches), _f32(z)
+    nf, dev = z.shape[0] // n_obj, z.device
+    rows = patches.numel() // 100
+    need = 1 if frames_per_patch == 0 else ((nf + frames_per_patch - 1) // frames_per_patch) * n_obj
+    if bg.numel() != 1024 or rows < need or z.shape[-1] != 4:
+        raise ValueError('render_frames: bad shapes bg %s patches %s z %s' % (tuple(bg.shape), tuple(patches.shape), tuple(z.shape)))
+    with torch.cuda.device(dev):
+        out = torch.empty(nf, 1024, dtype=torch.float32, device=dev)
+        check(lib.stove_render_frames(ptr(bg), ptr(patches), int(frames_per_patch), ptr(z), ptr(out), nf, int(n_obj), stream()),
+              'stove_render_frames')
+    return out
+
+
 def scene_likelihood(frames, z, obj_tabs, bg_tabs, n_obj, beta, sink=None):
     """frames (nf,1024), z (nf*n_obj,4)=[sx,sy,x,y]; obj_tabs=(coef,wsum,wroot,scope,leaf_slot),
     bg_tabs=(coef,wroot,side) -> ll (nf,), parts (nf,3)=(bg, patches, overlap).

@@ -18,6 +18,7 @@ Two shapes have kernels, the two STOVE builds (probabilistic_models.py): the 100
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -79,6 +80,37 @@ class NodeVector(nn.Module):
     def num_params(self):
         return 0
 
+    def reconstruct(self, idxs, node_num, sample):
+        """The input (num_dims,) this node explains best when every sum node below it follows `idxs[vector][node]`
+        (reference rat_torch.py:126-135 leaf, :177-183 product, :224-229 sum): leaves write the mean (or a draw) of
+        the reached component on their scope, everything outside this node's scope stays 0."""
+        out = np.zeros(_num_dims_of(self))
+        todo = [(self, int(node_num))]
+        while todo:
+            vec, n = todo.pop()
+            if isinstance(vec, GaussVector):
+                mu = vec.means[:, n].detach().cpu().double().numpy()
+                if sample:
+                    mu = np.random.normal(mu, np.sqrt(vec.variance()[:, n].detach().cpu().double().numpy()))
+                out[vec.scope] = mu
+            elif isinstance(vec, ProductVector):
+                first = vec.inputs[0].size                  # node = row * first + col: input 0 <- col, input 1 <- row
+                todo += [(vec.inputs[1], n // first), (vec.inputs[0], n % first)]
+            else:
+                k = int(idxs[vec][n])
+                for child in vec.inputs:                    # k indexes the concatenation of the product vectors
+                    if k < child.size:
+                        todo.append((child, k))
+                        break
+                    k -= child.size
+        return out
+
+
+def _num_dims_of(vec):
+    while not isinstance(vec, GaussVector):
+        vec = vec.inputs[0]
+    return vec.num_dims
+
 
 class GaussVector(NodeVector):
     def __init__(self, region, args, name, num_dims=0):
@@ -98,6 +130,10 @@ class GaussVector(NodeVector):
 
     def num_params(self):
         return self.means.numel() + self.sigma_params.numel()
+
+    def variance(self):
+        a = self.args
+        return a.gauss_min_sigma + (a.gauss_max_sigma - a.gauss_min_sigma) * torch.sigmoid(self.sigma_params)
 
 
 class ProductVector(NodeVector):
@@ -182,6 +218,32 @@ class RatSpn(nn.Module):
 
     def num_params(self):
         return sum(v.num_params() for layer in self.vector_list for v in layer)
+
+    def reconstruct(self, idxs, node_num, sample):
+        """Input reached from root node `node_num` by following `idxs` (sum vector -> chosen child per node), leaves giving
+        their component mean (or a draw if `sample`); numpy (num_dims,).  Reference rat_torch.py:359-372."""
+        return self.output_vector.reconstruct(idxs, node_num, sample)
+
+    def max_activation_idxs(self):
+        """{sum vector: argmax child per node by weight} (the `max_idxs` of Supair.spn_max_activation, supair.py:371-372);
+        one device->host copy for all sum vectors."""
+        sums = list(self.get_sum_params().items())
+        flat = torch.cat([p.detach().argmax(0).reshape(-1) for _, p in sums]).cpu().numpy()
+        out, pos = {}, 0
+        for v, p in sums:
+            out[v] = flat[pos:pos + p.shape[1]]
+            pos += p.shape[1]
+        return out
+
+    def mpe(self, inputs, return_pick=False):
+        """Per row of inputs (B, D): the reconstruction along argmax_k(child_k + log w_k) of every sum node, clamped to
+        [0, 1] (what Supair.spn_mpe builds from compute_activations(get_sum_child_acts=True) + reconstruct,
+        supair.py:407-421).  Object-SPN shape only (one kernel, ops.objspn_mpe)."""
+        if self._kind != 'obj':
+            raise NotImplementedError('RatSpn.mpe: gfx950 kernel exists for the object SPN shape only')
+        coef, wsum, wroot, scope, leaf_slot = self.tables()
+        mu = torch.stack([v.means for v in self.vector_list[0]])[self._plan(coef.device)['leaf_order']]
+        return ops.objspn_mpe(inputs, mu.detach(), coef.detach(), wsum.detach(), wroot.detach(), scope, leaf_slot, return_pick)
 
     # ------------------------------------------------------------------ kernel plan
     def _make_plan(self):

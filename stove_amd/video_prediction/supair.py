@@ -7,6 +7,7 @@ both SPN sweeps, patch scaling and the overlap prior, with an analytic backward 
 every SPN parameter.  The stand-alone `patches_from_z` / `masks_from_z` API methods (debug
 plots, appearance embedding; not on the hot path) stay PyTorch-ROCm host code.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -139,9 +140,51 @@ class Supair(nn.Module):
         marg = torch.stack(per_obj, 1)
         return marg.flatten(end_dim=1), bg, marg.flatten(start_dim=2).mean(dim=2)
 
-    def reconstruct_from_z(self, *args, **kwargs):
-        raise NotImplementedError('MPE rendering (reference supair.py:358-501) is visualisation code, '
-                                  'out of the hot-path scope of this build')
+    # ------------------------------------------------------------------ MPE rendering (reference supair.py:357-498)
+    @torch.no_grad()
+    def spn_max_activation(self, spn=None):
+        """Input-independent most probable input of one SPN: follow the largest weight of every sum node from the root
+        and take the means of the Gaussians reached; clipped to [0, 1].  -> (num_dims,).  (supair.py:357-380)"""
+        spn = self.obj_spn if spn is None else spn
+        img = np.clip(spn.reconstruct(spn.max_activation_idxs(), 0, sample=False), 0.0, 1.0)
+        return torch.as_tensor(img, device=self.c.device).type(self.c.dtype)
+
+    @torch.no_grad()
+    def spn_mpe(self, z, x, spn=None):
+        """MPE reconstruction of every object's glimpse.  z (nT, o, >=4) [sx, sy, x, y], x (nT, c, w, h) ->
+        (nT, o, patch pixels): each glimpse is pushed through the SPN, every sum node keeps its strongest child, and the
+        patch is rebuilt from the Gaussian means on that path (supair.py:382-424).  One kernel instead of the
+        reference's per-glimpse Python walk."""
+        spn = self.bg_spn if isinstance(spn, str) and spn == 'bg' else (self.obj_spn if spn is None else spn)
+        if x.shape[0] != z.shape[0]:
+            raise ValueError('x and z need to have same batch_dim.')
+        patches = self.patches_from_z(x, z[..., :4].flatten(end_dim=1))
+        recons = spn.mpe(patches.flatten(start_dim=1))
+        return recons.view(x.shape[0], self.c.num_obj, -1).type(self.c.dtype)
+
+    @torch.no_grad()
+    def reconstruct_from_z(self, z, x=None, max_activation=True, single_image=True):
+        """Render frames from object states: the background SPN's max-activation image plus one patch per object pasted
+        at its (scale, position), clamped to [0, 1].  z (n, T, o, >=4) -> (n, T, c, w, h).
+
+        max_activation=True: every object shows the object SPN's max-activation patch (independent of any image);
+        False: the MPE reconstruction of its glimpse of x -- x (n, T, c, w, h), or with single_image x (n, c, w, h) whose
+        patches (cut at z[:, 0]) are reused for all T frames.  (supair.py:426-498)"""
+        c = self.c
+        z = z[..., :4]
+        n, T, o = z.shape[:3]
+        if c.channels != 1:
+            raise NotImplementedError('reconstruct_from_z: single-channel SPN inputs only (as the reference, supair.py:452-464)')
+        bg = self.spn_max_activation(self.bg_spn)
+        if max_activation:
+            patches, per = self.spn_max_activation(self.obj_spn).view(1, -1), 0
+        else:
+            if x is None:
+                raise ValueError('Need x for reconstructions.')
+            z_in, x_in = (z[:, 0], x) if single_image else (z.flatten(end_dim=1), x.flatten(end_dim=1))
+            patches, per = self.spn_mpe(z_in, x_in, spn=self.obj_spn), (T if single_image else 1)
+        frames = ops.render_frames(bg.float(), patches.float(), per, z.reshape(-1, 4).float(), o)
+        return frames.view(n, T, c.channels, c.width, c.height).type(c.dtype)
 
     # ------------------------------------------------------------------ SuPAIR-only ELBO
     def forward(self, x):

@@ -23,7 +23,7 @@ from ..arena import ParamArena
 from .load_data import DeviceClipLoader
 from ..optim import FlatAdam
 from ..parallel import GradBucket
-from ..utils.utils import ExperimentLogger
+from ..utils.utils import ExperimentLogger, bw_transform
 
 
 class AbstractTrainer:
@@ -118,6 +118,17 @@ class AbstractTrainer:
         lr = max(self.c.learning_rate * np.exp(-step / value), self.c.min_learning_rate)
         for group in optimizer.param_groups:
             group['lr'] = lr
+
+
+def _save_clip(path, frames, fps=24):
+    """frames (T, H, W) uint8 -> path.gif (PIL) or path.npy."""
+    try:
+        from PIL import Image
+    except ImportError:
+        np.save(path + '.npy', frames)
+        return
+    imgs = [Image.fromarray(f, mode='L') for f in frames]
+    imgs[0].save(path + '.gif', save_all=True, append_images=imgs[1:], duration=int(1000 / fps), loop=0)
 
 
 class Trainer(AbstractTrainer):
@@ -303,7 +314,8 @@ class Trainer(AbstractTrainer):
     @torch.no_grad()
     def long_rollout(self, idx=None, actions=None, step_counter=None, num=500):
         """Roll the dynamics out for `num` frames from the first visible frames of a few test
-        sequences and log the position error over time (no GIF rendering in this build)."""
+        sequences, log the position error over time and render real / rollout / reconstruction clips with
+        `reconstruct_from_z` (reference train.py:684-849; GIFs through PIL when it is importable, uint8 .npy otherwise)."""
         self.stove.eval()
         idx = list(idx) if idx is not None else [0, 1]
         ds = self.test_dataset
@@ -323,8 +335,17 @@ class Trainer(AbstractTrainer):
             true = self.init_t(torch.from_numpy(np.stack([ds.total_data[i, nv:nv + avail] for i in idx])))
             err = self.prediction_error(z_pred[:, :avail, :, 2:], true, return_full=True, return_id_swaps=False)
             out.update({k: v.numpy() for k, v in err.items()})
+        z_recon = prop_dict['z']
+        if self.c.channels == 1:
+            real = bw_transform(present) if present.shape[2] != 1 else present
+            clips = {'real': real[:, self.c.skip:],
+                     'rollout': self.stove.reconstruct_from_z(torch.cat([z_recon, z_pred], 1)),
+                     'recon': self.stove.reconstruct_from_z(z_recon)}
+            out.update({'frames_' + k: (255 * v).clamp(0, 255).to(torch.uint8).cpu().numpy() for k, v in clips.items()})
         if self.rank == 0 and not self.c.nolog:
             tag = 'final' if step_counter is None else '{:06d}'.format(step_counter)
             np.save(os.path.join(self.logger.rollout_states_dir, 'rollout_states_{}.npy'.format(tag)), out['z_pred'])
+            for k in [k for k in out if k.startswith('frames_')]:
+                _save_clip(os.path.join(self.logger.rollout_gifs_dir, k[len('frames_'):]), out[k][0, :, 0])
         self.stove.train()
         return out

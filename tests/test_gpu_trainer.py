@@ -1,6 +1,8 @@
 """End-to-end on the GPU through the reference's entry point: model.main.main(sh_args) -> Trainer.train()."""
 import pickle
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -46,6 +48,20 @@ def test_main_train_test_rollout(tmp_path, preset):
     trainer.test(3, 0.0)                         # ELBO + 4-frame rollout errors through the logger
     out = trainer.long_rollout(idx=[0, 1], num=12)
     assert out['z_pred'].shape == (2, 12, 3, 18) and np.isfinite(out['z_pred']).all()
+    # rendered clips (reference train.py:803-815): real frames after `skip`, reconstruction + rollout, reconstruction
+    skip = trainer.c.skip
+    assert out['frames_real'].shape == (2, 6 - skip, 1, 32, 32) and out['frames_real'].dtype == np.uint8
+    assert out['frames_recon'].shape == (2, 6 - skip, 1, 32, 32)
+    assert out['frames_rollout'].shape == (2, 6 - skip + 12, 1, 32, 32)
+    assert (out['frames_rollout'][:, :6 - skip] == out['frames_recon']).all()
+    assert out['frames_recon'].std() > 0
+    # with logging on, the clips land in the experiment's gifs directory
+    trainer.c.nolog = False
+    from stove_amd.utils.utils import ExperimentLogger
+    trainer.logger = ExperimentLogger(trainer.c)
+    trainer.long_rollout(idx=[0], num=3)
+    files = sorted(os.listdir(trainer.logger.rollout_gifs_dir))
+    assert [f.split('.')[0] for f in files] == ['real', 'recon', 'rollout']
 
 
 def test_full_size_properties():

@@ -237,3 +237,22 @@ def test_supair_only_elbo():
             assert abs(float(params[k[3:]].grad.norm()) - float(v)) <= 1e-4 * float(v) + 1e-12, k
             n += 1
     assert n > 60
+
+
+# ---------------------------------------------------------------- G12 MPE rendering
+@pytest.mark.parametrize('tag,dtype,tol', [('f64', torch.float64, 1e-12), ('f32', torch.float32, 1e-6)])
+def test_reconstruct_from_z(tag, dtype, tol):
+    g = load_golden(f'g12_reconstruct_{tag}')
+    c, structs, params = oracle_setup(dtype, requires_grad=False)
+    z, x = t_(g['z'], dtype), t_(g['x'], dtype)
+    assert np.abs(O.spn_max_activation(structs['bg'], params, 'sup.bg_spn.', dtype).numpy() - g['bg_max']).max() < tol
+    assert np.abs(O.spn_max_activation(structs['obj'], params, 'sup.obj_spn.', dtype).numpy() - g['obj_max']).max() < tol
+    mpe = O.spn_mpe(c, params, structs, z.flatten(0, 1), x.flatten(0, 1))
+    assert mpe.shape == g['mpe_patches'].shape
+    assert np.abs(mpe.numpy() - g['mpe_patches']).max() < tol
+    assert len(np.unique(g['mpe_patches'].reshape(-1, 100), axis=0)) > 3        # the walks do depend on the glimpse
+    for key, kw in (('recon_max', {}), ('recon_mpe', dict(x=x, max_activation=False, single_image=False)),
+                    ('recon_mpe_single', dict(x=x[:, 0], max_activation=False, single_image=True))):
+        r = O.reconstruct_from_z(c, params, structs, z, **kw)
+        assert r.shape == g[key].shape and r.dtype == dtype
+        assert np.abs(r.numpy() - g[key]).max() < tol * 10, key
