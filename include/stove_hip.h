@@ -275,6 +275,15 @@ int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, f
 int stove_lstm_cell_bwd(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
                         const float* dc_in, float* dg, float* dc_out, float* dgx_acc, int first, int n, int H, void* stream);
 
+/* ---- output head of RnnStates behind fc1 (encoder.py:53-56: zps = fc2(sigmoid(fc1(output)))).  a1 (rows, H1) = fc1
+ * pre-activations (library GEMM) -> h1 = sigmoid(a1) (rows, H1) and codes (rows, OUT) = h1 W2^T + b2; W2 (OUT, H1).
+ * bwd: dcodes (rows, OUT) -> d_a1 (rows, H1) = dL/d a1 and g_w2b1b2 = [dW2 (OUT*H1) | db1 (H1) | db2 (OUT)] (db1 = column sums
+ * of d_a1, i.e. fc1's bias gradient); ws: stove_head_bwd_ws_floats floats.  H1 <= 64, OUT <= 8.  Fixed summation order. */
+int stove_head_fwd(const float* a1, const float* W2, const float* b2, float* h1, float* codes, int rows, int H1, int OUT, void* stream);
+size_t stove_head_bwd_ws_floats(int rows, int H1, int OUT);
+int stove_head_bwd(const float* dcodes, const float* h1, const float* W2, float* d_a1, float* g_w2b1b2, float* ws, int rows, int H1,
+                   int OUT, void* stream);
+
 /* ---- measurement hooks (bench.py): when enabled, every kernel launch of this library is bracketed by
  * two HIP events recorded on the launch stream.  stove_profile_report() synchronises them, writes
  * "kernel\ttotal_ms\tcount\n" lines into buf and clears the records; returns the bytes needed.

@@ -62,10 +62,11 @@ static inline int nmax_of(int n_obj) { return n_obj <= 3 ? 3 : (n_obj <= 6 ? 6 :
 template <int NMAX>
 static int scene_bwd_tail(const float* frames, const float* z, const float* dxw, const float* d_ovl, float* dzc,
                           const float* dll, const float* obj_ll, const float* dz_bg, float* dz, int n_obj, int np,
-                          hipStream_t st) {
+                          hipStream_t st, hipStream_t bg_stream) {
   const int nb = (np + 63) / 64;
   STOVE_LAUNCH((scene_tile_bwd_k<NMAX>), dim3(nb < 4096 ? nb : 4096), dim3(256), 0, st, frames, z, dxw, d_ovl, dzc, n_obj, np, nb);
   STOVE_LAUNCH_CHECK();
+  stream_after(st, bg_stream);                  // join: only the last kernel needs the background chain's dz_bg
   STOVE_LAUNCH((scene_finalize_bwd_k<NMAX>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, obj_ll, dz_bg, dzc, dz, n_obj, np);
   STOVE_LAUNCH_CHECK();
   return 0;
@@ -213,6 +214,17 @@ static SceneWs scene_ws_layout(int nf, int n_obj) {
 
 size_t stove_scene_bwd_ws_bytes(int n_frames, int n_obj) { return scene_ws_layout(n_frames, n_obj).total * sizeof(float); }
 
+// STOVE_PARAMS_LATE=1 holds the object-SPN table-gradient passes back until dz is out (A/B switch, see below; measured
+// 5.39 vs 5.34 ms per step: underneath the recursion backward they slow it down more than they cost next to pix / tile_bwd)
+static int params_late() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("STOVE_PARAMS_LATE");
+    v = (e != nullptr && e[0] == '1') ? 1 : 0;
+  }
+  return v;
+}
+
 int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
                     float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g, void* ws_,
                     void* stream) {
@@ -233,21 +245,32 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
   STOVE_LAUNCH_CHECK();
   hipStream_t sb = scene_fork_stream(st);       // background chain next to the object chain, joined before the tail
   stream_after(sb, st);
-  int rc = objspn_backward(saved + L.xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot,
-                           saved + L.obj_ll, ws + W.d_obj, ws + W.dxw, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, st,
-                           saved + L.obj_state, sp);
+  int rc = objspn_backward_data(saved + L.xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot,
+                                saved + L.obj_ll, ws + W.d_obj, ws + W.dxw, ws + W.obj, np, st, saved + L.obj_state);
   if (rc) return rc;
+  // The object-SPN table gradients (coefgrad + wgrad + reductions, ~0.5 ms of throughput-bound work) start right behind
+  // their producer on the parameter stream, or (STOVE_PARAMS_LATE=1) only once dz is out.
+  const bool late = sp != st && params_late();
+  if (!late) {
+    stream_after(sp, st);
+    rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, sp);
+    if (rc) return rc;
+  }
   rc = bgspn_backward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, dll,
                       nullptr, nullptr, ws + W.dz_bg, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, sb, sp == st ? sb : sp);
   if (rc) return rc;
-  stream_after(st, sb);                         // join: the tail needs dz_bg (and, without a parameter stream, the bg table grads)
+  // the tail joins `sb` before its last kernel (dz_bg; without a parameter stream also the bg table grads)
   if (n_obj <= 3)
-    return scene_bwd_tail<3>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st);
-  if (n_obj <= 6)
-    return scene_bwd_tail<6>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st);
-  if (n_obj <= 8)
-    return scene_bwd_tail<8>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st);
-  return (int)hipErrorInvalidValue;
+    rc = scene_bwd_tail<3>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st, sb);
+  else if (n_obj <= 6)
+    rc = scene_bwd_tail<6>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st, sb);
+  else if (n_obj <= 8)
+    rc = scene_bwd_tail<8>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st, sb);
+  else
+    rc = (int)hipErrorInvalidValue;
+  if (rc || !late) return rc;
+  stream_after(sp, st);
+  return objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, sp);
 }
 
 int stove_glimpse_mean(const float* x_color, const float* z, float* emb, int n_frames, int n_obj, int channels, void* stream) {
@@ -691,6 +714,49 @@ int stove_elbo_bwd(const float* zs, const float* mean, const float* std_, const 
 }
 
 // ---------------------------------------------------------------- LSTM cell (recognition network)
+// ---------------------------------------------------------------- recognition-network head
+static inline int head_waves(int H1, bool bwd) {
+  const size_t per_wave = (size_t)(64 * (H1 | 1) + (bwd ? 64 * kHeadOut : 0)) * sizeof(float);
+  const int w = (int)((65536 - kHeadHid * kHeadOut * sizeof(float)) / per_wave);
+  return w > 4 ? 4 : w;
+}
+static inline int head_grid(int rows, int nw) {
+  const int tiles = (rows + 63) / 64, blocks = (tiles + nw - 1) / nw;
+  return blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048;
+}
+
+int stove_head_fwd(const float* a1, const float* W2, const float* b2, float* h1, float* codes, int rows, int H1, int OUT, void* stream) {
+  if (H1 < 1 || H1 > kHeadHid || OUT < 1 || OUT > kHeadOut) return (int)hipErrorInvalidValue;
+  if (rows == 0) return 0;
+  const int nw = head_waves(H1, false);
+  STOVE_LAUNCH(head_fwd_k, dim3(head_grid(rows, nw)), dim3(64 * nw), (size_t)(kHeadHid * kHeadOut + nw * 64 * (H1 | 1)) * sizeof(float), (hipStream_t)stream,
+               a1, W2, b2, h1, codes, rows, H1, OUT);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t stove_head_bwd_ws_floats(int rows, int H1, int OUT) {
+  return (size_t)head_grid(rows, head_waves(H1, true)) * (OUT * H1 + H1 + OUT) + 4;
+}
+
+int stove_head_bwd(const float* dcodes, const float* h1, const float* W2, float* d_a1, float* g_w2b1b2, float* ws, int rows, int H1,
+                   int OUT, void* stream) {
+  if (H1 < 1 || H1 > kHeadHid || OUT < 1 || OUT > kHeadOut) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_out = OUT * H1 + H1 + OUT;
+  if (rows == 0) {
+    hipMemsetAsync(g_w2b1b2, 0, sizeof(float) * n_out, st);
+    return 0;
+  }
+  const int nw = head_waves(H1, true), grid = head_grid(rows, nw);
+  STOVE_LAUNCH(head_bwd_k, dim3(grid), dim3(64 * nw), (size_t)(kHeadHid * kHeadOut + nw * (64 * (H1 | 1) + 64 * kHeadOut)) * sizeof(float), st,
+               dcodes, h1, W2, d_a1, ws, rows, H1, OUT);
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH(reduce_chunks_k, dim3((n_out + 31) / 32), dim3(256), 0, st, ws, g_w2b1b2, n_out, grid, 0);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
 int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, float* c, float* h, int n, int H, void* stream) {
   if (n == 0) return 0;
   if (H % 4) return (int)hipErrorInvalidValue;

@@ -395,8 +395,8 @@ __global__ __launch_bounds__(64 * SLOTS) void objspn_pix_k(
     for (int p = slot; p < D; p += SLOTS) {
       const float x = tile[(p * 2) * 64 + lane];
       const float w = tile[(p * 2 + 1) * 64 + lane];
-      const float x2 = x * x, tx = x + x;
-      float dx = 0.0f, dw = 0.0f;
+      // sum_g d_g (a_g x^2 + b_g x + c_g) = x^2 A + x B + C with A = sum d_g a_g, ...: 3 FMAs per (replica, gaussian)
+      float A = 0.0f, Bq = 0.0f, C = 0.0f;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int ls = leaf_slot[r * D + p];          // L*S + i (wave-uniform)
@@ -406,13 +406,13 @@ __global__ __launch_bounds__(64 * SLOTS) void objspn_pix_k(
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const float d = dlp[g * 64];
-          const float a = cf[g * 3], bb = cf[g * 3 + 1], c = cf[g * 3 + 2];
-          dx = fmaf(d, fmaf(a, tx, bb), dx);
-          dw = fmaf(d, fmaf(a, x2, fmaf(bb, x, c)), dw);
+          A = fmaf(d, cf[g * 3], A);
+          Bq = fmaf(d, cf[g * 3 + 1], Bq);
+          C = fmaf(d, cf[g * 3 + 2], C);
         }
       }
-      otile[(p * 2) * 64 + lane] = dx * w;
-      otile[(p * 2 + 1) * 64 + lane] = dw;
+      otile[(p * 2) * 64 + lane] = fmaf(x + x, A, Bq) * w;
+      otile[(p * 2 + 1) * 64 + lane] = fmaf(x, fmaf(x, A, Bq), C);
     }
     __syncthreads();
   }
@@ -697,13 +697,28 @@ size_t objspn_bwd_ws_floats(int n) {
 }
 
 // dxw: [nb][100][2][64] out.  g_coef/g_wsum/g_wroot: gradients w.r.t. the baked tables (overwritten).
-int objspn_backward(const float* xw, const int* scope, const int* leaf_slot, const float* coef, const float* wsum,
-                    const float* wroot, const float* out, const float* dout, float* dxw,
-                    float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n, hipStream_t st, const float* st_save = nullptr,
-                    hipStream_t st_par = nullptr) {
-  // st_par: stream of the parameter-gradient passes (default: st).  They only feed the optimiser, so on a second
-  // stream they overlap with whatever the caller enqueues on `st` next (the latency-bound recursion backward).
-  if (st_par == nullptr) st_par = st;
+// The backward in two parts: `objspn_backward_data` (leaf gradients + dL/d tile, on `st`) and `objspn_backward_params`
+// (table gradients from the scratch the first part left in `ws`; they only feed the optimiser, so a caller may put them on
+// another stream, ordered after the data part, where they overlap with whatever runs on `st` next).
+int objspn_backward_data(const float* xw, const int* scope, const int* leaf_slot, const float* coef, const float* wsum,
+                         const float* wroot, const float* out, const float* dout, float* dxw, float* ws, int n, hipStream_t st,
+                         const float* st_save = nullptr) {
+  const int nb = (n + 63) / 64;
+  if (nb == 0) return 0;
+  float* Dscr = ws;
+  float* Sscr = Dscr + (size_t)nb * kObjD;
+  float* Rscr = Sscr + (size_t)nb * kObjS;
+  STOVE_LAUNCH((objspn_bwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
+                     xw, scope, coef, wsum, wroot, out, dout, Dscr, Sscr, Rscr, n, nb, st_save);
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH((objspn_pix_k<6, 25, 10, 8>), dim3(grid_for(nb, 4096)), dim3(512), 0, st,
+                     xw, Dscr, leaf_slot, coef, dxw, nb);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int objspn_backward_params(const float* xw, const int* scope, float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n,
+                           hipStream_t st) {
   const int nb = (n + 63) / 64;
   if (nb == 0) {
     hipMemsetAsync(g_coef, 0, kObjCoefN * 4, st);
@@ -718,22 +733,23 @@ int objspn_backward(const float* xw, const int* scope, const int* leaf_slot, con
   float* pw = pc + (size_t)kObjChunks * kObjCoefN;
   float* pr = pw + (size_t)kObjChunks * kObjWN;
   const int chunks = nb < kObjChunks ? nb : kObjChunks;
-  STOVE_LAUNCH((objspn_bwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
-                     xw, scope, coef, wsum, wroot, out, dout, Dscr, Sscr, Rscr, n, nb, st_save);
+  STOVE_LAUNCH((objspn_coefgrad_k<6, 25, 10>), dim3(6 * chunks), dim3(128), 0, st, xw, Dscr, scope, pc, nb, chunks);
   STOVE_LAUNCH_CHECK();
-  stream_after(st_par, st);                    // the parameter passes read Dscr / Sscr / Rscr of objspn_bwd_k
-  STOVE_LAUNCH((objspn_pix_k<6, 25, 10, 8>), dim3(grid_for(nb, 4096)), dim3(512), 0, st,
-                     xw, Dscr, leaf_slot, coef, dxw, nb);
+  STOVE_LAUNCH((objspn_wgrad_k<6, 10, 10>), dim3(chunks), dim3(6 * 2 * 10 * 2 + 64), 0, st, Sscr, Rscr, pw, pr, nb, chunks);
   STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH((objspn_coefgrad_k<6, 25, 10>), dim3(6 * chunks), dim3(128), 0, st_par, xw, Dscr, scope, pc, nb, chunks);
-  STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH((objspn_wgrad_k<6, 10, 10>), dim3(chunks), dim3(6 * 2 * 10 * 2 + 64), 0, st_par, Sscr, Rscr, pw, pr, nb, chunks);
-  STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjCoefN + 31) / 32), dim3(256), 0, st_par, pc, g_coef, (int)kObjCoefN, chunks, 0);
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjWN + 31) / 32), dim3(256), 0, st_par, pw, g_wsum, (int)kObjWN, chunks, 0);
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjRootN + 31) / 32), dim3(256), 0, st_par, pr, g_wroot, (int)kObjRootN, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjCoefN + 31) / 32), dim3(256), 0, st, pc, g_coef, (int)kObjCoefN, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjWN + 31) / 32), dim3(256), 0, st, pw, g_wsum, (int)kObjWN, chunks, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjRootN + 31) / 32), dim3(256), 0, st, pr, g_wroot, (int)kObjRootN, chunks, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
+}
+
+int objspn_backward(const float* xw, const int* scope, const int* leaf_slot, const float* coef, const float* wsum,
+                    const float* wroot, const float* out, const float* dout, float* dxw,
+                    float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n, hipStream_t st, const float* st_save = nullptr) {
+  int rc = objspn_backward_data(xw, scope, leaf_slot, coef, wsum, wroot, out, dout, dxw, ws, n, st, st_save);
+  if (rc) return rc;
+  return objspn_backward_params(xw, scope, g_coef, g_wsum, g_wroot, ws, n, st);
 }
 
 }  // namespace stove

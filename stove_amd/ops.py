@@ -638,6 +638,47 @@ def linear(x, weight, bias):
     return out.view(*shape[:-1], weight.shape[0])
 
 
+class _EncoderHeadFn(torch.autograd.Function):
+    """fc2(sigmoid(fc1(h))) of the recognition network (reference encoder.py:53-56) on (rows, 256) LSTM outputs: fc1 and its
+    two gradient products are library GEMMs, everything behind fc1 is one HIP pass each way (csrc/lstm.hip head_*_k)."""
+
+    @staticmethod
+    def forward(ctx, h, w1, b1, w2, b2):
+        lib = _lib.load()
+        rows, H1, OUT = h.shape[0], w1.shape[0], w2.shape[0]
+        a1 = torch.addmm(b1, h, w1.t())
+        h1 = torch.empty_like(a1)
+        codes = torch.empty(rows, OUT, dtype=torch.float32, device=h.device)
+        with torch.cuda.device(h.device):
+            check(lib.stove_head_fwd(ptr(a1), ptr(w2), ptr(b2), ptr(h1), ptr(codes), rows, H1, OUT, stream()), 'stove_head_fwd')
+        ctx.save_for_backward(h, w1, w2, h1)
+        return codes
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        h, w1, w2, h1 = ctx.saved_tensors
+        rows, H1, OUT = h.shape[0], w1.shape[0], w2.shape[0]
+        g = _f32(g)
+        d_a1 = torch.empty_like(h1)
+        small = torch.empty(OUT * H1 + H1 + OUT, dtype=torch.float32, device=h.device)
+        with torch.cuda.device(h.device):
+            ws = torch.empty(lib.stove_head_bwd_ws_floats(rows, H1, OUT), dtype=torch.float32, device=h.device)
+            check(lib.stove_head_bwd(ptr(g), ptr(h1), ptr(w2), ptr(d_a1), ptr(small), ptr(ws), rows, H1, OUT, stream()), 'stove_head_bwd')
+        gh = torch.mm(d_a1, w1) if ctx.needs_input_grad[0] else None
+        gw1 = _splitk_tn(d_a1, h) if ctx.needs_input_grad[1] else None
+        return gh, gw1, small[OUT * H1:OUT * H1 + H1], small[:OUT * H1].view(OUT, H1), small[OUT * H1 + H1:]
+
+
+def encoder_head(h, w1, b1, w2, b2):
+    """(..., 256) -> (..., 8): fc2(sigmoid(fc1(h)))."""
+    shape = h.shape
+    if w1.shape[0] > 64 or w2.shape[0] > 8:
+        return linear(torch.sigmoid(linear(h, w1, b1)), w2, b2)
+    out = _EncoderHeadFn.apply(_f32(h.reshape(-1, shape[-1])), _f32(w1), _f32(b1), _f32(w2), _f32(b2))
+    return out.view(*shape[:-1], w2.shape[0])
+
+
 def _splitk_tn(a, b):
     """a^T @ b for tall a (K, M), b (K, N) with K >> M, N (weight gradients over all frames).
 

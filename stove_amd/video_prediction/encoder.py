@@ -5,7 +5,8 @@ API and parameter names of the reference's model/video_prediction/encoder.py:7-5
 256 -> 50 -> 8).  Because the input is identical at every step, its projection through
 W_ih is computed once (one (nT x 1024) @ (1024 x 1024) GEMM on rocBLAS/hipBLASLt) instead of
 num_obj times; the recurrent part is num_obj small GEMMs, and all gate math between the GEMMs is
-the fused HIP cell of csrc/lstm.hip (`ops.encoder_lstm`), forward and backward.
+the fused HIP cell of csrc/lstm.hip (`ops.encoder_lstm`), forward and backward; behind the fc1 GEMM the head
+(sigmoid, fc2, and in the backward their gradients and bias sums) is one pass each way (`ops.encoder_head`).
 """
 import torch
 import torch.nn as nn
@@ -35,5 +36,5 @@ class RnnStates(nn.Module):
         hs = ops.encoder_lstm(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, self.c.num_obj,
                               time_major=True)                       # (num_obj, n, 256), as the LSTM kernels write it
         fc1, fc2 = self.fc1, self.fc2
-        codes = ops.linear(torch.sigmoid(ops.linear(hs, fc1.weight, fc1.bias)), fc2.weight, fc2.bias)
+        codes = ops.encoder_head(hs, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
         return codes.transpose(0, 1)                                 # (n, num_obj, 8): only the small output is permuted

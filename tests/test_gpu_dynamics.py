@@ -405,3 +405,33 @@ def test_object_embedding_kernel_against_grid_sample():
     want = st.sup.patches_from_z(x, z).mean((-1, -2))
     got = ops.glimpse_mean(x, z, o)
     assert err(got, want) < 1e-5
+
+
+@pytest.mark.parametrize('rows,H1,OUT', [(111, 50, 8), (1, 50, 8), (64, 50, 8), (65, 64, 8), (3 * 25600, 50, 8), (200, 7, 3), (0, 50, 8)])
+def test_encoder_head_kernels(rows, H1, OUT):
+    """fc2(sigmoid(fc1(h))) (reference encoder.py:53-56): fused head pass vs the op-by-op chain in float64."""
+    from stove_amd import ops
+    g = torch.Generator().manual_seed(rows + H1)
+    h = torch.randn(rows, 256, generator=g, dtype=torch.float64)
+    w1 = torch.randn(H1, 256, generator=g, dtype=torch.float64) * 0.1
+    b1 = torch.randn(H1, generator=g, dtype=torch.float64)
+    w2 = torch.randn(OUT, H1, generator=g, dtype=torch.float64) * 0.3
+    b2 = torch.randn(OUT, generator=g, dtype=torch.float64)
+    wout = torch.randn(rows, OUT, generator=g, dtype=torch.float64)
+    ref_in = [t.clone().requires_grad_() for t in (h, w1, b1, w2, b2)]
+    ref = torch.nn.functional.linear(torch.sigmoid(torch.nn.functional.linear(ref_in[0], ref_in[1], ref_in[2])), ref_in[3], ref_in[4])
+    (ref * wout).sum().backward()
+    dev_in = [t.float().to(DEV).requires_grad_() for t in (h, w1, b1, w2, b2)]
+    out = ops.encoder_head(*dev_in)
+    assert out.shape == (rows, OUT)
+    if rows == 0:
+        return
+    assert err(out, ref) < 1e-5
+    (out * wout.float().to(DEV)).sum().backward()
+    for a, b, name in zip(dev_in, ref_in, ('h', 'w1', 'b1', 'w2', 'b2')):
+        assert err(a.grad, b.grad) < (2e-4 if rows > 10000 else 2e-5), name
+    # fixed summation order: bitwise reproducible
+    again = [t.detach().clone().requires_grad_() for t in dev_in]
+    (ops.encoder_head(*again) * wout.float().to(DEV)).sum().backward()
+    for a, b in zip(dev_in, again):
+        assert torch.equal(a.grad, b.grad)
