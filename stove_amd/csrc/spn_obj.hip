@@ -27,6 +27,27 @@ __device__ __forceinline__ float vmax(const float (&v)[N]) {
   return m;
 }
 
+// ---- wave-uniform weight tables held lane-distributed in VGPRs --------------------------------
+// The sum-layer weights of a (replica, side) are wave-uniform and each is used once per batch.  As plain scalar loads the
+// compiler hoists all ~1000 of them out of the batch loop, runs out of SGPRs and parks them in VGPR lanes: one v_writelane
+// plus one v_readlane per weight around ~2700 useful FMAs.  Loading the table with ordinary coalesced vector loads
+// (element i*64 + lane in register i) leaves just the v_readlane, whose SGPR result feeds the FMA directly.
+template <int N>
+struct LaneTable {
+  float v[(N + 63) / 64];
+  __device__ __forceinline__ void load(const float* __restrict__ p, int lane) {
+#pragma unroll
+    for (int i = 0; i < (N + 63) / 64; ++i) v[i] = (i * 64 + lane < N) ? p[i * 64 + lane] : 0.0f;
+  }
+  template <int IDX>
+  __device__ __forceinline__ float get() const {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[IDX / 64]), IDX % 64));
+  }
+  __device__ __forceinline__ float at(int idx) const {      // idx must fold to a constant (fully unrolled callers)
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[idx >> 6]), idx & 63));
+  }
+};
+
 // ---- shared piece: leaves + sum node of one (replica, side) -------------------------------
 template <int S, int G, int K>
 struct SideState {
@@ -38,7 +59,7 @@ struct SideState {
 template <int S, int G, int K>
 __device__ __forceinline__ void side_forward(const float* __restrict__ tile, int lane,
                                              const int* __restrict__ scope, const float* __restrict__ coef,
-                                             const float* __restrict__ W, SideState<S, G, K>& st) {
+                                             const LaneTable<G * G * K>& W, SideState<S, G, K>& st) {
   float ell[2][G];
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
@@ -76,9 +97,8 @@ __device__ __forceinline__ void side_forward(const float* __restrict__ tile, int
 #pragma unroll
     for (int j1 = 0; j1 < G; ++j1) {
       const float t = st.E1[j1] * st.E2[j2];
-      const float* wk = W + (j2 * G + j1) * K;
 #pragma unroll
-      for (int s = 0; s < K; ++s) st.acc[s] = fmaf(t, wk[s], st.acc[s]);
+      for (int s = 0; s < K; ++s) st.acc[s] = fmaf(t, W.at((j2 * G + j1) * K + s), st.acc[s]);
     }
   }
 #pragma unroll
@@ -98,11 +118,12 @@ __global__ __launch_bounds__(128 * R) void objspn_fwd_k(
   const int lane = lane_id();
   const int wv = wave_id();
   const int r = wv >> 1, side = wv & 1;
+  LaneTable<G * G * K> W;
+  W.load(wsum + (size_t)(r * 2 + side) * G * G * K, lane);
   for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
     const float* tile = xw + (size_t)b * (D * 2 * 64);
     SideState<S, G, K> st;
-    side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3,
-                          wsum + (size_t)(r * 2 + side) * G * G * K, st);
+    side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3, W, st);
     if (st_save != nullptr) {      // (replica, side) state for the backward: [batch][wave][E1 G | E2 G | acc K | o K][64]
       float* sp = st_save + ((size_t)b * (R * 2) + wv) * (2 * G + 2 * K) * 64 + lane;
 #pragma unroll
@@ -185,7 +206,8 @@ __global__ __launch_bounds__(128 * R) void objspn_mpe_k(
   for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
     const float* tile = xw + (size_t)b * (D * 2 * 64);
     SideState<S, G, K> st;
-    const float* W = wsum + (size_t)(r * 2 + side) * G * G * K;
+    LaneTable<G * G * K> W;
+    W.load(wsum + (size_t)(r * 2 + side) * G * G * K, lane);
     side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3, W, st);
 #pragma unroll
     for (int s = 0; s < K; ++s) {
@@ -195,7 +217,7 @@ __global__ __launch_bounds__(128 * R) void objspn_mpe_k(
       for (int j2 = 0; j2 < G; ++j2)
 #pragma unroll
         for (int j1 = 0; j1 < G; ++j1) {
-          const float t = st.E1[j1] * st.E2[j2] * W[(j2 * G + j1) * K + s];
+          const float t = st.E1[j1] * st.E2[j2] * W.at((j2 * G + j1) * K + s);
           if (t > bv) { bv = t; bk = j2 * G + j1; }
         }
       best_pair[((r * 2 + side) * K + s) * 64 + lane] = (unsigned char)bk;
@@ -273,9 +295,12 @@ __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
   const int lane = lane_id();
   const int wv = wave_id();
   const int r = wv >> 1, side = wv & 1;
+  LaneTable<G * G * K> W;
+  W.load(wsum + (size_t)(r * 2 + side) * G * G * K, lane);
+  LaneTable<K * K> WR;
+  WR.load(wroot + r * K * K, lane);
   for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
     const float* tile = xw + (size_t)b * (D * 2 * 64);
-    const float* W = wsum + (size_t)(r * 2 + side) * G * G * K;
     SideState<S, G, K> st;
     if (st_save != nullptr) {      // written by objspn_fwd_k: 10 KB per wave instead of re-running leaves + sum node
       const float* sp = st_save + ((size_t)b * (R * 2) + wv) * (2 * G + 2 * K) * 64 + lane;
@@ -310,7 +335,6 @@ __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
     const float go = live ? dout[smp] : 0.0f;
     const float ro = live ? out[smp] : 0.0f;
     const float rho = go * __expf(mO + mP - ro);
-    const float* wr = wroot + r * K * K;
     // g[s] = dL/d o[s] of this side
     float g[K];
 #pragma unroll
@@ -319,12 +343,12 @@ __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
 #pragma unroll
       for (int j2 = 0; j2 < K; ++j2)
 #pragma unroll
-        for (int j1 = 0; j1 < K; ++j1) g[j1] = fmaf(EP[j2], wr[j2 * K + j1], g[j1]);
+        for (int j1 = 0; j1 < K; ++j1) g[j1] = fmaf(EP[j2], WR.at(j2 * K + j1), g[j1]);
     } else {
 #pragma unroll
       for (int j2 = 0; j2 < K; ++j2)
 #pragma unroll
-        for (int j1 = 0; j1 < K; ++j1) g[j2] = fmaf(EP[j1], wr[j2 * K + j1], g[j2]);
+        for (int j1 = 0; j1 < K; ++j1) g[j2] = fmaf(EP[j1], WR.at(j2 * K + j1), g[j2]);
     }
     float gam[K];
 #pragma unroll
@@ -339,10 +363,9 @@ __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
     for (int j2 = 0; j2 < G; ++j2) {
 #pragma unroll
       for (int j1 = 0; j1 < G; ++j1) {
-        const float* wk = W + (j2 * G + j1) * K;
         float t = 0.0f;
 #pragma unroll
-        for (int s = 0; s < K; ++s) t = fmaf(gam[s], wk[s], t);
+        for (int s = 0; s < K; ++s) t = fmaf(gam[s], W.at((j2 * G + j1) * K + s), t);
         d1[j1] = fmaf(st.E2[j2], t, d1[j1]);
         d2[j2] = fmaf(st.E1[j1], t, d2[j2]);
       }
