@@ -39,6 +39,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// Packed fp32 pair: v_pk_fma_f32 does two fp32 FMAs per lane in one VALU slot (full rate on CDNA3/4) when its operands sit in
+// natural register pairs.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
 // One-dimensional bilinear tap pair of torch's grid_sample (align_corners=False, zero padding):
 // pixel coordinate q in an axis of `n` samples -> floor index i0, weights (1-t, t), in-bounds flags.
 struct Tap1 {

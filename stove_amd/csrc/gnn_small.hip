@@ -148,8 +148,7 @@ __device__ __forceinline__ SmW<K4> sm_wload(const float* Wl, int OUT, int o, int
 // Packed fp32 FMA (v_pk_fma_f32: two lanes of fp32 per VGPR pair, full rate on CDNA3/4).  The operands are laid out
 // so that every packed operand is a natural register pair -- (w.x, w.y) and (w.z, w.w) of a float4, an SGPR pair
 // of consecutive readlanes -- otherwise the compiler pays two v_mov per packed instruction.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// (v2f / pk_fma live in common.h)
 
 // y[o] = sum_k W[o][k] x[k].  The activation vector goes through a per-wave LDS scratch and comes back as K/4 broadcast
 // float4 reads (every lane reads the same address: one LDS pass), then K/2 packed FMAs on four independent chains.

@@ -27,11 +27,14 @@ __device__ __forceinline__ float vmax(const float (&v)[N]) {
   return m;
 }
 
-// ---- wave-uniform weight tables held lane-distributed in VGPRs --------------------------------
-// The sum-layer weights of a (replica, side) are wave-uniform and each is used once per batch.  As plain scalar loads the
-// compiler hoists all ~1000 of them out of the batch loop, runs out of SGPRs and parks them in VGPR lanes: one v_writelane
-// plus one v_readlane per weight around ~2700 useful FMAs.  Loading the table with ordinary coalesced vector loads
-// (element i*64 + lane in register i) leaves just the v_readlane, whose SGPR result feeds the FMA directly.
+// ---- wave-uniform weight tables -------------------------------------------------------------------
+// The sum-layer weights of a (replica, side) are wave-uniform and each is used once per batch.  Three ways to feed them:
+//  * plain scalar loads: the compiler hoists all ~1000 out of the batch loop, runs out of SGPRs and parks them in VGPR
+//    lanes -- a v_writelane and a v_readlane per weight around ~2700 useful FMAs (objspn_bwd_k: 0.51 ms);
+//  * lane-distributed in VGPRs (LaneTable): one v_readlane (+ a hazard s_nop) per weight feeding the FMA as an SGPR
+//    operand: 2 VALU slots per weight (0.13 ms);
+//  * the wave's table in LDS (used for the K-wide rows of the sum nodes): broadcast ds_read_b64 of two neighbouring
+//    weights straight into a register pair, one v_pk_fma_f32 per pair: 0.5 VALU slots per weight, the reads on the LDS port.
 template <int N>
 struct LaneTable {
   float v[(N + 63) / 64];
@@ -39,14 +42,19 @@ struct LaneTable {
 #pragma unroll
     for (int i = 0; i < (N + 63) / 64; ++i) v[i] = (i * 64 + lane < N) ? p[i * 64 + lane] : 0.0f;
   }
-  template <int IDX>
-  __device__ __forceinline__ float get() const {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[IDX / 64]), IDX % 64));
-  }
   __device__ __forceinline__ float at(int idx) const {      // idx must fold to a constant (fully unrolled callers)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[idx >> 6]), idx & 63));
   }
 };
+
+// copy a wave-uniform table of N floats (N even) into the wave's LDS slice
+template <int N>
+__device__ __forceinline__ void lds_table_load(float* dst, const float* __restrict__ src, int lane) {
+#pragma unroll
+  for (int i = 0; i < (N + 63) / 64; ++i)
+    if (i * 64 + lane < N) dst[i * 64 + lane] = src[i * 64 + lane];
+}
+__device__ __forceinline__ v2f lds_pair(const float* t, int idx) { return *reinterpret_cast<const v2f*>(t + idx); }
 
 // ---- shared piece: leaves + sum node of one (replica, side) -------------------------------
 template <int S, int G, int K>
@@ -59,7 +67,7 @@ struct SideState {
 template <int S, int G, int K>
 __device__ __forceinline__ void side_forward(const float* __restrict__ tile, int lane,
                                              const int* __restrict__ scope, const float* __restrict__ coef,
-                                             const LaneTable<G * G * K>& W, SideState<S, G, K>& st) {
+                                             const float* W, SideState<S, G, K>& st) {   // W: the wave's LDS table
   float ell[2][G];
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
@@ -90,16 +98,24 @@ __device__ __forceinline__ void side_forward(const float* __restrict__ tile, int
     st.E1[g] = __expf(ell[0][g] - m1);
     st.E2[g] = __expf(ell[1][g] - m2);
   }
+  static_assert(K % 2 == 0, "sum nodes are processed in pairs");
+  v2f acc2[K / 2];
 #pragma unroll
-  for (int s = 0; s < K; ++s) st.acc[s] = 0.0f;
+  for (int s = 0; s < K / 2; ++s) acc2[s] = v2f{0.0f, 0.0f};
 #pragma unroll
   for (int j2 = 0; j2 < G; ++j2) {
 #pragma unroll
     for (int j1 = 0; j1 < G; ++j1) {
       const float t = st.E1[j1] * st.E2[j2];
+      const v2f tt = {t, t};
 #pragma unroll
-      for (int s = 0; s < K; ++s) st.acc[s] = fmaf(t, W.at((j2 * G + j1) * K + s), st.acc[s]);
+      for (int s = 0; s < K / 2; ++s) acc2[s] = pk_fma(tt, lds_pair(W, (j2 * G + j1) * K + 2 * s), acc2[s]);
     }
+  }
+#pragma unroll
+  for (int s = 0; s < K / 2; ++s) {
+    st.acc[2 * s] = acc2[s].x;
+    st.acc[2 * s + 1] = acc2[s].y;
   }
 #pragma unroll
   for (int s = 0; s < K; ++s) st.o[s] = m1 + m2 + __logf(st.acc[s]);
@@ -115,11 +131,12 @@ __global__ __launch_bounds__(128 * R) void objspn_fwd_k(
   constexpr int D = 4 * S;
   __shared__ float xch[R * 2 * K * 64];
   __shared__ float part[R * 2 * 64];
+  __shared__ __attribute__((aligned(16))) float wtab[R * 2][G * G * K];
   const int lane = lane_id();
   const int wv = wave_id();
   const int r = wv >> 1, side = wv & 1;
-  LaneTable<G * G * K> W;
-  W.load(wsum + (size_t)(r * 2 + side) * G * G * K, lane);
+  const float* W = wtab[wv];
+  lds_table_load<G * G * K>(wtab[wv], wsum + (size_t)(r * 2 + side) * G * G * K, lane);
   for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
     const float* tile = xw + (size_t)b * (D * 2 * 64);
     SideState<S, G, K> st;
@@ -200,28 +217,42 @@ __global__ __launch_bounds__(128 * R) void objspn_mpe_k(
   __shared__ float root_val[R * 64];
   __shared__ int root_arg[R * 64];
   __shared__ int chosen[64];                            // r*K*K + j2*K + j1 of the root's winner
+  __shared__ __attribute__((aligned(16))) float wtab[R * 2][G * G * K];
   const int lane = lane_id();
   const int wv = wave_id();
   const int r = wv >> 1, side = wv & 1;
+  const float* W = wtab[wv];
+  lds_table_load<G * G * K>(wtab[wv], wsum + (size_t)(r * 2 + side) * G * G * K, lane);
   for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
     const float* tile = xw + (size_t)b * (D * 2 * 64);
     SideState<S, G, K> st;
-    LaneTable<G * G * K> W;
-    W.load(wsum + (size_t)(r * 2 + side) * G * G * K, lane);
     side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3, W, st);
+    {
+      float bv[K];
+      int bk[K];
 #pragma unroll
-    for (int s = 0; s < K; ++s) {
-      float bv = -1.0f;
-      int bk = 0;
+      for (int s = 0; s < K; ++s) {
+        bv[s] = -1.0f;
+        bk[s] = 0;
+      }
 #pragma unroll
       for (int j2 = 0; j2 < G; ++j2)
 #pragma unroll
         for (int j1 = 0; j1 < G; ++j1) {
-          const float t = st.E1[j1] * st.E2[j2] * W.at((j2 * G + j1) * K + s);
-          if (t > bv) { bv = t; bk = j2 * G + j1; }
+          const float e = st.E1[j1] * st.E2[j2];
+#pragma unroll
+          for (int s2 = 0; s2 < K / 2; ++s2) {
+            const v2f w = lds_pair(W, (j2 * G + j1) * K + 2 * s2);
+            const float t0 = e * w.x, t1 = e * w.y;
+            if (t0 > bv[2 * s2]) { bv[2 * s2] = t0; bk[2 * s2] = j2 * G + j1; }
+            if (t1 > bv[2 * s2 + 1]) { bv[2 * s2 + 1] = t1; bk[2 * s2 + 1] = j2 * G + j1; }
+          }
         }
-      best_pair[((r * 2 + side) * K + s) * 64 + lane] = (unsigned char)bk;
-      xch[((r * 2 + side) * K + s) * 64 + lane] = st.o[s];
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        best_pair[((r * 2 + side) * K + s) * 64 + lane] = (unsigned char)bk[s];
+        xch[((r * 2 + side) * K + s) * 64 + lane] = st.o[s];
+      }
     }
     __syncthreads();
     if (side == 0) {
@@ -295,8 +326,9 @@ __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
   const int lane = lane_id();
   const int wv = wave_id();
   const int r = wv >> 1, side = wv & 1;
-  LaneTable<G * G * K> W;
-  W.load(wsum + (size_t)(r * 2 + side) * G * G * K, lane);
+  __shared__ __attribute__((aligned(16))) float wtab[R * 2][G * G * K];
+  const float* W = wtab[wv];
+  lds_table_load<G * G * K>(wtab[wv], wsum + (size_t)(r * 2 + side) * G * G * K, lane);
   LaneTable<K * K> WR;
   WR.load(wroot + r * K * K, lane);
   for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
@@ -359,13 +391,17 @@ __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
     float d1[G], d2[G];
 #pragma unroll
     for (int j = 0; j < G; ++j) d1[j] = d2[j] = 0.0f;
+    v2f gam2[K / 2];
+#pragma unroll
+    for (int s = 0; s < K / 2; ++s) gam2[s] = v2f{gam[2 * s], gam[2 * s + 1]};
 #pragma unroll
     for (int j2 = 0; j2 < G; ++j2) {
 #pragma unroll
       for (int j1 = 0; j1 < G; ++j1) {
-        float t = 0.0f;
+        v2f tp = gam2[0] * lds_pair(W, (j2 * G + j1) * K);
 #pragma unroll
-        for (int s = 0; s < K; ++s) t = fmaf(gam[s], W.at((j2 * G + j1) * K + s), t);
+        for (int s = 1; s < K / 2; ++s) tp = pk_fma(gam2[s], lds_pair(W, (j2 * G + j1) * K + 2 * s), tp);
+        const float t = tp.x + tp.y;
         d1[j1] = fmaf(st.E2[j2], t, d1[j1]);
         d2[j2] = fmaf(st.E1[j1], t, d2[j2]);
       }
