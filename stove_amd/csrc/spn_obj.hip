@@ -76,6 +76,8 @@ __device__ __forceinline__ void side_forward(const float* __restrict__ tile, int
     for (int g = 0; g < G; ++g) acc[g] = 0.0f;
     const int* sc = scope + l * S;
     const float* cf = coef + l * S * G * 3;
+    // unrolled: as a rolled loop every pixel paid two dependent load latencies (scope index, then x / w) back to back
+#pragma unroll 5
     for (int i = 0; i < S; ++i) {
       const int p = sc[i];
       const float x = tile[(p * 2) * 64 + lane];
