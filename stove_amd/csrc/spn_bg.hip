@@ -259,7 +259,9 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
     float* __restrict__ gcoef_part, int n_frames, const float* __restrict__ T) {
   constexpr int NO = R * 2 * G;
   constexpr int NW = kBgThreads / 64;
-  __shared__ float zred[2][NW * 4][NMAX * 4];
+  // SCENE: d box (= -dL/dw where no clamp fired) of the last NW frames, [slot][pixel of this half]; every NW frames the
+  // block turns them into dz, one wave per frame (see flush below)
+  __shared__ __attribute__((aligned(16))) float dbx[SCENE ? NW : 1][SCENE ? kBgThreads : 1];
   const int half = blockIdx.x % kBgHalves;
   const int p = half * kBgThreads + threadIdx.x;
   const int lane = lane_id(), wv = wave_id();
@@ -281,7 +283,8 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
   // the pixel and the coverage-table entries of the NEXT frame are fetched while the current one is processed: with
   // ~100 frames per block and a dependent global load at the top of every iteration, the load latency was the kernel
   const int fstep = gridDim.x / kBgHalves;
-  float xn = 0.0f, fxn[NMAX], fyn[NMAX], dfxn[NMAX], dfyn[NMAX];
+  const int f0 = blockIdx.x / kBgHalves;
+  float xn = 0.0f, fxn[NMAX], fyn[NMAX];
   auto prefetch = [&](int f) {
     xn = frames[(size_t)f * kBgPix + p];
     if (SCENE) {
@@ -290,25 +293,69 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
         if (k < n_obj) {
           const float* tk = T + ((size_t)f * n_obj + k) * kBgTab;
           fxn[k] = tk[col];
-          dfxn[k] = tk[32 + col];
           fyn[k] = tk[64 + row];
-          dfyn[k] = tk[96 + row];
         }
       }
     }
   };
-  if ((int)(blockIdx.x / kBgHalves) < n_frames) prefetch(blockIdx.x / kBgHalves);
-  for (int f = blockIdx.x / kBgHalves; f < n_frames; f += fstep, ++it) {
+  // dz of the buffered frames.  The d box image of a frame enters the four gradients of object k only through three sums
+  // per image row,  Sx = sum_c d dcover_x(c),  Sxu = sum_c d dcover_x(c) u(c),  Sy = sum_c d cover_x(c)  (the row factors
+  // cover_y, dcover_y, v come out of the column sum), so one wave takes one frame: lane = (row, quarter of the columns),
+  // 8 columns each, then ONE wave reduction per gradient -- instead of twelve 16-lane reductions, an LDS stage and a
+  // workgroup barrier per frame in the pixel-parallel layout above.
+  auto flush = [&](int n_buf, int f_first) {
+    __syncthreads();
+    if (wv < n_buf) {
+      const int f = f_first + wv * fstep;
+      const int r16 = lane >> 2, q = lane & 3;
+      const int rw = half * (kBgThreads / kBgSide) + r16;
+      const float4 da = *reinterpret_cast<const float4*>(&dbx[wv][r16 * kBgSide + q * 8]);
+      const float4 db = *reinterpret_cast<const float4*>(&dbx[wv][r16 * kBgSide + q * 8 + 4]);
+      const float d[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+      const float vrow = (2.0f * rw + 1.0f) * (1.0f / kBgSide) - 1.0f;
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        if (k < n_obj) {
+          const float* tk = T + ((size_t)f * n_obj + k) * kBgTab;
+          const float4 ca = *reinterpret_cast<const float4*>(tk + q * 8), cb = *reinterpret_cast<const float4*>(tk + q * 8 + 4);
+          const float4 ga = *reinterpret_cast<const float4*>(tk + 32 + q * 8), gb = *reinterpret_cast<const float4*>(tk + 32 + q * 8 + 4);
+          const float cx[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+          const float dcx[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+          const float fyk = tk[64 + rw], dfyk = tk[96 + rw];
+          const float isx = tk[128], isy = tk[129], zx = tk[130], zy = tk[131];
+          float Sx = 0.0f, Sxu = 0.0f, Sy = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const float u = (2.0f * (q * 8 + c) + 1.0f) * (1.0f / kBgSide) - 1.0f;
+            const float t = d[c] * dcx[c];
+            Sx += t;
+            Sxu = fmaf(t, u, Sxu);
+            Sy = fmaf(d[c], cx[c], Sy);
+          }
+          // q = ((u - x)/sx + 1) * 16 - 0.5  ->  d q / d(1/sx) etc. carry the factor 0.5 * kBgSide
+          const float hx = -(0.5f * kBgSide) * fyk * isx, hy = -(0.5f * kBgSide) * dfyk * isy * Sy;
+          const float g_sx = wave_sum_lane63(hx * isx * (Sxu - zx * Sx));
+          const float g_sy = wave_sum_lane63(hy * isy * (vrow - zy));
+          const float g_x = wave_sum_lane63(hx * Sx);
+          const float g_y = wave_sum_lane63(hy);
+          if (lane == 63)
+            *reinterpret_cast<float4*>(dz_part + (((size_t)f * kBgHalves + half) * n_obj + k) * 4) = float4{g_sx, g_sy, g_x, g_y};
+        }
+      }
+    }
+    __syncthreads();
+  };
+  if (f0 < n_frames) prefetch(f0);
+  int f_first = f0;
+  for (int f = f0; f < n_frames; f += fstep, ++it) {
     const float x = xn;
     float w, mraw = 0.0f;
     // per-object box factors for the scene backward
-    float fx[NMAX], fy[NMAX], dfx[NMAX], dfy[NMAX];
+    float fx[NMAX], fy[NMAX];
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
       fx[k] = fxn[k];
       fy[k] = fyn[k];
-      dfx[k] = dfxn[k];
-      dfy[k] = dfyn[k];
     }
     if (f + fstep < n_frames) prefetch(f + fstep);
     bool pass = true;
@@ -350,44 +397,16 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
     }
     if (SCENE) {
       // w = 1 - min(1, sum box): d box_k = -dw when no clamp fired
-      const float dbox = pass ? -dw : 0.0f;
-      float* zr = zred[it & 1][wv * 4 + (lane >> 4)];
-      const bool row_last = (lane & 15) == 15;
-#pragma unroll
-      for (int k = 0; k < NMAX; ++k) {
-        if (k < n_obj) {
-          const float* gk = T + ((size_t)f * n_obj + k) * kBgTab + 128;       // 1/sx, 1/sy, x, y
-          const float isx = gk[0], isy = gk[1];
-          const float zk[4] = {0.0f, 0.0f, gk[2], gk[3]};
-          const float u = (2.0f * col + 1.0f) * (1.0f / kBgSide) - 1.0f;
-          const float v = (2.0f * row + 1.0f) * (1.0f / kBgSide) - 1.0f;
-          // q = ((u - x)/sx + 1) * 16 - 0.5
-          const float dqx = dbox * fy[k] * dfx[k] * (0.5f * kBgSide);
-          const float dqy = dbox * fx[k] * dfy[k] * (0.5f * kBgSide);
-          const float g_sx = row_sum_lane15(-dqx * (u - zk[2]) * isx * isx);
-          const float g_sy = row_sum_lane15(-dqy * (v - zk[3]) * isy * isy);
-          const float g_x = row_sum_lane15(-dqx * isx);
-          const float g_y = row_sum_lane15(-dqy * isy);
-          if (row_last) {
-            zr[k * 4] = g_sx;
-            zr[k * 4 + 1] = g_sy;
-            zr[k * 4 + 2] = g_x;
-            zr[k * 4 + 3] = g_y;
-          }
-        }
-      }
-      __syncthreads();
-      if ((int)threadIdx.x < n_obj * 4) {
-        float s = 0.0f;
-#pragma unroll
-        for (int q = 0; q < NW * 4; ++q) s += zred[it & 1][q][threadIdx.x];
-        dz_part[((size_t)f * kBgHalves + half) * n_obj * 4 + threadIdx.x] = s;
-      }
+      const int slot = it % NW;
+      if (slot == 0) f_first = f;
+      dbx[slot][threadIdx.x] = pass ? -dw : 0.0f;
+      if (slot == NW - 1) flush(NW, f_first);
     } else {
       if (d_marg != nullptr) d_marg[(size_t)f * kBgPix + p] = (mraw >= 0.0f && mraw <= 1.0f) ? -dw : 0.0f;
       if (d_inputs != nullptr) d_inputs[(size_t)f * kBgPix + p] = dx * w;
     }
   }
+  if (SCENE && (it % NW) != 0) flush(it % NW, f_first);
   float* o = gcoef_part + ((size_t)blockIdx.x * R * kBgThreads) * G * 3;
 #pragma unroll
   for (int r = 0; r < R; ++r)
