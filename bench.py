@@ -243,6 +243,16 @@ def main():
                 roofline = {'bound': 'hbm', 'kernel': name, 'avg_ms': avg_ms, 'launches': count, 'achieved': ach,
                             'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0, 'traffic': None,
                             'note': 'VALU-bound sweep (~120 flop/B, ridge ~20 flop/B)', 'kernels_ms_per_step': per_step}
+    if roofline is not None and prof:
+        # second kernel family of SURVEY.md section 8d: the SPN / scene sweep (all its launches of one step together) against
+        # HBM with the algorithmic 8200 + 32 N bytes per frame forward + backward
+        spn_ms = sum(v[0] for k, v in prof.items() if k.startswith(('objspn_', 'bgspn_', 'bg_', 'scene_', 'spn_bake'))) / a.profile_steps
+        if spn_ms > 0:
+            alg = (8200 + 32 * cfg.num_obj) * a.batch * (a.frames - 1)
+            ach = alg / (spn_ms * 1e-3) / 1e9
+            roofline['spn_sweep'] = {'bound': 'hbm', 'ms_per_step': round(spn_ms, 4), 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s',
+                                     'frac': ach / 8000.0, 'note': 'launch durations summed (the chains overlap on three streams, so this exceeds their wall time); '
+                                             'fp32-VALU bound: ~120 flop/B against a ridge of ~20 flop/B'}
     if roofline is not None:
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (if present)
         import glob
