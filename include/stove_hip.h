@@ -267,6 +267,12 @@ int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void
 int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad_norm,
                     size_t numel, float lr, float beta1, float beta2, float eps, int step, float max_norm, void* stream);
 
+/* The same step with its constants in device memory, for captured hipGraphs (kernel arguments are frozen at capture, the step
+ * count and the learning-rate schedule are not): hyper = f32[7] = lr, beta1, beta2, eps, 1 - beta1^step, sqrt(1 - beta2^step),
+ * max_norm (read only when grad_norm != NULL). */
+int stove_flat_adam_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad_norm,
+                        size_t numel, const float* hyper, void* stream);
+
 /* ---- gate math of RnnStates' LSTM (encoder.py:43-51, torch.nn.LSTM cell, gate order i,f,g,o); the GEMMs
  * around it stay on rocBLAS.  gx (n,4H): x W_ih^T + b_ih + b_hh; gh (n,4H): h_prev W_hh^T or NULL; c_prev
  * (n,H) or NULL (zero state).  bwd: dh, dc_in (NULL = 0) -> dg (n,4H), dc_out (n,H); dgx_acc (n,4H) gets

@@ -194,6 +194,35 @@ __global__ void flat_adam_k(float* __restrict__ p, const float* __restrict__ g, 
   if (vmax != nullptr) reinterpret_cast<float4*>(vmax)[i] = x4;
 }
 
+// The same step with the constants read from device memory: inside a captured hipGraph kernel arguments are frozen, the
+// step count (bias corrections) and the learning-rate schedule are not.  hyper = [lr, b1, b2, eps, bc1, sqrt_bc2, max_norm].
+__global__ void flat_adam_dev_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                float* __restrict__ vmax, const float* __restrict__ norm, const float* __restrict__ hyper, int n4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], sqrt_bc2 = hyper[5], max_norm = hyper[6];
+  float coef = 1.0f;
+  if (norm != nullptr) coef = fminf(1.0f, max_norm / (norm[0] + 1e-6f));
+  const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+  float4 p4 = reinterpret_cast<float4*>(p)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+  float4 x4 = vmax != nullptr ? reinterpret_cast<float4*>(vmax)[i] : v4;
+  const float step = lr / bc1;
+#define STOVE_ADAM1(c)                                           \
+  {                                                              \
+    const float gg = g4.c * coef;                                \
+    m4.c = m4.c + (1.0f - b1) * (gg - m4.c);                     \
+    v4.c = b2 * v4.c + (1.0f - b2) * gg * gg;                    \
+    x4.c = vmax != nullptr ? fmaxf(x4.c, v4.c) : v4.c;           \
+    p4.c -= step * m4.c / (sqrtf(x4.c) / sqrt_bc2 + eps);        \
+  }
+  STOVE_ADAM1(x) STOVE_ADAM1(y) STOVE_ADAM1(z) STOVE_ADAM1(w)
+#undef STOVE_ADAM1
+  reinterpret_cast<float4*>(p)[i] = p4;
+  reinterpret_cast<float4*>(m)[i] = m4;
+  reinterpret_cast<float4*>(v)[i] = v4;
+  if (vmax != nullptr) reinterpret_cast<float4*>(vmax)[i] = x4;
+}
+
 // out[j] = sum_c part[c][j], fixed order; n4 = n / 4 (split-K partials of the batched weight-gradient GEMMs)
 __global__ void sum_chunks4_k(const float* __restrict__ part, float* __restrict__ out, int n4, int chunks) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

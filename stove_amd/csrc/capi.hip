@@ -628,6 +628,17 @@ int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* ex
   return 0;
 }
 
+int stove_flat_adam_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad_norm,
+                        size_t numel, const float* hyper, void* stream) {
+  if (numel == 0) return 0;
+  if (numel % 4 != 0 || hyper == nullptr) return (int)hipErrorInvalidValue;
+  const int n4 = (int)(numel / 4);
+  STOVE_LAUNCH(flat_adam_dev_k, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq,
+               grad_norm, hyper, n4);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------- SuPAIR state pipeline / ELBO assembly
 static ZpConst zp_const(const float* span_low) {
   ZpConst k;

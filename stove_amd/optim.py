@@ -29,17 +29,37 @@ class FlatAdam(torch.optim.Optimizer):
             for k, flat in self._flat.items():
                 st[k] = self.arena.view_of(p, flat)
 
+    def hyper(self, max_norm=None, step=None):
+        """[lr, beta1, beta2, eps, 1 - beta1^step, sqrt(1 - beta2^step), max_norm] of step `step` (default: the next one),
+        the constants `stove_flat_adam_dev` reads from device memory (captured-graph steps, stove_amd/graphed.py)."""
+        g = self.param_groups[0]
+        t = self._steps + 1 if step is None else step
+        b1, b2 = float(g['betas'][0]), float(g['betas'][1])
+        return [float(g['lr']), b1, b2, float(g['eps']), 1.0 - b1 ** t, (1.0 - b2 ** t) ** 0.5, float(max_norm or 0.0)]
+
     @torch.no_grad()
-    def step(self, closure=None, max_norm=None):
+    def step(self, closure=None, max_norm=None, hyper_dev=None):
         """One step on arena.grad.  `max_norm`: clip_grad_norm_(params, max_norm) applied on the fly (the gradient
-        buffer itself keeps the unclipped values); returns the total gradient norm (device scalar) if clipping."""
+        buffer itself keeps the unclipped values); returns the total gradient norm (device scalar) if clipping.
+        `hyper_dev`: device tensor holding `self.hyper(...)` -- the step then takes its constants from there (and does
+        not advance the host-side step count: the owner of the captured graph does, see count_step)."""
         if closure is not None:
             raise NotImplementedError('closures are not supported')
         ar = self.arena
         ar.check()
         group = self.param_groups[0]
-        self._steps += 1
         norm = None
+        if hyper_dev is not None:
+            with torch.cuda.device(ar.data.device):
+                if max_norm is not None:
+                    norm = torch.linalg.vector_norm(ar.grad).reshape(1)
+                vmax = self._flat.get('max_exp_avg_sq')
+                _lib.check(_lib.load().stove_flat_adam_dev(
+                    ar.data.data_ptr(), ar.grad.data_ptr(), self._flat['exp_avg'].data_ptr(), self._flat['exp_avg_sq'].data_ptr(),
+                    None if vmax is None else vmax.data_ptr(), None if norm is None else norm.data_ptr(), ar.numel,
+                    hyper_dev.data_ptr(), _lib.stream()), 'stove_flat_adam_dev')
+            return norm
+        self._steps += 1
         with torch.cuda.device(ar.data.device):
             if max_norm is not None:
                 norm = torch.linalg.vector_norm(ar.grad).reshape(1)
@@ -50,6 +70,10 @@ class FlatAdam(torch.optim.Optimizer):
                 float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']), self._steps,
                 float(max_norm) if max_norm is not None else 0.0, _lib.stream()), 'stove_flat_adam')
         return norm
+
+    def count_step(self):
+        """A step was applied outside step() (replay of a captured graph)."""
+        self._steps += 1
 
     def state_dict(self):
         for p in self.arena.params:

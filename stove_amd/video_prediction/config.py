@@ -46,6 +46,7 @@ _DEFAULTS = dict(
     fused_dynamics=True,     # run the inference recursion in the persistent HIP time-loop kernel
     fused_state=True,        # constrain_zp / matching / fix_supair / velocities as the fused state pipeline (csrc/state.hip)
     fused_elbo=True,         # log q, transition likelihood and the ELBO means in two launches
+    graph_step=False,        # Trainer: replay the non-logging training steps as one captured hipGraph (stove_amd/graphed.py)
     device_dataset=True,     # Trainer: training set resident on the GPU, batches gathered there (load_data.DeviceClipLoader)
     device_dataset_gb=64.0,  # ... when it needs at most this much HBM
     param_arena=True,        # Trainer: parameters / gradients as views into one flat buffer (stove_amd/arena.py)

@@ -35,6 +35,7 @@ class AbstractTrainer:
             config.plot_every = 1
         self.c = config
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self._graphed = None
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.dataloader = train_dataset
         self.test_dataset = test_dataset
@@ -218,6 +219,20 @@ class Trainer(AbstractTrainer):
         return loss, self.c.debug_reward_factor * weight * loss
 
     # ------------------------------------------------------------------ training
+    def _graph_ok(self, step_counter):
+        """config.graph_step: replay the captured step when nothing but the loss is needed from it."""
+        if not getattr(self.c, 'graph_step', False) or self.world_size > 1 or self.c.action_conditioned:
+            return False
+        if not isinstance(self.optimizer, FlatAdam) or torch.device(self.c.device).type != 'cuda':
+            return False
+        if step_counter % self.c.print_every == 0 or step_counter % self.c.plot_every == 0:
+            return False
+        if self._graphed is None:
+            from ..graphed import GraphedTrainStep
+            self._graphed = GraphedTrainStep(self.stove, self.bucket, self.optimizer, 1 if self.c.debug_gradient_clip else None,
+                                             self.c.supair_only)
+        return True
+
     def train_step(self, data, step_counter):
         """One optimisation step on a batch dict (present_images [, present_actions, present_rewards])."""
         images = self.init_t(data['present_images'])
@@ -254,7 +269,14 @@ class Trainer(AbstractTrainer):
                 step_counter += 1
                 if self.c.debug_anneal_lr:
                     self.adjust_learning_rate(self.optimizer, self.c.debug_anneal_lr, step_counter)
-                elbo, prop_dict, rewards, min_ll, mse_rewards = self.train_step(data, step_counter)
+                if self._graph_ok(step_counter):
+                    # [amd] launch-bound shapes: the whole step replayed as one captured hipGraph (stove_amd/graphed.py);
+                    # steps that log (they read prop_dict) stay eager
+                    elbo = self._graphed(self.init_t(data['present_images']))
+                    prop_dict, rewards, min_ll, mse_rewards = self.stove.prop_dict, None, -1.0 * elbo, torch.zeros(1)
+                else:
+                    elbo, prop_dict, rewards, min_ll, mse_rewards = self.train_step(data, step_counter)
+                    elbo, min_ll = elbo.detach(), min_ll.detach()      # values only from here on: drop the autograd graph
                 if step_counter % self.c.print_every == 0:
                     self.error_and_log(elbo.item(), mse_rewards.item(), min_ll.item(), prop_dict, data, step_counter, now)
                 if step_counter % self.c.save_every == 0:

@@ -1,5 +1,5 @@
 """Host-side enqueue time of one training step vs its GPU time (is the step launch-bound?).
-python tools/host_time.py [batch]"""
+python tools/host_time.py [batch [frames]]"""
 import os
 import sys
 import time
@@ -14,13 +14,14 @@ from stove_amd.optim import FlatAdam  # noqa: E402
 from stove_amd.video_prediction.stove import Stove  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 dev = torch.device('cuda:0')
 cfg = bench.build_config('billiards', dev)
 torch.manual_seed(0)
 model = Stove(cfg).to(dev)
 arena = ParamArena(model, 1)
 opt = FlatAdam(arena, lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)
-x = torch.from_numpy(bench.make_batch('billiards', B, 100, 0)['X']).to(dev).contiguous()
+x = torch.from_numpy(bench.make_batch('billiards', B, 100, 0)['X'])[:, :T].to(dev).contiguous()
 
 
 def step(i):
@@ -47,4 +48,4 @@ for i in range(10):
     t2 = time.perf_counter()
     host.append((f, b, o, t1 - t0, t2 - t0))
 for h in host[-4:]:
-    print('B=%d host fwd %.2f ms  bwd %.2f ms  opt %.2f ms | enqueue total %.2f ms | step incl. GPU %.2f ms' % ((B,) + tuple(1e3 * v for v in h)))
+    print('T=%d ' % T + 'B=%d host fwd %.2f ms  bwd %.2f ms  opt %.2f ms | enqueue total %.2f ms | step incl. GPU %.2f ms' % ((B,) + tuple(1e3 * v for v in h)))

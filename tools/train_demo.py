@@ -1,5 +1,5 @@
 """Training sanity run through the reference's entry point (model.main.main -> Trainer.train) on generated billiards data:
-prints the ELBO / position-error log lines and the wall time per training step.  python tools/train_demo.py [epochs]"""
+prints the ELBO / position-error log lines and the wall time per training step.  python tools/train_demo.py [epochs [graph]]"""
 import os
 import pickle
 import sys
@@ -14,6 +14,7 @@ from stove_amd.envs import envs  # noqa: E402
 import model.main as M  # noqa: E402
 
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+graph = len(sys.argv) > 2 and sys.argv[2] == 'graph'      # config.graph_step: non-logging steps as one captured hipGraph
 tmp = tempfile.mkdtemp()
 paths = {}
 for name, n_seq, seed0 in (('train', 300, 0), ('test', 40, 10 ** 5)):
@@ -23,7 +24,7 @@ for name, n_seq, seed0 in (('train', 300, 0), ('test', 40, 10 ** 5)):
     with open(paths[name], 'wb') as f:
         pickle.dump(data, f)
 args = {'traindata': paths['train'], 'testdata': paths['test'], 'experiment_dir': tmp, 'dtype': 'torch.float', 'random_seed': '42',
-        'num_epochs': str(epochs), 'print_every': '50', 'num_workers': '0', 'save_every': '1000000', 'long_rollout_every': '1000000'}
+        'num_epochs': str(epochs), 'print_every': '50', 'num_workers': '0', 'save_every': '1000000', 'long_rollout_every': '1000000', 'graph_step': str(graph)}
 trainer = M.main(sh_args=args)
 t0 = time.time()
 trainer.train()
