@@ -39,8 +39,7 @@ class AbstractTrainer:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.dataloader = train_dataset
         self.test_dataset = test_dataset
-        self.test_dataloader = DataLoader(test_dataset, batch_size=self.c.batch_size, shuffle=True,
-                                          num_workers=self.c.num_workers, drop_last=True)
+        self.test_dataloader = self._make_loader(test_dataset)
         self.optimizer = optim.Adam(self.stove.parameters(), lr=self.c.learning_rate, amsgrad=self.c.debug_amsgrad)
         if self.c.load_encoder is not None:
             self.load_encoder()
@@ -65,16 +64,17 @@ class AbstractTrainer:
 
     @dataloader.setter
     def dataloader(self, train_dataset):
-        # [amd] the training set lives on the GPU and batches are gathered there (no per-step host collate / PCIe copy)
-        # when it fits the budget; otherwise the reference's DataLoader
+        self._train_dataset = self._make_loader(train_dataset)
+
+    def _make_loader(self, dataset):
+        """Shuffled, drop-last batches of clips (reference train.py:39-44, 69-76).  [amd] The set lives on the GPU and batches are
+        gathered there (no per-step host collate / PCIe copy) when it fits the budget; otherwise the reference's DataLoader."""
         dev = torch.device(self.c.device)
         budget = float(getattr(self.c, 'device_dataset_gb', 64.0)) * 2 ** 30
         if dev.type == 'cuda' and getattr(self.c, 'device_dataset', True) \
-                and DeviceClipLoader.nbytes(train_dataset, self.c.dtype) <= budget:
-            self._train_dataset = DeviceClipLoader(train_dataset, self.c.batch_size, dev, self.c.dtype, shuffle=True, drop_last=True)
-        else:
-            self._train_dataset = DataLoader(train_dataset, batch_size=self.c.batch_size, shuffle=True,
-                                             num_workers=self.c.num_workers, drop_last=True)
+                and DeviceClipLoader.nbytes(dataset, self.c.dtype) <= budget:
+            return DeviceClipLoader(dataset, self.c.batch_size, dev, self.c.dtype, shuffle=True, drop_last=True)
+        return DataLoader(dataset, batch_size=self.c.batch_size, shuffle=True, num_workers=self.c.num_workers, drop_last=True)
 
     # ------------------------------------------------------------------ checkpoints
     def _state(self, epoch, step):
@@ -149,18 +149,24 @@ class Trainer(AbstractTrainer):
         if self.c.supair_only:
             return_velocity, level = False, 'image'
         perms = list(itertools.permutations(range(self.c.num_obj)))
+        perm_t = torch.tensor(perms, device=predicted.device)                     # (P, o)
         pos_p, pos_t = predicted[..., :2], true[..., :2]
         t_fit = min(4, predicted.shape[1])
+
+        def permuted(x, best):
+            """x (n, T, o, d) with the objects of sequence i reordered by perms[best[i]] (one gather, no host loop)."""
+            idx = perm_t[best][:, None, :, None].expand(-1, x.shape[1], -1, x.shape[3])
+            return x.gather(2, idx)
         if level == 'sequence':
             errs = torch.stack([torch.sqrt(((pos_p[:, :t_fit, list(p)] - pos_t[:, :t_fit]) ** 2).sum(-1)).mean((1, 2))
                                 for p in perms], 1)
-            best = errs.argmin(1).cpu().tolist()
-            pos_m = torch.stack([pos_p[i][:, list(perms[j])] for i, j in enumerate(best)], 0)
+            best = errs.argmin(1)
+            pos_m = permuted(pos_p, best)
         elif level == 'image':
             pf, tf = pos_p.flatten(end_dim=1), pos_t.flatten(end_dim=1)
             errs = torch.stack([torch.sqrt(((pf[:, list(p)] - tf) ** 2).sum(-1)).mean(1) for p in perms], 1)
-            best = errs.argmin(1).cpu().tolist()
-            pos_m = torch.stack([pf[i][list(perms[j])] for i, j in enumerate(best)], 0).reshape(pos_p.shape)
+            best = errs.argmin(1)
+            pos_m = permuted(pf[:, None], best)[:, 0].reshape(pos_p.shape)
         else:
             raise ValueError
         res = {}
@@ -173,7 +179,7 @@ class Trainer(AbstractTrainer):
             res['error'], res['std_error'] = per_seq.mean().cpu(), per_seq.std().cpu()
         if return_velocity:
             vel_p = predicted[..., 2:4]
-            vel_m = torch.stack([vel_p[i][:, list(perms[j])] for i, j in enumerate(best)], 0)
+            vel_m = permuted(vel_p, best)
             v_err = torch.sqrt(((true[..., 2:] - vel_m) ** 2).sum(-1)).mean(-1)
             if return_full:
                 res['v_error'], res['std_v_error'] = v_err.mean(0).cpu(), v_err.std(0).cpu()

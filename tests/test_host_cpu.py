@@ -103,3 +103,34 @@ def test_host_side_units_against_reference():
         assert np.abs(a.numpy() - gf['z_fixed']).max() < 1e-15 and np.abs(b.numpy() - gf['zstd_fixed']).max() < 1e-15
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+def test_prediction_error_permutation_gather():
+    """Trainer.prediction_error (reference train.py:475-563): the best-permutation reordering as one gather equals the
+    per-sequence Python loop of the reference."""
+    import itertools
+    from types import SimpleNamespace
+    import torch
+    from stove_amd.video_prediction.train import Trainer
+    g = torch.Generator().manual_seed(0)
+    n, T, o = 9, 6, 3
+    true = torch.rand(n, T, o, 4, generator=g)
+    pred = true[:, :, torch.tensor([2, 0, 1])] + 0.01 * torch.randn(n, T, o, 4, generator=g)
+    pred[::2] = true[::2][:, :, torch.tensor([1, 0, 2])] + 0.01 * torch.randn(5, T, o, 4, generator=g)
+    me = SimpleNamespace(c=SimpleNamespace(supair_only=False, num_obj=o))
+    res = Trainer.prediction_error(me, pred, true, return_matched=True)
+    perms = list(itertools.permutations(range(o)))
+    errs = torch.stack([torch.sqrt(((pred[:, :4, list(p), :2] - true[:, :4, :, :2]) ** 2).sum(-1)).mean((1, 2)) for p in perms], 1)
+    best = errs.argmin(1).tolist()
+    pos_m = torch.stack([pred[i, :, list(perms[j]), :2] for i, j in enumerate(best)], 0)
+    vel_m = torch.stack([pred[i, :, list(perms[j]), 2:4] for i, j in enumerate(best)], 0)
+    assert torch.equal(res['pos_matched'], pos_m) and torch.equal(res['vel_matched'], vel_m)
+    assert float(res['error']) < 0.05 and float(res['swaps']) == 1.0
+    # SuPAIR-only: one permutation per image
+    me.c.supair_only = True
+    res = Trainer.prediction_error(me, pred, true, return_matched=True)
+    pf, tf = pred[..., :2].flatten(end_dim=1), true[..., :2].flatten(end_dim=1)
+    errs = torch.stack([torch.sqrt(((pf[:, list(p)] - tf) ** 2).sum(-1)).mean(1) for p in perms], 1)
+    best = errs.argmin(1).tolist()
+    want = torch.stack([pf[i][list(perms[j])] for i, j in enumerate(best)], 0).reshape(n, T, o, 2)
+    assert torch.equal(res['pos_matched'], want)
