@@ -73,7 +73,7 @@ def make_batch(workload, n_seq, T, seed0):
     return d
 
 
-def cpu_baseline(workload, T, n_seq, iters):
+def cpu_baseline(workload, T, n_seq, iters, full_batch=None):
     """Time the CPU oracle (oracle/stove_oracle.py: the reference's ATen op sequence restated) on
     the host cores: same workload shape, bounded batch."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -114,8 +114,30 @@ def cpu_baseline(workload, T, n_seq, iters):
         if it > 0:
             times.append(dt)
     med = float(np.median(times))
-    return {'value': n_seq * T / med, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{workload} B={n_seq} T={T} fp32 fwd+bwd, median of {len(times)} after 1 warm-up, {med:.2f} s/step'}
+    out = {'value': n_seq * T / med, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{workload} B={n_seq} T={T} fp32 fwd+bwd, median of {len(times)} after 1 warm-up, {med:.2f} s/step',
+           'cpu_model': _cpu_model(), 'cores_total': os.cpu_count(), 'cores_available': avail}
+    # one iteration at the batch the metric is quoted on (B=full_batch), when the sample says it fits in ~90 s
+    if full_batch and full_batch > n_seq and med * full_batch / n_seq < 90.0:
+        xf = torch.from_numpy(make_batch(workload, full_batch, T, 0)['X'])
+        eps = O.draw_eps(full_batch, c.num_obj, T, generator=g)
+        t0 = time.perf_counter()
+        elbo, _ = O.stove_forward(c, params, structs, xf, eps)
+        (-elbo).backward()
+        dt = time.perf_counter() - t0
+        out['full_batch'] = {'value': full_batch * T / dt, 'unit': 'frames/s', 'sample': f'B={full_batch} T={T}, one iteration, {dt:.1f} s'}
+    return out
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
 def log(msg):
@@ -131,6 +153,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # hipcc (if the library is stale; keyed on a content hash of the sources) runs BEFORE this process touches the GPU:
+    # torch.cuda.device_count() does not initialise HIP, torch.cuda.is_available() / set_device below do
+    from stove_amd import build as _build
+    if local == 0:
+        _build.build_library()
+    else:
+        t_wait = time.time()
+        while _build._stale():
+            if time.time() - t_wait > 600:
+                raise SystemExit('libstove_hip.so was not built by local rank 0 within 10 minutes')
+            time.sleep(0.5)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the STOVE hot path has no CPU fallback')
     # one process per GPU; STOVE_DIST_BACKEND=gloo lets the multi-process path be exercised on a
@@ -145,11 +178,6 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from stove_amd import build as _build
-    if rank == 0 or world == 1:
-        _build.build_library()
-    if world > 1:
-        dist.barrier()
     from stove_amd import _lib
     from stove_amd.arena import ParamArena
     from stove_amd.video_prediction.stove import Stove
@@ -158,6 +186,7 @@ def main():
     torch.manual_seed(0)
     model = Stove(cfg).to(dev)
     bucket = ParamArena(model, world)          # parameters / gradients flat; grad buffer == all-reduce bucket
+    bucket.sync(0)                             # replicas start from rank 0's parameters (one broadcast of the flat buffer)
     from stove_amd.optim import FlatAdam
     opt = FlatAdam(bucket, lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)       # torch.optim.Adam's update as one launch
 
@@ -184,9 +213,12 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]       # device-side step boundaries (no host sync)
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(a.steps):
         last = step(a.warmup + i)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -197,6 +229,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     elbo_val = float(last.detach())
+    per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     log('timed region done: %.1f ms/step' % (dt / a.steps * 1e3))
 
     # ---- per-kernel HIP-event timing of extra steps (profiling hooks off during the timed region)
@@ -262,12 +295,15 @@ def main():
                 if tr and a.workload == 'billiards' and a.batch == 256 and a.frames == 100:
                     roofline['traffic'] = tr['hbm_bytes_per_launch']
                     roofline['traffic_source'] = os.path.basename(path)
+                    # the PMC passes serialise kernels and cannot run inside a timed bench: the figure is read from the
+                    # committed summary of tools/profile_round.sh on this workload, not measured by this process
+                    roofline['traffic_measured_in_run'] = False
             except (OSError, ValueError):
                 pass
     log('kernel profile done')
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.workload, a.frames, a.cpu_batch, a.cpu_iters)
+        cpu = cpu_baseline(a.workload, a.frames, a.cpu_batch, a.cpu_iters, full_batch=a.batch)
         log('cpu baseline done')
 
     if rank == 0:
@@ -275,7 +311,9 @@ def main():
         out = {
             'metric': 'frames/s (fwd+bwd) for 3-obj billiards 32x32 T=100, 1/2/4/8 GPU; ELBO delta vs ref',
             'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': dt / a.steps * 1e3,
+            'ms_per_step_p50': per_step_ms[len(per_step_ms) // 2], 'ms_per_step_p99': per_step_ms[min(len(per_step_ms) - 1, int(0.99 * len(per_step_ms)))],
+            'ms_per_step_min': per_step_ms[0], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{a.workload} {cfg.num_obj}-object 32x32 T={a.frames} batch={a.batch}/GPU' + (' (BASELINE.json configs[1])' if a.workload == 'billiards' and a.batch == 256 and a.frames == 100 else ''),
                        'objects': cfg.num_obj, 'global_batch': a.batch * world,

@@ -260,18 +260,20 @@ int stove_bw_transform(const float* x, float* out, int n_frames, int channels, i
 size_t stove_colsum_ws_floats(int rows, int cols);
 int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void* stream);
 
-/* One Adam / AMSGrad step of torch.optim.Adam (weight_decay 0; reference train.py:431-473) over the flat arena, with
- * clip_grad_norm_(max_norm) folded in: gradients are scaled by min(1, max_norm / (*grad_norm + 1e-6)) on the fly
- * (grad_norm = device scalar holding the L2 norm of grads, NULL = no clipping).  max_exp_avg_sq NULL = plain Adam.
- * numel must be a multiple of 4 (the arena pads to 16 bytes); step counts from 1. */
-int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad_norm,
-                    size_t numel, float lr, float beta1, float beta2, float eps, int step, float max_norm, void* stream);
-
-/* The same step with its constants in device memory, for captured hipGraphs (kernel arguments are frozen at capture, the step
- * count and the learning-rate schedule are not): hyper = f32[7] = lr, beta1, beta2, eps, 1 - beta1^step, sqrt(1 - beta2^step),
- * max_norm (read only when grad_norm != NULL). */
-int stove_flat_adam_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad_norm,
-                        size_t numel, const float* hyper, void* stream);
+/* One Adam / AMSGrad step of torch.optim.Adam (weight_decay 0; reference train.py:46-49, 431-473) over the flat arena,
+ * with clip_grad_norm_(max_norm) folded in (clip != 0: gradients are scaled by min(1, max_norm / (||grads|| + 1e-6)) on the
+ * fly; the norm is computed here, in a fixed order, and stored to grad_norm_out if that is not NULL).
+ * torch's per-parameter semantics are kept: a SEGMENT is one parameter tensor (each starts on a float4 boundary);
+ * seg_of4[i] = segment of floats 4i..4i+3 (numel/4 ints); seg_trainable[s] = requires_grad; seg_steps[s] = steps taken so
+ * far (float, advanced here).  A segment steps only if it is trainable and its gradient slice has a non-zero element (what
+ * `p.grad is None` means in a flat buffer) and uses ITS step count for the bias corrections; other segments are untouched.
+ * ws: stove_flat_adam_ws_bytes(nseg) bytes, zeroed once by the caller before the first call.  max_exp_avg_sq NULL = plain
+ * Adam.  hyper_dev != NULL: f32[5] = lr, beta1, beta2, eps, max_norm in device memory override the by-value arguments
+ * (captured hipGraphs: kernel arguments are frozen at capture, the learning-rate schedule is not). */
+size_t stove_flat_adam_ws_bytes(int nseg);
+int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, size_t numel,
+                    const int* seg_of4, const unsigned char* seg_trainable, float* seg_steps, int nseg, void* ws, float* grad_norm_out,
+                    const float* hyper_dev, float lr, float beta1, float beta2, float eps, float max_norm, int clip, void* stream);
 
 /* ---- gate math of RnnStates' LSTM (encoder.py:43-51, torch.nn.LSTM cell, gate order i,f,g,o); the GEMMs
  * around it stay on rocBLAS.  gx (n,4H): x W_ih^T + b_ih + b_hh; gh (n,4H): h_prev W_hh^T or NULL; c_prev

@@ -112,12 +112,19 @@ class ParamArena:
     def pack(self):
         return self.grad
 
-    def all_reduce(self):
-        """Average the gradients over the ranks: ONE collective on the flat buffer (no-op for one rank)."""
-        if self.world_size <= 1:
+    def all_reduce(self, force=False):
+        """Average the gradients over the ranks: ONE collective on the flat buffer (no-op for one rank; `force` sends a
+        single rank's buffer through the backend anyway -- the 1-GPU RCCL test)."""
+        if self.world_size <= 1 and not force:
             return
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
-        self.grad.div_(self.world_size)
+        if self.world_size > 1:
+            self.grad.div_(self.world_size)
+
+    def sync(self, src=0):
+        """Every rank takes rank `src`'s parameters: ONE broadcast of the flat buffer (all parameters are views into it)."""
+        if self.world_size > 1:
+            dist.broadcast(self.data, src)
 
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_(params, max_norm) on the flat buffer (pads are zero)."""

@@ -165,26 +165,74 @@ namespace stove {
 //   g' = g * min(1, max_norm / (norm + 1e-6))        (norm: device scalar, null = no clipping)
 //   m = b1 m + (1 - b1) g' ; v = b2 v + (1 - b2) g'^2 ; vmax = max(vmax, v)   (vmax null = plain Adam)
 //   p -= (lr / bc1) * m / (sqrt(vmax or v) / sqrt(bc2) + eps)
-struct AdamConst {
-  float lr, b1, b2, eps, bc1, sqrt_bc2, max_norm;
+// ---- Adam / AMSGrad over the flat arena with torch.optim.Adam's per-parameter semantics.
+// torch keeps one step count per parameter TENSOR and skips tensors whose .grad is None (frozen ones, and ones that took no
+// part in the backward pass).  In the arena every gradient is a slice of one buffer, so "no gradient" shows up as a slice
+// that is exactly zero.  A SEGMENT = one parameter tensor (every tensor starts on a float4 boundary):
+//   grad_scan_k   flags[seg] = 1 for every segment with a non-zero gradient element; part[block] = the block's share of
+//                 sum g^2 (fixed grid-stride assignment, fixed reduction order: bitwise reproducible);
+//   flat_adam_k   segments that are trainable AND flagged take one step with THEIR step count (bias corrections from
+//                 steps[seg] + 1, in double like torch's host arithmetic); all others are not touched at all;
+//   adam_tick_k   steps[seg] += 1 for the segments that stepped, flags cleared for the next call.
+// hyper = [lr, beta1, beta2, eps, max_norm] is read from device memory when hyper_dev != NULL (captured hipGraphs: kernel
+// arguments are frozen at capture, the learning-rate schedule is not), else from the by-value copy.
+struct AdamHyper {
+  float lr, b1, b2, eps, max_norm;
 };
-__global__ void flat_adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            float* __restrict__ vmax, const float* __restrict__ norm, AdamConst k, int n4) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int ADAM_SCAN_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void grad_scan_k(const float* __restrict__ g, const int* __restrict__ seg_of4, int* __restrict__ flags,
+                                                   float* __restrict__ part, int n4) {
+  float acc = 0.0f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += ADAM_SCAN_BLOCKS * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) flags[seg_of4[i]] = 1;      // every writer stores the same value
+  }
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void flat_adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   float* __restrict__ vmax, const int* __restrict__ seg_of4,
+                                                   const unsigned char* __restrict__ trainable, const float* __restrict__ steps,
+                                                   const int* __restrict__ flags, const float* __restrict__ part, float* __restrict__ norm_out,
+                                                   const float* __restrict__ hyper_dev, AdamHyper k, int clip, int n4) {
+  if (hyper_dev != nullptr) {
+    k.lr = hyper_dev[0]; k.b1 = hyper_dev[1]; k.b2 = hyper_dev[2]; k.eps = hyper_dev[3]; k.max_norm = hyper_dev[4];
+  }
+  __shared__ float s_norm;
+  if (threadIdx.x < 64) {                   // total gradient norm: the 256 partials in a fixed order, by every block alike
+    float t = (part[threadIdx.x] + part[threadIdx.x + 64]) + (part[threadIdx.x + 128] + part[threadIdx.x + 192]);
+    t = wave_sum(t);
+    if (threadIdx.x == 0) {
+      s_norm = sqrtf(t);
+      if (blockIdx.x == 0 && norm_out != nullptr) norm_out[0] = s_norm;
+    }
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
-  float coef = 1.0f;
-  if (norm != nullptr) coef = fminf(1.0f, k.max_norm / (norm[0] + 1e-6f));
+  const int seg = seg_of4[i];
+  if (trainable[seg] == 0 || flags[seg] == 0) return;
+  const float coef = clip ? fminf(1.0f, k.max_norm / (s_norm + 1e-6f)) : 1.0f;
+  const double t = (double)steps[seg] + 1.0;
+  const float bc1 = (float)(1.0 - pow((double)k.b1, t));
+  const float sqrt_bc2 = (float)sqrt(1.0 - pow((double)k.b2, t));
   const float4 g4 = reinterpret_cast<const float4*>(g)[i];
   float4 p4 = reinterpret_cast<float4*>(p)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
   float4 x4 = vmax != nullptr ? reinterpret_cast<float4*>(vmax)[i] : v4;
-  const float step = k.lr / k.bc1;
+  const float step = k.lr / bc1;
 #define STOVE_ADAM1(c)                                           \
   {                                                              \
     const float gg = g4.c * coef;                                \
     m4.c = m4.c + (1.0f - k.b1) * (gg - m4.c);                   \
     v4.c = k.b2 * v4.c + (1.0f - k.b2) * gg * gg;                \
     x4.c = vmax != nullptr ? fmaxf(x4.c, v4.c) : v4.c;           \
-    p4.c -= step * m4.c / (sqrtf(x4.c) / k.sqrt_bc2 + k.eps);    \
+    p4.c -= step * m4.c / (sqrtf(x4.c) / sqrt_bc2 + k.eps);      \
   }
   STOVE_ADAM1(x) STOVE_ADAM1(y) STOVE_ADAM1(z) STOVE_ADAM1(w)
 #undef STOVE_ADAM1
@@ -194,33 +242,11 @@ __global__ void flat_adam_k(float* __restrict__ p, const float* __restrict__ g, 
   if (vmax != nullptr) reinterpret_cast<float4*>(vmax)[i] = x4;
 }
 
-// The same step with the constants read from device memory: inside a captured hipGraph kernel arguments are frozen, the
-// step count (bias corrections) and the learning-rate schedule are not.  hyper = [lr, b1, b2, eps, bc1, sqrt_bc2, max_norm].
-__global__ void flat_adam_dev_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                float* __restrict__ vmax, const float* __restrict__ norm, const float* __restrict__ hyper, int n4) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], sqrt_bc2 = hyper[5], max_norm = hyper[6];
-  float coef = 1.0f;
-  if (norm != nullptr) coef = fminf(1.0f, max_norm / (norm[0] + 1e-6f));
-  const float4 g4 = reinterpret_cast<const float4*>(g)[i];
-  float4 p4 = reinterpret_cast<float4*>(p)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
-  float4 x4 = vmax != nullptr ? reinterpret_cast<float4*>(vmax)[i] : v4;
-  const float step = lr / bc1;
-#define STOVE_ADAM1(c)                                           \
-  {                                                              \
-    const float gg = g4.c * coef;                                \
-    m4.c = m4.c + (1.0f - b1) * (gg - m4.c);                     \
-    v4.c = b2 * v4.c + (1.0f - b2) * gg * gg;                    \
-    x4.c = vmax != nullptr ? fmaxf(x4.c, v4.c) : v4.c;           \
-    p4.c -= step * m4.c / (sqrtf(x4.c) / sqrt_bc2 + eps);        \
-  }
-  STOVE_ADAM1(x) STOVE_ADAM1(y) STOVE_ADAM1(z) STOVE_ADAM1(w)
-#undef STOVE_ADAM1
-  reinterpret_cast<float4*>(p)[i] = p4;
-  reinterpret_cast<float4*>(m)[i] = m4;
-  reinterpret_cast<float4*>(v)[i] = v4;
-  if (vmax != nullptr) reinterpret_cast<float4*>(vmax)[i] = x4;
+__global__ void adam_tick_k(const unsigned char* __restrict__ trainable, float* __restrict__ steps, int* __restrict__ flags, int nseg) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  if (trainable[s] != 0 && flags[s] != 0) steps[s] += 1.0f;
+  flags[s] = 0;
 }
 
 // out[j] = sum_c part[c][j], fixed order; n4 = n / 4 (split-K partials of the batched weight-gradient GEMMs)

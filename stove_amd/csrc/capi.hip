@@ -66,7 +66,7 @@ static int scene_bwd_tail(const float* frames, const float* z, const float* dxw,
   const int nb = (np + 63) / 64;
   STOVE_LAUNCH((scene_tile_bwd_k<NMAX>), dim3(nb < 4096 ? nb : 4096), dim3(256), 0, st, frames, z, dxw, d_ovl, dzc, n_obj, np, nb);
   STOVE_LAUNCH_CHECK();
-  stream_after(st, bg_stream);                  // join: only the last kernel needs the background chain's dz_bg
+  STOVE_TRY(stream_after(st, bg_stream));       // join: only the last kernel needs the background chain's dz_bg
   STOVE_LAUNCH((scene_finalize_bwd_k<NMAX>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, obj_ll, dz_bg, dzc, dz, n_obj, np);
   STOVE_LAUNCH_CHECK();
   return 0;
@@ -160,14 +160,15 @@ size_t stove_scene_saved_floats(int n_frames, int n_obj) { return scene_saved_la
 // returns, so callers see plain single-stream semantics.  STOVE_NO_OVERLAP=1 keeps everything on the caller's stream.
 static hipStream_t scene_fork_stream(hipStream_t st) {
   static hipStream_t side[16] = {nullptr};
-  static int off = -1;
-  if (off < 0) {
+  static const bool off = [] {
     const char* e = getenv("STOVE_NO_OVERLAP");
-    off = (e != nullptr && e[0] == '1') ? 1 : 0;
-  }
+    return e != nullptr && e[0] == '1';
+  }();                                           // C++11 static initialisation: thread-safe
+  static std::mutex mu;
   if (off) return st;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return st;
+  std::lock_guard<std::mutex> lock(mu);           // backward is called from the autograd thread, forward from the main one
   if (side[dev] == nullptr && hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking) != hipSuccess) return st;
   return side[dev];
 }
@@ -179,7 +180,8 @@ int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z
   const SceneSaved L = scene_saved_layout(n_frames, n_obj);
   const int np = n_frames * n_obj;
   hipStream_t sb = scene_fork_stream(st);       // background chain (MFMA-bound) next to the object chain (VALU-bound)
-  stream_after(sb, st);                         // fork: inputs are ready in `st` order
+  STOVE_TRY(stream_after(sb, st));              // fork: inputs are ready in `st` order
+  JoinGuard jb(st, sb);                         // joined on every exit path
   int rc = scene_tile_fwd_any(frames, z, saved + L.xw, n_obj, np, st);
   if (rc) return rc;
   rc = objspn_forward(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl, np, st,
@@ -187,7 +189,7 @@ int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z
   if (rc) return rc;
   rc = bgspn_forward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, sb);
   if (rc) return rc;
-  stream_after(st, sb);                         // join
+  STOVE_TRY(jb.join());
   STOVE_LAUNCH(scene_assemble_fwd_k, dim3((n_frames + 255) / 256), dim3(256), 0, st, saved + L.bg_out, saved + L.obj_ll,
                      saved + L.ovl, z, ll, parts, n_obj, n_frames, overlap_beta, logf(overlap_beta));
   STOVE_LAUNCH_CHECK();
@@ -244,7 +246,9 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
   STOVE_LAUNCH(scene_assemble_bwd_k, dim3((np + 255) / 256), dim3(256), 0, st, dll, z, ws + W.d_obj, ws + W.d_ovl, n_obj, np, overlap_beta);
   STOVE_LAUNCH_CHECK();
   hipStream_t sb = scene_fork_stream(st);       // background chain next to the object chain, joined before the tail
-  stream_after(sb, st);
+  STOVE_TRY(stream_after(sb, st));
+  JoinGuard jb(st, sb);                         // error paths: the tail below is what joins `sb` normally
+  JoinGuard jp(st, sp);                         // error paths only: the caller joins the parameter stream after a clean return
   int rc = objspn_backward_data(saved + L.xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot,
                                 saved + L.obj_ll, ws + W.d_obj, ws + W.dxw, ws + W.obj, np, st, saved + L.obj_state);
   if (rc) return rc;
@@ -252,7 +256,7 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
   // their producer on the parameter stream, or (STOVE_PARAMS_LATE=1) only once dz is out.
   const bool late = sp != st && params_late();
   if (!late) {
-    stream_after(sp, st);
+    STOVE_TRY(stream_after(sp, st));
     rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, sp);
     if (rc) return rc;
   }
@@ -268,9 +272,15 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
     rc = scene_bwd_tail<8>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st, sb);
   else
     rc = (int)hipErrorInvalidValue;
-  if (rc || !late) return rc;
-  stream_after(sp, st);
-  return objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, sp);
+  if (rc) return rc;
+  jb.dismiss();                                 // scene_bwd_tail joined `sb`
+  if (late) {
+    STOVE_TRY(stream_after(sp, st));
+    rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, sp);
+    if (rc) return rc;
+  }
+  jp.dismiss();
+  return 0;
 }
 
 int stove_glimpse_mean(const float* x_color, const float* z, float* emb, int n_frames, int n_obj, int channels, void* stream) {
@@ -468,7 +478,7 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
     STOVE_LAUNCH_CHECK();
     rc = (int)hipFuncSetAttribute((const void*)gnn_dw_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDwLdsFloats * sizeof(float)));
     if (rc) return rc;
-    stream_after(sp, st);        // the weight-gradient pass reads the dY streams; it only feeds the optimiser (second stream)
+    STOVE_TRY(stream_after(sp, st));        // the weight-gradient pass reads the dY streams; it only feeds the optimiser (second stream)
     STOVE_LAUNCH(gnn_dw_small_k, dim3(B), dim3(256), kDwLdsFloats * sizeof(float), sp, act, (const float*)dy, gpart, B, Ts, N);
     STOVE_LAUNCH_CHECK();
     STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 31) / 32), dim3(256), 0, sp, (const float*)gpart, g_params, kGnnGrads, B, 0);
@@ -481,7 +491,7 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
   STOVE_LAUNCH(dyn_loop_bwd_k, dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, z1, zsup, zsstd, eps, extra, params, z, act,
                      dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, (float*)ws, B, Ts, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
   STOVE_LAUNCH_CHECK();
-  stream_after(sp, st);
+  STOVE_TRY(stream_after(sp, st));
   STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 31) / 32), dim3(256), 0, sp, (const float*)ws, g_params, kGnnGrads, nb, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
@@ -613,28 +623,24 @@ int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void
   return 0;
 }
 
-int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad_norm,
-                    size_t numel, float lr, float beta1, float beta2, float eps, int step, float max_norm, void* stream) {
-  if (numel == 0) return 0;
-  if (numel % 4 != 0 || step < 1) return (int)hipErrorInvalidValue;
-  AdamConst k;
-  k.lr = lr; k.b1 = beta1; k.b2 = beta2; k.eps = eps; k.max_norm = max_norm;
-  k.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-  k.sqrt_bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  const int n4 = (int)(numel / 4);
-  STOVE_LAUNCH(flat_adam_k, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq,
-               grad_norm, k, n4);
-  STOVE_LAUNCH_CHECK();
-  return 0;
-}
+size_t stove_flat_adam_ws_bytes(int nseg) { return (size_t)nseg * sizeof(int) + ADAM_SCAN_BLOCKS * sizeof(float); }
 
-int stove_flat_adam_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad_norm,
-                        size_t numel, const float* hyper, void* stream) {
-  if (numel == 0) return 0;
-  if (numel % 4 != 0 || hyper == nullptr) return (int)hipErrorInvalidValue;
+int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, size_t numel,
+                    const int* seg_of4, const unsigned char* seg_trainable, float* seg_steps, int nseg, void* ws, float* grad_norm_out,
+                    const float* hyper_dev, float lr, float beta1, float beta2, float eps, float max_norm, int clip, void* stream) {
+  if (numel == 0 || nseg == 0) return 0;
+  if (numel % 4 != 0 || ws == nullptr || seg_of4 == nullptr || seg_trainable == nullptr || seg_steps == nullptr)
+    return (int)hipErrorInvalidValue;
+  AdamHyper k;
+  k.lr = lr; k.b1 = beta1; k.b2 = beta2; k.eps = eps; k.max_norm = max_norm;
   const int n4 = (int)(numel / 4);
-  STOVE_LAUNCH(flat_adam_dev_k, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq,
-               grad_norm, hyper, n4);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = reinterpret_cast<float*>(ws);
+  int* flags = reinterpret_cast<int*>(part + ADAM_SCAN_BLOCKS);          // cleared by the caller once, by adam_tick_k ever after
+  STOVE_LAUNCH(grad_scan_k, dim3(ADAM_SCAN_BLOCKS), dim3(256), 0, st, grads, seg_of4, flags, part, n4);
+  STOVE_LAUNCH(flat_adam_k, dim3((n4 + 255) / 256), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq, seg_of4,
+               seg_trainable, (const float*)seg_steps, (const int*)flags, (const float*)part, grad_norm_out, hyper_dev, k, clip, n4);
+  STOVE_LAUNCH(adam_tick_k, dim3((nseg + 255) / 256), dim3(256), 0, st, seg_trainable, seg_steps, flags, nseg);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

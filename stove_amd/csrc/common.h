@@ -69,17 +69,41 @@ __device__ __forceinline__ float cover(float q, int n, float* dq) {
 
 }  // namespace stove
 
-// make stream `to` wait for everything enqueued on `from` so far (no-op when they are the same stream)
+// make stream `to` wait for everything enqueued on `from` so far (no-op when they are the same stream).  A failed fork or
+// join would turn into an unordered race on saved tensors / workspaces, so every caller propagates the error code.
 namespace stove {
-inline void stream_after(hipStream_t to, hipStream_t from) {
-  if (to == from) return;
+inline hipError_t stream_after(hipStream_t to, hipStream_t from) {
+  if (to == from) return hipSuccess;
   hipEvent_t ev;
-  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return;
-  hipEventRecord(ev, from);
-  hipStreamWaitEvent(to, ev, 0);
-  hipEventDestroy(ev);          // released by the runtime once the wait has been satisfied
+  hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e != hipSuccess) return e;
+  e = hipEventRecord(ev, from);
+  if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
+  const hipError_t d = hipEventDestroy(ev);          // released by the runtime once the wait has been satisfied
+  return e != hipSuccess ? e : d;
 }
+// A forked stream must be joined on EVERY exit path (an unjoined stream inside a hipGraph capture invalidates the capture;
+// outside one it leaves work racing with whatever the caller enqueues next): joins in the destructor unless join() ran.
+struct JoinGuard {
+  hipStream_t to, from;
+  bool done;
+  JoinGuard(hipStream_t to_, hipStream_t from_) : to(to_), from(from_), done(to_ == from_) {}
+  hipError_t join() {
+    if (done) return hipSuccess;
+    done = true;
+    return stream_after(to, from);
+  }
+  void dismiss() { done = true; }
+  ~JoinGuard() {
+    if (!done) (void)stream_after(to, from);
+  }
+};
 }  // namespace stove
+#define STOVE_TRY(expr)                               \
+  do {                                                \
+    hipError_t e__ = (expr);                          \
+    if (e__ != hipSuccess) return (int)e__;           \
+  } while (0)
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py `roofline`) ----
 // Off by default (no overhead, no global state touched).  When enabled, every kernel launch is

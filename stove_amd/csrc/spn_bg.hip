@@ -570,7 +570,7 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
   else
     rc = bg_bwd_launch<8>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T);
   if (rc) return rc;
-  stream_after(st_par, st);                    // gcoef_part of bgspn_bwd_k, rsc of bgspn_root_bwd_k
+  STOVE_TRY(stream_after(st_par, st));         // gcoef_part of bgspn_bwd_k, rsc of bgspn_root_bwd_k
   if (scene) {
     const int n = n_frames * n_obj * 4;
     STOVE_LAUNCH(bg_dz_halves_k, dim3((n + 255) / 256), dim3(256), 0, st, dz_part, dz, n_frames, n_obj * 4);

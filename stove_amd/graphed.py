@@ -4,7 +4,7 @@ At the reference's default training shape (256 clips x 8 visible frames, config.
 the host ~2.0 ms to enqueue its ~100 launches (tools/host_time.py): the step is launch-bound.  Capturing
 zero_grad + Stove.forward + backward + clip + Adam once and replaying it removes the host from the loop.  What varies from
 step to step enters through device memory: the batch (copied into static input tensors), the optimiser's step-dependent
-constants (`FlatAdam.hyper`, 7 floats), the random draws (torch's graph-safe Philox offsets).
+constants (`FlatAdam.hyper`, 5 floats: the learning rate and the fixed betas / eps / clip norm; step counts live on the device), the random draws (torch's graph-safe Philox offsets).
 
 Only steps that need nothing but the loss are replayed: logging steps (`step % print_every == 0`, which read prop_dict) and
 multi-process runs (the all-reduce sits between backward and the optimiser) go through the eager path.
@@ -31,10 +31,11 @@ class GraphedTrainStep:
         dev = images.device
         self.x = images.clone()
         self.a = actions.clone() if actions is not None else None
-        self.hyper_dev = torch.empty(7, dtype=torch.float32, device=dev)
+        self.hyper_dev = torch.empty(5, dtype=torch.float32, device=dev)
         # warm-up on a side stream (allocator pools, BLAS workspaces, lazily created streams); parameters, optimiser state
         # and the generator are put back afterwards, so capturing does not count as training
-        snap = (self.arena.data.clone(), {k: v.clone() for k, v in self.opt._flat.items()}, torch.cuda.get_rng_state(dev))
+        snap = (self.arena.data.clone(), {k: v.clone() for k, v in self.opt._flat.items()}, torch.cuda.get_rng_state(dev),
+                self.opt._seg_steps.clone())
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -47,6 +48,7 @@ class GraphedTrainStep:
             self.arena.data.copy_(snap[0])
             for k, v in snap[1].items():
                 self.opt._flat[k].copy_(v)
+            self.opt._seg_steps.copy_(snap[3])
         torch.cuda.set_rng_state(snap[2], dev)
         # capture on the stream the warm-up ran on: the autograd nodes then see one stream throughout
         self.graph = torch.cuda.CUDAGraph()

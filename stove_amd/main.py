@@ -18,11 +18,15 @@ def _init_distributed():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world > 1 and not dist.is_initialized():
         local = int(os.environ.get('LOCAL_RANK', '0'))
+        # nccl (= RCCL over xGMI) with one process per GPU; STOVE_DIST_BACKEND=gloo lets several ranks share one GPU
+        # (the 1-GPU test box) or run without one
+        backend = os.environ.get('STOVE_DIST_BACKEND', 'nccl' if torch.cuda.is_available() else 'gloo')
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
+        if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
-            dist.init_process_group('gloo')
+            dist.init_process_group(backend)
     return world
 
 
@@ -58,9 +62,15 @@ def build_config(sh_args=None, restore=None, extras=None):
         config.dtype = torch.float
     torch.set_default_dtype(config.dtype)
     config.skip = 0 if config.supair_only else 2
+    # [amd] replicas must agree: rank 0's seed (drawn there if None) on every rank -- the SPN region graphs are built
+    # from it (supair.py:37,42); a per-process draw (reference main.py:166-168) would give every GPU another structure
+    from . import parallel
+    config.rank = parallel.rank()
     if config.random_seed is None:
         print('Set new random seed.')
-        config.random_seed = int(np.random.randint(low=0, high=1000))
+    config.random_seed = parallel.agree_on_seed(config.random_seed)
+    # shared base of the per-epoch clip permutations and of the per-rank noise streams (noise seed = base + rank)
+    config.dp_seed = parallel.broadcast_int(int(np.random.randint(low=0, high=2 ** 31 - 1))) if world > 1 else 0
     return config
 
 

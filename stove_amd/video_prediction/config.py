@@ -42,6 +42,8 @@ _DEFAULTS = dict(
     debug_match_objects='3_only', debug_no_reuse=False, debug_no_velocity=False,
     # ---- [amd] additions
     world_size=1,            # data-parallel ranks (one process per GPU, RCCL all-reduce of the flat gradient)
+    rank=0,                  # this process's rank
+    dp_seed=0,               # base seed shared by all ranks: clip permutation of epoch e = dp_seed + e, noise = dp_seed + rank
     align_corners=False,     # spatial-transformer convention; False = what the runnable reference computes
     fused_dynamics=True,     # run the inference recursion in the persistent HIP time-loop kernel
     fused_state=True,        # constrain_zp / matching / fix_supair / velocities as the fused state pipeline (csrc/state.hip)

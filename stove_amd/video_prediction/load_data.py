@@ -82,11 +82,18 @@ class DeviceClipLoader:
 
     Yields the same dicts (keys, shapes) as `DataLoader(StoveDataset, batch_size, shuffle, drop_last=True)`, with tensors
     already on the device in the model dtype; the shuffle uses torch's global CPU generator like RandomSampler does.
+
+    Data parallelism (`world` > 1): every rank holds the whole set (it is small) and draws the SAME
+    permutation per epoch from `seed + epoch`; rank r owns `order[r::world]`, cut to a number of `batch_size` batches
+    that is equal on all ranks.  `batch_size` is the PER-RANK batch, so the effective batch of a step is
+    world x batch_size (weak scaling, what bench.py measures); `last_clip_ids` is what the last batch was cut from.
     """
 
-    def __init__(self, dataset, batch_size, device, dtype, shuffle=True, drop_last=True):
+    def __init__(self, dataset, batch_size, device, dtype, shuffle=True, drop_last=True, rank=0, world=1, seed=0):
         import torch
         self.ds, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
+        self.rank, self.world, self.seed, self.epoch = int(rank), int(world), int(seed), 0
+        self.last_clip_ids = None
         c = dataset.c
         self.step, self.nv, self.nr = c.frame_step, c.num_visible, c.num_rollout
 
@@ -112,8 +119,8 @@ class DeviceClipLoader:
         return n * item
 
     def __len__(self):
-        n = len(self.idxs)
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        n = len(self.idxs) // self.world
+        return n // self.batch_size if self.drop_last or self.world > 1 else (n + self.batch_size - 1) // self.batch_size
 
     def batch(self, clip_ids):
         """The batch of the given clip numbers (indices into dataset.idxs)."""
@@ -129,6 +136,34 @@ class DeviceClipLoader:
     def __iter__(self):
         import torch
         n = len(self.idxs)
-        order = torch.randperm(n) if self.shuffle else torch.arange(n)
+        if self.world > 1:
+            from ..parallel import shard_order
+            g = torch.Generator().manual_seed(self.seed + self.epoch)         # the same order on every rank
+            order = torch.randperm(n, generator=g) if self.shuffle else torch.arange(n)
+            order = shard_order(order, self.rank, self.world, self.batch_size)
+            self.epoch += 1
+        else:
+            order = torch.randperm(n) if self.shuffle else torch.arange(n)
         for b in range(len(self)):
-            yield self.batch(order[b * self.batch_size:(b + 1) * self.batch_size])
+            self.last_clip_ids = order[b * self.batch_size:(b + 1) * self.batch_size]
+            yield self.batch(self.last_clip_ids)
+
+
+class ShardedDataLoader:
+    """The host DataLoader fallback of the Trainer under data parallelism: a DistributedSampler with the shared seed
+    (disjoint per-rank shards of one common permutation, equal batch counts), re-seeded every epoch."""
+
+    def __init__(self, dataset, batch_size, num_workers, rank, world, seed):
+        from torch.utils.data import DataLoader
+        from torch.utils.data.distributed import DistributedSampler
+        self.sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, seed=seed, drop_last=True)
+        self.loader = DataLoader(dataset, batch_size=batch_size, sampler=self.sampler, num_workers=num_workers, drop_last=True)
+        self.epoch = 0
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        self.sampler.set_epoch(self.epoch)
+        self.epoch += 1
+        return iter(self.loader)

@@ -20,9 +20,9 @@ from torch import nn
 from torch.utils.data import DataLoader
 
 from ..arena import ParamArena
-from .load_data import DeviceClipLoader
+from .load_data import DeviceClipLoader, ShardedDataLoader
 from ..optim import FlatAdam
-from ..parallel import GradBucket
+from ..parallel import GradBucket, broadcast_int, broadcast_tensors
 from ..utils.utils import ExperimentLogger, bw_transform
 
 
@@ -35,8 +35,8 @@ class AbstractTrainer:
             config.plot_every = 1
         self.c = config
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
-        self._graphed = None
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self._graphed = None
         self.dataloader = train_dataset
         self.test_dataset = test_dataset
         self.test_dataloader = self._make_loader(test_dataset)
@@ -57,6 +57,24 @@ class AbstractTrainer:
         self.epoch_start, self.step_start = 0, 0
         if self.c.checkpoint_path is not None:
             self.load()
+        else:
+            self.sync_replicas()
+
+    def sync_replicas(self):
+        """[amd] Data parallelism: every rank starts from rank 0's parameters, optimiser state and step counters (each
+        process initialised its own weights from its own torch RNG), and draws its reparameterisation noise from its own
+        stream.  Called after construction and after load(); a no-op for a single process."""
+        if self.world_size <= 1:
+            return
+        self.bucket.sync(0)
+        if isinstance(self.optimizer, FlatAdam):
+            broadcast_tensors(list(self.optimizer._flat.values()), 0)
+            self.optimizer._steps = broadcast_int(self.optimizer._steps)
+        else:
+            broadcast_tensors([v for st in self.optimizer.state.values() for v in st.values() if torch.is_tensor(v)], 0)
+        self.epoch_start, self.step_start = broadcast_int(self.epoch_start), broadcast_int(self.step_start)
+        seed = int(getattr(self.c, 'dp_seed', 0)) + self.rank
+        torch.manual_seed(seed)                 # CPU and every device generator: eps of rank r = stream (dp_seed + r)
 
     @property
     def dataloader(self):
@@ -71,9 +89,13 @@ class AbstractTrainer:
         gathered there (no per-step host collate / PCIe copy) when it fits the budget; otherwise the reference's DataLoader."""
         dev = torch.device(self.c.device)
         budget = float(getattr(self.c, 'device_dataset_gb', 64.0)) * 2 ** 30
+        seed = int(getattr(self.c, 'dp_seed', 0))
         if dev.type == 'cuda' and getattr(self.c, 'device_dataset', True) \
                 and DeviceClipLoader.nbytes(dataset, self.c.dtype) <= budget:
-            return DeviceClipLoader(dataset, self.c.batch_size, dev, self.c.dtype, shuffle=True, drop_last=True)
+            return DeviceClipLoader(dataset, self.c.batch_size, dev, self.c.dtype, shuffle=True, drop_last=True,
+                                    rank=self.rank, world=self.world_size, seed=seed)
+        if self.world_size > 1:
+            return ShardedDataLoader(dataset, self.c.batch_size, self.c.num_workers, self.rank, self.world_size, seed)
         return DataLoader(dataset, batch_size=self.c.batch_size, shuffle=True, num_workers=self.c.num_workers, drop_last=True)
 
     # ------------------------------------------------------------------ checkpoints
@@ -98,6 +120,7 @@ class AbstractTrainer:
         else:
             self.stove.load_state_dict(ckpt)
         print('Parameters loaded from {}.'.format(self.c.checkpoint_path))
+        self.sync_replicas()
 
     def load_encoder(self):
         pretrained = torch.load(self.c.load_encoder, map_location=self.c.device)['model_state_dict']
@@ -135,7 +158,8 @@ def _save_clip(path, frames, fps=24):
 class Trainer(AbstractTrainer):
     def __init__(self, config, stove, train_dataset, test_dataset):
         super().__init__(config, stove, train_dataset, test_dataset)
-        self.logger = ExperimentLogger(self.c)
+        # [amd] one run directory per job: rank 0 logs and saves, the other ranks get a logger without a directory
+        self.logger = ExperimentLogger(self.c) if self.rank == 0 else None
         self.z_types = ['z', 'z_sup', 'z_dyn'] if not self.c.supair_only else ['z']
         if self.c.action_conditioned:
             self.reward_loss = nn.MSELoss() if self.c.debug_mse else nn.BCELoss()
@@ -284,7 +308,14 @@ class Trainer(AbstractTrainer):
                     elbo, prop_dict, rewards, min_ll, mse_rewards = self.train_step(data, step_counter)
                     elbo, min_ll = elbo.detach(), min_ll.detach()      # values only from here on: drop the autograd graph
                 if step_counter % self.c.print_every == 0:
-                    self.error_and_log(elbo.item(), mse_rewards.item(), min_ll.item(), prop_dict, data, step_counter, now)
+                    if self.world_size > 1:
+                        # [amd] the logged ELBO / loss are the means over the global batch: one 3-float all-reduce
+                        tot = torch.stack([elbo.reshape(()).float(), min_ll.reshape(()).float(),
+                                           mse_rewards.reshape(()).float().to(elbo.device)])
+                        dist.all_reduce(tot)
+                        elbo, min_ll, mse_rewards = (tot / self.world_size).unbind(0)
+                    if self.rank == 0:          # error metrics of rank 0's shard, as one process would log its batch
+                        self.error_and_log(elbo.item(), mse_rewards.item(), min_ll.item(), prop_dict, data, step_counter, now)
                 if step_counter % self.c.save_every == 0:
                     self.save(epoch, step_counter)
                 if step_counter % self.c.long_rollout_every == 0:
@@ -308,6 +339,8 @@ class Trainer(AbstractTrainer):
     @torch.no_grad()
     def test(self, step_counter, start):
         """ELBO + reconstruction errors on test clips, then rollout errors of the generative model."""
+        if self.rank != 0:
+            return                  # [amd] evaluation has no collective in it: rank 0 evaluates and logs, the others go on
         self.stove.eval()
         for i, data in enumerate(self.test_dataloader):
             now = time.time() - start
@@ -344,6 +377,8 @@ class Trainer(AbstractTrainer):
         """Roll the dynamics out for `num` frames from the first visible frames of a few test
         sequences, log the position error over time and render real / rollout / reconstruction clips with
         `reconstruct_from_z` (reference train.py:684-849; GIFs through PIL when it is importable, uint8 .npy otherwise)."""
+        if self.rank != 0:
+            return None
         self.stove.eval()
         idx = list(idx) if idx is not None else [0, 1]
         ds = self.test_dataset

@@ -81,3 +81,133 @@ def test_two_rank_gradients_equal_single_process(tmp_path):
         if n not in used:
             assert float(g.abs().max()) == 0.0, n
     assert got['bucket_numel'] >= 1410255          # exchanged as ONE flat buffer (all parameters, 16-byte aligned)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The Trainer's data-parallel path, through the reference's entry point (model.main.main under a process group):
+# rank 0's random_seed and parameters everywhere, disjoint clip shards, per-rank noise, one all-reduce, identical
+# parameters after the step -- and the step equals ONE process stepping on the concatenated batch.
+# ---------------------------------------------------------------------------------------------------------------------
+def _write_data(tmp, n_seq=6, t_len=24):
+    import pickle
+    from stove_amd.envs import envs
+    d = envs.synth_sequences('billiards', n_seq, t_len)
+    data = {'X': np.transpose(d['X'], (0, 1, 3, 4, 2)).astype(np.float64), 'y': d['y'], 'coord_lim': 10, 'r': 1.2}
+    path = os.path.join(tmp, 'billiards.pkl')
+    with open(path, 'wb') as f:
+        pickle.dump(data, f)
+    return path
+
+
+def _args(path, tmp, **kw):
+    a = {'traindata': path, 'testdata': path, 'nolog': 'True', 'experiment_dir': tmp, 'batch_size': '4',
+         'num_visible': '6', 'num_rollout': '4', 'num_workers': '0', 'dtype': 'torch.float',
+         'print_every': '1', 'num_epochs': '1', 'long_rollout_every': '1000000', 'save_every': '1000000'}
+    a.update(kw)
+    return a
+
+
+def _spy_noise(stove):
+    rec, orig = {}, stove._noise
+
+    def spy(kind, shape, like):
+        t = orig(kind, shape, like)
+        rec[kind] = t.detach().clone().cpu()
+        return t
+    stove._noise = spy
+    return rec
+
+
+def _trainer_worker(rank, world, port, path, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0', STOVE_DIST_BACKEND='gloo')           # both ranks share cuda:0 on the 1-GPU box
+    np.random.seed(1000 + rank)                     # the per-process seed draw of reference main.py:166-168 would differ
+    torch.manual_seed(50 + rank)                    # ... and so would the initial weights
+    import model.main as M
+    trainer = M.main(sh_args=_args(path, tmp))      # random_seed None
+    assert trainer.world_size == 2 and trainer.rank == rank and trainer.c.world_size == 2
+    assert (trainer.logger is not None) == (rank == 0)
+    start = trainer.bucket.data.clone().cpu()
+    rec = _spy_noise(trainer.stove)
+    it = iter(trainer.dataloader)
+    data = next(it)
+    ids = trainer.dataloader.last_clip_ids.clone()
+    elbo, _, _, _, _ = trainer.train_step(data, 1)
+    out = {'seed': trainer.c.random_seed, 'dp_seed': trainer.c.dp_seed, 'start': start, 'ids': ids, 'noise': rec,
+           'images': data['present_images'].cpu(), 'elbo': float(elbo), 'grad': trainer.bucket.grad.clone().cpu(),
+           'after': trainer.bucket.data.clone().cpu(), 'len': len(trainer.dataloader),
+           'steps': trainer.optimizer.state_dict()['state'][0]['step']}
+    # a second step keeps the replicas together (moments and step counts are part of the state)
+    trainer.train_step(next(it), 2)
+    out['after2'] = trainer.bucket.data.clone().cpu()
+    trainer.test(2, 0.0)                            # evaluation: rank 0 only, no collective inside
+    torch.save(out, os.path.join(tmp, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_data_parallel_step(tmp_path):
+    tmp = str(tmp_path)
+    path = _write_data(tmp)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_trainer_worker, args=(2, port, path, tmp), nprocs=2, join=True)
+    r0, r1 = torch.load(os.path.join(tmp, 'rank0.pt')), torch.load(os.path.join(tmp, 'rank1.pt'))
+    assert r0['seed'] == r1['seed'] and r0['dp_seed'] == r1['dp_seed']                # rank 0's draws on both ranks
+    assert torch.equal(r0['start'], r1['start'])                                      # parameters broadcast at start
+    assert r0['len'] == r1['len'] and not (set(r0['ids'].tolist()) & set(r1['ids'].tolist()))      # disjoint clips
+    assert not torch.equal(r0['images'], r1['images'])
+    for kind in ('latent', 'steps'):
+        assert not torch.equal(r0['noise'][kind], r1['noise'][kind])                  # per-rank noise streams
+    assert torch.equal(r0['grad'], r1['grad'])                                        # the reduced gradient ...
+    assert torch.equal(r0['after'], r1['after']) and torch.equal(r0['after2'], r1['after2'])     # ... and the replicas stay equal
+    assert not torch.equal(r0['after'], r0['start']) and float(r0['steps']) == 1.0
+
+    # one process, the concatenated batch, the same noise: the same step
+    import model.main as M
+    trainer = M.main(sh_args=_args(path, tmp, random_seed=str(r0['seed']), batch_size='8'))
+    with torch.no_grad():
+        trainer.bucket.data.copy_(r0['start'].to(trainer.bucket.data.device))
+    noise = {k: torch.cat([r0['noise'][k], r1['noise'][k]]) for k in r0['noise']}
+    trainer.stove.noise_fn = lambda kind, shape: noise[kind].reshape(shape)
+    images = torch.cat([r0['images'], r1['images']])
+    elbo, _, _, _, _ = trainer.train_step({'present_images': images}, 1)
+    assert abs(float(elbo) - (r0['elbo'] + r1['elbo']) / 2) < 1e-5 * abs(float(elbo))
+    g1, gd = trainer.bucket.grad.cpu(), r0['grad']
+    assert float((g1 - gd).abs().max()) < 2e-4 * float(g1.abs().max())
+    # Adam's first step is lr * g / (|g| + eps): elements whose gradient is ~0 may step either way, the rest agree
+    diff = (trainer.bucket.data.cpu() - r0['after']).abs()
+    assert float(diff.median()) < 1e-6 and float((diff > 1e-4).float().mean()) < 2e-3, (float(diff.median()), float((diff > 1e-4).float().mean()))
+
+
+def _rccl_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    from stove_amd.arena import ParamArena
+    from stove_amd import parallel
+    from stove_amd.video_prediction.stove import Stove
+    model = Stove(_cfg()).to('cuda:0')
+    arena = ParamArena(model)
+    arena.grad.copy_(torch.sin(torch.arange(arena.numel, device='cuda:0') * 0.01))
+    before = arena.grad.clone()
+    arena.all_reduce(force=True)                    # the flat bucket through RCCL (one rank: sum == identity)
+    dist.broadcast(arena.data, 0)                   # what ParamArena.sync issues
+    ok = torch.equal(arena.grad, before) and parallel.agree_on_seed(None) >= 0 and parallel.broadcast_int(41) == 41
+    torch.cuda.synchronize()
+    torch.save({'ok': bool(ok), 'backend': dist.get_backend()}, out)
+    dist.destroy_process_group()
+
+
+def test_arena_all_reduce_through_rccl(tmp_path):
+    """RCCL itself (backend 'nccl' on ROCm) moves the arena's flat gradient buffer: a one-rank group on the 1-GPU box."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'rccl.pt')
+    mp.spawn(_rccl_worker, args=(port, out), nprocs=1, join=True)
+    got = torch.load(out)
+    assert got['ok'] and got['backend'] == 'nccl'
