@@ -133,8 +133,8 @@ def _trainer_worker(rank, world, port, path, tmp):
     data = next(it)
     ids = trainer.dataloader.last_clip_ids.clone()
     elbo, _, _, _, _ = trainer.train_step(data, 1)
-    out = {'seed': trainer.c.random_seed, 'dp_seed': trainer.c.dp_seed, 'start': start, 'ids': ids, 'noise': rec,
-           'images': data['present_images'].cpu(), 'elbo': float(elbo), 'grad': trainer.bucket.grad.clone().cpu(),
+    out = {'seed': trainer.c.random_seed, 'dp_seed': trainer.c.dp_seed, 'start': start, 'ids': ids, 'noise': dict(rec),
+           'images': data['present_images'].cpu(), 'elbo': float(elbo.detach()), 'grad': trainer.bucket.grad.clone().cpu(),
            'after': trainer.bucket.data.clone().cpu(), 'len': len(trainer.dataloader),
            'steps': trainer.optimizer.state_dict()['state'][0]['step']}
     # a second step keeps the replicas together (moments and step counts are part of the state)
