@@ -275,6 +275,18 @@ int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* ex
                     const int* seg_of4, const unsigned char* seg_trainable, float* seg_steps, int nseg, void* ws, float* grad_norm_out,
                     const float* hyper_dev, float lr, float beta1, float beta2, float eps, float max_norm, int clip, void* stream);
 
+/* ---- the dense products of RnnStates (encoder.py:43-57: nn.LSTM's x W_ih^T, h W_hh^T, fc1, and their gradients) as fp32
+ * GEMMs on the bf16 matrix cores:  C[m][n] = sum_k a(m,k) b(n,k) (+ bias[n]) (+ add[m*ldc + n]),  a(m,k) = A[m*lda + k], or A[k*lda + m] when
+ * a_kmajor (the operand is stored K-major, as dg / x are in the weight-gradient products dW = dg^T x); b likewise.
+ * nsplit = 2: every fp32 operand element is split on the fly into bf16 hi + lo and the product is three bf16 MFMAs with fp32
+ * accumulation (~2^-16 relative per product); nsplit = 1: plain bf16 operands (2^-8), fp32 accumulate.  A, B, bias, C stay fp32.
+ * splitk > 1: K is cut into `splitk` slices computed by different workgroups into ws (stove_gemm_bf16_ws_floats floats), then
+ * summed in slice order into C (needs ldc == N, bias and add NULL): fills the chip when M x N is small and K huge (weight gradients).
+ * lda, ldb, ldc, N and the contiguous extent of each operand (K, or M / N when K-major) must be multiples of 4. */
+size_t stove_gemm_bf16_ws_floats(int M, int N, int splitk);
+int stove_gemm_bf16(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                    int a_kmajor, int b_kmajor, int nsplit, int splitk, float* ws, void* stream);
+
 /* ---- gate math of RnnStates' LSTM (encoder.py:43-51, torch.nn.LSTM cell, gate order i,f,g,o); the GEMMs
  * around it stay on rocBLAS.  gx (n,4H): x W_ih^T + b_ih + b_hh; gh (n,4H): h_prev W_hh^T or NULL; c_prev
  * (n,H) or NULL (zero state).  bwd: dh, dc_in (NULL = 0) -> dg (n,4H), dc_out (n,H); dgx_acc (n,4H) gets

@@ -16,6 +16,7 @@
 #include "lstm.hip"
 #include "arena.hip"
 #include "state.hip"
+#include "gemm_bf16.hip"
 
 namespace stove {
 
@@ -567,6 +568,36 @@ int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void*
   const int n4 = (int)(n / 4);
   STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, parts, out, n4, chunks);
   STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t stove_gemm_bf16_ws_floats(int M, int N, int splitk) { return splitk > 1 ? (size_t)splitk * M * N : 0; }
+
+int stove_gemm_bf16(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                    int a_kmajor, int b_kmajor, int nsplit, int splitk, float* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0 || N == 0) return 0;
+  if (K <= 0 || splitk < 1 || (nsplit != 1 && nsplit != 2)) return (int)hipErrorInvalidValue;
+  // float4 granularity along the contiguous dimension of every operand and of C
+  if ((lda & 3) || (ldb & 3) || (ldc & 3) || (N & 3) || ((a_kmajor ? M : K) & 3) || ((b_kmajor ? N : K) & 3)) return (int)hipErrorInvalidValue;
+  if (splitk > 1 && (ws == nullptr || bias != nullptr || add != nullptr || ldc != N)) return (int)hipErrorInvalidValue;
+  float* out = splitk > 1 ? ws : C;
+  const int ldo = splitk > 1 ? N : ldc;
+  int rc;
+#define STOVE_GEMM_CASE(AK, BK_)                                                                                              \
+  rc = nsplit == 2 ? gemm_launch<AK, BK_, 2>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st)                                \
+                   : gemm_launch<AK, BK_, 1>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st)
+  if (!a_kmajor && !b_kmajor) { STOVE_GEMM_CASE(false, false); }
+  else if (!a_kmajor && b_kmajor) { STOVE_GEMM_CASE(false, true); }
+  else if (a_kmajor && b_kmajor) { STOVE_GEMM_CASE(true, true); }
+  else { STOVE_GEMM_CASE(true, false); }
+#undef STOVE_GEMM_CASE
+  if (rc) return rc;
+  if (splitk > 1) {
+    const int n4 = (int)((size_t)M * N / 4);
+    STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, st, (const float*)ws, C, n4, splitk);
+    STOVE_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -725,31 +725,42 @@ class _blas:
 class _EncoderLstmFn(torch.autograd.Function):
     """num_steps LSTM steps on the SAME input x (reference encoder.py:43-51): hs (n, num_steps, H).
 
-    rocBLAS GEMMs + the fused gate kernels of csrc/lstm.hip.  The input projection x W_ih^T is
-    computed once; its gradient is the sum of the per-step gate gradients (accumulated in-kernel),
-    so dW_ih is ONE (4H x n) @ (n x D) GEMM."""
+    MFMA GEMMs (csrc/gemm_bf16.hip; library fp32 GEMMs with gemm='fp32') + the fused gate kernels of csrc/lstm.hip.  The
+    input projection x W_ih^T is computed once; its gradient is the sum of the per-step gate gradients (accumulated
+    in-kernel), so dW_ih is ONE (4H x n) @ (n x D) GEMM."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major=False):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major=False, gemm='bf16x3'):
         lib = _lib.load()
         x, w_ih, w_hh = _f32(x), _f32(w_ih), _f32(w_hh)
         n, H = x.shape[0], w_hh.shape[1]
         dev = x.device
+        ns = {'bf16x3': 2, 'bf16': 1, 'fp32': 0}[gemm]
+        if not gemm_ok(x.shape[1], H):
+            ns = 0                               # odd sizes: library GEMMs
         with torch.cuda.device(dev):
-            with _blas('hipblas'):
-                gx = torch.addmm(b_ih + b_hh, x, w_ih.t())
+            if ns:
+                gx = gemm_bf16(x, w_ih, bias=_f32(b_ih + b_hh), nsplit=ns, splitk=1)
+            else:
+                with _blas('hipblas'):
+                    gx = torch.addmm(b_ih + b_hh, x, w_ih.t())
             hs = torch.empty(num_steps, n, H, dtype=torch.float32, device=dev)
             cs = torch.empty(num_steps, n, H, dtype=torch.float32, device=dev)
             ghs = []
             for k in range(num_steps):
-                with _blas('hipblas'):
-                    gh = torch.mm(hs[k - 1], w_hh.t()) if k > 0 else None
+                gh = None
+                if k > 0 and ns:
+                    gh = gemm_bf16(hs[k - 1], w_hh, nsplit=ns, splitk=1)
+                elif k > 0:
+                    with _blas('hipblas'):
+                        gh = torch.mm(hs[k - 1], w_hh.t())
                 ghs.append(gh)
                 check(lib.stove_lstm_cell_fwd(ptr(gx), ptr(gh), ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(hs[k]),
                                               n, H, stream()), 'stove_lstm_cell_fwd')
         ctx.save_for_backward(x, w_ih, w_hh, gx, hs, cs, *[g for g in ghs if g is not None])
         ctx.num_steps = num_steps
         ctx.time_major = bool(time_major)
+        ctx.ns = ns
         return hs if time_major else hs.transpose(0, 1)
 
     @staticmethod
@@ -758,9 +769,16 @@ class _EncoderLstmFn(torch.autograd.Function):
         x, w_ih, w_hh, gx, hs, cs = ctx.saved_tensors[:6]
         ghs = [None] + list(ctx.saved_tensors[6:])
         K = ctx.num_steps
+        ns = ctx.ns
         n, H = x.shape[0], w_hh.shape[1]
         dev = x.device
         dhs = _f32(dhs if ctx.time_major else dhs.transpose(0, 1))                       # (K, n, H)
+
+        def wgrad(dy, inp):
+            """dy^T @ inp over all rows: both operands are stored K-major for this product."""
+            if ns and gemm_ok(dy.shape[0]):
+                return gemm_bf16(dy, inp, None, True, True, ns)
+            return _splitk_tn(dy, inp)
         with torch.cuda.device(dev):
             dgx = torch.empty_like(gx)
             # gate gradients of steps 1..K-1 are kept ((K-1) x 105 MB at 25 600 frames) so that dW_hh is ONE
@@ -771,22 +789,60 @@ class _EncoderLstmFn(torch.autograd.Function):
             d_whh = None
             for k in range(K - 1, -1, -1):
                 if k == 0 and K > 1:
-                    d_whh = _splitk_tn(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H))       # before slot 0 is reused
+                    d_whh = wgrad(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H))           # before slot 0 is reused
                 dg = dg_all[max(k - 1, 0)]
                 check(lib.stove_lstm_cell_bwd(ptr(gx), ptr(ghs[k]), ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(dh),
                                               ptr(dc[(k + 1) % 2]) if k < K - 1 else None, ptr(dg), ptr(dc[k % 2]), ptr(dgx),
                                               1 if k == K - 1 else 0, n, H, stream()), 'stove_lstm_cell_bwd')
                 if k > 0:
-                    dh = torch.addmm(dhs[k - 1], dg, w_hh)
+                    if ns:
+                        dh = gemm_bf16(dg, w_hh, None, False, True, ns, 1, add=dhs[k - 1])     # dhs[k-1] + dg W_hh
+                    else:
+                        dh = torch.addmm(dhs[k - 1], dg, w_hh)
             if d_whh is None:
                 d_whh = torch.zeros_like(w_hh)
-            d_wih = _splitk_tn(dgx, x)
+            d_wih = wgrad(dgx, x)
             d_b = colsum(dgx)
         dx = torch.mm(dgx, w_ih) if ctx.needs_input_grad[0] else None
-        return dx, d_wih, d_whh, d_b, d_b, None, None
+        return dx, d_wih, d_whh, d_b, d_b, None, None, None
 
 
-def encoder_lstm(x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major=False):
+def encoder_lstm(x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major=False, gemm='bf16x3'):
     """-> hs (n, num_steps, H), or (num_steps, n, H) with time_major=True: the layout the kernels produce; the row-wise
-    head can run on it directly, which saves two 78 MB transposes per step (only its 8-wide output is permuted)."""
-    return _EncoderLstmFn.apply(x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major)
+    head can run on it directly, which saves two 78 MB transposes per step (only its 8-wide output is permuted).
+    gemm: 'bf16x3' = fp32 products as three bf16 MFMAs on hi/lo-split operands (csrc/gemm_bf16.hip, ~2^-17 relative),
+    'fp32' = library fp32 GEMMs, 'bf16' = plain bf16 operands with fp32 accumulation (the reported, never default, variant)."""
+    return _EncoderLstmFn.apply(x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major, gemm)
+
+
+def gemm_splitk(M, N, K):
+    """K slices that fill the chip when the output has few tiles (weight gradients: 1024 x 1024 over K = 25 600)."""
+    tiles = ((M + 255) // 256) * ((N + 127) // 128)
+    s = 1
+    while tiles * s * 2 <= 256 and K // (s * 2) >= 256:
+        s *= 2
+    return s
+
+
+def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=None, add=None):
+    """C (M, N) = sum_k a(m,k) b(n,k) (+ bias) (+ add) on the bf16 matrix cores with fp32 in / out (csrc/gemm_bf16.hip).
+    a: (M, K), or (K, M) when a_kmajor; b: (N, K), or (K, N) when b_kmajor.  nsplit 2 = hi+lo split (3 MFMAs), 1 = plain bf16.
+    splitk None = chosen from the shape (only without bias / add)."""
+    a, b = _f32(a), _f32(b)
+    M, K = (a.shape[1], a.shape[0]) if a_kmajor else a.shape
+    N = b.shape[1] if b_kmajor else b.shape[0]
+    if splitk is None:
+        splitk = gemm_splitk(M, N, K) if bias is None and add is None else 1
+    lib = _lib.load()
+    c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        ws = torch.empty(lib.stove_gemm_bf16_ws_floats(M, N, splitk), dtype=torch.float32, device=a.device) if splitk > 1 else None
+        check(lib.stove_gemm_bf16(ptr(a), ptr(b), ptr(bias) if bias is not None else None, ptr(_f32(add)) if add is not None else None,
+                                  ptr(c), M, N, K, a.stride(0), b.stride(0), N, int(a_kmajor), int(b_kmajor), nsplit, splitk,
+                                  ptr(ws) if ws is not None else None, stream()), 'stove_gemm_bf16')
+    return c
+
+
+def gemm_ok(*dims):
+    """Shapes the MFMA GEMM takes (float4 granularity); anything else goes to the library."""
+    return all(int(d) % 4 == 0 and int(d) > 0 for d in dims)

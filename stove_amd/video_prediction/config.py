@@ -51,6 +51,7 @@ _DEFAULTS = dict(
     graph_step=False,        # Trainer: replay the non-logging training steps as one captured hipGraph (stove_amd/graphed.py)
     device_dataset=True,     # Trainer: training set resident on the GPU, batches gathered there (load_data.DeviceClipLoader)
     device_dataset_gb=64.0,  # ... when it needs at most this much HBM
+    encoder_gemm='bf16x3',   # recognition-network GEMMs: 'bf16x3' (fp32 as 3 bf16 MFMAs on hi/lo-split operands), 'fp32' (library), 'bf16'
     param_arena=True,        # Trainer: parameters / gradients as views into one flat buffer (stove_amd/arena.py)
 )
 

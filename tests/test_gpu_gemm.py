@@ -1,0 +1,66 @@
+"""The split-bf16 MFMA GEMM of the recognition network (csrc/gemm_bf16.hip through stove_gemm_bf16) against fp64 matmul:
+all four operand layouts, ragged M / N / K (predicated tile edges), split-K, bias, and exact-integer data that pins the
+fragment / transposed-read / k-permutation maps (a symmetric or random check can hide a transposed tile)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+
+
+def _ref(a, b, bias, ak, bk):
+    A = a.double().t() if ak else a.double()
+    B = b.double().t() if bk else b.double()
+    c = A @ B.t()
+    return c + bias.double() if bias is not None else c
+
+
+@pytest.mark.parametrize('ak,bk', [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize('M,N,K,splitk', [(256, 128, 32, 1), (512, 256, 96, 1), (300, 132, 100, 1), (20, 1024, 1024, 1),
+                                            (1024, 256, 3000, 8), (64, 64, 4, 3)])
+def test_gemm_layouts_and_edges(ak, bk, M, N, K, splitk):
+    from stove_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((K, M) if ak else (M, K), generator=g).to(DEV)
+    b = torch.randn((K, N) if bk else (N, K), generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV) if splitk == 1 else None
+    ref = _ref(a, b, bias, ak, bk)
+    scale = float(ref.abs().max())
+    for nsplit, tol in ((2, 1.5e-5), (1, 2e-2)):
+        c = ops.gemm_bf16(a, b, bias, ak, bk, nsplit, splitk)
+        err = float((c.double() - ref).abs().max()) / scale
+        assert err < tol, (nsplit, err)
+
+
+@pytest.mark.parametrize('ak,bk', [(False, False), (False, True), (True, True), (True, False)])
+def test_gemm_exact_on_small_integers(ak, bk):
+    """bf16 holds integers up to 256 exactly and fp32 accumulation of such products is exact: any wrong lane / k map shows
+    as a non-zero difference.  B is asymmetric (not a function of |row - col| or row + col)."""
+    from stove_amd import ops
+    M, N, K = 256 + 16, 128 + 4, 64 + 8
+    m, n, k = torch.arange(M).view(-1, 1), torch.arange(N).view(-1, 1), torch.arange(K).view(1, -1)
+    a = ((m * 3 + k * 5) % 17 - 8).float()
+    b = ((n * 7 + k * 11 + (n * k) % 5) % 13 - 6).float()
+    at, bt = (a.t().contiguous() if ak else a), (b.t().contiguous() if bk else b)
+    for nsplit in (1, 2):
+        c = ops.gemm_bf16(at.to(DEV), bt.to(DEV), None, ak, bk, nsplit, 1)
+        assert torch.equal(c.cpu(), a @ b.t())
+
+
+def test_gemm_encoder_shapes_accuracy():
+    """The headline shapes (25 600 frames): input projection x W_ih^T and its weight gradient dgx^T x; error of the 3-MFMA
+    split against fp64, next to the fp32 library GEMM's own error."""
+    from stove_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(25600, 1024, generator=g).to(DEV)
+    w = (torch.randn(1024, 1024, generator=g) * 0.03).to(DEV)
+    ref = x[:2048].double() @ w.double().t()
+    got = ops.gemm_bf16(x, w)[:2048].double()
+    lib = (x[:2048] @ w.t()).double()
+    e_split = float((got - ref).abs().max() / ref.abs().max())
+    e_lib = float((lib - ref).abs().max() / ref.abs().max())
+    assert e_split < 1e-5, (e_split, e_lib)
+    dg = torch.randn(25600, 1024, generator=g).to(DEV)
+    ref = dg.double().t() @ x.double()
+    got = ops.gemm_bf16(dg, x, None, True, True, 2, 8).double()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
