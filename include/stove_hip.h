@@ -282,10 +282,11 @@ int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* ex
  * accumulation (~2^-16 relative per product); nsplit = 1: plain bf16 operands (2^-8), fp32 accumulate.  A, B, bias, C stay fp32.
  * splitk > 1: K is cut into `splitk` slices computed by different workgroups into ws (stove_gemm_bf16_ws_floats floats), then
  * summed in slice order into C (needs ldc == N, bias and add NULL): fills the chip when M x N is small and K huge (weight gradients).
+ * tile: workgroup tile, 0 = chosen by the library, 1 = 256 x 128 (8 waves), 2 = 128 x 128 (4 waves).
  * lda, ldb, ldc, N and the contiguous extent of each operand (K, or M / N when K-major) must be multiples of 4. */
 size_t stove_gemm_bf16_ws_floats(int M, int N, int splitk);
 int stove_gemm_bf16(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                    int a_kmajor, int b_kmajor, int nsplit, int splitk, float* ws, void* stream);
+                    int a_kmajor, int b_kmajor, int nsplit, int splitk, int tile, float* ws, void* stream);
 
 /* ---- gate math of RnnStates' LSTM (encoder.py:43-51, torch.nn.LSTM cell, gate order i,f,g,o); the GEMMs
  * around it stay on rocBLAS.  gx (n,4H): x W_ih^T + b_ih + b_hh; gh (n,4H): h_prev W_hh^T or NULL; c_prev

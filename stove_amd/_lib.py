@@ -97,7 +97,7 @@ def _declare(lib):
         'stove_sum_chunks': (I, [P, P, S, I, P]),
         'stove_flat_adam_ws_bytes': (S, [I]),
         'stove_gemm_bf16_ws_floats': (S, [I, I, I]),
-        'stove_gemm_bf16': (I, [P, P, P, P, P] + [I] * 10 + [P, P]),
+        'stove_gemm_bf16': (I, [P, P, P, P, P] + [I] * 11 + [P, P]),
         'stove_flat_adam': (I, [P] * 5 + [S, P, P, P, I, P, P, P, F, F, F, F, F, I, P]),
         'stove_supair_state_fwd': (I, [P] * 10 + [I] * 6 + [P]),
         'stove_supair_state_bwd': (I, [P] * 11 + [I] * 4 + [P]),

@@ -573,25 +573,35 @@ int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void*
 
 size_t stove_gemm_bf16_ws_floats(int M, int N, int splitk) { return splitk > 1 ? (size_t)splitk * M * N : 0; }
 
-int stove_gemm_bf16(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                    int a_kmajor, int b_kmajor, int nsplit, int splitk, float* ws, void* stream) {
+int stove_gemm_bf16(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda,
+                    int ldb, int ldc, int a_kmajor, int b_kmajor, int nsplit, int splitk, int tile, float* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (M == 0 || N == 0) return 0;
-  if (K <= 0 || splitk < 1 || (nsplit != 1 && nsplit != 2)) return (int)hipErrorInvalidValue;
+  if (K <= 0 || splitk < 1 || (nsplit != 1 && nsplit != 2) || tile < 0 || tile > 2) return (int)hipErrorInvalidValue;
   // float4 granularity along the contiguous dimension of every operand and of C
   if ((lda & 3) || (ldb & 3) || (ldc & 3) || (N & 3) || ((a_kmajor ? M : K) & 3) || ((b_kmajor ? N : K) & 3)) return (int)hipErrorInvalidValue;
   if (splitk > 1 && (ws == nullptr || bias != nullptr || add != nullptr || ldc != N)) return (int)hipErrorInvalidValue;
   float* out = splitk > 1 ? ws : C;
   const int ldo = splitk > 1 ? N : ldc;
+  if (tile == 0) tile = 1;
   int rc;
-#define STOVE_GEMM_CASE(AK, BK_)                                                                                              \
-  rc = nsplit == 2 ? gemm_launch<AK, BK_, 2>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st)                                \
-                   : gemm_launch<AK, BK_, 1>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st)
-  if (!a_kmajor && !b_kmajor) { STOVE_GEMM_CASE(false, false); }
-  else if (!a_kmajor && b_kmajor) { STOVE_GEMM_CASE(false, true); }
-  else if (a_kmajor && b_kmajor) { STOVE_GEMM_CASE(true, true); }
-  else { STOVE_GEMM_CASE(true, false); }
+#define STOVE_GEMM_TILE(AK, BK_, NS)                                                                       \
+  rc = tile == 1 ? gemm_launch<AK, BK_, NS, 256, 128>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st) \
+                 : gemm_launch<AK, BK_, NS, 128, 128>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st)
+#define STOVE_GEMM_CASE(AK, BK_)             \
+  do {                                       \
+    if (nsplit == 2) {                       \
+      STOVE_GEMM_TILE(AK, BK_, 2);           \
+    } else {                                 \
+      STOVE_GEMM_TILE(AK, BK_, 1);           \
+    }                                        \
+  } while (0)
+  if (!a_kmajor && !b_kmajor) STOVE_GEMM_CASE(false, false);
+  else if (!a_kmajor && b_kmajor) STOVE_GEMM_CASE(false, true);
+  else if (a_kmajor && b_kmajor) STOVE_GEMM_CASE(true, true);
+  else STOVE_GEMM_CASE(true, false);
 #undef STOVE_GEMM_CASE
+#undef STOVE_GEMM_TILE
   if (rc) return rc;
   if (splitk > 1) {
     const int n4 = (int)((size_t)M * N / 4);

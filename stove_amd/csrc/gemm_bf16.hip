@@ -37,11 +37,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
-constexpr int kGemmBM = 256, kGemmBN = 128, kGemmBK = 32, kGemmThreads = 512;
-constexpr int kGemmAStrideKM = (kGemmBM + 16) * 2;        // bytes per k-row of a K-major A image
-constexpr int kGemmBStrideKM = (kGemmBN + 16) * 2;
-constexpr int kGemmAPart = kGemmBK * kGemmAStrideKM;      // 17 408 B >= 256 rows x 64 B
-constexpr int kGemmBPart = kGemmBK * kGemmBStrideKM;      //  9 216 B >= 128 rows x 64 B
+constexpr int kGemmBK = 32;
+// bytes of one bf16 image of a ROWS x 32 operand tile: K-major images are [32][ROWS + 16], K-contiguous ones [ROWS][32]
+constexpr int gemm_part_bytes(int rows) { return kGemmBK * (rows + 16) * 2; }
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   const bf16x2 v = {(__bf16)a, (__bf16)b};
@@ -60,33 +58,66 @@ __device__ __forceinline__ void split4(const float4 v, u32x2& hi, u32x2& lo) {
   }
 }
 
-// one operand tile (ROWS x 32) of k-step `k0`: NLD float4 per thread
-template <int ROWS, bool KMAJOR>
-struct TileLoad {
-  static constexpr int NLD = ROWS * kGemmBK / 4 / kGemmThreads;
-  float4 v[NLD];
-  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int n_rows, int k0, int k_end, int tid) {
+// Where one thread's NLD float4 pieces of an operand tile (ROWS x 32) come from: a running pointer per piece, advanced by one
+// k-step per tile, plus the piece's k offset inside the tile and whether its rows exist (edge tiles).
+template <int ROWS, bool KMAJOR, int THREADS>
+struct TileSrc {
+  static constexpr int NLD = ROWS * kGemmBK / 4 / THREADS;
+  const float* p[NLD];
+  const float* safe;
+  int kloc[NLD];
+  unsigned rowmask;
+  size_t step;
+  __device__ __forceinline__ void init(const float* __restrict__ P, int ld, int row0, int n_rows, int k_begin, int tid) {
+    rowmask = 0u;
+    safe = P;
+    step = KMAJOR ? (size_t)kGemmBK * ld : (size_t)kGemmBK;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      const int f = tid + kGemmThreads * j;
-      int row, k;
+      const int f = tid + THREADS * j;
+      int row;
       if (KMAJOR) {
-        k = k0 + f / (ROWS / 4);
+        kloc[j] = f / (ROWS / 4);
         row = row0 + 4 * (f % (ROWS / 4));
       } else {
         row = row0 + (f >> 3);
-        k = k0 + 4 * (f & 7);
+        kloc[j] = 4 * (f & 7);
       }
-      const bool ok = row < n_rows && k < k_end;
-      const float* src = KMAJOR ? P + (size_t)k * ld + row : P + (size_t)row * ld + k;
-      v[j] = ok ? *reinterpret_cast<const float4*>(src) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+      const int k = k_begin + kloc[j];
+      p[j] = KMAJOR ? P + (size_t)k * ld + row : P + (size_t)row * ld + k;
+      rowmask |= row < n_rows ? (1u << j) : 0u;
+    }
+  }
+};
+
+// one staged operand tile: NLD float4 per thread
+template <int ROWS, bool KMAJOR, int THREADS>
+struct TileLoad {
+  static constexpr int NLD = ROWS * kGemmBK / 4 / THREADS;
+  float4 v[NLD];
+  unsigned okmask;      // bit j: piece j is inside the operand (the zeroing of edge pieces is deferred to store_piece: a
+                        // select right behind the load would make the wave wait for it at once)
+  // loads the tile whose first k is `k0` and advances the source by one k-step
+  __device__ __forceinline__ void load(TileSrc<ROWS, KMAJOR, THREADS>& src, int k0, int k_end) {
+    okmask = 0u;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      // branch-free edge predication: out-of-range pieces read the operand's first float4 (always valid) and are zeroed later
+      const bool ok = ((src.rowmask >> j) & 1u) && (k0 + src.kloc[j] < k_end);
+      v[j] = *reinterpret_cast<const float4*>(ok ? src.p[j] : src.safe);
+      okmask |= ok ? (1u << j) : 0u;
+      src.p[j] += src.step;
     }
   }
   template <int NSPLIT>
   __device__ __forceinline__ void store(char* hi_img, char* lo_img, int tid) const {
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-      const int f = tid + kGemmThreads * j;
+    for (int j = 0; j < NLD; ++j) store_piece<NSPLIT>(j, hi_img, lo_img, tid);
+  }
+  template <int NSPLIT>
+  __device__ __forceinline__ void store_piece(int j, char* hi_img, char* lo_img, int tid) const {
+    {
+      const int f = tid + THREADS * j;
       int off;
       if (KMAJOR) {
         off = (f / (ROWS / 4)) * ((ROWS + 16) * 2) + (f % (ROWS / 4)) * 8;
@@ -95,7 +126,7 @@ struct TileLoad {
         off = row * 64 + ((((kq & 3) << 4) | ((kq >> 2) << 3)) ^ (((row >> 3) & 1) << 5));
       }
       u32x2 hi, lo;
-      split4<NSPLIT>(v[j], hi, lo);
+      split4<NSPLIT>(((okmask >> j) & 1u) ? v[j] : float4{0.0f, 0.0f, 0.0f, 0.0f}, hi, lo);
       *reinterpret_cast<u32x2*>(hi_img + off) = hi;
       if (NSPLIT == 2) *reinterpret_cast<u32x2*>(lo_img + off) = lo;
     }
@@ -120,14 +151,16 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int r0, int lane) {
   }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT>
-__global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_k(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT, int BM, int BN>
+__global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                                                const float* __restrict__ add, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
                                                                int tiles_m, int tiles_n, int splitk, int k_per_slice) {
   extern __shared__ __attribute__((aligned(16))) char gemm_lds[];
+  constexpr int kGemmBM = BM, kGemmBN = BN, THREADS = BM * BN / 64;      // one wave per 64 x 64 of the tile
+  constexpr int kGemmAPart = gemm_part_bytes(BM), kGemmBPart = gemm_part_bytes(BN);
   constexpr int STAGE = NSPLIT * (kGemmAPart + kGemmBPart);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wm = wv >> 1, wn = wv & 1;
+  const int wm = wv / (BN / 64), wn = wv % (BN / 64);
   // XCD-aware tile id
   const int n_wg = tiles_m * tiles_n * splitk;
   int id = blockIdx.x;
@@ -144,27 +177,37 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_k(const float* __re
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-  TileLoad<kGemmBM, A_KMAJOR> la;
-  TileLoad<kGemmBN, B_KMAJOR> lb;
   auto img = [&](int stage, int which) -> char* {      // which: 0 A_hi, 1 A_lo, 2 B_hi, 3 B_lo
     char* s = gemm_lds + stage * STAGE;
     if (NSPLIT == 2) return s + (which < 2 ? which * kGemmAPart : 2 * kGemmAPart + (which - 2) * kGemmBPart);
     return s + (which < 2 ? 0 : kGemmAPart);
   };
+  // Two register sets of staged fp32 pieces: tile t+1 sits in one while tile t+2 is being loaded into the other.  The loads of
+  // tile t+2 are issued at the top of step t and consumed in step t+1 (a whole k-step of MFMAs later); the pieces of tile t+1
+  // are converted and written into the other LDS buffer BETWEEN the MFMA groups of step t, so the matrix pipe never waits for
+  // the staging of the same wave.  One barrier per k-step.
+  TileLoad<kGemmBM, A_KMAJOR, THREADS> la0, la1;
+  TileLoad<kGemmBN, B_KMAJOR, THREADS> lb0, lb1;
+  TileSrc<kGemmBM, A_KMAJOR, THREADS> sa;
+  TileSrc<kGemmBN, B_KMAJOR, THREADS> sb;
+  sa.init(A, lda, m0, M, k_begin, tid);
+  sb.init(B, ldb, n0, N, k_begin, tid);
   if (nt > 0) {
-    la.load(A, lda, m0, M, k_begin, k_end, tid);
-    lb.load(B, ldb, n0, N, k_begin, k_end, tid);
-    la.template store<NSPLIT>(img(0, 0), img(0, 1), tid);
-    lb.template store<NSPLIT>(img(0, 2), img(0, 3), tid);
+    la0.load(sa, k_begin, k_end);
+    lb0.load(sb, k_begin, k_end);
+    la1.load(sa, k_begin + kGemmBK, k_end);
+    lb1.load(sb, k_begin + kGemmBK, k_end);
+    la0.template store<NSPLIT>(img(0, 0), img(0, 1), tid);
+    lb0.template store<NSPLIT>(img(0, 2), img(0, 3), tid);
   }
   __syncthreads();
-  for (int t = 0; t < nt; ++t) {
+  auto kstep = [&](int t, auto& a_next, auto& b_next, auto& a_far, auto& b_far) {
     const int cur = t & 1;
-    const bool more = t + 1 < nt;
-    if (more) {
-      la.load(A, lda, m0, M, k_begin + (t + 1) * kGemmBK, k_end, tid);
-      lb.load(B, ldb, n0, N, k_begin + (t + 1) * kGemmBK, k_end, tid);
-    }
+    // no branches in here: past the last tile the loads are predicated off (they read the operand's first float4) and the
+    // stores write a zero tile nobody reads.  With a branch around either, hipcc has to assume the worse path and waits for the
+    // loads it has just issued (s_waitcnt vmcnt counts in issue order).
+    a_far.load(sa, k_begin + (t + 2) * kGemmBK, k_end);
+    b_far.load(sb, k_begin + (t + 2) * kGemmBK, k_end);
     bf16x8 ah[4], bh[4], al[4], bl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -176,7 +219,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_k(const float* __re
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (NSPLIT == 2) {
@@ -185,11 +228,20 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_k(const float* __re
         }
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
       }
-    if (more) {
-      la.template store<NSPLIT>(img(cur ^ 1, 0), img(cur ^ 1, 1), tid);
-      lb.template store<NSPLIT>(img(cur ^ 1, 2), img(cur ^ 1, 3), tid);
+      // a quarter of the next tile's staging behind every quarter of the MFMAs
+      constexpr int NA = decltype(la0)::NLD, NB = decltype(lb0)::NLD;
+#pragma unroll
+      for (int q = 0; q < NA; ++q)
+        if (q % 4 == i) a_next.template store_piece<NSPLIT>(q, img(cur ^ 1, 0), img(cur ^ 1, 1), tid);
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+        if ((q + 2) % 4 == i) b_next.template store_piece<NSPLIT>(q, img(cur ^ 1, 2), img(cur ^ 1, 3), tid);
     }
     __syncthreads();
+  };
+  for (int t = 0; t < nt; t += 2) {
+    kstep(t, la1, lb1, la0, lb0);
+    if (t + 1 < nt) kstep(t + 1, la0, lb0, la1, lb1);
   }
   // epilogue: lane holds C[m][n .. n+3], m = tile row (lane & 15), n = 4 (lane >> 4) + reg
   float* out = C + (splitk > 1 ? (size_t)z * M * ldc : 0);
@@ -216,17 +268,17 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_k(const float* __re
 }
 
 // LDS bytes of the kernel
-constexpr int gemm_lds_bytes(int nsplit) { return 2 * nsplit * (kGemmAPart + kGemmBPart); }
+constexpr int gemm_lds_bytes(int nsplit, int bm, int bn) { return 2 * nsplit * (gemm_part_bytes(bm) + gemm_part_bytes(bn)); }
 
-template <bool AK, bool BK_, int NS>
+template <bool AK, bool BK_, int NS, int BM = 256, int BN = 128>
 static int gemm_launch(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                        int splitk, hipStream_t st) {
-  const int tiles_m = (M + kGemmBM - 1) / kGemmBM, tiles_n = (N + kGemmBN - 1) / kGemmBN;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   int kper = ((K + splitk - 1) / splitk + kGemmBK - 1) / kGemmBK * kGemmBK;
-  const void* fn = (const void*)gemm_bf16_k<AK, BK_, NS>;
-  int rc = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(NS));
+  const void* fn = (const void*)gemm_bf16_k<AK, BK_, NS, BM, BN>;
+  int rc = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(NS, BM, BN));
   if (rc) return rc;
-  STOVE_LAUNCH((gemm_bf16_k<AK, BK_, NS>), dim3(tiles_m * tiles_n * splitk), dim3(kGemmThreads), gemm_lds_bytes(NS), st, A, B, bias, add, C,
+  STOVE_LAUNCH((gemm_bf16_k<AK, BK_, NS, BM, BN>), dim3(tiles_m * tiles_n * splitk), dim3(BM * BN / 64), gemm_lds_bytes(NS, BM, BN), st, A, B, bias, add, C,
                M, N, K, lda, ldb, ldc, tiles_m, tiles_n, splitk, kper);
   STOVE_LAUNCH_CHECK();
   return 0;

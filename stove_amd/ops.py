@@ -824,7 +824,7 @@ def gemm_splitk(M, N, K):
     return s
 
 
-def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=None, add=None):
+def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=None, add=None, tile=0):
     """C (M, N) = sum_k a(m,k) b(n,k) (+ bias) (+ add) on the bf16 matrix cores with fp32 in / out (csrc/gemm_bf16.hip).
     a: (M, K), or (K, M) when a_kmajor; b: (N, K), or (K, N) when b_kmajor.  nsplit 2 = hi+lo split (3 MFMAs), 1 = plain bf16.
     splitk None = chosen from the shape (only without bias / add)."""
@@ -838,7 +838,7 @@ def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=
     with torch.cuda.device(a.device):
         ws = torch.empty(lib.stove_gemm_bf16_ws_floats(M, N, splitk), dtype=torch.float32, device=a.device) if splitk > 1 else None
         check(lib.stove_gemm_bf16(ptr(a), ptr(b), ptr(bias) if bias is not None else None, ptr(_f32(add)) if add is not None else None,
-                                  ptr(c), M, N, K, a.stride(0), b.stride(0), N, int(a_kmajor), int(b_kmajor), nsplit, splitk,
+                                  ptr(c), M, N, K, a.stride(0), b.stride(0), N, int(a_kmajor), int(b_kmajor), nsplit, splitk, tile,
                                   ptr(ws) if ws is not None else None, stream()), 'stove_gemm_bf16')
     return c
 

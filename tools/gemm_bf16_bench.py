@@ -8,6 +8,8 @@ import torch
 
 from stove_amd import ops
 
+TILE = int(os.environ.get('GEMM_TILE', '0'))
+
 dev = torch.device('cuda:0')
 n = 25600
 
@@ -34,11 +36,11 @@ dg = torch.randn(n, 1024, device=dev)
 dg2 = torch.randn(2 * n, 1024, device=dev)
 h2 = torch.randn(2 * n, 256, device=dev)
 cases = [
-    ('gx = x W_ih^T        (25600x1024x1024)', lambda ns: ops.gemm_bf16(x, w_ih, None, False, False, ns, 1), lambda: x @ w_ih.t(), 2 * n * 1024 * 1024),
-    ('gh = h W_hh^T        (25600x1024x256)', lambda ns: ops.gemm_bf16(h, w_hh, None, False, False, ns, 1), lambda: h @ w_hh.t(), 2 * n * 1024 * 256),
-    ('dh = dg W_hh         (25600x256x1024)', lambda ns: ops.gemm_bf16(dg, w_hh, None, False, True, ns, 1), lambda: dg @ w_hh, 2 * n * 1024 * 256),
-    ('dW_ih = dgx^T x      (1024x1024x25600, split-K 8)', lambda ns: ops.gemm_bf16(dg, x, None, True, True, ns, 8), lambda: dg.t() @ x, 2 * n * 1024 * 1024),
-    ('dW_hh = dg^T h       (1024x256x51200, split-K 32)', lambda ns: ops.gemm_bf16(dg2, h2, None, True, True, ns, 32), lambda: dg2.t() @ h2, 4 * n * 1024 * 256),
+    ('gx = x W_ih^T        (25600x1024x1024)', lambda ns: ops.gemm_bf16(x, w_ih, None, False, False, ns, 1, tile=TILE), lambda: x @ w_ih.t(), 2 * n * 1024 * 1024),
+    ('gh = h W_hh^T        (25600x1024x256)', lambda ns: ops.gemm_bf16(h, w_hh, None, False, False, ns, 1, tile=TILE), lambda: h @ w_hh.t(), 2 * n * 1024 * 256),
+    ('dh = dg W_hh         (25600x256x1024)', lambda ns: ops.gemm_bf16(dg, w_hh, None, False, True, ns, 1, tile=TILE), lambda: dg @ w_hh, 2 * n * 1024 * 256),
+    ('dW_ih = dgx^T x      (1024x1024x25600, split-K 8)', lambda ns: ops.gemm_bf16(dg, x, None, True, True, ns, 8, tile=TILE), lambda: dg.t() @ x, 2 * n * 1024 * 1024),
+    ('dW_hh = dg^T h       (1024x256x51200, split-K 32)', lambda ns: ops.gemm_bf16(dg2, h2, None, True, True, ns, 32, tile=TILE), lambda: dg2.t() @ h2, 4 * n * 1024 * 256),
 ]
 for name, mine, lib, flops in cases:
     t2, t1, tl = timeit(lambda: mine(2)), timeit(lambda: mine(1)), timeit(lib)
