@@ -9,6 +9,7 @@
 #include "spn_obj.hip"
 #include "spn_bg.hip"
 #include "scene.hip"
+#include "scene_fused.hip"
 #include "gnn.hip"
 #include "match.hip"
 #include "gnn_small.hip"
@@ -60,13 +61,14 @@ static int scene_tile_fwd_any(const float* frames, const float* z, float* xw, in
 
 static inline int nmax_of(int n_obj) { return n_obj <= 3 ? 3 : (n_obj <= 6 ? 6 : 8); }
 
+// Tail of the scene backward: dL/d tile + transformer / mask backward in one pass over the leaf gradients `Dscr`
+// (scene_pixtile_bwd_k), then the per-object sums with the background chain's dz_bg.
 template <int NMAX>
-static int scene_bwd_tail(const float* frames, const float* z, const float* dxw, const float* d_ovl, float* dzc,
-                          const float* dll, const float* obj_ll, const float* dz_bg, float* dz, int n_obj, int np,
-                          hipStream_t st, hipStream_t bg_stream) {
-  const int nb = (np + 63) / 64;
-  STOVE_LAUNCH((scene_tile_bwd_k<NMAX>), dim3(nb < 4096 ? nb : 4096), dim3(256), 0, st, frames, z, dxw, d_ovl, dzc, n_obj, np, nb);
-  STOVE_LAUNCH_CHECK();
+static int scene_bwd_tail(const float* frames, const float* z, const float* xw, const float* Dscr, const int* leaf_slot,
+                          const float* coef, const float* d_ovl, float* dzc, const float* dll, const float* obj_ll,
+                          const float* dz_bg, float* dz, int n_obj, int np, hipStream_t st, hipStream_t bg_stream) {
+  int rc = scene_pixtile_bwd<NMAX>(frames, z, xw, Dscr, leaf_slot, coef, d_ovl, dzc, n_obj, np, st);
+  if (rc) return rc;
   STOVE_TRY(stream_after(st, bg_stream));       // join: only the last kernel needs the background chain's dz_bg
   STOVE_LAUNCH((scene_finalize_bwd_k<NMAX>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, obj_ll, dz_bg, dzc, dz, n_obj, np);
   STOVE_LAUNCH_CHECK();
@@ -197,15 +199,14 @@ int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z
   return 0;
 }
 
-// ws = [ dxw tile | d_obj (np) | d_ovl (np) | dzc (np*NMAX*4) | dz_bg (np*4) | obj ws | bg ws ]
+// ws = [ d_obj (np) | d_ovl (np) | dzc (np*NMAX*4) | dz_bg (np*4) | obj ws | bg ws ]
 struct SceneWs {
-  size_t dxw, d_obj, d_ovl, dzc, dz_bg, obj, bg, total;
+  size_t d_obj, d_ovl, dzc, dz_bg, obj, bg, total;
 };
 static SceneWs scene_ws_layout(int nf, int n_obj) {
   const size_t np = (size_t)nf * n_obj;
   SceneWs s;
-  s.dxw = 0;
-  s.d_obj = align64(stove_objspn_tile_floats((int)np));
+  s.d_obj = 0;
   s.d_ovl = s.d_obj + align64(np);
   s.dzc = s.d_ovl + align64(np);
   s.dz_bg = s.dzc + align64(np * nmax_of(n_obj) * 4);
@@ -251,7 +252,7 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
   JoinGuard jb(st, sb);                         // error paths: the tail below is what joins `sb` normally
   JoinGuard jp(st, sp);                         // error paths only: the caller joins the parameter stream after a clean return
   int rc = objspn_backward_data(saved + L.xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot,
-                                saved + L.obj_ll, ws + W.d_obj, ws + W.dxw, ws + W.obj, np, st, saved + L.obj_state);
+                                saved + L.obj_ll, ws + W.d_obj, nullptr, ws + W.obj, np, st, saved + L.obj_state);
   if (rc) return rc;
   // The object-SPN table gradients (coefgrad + wgrad + reductions, ~0.5 ms of throughput-bound work) start right behind
   // their producer on the parameter stream, or (STOVE_PARAMS_LATE=1) only once dz is out.
@@ -266,11 +267,14 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
   if (rc) return rc;
   // the tail joins `sb` before its last kernel (dz_bg; without a parameter stream also the bg table grads)
   if (n_obj <= 3)
-    rc = scene_bwd_tail<3>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st, sb);
+    rc = scene_bwd_tail<3>(frames, z, saved + L.xw, ws + W.obj, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
+                           ws + W.dz_bg, dz, n_obj, np, st, sb);
   else if (n_obj <= 6)
-    rc = scene_bwd_tail<6>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st, sb);
+    rc = scene_bwd_tail<6>(frames, z, saved + L.xw, ws + W.obj, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
+                           ws + W.dz_bg, dz, n_obj, np, st, sb);
   else if (n_obj <= 8)
-    rc = scene_bwd_tail<8>(frames, z, ws + W.dxw, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll, ws + W.dz_bg, dz, n_obj, np, st, sb);
+    rc = scene_bwd_tail<8>(frames, z, saved + L.xw, ws + W.obj, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
+                           ws + W.dz_bg, dz, n_obj, np, st, sb);
   else
     rc = (int)hipErrorInvalidValue;
   if (rc) return rc;

@@ -621,6 +621,172 @@ __global__ __launch_bounds__(R * 2 * G * 2 + ((R * K + 63) / 64) * 64) void objs
   }
 }
 
+// ---- backward (all table gradients) on the matrix cores ------------------------------------------------------------
+// The three table gradients are sums over the samples of outer products,
+//     d coef[r][L][i][g][c] = sum_s  f_c(x, w)[pixel(r, L, i)][s] * dl[r][L][g][s]          f = (w x^2, w x, w)
+//     d wsum[node][j2 G + j1][k] = sum_s  E1[j1][s] E2[j2][s] * gamma[k][s]
+//     d wroot[r][j2 K + j1]      = sum_s  rho[s] EB[j2][s] * EA[j1][s]
+// i.e. GEMMs with the sample index as K: M = 75 / 100 / 10 rows, N = 10 columns, K = 64 per batch -- what objspn_coefgrad_k
+// and objspn_wgrad_k (kept below for reference sizes other than the template's) do with one thread per output row on the
+// VALU, which is also what every other kernel of this phase of the step is bound by.  Here they go through
+// v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, so the numerics stay those of an fp32 sum; the matrix pipe is otherwise idle
+// in the backward): a wave = one (replica, side) = its two leaves, its sum node and (side 0) the replica's root, 18 output
+// tiles of 16 x 16 held in 72 accumulator registers across ALL batches of the workgroup's chunk.
+// Operands are rows of 64 samples stored sample-contiguous ([row][64]); lane (row = lane & 15, kk = lane >> 4) takes the 16
+// samples 16 kk .. 16 kk + 15 of its row as four float4 and feeds sample 16 kk + s in k-slot kk of MFMA s (A and B use the
+// same assignment; a sum over samples does not care).  Rows beyond M and columns beyond N compute garbage that is never
+// stored (rows / columns of an MFMA result are independent).  The glimpse tile (read by all six replicas) and the sum-node
+// scratch are staged in LDS with rows padded to 68 floats (2-way instead of 8-way bank conflicts on the 16-byte reads).
+// Fixed summation order: bitwise reproducible.
+template <int R, int S, int G, int K>
+__global__ __launch_bounds__(128 * R) void objspn_tablegrad_k(
+    const float* __restrict__ xw, const float* __restrict__ Dscr, const float* __restrict__ Sscr, const float* __restrict__ Rscr,
+    const int* __restrict__ scope, float* __restrict__ part_c, float* __restrict__ part_w, float* __restrict__ part_r,
+    int n_batches, int n_chunks) {
+  constexpr int D = 4 * S, LD = 68, NS = K + 2 * G;
+  constexpr int TC = (3 * S + 15) / 16, TW = (G * G + 15) / 16;       // 5 coefficient tiles per leaf, 7 sum-weight tiles
+  static_assert(G <= 16 && K <= 16, "one column tile");
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  extern __shared__ __attribute__((aligned(16))) float tg_lds[];
+  float* tileP = tg_lds;                         // [2 D][LD]: row 2 p = x of pixel p, 2 p + 1 = w
+  float* nodeS = tileP + 2 * D * LD;             // [2 R][NS][LD]: gamma[K] | E1[G] | E2[G] of every sum node
+  const int lane = lane_id(), wv = wave_id();
+  const int r = wv >> 1, side = wv & 1, node = wv;
+  const int rr = lane & 15, kk = lane >> 4;
+  const int c = blockIdx.x;
+  // per-lane row descriptors (constant over the batches)
+  int c_row[2][TC], c_feat[2][TC];               // tileP row of the pixel's x, feature index 0..2
+#pragma unroll
+  for (int l2 = 0; l2 < 2; ++l2)
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+      const int row = min(16 * t + rr, 3 * S - 1);
+      c_feat[l2][t] = row / S;
+      c_row[l2][t] = 2 * scope[(r * 4 + side * 2 + l2) * S + row % S];
+    }
+  int w_e1[TW], w_e2[TW];                        // nodeS rows of E1[j1], E2[j2] of sum-weight row j2 G + j1
+#pragma unroll
+  for (int t = 0; t < TW; ++t) {
+    const int row = min(16 * t + rr, G * G - 1);
+    w_e1[t] = K + row % G;
+    w_e2[t] = K + G + row / G;
+  }
+  f4 acc_c[2][TC], acc_w[TW], acc_r;
+#pragma unroll
+  for (int l2 = 0; l2 < 2; ++l2)
+#pragma unroll
+    for (int t = 0; t < TC; ++t) acc_c[l2][t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int t = 0; t < TW; ++t) acc_w[t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+  acc_r = f4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  for (int b = c; b < n_batches; b += n_chunks) {
+    {   // stage the tile (all waves) and the wave's own sum-node scratch
+      const float4* src = reinterpret_cast<const float4*>(xw + (size_t)b * (D * 2 * 64));
+      for (int i = threadIdx.x; i < 2 * D * 16; i += 128 * R)
+        *reinterpret_cast<float4*>(tileP + (i >> 4) * LD + 4 * (i & 15)) = src[i];
+      const float4* ss = reinterpret_cast<const float4*>(Sscr + (size_t)(b * R * 2 + node) * NS * 64);
+      float* dst = nodeS + node * NS * LD;
+      for (int i = lane; i < NS * 16; i += 64) *reinterpret_cast<float4*>(dst + (i >> 4) * LD + 4 * (i & 15)) = ss[i];
+    }
+    __syncthreads();
+    // ---- leaf coefficients: A = features of the leaf's pixels, B = leaf gradients
+#pragma unroll
+    for (int l2 = 0; l2 < 2; ++l2) {
+      const int L = side * 2 + l2;
+      const float4* dp = reinterpret_cast<const float4*>(Dscr + (((size_t)(b * R + r) * 4 + L) * G + min(rr, G - 1)) * 64 + 16 * kk);
+      const float4 d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3];
+      const float dv[16] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x, d3.y, d3.z, d3.w};
+#pragma unroll
+      for (int t = 0; t < TC; ++t) {
+        const float* xr = tileP + c_row[l2][t] * LD + 16 * kk;
+        const int feat = c_feat[l2][t];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const float4 x4 = *reinterpret_cast<const float4*>(xr + 4 * h);
+          const float4 w4 = *reinterpret_cast<const float4*>(xr + LD + 4 * h);
+          const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float wx = ws[e] * xs[e];
+            const float fv = feat == 0 ? wx * xs[e] : (feat == 1 ? wx : ws[e]);
+            acc_c[l2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fv, dv[4 * h + e], acc_c[l2][t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- sum-node weights: A = E1[j1] E2[j2], B = gamma
+    {
+      const float* nb = nodeS + node * NS * LD + 16 * kk;
+      const float* gp = nb + min(rr, K - 1) * LD;
+      float gv[16];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gp + 4 * h);
+        gv[4 * h] = g4.x; gv[4 * h + 1] = g4.y; gv[4 * h + 2] = g4.z; gv[4 * h + 3] = g4.w;
+      }
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        const float* e1 = nb + w_e1[t] * LD;
+        const float* e2 = nb + w_e2[t] * LD;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const float4 a4 = *reinterpret_cast<const float4*>(e1 + 4 * h);
+          const float4 b4 = *reinterpret_cast<const float4*>(e2 + 4 * h);
+          acc_w[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x * b4.x, gv[4 * h], acc_w[t], 0, 0, 0);
+          acc_w[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y * b4.y, gv[4 * h + 1], acc_w[t], 0, 0, 0);
+          acc_w[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z * b4.z, gv[4 * h + 2], acc_w[t], 0, 0, 0);
+          acc_w[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w * b4.w, gv[4 * h + 3], acc_w[t], 0, 0, 0);
+        }
+      }
+    }
+    // ---- root weights of the replica (side-0 wave): A = rho EB[j2], B = EA[j1]
+    if (side == 0) {
+      const float* rp = Rscr + (size_t)(b * R + r) * (1 + 2 * K) * 64 + 16 * kk;
+      const float4* rho = reinterpret_cast<const float4*>(rp);
+      const float4* ea = reinterpret_cast<const float4*>(rp + (1 + min(rr, K - 1)) * 64);
+      const float4* eb = reinterpret_cast<const float4*>(rp + (1 + K + min(rr, K - 1)) * 64);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const float4 q4 = rho[h], a4 = ea[h], b4 = eb[h];
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.x * b4.x, a4.x, acc_r, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.y * b4.y, a4.y, acc_r, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.z * b4.z, a4.z, acc_r, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.w * b4.w, a4.w, acc_r, 0, 0, 0);
+      }
+    }
+    __syncthreads();      // the LDS images are restaged for the next batch
+  }
+  // ---- partial sums of this chunk: result element (row 4 (lane >> 4) + e, column lane & 15) in register e
+  const int col = lane & 15;
+#pragma unroll
+  for (int l2 = 0; l2 < 2; ++l2)
+#pragma unroll
+    for (int t = 0; t < TC; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 16 * t + 4 * kk + e;
+        if (row < 3 * S && col < G) {
+          const int feat = row / S, i = row % S;
+          part_c[((size_t)(c * R + r) * D + (side * 2 + l2) * S + i) * G * 3 + col * 3 + feat] = acc_c[l2][t][e];
+        }
+      }
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 16 * t + 4 * kk + e;
+      if (row < G * G && col < K) part_w[((size_t)(c * R * 2 + node) * G * G + row) * K + col] = acc_w[t][e];
+    }
+  if (side == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 4 * kk + e;
+      if (row < K && col < K) part_r[((size_t)(c * R + r) * K + row) * K + col] = acc_r[e];
+    }
+  }
+}
+
 // ---- tile staging for the stand-alone RatSpn.forward(inputs, marginalized) operator --------
 // inputs/marg are (n, D) row-major; w = 1 - clamp(marg, 0, 1) (rat_torch.py:104-106).
 __global__ void objspn_tile_from_arrays_k(const float* __restrict__ inputs, const float* __restrict__ marg,
@@ -749,7 +915,7 @@ int objspn_mpe(const float* xw, const int* scope, const float* coef, const float
 
 // workspace layout (floats) for the backward, per batch of 64 samples
 constexpr size_t kObjD = 6 * 4 * 10 * 64, kObjS = 12 * 30 * 64, kObjR = 6 * 21 * 64, kObjX = 100 * 2 * 64;
-constexpr int kObjChunks = 288;
+constexpr int kObjChunks = 256;        // one workgroup of the table-gradient kernel per CU
 constexpr size_t kObjCoefN = 6 * 100 * 10 * 3, kObjWN = 12 * 100 * 10, kObjRootN = 6 * 100;
 
 size_t objspn_bwd_ws_floats(int n) {
@@ -763,7 +929,8 @@ size_t objspn_bwd_ws_floats(int n) {
 // another stream, ordered after the data part, where they overlap with whatever runs on `st` next).
 int objspn_backward_data(const float* xw, const int* scope, const int* leaf_slot, const float* coef, const float* wsum,
                          const float* wroot, const float* out, const float* dout, float* dxw, float* ws, int n, hipStream_t st,
-                         const float* st_save = nullptr) {
+                         const float* st_save = nullptr) {      // dxw == nullptr: leaf gradients only (the scene path forms
+                                                                // dL/d tile inside scene_pixtile_bwd_k, csrc/scene_fused.hip)
   const int nb = (n + 63) / 64;
   if (nb == 0) return 0;
   float* Dscr = ws;
@@ -772,10 +939,19 @@ int objspn_backward_data(const float* xw, const int* scope, const int* leaf_slot
   STOVE_LAUNCH((objspn_bwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
                      xw, scope, coef, wsum, wroot, out, dout, Dscr, Sscr, Rscr, n, nb, st_save);
   STOVE_LAUNCH_CHECK();
+  if (dxw == nullptr) return 0;
   STOVE_LAUNCH((objspn_pix_k<6, 25, 10, 8>), dim3(grid_for(nb, 4096)), dim3(512), 0, st,
                      xw, Dscr, leaf_slot, coef, dxw, nb);
   STOVE_LAUNCH_CHECK();
   return 0;
+}
+
+static bool objspn_tablegrad_valu() {
+  static const bool v = [] {
+    const char* e = getenv("STOVE_TABLEGRAD_VALU");
+    return e != nullptr && e[0] == '1';
+  }();
+  return v;
 }
 
 int objspn_backward_params(const float* xw, const int* scope, float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n,
@@ -794,10 +970,18 @@ int objspn_backward_params(const float* xw, const int* scope, float* g_coef, flo
   float* pw = pc + (size_t)kObjChunks * kObjCoefN;
   float* pr = pw + (size_t)kObjChunks * kObjWN;
   const int chunks = nb < kObjChunks ? nb : kObjChunks;
-  STOVE_LAUNCH((objspn_coefgrad_k<6, 25, 10>), dim3(6 * chunks), dim3(128), 0, st, xw, Dscr, scope, pc, nb, chunks);
-  STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH((objspn_wgrad_k<6, 10, 10>), dim3(chunks), dim3(6 * 2 * 10 * 2 + 64), 0, st, Sscr, Rscr, pw, pr, nb, chunks);
-  STOVE_LAUNCH_CHECK();
+  if (objspn_tablegrad_valu()) {      // STOVE_TABLEGRAD_VALU=1: the VALU formulation (A/B switch, cross-check in tests)
+    STOVE_LAUNCH((objspn_coefgrad_k<6, 25, 10>), dim3(6 * chunks), dim3(128), 0, st, xw, Dscr, scope, pc, nb, chunks);
+    STOVE_LAUNCH_CHECK();
+    STOVE_LAUNCH((objspn_wgrad_k<6, 10, 10>), dim3(chunks), dim3(6 * 2 * 10 * 2 + 64), 0, st, Sscr, Rscr, pw, pr, nb, chunks);
+    STOVE_LAUNCH_CHECK();
+  } else {
+    constexpr int kTgLds = (2 * 100 * 68 + 12 * 30 * 68) * (int)sizeof(float);
+    int rc = (int)hipFuncSetAttribute((const void*)objspn_tablegrad_k<6, 25, 10, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, kTgLds);
+    if (rc) return rc;
+    STOVE_LAUNCH((objspn_tablegrad_k<6, 25, 10, 10>), dim3(chunks), dim3(768), kTgLds, st, xw, Dscr, Sscr, Rscr, scope, pc, pw, pr, nb, chunks);
+    STOVE_LAUNCH_CHECK();
+  }
   STOVE_LAUNCH(reduce_chunks_k, dim3((kObjCoefN + 31) / 32), dim3(256), 0, st, pc, g_coef, (int)kObjCoefN, chunks, 0);
   STOVE_LAUNCH(reduce_chunks_k, dim3((kObjWN + 31) / 32), dim3(256), 0, st, pw, g_wsum, (int)kObjWN, chunks, 0);
   STOVE_LAUNCH(reduce_chunks_k, dim3((kObjRootN + 31) / 32), dim3(256), 0, st, pr, g_wroot, (int)kObjRootN, chunks, 0);
