@@ -581,7 +581,11 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
                     int ldb, int ldc, int a_kmajor, int b_kmajor, int nsplit, int splitk, int tile, float* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (M == 0 || N == 0) return 0;
-  if (K <= 0 || splitk < 1 || (nsplit != 1 && nsplit != 2) || tile < 0 || tile > 2) return (int)hipErrorInvalidValue;
+  if (K <= 0 || splitk < 1 || (nsplit != 1 && nsplit != 2) || tile < 0 || (tile > 2 && tile != 11 && tile != 12)) return (int)hipErrorInvalidValue;
+  // tile 11 / 12: measurement variants of the 256 x 128 NT kernel (tools/gemm_bf16_bench.py): no loads in the loop / no MFMAs
+  if (tile == 11 && !a_kmajor && !b_kmajor && nsplit == 2) return gemm_launch<false, false, 2, 256, 128, 1>(A, B, bias, add, C, M, N, K, lda, ldb, ldc, 1, st);
+  if (tile == 12 && !a_kmajor && !b_kmajor && nsplit == 2) return gemm_launch<false, false, 2, 256, 128, 2>(A, B, bias, add, C, M, N, K, lda, ldb, ldc, 1, st);
+  if (tile > 2) tile = 1;
   // float4 granularity along the contiguous dimension of every operand and of C
   if ((lda & 3) || (ldb & 3) || (ldc & 3) || (N & 3) || ((a_kmajor ? M : K) & 3) || ((b_kmajor ? N : K) & 3)) return (int)hipErrorInvalidValue;
   if (splitk > 1 && (ws == nullptr || bias != nullptr || add != nullptr || ldc != N)) return (int)hipErrorInvalidValue;
@@ -589,8 +593,8 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
   const int ldo = splitk > 1 ? N : ldc;
   if (tile == 0) tile = 1;
   int rc;
-#define STOVE_GEMM_TILE(AK, BK_, NS)                                                                       \
-  rc = tile == 1 ? gemm_launch<AK, BK_, NS, 256, 128>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st) \
+#define STOVE_GEMM_TILE(AK, BK_, NS)                                                                                \
+  rc = tile == 1 ? gemm_launch<AK, BK_, NS, 256, 128>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st)           \
                  : gemm_launch<AK, BK_, NS, 128, 128>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st)
 #define STOVE_GEMM_CASE(AK, BK_)             \
   do {                                       \

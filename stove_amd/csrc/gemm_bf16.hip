@@ -151,7 +151,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int r0, int lane) {
   }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT, int BM, int BN>
+template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT, int BM, int BN, int DEBUG = 0>      // DEBUG (tools only): 1 = no loads in the loop, 2 = no MFMAs
 __global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                                                const float* __restrict__ add, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
                                                                int tiles_m, int tiles_n, int splitk, int k_per_slice) {
@@ -206,8 +206,10 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restr
     // no branches in here: past the last tile the loads are predicated off (they read the operand's first float4) and the
     // stores write a zero tile nobody reads.  With a branch around either, hipcc has to assume the worse path and waits for the
     // loads it has just issued (s_waitcnt vmcnt counts in issue order).
-    a_far.load(sa, k_begin + (t + 2) * kGemmBK, k_end);
-    b_far.load(sb, k_begin + (t + 2) * kGemmBK, k_end);
+    if (DEBUG != 1) {
+      a_far.load(sa, k_begin + (t + 2) * kGemmBK, k_end);
+      b_far.load(sb, k_begin + (t + 2) * kGemmBK, k_end);
+    }
     bf16x8 ah[4], bh[4], al[4], bl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -222,6 +224,10 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restr
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (DEBUG == 2) {
+          acc[i][j].x += (float)ah[i][0] * (float)bh[j][0] + (NSPLIT == 2 ? (float)al[i][0] * (float)bl[j][0] : 0.0f);
+          continue;
+        }
         if (NSPLIT == 2) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
@@ -270,15 +276,15 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restr
 // LDS bytes of the kernel
 constexpr int gemm_lds_bytes(int nsplit, int bm, int bn) { return 2 * nsplit * (gemm_part_bytes(bm) + gemm_part_bytes(bn)); }
 
-template <bool AK, bool BK_, int NS, int BM = 256, int BN = 128>
+template <bool AK, bool BK_, int NS, int BM = 256, int BN = 128, int DEBUG = 0>
 static int gemm_launch(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                        int splitk, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   int kper = ((K + splitk - 1) / splitk + kGemmBK - 1) / kGemmBK * kGemmBK;
-  const void* fn = (const void*)gemm_bf16_k<AK, BK_, NS, BM, BN>;
+  const void* fn = (const void*)gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG>;
   int rc = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(NS, BM, BN));
   if (rc) return rc;
-  STOVE_LAUNCH((gemm_bf16_k<AK, BK_, NS, BM, BN>), dim3(tiles_m * tiles_n * splitk), dim3(BM * BN / 64), gemm_lds_bytes(NS, BM, BN), st, A, B, bias, add, C,
+  STOVE_LAUNCH((gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG>), dim3(tiles_m * tiles_n * splitk), dim3(BM * BN / 64), gemm_lds_bytes(NS, BM, BN), st, A, B, bias, add, C,
                M, N, K, lda, ldb, ldc, tiles_m, tiles_n, splitk, kper);
   STOVE_LAUNCH_CHECK();
   return 0;
