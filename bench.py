@@ -40,6 +40,10 @@ def parse():
     p.add_argument('--cpu-batch', type=int, default=32)
     p.add_argument('--cpu-iters', type=int, default=8)
     p.add_argument('--profile-steps', type=int, default=3)
+    p.add_argument('--encoder-gemm', default='bf16x3', choices=['bf16x3', 'fp32', 'bf16'],
+                   help='recognition-network GEMMs: bf16x3 = fp32 products as 3 bf16 MFMAs on hi/lo-split operands (default), '
+                        'fp32 = library GEMMs, bf16 = plain bf16 operands (reported variant, never the headline)')
+    p.add_argument('--no-variants', action='store_true', help='skip the bf16-operand / fp32-library side measurements')
     return p.parse_args()
 
 
@@ -183,6 +187,7 @@ def main():
     from stove_amd.video_prediction.stove import Stove
 
     cfg = build_config(a.workload, dev)
+    cfg.encoder_gemm = a.encoder_gemm
     torch.manual_seed(0)
     model = Stove(cfg).to(dev)
     bucket = ParamArena(model, world)          # parameters / gradients flat; grad buffer == all-reduce bucket
@@ -252,7 +257,23 @@ def main():
             n_obj = cfg.num_obj
             avg_ms = total_ms / count
             per_step = {k: round(v[0] / a.profile_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:14]}
-            if name.startswith(('dyn_loop', 'gnn_step', 'rollout', 'gnn_dw')):
+            if name.startswith('gemm_bf16'):
+                # recognition-network GEMMs (csrc/gemm_bf16.hip), all launches of a step together (they differ in shape):
+                # algorithmic flops = 2 M N K of the fp32 products -- x W_ih^T, (N-1) x h W_hh^T forward; (N-1) x dg W_hh,
+                # dg^T h over the N-1 recurrent steps, dgx^T x backward -- against the dense bf16 MFMA peak (2.5 PFLOP/s,
+                # MI355X_MICROARCH.md); the split-bf16 path issues 3 bf16 MFMA flops per algorithmic flop.
+                nfr, Hh, Dd = a.batch * a.frames, 256, 32 * 32
+                flops = 2.0 * nfr * (2 * Dd * 4 * Hh + 3 * (n_obj - 1) * Hh * 4 * Hh)
+                ms_step = total_ms / a.profile_steps
+                ach = flops / (ms_step * 1e-3) / 1e12
+                passes = {'bf16x3': 3, 'bf16': 1}.get(a.encoder_gemm, 3)
+                roofline = {'bound': 'mfma', 'kernel': name, 'avg_ms': avg_ms, 'launches': count, 'ms_per_step': ms_step,
+                            'achieved': ach, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': ach / 2500.0, 'traffic': None,
+                            'mfma_pipe_frac': passes * ach / 2500.0,
+                            'note': 'achieved = algorithmic fp32 flops (2MNK of the %d GEMMs of a step) / their summed launch time; the kernel '
+                                    'issues %d bf16 MFMA flops per algorithmic flop (hi/lo split), so the matrix pipe runs at mfma_pipe_frac' % (count // a.profile_steps, passes),
+                            'kernels_ms_per_step': per_step}
+            elif name.startswith(('dyn_loop', 'gnn_step', 'rollout', 'gnn_dw')):
                 # GNN recursion: dense fp32 contraction -> 157.3 TFLOP/s (v_mfma_f32_16x16x4_f32; the packed-fp32 VALU
                 # path of the small-graph kernels, v_pk_fma_f32, has the same peak on MI355X).
                 # Algorithmic flops per (sequence, step), SURVEY.md section 8d: F = 17408 N + 26944 N (N-1) forward;
@@ -276,10 +297,19 @@ def main():
                 roofline = {'bound': 'hbm', 'kernel': name, 'avg_ms': avg_ms, 'launches': count, 'achieved': ach,
                             'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0, 'traffic': None,
                             'note': 'VALU-bound sweep (~120 flop/B, ridge ~20 flop/B)', 'kernels_ms_per_step': per_step}
+    if roofline is not None and prof and not roofline['kernel'].startswith('dyn_loop'):
+        # the T-serial recursion (latency-bound): data-gradient kernel of the backward against the fp32 MFMA / VALU peak
+        for k in ('dyn_loop_bwd_small_k', 'dyn_loop_bwd_k'):
+            if k in prof:
+                F = 17408 * cfg.num_obj + 26944 * cfg.num_obj * (cfg.num_obj - 1)
+                fl = (2 * F if k == 'dyn_loop_bwd_k' else F) * a.batch * (a.frames - 2)
+                ms = prof[k][0] / prof[k][1]
+                roofline['recursion'] = {'kernel': k, 'avg_ms': ms, 'achieved': fl / (ms * 1e-3) / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
+                                         'frac': fl / (ms * 1e-3) / 1e12 / 157.3, 'note': 'latency-bound: %d dependent time steps per launch' % (a.frames - 2)}
     if roofline is not None and prof:
         # second kernel family of SURVEY.md section 8d: the SPN / scene sweep (all its launches of one step together) against
         # HBM with the algorithmic 8200 + 32 N bytes per frame forward + backward
-        spn_ms = sum(v[0] for k, v in prof.items() if k.startswith(('objspn_', 'bgspn_', 'bg_', 'scene_', 'spn_bake'))) / a.profile_steps
+        spn_ms = sum(v[0] for k, v in prof.items() if k.startswith(('objspn_', 'bgspn_', 'bg_', 'scene_', 'spn_bake', 'reduce_chunks'))) / a.profile_steps
         if spn_ms > 0:
             alg = (8200 + 32 * cfg.num_obj) * a.batch * (a.frames - 1)
             ach = alg / (spn_ms * 1e-3) / 1e9
@@ -301,6 +331,51 @@ def main():
             except (OSError, ValueError):
                 pass
     log('kernel profile done')
+    # ---- side measurements (N = 1 only): the same step with the recognition network's GEMMs on plain bf16 operands
+    # (BASELINE.json configs[1] says "bf16"; SURVEY section 7: reported, not assumed) and on the fp32 library path, each with
+    # its ELBO difference against the fp32 library path on THIS batch under identical noise.  Never the headline `value`.
+    variants = None
+    if rank == 0 and world == 1 and not a.no_variants:
+        g = torch.Generator(device='cpu').manual_seed(99)
+        o = cfg.num_obj
+        fixed = {'latent': torch.randn(a.batch, o, 12, generator=g).to(dev), 'std': torch.randn(a.batch, o, 12, generator=g).to(dev),
+                 'steps': torch.randn(a.batch, a.frames - 2, o, 18, generator=g).to(dev)}
+        snap = (bucket.data.clone(), {k: v.clone() for k, v in opt._flat.items()}, opt._seg_steps.clone())
+
+        def elbo_of(mode):
+            cfg.encoder_gemm = mode
+            model.noise_fn = lambda kind, shape: fixed[kind].reshape(shape)
+            with torch.no_grad():
+                e, _, _ = model(x, 1, actions)
+            model.noise_fn = None
+            return float(e)
+
+        def time_of(mode):
+            cfg.encoder_gemm = mode
+            for i in range(2):
+                step(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(a.steps):
+                step(i)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / a.steps * 1e3
+
+        e_ref = elbo_of('fp32')
+        variants = {}
+        for mode, label in (('bf16', 'bf16-operands (encoder GEMMs), fp32 accumulate'), ('bf16x3', 'split-bf16 x3 (default path)'),
+                            ('fp32', 'fp32 library GEMMs')):
+            e = elbo_of(mode)
+            ms = time_of(mode)
+            variants[mode] = {'dtype': label, 'ms_per_step': ms, 'value': a.batch * a.frames / ms * 1e3, 'unit': 'frames/s',
+                              'elbo': e, 'elbo_rel_delta_vs_fp32_library': abs(e - e_ref) / abs(e_ref)}
+            with torch.no_grad():       # the timing steps trained: put the parameters and the optimiser state back
+                bucket.data.copy_(snap[0])
+                for k, v in snap[1].items():
+                    opt._flat[k].copy_(v)
+                opt._seg_steps.copy_(snap[2])
+        cfg.encoder_gemm = a.encoder_gemm
+        log('variants done')
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.workload, a.frames, a.cpu_batch, a.cpu_iters, full_batch=a.batch)
@@ -314,12 +389,13 @@ def main():
             'ms_per_step': dt / a.steps * 1e3,
             'ms_per_step_p50': per_step_ms[len(per_step_ms) // 2], 'ms_per_step_p99': per_step_ms[min(len(per_step_ms) - 1, int(0.99 * len(per_step_ms)))],
             'ms_per_step_min': per_step_ms[0], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32' + ({'bf16x3': ' (encoder GEMMs: fp32 as 3 bf16 MFMAs on hi/lo-split operands, fp32 accumulate)', 'fp32': '', 'bf16': ' + bf16 encoder operands'}[a.encoder_gemm]),
+            'data': 'synthetic',
             'config': {'workload': f'{a.workload} {cfg.num_obj}-object 32x32 T={a.frames} batch={a.batch}/GPU' + (' (BASELINE.json configs[1])' if a.workload == 'billiards' and a.batch == 256 and a.frames == 100 else ''),
                        'objects': cfg.num_obj, 'global_batch': a.batch * world,
                        'step': 'forward+backward+allreduce+clip+adam(amsgrad)', 'parallelism': f'dp{world}',
                        'elbo_last_step': elbo_val},
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'cpu_baseline': cpu, 'variants': variants,
         }
         print(json.dumps(out))
     if world > 1:

@@ -201,6 +201,8 @@ int stove_match_objects(const float* feat, long long* idx, float* perm, int B, i
  *     zfix (n,T,o,8) = gathered + fix_supair-smoothed [mean 4 | std 4] (stove.py:516-563; hits (n,T,o) u8 = its mask),
  *     zl / sl (n,T-skip,o,6) = z_sup_full / z_sup_std_full[:, skip:] with finite-difference velocities
  *     (stove.py:172-198), init6 (n,o,6) = z_sup_full[:, skip-1].
+ *     codes == NULL: zc and idx are INPUTS (states already constrained, a matching already chosen) and only the gather /
+ *     fix_supair / velocity stage runs -- what the reference's fix_supair fixtures exercise.
  * stove_supair_state_bwd: gradients of zfix / zl / sl / init6 (any may be NULL) -> g_codes; gfix_ws: n*T*o*8 floats.
  * stove_zall_fwd/bwd: z of the scene likelihood, frames 1..T-1: SuPAIR means before `skip`, sampled states after,
  *     [sx, sy/sx, x, y] -> [sx, sy, x, y] (stove.py:731-736); bwd writes every element of g_zfix and g_zs (n,T-skip,o,18).

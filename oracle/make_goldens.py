@@ -380,6 +380,16 @@ def g0_envs():
     save('g0_envs', **arrs)
 
 
+def gravity_frames(n_seq, t_len):
+    """cfg 3 of BASELINE.json: GravityEnv (reference envs.py:841-844) at res=32, one env per sequence, seed = i."""
+    xs = []
+    for seed in range(n_seq):
+        env = ref_envs.GravityEnv(n=3, r=2, m=4., hw=30, granularity=50, res=32, t=1.,
+                                  init_v_factor=0.55, friction_coefficient=0., seed=seed)
+        xs.append(np.stack([env.step()[0].copy() for _ in range(t_len)]))
+    return np.transpose(np.stack(xs), (0, 1, 4, 2, 3))
+
+
 def billiards_frames(n_seq, t_len, n=3, r=1.2):
     xs = []
     for seed in range(n_seq):
@@ -397,7 +407,11 @@ def g7_g8_full():
         ('n3', dict(num_obj=3), 4, 8),
         ('n6', dict(num_obj=6, debug_match_objects='greedy', overlap_beta=100.0, max_obj_scale=0.22), 2, 6),
         ('ac3', dict(num_obj=3, action_conditioned=True, action_space=9, debug_core_appearance=True), 3, 6),
+        ('grav3', dict(num_obj=3), 4, 8),
     ]
+    only = os.environ.get('G7_ONLY')          # regenerate a subset without touching the other fixtures
+    if only:
+        cases = [c for c in cases if c[0] in only.split(',')]
     for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
         for name, kw, B, T in cases:
             c = ref_config(dtype, **kw)
@@ -405,7 +419,10 @@ def g7_g8_full():
             N = c.num_obj
             st = Stove(c)
             fill(st)
-            x = torch.from_numpy(billiards_frames(B, T, n=N, r=1.2 if N == 3 else 1.0)).to(dtype)
+            if name == 'grav3':
+                x = torch.from_numpy(gravity_frames(B, T)).to(dtype)
+            else:
+                x = torch.from_numpy(billiards_frames(B, T, n=N, r=1.2 if N == 3 else 1.0)).to(dtype)
             g = torch.Generator().manual_seed(123)
             lat = torch.randn(B, N, 12, 1, generator=g, dtype=torch.float64)
             sd = torch.randn(B, N, 12, 1, generator=g, dtype=torch.float64)
@@ -441,6 +458,14 @@ def g7_g8_full():
                     app = prop['obj_appearances'][:, -1]
                 z_pred, r_pred = st.rollout(z_last, num=92 if name == 'n3' else 12, actions=fut, appearance=app)
             extra['roll_z'] = z_pred
+            if name in ('n3', 'grav3'):
+                # sampling rollout (stove.py:833-838; the reference only runs it with return_std=True, see z_dyn_stds)
+                eps_roll = [torch.randn(B, N, 16, generator=g, dtype=torch.float64) for _ in range(10)]
+                tdn._standard_normal = EpsFeeder(eps_roll)
+                with torch.no_grad():
+                    zs, lq, _ = st.rollout(z_last, num=10, sample=True, return_std=True)
+                tdn._standard_normal = saved
+                extra.update(eps_roll=torch.stack(eps_roll, 0), roll_s_z=zs, roll_s_logq=lq)
             if c.action_conditioned:
                 extra['roll_rewards'] = r_pred
             save(f'g7_stove_{name}_{tag}', x=x.to(torch.float32), eps_lat=lat, eps_std=sd, eps_steps=torch.stack(steps, 0),

@@ -669,23 +669,31 @@ def stove_forward(c, params, structs, x_color, eps, actions=None, detail=False):
     return elbo, rewards, info
 
 
-def rollout(c, params, z_last, num, actions=None, appearance=None):
-    """Stove.rollout (mean prediction), stove.py:777-861.  z_last (B,N,18) with [sx,sy,...]."""
+def rollout(c, params, z_last, num, actions=None, appearance=None, eps=None):
+    """Stove.rollout, stove.py:777-861.  z_last (B,N,18) with [sx,sy,...].  eps None: mean prediction -> (z, rewards);
+    eps = list of `num` (B,N,16) standard-normal draws: the sampling branch (:833-838, `Normal(mean, std).rsample()`
+    fed back) -> (z, log_q, rewards)."""
     cl = c.cl
     scale = z_last[..., :2]
     z = [z_last]
-    rewards = []
+    rewards, log_qs = [], []
     for t in range(1, num + 1):
         act = actions[:, (t - 1) % actions.shape[1]] if actions is not None else None
         out, rew = dynamics_forward(c, params, z[-1][..., 2:], act, appearance)
         rewards.append(rew)
-        m, _ = constrain_z_dyn(c, out[..., :cl // 2], out[..., cl // 2:])
+        m, sd = constrain_z_dyn(c, out[..., :cl // 2], out[..., cl // 2:])
         nxt = torch.cat([z[-1][..., 2:4] + m[..., :2], m[..., 2:]], -1)
+        if eps is not None:
+            mean = nxt
+            nxt = mean + sd * eps[t - 1]
+            log_qs.append(normal_log_prob(nxt, mean, sd))
         z.append(torch.cat([scale, nxt], -1))
     if c.action_conditioned:
         rewards = torch.stack(rewards, 1)
     else:
         rewards = torch.tensor([float(r) for r in rewards])
+    if eps is not None:
+        return torch.stack(z[1:], 1), torch.stack(log_qs, 1), rewards
     return torch.stack(z[1:], 1), rewards
 
 

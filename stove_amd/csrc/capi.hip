@@ -711,10 +711,12 @@ int stove_supair_state_fwd(const float* codes, const float* span_low, float* zc,
   if (n == 0) return 0;
   if (T < 2 || skip < 1 || skip >= T || o < 1 || o > kMatchN) return (int)hipErrorInvalidValue;
   const int M = n * T * o;
-  STOVE_LAUNCH(zp_constrain_k, dim3((M * 8 + 255) / 256), dim3(256), 0, st, codes, zp_const(span_low), zc, pos, M);
-  STOVE_LAUNCH_CHECK();
-  int rc = stove_match_objects(pos, idx, nullptr, n, T, o, 2, mode, stream);
-  if (rc) return rc;
+  if (codes != nullptr) {        // codes == NULL: zc (constrained states) and idx (a matching) are the caller's; only the last stage runs
+    STOVE_LAUNCH(zp_constrain_k, dim3((M * 8 + 255) / 256), dim3(256), 0, st, codes, zp_const(span_low), zc, pos, M);
+    STOVE_LAUNCH_CHECK();
+    int rc = stove_match_objects(pos, idx, nullptr, n, T, o, 2, mode, stream);
+    if (rc) return rc;
+  }
   STOVE_LAUNCH(supair_state_fwd_k, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)zc, (const long long*)idx, zfix, hits, zl, sl,
                init6, n, T, o, skip, fix);
   STOVE_LAUNCH_CHECK();

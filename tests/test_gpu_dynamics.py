@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import stove_oracle as O
-from gpu_helpers import err, fill_analytic
+from gpu_helpers import check, err, fill_analytic
 from helpers import load_golden, oracle_setup, t_
 
 pytestmark = pytest.mark.gpu
@@ -44,21 +44,21 @@ def test_dynamics_step(name, arena):
     act = t_(gold['actions']).float().to(DEV) if 'actions' in gold else None
     app = t_(gold['app']).float().to(DEV).requires_grad_() if 'app' in gold else None
     res, rew = dyn(s, 0, act, app, lim_enc=int(gold['lim_enc']))
-    assert err(res, gold['result']) < 1e-4
+    check('dyn_step.result', err(res, gold['result']), 2e-6)
     loss = (res * t_(gold['w']).float().to(DEV)).sum()
     if act is not None:
-        assert err(rew, gold['reward']) < 1e-4
+        check('dyn_step.reward', err(rew, gold['reward']), 1e-6)
         loss = loss + (rew * torch.linspace(1, 2, s.shape[0], device=DEV).view(-1, 1)).sum()
     loss.backward()
-    assert err(s.grad, gold['gs']) < 1e-3
+    check('dyn_step.grad_s', err(s.grad, gold['gs']), 5e-6)
     if app is not None:
-        assert err(app.grad, gold['gapp']) < 1e-3
+        check('dyn_step.grad_app', err(app.grad, gold['gapp']), 1e-5)
     params = dict(dyn.named_parameters())
     n = 0
     for k, v in gold.items():
         if k.startswith('g_'):
             assert params[k[2:]].grad is not None, k
-            assert err(params[k[2:]].grad, v) < 1e-3, k
+            check('dyn_step.grad_param', err(params[k[2:]].grad, v), 2.5e-5)
             n += 1
     assert n >= 26
 
@@ -113,10 +113,37 @@ def test_match_greedy():
     assert err(zm, g['z_matched']) < 1e-6 and err(zsm, g['zstd_matched']) < 1e-6
 
 
+def test_fix_supair_stage_on_reference_fixture():
+    """g6_fix_supair (crafted glitches on the scale dims, reference stove.py:516-563) straight into the state stage of
+    stove_supair_state_fwd (csrc/state.hip supair_state_fwd_k): codes NULL = given states, identity matching."""
+    from stove_amd import _lib
+    g = load_golden('g6_fix_supair')
+    z, zs = t_(g['z']).float(), t_(g['zstd']).float()
+    n, T, o = z.shape[:3]
+    zc = torch.cat([z, zs], -1).contiguous().to(DEV)
+    idx = torch.arange(o, dtype=torch.int64).expand(n, T, o).contiguous().to(DEV)
+    skip = 2
+    zfix = torch.empty(n, T, o, 8, device=DEV)
+    hits = torch.empty(n, T, o, dtype=torch.uint8, device=DEV)
+    zl, sl, init6 = torch.empty(n, T - skip, o, 6, device=DEV), torch.empty(n, T - skip, o, 6, device=DEV), torch.empty(n, o, 6, device=DEV)
+    lib = _lib.load()
+    _lib.check(lib.stove_supair_state_fwd(None, None, zc.data_ptr(), None, idx.data_ptr(), zfix.data_ptr(), hits.data_ptr(), zl.data_ptr(),
+                                          sl.data_ptr(), init6.data_ptr(), n, T, o, skip, 1, 0, _lib.stream()), 'stove_supair_state_fwd')
+    torch.cuda.synchronize()
+    check('fix_supair.z', err(zfix[..., :4], g['z_fixed']), 1e-6)
+    check('fix_supair.zstd', err(zfix[..., 4:], g['zstd_fixed']), 1e-6)
+    fired = (t_(g['z_fixed']) != t_(g['z'])).any(-1)
+    assert torch.equal(hits.bool().cpu(), fired) and int(fired.sum()) >= 3
+    # velocities of the smoothed states (stove.py:54-101)
+    zf = t_(g['z_fixed']).float()
+    check('fix_supair.vel', err(zl[..., 4:], (zf[:, skip:, :, 2:] - zf[:, skip - 1:-1, :, 2:])), 1e-5)
+
+
 CASES = {
     'n3': dict(num_obj=3),
     'n6': dict(num_obj=6, debug_match_objects='greedy', overlap_beta=100.0, max_obj_scale=0.22),
     'ac3': dict(num_obj=3, action_conditioned=True, action_space=9, debug_core_appearance=True),
+    'grav3': dict(num_obj=3),          # BASELINE.json configs[2]: gravity frames through the same path
 }
 
 
@@ -146,13 +173,13 @@ def test_stove_forward_elbo_and_grads(name, fused, arena):
     actions = t_(gold['actions']).float().to(DEV) if 'actions' in gold else None
     elbo, prop, rewards = st(x, 0, actions)
     rel = abs(float(elbo) - float(gold['elbo'])) / abs(float(gold['elbo']))
-    assert rel < 1e-4, rel                                     # the north-star ELBO bar
+    check('stove.elbo_rel', rel, 1.5e-6)                       # the north-star bar is 1e-4; achieved 2.5e-7
     for k in ('z', 'z_dyn', 'z_sup', 'z_std', 'z_sup_std', 'log_q', 'translik', 'bg', 'patch', 'overlap'):
-        assert err(prop[k], gold['p_' + k]) < 2e-4, k
-    assert err(prop['z_dyn_std'][2:], gold['p_z_dyn_std'][2:]) < 2e-4
+        check('stove.prop_' + k, err(prop[k], gold['p_' + k]), 8e-6 if k == 'z_sup' else 3e-6)
+    check('stove.prop_z_dyn_std', err(prop['z_dyn_std'][2:], gold['p_z_dyn_std'][2:]), 1e-6)
     loss = -elbo
     if actions is not None:
-        assert err(rewards, gold['rewards']) < 2e-4
+        check('stove.rewards', err(rewards, gold['rewards']), 1e-6)
         loss = loss + 3.0 * (rewards ** 2).sum()
     loss.backward()
     params = dict(st.named_parameters())
@@ -161,10 +188,10 @@ def test_stove_forward_elbo_and_grads(name, fused, arena):
         if k.startswith('gn_'):
             p = params[k[3:]]
             assert p.grad is not None, k
-            assert abs(float(p.grad.norm()) - float(v)) <= 5e-3 * float(v) + 1e-9, (k, float(p.grad.norm()), float(v))
+            check('stove.grad_norm', abs(float(p.grad.norm()) - float(v)) / (float(v) + 1e-9), 1.5e-4)
             n += 1
         elif k.startswith('g_'):
-            assert err(params[k[2:]].grad, v) < 5e-3, k
+            check('stove.grad_tensor', err(params[k[2:]].grad, v), 3e-4)     # the reference's own fp32-vs-fp64 gap is 3.3e-4
     assert n > 50
     if arena:                                                  # cores 1-2 are never used: their gradients stay zero
         assert float(params['dyn.self_cores.1.0.weight'].grad.abs().max()) == 0.0
@@ -175,9 +202,20 @@ def test_stove_forward_elbo_and_grads(name, fused, arena):
         fut = actions[:, :5] if actions is not None else None
         app = prop['obj_appearances'][:, -1] if actions is not None else None
         zp, rp = st.rollout(z_last, num=gold['roll_z'].shape[1], actions=fut, appearance=app)
-    assert err(zp, gold['roll_z']) < 1e-3
+    check('stove.rollout_z', err(zp, gold['roll_z']), 3e-6)
     if actions is not None:
-        assert err(rp, gold['roll_rewards']) < 1e-3
+        check('stove.rollout_rewards', err(rp, gold['roll_rewards']), 1e-6)
+    if 'eps_roll' in gold:
+        # sampling rollout (stove.py:833-838) under the reference's draws: the sampled state feeds back
+        eps_roll = [t_(e).float().to(DEV) for e in gold['eps_roll']]
+        it = iter(eps_roll)
+        saved = st.noise_fn
+        st.noise_fn = lambda kind, shape: next(it).reshape(shape)
+        with torch.no_grad():
+            zs, lq, _ = st.rollout(z_last, num=len(eps_roll), sample=True)
+        st.noise_fn = saved
+        check('stove.rollout_sample_z', err(zs, gold['roll_s_z']), 2e-6)
+        check('stove.rollout_sample_logq', err(lq, gold['roll_s_logq']), 1.5e-5)
 
 
 def test_rollout_std_and_sampling_api():
@@ -212,10 +250,10 @@ def test_encoder_lstm_against_oracle():
     (out_o * w64).sum().backward()
     out_d = enc(x64.float().to(DEV))
     assert out_d.shape == (37, 3, 8)
-    assert err(out_d, out_o) < 1e-5
+    check('encoder.codes', err(out_d, out_o), 1.2e-5)
     (out_d * w64.float().to(DEV)).sum().backward()
     for name, p in enc.named_parameters():
-        assert err(p.grad, params['sup.encoder.' + name].grad) < 1e-3, name
+        check('encoder.grad', err(p.grad, params['sup.encoder.' + name].grad), 4e-5)
 
 
 def test_match_volatile():
@@ -435,3 +473,17 @@ def test_encoder_head_kernels(rows, H1, OUT):
     (ops.encoder_head(*again) * wout.float().to(DEV)).sum().backward()
     for a, b in zip(dev_in, again):
         assert torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize('mode,bar', [('fp32', 1e-6), ('bf16x3', 1e-6), ('bf16', 2e-5)])
+def test_encoder_gemm_variants_elbo_delta(mode, bar):
+    """config.encoder_gemm: the recognition network's products on library fp32 GEMMs, on the split-bf16 MFMA kernel (default)
+    and on plain bf16 operands (BASELINE.json configs[1] "bf16": reported, never the default).  ELBO against the reference's
+    golden; the achieved deltas land in gpurun_out/parity_errors.json."""
+    from stove_amd.video_prediction.stove import Stove
+    gold = load_golden('g7_stove_n3_f64')
+    st = fill_analytic(Stove(make_cfg(encoder_gemm=mode))).to(DEV)
+    st.noise_fn = _golden_noise(gold)
+    elbo, prop, _ = st(t_(gold['x']).float().to(DEV), 0, None)
+    check('stove.elbo_rel_encoder_' + mode, abs(float(elbo) - float(gold['elbo'])) / abs(float(gold['elbo'])), bar)
+    check('stove.z_sup_encoder_' + mode, err(prop['z_sup'], gold['p_z_sup']), 5e-4 if mode == 'bf16' else 3e-6)

@@ -1,18 +1,18 @@
 """GPU parity tests of the SPN / scene HIP kernels against the CPU oracle (fp64) and the
-reference-generated goldens.  Tolerances: forward values 1e-4 relative (the north_star bar),
-gradients 2e-3 relative to the largest entry (fp32 vs fp64; the reference's own fp32-vs-fp64
-gradient self-consistency is 3e-4)."""
+reference-generated goldens.  Tolerances are pinned a few times above what the kernels achieve on an MI355X
+(tests/gpu_helpers.check records the worst case of every key): forward values 5e-6 relative (north_star bar: 1e-4),
+gradients 3e-4 relative to the largest entry -- the reference's own fp32-vs-fp64 gradient gap."""
 import numpy as np
 import pytest
 import torch
 
 import stove_oracle as O
-from gpu_helpers import err, fill_analytic
+from gpu_helpers import check, err, fill_analytic
 from helpers import load_golden, oracle_setup, t_
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-FWD_TOL, GRAD_TOL = 1e-4, 2e-3
+FWD_TOL, GRAD_TOL = 5e-6, 3e-4       # achieved on MI355X: 8.9e-7 / 8.7e-5 (gpurun_out/parity_errors.json)
 
 
 def test_wave_sum_dpp():
@@ -66,18 +66,18 @@ def test_ratspn_operator(kind, n):
     m_d = m64.float().to(DEV).requires_grad_()
     out_d = spn(x_d, m_d)
     assert out_d.shape == (n, 1)
-    assert err(out_d, out_o) < FWD_TOL
+    check('spn.fwd', err(out_d, out_o), FWD_TOL)
     (out_d[:, 0] * wsum.float().to(DEV)).sum().backward()
-    assert err(x_d.grad, x_o.grad) < GRAD_TOL
-    assert err(m_d.grad, m_o.grad) < GRAD_TOL
+    check('spn.grad', err(x_d.grad, x_o.grad), GRAD_TOL)
+    check('spn.grad', err(m_d.grad, m_o.grad), GRAD_TOL)
     for name, p in spn.named_parameters():
         if name.startswith('output_vector'):
             continue
-        assert err(p.grad, params[f'sup.{kind}_spn.' + name].grad) < GRAD_TOL, name
+        check('spn.grad', err(p.grad, params[f'sup.{kind}_spn.' + name].grad), GRAD_TOL)
     if n == 8:   # also against the reference's own fp32 outputs
-        assert err(out_d, gold['out']) < FWD_TOL
+        check('spn.fwd', err(out_d, gold['out']), FWD_TOL)
         out_nm = spn(x_d.detach(), None)
-        assert err(out_nm, gold['out_nomarg']) < FWD_TOL
+        check('spn.fwd', err(out_nm, gold['out_nomarg']), FWD_TOL)
 
 
 def test_ratspn_operator_empty_batch():
@@ -126,16 +126,16 @@ def test_scene_likelihood_vs_reference_golden(n_obj, extra):
     z = t_(gold['z']).float().to(DEV).requires_grad_()
     sup.step_counter = 0
     lp, prop = sup.likelihood(x, z)
-    assert err(lp, gold['log_p']) < FWD_TOL
+    check('spn.fwd', err(lp, gold['log_p']), FWD_TOL)
     for k in ('bg', 'patch', 'overlap'):
         assert abs(float(prop[k]) - float(gold[k])) < FWD_TOL * abs(float(gold[k])) + 1e-6, k
     (lp * t_(gold['w']).float().to(DEV)).sum().backward()
-    assert err(z.grad, gold['gz']) < GRAD_TOL
+    check('spn.grad', err(z.grad, gold['gz']), GRAD_TOL)
     n = 0
     for k, v in gold.items():
         if k.startswith('g_') and 'encoder' not in k:
             p = dict(sup.named_parameters())[k[2:]]
-            assert err(p.grad, v) < GRAD_TOL, k
+            check('spn.grad', err(p.grad, v), GRAD_TOL)
             n += 1
     assert n > 60
 
@@ -161,14 +161,14 @@ def test_scene_likelihood_vs_oracle_ragged(n_obj):
     z_d = z64.float().to(DEV).requires_grad_()
     sup.step_counter = 0
     lp_d, prop = sup.likelihood(x64.float().to(DEV), z_d)
-    assert err(lp_d, lp_o) < FWD_TOL
+    check('spn.fwd', err(lp_d, lp_o), FWD_TOL)
     assert abs(float(prop['bg']) - float(bg_o.mean())) < FWD_TOL * abs(float(bg_o.mean())) + 1e-6
     (lp_d * w.float().to(DEV)).sum().backward()
-    assert err(z_d.grad, z_o.grad) < GRAD_TOL
+    check('spn.grad', err(z_d.grad, z_o.grad), GRAD_TOL)
     for name, p in sup.named_parameters():
         if 'encoder' in name or name.endswith('output_vector.params'):
             continue
-        assert err(p.grad, params['sup.' + name].grad) < GRAD_TOL, name
+        check('spn.grad', err(p.grad, params['sup.' + name].grad), GRAD_TOL)
 
 
 @pytest.mark.parametrize('n_obj', [3, 6])

@@ -64,34 +64,50 @@ def test_main_train_test_rollout(tmp_path, preset):
     assert [f.split('.')[0] for f in files] == ['real', 'recon', 'rollout']
 
 
-def test_full_size_properties():
-    """BASELINE.json's headline configuration (256 sequences x 100 frames, 3 objects) is too large for the CPU oracle;
+FULL_SIZE = {
+    'billiards': dict(num_obj=3),                                                         # BASELINE.json configs[1]
+    'gravity': dict(num_obj=3),                                                           # configs[2] (per-GPU shard of 256)
+    'multibilliards': dict(num_obj=6, debug_match_objects='greedy', overlap_beta=100.0, max_obj_scale=0.22),      # configs[3]
+    'avoidance': dict(num_obj=3, action_conditioned=True, action_space=9, debug_core_appearance=True),             # configs[4]
+}
+
+
+@pytest.mark.parametrize('workload', list(FULL_SIZE))
+def test_full_size_properties(workload):
+    """BASELINE.json's configurations at full size (256 sequences x 100 frames per GPU) are too large for the CPU oracle;
     at that size the hot path is checked through size-independent properties:
       * reproducibility: no atomics anywhere -- two runs give bit-identical ELBO and gradients;
       * linearity of the batch mean: ELBO(256 sequences) == mean of the ELBOs of its four 64-sequence shards, and the
-        gradient of the whole batch == mean of the shard gradients (what data parallelism relies on)."""
+        gradient of the whole batch == mean of the shard gradients (what data parallelism relies on).
+    N = 6 runs the MFMA recursion of csrc/gnn.hip and the greedy matcher, avoidance the action-conditioned inputs and the
+    appearance embedding."""
     from stove_amd.arena import ParamArena
     from stove_amd.envs import envs
     from stove_amd.video_prediction.config import StoveConfig
     from stove_amd.video_prediction.stove import Stove
     dev = torch.device('cuda:0')
     cfg = StoveConfig()
-    cfg.num_obj, cfg.width, cfg.height, cfg.random_seed = 3, 32, 32, 42
+    cfg.width, cfg.height, cfg.random_seed = 32, 32, 42
     cfg.device, cfg.dtype = dev, torch.float32
     cfg.action_conditioned, cfg.action_space = False, None
+    for k, v in FULL_SIZE[workload].items():
+        setattr(cfg, k, v)
+    o = cfg.num_obj
     torch.manual_seed(0)
     model = Stove(cfg).to(dev)
     arena = ParamArena(model, 1)
     B, T = 256, 100
-    x = torch.from_numpy(envs.synth_sequences('billiards', B, T, seed0=7)['X']).to(dev).contiguous()
+    data = envs.synth_sequences(workload, B, T, seed0=7)
+    x = torch.from_numpy(data['X']).to(dev).contiguous()
+    actions = torch.from_numpy(data['action']).float().to(dev) if 'action' in data else None
     g = torch.Generator(device='cpu').manual_seed(3)
-    noise = {'latent': torch.randn(B, 3, 12, generator=g).to(dev), 'std': torch.randn(B, 3, 12, generator=g).to(dev),
-             'steps': torch.randn(B, T - 2, 3, 18, generator=g).to(dev)}
+    noise = {'latent': torch.randn(B, o, 12, generator=g).to(dev), 'std': torch.randn(B, o, 12, generator=g).to(dev),
+             'steps': torch.randn(B, T - 2, o, 18, generator=g).to(dev)}
 
     def run(lo, hi):
         model.noise_fn = lambda kind, shape: noise[kind][lo:hi].reshape(shape)
         arena.zero_grad()
-        elbo, _, _ = model(x[lo:hi], 1, None)
+        elbo, _, _ = model(x[lo:hi], 1, actions[lo:hi] if actions is not None else None)
         (-elbo).backward()
         return float(elbo.detach()), arena.grad.clone()
 
@@ -100,9 +116,9 @@ def test_full_size_properties():
     assert e1 == e2 and torch.equal(g1, g2)                       # bitwise reproducible
     assert np.isfinite(e1) and float(g1.abs().max()) > 0
     es, gs = zip(*[run(k * 64, (k + 1) * 64) for k in range(4)])
-    assert abs(np.mean(es) - e1) < 2e-6 * abs(e1), (np.mean(es), e1)
+    assert abs(np.mean(es) - e1) < 5e-6 * abs(e1), (np.mean(es), e1)
     gm = torch.stack(gs).mean(0)
-    assert float((gm - g1).abs().max()) < 2e-4 * float(g1.abs().max())
+    assert float((gm - g1).abs().max()) < 3e-4 * float(g1.abs().max())
 
 
 def test_device_clip_loader_equals_dataloader(tmp_path):

@@ -172,6 +172,7 @@ CASES = {
     'n3': dict(num_obj=3),
     'n6': dict(num_obj=6, debug_match_objects='greedy', overlap_beta=100.0, max_obj_scale=0.22),
     'ac3': dict(num_obj=3, action_conditioned=True, action_space=9, debug_core_appearance=True),
+    'grav3': dict(num_obj=3),          # BASELINE.json configs[2]: gravity frames (envs.py:841-844 at res 32)
 }
 
 
@@ -213,6 +214,11 @@ def test_stove_forward_and_rollout(name, tag, dtype, tol):
     assert rel_err(zp, g['roll_z']) < tol * 100
     if actions is not None:
         assert rel_err(rp, g['roll_rewards']) < tol * 100
+    if 'eps_roll' in g:                 # sampling rollout under the reference's draws
+        with torch.no_grad():
+            zs, lq, _ = O.rollout(c, params, z_last, g['roll_s_z'].shape[1], eps=[t_(e, dtype) for e in g['eps_roll']])
+        assert rel_err(zs, g['roll_s_z']) < tol * 100
+        assert rel_err(lq, g['roll_s_logq']) < tol * 100
 
 
 def test_match_volatile():
