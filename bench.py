@@ -202,11 +202,12 @@ def main():
     actions = torch.from_numpy(data['action']).float().to(dev) if 'action' in data else None
     torch.manual_seed(1234 + rank)
 
+    minus_one = torch.tensor(-1.0, device=dev)
+
     def step(i):
         bucket.zero()
         elbo, _, rewards = model(x, i + 1, actions)
-        loss = -elbo
-        loss.backward()
+        elbo.backward(minus_one)                                 # d(-ELBO): the loss of train.py:452 without the neg / fill launches
         bucket.all_reduce()
         opt.step(max_norm=1.0)                                    # clip_grad_norm_(1) folded into the Adam launch
         return elbo

@@ -84,22 +84,24 @@ int stove_bgspn_bwd(const StoveSpnTables* t, const float* inputs, const float* m
 /* ---- Supair.likelihood (supair.py:44-110), fused: masks_from_z (:278-356), patches_from_z
  * (:241-276), both SPN sweeps, patch scaling + Exponential(beta) overlap prior (:79-94).
  * frames: (n_frames,1024) one-channel frames; z: (n_frames*n_obj,4) = [sx,sy,x,y].
+ * seq_frames / seq_stride: the frames may be a time-slice of longer clips handed over WITHOUT a copy (Stove.forward scores
+ * x[:, 1:], stove.py:731-736): frame f is row (f / seq_frames) * seq_stride + f % seq_frames behind `frames`; 0, 0 = dense.
  * ll: (n_frames,) log p(x,z); parts: (n_frames,3) = bg, patches, overlap (may be NULL).
  * saved: stove_scene_saved_floats() floats kept for the backward. */
 size_t stove_scene_saved_floats(int n_frames, int n_obj);
-int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
-                    float overlap_beta, float* ll, float* parts, float* saved, void* stream);
+int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
+                    int seq_stride, float overlap_beta, float* ll, float* parts, float* saved, void* stream);
 size_t stove_scene_bwd_ws_bytes(int n_frames, int n_obj);
 /* dll: (n_frames,) -> dz: (n_frames*n_obj,4) and table gradients. */
-int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
-                    float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g,
+int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
+                    int seq_stride, float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g,
                     void* ws, void* stream);
 /* The same with the parameter-gradient passes (leaf / sum / root table gradients: they only feed the optimiser) on a
  * second stream, so that they overlap with what the caller enqueues on `stream` next -- in STOVE the latency-bound
  * backward of the recursion, which leaves most of every CU idle.  dz is complete in `stream` order when the call
  * returns; *g is complete in `param_stream` order.  param_stream NULL or == stream: identical to stove_scene_bwd. */
-int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
-                    float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g,
+int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
+                    int seq_stride, float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g,
                     void* ws, void* stream, void* param_stream);
 
 /* Stove.object_embedding (stove.py:565-590): emb (n_frames*n_obj, channels) = mean over the 10x10 glimpse of object k of

@@ -58,10 +58,10 @@ def _declare(lib):
         'stove_bgspn_bwd_ws_bytes': (S, [I]),
         'stove_bgspn_bwd': (I, [T, P, P, P, P, P, P, P, G, P, I, P]),
         'stove_scene_saved_floats': (S, [I, I]),
-        'stove_scene_fwd': (I, [T, P, P, I, I, F, P, P, P, P]),
+        'stove_scene_fwd': (I, [T, P, P, I, I, I, I, F, P, P, P, P]),
         'stove_scene_bwd_ws_bytes': (S, [I, I]),
-        'stove_scene_bwd': (I, [T, P, P, I, I, F, P, P, P, G, P, P]),
-        'stove_scene_bwd_overlap': (I, [T, P, P, I, I, F, P, P, P, G, P, P, P]),
+        'stove_scene_bwd': (I, [T, P, P, I, I, I, I, F, P, P, P, G, P, P]),
+        'stove_scene_bwd_overlap': (I, [T, P, P, I, I, I, I, F, P, P, P, G, P, P, P]),
         'stove_scene_glimpses': (I, [P, P, I, I, P, P, P, P]),
         'stove_gnn_param_floats': (S, []),
         'stove_gnn_grad_floats': (S, []),

@@ -43,19 +43,19 @@ __global__ void tile_unpack_k(const float* __restrict__ tile, float* __restrict_
 }
 
 template <int NMAX>
-static int scene_tile_fwd(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st) {
+static int scene_tile_fwd(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st, FrameMap fm) {
   const int nb = (np + 63) / 64;
   const int items = nb * kPD;
   const int grid = items / 4 < 8192 ? (items + 3) / 4 : 8192;
-  STOVE_LAUNCH((scene_tile_fwd_k<NMAX>), dim3(grid), dim3(256), 0, st, frames, z, xw, n_obj, np, nb);
+  STOVE_LAUNCH((scene_tile_fwd_k<NMAX>), dim3(grid), dim3(256), 0, st, frames, z, xw, n_obj, np, nb, fm);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
 
-static int scene_tile_fwd_any(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st) {
-  if (n_obj <= 3) return scene_tile_fwd<3>(frames, z, xw, n_obj, np, st);
-  if (n_obj <= 6) return scene_tile_fwd<6>(frames, z, xw, n_obj, np, st);
-  if (n_obj <= 8) return scene_tile_fwd<8>(frames, z, xw, n_obj, np, st);
+static int scene_tile_fwd_any(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st, FrameMap fm = FrameMap{0, 0}) {
+  if (n_obj <= 3) return scene_tile_fwd<3>(frames, z, xw, n_obj, np, st, fm);
+  if (n_obj <= 6) return scene_tile_fwd<6>(frames, z, xw, n_obj, np, st, fm);
+  if (n_obj <= 8) return scene_tile_fwd<8>(frames, z, xw, n_obj, np, st, fm);
   return (int)hipErrorInvalidValue;
 }
 
@@ -66,8 +66,8 @@ static inline int nmax_of(int n_obj) { return n_obj <= 3 ? 3 : (n_obj <= 6 ? 6 :
 template <int NMAX>
 static int scene_bwd_tail(const float* frames, const float* z, const float* xw, const float* Dscr, const int* leaf_slot,
                           const float* coef, const float* d_ovl, float* dzc, const float* dll, const float* obj_ll,
-                          const float* dz_bg, float* dz, int n_obj, int np, hipStream_t st, hipStream_t bg_stream) {
-  int rc = scene_pixtile_bwd<NMAX>(frames, z, xw, Dscr, leaf_slot, coef, d_ovl, dzc, n_obj, np, st);
+                          const float* dz_bg, float* dz, int n_obj, int np, hipStream_t st, hipStream_t bg_stream, FrameMap fm) {
+  int rc = scene_pixtile_bwd<NMAX>(frames, z, xw, Dscr, leaf_slot, coef, d_ovl, dzc, n_obj, np, st, fm);
   if (rc) return rc;
   STOVE_TRY(stream_after(st, bg_stream));       // join: only the last kernel needs the background chain's dz_bg
   STOVE_LAUNCH((scene_finalize_bwd_k<NMAX>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, obj_ll, dz_bg, dzc, dz, n_obj, np);
@@ -176,21 +176,31 @@ static hipStream_t scene_fork_stream(hipStream_t st) {
   return side[dev];
 }
 
-int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
-                    float overlap_beta, float* ll, float* parts, float* saved, void* stream) {
+static int frame_map(int n_frames, int seq_frames, int seq_stride, FrameMap* fm) {
+  *fm = FrameMap{0, 0};
+  if (seq_frames == 0) return 0;                                   // dense
+  if (seq_frames < 0 || seq_stride < seq_frames || n_frames % seq_frames != 0) return (int)hipErrorInvalidValue;
+  if (seq_stride != seq_frames) *fm = FrameMap{seq_frames, seq_stride};
+  return 0;
+}
+
+int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
+                    int seq_stride, float overlap_beta, float* ll, float* parts, float* saved, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n_frames == 0) return 0;
+  FrameMap fm;
+  if (frame_map(n_frames, seq_frames, seq_stride, &fm)) return (int)hipErrorInvalidValue;
   const SceneSaved L = scene_saved_layout(n_frames, n_obj);
   const int np = n_frames * n_obj;
   hipStream_t sb = scene_fork_stream(st);       // background chain (MFMA-bound) next to the object chain (VALU-bound)
   STOVE_TRY(stream_after(sb, st));              // fork: inputs are ready in `st` order
   JoinGuard jb(st, sb);                         // joined on every exit path
-  int rc = scene_tile_fwd_any(frames, z, saved + L.xw, n_obj, np, st);
+  int rc = scene_tile_fwd_any(frames, z, saved + L.xw, n_obj, np, st, fm);
   if (rc) return rc;
   rc = objspn_forward(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl, np, st,
                       saved + L.obj_state);
   if (rc) return rc;
-  rc = bgspn_forward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, sb);
+  rc = bgspn_forward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, sb, fm);
   if (rc) return rc;
   STOVE_TRY(jb.join());
   STOVE_LAUNCH(scene_assemble_fwd_k, dim3((n_frames + 255) / 256), dim3(256), 0, st, saved + L.bg_out, saved + L.obj_ll,
@@ -229,18 +239,20 @@ static int params_late() {
   return v;
 }
 
-int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
-                    float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g, void* ws_,
-                    void* stream) {
-  return stove_scene_bwd_overlap(t, frames, z, n_frames, n_obj, overlap_beta, saved, dll, dz, g, ws_, stream, stream);
+int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
+                    int seq_stride, float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g,
+                    void* ws_, void* stream) {
+  return stove_scene_bwd_overlap(t, frames, z, n_frames, n_obj, seq_frames, seq_stride, overlap_beta, saved, dll, dz, g, ws_, stream, stream);
 }
 
-int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj,
-                            float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g, void* ws_,
-                            void* stream, void* param_stream) {
+int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
+                            int seq_stride, float overlap_beta, const float* saved, const float* dll, float* dz,
+                            StoveSpnTableGrads* g, void* ws_, void* stream, void* param_stream) {
   hipStream_t st = (hipStream_t)stream;
   hipStream_t sp = param_stream != nullptr ? (hipStream_t)param_stream : st;
   if (n_frames == 0) return 0;
+  FrameMap fm;
+  if (frame_map(n_frames, seq_frames, seq_stride, &fm)) return (int)hipErrorInvalidValue;
   float* ws = (float*)ws_;
   const SceneSaved L = scene_saved_layout(n_frames, n_obj);
   const SceneWs W = scene_ws_layout(n_frames, n_obj);
@@ -263,18 +275,18 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
     if (rc) return rc;
   }
   rc = bgspn_backward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, dll,
-                      nullptr, nullptr, ws + W.dz_bg, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, sb, sp == st ? sb : sp);
+                      nullptr, nullptr, ws + W.dz_bg, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, sb, sp == st ? sb : sp, fm);
   if (rc) return rc;
   // the tail joins `sb` before its last kernel (dz_bg; without a parameter stream also the bg table grads)
   if (n_obj <= 3)
     rc = scene_bwd_tail<3>(frames, z, saved + L.xw, ws + W.obj, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
-                           ws + W.dz_bg, dz, n_obj, np, st, sb);
+                           ws + W.dz_bg, dz, n_obj, np, st, sb, fm);
   else if (n_obj <= 6)
     rc = scene_bwd_tail<6>(frames, z, saved + L.xw, ws + W.obj, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
-                           ws + W.dz_bg, dz, n_obj, np, st, sb);
+                           ws + W.dz_bg, dz, n_obj, np, st, sb, fm);
   else if (n_obj <= 8)
     rc = scene_bwd_tail<8>(frames, z, saved + L.xw, ws + W.obj, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
-                           ws + W.dz_bg, dz, n_obj, np, st, sb);
+                           ws + W.dz_bg, dz, n_obj, np, st, sb, fm);
   else
     rc = (int)hipErrorInvalidValue;
   if (rc) return rc;

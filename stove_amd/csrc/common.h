@@ -60,6 +60,16 @@ __device__ __forceinline__ Tap1 make_tap(float q, int n) {
   r.in1 = (r.i0 + 1 >= 0 && r.i0 + 1 < n) ? 1.0f : 0.0f;
   return r;
 }
+// Where frame f of a (sequences x frames) batch lives when the caller hands over a time-slice of a longer clip without
+// copying it (Stove.forward scores frames 1..T-1 of x (n, T, 1024), reference stove.py:731-736: x[:, 1:]): the slice has
+// `seq_frames` frames per sequence, consecutive sequences are `seq_stride` frames apart.  seq_frames = 0: dense.
+struct FrameMap {
+  int seq_frames, seq_stride;
+  __host__ __device__ __forceinline__ size_t row(int f) const {
+    return seq_frames > 0 ? (size_t)(f / seq_frames) * seq_stride + (f % seq_frames) : (size_t)f;
+  }
+};
+
 // Coverage of a ones-image sampled at q (zero padding): value and d/dq.
 __device__ __forceinline__ float cover(float q, int n, float* dq) {
   const Tap1 t = make_tap(q, n);

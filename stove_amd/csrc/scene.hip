@@ -46,7 +46,7 @@ __device__ __forceinline__ float inv_pix(float inv_s, float off, int idx) {
 // frames [n_frames][1024], z [n_frames*n_obj][4] = [sx, sy, x, y]; xw [n_batches][100][2][64]
 template <int NMAX>
 __global__ __launch_bounds__(256) void scene_tile_fwd_k(const float* __restrict__ frames, const float* __restrict__ z,
-                                                        float* __restrict__ xw, int n_obj, int n_patches, int n_batches) {
+                                                        float* __restrict__ xw, int n_obj, int n_patches, int n_batches, FrameMap fm) {
   const int lane = lane_id();
   const int total = n_batches * kPD;
   for (int item = blockIdx.x * 4 + wave_id(); item < total; item += gridDim.x * 4) {
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void scene_tile_fwd_k(const float* __restrict_
       const float* zf = z + (size_t)f * n_obj * 4;
       const float zk[4] = {zf[k * 4], zf[k * 4 + 1], zf[k * 4 + 2], zf[k * 4 + 3]};
       const PatchPix q = patch_pix(zk, p);
-      const float* img = frames + (size_t)f * kImg * kImg;
+      const float* img = frames + fm.row(f) * (kImg * kImg);
       // earlier objects' coverage at the two tap columns / rows
       float cx[NMAX][2], cy[NMAX][2];
 #pragma unroll
@@ -99,150 +99,7 @@ __global__ __launch_bounds__(256) void scene_tile_fwd_k(const float* __restrict_
   }
 }
 
-// ---- tile backward: dL/d(x,w) of the tile -> dL/dz of the patch's own object and of the
-// earlier objects of the same frame.  block = 64 patches x 4 pixel slots.
-// dzc[patch][NMAX][4]: slot k = own object, slots j<k = occluders.
-// d_ovl[patch] = dL/d overlap_k (overlap = mean over the patch of marg).
-template <int NMAX>
-__global__ __launch_bounds__(256) void scene_tile_bwd_k(const float* __restrict__ frames, const float* __restrict__ z,
-                                                        const float* __restrict__ dxw, const float* __restrict__ d_ovl,
-                                                        float* __restrict__ dzc, int n_obj, int n_patches, int n_batches) {
-  __shared__ float red[4][NMAX * 4][64];
-  const int lane = lane_id(), slot = wave_id();
-  for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
-    const int patch = b * 64 + lane;
-    const bool live = patch < n_patches;
-    const int f = live ? patch / n_obj : 0, k = live ? patch % n_obj : 0;
-    const float* zf = z + (size_t)f * n_obj * 4;
-    const float zk[4] = {zf[k * 4], zf[k * 4 + 1], zf[k * 4 + 2], zf[k * 4 + 3]};
-    const float* img = frames + (size_t)f * kImg * kImg;
-    const float govl = live ? d_ovl[patch] * (-1.0f / kPD) : 0.0f;   // d overlap / d seen = -1/100
-    float acc[NMAX][4];
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
-    float isx[NMAX], isy[NMAX], ox[NMAX], oy[NMAX];
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j) {
-      if (j < k) {
-        isx[j] = 1.0f / zf[j * 4];
-        isy[j] = 1.0f / zf[j * 4 + 1];
-        ox[j] = -zf[j * 4 + 2] * isx[j];
-        oy[j] = -zf[j * 4 + 3] * isy[j];
-      }
-    }
-    float own[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (live) {
-      for (int p = slot; p < kPD; p += 4) {
-        const float* t = dxw + ((size_t)b * kPD + p) * 2 * 64;
-        const float gX = t[lane], gW = t[64 + lane];
-        const PatchPix q = patch_pix(zk, p);
-        float cx[NMAX][2], cy[NMAX][2], dcx[NMAX][2], dcy[NMAX][2];
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) {
-          if (j < k) {
-            cx[j][0] = cover(inv_pix(isx[j], ox[j], q.tx.i0), kImg, &dcx[j][0]);
-            cx[j][1] = cover(inv_pix(isx[j], ox[j], q.tx.i0 + 1), kImg, &dcx[j][1]);
-            cy[j][0] = cover(inv_pix(isy[j], oy[j], q.ty.i0), kImg, &dcy[j][0]);
-            cy[j][1] = cover(inv_pix(isy[j], oy[j], q.ty.i0 + 1), kImg, &dcy[j][1]);
-          }
-        }
-        // forward pieces at the four taps
-        float im[2][2], vis[2][2];
-        bool pass[2][2];
-        float seen = 0.0f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const float inb = (a ? q.ty.in1 : q.ty.in0) * (c ? q.tx.in1 : q.tx.in0);
-            im[a][c] = 0.0f;
-            vis[a][c] = 0.0f;
-            pass[a][c] = false;
-            if (inb != 0.0f) {
-              im[a][c] = img[(q.ty.i0 + a) * kImg + q.tx.i0 + c];
-              float run = 0.0f;
-              bool ok = true;
-#pragma unroll
-              for (int j = 0; j < NMAX; ++j) {
-                if (j < k) {
-                  run += cx[j][c] * cy[j][a];
-                  if (run > 1.0f) {
-                    run = 1.0f;
-                    ok = false;
-                  }
-                }
-              }
-              vis[a][c] = 1.0f - run;
-              pass[a][c] = ok;
-              const float wt = (a ? q.ty.t : 1.0f - q.ty.t) * (c ? q.tx.t : 1.0f - q.tx.t);
-              seen = fmaf(wt, vis[a][c], seen);
-            }
-          }
-        }
-        const float mg = 1.0f - seen;
-        // w = 1 - clamp(1 - seen): dw/dseen = 1 inside the clamp range (boundaries pass, as ATen)
-        const float dseen = ((mg >= 0.0f && mg <= 1.0f) ? gW : 0.0f) + govl;
-        // own object: through the sample location
-        const float wy0 = 1.0f - q.ty.t, wy1 = q.ty.t, wx0 = 1.0f - q.tx.t, wx1 = q.tx.t;
-        const float dpx = gX * (wy0 * (im[0][1] - im[0][0]) + wy1 * (im[1][1] - im[1][0])) +
-                          dseen * (wy0 * (vis[0][1] - vis[0][0]) + wy1 * (vis[1][1] - vis[1][0]));
-        const float dpy = gX * (wx0 * (im[1][0] - im[0][0]) + wx1 * (im[1][1] - im[0][1])) +
-                          dseen * (wx0 * (vis[1][0] - vis[0][0]) + wx1 * (vis[1][1] - vis[0][1]));
-        const float dgx = dpx * (0.5f * kImg), dgy = dpy * (0.5f * kImg);
-        own[0] = fmaf(dgx, q.u, own[0]);
-        own[1] = fmaf(dgy, q.v, own[1]);
-        own[2] += dgx;
-        own[3] += dgy;
-        // occluders: through the mask value at each tap
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            if (pass[a][c]) {
-              const float wt = (a ? wy1 : wy0) * (c ? wx1 : wx0);
-              const float dbox = -dseen * wt;   // vis = 1 - sum box
-              const int col = q.tx.i0 + c, row = q.ty.i0 + a;
-              const float uu = (2.0f * col + 1.0f) * (1.0f / kImg) - 1.0f;
-              const float vv = (2.0f * row + 1.0f) * (1.0f / kImg) - 1.0f;
-#pragma unroll
-              for (int j = 0; j < NMAX; ++j) {
-                if (j < k) {
-                  const float dqx = dbox * cy[j][a] * dcx[j][c] * (0.5f * kImg);
-                  const float dqy = dbox * cx[j][c] * dcy[j][a] * (0.5f * kImg);
-                  acc[j][0] = fmaf(-dqx * (uu - zf[j * 4 + 2]), isx[j] * isx[j], acc[j][0]);
-                  acc[j][1] = fmaf(-dqy * (vv - zf[j * 4 + 3]), isy[j] * isy[j], acc[j][1]);
-                  acc[j][2] = fmaf(-dqx, isx[j], acc[j][2]);
-                  acc[j][3] = fmaf(-dqy, isy[j], acc[j][3]);
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-    // own object goes to slot k
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j) {
-      const bool mine = (j == k);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) red[slot][j * 4 + e][lane] = mine ? own[e] : ((j < k) ? acc[j][e] : 0.0f);
-    }
-    __syncthreads();
-    if (slot == 0 && live) {
-#pragma unroll
-      for (int j = 0; j < NMAX; ++j) {
-        if (j < n_obj) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float s = red[0][j * 4 + e][lane] + red[1][j * 4 + e][lane] + red[2][j * 4 + e][lane] + red[3][j * 4 + e][lane];
-            dzc[((size_t)patch * NMAX + j) * 4 + e] = s;
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
+// (the tile backward lives in scene_fused.hip: scene_pixtile_bwd_k)
 
 // ---- assemble: log p(x, z) per frame (supair.py:79-94) -------------------------------------
 // parts[frame][3] = (bg, patches, overlap prior)

@@ -32,7 +32,7 @@ template <int R, int S, int G, int NMAX, int SLOTS>
 __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
     const float* __restrict__ frames, const float* __restrict__ z, const float* __restrict__ xw, const float* __restrict__ Dscr,
     const int* __restrict__ leaf_slot, const float* __restrict__ coef, const float* __restrict__ d_ovl, float* __restrict__ dzc,
-    int n_obj, int n_patches, int n_batches) {
+    int n_obj, int n_patches, int n_batches, FrameMap fm) {
   constexpr int D = 4 * S;
   constexpr int DT = R * 4 * G * 64;
   constexpr int RED = SLOTS * NMAX * 4 * 64;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
     const int f = live ? patch / n_obj : 0, k = live ? patch % n_obj : 0;
     const float* zf = z + (size_t)f * n_obj * 4;
     const float zk[4] = {zf[k * 4], zf[k * 4 + 1], zf[k * 4 + 2], zf[k * 4 + 3]};
-    const float* img = frames + (size_t)f * kImg * kImg;
+    const float* img = frames + fm.row(f) * (kImg * kImg);
     const float govl = live ? d_ovl[patch] * (-1.0f / kPD) : 0.0f;   // d overlap / d seen = -1/100
     // occluders j < k: q(X) = isx (X - 15.5) + cxo;  j >= k: coverage 0 everywhere
     float isx[NMAX], isy[NMAX], cxo[NMAX], cyo[NMAX], xj[NMAX], yj[NMAX];
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
 
 template <int NMAX>
 static int scene_pixtile_bwd(const float* frames, const float* z, const float* xw, const float* Dscr, const int* leaf_slot,
-                             const float* coef, const float* d_ovl, float* dzc, int n_obj, int np, hipStream_t st) {
+                             const float* coef, const float* d_ovl, float* dzc, int n_obj, int np, hipStream_t st, FrameMap fm) {
   constexpr int SLOTS = 8;
   constexpr int DT = 6 * 4 * 10 * 64, RED = SLOTS * NMAX * 4 * 64;
   constexpr int LDS = (DT > RED ? DT : RED) * (int)sizeof(float);
@@ -188,7 +188,7 @@ static int scene_pixtile_bwd(const float* frames, const float* z, const float* x
   int rc = (int)hipFuncSetAttribute((const void*)scene_pixtile_bwd_k<6, 25, 10, NMAX, SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (rc) return rc;
   STOVE_LAUNCH((scene_pixtile_bwd_k<6, 25, 10, NMAX, SLOTS>), dim3(nb < 4096 ? nb : 4096), dim3(64 * SLOTS), LDS, st, frames, z, xw, Dscr,
-               leaf_slot, coef, d_ovl, dzc, n_obj, np, nb);
+               leaf_slot, coef, d_ovl, dzc, n_obj, np, nb, fm);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

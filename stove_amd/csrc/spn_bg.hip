@@ -43,7 +43,7 @@ __device__ __forceinline__ float inv_coord(float inv_s, float off, int idx) {
 template <int R, int G, bool SCENE>
 __global__ __launch_bounds__(kBgThreads) void bgspn_fwd_k(
     const float* __restrict__ frames, const float* __restrict__ marg, const float* __restrict__ z, int n_obj,
-    const int* __restrict__ side, const float* __restrict__ coef, float* __restrict__ ell_part, int n_frames) {
+    const int* __restrict__ side, const float* __restrict__ coef, float* __restrict__ ell_part, int n_frames, FrameMap fm) {
   constexpr int NO = R * 2 * G;
   constexpr int NW = kBgThreads / 64;
   __shared__ float part[2][NW * 4][NO];     // one partial per 16-lane row of every wave
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_fwd_k(
   const int col = p % kBgSide, row = p / kBgSide;
   int it = 0;
   for (int f = blockIdx.x / kBgHalves; f < n_frames; f += gridDim.x / kBgHalves, ++it) {
-    const float x = frames[(size_t)f * kBgPix + p];
+    const float x = frames[fm.row(f) * kBgPix + p];
     float w;
     if (SCENE) {
       float run = 0.0f;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
     const float* __restrict__ frames, const float* __restrict__ marg, const float* __restrict__ z, int n_obj,
     const int* __restrict__ side, const float* __restrict__ coef, const float* __restrict__ dell,
     float* __restrict__ d_inputs, float* __restrict__ d_marg, float* __restrict__ dz_part,
-    float* __restrict__ gcoef_part, int n_frames, const float* __restrict__ T) {
+    float* __restrict__ gcoef_part, int n_frames, const float* __restrict__ T, FrameMap fm) {
   constexpr int NO = R * 2 * G;
   constexpr int NW = kBgThreads / 64;
   // SCENE: d box (= -dL/dw where no clamp fired) of the last NW frames, [slot][pixel of this half]; every NW frames the
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
   const int f0 = blockIdx.x / kBgHalves;
   float xn = 0.0f, fxn[NMAX], fyn[NMAX];
   auto prefetch = [&](int f) {
-    xn = frames[(size_t)f * kBgPix + p];
+    xn = frames[fm.row(f) * kBgPix + p];
     if (SCENE) {
 #pragma unroll
       for (int k = 0; k < NMAX; ++k) {
@@ -467,7 +467,7 @@ static inline float* bg_dense_of(float* ell_part, int n_frames) { return ell_par
 
 // ell_part must stay alive until the backward (it is the saved activation).
 int bgspn_forward(const float* frames, const float* marg, const float* z, int n_obj, const int* side, const float* coef,
-                  const float* wroot, float* ell_part, float* out, int n_frames, hipStream_t st) {
+                  const float* wroot, float* ell_part, float* out, int n_frames, hipStream_t st, FrameMap fm = FrameMap{0, 0}) {
   if (n_frames == 0) return 0;
   const int grid = bg_grid(n_frames);
   int halves = kBgHalves;
@@ -485,7 +485,7 @@ int bgspn_forward(const float* frames, const float* marg, const float* z, int n_
   {                                                                                                                               \
     int rc = (int)hipFuncSetAttribute((const void*)bgspn_mfma_fwd_k<TPW, NOBJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     if (rc) return rc;                                                                                                            \
-    STOVE_LAUNCH((bgspn_mfma_fwd_k<TPW, NOBJ>), grid_m, block_m, lds, st, frames, z, n_obj, (const float*)Cf, ell_part, n_frames);  \
+    STOVE_LAUNCH((bgspn_mfma_fwd_k<TPW, NOBJ>), grid_m, block_m, lds, st, frames, z, n_obj, (const float*)Cf, ell_part, n_frames, fm);  \
   }
     if (n_obj == 3) STOVE_BG_FWD(3)
     else if (n_obj == 6) STOVE_BG_FWD(6)
@@ -496,10 +496,10 @@ int bgspn_forward(const float* frames, const float* marg, const float* z, int n_
     STOVE_LAUNCH_CHECK();
     halves = 1;
   } else if (z != nullptr) {
-    STOVE_LAUNCH((bgspn_fwd_k<kBgR, kBgG, true>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, ell_part, n_frames);
+    STOVE_LAUNCH((bgspn_fwd_k<kBgR, kBgG, true>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, ell_part, n_frames, fm);
     STOVE_LAUNCH_CHECK();
   } else {
-    STOVE_LAUNCH((bgspn_fwd_k<kBgR, kBgG, false>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, ell_part, n_frames);
+    STOVE_LAUNCH((bgspn_fwd_k<kBgR, kBgG, false>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, ell_part, n_frames, fm);
     STOVE_LAUNCH_CHECK();
   }
   STOVE_LAUNCH((bgspn_root_fwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, n_frames, halves);
@@ -516,11 +516,11 @@ size_t bgspn_bwd_ws_floats(int n_frames, int n_obj = 0) {
 template <int NMAX>
 static int bg_bwd_launch(bool scene, int grid, hipStream_t st, const float* frames, const float* marg, const float* z,
                          int n_obj, const int* side, const float* coef, const float* dell, float* d_inputs,
-                         float* d_marg, float* dz_part, float* gpart, int n_frames, const float* T) {
+                         float* d_marg, float* dz_part, float* gpart, int n_frames, const float* T, FrameMap fm) {
   if (scene)
-    STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, true, NMAX>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T);
+    STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, true, NMAX>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T, fm);
   else
-    STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, false, 1>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T);
+    STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, false, 1>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T, fm);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -538,7 +538,7 @@ __global__ void bg_dz_halves_k(const float* __restrict__ dz_part, float* __restr
 int bgspn_backward(const float* frames, const float* marg, const float* z, int n_obj, const int* side, const float* coef,
                    const float* wroot, const float* ell_part, const float* out, const float* dout,
                    float* d_inputs, float* d_marg, float* dz, float* g_coef, float* g_wroot, float* ws,
-                   int n_frames, hipStream_t st, hipStream_t st_par = nullptr) {
+                   int n_frames, hipStream_t st, hipStream_t st_par = nullptr, FrameMap fm = FrameMap{0, 0}) {
   if (st_par == nullptr) st_par = st;          // stream of the parameter-gradient reductions (see objspn_backward)
   if (n_frames == 0) {
     hipMemsetAsync(g_coef, 0, sizeof(float) * kBgR * kBgPix * kBgG * 3, st);
@@ -564,11 +564,11 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
   }
   int rc;
   if (!scene || n_obj <= 3)
-    rc = bg_bwd_launch<3>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T);
+    rc = bg_bwd_launch<3>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T, fm);
   else if (n_obj <= 6)
-    rc = bg_bwd_launch<6>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T);
+    rc = bg_bwd_launch<6>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T, fm);
   else
-    rc = bg_bwd_launch<8>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T);
+    rc = bg_bwd_launch<8>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T, fm);
   if (rc) return rc;
   STOVE_TRY(stream_after(st_par, st));         // gcoef_part of bgspn_bwd_k, rsc of bgspn_root_bwd_k
   if (scene) {

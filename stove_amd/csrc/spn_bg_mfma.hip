@@ -40,7 +40,7 @@ __global__ void bg_dense_fwd_k(const int* __restrict__ side, const float* __rest
 // so the scheduler overlaps one tile's mask / feature VALU work with the other tile's MFMAs); NOBJ = 0: runtime n_obj.
 template <int TPW, int NOBJ>
 __global__ __launch_bounds__(256) void bgspn_mfma_fwd_k(const float* __restrict__ frames, const float* __restrict__ z, int n_obj_rt,
-                                                       const float* __restrict__ Cf, float* __restrict__ ell, int F) {
+                                                       const float* __restrict__ Cf, float* __restrict__ ell, int F, FrameMap fm) {
   const int n_obj = NOBJ > 0 ? NOBJ : n_obj_rt;
   extern __shared__ __attribute__((aligned(16))) float bg_lds[];
   const int wv = wave_id(), lane = lane_id(), i = lane & 15, kq = lane >> 4;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void bgspn_mfma_fwd_k(const float* __restrict_
 #pragma unroll
   for (int tl = 0; tl < TPW; ++tl) {
     const int f = f0 + tl * 16 + i;
-    fptr[tl] = frames + (size_t)(f < F ? f : 0) * kBgPix + 4 * kq;
+    fptr[tl] = frames + fm.row(f < F ? f : 0) * kBgPix + 4 * kq;
 #pragma unroll
     for (int u = 0; u < GRP; ++u) xc[u][tl] = *reinterpret_cast<const float4*>(fptr[tl] + 16 * ((kofs + u) & 63));
   }

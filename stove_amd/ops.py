@@ -136,17 +136,31 @@ class _SceneFn(torch.autograd.Function):
     def forward(ctx, frames, z, obj_coef, obj_wsum, obj_wroot, bg_coef, bg_wroot,
                 obj_scope, obj_leaf_slot, bg_side, n_obj, beta, sink=None):
         lib = _lib.load()
-        frames, z = _f32(frames), _f32(z)
+        z = _f32(z)
         tabs = [_f32(x) for x in (obj_coef, obj_wsum, obj_wroot, bg_coef, bg_wroot)]
-        nf = frames.shape[0]
+        # frames: (nf, 1024) dense, or a (n, T', 1024) time-slice of longer clips (x[:, 1:] in Stove.forward) whose rows are
+        # contiguous: handed to the kernels as it lies in memory (frame map) instead of a 100 MB copy per step
+        seq_frames = seq_stride = 0
+        if frames.dim() == 3:
+            if frames.stride(2) == 1 and frames.stride(1) == frames.shape[2] and frames.stride(0) >= frames.shape[1] * frames.shape[2] \
+                    and frames.stride(0) % frames.shape[2] == 0 and frames.dtype == torch.float32 and frames.is_cuda:
+                seq_frames, seq_stride = frames.shape[1], frames.stride(0) // frames.shape[2]
+                nf = frames.shape[0] * frames.shape[1]
+            else:
+                frames = _f32(frames.reshape(-1, frames.shape[2]))
+                nf = frames.shape[0]
+        else:
+            frames = _f32(frames)
+            nf = frames.shape[0]
+        ctx.frame_map = (nf, seq_frames, seq_stride)
         dev = frames.device
         with torch.cuda.device(dev):
             ll = torch.empty(nf, dtype=torch.float32, device=dev)
             parts = torch.empty(nf, 3, dtype=torch.float32, device=dev)
             saved = torch.empty(lib.stove_scene_saved_floats(nf, n_obj) + 1, dtype=torch.float32, device=dev)
             t = _tables(obj=(obj_scope, obj_leaf_slot, tabs[0], tabs[1], tabs[2]), bg=(bg_side, tabs[3], tabs[4]))
-            check(lib.stove_scene_fwd(ctypes.byref(t), ptr(frames), ptr(z), nf, n_obj, float(beta), ptr(ll), ptr(parts),
-                                      ptr(saved), stream()), 'stove_scene_fwd')
+            check(lib.stove_scene_fwd(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, float(beta),
+                                      ptr(ll), ptr(parts), ptr(saved), stream()), 'stove_scene_fwd')
         ctx.save_for_backward(frames, z, *tabs, obj_scope, obj_leaf_slot, bg_side, saved)
         ctx.n_obj, ctx.beta, ctx.sink = n_obj, float(beta), sink
         ctx.mark_non_differentiable(parts)
@@ -156,7 +170,7 @@ class _SceneFn(torch.autograd.Function):
     def backward(ctx, dll, _dparts):
         lib = _lib.load()
         frames, z, oc, ow, orr, bc, bw, obj_scope, obj_leaf_slot, bg_side, saved = ctx.saved_tensors
-        nf, n_obj = frames.shape[0], ctx.n_obj
+        (nf, seq_frames, seq_stride), n_obj = ctx.frame_map, ctx.n_obj
         dev = frames.device
         dll = _f32(dll)
         with torch.cuda.device(dev):
@@ -171,8 +185,9 @@ class _SceneFn(torch.autograd.Function):
                 # second stream and overlap with what autograd enqueues next on this one: the recursion's backward,
                 # latency-bound with one sequence per CU.  The main stream waits for them at the end of the backward pass.
                 main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-                check(lib.stove_scene_bwd_overlap(ctypes.byref(t), ptr(frames), ptr(z), nf, n_obj, ctx.beta, ptr(saved), ptr(dll),
-                                                  ptr(dz), ctypes.byref(g), ptr(ws), main.cuda_stream, side.cuda_stream),
+                check(lib.stove_scene_bwd_overlap(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, ctx.beta,
+                                                  ptr(saved), ptr(dll), ptr(dz), ctypes.byref(g), ptr(ws), main.cuda_stream,
+                                                  side.cuda_stream),
                       'stove_scene_bwd_overlap')
                 with torch.cuda.stream(side):
                     ctx.sink(grads)
@@ -180,8 +195,8 @@ class _SceneFn(torch.autograd.Function):
                     buf.record_stream(side)          # the caching allocator must not hand these out before `side` is done
                 torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_stream(side))
                 return (None, dz, None, None, None, None, None, None, None, None, None, None, None)
-            check(lib.stove_scene_bwd(ctypes.byref(t), ptr(frames), ptr(z), nf, n_obj, ctx.beta, ptr(saved), ptr(dll),
-                                      ptr(dz), ctypes.byref(g), ptr(ws), stream()), 'stove_scene_bwd')
+            check(lib.stove_scene_bwd(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, ctx.beta,
+                                      ptr(saved), ptr(dll), ptr(dz), ctypes.byref(g), ptr(ws), stream()), 'stove_scene_bwd')
         if ctx.sink is not None:               # flat parameter arena: table gradients go straight into the bucket
             ctx.sink(grads)
             grads = [None] * 5

@@ -191,10 +191,17 @@ class Stove(nn.Module):
             zsup_loop, zsstd_loop, init6 = z_sup_full[:, skip:], z_sup_std_full[:, skip:], z_sup_full[:, skip - 1]
 
         # 2. initial state at t = skip-1 and the inference recursion
-        lat0 = 0.01 * self._noise('latent', (n, o, cl // 2 - 4), z_sup)
-        _ = 0.1 + 0.01 * self._noise('std', (n, o, cl // 2 - 4), z_sup)     # drawn as in the reference, unused
-        init_z = torch.cat([init6, lat0], -1)
         Ts = T - skip
+        pooled = None
+        if self.noise_fn is None and getattr(c, 'fused_dynamics', True):
+            # device RNG: the three draws of the reference (latent prior, the unused std prior, the step noise) as ONE launch
+            nl = n * o * (cl // 2 - 4)
+            pooled = self._noise('pooled', (2 * nl + n * Ts * o * (cl // 2 + 2),), z_sup)      # [latent | std | steps]
+            lat0 = 0.01 * pooled[:nl].view(n, o, cl // 2 - 4)
+        else:
+            lat0 = 0.01 * self._noise('latent', (n, o, cl // 2 - 4), z_sup)
+            _ = 0.1 + 0.01 * self._noise('std', (n, o, cl // 2 - 4), z_sup)     # drawn as in the reference, unused
+        init_z = torch.cat([init6, lat0], -1)
         use_app = bool(c.debug_core_appearance)
         if getattr(c, 'fused_dynamics', True):
             extra = []
@@ -204,7 +211,10 @@ class Stove(nn.Module):
             if use_app:
                 extra.append(obj_appearances[:, skip - 1:T - 1])
             extra = torch.cat(extra, -1) if extra else None
-            eps = self._noise('steps', (n, Ts, o, cl // 2 + 2), z_sup)
+            if pooled is not None:
+                eps = pooled[2 * n * o * (cl // 2 - 4):].view(n, Ts, o, cl // 2 + 2)
+            else:
+                eps = self._noise('steps', (n, Ts, o, cl // 2 + 2), z_sup)
             image, sink = self.dyn.kernel_params(0)
             z_s, z_dyn_s, z_dyn_std_s, mean_s, z_std_s, pred = ops.dyn_loop(
                 init_z, zsup_loop, zsstd_loop, eps, extra, image,

@@ -42,7 +42,7 @@ class Supair(nn.Module):
         if self.c.channels != 1 or x.shape[-1] != 32 or x.shape[-2] != 32 \
                 or self.c.patch_width != 10 or self.c.patch_height != 10:
             raise NotImplementedError('scene kernels are built for 1x32x32 frames and 10x10 glimpses')
-        frames = x.flatten(end_dim=1).flatten(start_dim=1)
+        frames = x.flatten(start_dim=2)                 # (n, T', 1024) view: a time-slice of longer clips is NOT copied (ops._SceneFn)
         arena = getattr(self, '_arena', None)
         if arena is not None and arena.has_spn:         # flat parameter arena: one bake launch, gradients sunk
             obj_tabs, bg_tabs = arena.spn_tables()

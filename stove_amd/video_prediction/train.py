@@ -269,12 +269,18 @@ class Trainer(AbstractTrainer):
         actions = self.init_t(data['present_actions']) if self.c.action_conditioned else None
         self.bucket.zero()
         elbo, prop_dict, rewards = self.stove(images, step_counter, actions, self.c.supair_only)
-        min_ll = -1.0 * elbo
         mse_rewards = torch.zeros(1)
         if self.c.action_conditioned:
+            min_ll = -1.0 * elbo
             mse_rewards, term = self._reward_term(rewards, data, step_counter)
             min_ll = min_ll + term
-        min_ll.backward()
+            min_ll.backward()
+        else:
+            # min_ll = -ELBO (train.py:452): seed the backward with -1 instead of building / differentiating the negation
+            if getattr(self, '_minus_one', None) is None or self._minus_one.device != elbo.device:
+                self._minus_one = torch.tensor(-1.0, device=elbo.device, dtype=elbo.dtype)
+            elbo.backward(self._minus_one)
+            min_ll = -elbo.detach()
         self.bucket.all_reduce()                     # [amd] one RCCL all-reduce of the flat gradient
         if isinstance(self.optimizer, FlatAdam):
             self.optimizer.step(max_norm=1 if self.c.debug_gradient_clip else None)      # clipping folded into the step

@@ -159,8 +159,7 @@ def test_trainer_data_parallel_step(tmp_path):
     assert torch.equal(r0['start'], r1['start'])                                      # parameters broadcast at start
     assert r0['len'] == r1['len'] and not (set(r0['ids'].tolist()) & set(r1['ids'].tolist()))      # disjoint clips
     assert not torch.equal(r0['images'], r1['images'])
-    for kind in ('latent', 'steps'):
-        assert not torch.equal(r0['noise'][kind], r1['noise'][kind])                  # per-rank noise streams
+    assert not torch.equal(r0['noise']['pooled'], r1['noise']['pooled'])              # per-rank noise streams
     assert torch.equal(r0['grad'], r1['grad'])                                        # the reduced gradient ...
     assert torch.equal(r0['after'], r1['after']) and torch.equal(r0['after2'], r1['after2'])     # ... and the replicas stay equal
     assert not torch.equal(r0['after'], r0['start']) and float(r0['steps']) == 1.0
@@ -170,7 +169,12 @@ def test_trainer_data_parallel_step(tmp_path):
     trainer = M.main(sh_args=_args(path, tmp, random_seed=str(r0['seed']), batch_size='8'))
     with torch.no_grad():
         trainer.bucket.data.copy_(r0['start'].to(trainer.bucket.data.device))
-    noise = {k: torch.cat([r0['noise'][k], r1['noise'][k]]) for k in r0['noise']}
+    # the ranks drew [latent | std | steps] as one buffer each (stove.py `pooled`): cut and concatenate along the batch
+    nb, o, Ts = r0['images'].shape[0], 3, r0['images'].shape[1] - 2
+    nl = nb * o * 12
+    cut = lambda p: {'latent': p[:nl].view(nb, o, 12), 'std': p[nl:2 * nl].view(nb, o, 12), 'steps': p[2 * nl:].view(nb, Ts, o, 18)}
+    c0, c1 = cut(r0['noise']['pooled']), cut(r1['noise']['pooled'])
+    noise = {k: torch.cat([c0[k], c1[k]]) for k in c0}
     trainer.stove.noise_fn = lambda kind, shape: noise[kind].reshape(shape)
     images = torch.cat([r0['images'], r1['images']])
     elbo, _, _, _, _ = trainer.train_step({'present_images': images}, 1)

@@ -133,7 +133,7 @@ def test_fix_supair_stage_on_reference_fixture():
     check('fix_supair.z', err(zfix[..., :4], g['z_fixed']), 1e-6)
     check('fix_supair.zstd', err(zfix[..., 4:], g['zstd_fixed']), 1e-6)
     fired = (t_(g['z_fixed']) != t_(g['z'])).any(-1)
-    assert torch.equal(hits.bool().cpu(), fired) and int(fired.sum()) >= 3
+    assert torch.equal(hits.bool().cpu(), fired) and int(fired.sum()) >= 2
     # velocities of the smoothed states (stove.py:54-101)
     zf = t_(g['z_fixed']).float()
     check('fix_supair.vel', err(zl[..., 4:], (zf[:, skip:, :, 2:] - zf[:, skip - 1:-1, :, 2:])), 1e-5)
