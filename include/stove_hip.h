@@ -293,12 +293,15 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
                     int a_kmajor, int b_kmajor, int nsplit, int splitk, int tile, float* ws, void* stream);
 
 /* ---- gate math of RnnStates' LSTM (encoder.py:43-51, torch.nn.LSTM cell, gate order i,f,g,o); the GEMMs
- * around it stay on rocBLAS.  gx (n,4H): x W_ih^T + b_ih + b_hh; gh (n,4H): h_prev W_hh^T or NULL; c_prev
- * (n,H) or NULL (zero state).  bwd: dh, dc_in (NULL = 0) -> dg (n,4H), dc_out (n,H); dgx_acc (n,4H) gets
- * dg added (first != 0: overwritten), the running sum over the unrolled steps that feeds dW_ih. */
+ * around it are stove_gemm_bf16 (or library GEMMs).  gx (n,4H): gate pre-activations -- x W_ih^T + b_ih + b_hh, or already
+ * the full sum with the recurrent term (the recurrent GEMM adds gx in its epilogue) and then gh NULL; gh (n,4H): h_prev W_hh^T
+ * or NULL; c_prev (n,H) or NULL (zero state).  bwd: dh, dc_in (NULL = 0) -> dg (n,4H) (NULL: not stored), dc_out (n,H);
+ * dgx_sum (n,4H) or NULL = dg of this step + the n_more gate gradients dg_more[m][n][4H] of other steps: the gradient of the
+ * input projection shared by all steps, formed once (by the last backward step) and feeding dW_ih. */
 int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, float* c, float* h, int n, int H, void* stream);
 int stove_lstm_cell_bwd(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
-                        const float* dc_in, float* dg, float* dc_out, float* dgx_acc, int first, int n, int H, void* stream);
+                        const float* dc_in, float* dg, float* dc_out, float* dgx_sum, const float* dg_more, int n_more, int n, int H,
+                        void* stream);
 
 /* ---- output head of RnnStates behind fc1 (encoder.py:53-56: zps = fc2(sigmoid(fc1(output)))).  a1 (rows, H1) = fc1
  * pre-activations (library GEMM) -> h1 = sigmoid(a1) (rows, H1) and codes (rows, OUT) = h1 W2^T + b2; W2 (OUT, H1).

@@ -78,7 +78,7 @@ def _declare(lib):
         'stove_match_objects': (I, [P, P, P, I, I, I, I, I, P]),
         'stove_profile_enable': (None, [I]),
         'stove_lstm_cell_fwd': (I, [P, P, P, P, P, I, I, P]),
-        'stove_lstm_cell_bwd': (I, [P] * 9 + [I, I, I, P]),
+        'stove_lstm_cell_bwd': (I, [P] * 10 + [I, I, I, P]),
         'stove_gnn_debug_stamps': (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
         'stove_profile_report': (S, [c_char_p, S]),
         'stove_spn_bake': (I, [P, A, P, P, P, P, P, P]),

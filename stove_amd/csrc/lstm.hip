@@ -51,12 +51,14 @@ __global__ void lstm_cell_fwd_k(const float* __restrict__ gx, const float* __res
 
 // dh (n,H): gradient of this step's hidden state (output grad + recurrent grad); dc_in (n,H) or null:
 // gradient flowing into this step's cell from the next step.
-// -> dg (n,4H) gate pre-activation gradients, dc_out (n,H) gradient of the previous cell,
-//    dgx_acc (n,4H): += dg (running sum over the steps; `first` overwrites instead).
+// -> dg (n,4H) gate pre-activation gradients (or null: not stored), dc_out (n,H) gradient of the previous cell,
+//    dgx_sum (n,4H) or null: this step's dg + the dg of `n_more` other steps, dg_more[m][n][4H] -- the input projection is
+//    shared by all steps, so its gradient is the sum over the steps; it is formed ONCE, by the last backward step (step 0),
+//    from the stored gate gradients of the others, instead of a read-modify-write of a running sum in every step.
 __global__ void lstm_cell_bwd_k(const float* __restrict__ gx, const float* __restrict__ gh, const float* __restrict__ c_prev,
                                 const float* __restrict__ c, const float* __restrict__ dh, const float* __restrict__ dc_in,
-                                float* __restrict__ dg, float* __restrict__ dc_out, float* __restrict__ dgx_acc,
-                                int first, int n, int H) {
+                                float* __restrict__ dg, float* __restrict__ dc_out, float* __restrict__ dgx_sum,
+                                const float* __restrict__ dg_more, int n_more, int n, int H) {
   const int q = H / 4;
   const size_t total = (size_t)n * q;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -93,13 +95,15 @@ __global__ void lstm_cell_bwd_k(const float* __restrict__ gx, const float* __res
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float4 v = {out[k][0], out[k][1], out[k][2], out[k][3]};
-      st4(dg + go_ + k * H, v);
-      float4 a = v;
-      if (!first) {
-        const float4 p = ld4(dgx_acc + go_ + k * H);
-        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+      if (dg != nullptr) st4(dg + go_ + k * H, v);
+      if (dgx_sum != nullptr) {
+        float4 a = v;
+        for (int m = 0; m < n_more; ++m) {
+          const float4 p = ld4(dg_more + (size_t)m * n * 4 * H + go_ + k * H);
+          a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+        }
+        st4(dgx_sum + go_ + k * H, a);
       }
-      st4(dgx_acc + go_ + k * H, a);
     }
     st4(dc_out + ho, float4{dcp[0], dcp[1], dcp[2], dcp[3]});
   }

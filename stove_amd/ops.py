@@ -761,18 +761,20 @@ class _EncoderLstmFn(torch.autograd.Function):
                     gx = torch.addmm(b_ih + b_hh, x, w_ih.t())
             hs = torch.empty(num_steps, n, H, dtype=torch.float32, device=dev)
             cs = torch.empty(num_steps, n, H, dtype=torch.float32, device=dev)
-            ghs = []
+            # gs[k]: gate pre-activations of step k = gx + h_{k-1} W_hh^T (the recurrent GEMM adds gx in its epilogue, so the
+            # cell kernels read ONE (n, 4H) tensor per step, forward and backward); gs[0] is gx itself
+            gss = []
             for k in range(num_steps):
-                gh = None
+                gs = gx
                 if k > 0 and ns:
-                    gh = gemm_bf16(hs[k - 1], w_hh, nsplit=ns, splitk=1)
+                    gs = gemm_bf16(hs[k - 1], w_hh, nsplit=ns, splitk=1, add=gx)
                 elif k > 0:
                     with _blas('hipblas'):
-                        gh = torch.mm(hs[k - 1], w_hh.t())
-                ghs.append(gh)
-                check(lib.stove_lstm_cell_fwd(ptr(gx), ptr(gh), ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(hs[k]),
+                        gs = torch.addmm(gx, hs[k - 1], w_hh.t())
+                gss.append(gs)
+                check(lib.stove_lstm_cell_fwd(ptr(gs), None, ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(hs[k]),
                                               n, H, stream()), 'stove_lstm_cell_fwd')
-        ctx.save_for_backward(x, w_ih, w_hh, gx, hs, cs, *[g for g in ghs if g is not None])
+        ctx.save_for_backward(x, w_ih, w_hh, gx, hs, cs, *gss[1:])
         ctx.num_steps = num_steps
         ctx.time_major = bool(time_major)
         ctx.ns = ns
@@ -782,7 +784,7 @@ class _EncoderLstmFn(torch.autograd.Function):
     def backward(ctx, dhs):
         lib = _lib.load()
         x, w_ih, w_hh, gx, hs, cs = ctx.saved_tensors[:6]
-        ghs = [None] + list(ctx.saved_tensors[6:])
+        gss = [gx] + list(ctx.saved_tensors[6:])
         K = ctx.num_steps
         ns = ctx.ns
         n, H = x.shape[0], w_hh.shape[1]
@@ -796,24 +798,24 @@ class _EncoderLstmFn(torch.autograd.Function):
             return _splitk_tn(dy, inp)
         with torch.cuda.device(dev):
             dgx = torch.empty_like(gx)
-            # gate gradients of steps 1..K-1 are kept ((K-1) x 105 MB at 25 600 frames) so that dW_hh is ONE
-            # GEMM over all steps; step 0 (h_{-1} = 0) only feeds dgx and uses slot 0 as scratch at the end
+            # gate gradients of steps 1..K-1 are kept ((K-1) x 105 MB at 25 600 frames): dW_hh is ONE GEMM over all of
+            # them, and step 0 -- the last to run, h_{-1} = 0 -- adds them to its own to form the gradient of the shared
+            # input projection, dgx (its own gate gradient is stored nowhere else)
             dg_all = torch.empty(max(K - 1, 1), n, 4 * H, dtype=torch.float32, device=dev)
             dc = [torch.empty(n, H, dtype=torch.float32, device=dev) for _ in range(2)]
             dh = dhs[K - 1]
-            d_whh = None
             for k in range(K - 1, -1, -1):
-                if k == 0 and K > 1:
-                    d_whh = wgrad(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H))           # before slot 0 is reused
-                dg = dg_all[max(k - 1, 0)]
-                check(lib.stove_lstm_cell_bwd(ptr(gx), ptr(ghs[k]), ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(dh),
-                                              ptr(dc[(k + 1) % 2]) if k < K - 1 else None, ptr(dg), ptr(dc[k % 2]), ptr(dgx),
-                                              1 if k == K - 1 else 0, n, H, stream()), 'stove_lstm_cell_bwd')
+                dg = dg_all[k - 1] if k > 0 else None
+                check(lib.stove_lstm_cell_bwd(ptr(gss[k]), None, ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(dh),
+                                              ptr(dc[(k + 1) % 2]) if k < K - 1 else None, ptr(dg) if dg is not None else None,
+                                              ptr(dc[k % 2]), ptr(dgx) if k == 0 else None, ptr(dg_all) if (k == 0 and K > 1) else None,
+                                              K - 1 if k == 0 else 0, n, H, stream()), 'stove_lstm_cell_bwd')
                 if k > 0:
                     if ns:
                         dh = gemm_bf16(dg, w_hh, None, False, True, ns, 1, add=dhs[k - 1])     # dhs[k-1] + dg W_hh
                     else:
                         dh = torch.addmm(dhs[k - 1], dg, w_hh)
+            d_whh = wgrad(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H)) if K > 1 else None
             if d_whh is None:
                 d_whh = torch.zeros_like(w_hh)
             d_wih = wgrad(dgx, x)
