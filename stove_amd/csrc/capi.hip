@@ -45,8 +45,7 @@ __global__ void tile_unpack_k(const float* __restrict__ tile, float* __restrict_
 template <int NMAX>
 static int scene_tile_fwd(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st, FrameMap fm) {
   const int nb = (np + 63) / 64;
-  const int items = nb * kPD;
-  const int grid = items / 4 < 8192 ? (items + 3) / 4 : 8192;
+  const int grid = nb < 8192 ? nb : 8192;          // one workgroup per batch of 64 glimpses
   STOVE_LAUNCH((scene_tile_fwd_k<NMAX>), dim3(grid), dim3(256), 0, st, frames, z, xw, n_obj, np, nb, fm);
   STOVE_LAUNCH_CHECK();
   return 0;

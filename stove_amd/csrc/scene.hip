@@ -48,9 +48,12 @@ template <int NMAX>
 __global__ __launch_bounds__(256) void scene_tile_fwd_k(const float* __restrict__ frames, const float* __restrict__ z,
                                                         float* __restrict__ xw, int n_obj, int n_patches, int n_batches, FrameMap fm) {
   const int lane = lane_id();
-  const int total = n_batches * kPD;
-  for (int item = blockIdx.x * 4 + wave_id(); item < total; item += gridDim.x * 4) {
-    const int b = item / kPD, p = item % kPD;
+  // workgroup = one batch of 64 glimpses, its 4 waves share the 100 pixels: the ~22 frames of a batch are then gathered by ONE
+  // workgroup (one XCD's L2).  With (batch, pixel) items dealt round-robin over the whole grid every frame was pulled into
+  // several L2s: 363 MB of HBM fetches per launch for 104 MB of frames (rocprofv3 FETCH_SIZE).
+  for (int item = 0;; ++item) {
+    const int b = blockIdx.x + (item / (kPD / 4)) * gridDim.x, p = wave_id() + 4 * (item % (kPD / 4));
+    if (b >= n_batches) break;
     const int patch = b * 64 + lane;
     float xv = 0.0f, wv = 0.0f;
     if (patch < n_patches) {
