@@ -36,9 +36,25 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
   constexpr int D = 4 * S;
   constexpr int DT = R * 4 * G * 64;
   constexpr int RED = SLOTS * NMAX * 4 * 64;
-  extern __shared__ float pt_lds[];          // max(DT, RED) floats: leaf gradients, then the slot reduction
-  float* dl = pt_lds;
+  constexpr int CFT = D * R * 32;            // per (pixel, replica): the leaf's G x 3 coefficients (30 floats), leaf index, pad
+  extern __shared__ __attribute__((aligned(16))) float pt_lds[];          // [CFT] coefficient rows by pixel | max(DT, RED): leaf gradients, then the slot reduction
+  float* cft = pt_lds;
+  float* dl = pt_lds + CFT;
   const int lane = lane_id(), slot = wave_id();
+  // The coefficients a pixel needs (one leaf per replica: 6 x 30 floats) are wave-uniform.  As scalar loads they came out as
+  // ~30 dependent "s_load; s_waitcnt lgkmcnt(0)" round trips per pixel (the leaf index feeds the row address, and lgkmcnt also
+  // counts the LDS reads of the leaf gradients): ~5 000 cycles per pixel, 20 % VALU issue.  The whole table is 77 KB: it is
+  // staged in LDS once per workgroup (persistent over its batches) and read back as broadcast float4.
+  for (int i = threadIdx.x; i < D * R; i += 64 * SLOTS) {
+    const int p = i / R, r = i % R;
+    const int ls = leaf_slot[r * D + p];
+    const float* cf = coef + (size_t)(r * 4 * S + ls) * G * 3;
+    float* dst = cft + i * 32;
+#pragma unroll
+    for (int e = 0; e < G * 3; ++e) dst[e] = cf[e];
+    dst[30] = __int_as_float(ls / S);
+    dst[31] = 0.0f;
+  }
   for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
     {
       const float4* src = reinterpret_cast<const float4*>(Dscr + (size_t)b * DT);
@@ -75,20 +91,33 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
       // ---- dL/dx, dL/dw of the pixel (GaussVector backward in expanded form: x^2 A + x B + C)
       const float x = tile[(p * 2) * 64 + lane];
       const float w = tile[(p * 2 + 1) * 64 + lane];
-      float A = 0.0f, Bq = 0.0f, C = 0.0f;
+      // per-replica partial sums: 3 R independent FMA chains of length G instead of 3 chains of length R G
+      float Ar[R], Br[R], Cr[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const int ls = leaf_slot[r * D + p];          // L*S + i (wave-uniform)
-        const int L = ls / S;
-        const float* cf = coef + (size_t)(r * 4 * S + ls) * G * 3;
+        const float4* row = reinterpret_cast<const float4*>(cft + (p * R + r) * 32);      // broadcast reads
+        float cf[32];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float4 v = row[e];
+          cf[4 * e] = v.x; cf[4 * e + 1] = v.y; cf[4 * e + 2] = v.z; cf[4 * e + 3] = v.w;
+        }
+        const int L = __float_as_int(cf[30]);
         const float* dlp = dl + ((r * 4 + L) * G) * 64 + lane;
+        float a = 0.0f, bq = 0.0f, c = 0.0f;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const float d = dlp[g * 64];
-          A = fmaf(d, cf[g * 3], A);
-          Bq = fmaf(d, cf[g * 3 + 1], Bq);
-          C = fmaf(d, cf[g * 3 + 2], C);
+          a = fmaf(d, cf[g * 3], a);
+          bq = fmaf(d, cf[g * 3 + 1], bq);
+          c = fmaf(d, cf[g * 3 + 2], c);
         }
+        Ar[r] = a; Br[r] = bq; Cr[r] = c;
+      }
+      float A = 0.0f, Bq = 0.0f, C = 0.0f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        A += Ar[r]; Bq += Br[r]; C += Cr[r];
       }
       const float gX = fmaf(x + x, A, Bq) * w;
       const float gW = fmaf(x, fmaf(x, A, Bq), C);
@@ -150,7 +179,7 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
       }
     }
     __syncthreads();            // every slot is done with the leaf gradients: the LDS becomes red[slot][NMAX * 4][64]
-    float* red = pt_lds;
+    float* red = dl;
 #pragma unroll
     for (int j = 0; j < NMAX; ++j) {
       const bool mine = (j == k);
@@ -180,14 +209,17 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
 template <int NMAX>
 static int scene_pixtile_bwd(const float* frames, const float* z, const float* xw, const float* Dscr, const int* leaf_slot,
                              const float* coef, const float* d_ovl, float* dzc, int n_obj, int np, hipStream_t st, FrameMap fm) {
-  constexpr int SLOTS = 8;
-  constexpr int DT = 6 * 4 * 10 * 64, RED = SLOTS * NMAX * 4 * 64;
-  constexpr int LDS = (DT > RED ? DT : RED) * (int)sizeof(float);
+  // 16 waves (4 per SIMD) when the cross-slot reduction buffer allows: the per-pixel code is a chain of dependent instructions
+  // (~9 cycles per instruction at 2 waves per SIMD), more resident waves hide it
+  constexpr int SLOTS = NMAX <= 3 ? 16 : 8;
+  constexpr int DT = 6 * 4 * 10 * 64, RED = SLOTS * NMAX * 4 * 64, CFT = 100 * 6 * 32;
+  constexpr int LDS = (CFT + (DT > RED ? DT : RED)) * (int)sizeof(float);
   const int nb = (np + 63) / 64;
   if (nb == 0) return 0;
   int rc = (int)hipFuncSetAttribute((const void*)scene_pixtile_bwd_k<6, 25, 10, NMAX, SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (rc) return rc;
-  STOVE_LAUNCH((scene_pixtile_bwd_k<6, 25, 10, NMAX, SLOTS>), dim3(nb < 4096 ? nb : 4096), dim3(64 * SLOTS), LDS, st, frames, z, xw, Dscr,
+  STOVE_LAUNCH((scene_pixtile_bwd_k<6, 25, 10, NMAX, SLOTS>), dim3(nb < 256 ? nb : 256), dim3(64 * SLOTS), LDS, st, frames, z, xw, Dscr,      // persistent: one workgroup per CU
+              
                leaf_slot, coef, d_ovl, dzc, n_obj, np, nb, fm);
   STOVE_LAUNCH_CHECK();
   return 0;
