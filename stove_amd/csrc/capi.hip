@@ -430,16 +430,25 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
   if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && extra == nullptr)) return (int)hipErrorInvalidValue;
   LoopConst kc{pos_var, vel_std, lat_std};
   if (N <= 4 && N >= 2) {      // small graphs: row-per-wave VALU formulation, two barriers per step (gnn_small.hip)
-    const void* fn = act != nullptr ? (const void*)dyn_loop_fwd_small_k<true> : (const void*)dyn_loop_fwd_small_k<false>;
-    int rc = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSmLdsFloats * sizeof(float)));
-    if (rc) return rc;
+    // STOVE_LOOP_VALU=1: the all-VALU edge phase (A/B switch; the default runs the edge chains on the matrix cores)
+    static const bool em = !(getenv("STOVE_LOOP_VALU") != nullptr && getenv("STOVE_LOOP_VALU")[0] == '1');
+#define STOVE_LOOP_LAUNCH(SAVE_, EM_, STREAMS)                                                                                  \
+  do {                                                                                                                          \
+    int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_fwd_small_k<SAVE_, EM_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)(kSmLdsFloats * sizeof(float)));                                                     \
+    if (rc) return rc;                                                                                                          \
+    STOVE_LAUNCH((dyn_loop_fwd_small_k<SAVE_, EM_>), dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream, \
+                 z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, \
+                 g_sm_stamps, STREAMS);                                                                                         \
+  } while (0)
     if (act != nullptr) {
-      STOVE_LAUNCH(dyn_loop_fwd_small_k<true>, dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
-                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps, small_bwd_enabled());
+      if (em) STOVE_LOOP_LAUNCH(true, true, small_bwd_enabled());
+      else STOVE_LOOP_LAUNCH(true, false, small_bwd_enabled());
     } else {
-      STOVE_LAUNCH(dyn_loop_fwd_small_k<false>, dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
-                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps, 0);
+      if (em) STOVE_LOOP_LAUNCH(false, true, 0);
+      else STOVE_LOOP_LAUNCH(false, false, 0);
     }
+#undef STOVE_LOOP_LAUNCH
     STOVE_LAUNCH_CHECK();
     return 0;
   }
@@ -520,10 +529,10 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
   if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && (extra == nullptr || A < 1))) return (int)hipErrorInvalidValue;
   LoopConst kc{pos_var, vel_std, lat_std};
   if (N <= 4 && N >= 2) {
-    int rc = (int)hipFuncSetAttribute((const void*)rollout_fwd_small_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+    int rc = (int)hipFuncSetAttribute((const void*)rollout_fwd_small_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(kSmLdsFloats * sizeof(float)));
     if (rc) return rc;
-    STOVE_LAUNCH(rollout_fwd_small_k, dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
+    STOVE_LAUNCH(rollout_fwd_small_k<true>, dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
                  z_last, extra, params, z_pred, zstd, pred, B, num, A < 1 ? 1 : A, N, sin_dim, lim_enc, elu, kc);
     STOVE_LAUNCH_CHECK();
     return 0;

@@ -176,10 +176,260 @@ __device__ __forceinline__ float sm_dotw(const SmW<K4>& W, float x) {
   return a.x + a.y;
 }
 
+// ---- edge phase on the matrix cores -----------------------------------------------------------------------------------
+// In the wave-per-row form the N(N-1) edges are 3-layer chains dealt out over four waves: with N = 3 two waves carry two edges
+// each plus the self-dynamics of their node row, 8 dependent layers between the two barriers of a step -- half of the step
+// (cycle stamps: profiles/r02_loop_stamps_before.txt).  Here the edge phase is column-parallel instead: ALL edges are the
+// columns of one v_mfma_f32_16x16x4_f32 chain (exact fp32 FMA chains), one wave per chain:
+//     wave 3  relation chain   R1 = phi(P_a[i] + P_b[j] + w_d d + b) -> R2 = phi(W R1 + b) -> R3 = W R2 + b + R2
+//     wave 2  attention chain  A1 likewise -> A2 -> att = exp(w . A2 + b)
+//     wave 1  self-dynamics of all node rows (columns = nodes)   H1 = phi(W S + b), SD = W H1 + b + H1
+// A layer's result tile has output o = 16 t' + 4 (lane >> 4) + reg in register `reg` of lane (column, lane >> 4) -- exactly the
+// B operand the next layer's MFMA wants for k-slot (lane >> 4) of k-step (t', reg): activations chain from accumulators to
+// operands with no data movement, and the A operands W[16 t' + i][16 t + 4 g .. +3] are float4s of the [K/4][OUT][4] LDS
+// weight image the row-per-lane dots already use.  3 dependent layers of 16-32 MFMAs instead of 8 layers of LDS round trips.
+typedef __attribute__((ext_vector_type(4))) float smf4;
+
+// acc[t'] += sum_k W[16 t' + i][k] x[k][column], k = 16 t + 4 g + s, for the two output tiles t' of a 32-wide layer
+template <int KT>
+struct SmMW {
+  float4 w[KT][2];        // [input tile t][output tile t']: W[16 t' + i][16 t + 4 g .. + 3]
+};
+// a layer's A operands, fetched from the LDS weight image ahead of use (all of them at once: the reads overlap with whatever
+// the wave does before the layer; fetched one input tile at a time, each MFMA group waited ~130 cycles for its weights)
+template <int KT>
+__device__ __forceinline__ SmMW<KT> sm_mfma_wload(const float* Wl, int lane) {
+  SmMW<KT> m;
+  const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    m.w[t][0] = *reinterpret_cast<const float4*>(Wl + ((4 * t + g) * 32 + i) * 4);
+    m.w[t][1] = *reinterpret_cast<const float4*>(Wl + ((4 * t + g) * 32 + 16 + i) * 4);
+  }
+  return m;
+}
+// Four accumulation chains (output tile x parity of the input tile), their MFMAs issued round-robin: a chain's next MFMA
+// comes four issues (128 cycles) after its previous one.  With two chains the dependent-accumulator latency showed: 58-86
+// cycles per MFMA measured in place against the 32-cycle issue rate.  The two partial tiles are added at the end.
+template <int KT>
+__device__ __forceinline__ void sm_mfma_layer(const SmMW<KT>& m, const smf4 (&x)[KT], smf4 (&acc)[2]) {
+  static_assert(KT % 2 == 0, "input tiles are taken in pairs");
+  smf4 p0 = {0.0f, 0.0f, 0.0f, 0.0f}, p1 = p0;
+#pragma unroll
+  for (int t = 0; t < KT; t += 2) {
+    const float4 a0 = m.w[t][0], a1 = m.w[t][1], b0 = m.w[t + 1][0], b1 = m.w[t + 1][1];
+    const float a0s[4] = {a0.x, a0.y, a0.z, a0.w}, a1s[4] = {a1.x, a1.y, a1.z, a1.w};
+    const float b0s[4] = {b0.x, b0.y, b0.z, b0.w}, b1s[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0s[e], x[t][e], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1s[e], x[t][e], acc[1], 0, 0, 0);
+      p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0s[e], x[t + 1][e], p0, 0, 0, 0);
+      p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1s[e], x[t + 1][e], p1, 0, 0, 0);
+    }
+  }
+  acc[0] += p0;
+  acc[1] += p1;
+}
+// phi on four values; the branch on the (wave-uniform) nonlinearity is taken once, not per element
+__device__ __forceinline__ smf4 sm_phi4(smf4 v, int elu) {
+  smf4 r;
+  if (elu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = v[e] > 0.0f ? v[e] : expm1f(v[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = fmaxf(v[e], 0.01f * v[e]);      // leaky_relu(0.01): max(x, 0.01 x)
+  }
+  return r;
+}
+__device__ __forceinline__ smf4 sm_ld4(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return smf4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void sm_st4(float* p, smf4 v) { *reinterpret_cast<float4*>(p) = float4{v[0], v[1], v[2], v[3]}; }
+
+// What a lane of the MFMA edge phase keeps over the whole time loop (column -> edge / node, LDS and stream offsets): the
+// integer divisions and address arithmetic behind them cost more than the 48 MFMAs of the relation chain when redone per step.
+struct SmEdgeLane {
+  int valid;                 // column < number of edges (chain waves) / of nodes (self-dynamics wave)
+  int pi, pj;                // float offsets into L.PR of the two first-layer halves of the lane's edge (incl. 4 g)
+  int pos_i, pos_j;          // float offsets into L.POS
+  int e32;                   // e * 32 + 4 g        (L.R3 row of the edge)
+  int e;                     // e = i N + j         (L.ATT slot)
+  int s64, s32, s1;          // stream offsets: eg * 64 + 4 g, eg * 32 + 4 g, eg
+  int node32;                // self-dynamics wave: r * 32 + 4 g
+};
+__device__ __forceinline__ SmEdgeLane sm_edge_lane(int N, int compact_streams) {
+  SmEdgeLane el;
+  const int wv = wave_id(), lane = lane_id();
+  const int c = lane & 15, g = lane >> 4;
+  const int E = N * (N - 1);
+  const int h = wv == 2 ? 1 : 0;
+  const int q = c < E ? c : (E > 0 ? E - 1 : 0);
+  const int nm1 = N > 1 ? N - 1 : 1;
+  const int i = q / nm1, jj = q % nm1, j = jj + (jj >= i ? 1 : 0);
+  el.e = i * N + j;
+  const int eg = compact_streams ? q : el.e;
+  el.valid = wv == 1 ? (c < N) : (c < E);
+  el.pi = i * 256 + 128 * h + 4 * g;
+  el.pj = j * 256 + 128 * h + 64 + 4 * g;
+  el.pos_i = i * 4;
+  el.pos_j = j * 4;
+  el.e32 = el.e * 32 + 4 * g;
+  el.s64 = eg * 64 + 4 * g;
+  el.s32 = eg * 32 + 4 * g;
+  el.s1 = eg;
+  el.node32 = (c < N ? c : N - 1) * 32 + 4 * g;
+  return el;
+}
+
+// Everything of the edge phase that does not depend on the step's data -- the A operands (weights) of the wave's chain and its
+// bias / distance vectors -- is read from LDS BEFORE the first barrier of the step (wave 3 idles there for ~6 000 cycles, the
+// others issue the reads behind their node work), so the chain starts on the barrier's release with its operands in registers.
+struct SmEdgePre {
+  SmMW<4> w1;            // chains: first 64 -> 32 layer;  self-dynamics wave: w1.w[0..1] = layer 0, w1.w[2..3] = layer 1
+  SmMW<2> w2;            // relation chain: 32 -> 32 layer
+  smf4 wd[4], b0[4];     // chains: distance weights and biases of the factorised first layer
+  smf4 bl2[2], bl3[2];   // biases of the wave's second / third layer (self-dynamics: layer 0 / layer 1)
+};
+__device__ __forceinline__ void sm_edge_prefetch(const SmLds& L, SmEdgePre& pre) {
+  const int wv = wave_id(), lane = lane_id(), g = lane >> 4;
+  const float* V = L.V;
+  if (wv == 1) {
+    const SmMW<2> a = sm_mfma_wload<2>(L.W + W_S0, lane), b = sm_mfma_wload<2>(L.W + W_S1, lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      pre.w1.w[t][0] = a.w[t][0]; pre.w1.w[t][1] = a.w[t][1];
+      pre.w1.w[2 + t][0] = b.w[t][0]; pre.w1.w[2 + t][1] = b.w[t][1];
+      pre.bl2[t] = sm_ld4(V + V_S0 + 16 * t + 4 * g);
+      pre.bl3[t] = sm_ld4(V + V_S1 + 16 * t + 4 * g);
+    }
+  } else if (wv >= 2) {
+    const int h = wv == 2 ? 1 : 0;
+    pre.w1 = sm_mfma_wload<4>(L.W + (h ? W_A1 : W_R1), lane);
+    if (h == 0) pre.w2 = sm_mfma_wload<2>(L.W + W_R2, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      pre.wd[t] = sm_ld4(V + (h ? V_WDA : V_WDR) + 16 * t + 4 * g);
+      pre.b0[t] = sm_ld4(V + (h ? V_BA0 : V_BR0) + 16 * t + 4 * g);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      pre.bl2[t] = sm_ld4(V + (h ? V_BA1 : V_BR1) + 16 * t + 4 * g);
+      pre.bl3[t] = sm_ld4(V + (h ? V_WA2 : V_BR2) + 16 * t + 4 * g);       // attention: the 32 -> 1 weights
+    }
+  }
+}
+
+// sbuf [4][32]: encoder outputs S of the node rows (written in P1); sdx [4][32]: SD of the node rows (read in P4)
+template <bool SAVE>
+__device__ __forceinline__ void sm_edge_phase_mfma(const SmLds& L, const SmCfg& cf, const SmAct& act, const float* sbuf, float* sdx,
+                                                   const SmEdgeLane& el, const SmEdgePre& pre) {
+  const int wv = wave_id(), lane = lane_id();
+  const int g = lane >> 4;
+  const float* V = L.V;
+  if (wv == 1) {
+    // ---- self-dynamics, columns = node rows
+    SmMW<2> ws0, ws1;
+    smf4 x[2], acc[2], h1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      ws0.w[t][0] = pre.w1.w[t][0]; ws0.w[t][1] = pre.w1.w[t][1];
+      ws1.w[t][0] = pre.w1.w[2 + t][0]; ws1.w[t][1] = pre.w1.w[2 + t][1];
+      x[t] = sm_ld4(sbuf + el.node32 + 16 * t);
+      acc[t] = pre.bl2[t];
+    }
+    sm_mfma_layer<2>(ws0, x, acc);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      h1[t] = sm_phi4(acc[t], cf.elu);
+      acc[t] = pre.bl3[t];
+    }
+    sm_mfma_layer<2>(ws1, h1, acc);
+    if (el.valid) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        sm_st4(sdx + el.node32 + 16 * t, acc[t] + h1[t]);
+        if (SAVE) sm_st4(act.H1 + el.node32 + 16 * t, h1[t]);
+      }
+    }
+    return;
+  }
+  if ((wv != 2 && wv != 3) || cf.N < 2) return;
+  // ---- relation (wave 3, h = 0) / attention (wave 2, h = 1) chain, columns = edges q = 0 .. E-1 (i -> j, i != j)
+  const int h = wv == 2 ? 1 : 0;
+  const float dx = L.POS[el.pos_i] - L.POS[el.pos_j], dy = L.POS[el.pos_i + 1] - L.POS[el.pos_j + 1];
+  const float d = dx * dx + dy * dy;
+  float* s1p = h ? act.A1 : act.R1;
+  float* s2p = h ? act.A2 : act.R2;
+  smf4 x1[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const smf4 a = sm_ld4(L.PR + el.pi + 16 * t), b = sm_ld4(L.PR + el.pj + 16 * t);
+    x1[t] = sm_phi4(a + b + pre.wd[t] * d + pre.b0[t], cf.elu);
+  }
+  sm_stamp(cf, 8);
+  smf4 acc[2], a2[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) acc[t] = pre.bl2[t];
+  sm_mfma_layer<4>(pre.w1, x1, acc);
+  if (SAVE && el.valid) {          // the stores of the layer input go out behind the MFMAs that consumed it
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sm_st4(s1p + el.s64 + 16 * t, x1[t]);
+  }
+  sm_stamp(cf, 9);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) a2[t] = sm_phi4(acc[t], cf.elu);
+  sm_stamp(cf, 10);
+  if (h == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = pre.bl3[t];
+    sm_mfma_layer<2>(pre.w2, a2, acc);
+    sm_stamp(cf, 11);
+    if (el.valid) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const smf4 r3 = acc[t] + a2[t];
+        sm_st4(L.R3 + el.e32 + 16 * t, r3);
+        if (SAVE) {
+          sm_st4(act.R3 + el.s32 + 16 * t, r3);
+          sm_st4(s2p + el.s32 + 16 * t, a2[t]);
+        }
+      }
+    }
+  } else {
+    float p = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) p = fmaf(pre.bl3[t][s2], a2[t][s2], p);
+    p += __shfl_xor(p, 16);
+    p += __shfl_xor(p, 32);
+    const float att = __expf(p + V[V_BA2]);
+    if (el.valid) {
+      if (SAVE) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) sm_st4(s2p + el.s32 + 16 * t, a2[t]);
+      }
+      if (g == 0) {
+        L.ATT[el.e] = att;
+        if (SAVE) {
+          act.ATT[el.s1] = att;
+          act.DIST[el.s1] = d;
+        }
+      }
+    }
+  }
+}
+
 // One GNN step.  Node wave r (< N): `sinv` = input row (lane k and k+32 hold s_in[r][k], zero beyond sin_dim);
 // returns RES[o] / PRED[o] in lane o (and o+32).  SAVE: write the activation block (act.* valid).
-template <bool SAVE>
-__device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float sinv, const SmAct& act, float& res_out, float& pred_out) {
+template <bool SAVE, bool EM>      // EM: edge phase + self-dynamics on the matrix cores (sm_edge_phase_mfma)
+__device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float sinv, const SmAct& act, float& res_out, float& pred_out,
+                                        const SmEdgeLane& el) {
+  __shared__ __attribute__((aligned(16))) float sbuf[4][32];       // S back as broadcast float4 reads (see sm_dotw)
+  __shared__ __attribute__((aligned(16))) float sdx[4][32];        // EM: SD of every node row, from the self-dynamics wave
   const int wv = wave_id();
   const int lane = lane_id();
   const int o = lane & 31, h = lane >> 5;
@@ -209,8 +459,11 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
       e = sm_dotw<8>(wa, sinv);
     }
     S = (o < cf.lim_enc) ? sinv : e + benc;
-    __shared__ __attribute__((aligned(16))) float sbuf[4][32];       // S back as broadcast float4 reads (see sm_dotw)
     if (lane < 32) sbuf[wv][lane] = S;
+    if (EM && SAVE && lane < 32) {
+      act.SIN[wv * 32 + o] = sinv;
+      act.S[wv * act.cat_ld + o] = S;
+    }
     float4 sx[8];
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) sx[k4] = *reinterpret_cast<const float4*>(&sbuf[wv][4 * k4]);
@@ -223,7 +476,7 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
         for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
           for (int g = 0; g < 4; ++g) nx[k4][g] = *reinterpret_cast<const float4*>(L.W + W_EF + ((4 + k4) * 256 + g * 64 + lane) * 4);
-      } else {
+      } else if (!EM) {
         wb = sm_wload<8>(L.W + W_S0, 32, o);        // self-dynamics layer 0, used right after the barrier
       }
 #pragma unroll
@@ -250,19 +503,25 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
     pr[192] = p[3].x + p[3].y;
     if (lane < 2) L.POS[r * 4 + lane] = S;
   }
+  // waves without a node row idle in front of the barrier: they fetch their chain's operands there; node waves (on the critical
+  // path of P1) fetch theirs behind it
+  SmEdgePre pre;
+  if (EM && wv >= N) sm_edge_prefetch(L, pre);
   sm_stamp(cf, 1);
   WG_SYNC();
   sm_stamp(cf, 2);
+  if (EM && wv < N) sm_edge_prefetch(L, pre);
   // ---- P3: edges (i -> j, i != j); half 0 = relation chain, half 1 = attention chain ----------------------------------
   // Wave 3 (no node row when N = 3) takes edges first.  Node waves interleave their self-dynamics layers (independent
   // of the edges) with the LDS round trip of their first edge's activation row.
-  bool self_done = !(wv < N);
+  if (EM) sm_edge_phase_mfma<SAVE>(L, cf, act, &sbuf[0][0], &sdx[0][0], el, pre);
+  bool self_done = EM || !(wv < N);
   const int vwd = h ? V_WDA : V_WDR, vb0 = h ? V_BA0 : V_BR0;
   const float wd_lo = V[vwd + o], wd_hi = V[vwd + o + 32], b0_lo = V[vb0 + o], b0_hi = V[vb0 + o + 32];
   const float b1 = V[(h ? V_BA1 : V_BR1) + o], br2 = V[V_BR2 + o], wa2 = V[V_WA2 + o], ba2 = V[V_BA2];
   const float* Wl2 = L.W + (h ? W_A1 : W_R1);
 #pragma unroll
-  for (int it = 0; it < 3; ++it) {
+  for (int it = 0; it < 3 && !EM; ++it) {
     if (it >= cf.ne && self_done) break;
     const bool has_edge = it < cf.ne;
     int e = 0, eg = 0;          // LDS edge row (i N + j); row in the saved-activation buffers
@@ -356,7 +615,7 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
     const int r = wv;
     wb = sm_wload<8>(L.W + W_F1, 32, o);
     const float bf0 = V[V_F0 + o], bf1 = V[V_F1 + o], bf2 = V[V_F2 + o], bo0 = V[V_O0 + o], bo1 = V[V_O1 + o];
-    float pred = SD;
+    float pred = EM ? sdx[r][o] : SD;
     for (int j = 0; j < N; ++j)
       if (j != r) pred = fmaf(L.R3[(r * N + j) * 32 + o], L.ATT[r * N + j], pred);
     sm_stamp(cf, 12);
@@ -395,7 +654,7 @@ __device__ __forceinline__ float sm_from_lane(float v, int src_lane) {
 // =================================================================================================
 // inference recursion, same contract as dyn_loop_fwd_k (gnn.hip) with G = 1: grid = B sequences
 // =================================================================================================
-template <bool SAVE>
+template <bool SAVE, bool EM>
 __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
@@ -411,6 +670,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
   sm_edges(cf);
   const int E = sin_dim - 16;
   const size_t act_stride = gnn_act_floats(N, 1);
+  const SmEdgeLane el = sm_edge_lane(N, SAVE && streams);
   sm_setup(L, P);
   // node wave r: lane l (and l+32) holds s_in[l]; dims 0..15 come from the running state z[t-1][2..17]
   float sinv = 0.0f;
@@ -440,7 +700,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     if (SAVE) a = streams ? sm_act2(act + (size_t)b * sm_act2_floats(N, Ts), N, Ts, ts) : sm_act(act + ((size_t)b * Ts + ts) * act_stride, N);
     cf.stamps = (ts == Ts - 1) ? stamps : nullptr;
     float res = 0.0f, prd = 0.0f;
-    sm_step<SAVE>(L, cf, sinv, a, res, prd);
+    sm_step<SAVE, EM>(L, cf, sinv, a, res, prd, el);
     if (wv < N) {
       // epilogue (stove.py:103-170 + constrain_z_dyn): lane d < 16 owns state dim d, lanes 16/17 the two scale dims
       const float res_s = sm_from_lane(res, (lane & 32) + ((l + 16) & 31));      // RES[16 + d] for d < 16
@@ -486,6 +746,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
 // =================================================================================================
 // generative rollout, same contract as rollout_fwd_k (gnn.hip) with G = 1
 // =================================================================================================
+template <bool EM>
 __global__ __launch_bounds__(64 * kSmWaves) void rollout_fwd_small_k(const float* __restrict__ z_last, const float* __restrict__ extra,
                                                            const float* __restrict__ P, float* __restrict__ z_pred,
                                                            float* __restrict__ zstd, float* __restrict__ pred,
@@ -498,6 +759,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void rollout_fwd_small_k(const float
   cf.stamps = nullptr;
   sm_edges(cf);
   const int E = sin_dim - 16;
+  const SmEdgeLane el = sm_edge_lane(N, 0);
   sm_setup(L, P);
   float sinv = 0.0f, scale = 0.0f;
   const int r = wv;
@@ -513,7 +775,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void rollout_fwd_small_k(const float
     if (wv < N && l >= 16 && l < sin_dim && t + 1 < num) xnext = extra[(((size_t)b * A + ((t + 1) % A)) * N + r) * E + (l - 16)];
     SmAct a{};
     float res = 0.0f, prd = 0.0f;
-    sm_step<false>(L, cf, sinv, a, res, prd);
+    sm_step<false, EM>(L, cf, sinv, a, res, prd, el);
     if (wv < N) {
       const float res_s = sm_from_lane(res, (lane & 32) + ((l + 16) & 31));
       float zv;

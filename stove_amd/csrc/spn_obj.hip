@@ -131,7 +131,7 @@ __global__ __launch_bounds__(128 * R) void objspn_fwd_k(
     const float* __restrict__ wsum, const float* __restrict__ wroot,
     float* __restrict__ out, float* __restrict__ ovl, int n_samples, int n_batches, float* __restrict__ st_save) {
   constexpr int D = 4 * S;
-  __shared__ float xch[R * 2 * K * 64];
+  __shared__ float xch[R * K * 64];        // side 1 -> side 0 of every replica (66 KB of LDS in all: two workgroups per CU)
   __shared__ float part[R * 2 * 64];
   __shared__ __attribute__((aligned(16))) float wtab[R * 2][G * G * K];
   const int lane = lane_id();
@@ -156,13 +156,14 @@ __global__ __launch_bounds__(128 * R) void objspn_fwd_k(
         sp[(2 * G + K + s) * 64] = st.o[s];
       }
     }
+    if (side == 1)
 #pragma unroll
-    for (int s = 0; s < K; ++s) xch[((r * 2 + side) * K + s) * 64 + lane] = st.o[s];
+      for (int s = 0; s < K; ++s) xch[(r * K + s) * 64 + lane] = st.o[s];
     __syncthreads();
     if (side == 0) {
       float oB[K];
 #pragma unroll
-      for (int s = 0; s < K; ++s) oB[s] = xch[((r * 2 + 1) * K + s) * 64 + lane];
+      for (int s = 0; s < K; ++s) oB[s] = xch[(r * K + s) * 64 + lane];
       const float mA = vmax<K>(st.o), mB = vmax<K>(oB);
       float EA[K], EB[K];
 #pragma unroll
