@@ -495,11 +495,16 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
     // small graphs: T-serial data-gradient chain (gnn_small_bwd.hip), then the weight gradients as a throughput pass
     float* gpart = (float*)ws;
     float* dy = gpart + (size_t)B * kGnnGrads;
-    int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_bwd_small_k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(kSmBLdsFloats * sizeof(float)));
+    static const bool em = !(getenv("STOVE_LOOP_VALU") != nullptr && getenv("STOVE_LOOP_VALU")[0] == '1');     // as stove_dynloop_fwd
+    int rc = (int)hipFuncSetAttribute(em ? (const void*)dyn_loop_bwd_small_k<true> : (const void*)dyn_loop_bwd_small_k<false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSmBLdsFloats * sizeof(float)));
     if (rc) return rc;
-    STOVE_LAUNCH(dyn_loop_bwd_small_k, dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, params,
-                 const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim, lim_enc, elu, kc);
+    if (em)
+      STOVE_LAUNCH(dyn_loop_bwd_small_k<true>, dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, params,
+                   const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim, lim_enc, elu, kc);
+    else
+      STOVE_LAUNCH(dyn_loop_bwd_small_k<false>, dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, params,
+                   const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim, lim_enc, elu, kc);
     STOVE_LAUNCH_CHECK();
     rc = (int)hipFuncSetAttribute((const void*)gnn_dw_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDwLdsFloats * sizeof(float)));
     if (rc) return rc;

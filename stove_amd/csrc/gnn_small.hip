@@ -231,6 +231,35 @@ __device__ __forceinline__ void sm_mfma_layer(const SmMW<KT>& m, const smf4 (&x)
   acc[0] += p0;
   acc[1] += p1;
 }
+// The general form (backward: transposed weight images with ROWS = the layer's input width as output rows): OT output tiles,
+// one accumulation chain each, KT input tiles; weights fetched inside.  Wl = [K/4][ROWS][4] LDS image.
+template <int KT, int OT>
+__device__ __forceinline__ void sm_mfma_layer_t(const float* Wl, const smf4 (&x)[KT], smf4 (&acc)[OT], int lane) {
+  constexpr int ROWS = 16 * OT;
+  const int i = lane & 15, g = lane >> 4;
+  float4 w[KT][OT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int u = 0; u < OT; ++u) w[t][u] = *reinterpret_cast<const float4*>(Wl + ((4 * t + g) * ROWS + 16 * u + i) * 4);
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int u = 0; u < OT; ++u) {
+        const float wv = e == 0 ? w[t][u].x : (e == 1 ? w[t][u].y : (e == 2 ? w[t][u].z : w[t][u].w));
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, x[t][e], acc[u], 0, 0, 0);
+      }
+  }
+}
+// d phi / d pre-activation from the activation's OUTPUT, four values
+__device__ __forceinline__ smf4 sm_dphi4(smf4 y, int elu) {
+  smf4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = y[e] > 0.0f ? 1.0f : (elu ? y[e] + 1.0f : 0.01f);
+  return r;
+}
 // phi on four values; the branch on the (wave-uniform) nonlinearity is taken once, not per element
 __device__ __forceinline__ smf4 sm_phi4(smf4 v, int elu) {
   smf4 r;
@@ -259,6 +288,7 @@ struct SmEdgeLane {
   int e;                     // e = i N + j         (L.ATT slot)
   int s64, s32, s1;          // stream offsets: eg * 64 + 4 g, eg * 32 + 4 g, eg
   int node32;                // self-dynamics wave: r * 32 + 4 g
+  int i32;                   // i * 32 + 4 g        (row of the edge's target node in [node][32] LDS buffers)
 };
 __device__ __forceinline__ SmEdgeLane sm_edge_lane(int N, int compact_streams) {
   SmEdgeLane el;
@@ -281,6 +311,7 @@ __device__ __forceinline__ SmEdgeLane sm_edge_lane(int N, int compact_streams) {
   el.s32 = eg * 32 + 4 * g;
   el.s1 = eg;
   el.node32 = (c < N ? c : N - 1) * 32 + 4 * g;
+  el.i32 = i * 32 + 4 * g;
   return el;
 }
 

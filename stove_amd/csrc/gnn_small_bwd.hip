@@ -38,15 +38,15 @@ __device__ __forceinline__ SmDy sm_dy(float* seq, int N, int Ts, int ts) {
 struct SmBLds {
   float *W, *V, *DSD, *EG, *DD, *POS, *X1, *DP;
 };
-constexpr int kSmBLdsFloats = W_END + V_END + 4 * 32 + 16 * 128 + 16 + 2 * 16 + kSmWaves * 64 + 4 * 256;
+constexpr int kSmBLdsFloats = W_END + V_END + 4 * 32 + 16 * 128 + 32 + 2 * 16 + kSmWaves * 64 + 4 * 256;
 __device__ __forceinline__ SmBLds smb_carve(float* base) {
   SmBLds L;
   L.W = base;
   L.V = L.W + W_END;
   L.DSD = L.V + V_END;        // [4][32]   dL/dPRED of every node row
   L.EG = L.DSD + 4 * 32;      // [16][dR1pre 64 | dA1pre 64] by edge row i*N + j
-  L.DD = L.EG + 16 * 128;     // [16]      dL/d dist of every edge
-  L.POS = L.DD + 16;          // [2][4][4] positions (two parities: a fast wave may already write the next step's)
+  L.DD = L.EG + 16 * 128;     // [2][16]   dL/d dist of every edge: relation-chain part | attention-chain part
+  L.POS = L.DD + 32;          // [2][4][4] positions (two parities: a fast wave may already write the next step's)
   L.X1 = L.POS + 32;          // [4 waves][E32 32 | dA2pre 32]
   L.DP = L.X1 + kSmWaves * 64;       // [4][256]  dP rows for the edge-first transpose product
   return L;
@@ -106,6 +106,98 @@ __device__ __forceinline__ SmBNodeIn smb_node_load(const SmAct& a, int r, int l,
   return n;
 }
 
+// ---- edge phase of the backward on the matrix cores (the adjoint of sm_edge_phase_mfma, gnn_small.hip) ------------------
+// Columns = edges; wave 3 walks the relation chain backwards, wave 2 the attention chain, through the transposed weight images:
+//     dq = (dSD_i . R3) att,  dR3 = dSD_i att,  E32 = (W_R2^T dR3 + dR3) phi'(R2),  dR1 = (W_R1^T E32) phi'(R1)          (wave 3)
+//     dA2 = dq w_a2 phi'(A2),  dA1 = (W_A1^T dA2) phi'(A1)                                                              (wave 2)
+// and each chain's share of dL/d dist = dX1 . w_d.  In the row-per-lane form every wave took its edges one after the other (two
+// rounds for N = 3); here all edges are one 48- (32-) MFMA chain.  Saved forward values arrive in the accumulator layout
+// (lane = (edge column, lane >> 4), four consecutive features per float4) straight from the activation streams.
+struct SmBEdgeIn {
+  smf4 r3[2], y2[2], x1[4];       // R3, R2 | A2, R1 | A1 of the lane's edge
+  float att;
+};
+__device__ __forceinline__ SmBEdgeIn smb_edge_load(const SmAct& a, const SmEdgeLane& el, int h) {
+  SmBEdgeIn in;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    in.r3[t] = sm_ld4(a.R3 + el.s32 + 16 * t);
+    in.y2[t] = sm_ld4((h ? a.A2 : a.R2) + el.s32 + 16 * t);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) in.x1[t] = sm_ld4((h ? a.A1 : a.R1) + el.s64 + 16 * t);
+  in.att = a.ATT[el.s1];
+  return in;
+}
+__device__ __forceinline__ void smb_edge_phase_mfma(const SmBLds& L, const SmEdgeLane& el, const SmBEdgeIn& in, const SmDy& g, int elu) {
+  const int wv = wave_id(), lane = lane_id(), gq = lane >> 4;
+  if (wv < 2) return;
+  const int h = wv == 2 ? 1 : 0;
+  const float* V = L.V;
+  smf4 dsd[2];
+  float pq = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    dsd[t] = sm_ld4(L.DSD + el.i32 + 16 * t);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pq = fmaf(dsd[t][e], in.r3[t][e], pq);
+  }
+  pq += __shfl_xor(pq, 16);
+  pq += __shfl_xor(pq, 32);
+  const float dq = pq * in.att;
+  smf4 y[2], d1[4];
+  if (h == 0) {
+    smf4 dr3[2], acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      dr3[t] = dsd[t] * in.att;
+      acc[t] = smf4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    sm_mfma_layer_t<2, 2>(L.W + W_R2, dr3, acc, lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) y[t] = (acc[t] + dr3[t]) * sm_dphi4(in.y2[t], elu);
+    if (el.valid) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        sm_st4(g.dR3 + el.s32 + 16 * t, dr3[t]);
+        sm_st4(g.E32 + el.s32 + 16 * t, y[t]);
+      }
+      if (gq == 0) g.dq[el.s1] = dq;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) y[t] = sm_ld4(V + V_WA2 + 16 * t + 4 * gq) * dq * sm_dphi4(in.y2[t], elu);
+    if (el.valid) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) sm_st4(g.dA2p + el.s32 + 16 * t, y[t]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) d1[u] = smf4{0.0f, 0.0f, 0.0f, 0.0f};
+  sm_mfma_layer_t<2, 4>(L.W + (h ? W_A1 : W_R1), y, d1, lane);
+  float dd = 0.0f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    d1[u] = d1[u] * sm_dphi4(in.x1[u], elu);
+    const smf4 wd = sm_ld4(V + (h ? V_WDA : V_WDR) + 16 * u + 4 * gq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dd = fmaf(d1[u][e], wd[e], dd);
+  }
+  dd += __shfl_xor(dd, 16);
+  dd += __shfl_xor(dd, 32);
+  if (el.valid) {
+    float* eg = L.EG + el.e * 128 + 64 * h + 4 * gq;
+    float* g1 = (h ? g.dA1p : g.dR1p) + el.s64;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      sm_st4(eg + 16 * u, d1[u]);
+      sm_st4(g1 + 16 * u, d1[u]);
+    }
+    if (gq == 0) L.DD[16 * h + el.e] = dd;
+  }
+}
+
+template <bool EM>
 __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     const float* __restrict__ zsup, const float* __restrict__ zsstd, const float* __restrict__ eps, const float* __restrict__ P,
     float* __restrict__ act, const float* __restrict__ dz, const float* __restrict__ dzdyn, const float* __restrict__ dmean,
@@ -122,6 +214,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
   const int E = sin_dim - 16;
   const int NEo = N * (N - 1);
   const float* V = L.V;
+  const SmEdgeLane el = sm_edge_lane(N, 1);
   smb_setup(L, P);
   float* aseq = act + (size_t)b * sm_act2_floats(N, Ts);
   float* dseq = dy + (size_t)b * sm_dy_floats(N, Ts);
@@ -145,10 +238,12 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     }
     // this wave's edges of the step: saved forward values, in flight across the node phase
     float eR3[3], eATT[3], eR2[3], eA2[3], eX_lo[3], eX_hi[3];
+    SmBEdgeIn ein{};
+    if (EM && wv >= 2) ein = smb_edge_load(a, el, wv == 2 ? 1 : 0);
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
       eR3[it] = eATT[it] = eR2[it] = eA2[it] = eX_lo[it] = eX_hi[it] = 0.0f;
-      if (it < cf.ne) {
+      if (!EM && it < cf.ne) {
         const int q = cf.eq[it];
         eR3[it] = a.R3[q * 32 + l];
         eATT[it] = a.ATT[q];
@@ -231,7 +326,9 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     }
     WG_SYNC();
     // ---- Q3: edges: half 0 = relation chain, half 1 = attention chain -----------------------------------------------
-    {
+    if (EM) {
+      smb_edge_phase_mfma(L, el, ein, g, elu);
+    } else {
       const float wa2 = V[V_WA2 + l];
       const int vwd = h ? V_WDA : V_WDR;
       const float wd_lo = V[vwd + l], wd_hi = V[vwd + l + 32];
@@ -269,7 +366,10 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
         float* eg = L.EG + e * 128 + 64 * h;
         eg[l] = d1_lo;
         eg[l + 32] = d1_hi;
-        if (lane == 0) L.DD[e] = dd;
+        if (lane == 0) {
+          L.DD[e] = dd;
+          L.DD[16 + e] = 0.0f;
+        }
         float* g1 = (h ? g.dA1p : g.dR1p) + q * 64;
         g1[l] = d1_lo;
         g1[l + 32] = d1_hi;
@@ -324,7 +424,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
       if (l < 2) {
         float dd = 0.0f;
         for (int j = 0; j < N; ++j)
-          if (j != r) dd += 2.0f * (pos[r * 4 + l] - pos[j * 4 + l]) * (L.DD[r * N + j] + L.DD[j * N + r]);
+          if (j != r) dd += 2.0f * (pos[r * 4 + l] - pos[j * 4 + l]) * ((L.DD[r * N + j] + L.DD[16 + r * N + j]) + (L.DD[j * N + r] + L.DD[16 + j * N + r]));
         tot += dd;
       }
       const bool raw = l < lim_enc;
