@@ -287,7 +287,8 @@ int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* ex
  * splitk > 1: K is cut into `splitk` slices computed by different workgroups into ws (stove_gemm_bf16_ws_floats floats), then
  * summed in slice order into C (needs ldc == N, bias and add NULL): fills the chip when M x N is small and K huge (weight gradients).
  * tile: workgroup tile, 0 = chosen by the library, 1 = 256 x 128 (8 waves), 2 = 128 x 128 (4 waves).
- * lda, ldb, ldc, N and the contiguous extent of each operand (K, or M / N when K-major) must be multiples of 4. */
+ * Operands / outputs whose leading dimension, contiguous extent or base address is not a multiple of 4 floats (fc1 of the
+ * recognition network: 50 columns) are handled element-wise (slow path, meant for small operands); split-K needs an aligned C. */
 size_t stove_gemm_bf16_ws_floats(int M, int N, int splitk);
 int stove_gemm_bf16(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                     int a_kmajor, int b_kmajor, int nsplit, int splitk, int tile, float* ws, void* stream);

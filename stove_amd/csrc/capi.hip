@@ -611,16 +611,27 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
   if (tile == 11 && !a_kmajor && !b_kmajor && nsplit == 2) return gemm_launch<false, false, 2, 256, 128, 1>(A, B, bias, add, C, M, N, K, lda, ldb, ldc, 1, st);
   if (tile == 12 && !a_kmajor && !b_kmajor && nsplit == 2) return gemm_launch<false, false, 2, 256, 128, 2>(A, B, bias, add, C, M, N, K, lda, ldb, ldc, 1, st);
   if (tile > 2) tile = 1;
-  // float4 granularity along the contiguous dimension of every operand and of C
-  if ((lda & 3) || (ldb & 3) || (ldc & 3) || (N & 3) || ((a_kmajor ? M : K) & 3) || ((b_kmajor ? N : K) & 3)) return (int)hipErrorInvalidValue;
-  if (splitk > 1 && (ws == nullptr || bias != nullptr || add != nullptr || ldc != N)) return (int)hipErrorInvalidValue;
+  // float4 granularity along the contiguous dimension of an operand / of C, or the element-wise slow path for it
+  // (fc1 of the recognition network has 50 columns)
+  auto odd = [](const void* p, int ld, int extent) { return ((uintptr_t)p & 15) != 0 || (ld & 3) != 0 || (extent & 3) != 0; };
+  const int scalar_bits = (odd(A, lda, a_kmajor ? M : K) ? 1 : 0) | (odd(B, ldb, b_kmajor ? N : K) ? 2 : 0) |
+                          ((odd(C, ldc, N) || (bias != nullptr && ((uintptr_t)bias & 15)) || (add != nullptr && ((uintptr_t)add & 15))) ? 4 : 0);
+  if (splitk > 1 && (ws == nullptr || bias != nullptr || add != nullptr || ldc != N || (scalar_bits & 4))) return (int)hipErrorInvalidValue;
+  if (scalar_bits & 2) return (int)hipErrorInvalidValue;           // B has to be float4-addressable
   float* out = splitk > 1 ? ws : C;
   const int ldo = splitk > 1 ? N : ldc;
   if (tile == 0) tile = 1;
   int rc;
+  if (scalar_bits & 1) {        // element-wise A: the two layouts fc1's backward needs (d_a1 W1 and d_a1^T h), 128 x 128 tile
+    if (!b_kmajor) return (int)hipErrorInvalidValue;
+    if (a_kmajor) rc = nsplit == 2 ? gemm_launch<true, true, 2, 128, 128, 0, true>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits)
+                                   : gemm_launch<true, true, 1, 128, 128, 0, true>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits);
+    else rc = nsplit == 2 ? gemm_launch<false, true, 2, 128, 128, 0, true>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits)
+                          : gemm_launch<false, true, 1, 128, 128, 0, true>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits);
+  } else {
 #define STOVE_GEMM_TILE(AK, BK_, NS)                                                                                \
-  rc = tile == 1 ? gemm_launch<AK, BK_, NS, 256, 128>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st)           \
-                 : gemm_launch<AK, BK_, NS, 128, 128>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st)
+  rc = tile == 1 ? gemm_launch<AK, BK_, NS, 256, 128>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits)           \
+                 : gemm_launch<AK, BK_, NS, 128, 128>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits)
 #define STOVE_GEMM_CASE(AK, BK_)             \
   do {                                       \
     if (nsplit == 2) {                       \
@@ -633,6 +644,7 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
   else if (!a_kmajor && b_kmajor) STOVE_GEMM_CASE(false, true);
   else if (a_kmajor && b_kmajor) STOVE_GEMM_CASE(true, true);
   else STOVE_GEMM_CASE(true, false);
+  }
 #undef STOVE_GEMM_CASE
 #undef STOVE_GEMM_TILE
   if (rc) return rc;

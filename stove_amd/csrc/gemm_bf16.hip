@@ -60,16 +60,20 @@ __device__ __forceinline__ void split4(const float4 v, u32x2& hi, u32x2& lo) {
 
 // Where one thread's NLD float4 pieces of an operand tile (ROWS x 32) come from: a running pointer per piece, advanced by one
 // k-step per tile, plus the piece's k offset inside the tile and whether its rows exist (edge tiles).
-template <int ROWS, bool KMAJOR, int THREADS>
+template <int ROWS, bool KMAJOR, int THREADS, bool SCALAR = false>
 struct TileSrc {
   static constexpr int NLD = ROWS * kGemmBK / 4 / THREADS;
   const float* p[NLD];
   const float* safe;
   int kloc[NLD];
   unsigned rowmask;
+  unsigned rowsleft;     // scalar mode, K-major: 3 bits per piece = how many of its 4 rows exist
+  // SCALAR: the operand is not float4-addressable (odd leading dimension / extent, e.g. fc1's 50 columns): every element is
+  // loaded and predicated on its own (a compile-time variant, so that the vector path keeps its branch-free loads)
   size_t step;
   __device__ __forceinline__ void init(const float* __restrict__ P, int ld, int row0, int n_rows, int k_begin, int tid) {
     rowmask = 0u;
+    rowsleft = 0u;
     safe = P;
     step = KMAJOR ? (size_t)kGemmBK * ld : (size_t)kGemmBK;
 #pragma unroll
@@ -86,26 +90,38 @@ struct TileSrc {
       const int k = k_begin + kloc[j];
       p[j] = KMAJOR ? P + (size_t)k * ld + row : P + (size_t)row * ld + k;
       rowmask |= row < n_rows ? (1u << j) : 0u;
+      const int left = n_rows - row;
+      rowsleft |= (unsigned)(left < 0 ? 0 : (left > 4 ? 4 : left)) << (3 * j);
     }
   }
 };
 
 // one staged operand tile: NLD float4 per thread
-template <int ROWS, bool KMAJOR, int THREADS>
+template <int ROWS, bool KMAJOR, int THREADS, bool SCALAR = false>
 struct TileLoad {
   static constexpr int NLD = ROWS * kGemmBK / 4 / THREADS;
   float4 v[NLD];
   unsigned okmask;      // bit j: piece j is inside the operand (the zeroing of edge pieces is deferred to store_piece: a
                         // select right behind the load would make the wave wait for it at once)
   // loads the tile whose first k is `k0` and advances the source by one k-step
-  __device__ __forceinline__ void load(TileSrc<ROWS, KMAJOR, THREADS>& src, int k0, int k_end) {
+  __device__ __forceinline__ void load(TileSrc<ROWS, KMAJOR, THREADS, SCALAR>& src, int k0, int k_end) {
     okmask = 0u;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       // branch-free edge predication: out-of-range pieces read the operand's first float4 (always valid) and are zeroed later
       const bool ok = ((src.rowmask >> j) & 1u) && (k0 + src.kloc[j] < k_end);
-      v[j] = *reinterpret_cast<const float4*>(ok ? src.p[j] : src.safe);
-      okmask |= ok ? (1u << j) : 0u;
+      if constexpr (!SCALAR) {
+        v[j] = *reinterpret_cast<const float4*>(ok ? src.p[j] : src.safe);
+        okmask |= ok ? (1u << j) : 0u;
+      } else {
+        // element-wise: along k (K-contiguous: the K tail) or along the rows (K-major: the row tail)
+        const int n_ok = !ok ? 0 : (KMAJOR ? (int)((src.rowsleft >> (3 * j)) & 7u) : (k_end - (k0 + src.kloc[j]) > 4 ? 4 : k_end - (k0 + src.kloc[j])));
+        float e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = q < n_ok ? src.p[j][q] : 0.0f;
+        v[j] = float4{e[0], e[1], e[2], e[3]};
+        okmask |= 1u << j;
+      }
       src.p[j] += src.step;
     }
   }
@@ -151,10 +167,12 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int r0, int lane) {
   }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT, int BM, int BN, int DEBUG = 0>      // DEBUG (tools only): 1 = no loads in the loop, 2 = no MFMAs
+// DEBUG (tools only): 1 = no loads in the loop, 2 = no MFMAs.  A_SCALAR: A is read element-wise (see TileSrc); bit 2 of `scalar_bits`
+// (run time): C / bias / add are written and read element-wise.
+template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT, int BM, int BN, int DEBUG = 0, bool A_SCALAR = false>
 __global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                                                const float* __restrict__ add, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
-                                                               int tiles_m, int tiles_n, int splitk, int k_per_slice) {
+                                                               int tiles_m, int tiles_n, int splitk, int k_per_slice, int scalar_bits) {
   extern __shared__ __attribute__((aligned(16))) char gemm_lds[];
   constexpr int kGemmBM = BM, kGemmBN = BN, THREADS = BM * BN / 64;      // one wave per 64 x 64 of the tile
   constexpr int kGemmAPart = gemm_part_bytes(BM), kGemmBPart = gemm_part_bytes(BN);
@@ -186,9 +204,9 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restr
   // tile t+2 are issued at the top of step t and consumed in step t+1 (a whole k-step of MFMAs later); the pieces of tile t+1
   // are converted and written into the other LDS buffer BETWEEN the MFMA groups of step t, so the matrix pipe never waits for
   // the staging of the same wave.  One barrier per k-step.
-  TileLoad<kGemmBM, A_KMAJOR, THREADS> la0, la1;
+  TileLoad<kGemmBM, A_KMAJOR, THREADS, A_SCALAR> la0, la1;
   TileLoad<kGemmBN, B_KMAJOR, THREADS> lb0, lb1;
-  TileSrc<kGemmBM, A_KMAJOR, THREADS> sa;
+  TileSrc<kGemmBM, A_KMAJOR, THREADS, A_SCALAR> sa;
   TileSrc<kGemmBN, B_KMAJOR, THREADS> sb;
   sa.init(A, lda, m0, M, k_begin, tid);
   sb.init(B, ldb, n0, N, k_begin, tid);
@@ -259,15 +277,27 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restr
       const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
       if (m < M && n < N) {
         f32x4 v = acc[i][j];
-        if (bias != nullptr && splitk == 1) {
-          const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
-          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        if (!(scalar_bits & 4)) {
+          if (bias != nullptr && splitk == 1) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          }
+          if (add != nullptr && splitk == 1) {
+            const float4 d4 = *reinterpret_cast<const float4*>(add + (size_t)m * ldc + n);
+            v.x += d4.x; v.y += d4.y; v.z += d4.z; v.w += d4.w;
+          }
+          *reinterpret_cast<f32x4*>(out + (size_t)m * ldc + n) = v;
+        } else {        // N or ldc not a multiple of 4: element-wise epilogue
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e < N) {
+              float t = v[e];
+              if (bias != nullptr && splitk == 1) t += bias[n + e];
+              if (add != nullptr && splitk == 1) t += add[(size_t)m * ldc + n + e];
+              out[(size_t)m * ldc + n + e] = t;
+            }
+          }
         }
-        if (add != nullptr && splitk == 1) {
-          const float4 d4 = *reinterpret_cast<const float4*>(add + (size_t)m * ldc + n);
-          v.x += d4.x; v.y += d4.y; v.z += d4.z; v.w += d4.w;
-        }
-        *reinterpret_cast<f32x4*>(out + (size_t)m * ldc + n) = v;
       }
     }
   }
@@ -276,16 +306,16 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restr
 // LDS bytes of the kernel
 constexpr int gemm_lds_bytes(int nsplit, int bm, int bn) { return 2 * nsplit * (gemm_part_bytes(bm) + gemm_part_bytes(bn)); }
 
-template <bool AK, bool BK_, int NS, int BM = 256, int BN = 128, int DEBUG = 0>
+template <bool AK, bool BK_, int NS, int BM = 256, int BN = 128, int DEBUG = 0, bool A_SCALAR = false>
 static int gemm_launch(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                       int splitk, hipStream_t st) {
+                       int splitk, hipStream_t st, int scalar_bits = 0) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   int kper = ((K + splitk - 1) / splitk + kGemmBK - 1) / kGemmBK * kGemmBK;
-  const void* fn = (const void*)gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG>;
+  const void* fn = (const void*)gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR>;
   int rc = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(NS, BM, BN));
   if (rc) return rc;
-  STOVE_LAUNCH((gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG>), dim3(tiles_m * tiles_n * splitk), dim3(BM * BN / 64), gemm_lds_bytes(NS, BM, BN), st, A, B, bias, add, C,
-               M, N, K, lda, ldb, ldc, tiles_m, tiles_n, splitk, kper);
+  STOVE_LAUNCH((gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR>), dim3(tiles_m * tiles_n * splitk), dim3(BM * BN / 64), gemm_lds_bytes(NS, BM, BN), st, A, B, bias, add, C,
+               M, N, K, lda, ldb, ldc, tiles_m, tiles_n, splitk, kper, scalar_bits);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -655,13 +655,19 @@ def linear(x, weight, bias):
 
 class _EncoderHeadFn(torch.autograd.Function):
     """fc2(sigmoid(fc1(h))) of the recognition network (reference encoder.py:53-56) on (rows, 256) LSTM outputs: fc1 and its
-    two gradient products are library GEMMs, everything behind fc1 is one HIP pass each way (csrc/lstm.hip head_*_k)."""
+    two gradient products are GEMMs (the MFMA GEMM of csrc/gemm_bf16.hip, whose element-wise operand path takes fc1's 50
+    columns; `gemm` = 'fp32' uses the library), everything behind fc1 is one HIP pass each way (csrc/lstm.hip head_*_k)."""
 
     @staticmethod
-    def forward(ctx, h, w1, b1, w2, b2):
+    def forward(ctx, h, w1, b1, w2, b2, gemm):
         lib = _lib.load()
         rows, H1, OUT = h.shape[0], w1.shape[0], w2.shape[0]
-        a1 = torch.addmm(b1, h, w1.t())
+        ctx.ns = {'bf16x3': 2, 'bf16': 1, 'fp32': 0}[gemm]
+        if ctx.ns and h.shape[1] % 4 == 0:
+            a1 = gemm_bf16(h, w1, bias=b1, nsplit=ctx.ns, tile=2)
+        else:
+            ctx.ns = 0
+            a1 = torch.addmm(b1, h, w1.t())
         h1 = torch.empty_like(a1)
         codes = torch.empty(rows, OUT, dtype=torch.float32, device=h.device)
         with torch.cuda.device(h.device):
@@ -680,17 +686,24 @@ class _EncoderHeadFn(torch.autograd.Function):
         with torch.cuda.device(h.device):
             ws = torch.empty(lib.stove_head_bwd_ws_floats(rows, H1, OUT), dtype=torch.float32, device=h.device)
             check(lib.stove_head_bwd(ptr(g), ptr(h1), ptr(w2), ptr(d_a1), ptr(small), ptr(ws), rows, H1, OUT, stream()), 'stove_head_bwd')
-        gh = torch.mm(d_a1, w1) if ctx.needs_input_grad[0] else None
-        gw1 = _splitk_tn(d_a1, h) if ctx.needs_input_grad[1] else None
-        return gh, gw1, small[OUT * H1:OUT * H1 + H1], small[:OUT * H1].view(OUT, H1), small[OUT * H1 + H1:]
+        gh = gw1 = None
+        if ctx.ns:
+            if ctx.needs_input_grad[0]:
+                gh = gemm_bf16(d_a1, w1, b_kmajor=True, nsplit=ctx.ns, splitk=1, tile=2)
+            if ctx.needs_input_grad[1]:
+                gw1 = gemm_bf16(d_a1, h, a_kmajor=True, b_kmajor=True, nsplit=ctx.ns, tile=2)
+        else:
+            gh = torch.mm(d_a1, w1) if ctx.needs_input_grad[0] else None
+            gw1 = _splitk_tn(d_a1, h) if ctx.needs_input_grad[1] else None
+        return gh, gw1, small[OUT * H1:OUT * H1 + H1], small[:OUT * H1].view(OUT, H1), small[OUT * H1 + H1:], None
 
 
-def encoder_head(h, w1, b1, w2, b2):
-    """(..., 256) -> (..., 8): fc2(sigmoid(fc1(h)))."""
+def encoder_head(h, w1, b1, w2, b2, gemm='bf16x3'):
+    """(..., 256) -> (..., 8): fc2(sigmoid(fc1(h))).  gemm: 'bf16x3' | 'bf16' | 'fp32' for the fc1 products (see encoder_lstm)."""
     shape = h.shape
     if w1.shape[0] > 64 or w2.shape[0] > 8:
         return linear(torch.sigmoid(linear(h, w1, b1)), w2, b2)
-    out = _EncoderHeadFn.apply(_f32(h.reshape(-1, shape[-1])), _f32(w1), _f32(b1), _f32(w2), _f32(b2))
+    out = _EncoderHeadFn.apply(_f32(h.reshape(-1, shape[-1])), _f32(w1), _f32(b1), _f32(w2), _f32(b2), gemm)
     return out.view(*shape[:-1], w2.shape[0])
 
 
@@ -767,7 +780,7 @@ class _EncoderLstmFn(torch.autograd.Function):
             for k in range(num_steps):
                 gs = gx
                 if k > 0 and ns:
-                    gs = gemm_bf16(hs[k - 1], w_hh, nsplit=ns, splitk=1, add=gx)
+                    gs = gemm_bf16(hs[k - 1], w_hh, nsplit=ns, splitk=1, add=gx, tile=2)      # K = 256: the 128 x 128 tile (8 k-steps, 1600 workgroups) wins
                 elif k > 0:
                     with _blas('hipblas'):
                         gs = torch.addmm(gx, hs[k - 1], w_hh.t())

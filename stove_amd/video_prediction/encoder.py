@@ -33,8 +33,9 @@ class RnnStates(nn.Module):
         """frames (-1, c, w, h) -> (-1, num_obj, 8): per-object (mean, std) codes of [sx, sy/sx, x, y]."""
         x = frames.flatten(start_dim=1)
         rnn = self.rnn
+        gemm = getattr(self.c, 'encoder_gemm', 'bf16x3')
         hs = ops.encoder_lstm(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, self.c.num_obj,
-                              time_major=True, gemm=getattr(self.c, 'encoder_gemm', 'bf16x3'))     # (num_obj, n, 256), as the LSTM kernels write it
+                              time_major=True, gemm=gemm)     # (num_obj, n, 256), as the LSTM kernels write it
         fc1, fc2 = self.fc1, self.fc2
-        codes = ops.encoder_head(hs, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+        codes = ops.encoder_head(hs, fc1.weight, fc1.bias, fc2.weight, fc2.bias, gemm=gemm)
         return codes.transpose(0, 1)                                 # (n, num_obj, 8): only the small output is permuted

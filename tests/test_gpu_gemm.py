@@ -64,3 +64,41 @@ def test_gemm_encoder_shapes_accuracy():
     ref = dg.double().t() @ x.double()
     got = ops.gemm_bf16(dg, x, None, True, True, 2, 8).double()
     assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+def test_gemm_unaligned_fc1_shapes():
+    """fc1 of the recognition network has 50 columns (reference encoder.py:25): C with N = ldc = 50 (element-wise epilogue
+    with bias), A with lda = K = 50 and A^T with M = ld = 50 (element-wise operand loads), also on exact integers and with
+    an 8-byte-aligned base pointer."""
+    from stove_amd import ops
+    g = torch.Generator().manual_seed(5)
+    rows = 3 * 700 + 1
+    h = torch.randn(rows, 256, generator=g).to(DEV)
+    w1 = torch.randn(50, 256, generator=g).to(DEV)
+    b1 = torch.randn(50, generator=g).to(DEV)
+    d = torch.randn(rows, 50, generator=g).to(DEV)
+    for nsplit, tol in ((2, 1.5e-5), (1, 2e-2)):
+        for tile in (1, 2):
+            a1 = ops.gemm_bf16(h, w1, bias=b1, nsplit=nsplit, tile=tile)
+            ref = h.double() @ w1.double().t() + b1.double()
+            assert a1.shape == (rows, 50) and float((a1.double() - ref).abs().max() / ref.abs().max()) < tol
+        gh = ops.gemm_bf16(d, w1, b_kmajor=True, nsplit=nsplit, splitk=1, tile=2)
+        ref = d.double() @ w1.double()
+        assert float((gh.double() - ref).abs().max() / ref.abs().max()) < tol
+        for splitk in (1, 4, None):
+            gw = ops.gemm_bf16(d, h, a_kmajor=True, b_kmajor=True, nsplit=nsplit, splitk=splitk, tile=2)
+            ref = d.double().t() @ h.double()
+            assert gw.shape == (50, 256) and float((gw.double() - ref).abs().max() / ref.abs().max()) < tol
+    # exact integers through the element-wise loads, base pointer off the 16-byte grid
+    m, k, n = torch.arange(131).view(-1, 1), torch.arange(50).view(1, -1), torch.arange(256).view(-1, 1)
+    a = ((m * 3 + k * 5) % 17 - 8).float()
+    b = ((n * 7 + k * 11 + (n * k) % 5) % 13 - 6).float()
+    buf = torch.zeros(a.numel() + 2, device=DEV)
+    a_off = buf[2:].view(131, 50)
+    a_off.copy_(a)
+    c = ops.gemm_bf16(a_off, b.t().contiguous().to(DEV), b_kmajor=True, nsplit=2, splitk=1, tile=2)
+    assert torch.equal(c.cpu(), a @ b.t())
+    at = torch.zeros(50 * 131 + 2, device=DEV)[2:].view(50, 131)
+    at.copy_(a.t())
+    c = ops.gemm_bf16(at, b.t().contiguous().to(DEV), a_kmajor=True, b_kmajor=True, nsplit=1, splitk=1, tile=2)
+    assert torch.equal(c.cpu(), a @ b.t())
