@@ -257,7 +257,7 @@ def main():
             name, (total_ms, count) = max(prof.items(), key=lambda kv: kv[1][0])
             n_obj = cfg.num_obj
             avg_ms = total_ms / count
-            per_step = {k: round(v[0] / a.profile_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:14]}
+            per_step = {k: round(v[0] / a.profile_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:24]}
             if name.startswith('gemm_bf16'):
                 # recognition-network GEMMs (csrc/gemm_bf16.hip), all launches of a step together (they differ in shape):
                 # algorithmic flops = 2 M N K of the fp32 products -- x W_ih^T, (N-1) x h W_hh^T forward; (N-1) x dg W_hh,

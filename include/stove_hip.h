@@ -313,6 +313,18 @@ size_t stove_head_bwd_ws_floats(int rows, int H1, int OUT);
 int stove_head_bwd(const float* dcodes, const float* h1, const float* W2, float* d_a1, float* g_w2b1b2, float* ws, int rows, int H1,
                    int OUT, void* stream);
 
+/* ---- the whole output head of RnnStates in one kernel each way (encoder.py:53-56), csrc/head_fused.hip: fc1, sigmoid and fc2 on the
+ * fp32 matrix-core instructions (fp32 operands and accumulation, nothing is rounded below fp32); H must be 256, HID <= 64, OUT 8.
+ * fwd: h (rows, H) -> h1 = sigmoid(h W1^T + b1) (rows, HID) and codes (rows, OUT) = h1 W2^T + b2; W1 (HID, H), W2 (OUT, HID).
+ * bwd: dcodes (rows, OUT), h1, h -> gh (rows, H) = dL/dh and grads = [dW1 (HID*H) | dW2 (OUT*HID) | db1 (HID) | db2 (OUT) | pad]
+ * (stove_enc_head_grad_floats(HID) floats); ws: stove_enc_head_bwd_ws_floats floats.  Fixed summation order. */
+int stove_enc_head_fwd(const float* h, const float* W1, const float* b1, const float* W2, const float* b2, float* h1, float* codes, int rows,
+                       int H, int HID, int OUT, void* stream);
+size_t stove_enc_head_bwd_ws_floats(int rows, int HID);
+int stove_enc_head_grad_floats(int HID);
+int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, const float* W1, const float* W2, float* gh, float* grads,
+                       float* ws, int rows, int H, int HID, int OUT, void* stream);
+
 /* ---- measurement hooks (bench.py): when enabled, every kernel launch of this library is bracketed by
  * two HIP events recorded on the launch stream.  stove_profile_report() synchronises them, writes
  * "kernel\ttotal_ms\tcount\n" lines into buf and clears the records; returns the bytes needed.

@@ -18,6 +18,7 @@
 #include "arena.hip"
 #include "state.hip"
 #include "gemm_bf16.hip"
+#include "head_fused.hip"
 
 namespace stove {
 
@@ -858,6 +859,58 @@ int stove_head_bwd(const float* dcodes, const float* h1, const float* W2, float*
                dcodes, h1, W2, d_a1, ws, rows, H1, OUT);
   STOVE_LAUNCH_CHECK();
   STOVE_LAUNCH(reduce_chunks_k, dim3((n_out + 31) / 32), dim3(256), 0, st, ws, g_w2b1b2, n_out, grid, 0);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- fused output head (csrc/head_fused.hip): H = 256, HID <= 64, OUT = 8 ------------------------------------------------------
+static int enc_head_groups(int rows) {
+  const int tiles = (rows + 15) / 16;
+  int g = (tiles + 3) / 4;
+  return g < 1 ? 1 : (g > 102 ? 102 : g);       // 102 groups x 5 roles = 510 workgroups: all resident at 2 per CU (a second round of
+                                                // workgroups would start when the first ends and double the kernel's time)
+}
+
+int stove_enc_head_fwd(const float* h, const float* W1, const float* b1, const float* W2, const float* b2, float* h1, float* codes, int rows,
+                       int H, int HID, int OUT, void* stream) {
+  if (H != kEhH || HID < 1 || HID > kEhHid || OUT != kEhOut) return (int)hipErrorInvalidValue;
+  if (rows == 0) return 0;
+  const size_t lds = sizeof(float) * kEhHid * kEhLd;
+  int rc = (int)hipFuncSetAttribute((const void*)enc_head_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (rc) return rc;
+  const int tiles = (rows + 15) / 16;
+  const int grid = (tiles + 3) / 4 < 512 ? (tiles + 3) / 4 : 512;
+  STOVE_LAUNCH(enc_head_fwd_k, dim3(grid), dim3(256), lds, (hipStream_t)stream, h, W1, b1, W2, b2, h1, codes, rows, HID);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t stove_enc_head_bwd_ws_floats(int rows, int HID) { return (size_t)enc_head_groups(rows) * eh_part_floats(HID); }
+int stove_enc_head_grad_floats(int HID) { return eh_part_floats(HID); }
+
+int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, const float* W1, const float* W2, float* gh, float* grads,
+                       float* ws, int rows, int H, int HID, int OUT, void* stream) {
+  if (H != kEhH || HID < 1 || HID > kEhHid || OUT != kEhOut) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const int P = eh_part_floats(HID);
+  if (rows == 0) {
+    hipMemsetAsync(grads, 0, sizeof(float) * P, st);
+    return 0;
+  }
+  const int groups = enc_head_groups(rows);
+  const size_t lds = sizeof(float) * kEhBwdLds;
+  int rc;
+  if (HID <= 50) {
+    rc = (int)hipFuncSetAttribute((const void*)enc_head_bwd_k<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc) return rc;
+    STOVE_LAUNCH(enc_head_bwd_k<14>, dim3(groups * 5), dim3(256), lds, st, dcodes, h1, h, W1, W2, gh, ws, rows, HID, groups);
+  } else {
+    rc = (int)hipFuncSetAttribute((const void*)enc_head_bwd_k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc) return rc;
+    STOVE_LAUNCH(enc_head_bwd_k<16>, dim3(groups * 5), dim3(256), lds, st, dcodes, h1, h, W1, W2, gh, ws, rows, HID, groups);
+  }
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH(reduce_chunks_k, dim3((P + 31) / 32), dim3(256), 0, st, (const float*)ws, grads, P, groups, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -285,8 +285,18 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
   const int fstep = gridDim.x / kBgHalves;
   const int f0 = blockIdx.x / kBgHalves;
   float xn = 0.0f, fxn[NMAX], fyn[NMAX];
+  // this lane's leaf gradients of the next frame (per replica the side its pixel belongs to): R * G vector loads that were
+  // issued at the top of the iteration that uses them -- the pass over the frame waited for them
+  float den[R][G];
+  const float* de_lane[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) de_lane[r] = dell + (sd[r] ? (r * 2 + 1) * G : (r * 2) * G);
   auto prefetch = [&](int f) {
     xn = frames[fm.row(f) * kBgPix + p];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int g = 0; g < G; ++g) den[r][g] = de_lane[r][(size_t)f * NO + g];
     if (SCENE) {
 #pragma unroll
       for (int k = 0; k < NMAX; ++k) {
@@ -357,6 +367,11 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
       fx[k] = fxn[k];
       fy[k] = fyn[k];
     }
+    float dcur[R][G];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int g = 0; g < G; ++g) dcur[r][g] = den[r][g];
     if (f + fstep < n_frames) prefetch(f + fstep);
     bool pass = true;
     if (SCENE) {
@@ -381,14 +396,13 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
       }
     }
     const float wx = w * x, wxx = wx * x, x2 = x * x;
-    const float* de = dell + (size_t)f * NO;
     float dwr[R], dx = 0.0f;      // one partial sum per replica: R short dependent FMA chains instead of one of R * G links
 #pragma unroll                    // (0.30 -> 0.23 ms: at two waves per SIMD the serial chain was what each frame waited for)
     for (int r = 0; r < R; ++r) {
       dwr[r] = 0.0f;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const float d = sd[r] ? de[(r * 2 + 1) * G + g] : de[(r * 2) * G + g];
+        const float d = dcur[r][g];
         dwr[r] = fmaf(d, fmaf(cf[r][g][0], x2, fmaf(cf[r][g][1], x, cf[r][g][2])), dwr[r]);
         if (!SCENE) dx = fmaf(d, fmaf(cf[r][g][0], x + x, cf[r][g][1]), dx);
         gc[r][g][0] = fmaf(d, wxx, gc[r][g][0]);

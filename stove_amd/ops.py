@@ -698,11 +698,46 @@ class _EncoderHeadFn(torch.autograd.Function):
         return gh, gw1, small[OUT * H1:OUT * H1 + H1], small[:OUT * H1].view(OUT, H1), small[OUT * H1 + H1:], None
 
 
+class _EncoderHeadFusedFn(torch.autograd.Function):
+    """The same head as ONE kernel each way (csrc/head_fused.hip): fc1, sigmoid and fc2 chained on the fp32 matrix-core
+    instructions, h read once; the backward returns dL/dh and all four parameter gradients.  H = 256, HID <= 64, OUT = 8."""
+
+    @staticmethod
+    def forward(ctx, h, w1, b1, w2, b2):
+        lib = _lib.load()
+        rows, H, HID, OUT = h.shape[0], h.shape[1], w1.shape[0], w2.shape[0]
+        h1 = torch.empty(rows, HID, dtype=torch.float32, device=h.device)
+        codes = torch.empty(rows, OUT, dtype=torch.float32, device=h.device)
+        with torch.cuda.device(h.device):
+            check(lib.stove_enc_head_fwd(ptr(h), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(h1), ptr(codes), rows, H, HID, OUT, stream()),
+                  'stove_enc_head_fwd')
+        ctx.save_for_backward(h, w1, w2, h1)
+        return codes
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        h, w1, w2, h1 = ctx.saved_tensors
+        rows, H, HID, OUT = h.shape[0], h.shape[1], w1.shape[0], w2.shape[0]
+        g = _f32(g)
+        gh = torch.empty_like(h)
+        grads = torch.empty(lib.stove_enc_head_grad_floats(HID), dtype=torch.float32, device=h.device)
+        with torch.cuda.device(h.device):
+            ws = torch.empty(lib.stove_enc_head_bwd_ws_floats(rows, HID), dtype=torch.float32, device=h.device)
+            check(lib.stove_enc_head_bwd(ptr(g), ptr(h1), ptr(h), ptr(w1), ptr(w2), ptr(gh), ptr(grads), ptr(ws), rows, H, HID, OUT,
+                                         stream()), 'stove_enc_head_bwd')
+        o1, o2, o3 = HID * H, HID * H + OUT * HID, HID * H + OUT * HID + HID
+        return gh, grads[:o1].view(HID, H), grads[o2:o3], grads[o1:o2].view(OUT, HID), grads[o3:o3 + OUT]
+
+
 def encoder_head(h, w1, b1, w2, b2, gemm='bf16x3'):
     """(..., 256) -> (..., 8): fc2(sigmoid(fc1(h))).  gemm: 'bf16x3' | 'bf16' | 'fp32' for the fc1 products (see encoder_lstm)."""
     shape = h.shape
     if w1.shape[0] > 64 or w2.shape[0] > 8:
         return linear(torch.sigmoid(linear(h, w1, b1)), w2, b2)
+    if gemm != 'fp32' and shape[-1] == 256 and w2.shape[0] == 8:       # the fused head; 'fp32' keeps the library GEMMs + head_*_k pair
+        out = _EncoderHeadFusedFn.apply(_f32(h.reshape(-1, shape[-1])), _f32(w1), _f32(b1), _f32(w2), _f32(b2))
+        return out.view(*shape[:-1], w2.shape[0])
     out = _EncoderHeadFn.apply(_f32(h.reshape(-1, shape[-1])), _f32(w1), _f32(b1), _f32(w2), _f32(b2), gemm)
     return out.view(*shape[:-1], w2.shape[0])
 

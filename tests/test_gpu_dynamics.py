@@ -445,9 +445,12 @@ def test_object_embedding_kernel_against_grid_sample():
     assert err(got, want) < 1e-5
 
 
-@pytest.mark.parametrize('rows,H1,OUT', [(111, 50, 8), (1, 50, 8), (64, 50, 8), (65, 64, 8), (3 * 25600, 50, 8), (200, 7, 3), (0, 50, 8)])
-def test_encoder_head_kernels(rows, H1, OUT):
-    """fc2(sigmoid(fc1(h))) (reference encoder.py:53-56): fused head pass vs the op-by-op chain in float64."""
+@pytest.mark.parametrize('gemm', ['bf16x3', 'fp32'])
+@pytest.mark.parametrize('rows,H1,OUT', [(111, 50, 8), (1, 50, 8), (64, 50, 8), (65, 64, 8), (3 * 25600, 50, 8), (200, 7, 3), (0, 50, 8),
+                                         (16 * 513 + 5, 49, 8), (40, 17, 8)])
+def test_encoder_head_kernels(rows, H1, OUT, gemm):
+    """fc2(sigmoid(fc1(h))) (reference encoder.py:53-56) vs the op-by-op chain in float64: the one-kernel head of
+    csrc/head_fused.hip (default; OUT = 8) and the library-GEMM + head_*_k pair (gemm='fp32', and any other OUT)."""
     from stove_amd import ops
     g = torch.Generator().manual_seed(rows + H1)
     h = torch.randn(rows, 256, generator=g, dtype=torch.float64)
@@ -460,7 +463,7 @@ def test_encoder_head_kernels(rows, H1, OUT):
     ref = torch.nn.functional.linear(torch.sigmoid(torch.nn.functional.linear(ref_in[0], ref_in[1], ref_in[2])), ref_in[3], ref_in[4])
     (ref * wout).sum().backward()
     dev_in = [t.float().to(DEV).requires_grad_() for t in (h, w1, b1, w2, b2)]
-    out = ops.encoder_head(*dev_in)
+    out = ops.encoder_head(*dev_in, gemm=gemm)
     assert out.shape == (rows, OUT)
     if rows == 0:
         return
@@ -470,7 +473,7 @@ def test_encoder_head_kernels(rows, H1, OUT):
         assert err(a.grad, b.grad) < (2e-4 if rows > 10000 else 2e-5), name
     # fixed summation order: bitwise reproducible
     again = [t.detach().clone().requires_grad_() for t in dev_in]
-    (ops.encoder_head(*again) * wout.float().to(DEV)).sum().backward()
+    (ops.encoder_head(*again, gemm=gemm) * wout.float().to(DEV)).sum().backward()
     for a, b in zip(dev_in, again):
         assert torch.equal(a.grad, b.grad)
 
