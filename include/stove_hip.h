@@ -192,7 +192,8 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
 /* ---- Stove._3_only_match_objects / _greedy_match_objects / _volatile_match_objects
  * (stove.py:200-329, 432-514, 331-430): the T-serial nearest-neighbour re-ordering of objects.
  * feat (B,T,N,F) matching features in [-1,1] (positions [, appearance]); mode 0 = '3_only',
- * 1 = 'greedy', 2 = 'volatile'.  idx (B,T,N) int64: current object assigned to slot a.
+ * 1 = 'greedy', 2 = 'volatile', 3 = '3_only' forced through the frame-by-frame walk (the three-object '3_only' case
+ * normally runs as a composition of per-frame transition tables, same indices).  idx (B,T,N) int64: current object assigned to slot a.
  * perm (B,T,N,N) f32, pre-zeroed, only written in mode 2 (may be NULL otherwise). */
 int stove_match_objects(const float* feat, long long* idx, float* perm, int B, int T, int N, int F, int mode, void* stream);
 

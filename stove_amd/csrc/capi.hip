@@ -979,13 +979,19 @@ size_t stove_profile_report(char* buf, size_t cap) {
 // ---------------------------------------------------------------- temporal object matching
 int stove_match_objects(const float* feat, long long* idx, float* perm, int B, int T, int N, int F, int mode, void* stream) {
   if (B == 0 || T == 0) return 0;
-  if (N < 1 || N > kMatchN || F < 1 || F > kMatchF || mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
+  if (N < 1 || N > kMatchN || F < 1 || F > kMatchF || mode < 0 || mode > 3) return (int)hipErrorInvalidValue;
+  const bool serial = mode == 3;       // '3_only' through the frame-by-frame walk (the check of match3_table_k in the tests)
+  if (serial) mode = 0;
   const size_t lds = (size_t)T * N * (F + 1) * sizeof(float);
   if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   // the lane-parallel kernel wins where the serial walk of lane 0 has real work per frame (the greedy matcher, more than
   // three objects: 580 -> 170 us for six); for three objects and the nearest-slot rules the serial walk is shorter
-  if (mode == 1 || N > 3)
+  if (!serial && mode == 0 && N == 3 && F == 2)
+    STOVE_LAUNCH((match3_table_k<2>), dim3(B), dim3(64), lds, st, feat, idx, B, T);
+  else if (!serial && mode == 0 && N == 3 && F == 5)
+    STOVE_LAUNCH((match3_table_k<5>), dim3(B), dim3(64), lds, st, feat, idx, B, T);
+  else if (mode == 1 || N > 3)
     STOVE_LAUNCH(match_objects_par_k, dim3(B), dim3(64), lds, st, feat, idx, B, T, N, F, mode);
   else if (N == 3 && F == 2)
     STOVE_LAUNCH((match_objects_k<3, 2>), dim3(B), dim3(64), lds, st, feat, idx, perm, B, T, N, F, mode);

@@ -203,4 +203,134 @@ __global__ __launch_bounds__(64) void match_objects_par_k(const float* __restric
   for (int i = lane; i < T * N; i += 64) idx_out[(size_t)b * T * N + i] = ibuf[i];
 }
 
+// ---- three objects, '3_only': the walk through time as a composition of per-frame transition tables -------------------
+// The slot contents before frame t are the objects of frame t-1 under one of the 6 permutations P of (0, 1, 2), and the
+// distances the matcher looks at are D_t[P(a)][j] with D_t[i][j] = |x_{t-1,i} - x_{t,j}|^2 on the RAW object order -- a
+// table every frame can form on its own.  So a lane takes a chunk of consecutive frames, runs the reference's rule
+// (nearest object per slot; on a collision the slots pick greedily in slot order with column knock-out, stove.py:273-301)
+// from each of the 6 possible incoming permutations, and gets its chunk's transition map (6 entries); the maps are
+// composed across the lanes by a log-step scan, every lane then knows the permutation it starts from and replays its
+// chunk once to emit idx.  Same float operations on the same values as the serial walk (bit-identical indices), but the
+// 99 dependent frame steps of lane 0 (65 us at T = 100) become ~2 steps per lane.
+struct Perm3 {
+  int p0, p1, p2;
+};
+__device__ __forceinline__ Perm3 perm3_of(int k) {
+  Perm3 r;
+  r.p0 = k >> 1;
+  const int lo = r.p0 == 0 ? 1 : 0, hi = r.p0 == 2 ? 1 : 2;
+  r.p1 = (k & 1) ? hi : lo;
+  r.p2 = (k & 1) ? lo : hi;
+  return r;
+}
+__device__ __forceinline__ int perm3_id(const Perm3& p) { return 2 * p.p0 + (p.p1 > p.p2 ? 1 : 0); }
+__device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
+// one frame: slots hold raw objects (p0, p1, p2) of the previous frame -> raw objects of this frame
+__device__ __forceinline__ Perm3 match3_step(const float (&D)[3][3], const Perm3& p) {
+  float e[3][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    e[0][j] = sel3(p.p0, D[0][j], D[1][j], D[2][j]);
+    e[1][j] = sel3(p.p1, D[0][j], D[1][j], D[2][j]);
+    e[2][j] = sel3(p.p2, D[0][j], D[1][j], D[2][j]);
+  }
+  int idx[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    int best = 0;
+    if (e[a][1] < e[a][best]) best = 1;
+    if (e[a][2] < sel3(best, e[a][0], e[a][1], e[a][2])) best = 2;
+    idx[a] = best;
+  }
+  if (idx[0] == idx[1] || idx[0] == idx[2] || idx[1] == idx[2]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int best = 0;
+      if (e[a][1] < e[a][0]) best = 1;
+      if (e[a][2] < sel3(best, e[a][0], e[a][1], e[a][2])) best = 2;
+      idx[a] = best;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        e[r][0] = best == 0 ? 1e12f : e[r][0];
+        e[r][1] = best == 1 ? 1e12f : e[r][1];
+        e[r][2] = best == 2 ? 1e12f : e[r][2];
+      }
+    }
+  }
+  return Perm3{idx[0], idx[1], idx[2]};
+}
+
+template <int F>
+__global__ __launch_bounds__(64) void match3_table_k(const float* __restrict__ feat, long long* __restrict__ idx_out, int B, int T) {
+  extern __shared__ float mlds[];                 // [T*3*F] features, then [T*3] int indices
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int n_feat = T * 3 * F;
+  int* ibuf = reinterpret_cast<int*>(mlds + n_feat);
+  for (int i = lane; i < n_feat; i += 64) mlds[i] = feat[(size_t)b * n_feat + i];
+  __syncthreads();
+  const int chunk = (T - 1 + 63) / 64;             // transitions t = 1 + lane * chunk .. (T - 1 of them in all)
+  const int t0 = 1 + lane * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
+  auto table = [&](int t, float (&D)[3][3]) {
+    float pv[3][F], cv[3][F];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        pv[i][f] = (mlds[((t - 1) * 3 + i) * F + f] + 1.0f) * 0.5f;
+        cv[i][f] = (mlds[(t * 3 + i) * F + f] + 1.0f) * 0.5f;
+      }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const float d = pv[i][f] - cv[j][f];
+          sacc += d * d;
+        }
+        D[i][j] = sacc;
+      }
+  };
+  // the chunk's map: entry k (3 bits) = permutation id after the chunk when entering with permutation k
+  int cur[6] = {0, 1, 2, 3, 4, 5};
+  for (int t = t0; t < t1; ++t) {
+    float D[3][3];
+    table(t, D);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cur[k] = perm3_id(match3_step(D, perm3_of(cur[k])));
+  }
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) m |= (unsigned)cur[k] << (3 * k);
+  // inclusive scan of the composition over the lanes: S_l = F_l o ... o F_0
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = (unsigned)__builtin_amdgcn_ds_bpermute(((lane - d) & 63) * 4, (int)m);
+    if (lane >= d) {
+      unsigned n = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) n |= ((m >> (3 * ((o >> (3 * k)) & 7u))) & 7u) << (3 * k);      // first the lower lanes' map, then mine
+      m = n;
+    }
+  }
+  const unsigned before = (unsigned)__builtin_amdgcn_ds_bpermute(((lane - 1) & 63) * 4, (int)m);
+  Perm3 p = perm3_of(lane == 0 ? 0 : (int)(before & 7u));        // entering with the identity at t = 0
+  if (lane == 0) {
+    ibuf[0] = 0;
+    ibuf[1] = 1;
+    ibuf[2] = 2;
+  }
+  for (int t = t0; t < t1; ++t) {
+    float D[3][3];
+    table(t, D);
+    p = match3_step(D, p);
+    ibuf[t * 3 + 0] = p.p0;
+    ibuf[t * 3 + 1] = p.p1;
+    ibuf[t * 3 + 2] = p.p2;
+  }
+  __syncthreads();
+  for (int i = lane; i < T * 3; i += 64) idx_out[(size_t)b * T * 3 + i] = ibuf[i];
+}
+
 }  // namespace stove

@@ -456,7 +456,7 @@ def rollout(z_last, extra, image, num, lim_enc, elu, consts, want_std=False, wan
     return z_pred, zstd, pred
 
 
-MATCH_MODES = {'3_only': 0, 'greedy': 1, 'volatile': 2}
+MATCH_MODES = {'3_only': 0, 'greedy': 1, 'volatile': 2, '3_only_serial': 3}
 
 
 @torch.no_grad()

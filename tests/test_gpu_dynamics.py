@@ -105,6 +105,36 @@ def test_match_3only():
     assert not np.array_equal(g['z_matched'], g['z'])
 
 
+@pytest.mark.parametrize('T', [2, 7, 100, 131])
+def test_match_3only_collisions_and_ties(T):
+    """The table-composition matcher (csrc/match.hip match3_table_k) against the oracle's frame-by-frame walk on tracks full
+    of collisions and exact ties (positions on a coarse grid, objects swapping and sitting on one another), with and
+    without appearance features: indices must agree exactly, so the matched tensors are bit-equal."""
+    from stove_amd import ops
+    from stove_amd.video_prediction.stove import Stove
+    g = torch.Generator().manual_seed(T)
+    B = 48
+    z = torch.rand(B, T, 3, 4, generator=g) * 2 - 1
+    z[..., 2:] = torch.round(z[..., 2:] * 4) / 4                   # 9 x 9 dyadic grid of positions: collisions and EXACT ties every
+                                                                   # few frames (every distance is exact in fp32 whatever the op order)
+    z[: B // 2, :, :, 2:] = torch.rand(B // 2, T, 3, 2, generator=g) * 2 - 1
+    zs = torch.rand(B, T, 3, 4, generator=g)
+    app = torch.round(torch.rand(B, T, 3, 3, generator=g) * 2) / 2
+    c, _, _ = oracle_setup(torch.float32)
+    for use_app in (False, True):
+        c.debug_match_appearance = use_app
+        zo, zso, ao = O.match_3only(c, z.clone(), zs.clone(), app.clone() if use_app else None)
+        st = Stove(make_cfg(debug_match_appearance=use_app))
+        zm, zsm, am = st._3_only_match_objects(z.to(DEV), zs.to(DEV), app.to(DEV) if use_app else None)
+        assert err(zm, zo) < 1e-6 and err(zsm, zso) < 1e-6, (T, use_app)
+        if use_app:
+            assert err(am, ao) < 1e-6
+        # and against the frame-by-frame walk of lane 0 (same arithmetic, so also on the continuous half of the batch, bit for bit)
+        feat = torch.cat([z[..., 2:4]] + ([2 * app - 1] if use_app else []), -1).to(DEV)
+        assert torch.equal(ops.match_objects(feat, '3_only')[0], ops.match_objects(feat, '3_only_serial')[0])
+    c.debug_match_appearance = False
+
+
 def test_match_greedy():
     from stove_amd.video_prediction.stove import Stove
     g = load_golden('g6_match_greedy')
