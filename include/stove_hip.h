@@ -264,6 +264,8 @@ int stove_bw_transform(const float* x, float* out, int n_frames, int channels, i
  * recognition network: 25 600 x 1024, 76 800 x 50, 76 800 x 8); ws: stove_colsum_ws_floats(rows, cols) floats.  Fixed summation order. */
 size_t stove_colsum_ws_floats(int rows, int cols);
 int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void* stream);
+/* the same with a second output receiving the same sums (b_ih and b_hh of an LSTM) and accumulate != 0: added to the outputs */
+int stove_colsum2(const float* a, float* out, float* out2, int accumulate, float* ws, int rows, int cols, void* stream);
 
 /* One Adam / AMSGrad step of torch.optim.Adam (weight_decay 0; reference train.py:46-49, 431-473) over the flat arena,
  * with clip_grad_norm_(max_norm) folded in (clip != 0: gradients are scaled by min(1, max_norm / (||grads|| + 1e-6)) on the
@@ -289,7 +291,8 @@ int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* ex
  * summed in slice order into C (needs ldc == N, bias and add NULL): fills the chip when M x N is small and K huge (weight gradients).
  * tile: workgroup tile, 0 = chosen by the library, 1 = 256 x 128 (8 waves), 2 = 128 x 128 (4 waves).
  * Operands / outputs whose leading dimension, contiguous extent or base address is not a multiple of 4 floats (fc1 of the
- * recognition network: 50 columns) are handled element-wise (slow path, meant for small operands); split-K needs an aligned C. */
+ * recognition network: 50 columns) are handled element-wise (slow path, meant for small operands); split-K needs an aligned C and
+ * takes no bias / add, except add == C: the product is accumulated into C (a gradient view). */
 size_t stove_gemm_bf16_ws_floats(int M, int N, int splitk);
 int stove_gemm_bf16(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                     int a_kmajor, int b_kmajor, int nsplit, int splitk, int tile, float* ws, void* stream);
@@ -317,14 +320,14 @@ int stove_head_bwd(const float* dcodes, const float* h1, const float* W2, float*
 /* ---- the whole output head of RnnStates in one kernel each way (encoder.py:53-56), csrc/head_fused.hip: fc1, sigmoid and fc2 on the
  * fp32 matrix-core instructions (fp32 operands and accumulation, nothing is rounded below fp32); H must be 256, HID <= 64, OUT 8.
  * fwd: h (rows, H) -> h1 = sigmoid(h W1^T + b1) (rows, HID) and codes (rows, OUT) = h1 W2^T + b2; W1 (HID, H), W2 (OUT, HID).
- * bwd: dcodes (rows, OUT), h1, h -> gh (rows, H) = dL/dh and grads = [dW1 (HID*H) | dW2 (OUT*HID) | db1 (HID) | db2 (OUT) | pad]
- * (stove_enc_head_grad_floats(HID) floats); ws: stove_enc_head_bwd_ws_floats floats.  Fixed summation order. */
+ * bwd: dcodes (rows, OUT), h1, h -> gh (rows, H) = dL/dh and the parameter gradients gW1 (HID, H), gb1 (HID), gW2 (OUT, HID),
+ * gb2 (OUT); accumulate != 0: added to what the four tensors hold (gradient views of a flat arena).  ws:
+ * stove_enc_head_bwd_ws_floats floats.  Fixed summation order. */
 int stove_enc_head_fwd(const float* h, const float* W1, const float* b1, const float* W2, const float* b2, float* h1, float* codes, int rows,
                        int H, int HID, int OUT, void* stream);
 size_t stove_enc_head_bwd_ws_floats(int rows, int HID);
-int stove_enc_head_grad_floats(int HID);
-int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, const float* W1, const float* W2, float* gh, float* grads,
-                       float* ws, int rows, int H, int HID, int OUT, void* stream);
+int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, const float* W1, const float* W2, float* gh, float* gW1,
+                       float* gb1, float* gW2, float* gb2, int accumulate, float* ws, int rows, int H, int HID, int OUT, void* stream);
 
 /* ---- measurement hooks (bench.py): when enabled, every kernel launch of this library is bracketed by
  * two HIP events recorded on the launch stream.  stove_profile_report() synchronises them, writes

@@ -22,7 +22,7 @@ import ctypes
 import torch
 import torch.distributed as dist
 
-from . import _lib
+from . import _lib, ops
 
 
 def _unique_params(module):
@@ -60,6 +60,7 @@ class ParamArena:
                 o, n = self.offset[id(p)], p.numel()
                 self.data[o:o + n].copy_(p.data.reshape(-1))
                 p.data = self.data[o:o + n].view(p.shape)
+        self._on_gpu_params = dev.type == 'cuda' and dt == torch.float32
         self._bind_grads()
         if world_size is None:
             world_size = dist.get_world_size() if dist.is_initialized() else 1
@@ -80,11 +81,15 @@ class ParamArena:
         for p in self.params:
             if not p.requires_grad:                     # frozen (Trainer.disable_supair_grad): no gradient view
                 p.grad = None
+                if self._on_gpu_params:
+                    ops.register_grad_view(p, None)
                 continue
             o, n = self.offset[id(p)], p.numel()
             g = p.grad
             if g is None or g.data_ptr() != self.grad.data_ptr() + self.grad.element_size() * o:
                 p.grad = self.grad[o:o + n].view(p.shape)
+            if self._on_gpu_params:                     # kernels that produce this parameter's gradient add it here themselves
+                ops.register_grad_view(p, p.grad)
 
     def view_of(self, p, flat=None):
         o = self.offset[id(p)]

@@ -250,10 +250,14 @@ __global__ void adam_tick_k(const unsigned char* __restrict__ trainable, float* 
 }
 
 // out[j] = sum_c part[c][j], fixed order; n4 = n / 4 (split-K partials of the batched weight-gradient GEMMs)
-__global__ void sum_chunks4_k(const float* __restrict__ part, float* __restrict__ out, int n4, int chunks) {
+__global__ void sum_chunks4_k(const float* __restrict__ part, float* __restrict__ out, int n4, int chunks, int accumulate = 0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   float4 a = reinterpret_cast<const float4*>(part)[i];
+  if (accumulate) {           // out += sum (a gradient view that may already hold a contribution)
+    const float4 o = reinterpret_cast<const float4*>(out)[i];
+    a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+  }
   for (int c = 1; c < chunks; ++c) {
     const float4 b = reinterpret_cast<const float4*>(part)[(size_t)c * n4 + i];
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;

@@ -596,7 +596,7 @@ int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void*
   if (n == 0) return 0;
   if (n % 4 != 0 || chunks < 1) return (int)hipErrorInvalidValue;
   const int n4 = (int)(n / 4);
-  STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, parts, out, n4, chunks);
+  STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, parts, out, n4, chunks, 0);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -617,6 +617,9 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
   auto odd = [](const void* p, int ld, int extent) { return ((uintptr_t)p & 15) != 0 || (ld & 3) != 0 || (extent & 3) != 0; };
   const int scalar_bits = (odd(A, lda, a_kmajor ? M : K) ? 1 : 0) | (odd(B, ldb, b_kmajor ? N : K) ? 2 : 0) |
                           ((odd(C, ldc, N) || (bias != nullptr && ((uintptr_t)bias & 15)) || (add != nullptr && ((uintptr_t)add & 15))) ? 4 : 0);
+  // split-K: no epilogue terms, except add == C (accumulate into C, e.g. a gradient view), applied by the slice sum
+  const bool acc_c = splitk > 1 && add != nullptr && add == C;
+  if (acc_c) add = nullptr;
   if (splitk > 1 && (ws == nullptr || bias != nullptr || add != nullptr || ldc != N || (scalar_bits & 4))) return (int)hipErrorInvalidValue;
   if (scalar_bits & 2) return (int)hipErrorInvalidValue;           // B has to be float4-addressable
   float* out = splitk > 1 ? ws : C;
@@ -651,7 +654,7 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
   if (rc) return rc;
   if (splitk > 1) {
     const int n4 = (int)((size_t)M * N / 4);
-    STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, st, (const float*)ws, C, n4, splitk);
+    STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, st, (const float*)ws, C, n4, splitk, acc_c ? 1 : 0);
     STOVE_LAUNCH_CHECK();
   }
   return 0;
@@ -687,11 +690,16 @@ static int colsum_level(const float* a, float* part, int rows, int cols, int max
   return used;
 }
 
-int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void* stream) {
+int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void* stream) { return stove_colsum2(a, out, nullptr, 0, ws, rows, cols, stream); }
+
+int stove_colsum2(const float* a, float* out, float* out2, int accumulate, float* ws, int rows, int cols, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (cols <= 0 || (cols % 4 != 0 && cols > 64)) return (int)hipErrorInvalidValue;
   if (rows == 0) {
-    hipMemsetAsync(out, 0, sizeof(float) * cols, st);
+    if (!accumulate) {
+      hipMemsetAsync(out, 0, sizeof(float) * cols, st);
+      if (out2 != nullptr) hipMemsetAsync(out2, 0, sizeof(float) * cols, st);
+    }
     return 0;
   }
   // 512 row chunks keep the first pass at HBM speed; a second pass folds them to <= 16 so that the final fixed-order
@@ -705,7 +713,8 @@ int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void
     STOVE_LAUNCH_CHECK();
     src = ws2;
   }
-  STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, src, out, cols, used, 0);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, src, out, cols, used, accumulate);
+  if (out2 != nullptr) STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, src, out2, cols, used, accumulate);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -886,15 +895,19 @@ int stove_enc_head_fwd(const float* h, const float* W1, const float* b1, const f
 }
 
 size_t stove_enc_head_bwd_ws_floats(int rows, int HID) { return (size_t)enc_head_groups(rows) * eh_part_floats(HID); }
-int stove_enc_head_grad_floats(int HID) { return eh_part_floats(HID); }
 
-int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, const float* W1, const float* W2, float* gh, float* grads,
-                       float* ws, int rows, int H, int HID, int OUT, void* stream) {
+int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, const float* W1, const float* W2, float* gh, float* gW1,
+                       float* gb1, float* gW2, float* gb2, int accumulate, float* ws, int rows, int H, int HID, int OUT, void* stream) {
   if (H != kEhH || HID < 1 || HID > kEhHid || OUT != kEhOut) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const int P = eh_part_floats(HID);
   if (rows == 0) {
-    hipMemsetAsync(grads, 0, sizeof(float) * P, st);
+    if (!accumulate) {
+      hipMemsetAsync(gW1, 0, sizeof(float) * HID * kEhH, st);
+      hipMemsetAsync(gW2, 0, sizeof(float) * kEhOut * HID, st);
+      hipMemsetAsync(gb1, 0, sizeof(float) * HID, st);
+      hipMemsetAsync(gb2, 0, sizeof(float) * kEhOut, st);
+    }
     return 0;
   }
   const int groups = enc_head_groups(rows);
@@ -910,7 +923,8 @@ int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, con
     STOVE_LAUNCH(enc_head_bwd_k<16>, dim3(groups * 5), dim3(256), lds, st, dcodes, h1, h, W1, W2, gh, ws, rows, HID, groups);
   }
   STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH(reduce_chunks_k, dim3((P + 31) / 32), dim3(256), 0, st, (const float*)ws, grads, P, groups, 0);
+  (void)P;
+  STOVE_LAUNCH(enc_head_reduce_k, dim3((eh_part_floats(HID) + 31) / 32), dim3(256), 0, st, (const float*)ws, gW1, gW2, gb1, gb2, HID, groups, accumulate);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -391,4 +391,27 @@ __global__ __launch_bounds__(256, 2) void enc_head_bwd_k(const float* __restrict
   }
 }
 
+// part[group][gw1 | gw2 | gb1 | gb2] summed over the groups in group order (256 threads = 32 elements x 8 group slices, as
+// reduce_chunks_k) and handed to the four gradient tensors; accumulate: added to what they hold.
+__global__ __launch_bounds__(256) void enc_head_reduce_k(const float* __restrict__ part, float* __restrict__ gW1, float* __restrict__ gW2,
+                                                          float* __restrict__ gb1, float* __restrict__ gb2, int HID, int n_groups, int accumulate) {
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + e;
+  const int P = eh_part_floats(HID), n = HID * kEhH + kEhOut * HID + HID + kEhOut;
+  float s = 0.0f;
+  if (j < n)
+    for (int c = q; c < n_groups; c += 8) s += part[(size_t)c * P + j];
+  red[q][e] = s;
+  __syncthreads();
+  if (q == 0 && j < n) {
+    float t = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][e];
+    const int o1 = HID * kEhH, o2 = o1 + kEhOut * HID, o3 = o2 + HID;
+    float* dst = j < o1 ? gW1 + j : j < o2 ? gW2 + (j - o1) : j < o3 ? gb1 + (j - o2) : gb2 + (j - o3);
+    *dst = accumulate ? *dst + t : t;
+  }
+}
+
 }  // namespace stove

@@ -163,6 +163,7 @@ class _SceneFn(torch.autograd.Function):
                                       ptr(ll), ptr(parts), ptr(saved), stream()), 'stove_scene_fwd')
         ctx.save_for_backward(frames, z, *tabs, obj_scope, obj_leaf_slot, bg_side, saved)
         ctx.n_obj, ctx.beta, ctx.sink = n_obj, float(beta), sink
+        ctx.set_materialize_grads(False)          # no zero tensors (one fill launch each) for the outputs nothing differentiates
         ctx.mark_non_differentiable(parts)
         return ll, parts
 
@@ -172,6 +173,8 @@ class _SceneFn(torch.autograd.Function):
         frames, z, oc, ow, orr, bc, bw, obj_scope, obj_leaf_slot, bg_side, saved = ctx.saved_tensors
         (nf, seq_frames, seq_stride), n_obj = ctx.frame_map, ctx.n_obj
         dev = frames.device
+        if dll is None:
+            return (None,) * 13
         dll = _f32(dll)
         with torch.cuda.device(dev):
             dz = torch.empty_like(z)
@@ -373,6 +376,7 @@ class _DynLoopFn(torch.autograd.Function):
         ctx.save_for_backward(z1, zsup, zsstd, eps, extra, params, z, act)
         ctx.cfg = (int(lim_enc), int(elu), tuple(float(c) for c in consts), sd)
         ctx.sink = sink
+        ctx.set_materialize_grads(False)          # no zero tensors (one fill launch each) for the outputs nothing differentiates
         ctx.mark_non_differentiable(zdstd)
         if pred is None:
             pred = z.new_zeros(0)
@@ -507,6 +511,7 @@ class _SupairStateFn(torch.autograd.Function):
                   'stove_supair_state_fwd')
         ctx.save_for_backward(zc, idx, hits, zfix)
         ctx.cfg = (tuple(span_low), n, T, o, skip, codes.shape)
+        ctx.set_materialize_grads(False)          # no zero tensors (one fill launch each) for the outputs nothing differentiates
         ctx.mark_non_differentiable(idx)
         return zfix, zl, sl, init6, idx
 
@@ -571,6 +576,7 @@ class _ElboFn(torch.autograd.Function):
         ctx.save_for_backward(zs, mean, std, zdyn)
         ctx.cfg = (tuple(trans_std), n, T, o, skip, lik.shape)
         stats = out3[1:]
+        ctx.set_materialize_grads(False)          # no zero tensors (one fill launch each) for the outputs nothing differentiates
         ctx.mark_non_differentiable(stats)
         return out3[0], stats
 
@@ -581,6 +587,8 @@ class _ElboFn(torch.autograd.Function):
         trans_std, n, T, o, skip, lik_shape = ctx.cfg
         ts = _host_floats(trans_std, 16)
         dev = zs.device
+        if g_elbo is None:
+            return (None,) * 10
         with torch.cuda.device(dev):
             g = _f32(g_elbo).reshape(1)
             g_zs, g_mean, g_std, g_zdyn = (torch.empty_like(t) for t in (zs, mean, std, zdyn))
@@ -653,6 +661,40 @@ def linear(x, weight, bias):
     return out.view(*shape[:-1], weight.shape[0])
 
 
+# ------------------------------------------------------------------------------------------------
+# Gradients straight into a flat arena.  A ParamArena registers the gradient view of every parameter it owns (keyed by the
+# parameter's storage address); the recognition network's backward passes then ADD their weight gradients into those views
+# inside the kernels that produce them (split-K sums, column sums, the head's reduction) and hand autograd None for them.
+# That removes one AccumulateGrad `add_` launch per parameter from the critical path (8 per step) and lets the weight-gradient
+# GEMMs run on the second stream, since nothing on the main stream consumes their result before the optimiser.
+# The semantics are those of .backward() (accumulate into .grad); torch.autograd.grad() on arena-bound parameters must
+# switch it off (STOVE_DIRECT_GRADS=0 or ops.DIRECT_GRADS = False).
+# ------------------------------------------------------------------------------------------------
+DIRECT_GRADS = os.environ.get('STOVE_DIRECT_GRADS', '1') != '0'
+_GRAD_VIEWS = {}
+
+
+def register_grad_view(p, g):
+    """ParamArena: g is the flat-gradient view of parameter p (None: forget it)."""
+    if g is None:
+        _GRAD_VIEWS.pop(p.data_ptr(), None)
+    else:
+        _GRAD_VIEWS[p.data_ptr()] = g
+
+
+def _grad_views(*params):
+    """The registered gradient views of all of `params`, or None if direct accumulation is off / any of them has none."""
+    if not DIRECT_GRADS:
+        return None
+    out = []
+    for p in params:
+        g = _GRAD_VIEWS.get(p.data_ptr())
+        if g is None or g.shape != p.shape or g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
+            return None
+        out.append(g)
+    return out
+
+
 class _EncoderHeadFn(torch.autograd.Function):
     """fc2(sigmoid(fc1(h))) of the recognition network (reference encoder.py:53-56) on (rows, 256) LSTM outputs: fc1 and its
     two gradient products are GEMMs (the MFMA GEMM of csrc/gemm_bf16.hip, whose element-wise operand path takes fc1's 50
@@ -711,23 +753,26 @@ class _EncoderHeadFusedFn(torch.autograd.Function):
         with torch.cuda.device(h.device):
             check(lib.stove_enc_head_fwd(ptr(h), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(h1), ptr(codes), rows, H, HID, OUT, stream()),
                   'stove_enc_head_fwd')
-        ctx.save_for_backward(h, w1, w2, h1)
+        ctx.save_for_backward(h, w1, b1, w2, b2, h1)
         return codes
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        h, w1, w2, h1 = ctx.saved_tensors
+        h, w1, b1, w2, b2, h1 = ctx.saved_tensors
         rows, H, HID, OUT = h.shape[0], h.shape[1], w1.shape[0], w2.shape[0]
         g = _f32(g)
+        dev = h.device
         gh = torch.empty_like(h)
-        grads = torch.empty(lib.stove_enc_head_grad_floats(HID), dtype=torch.float32, device=h.device)
-        with torch.cuda.device(h.device):
-            ws = torch.empty(lib.stove_enc_head_bwd_ws_floats(rows, HID), dtype=torch.float32, device=h.device)
-            check(lib.stove_enc_head_bwd(ptr(g), ptr(h1), ptr(h), ptr(w1), ptr(w2), ptr(gh), ptr(grads), ptr(ws), rows, H, HID, OUT,
-                                         stream()), 'stove_enc_head_bwd')
-        o1, o2, o3 = HID * H, HID * H + OUT * HID, HID * H + OUT * HID + HID
-        return gh, grads[:o1].view(HID, H), grads[o2:o3], grads[o1:o2].view(OUT, HID), grads[o3:o3 + OUT]
+        views = _grad_views(w1, b1, w2, b2)
+        outs = views if views is not None else [torch.empty_like(t) for t in (w1, b1, w2, b2)]
+        with torch.cuda.device(dev):
+            ws = torch.empty(lib.stove_enc_head_bwd_ws_floats(rows, HID), dtype=torch.float32, device=dev)
+            check(lib.stove_enc_head_bwd(ptr(g), ptr(h1), ptr(h), ptr(w1), ptr(w2), ptr(gh), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]),
+                                         ptr(outs[3]), int(views is not None), ptr(ws), rows, H, HID, OUT, stream()), 'stove_enc_head_bwd')
+        if views is not None:
+            return gh, None, None, None, None
+        return (gh, *outs)
 
 
 def encoder_head(h, w1, b1, w2, b2, gemm='bf16x3'):
@@ -822,7 +867,7 @@ class _EncoderLstmFn(torch.autograd.Function):
                 gss.append(gs)
                 check(lib.stove_lstm_cell_fwd(ptr(gs), None, ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(hs[k]),
                                               n, H, stream()), 'stove_lstm_cell_fwd')
-        ctx.save_for_backward(x, w_ih, w_hh, gx, hs, cs, *gss[1:])
+        ctx.save_for_backward(x, w_ih, w_hh, gx, hs, cs, b_ih, b_hh, *gss[1:])
         ctx.num_steps = num_steps
         ctx.time_major = bool(time_major)
         ctx.ns = ns
@@ -831,19 +876,35 @@ class _EncoderLstmFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dhs):
         lib = _lib.load()
-        x, w_ih, w_hh, gx, hs, cs = ctx.saved_tensors[:6]
-        gss = [gx] + list(ctx.saved_tensors[6:])
+        x, w_ih, w_hh, gx, hs, cs, b_ih, b_hh = ctx.saved_tensors[:8]
+        gss = [gx] + list(ctx.saved_tensors[8:])
         K = ctx.num_steps
         ns = ctx.ns
         n, H = x.shape[0], w_hh.shape[1]
         dev = x.device
         dhs = _f32(dhs if ctx.time_major else dhs.transpose(0, 1))                       # (K, n, H)
+        # Parameter gradients straight into the arena's views (see _grad_views): no AccumulateGrad launches, and the two
+        # weight-gradient GEMMs run on the second stream next to the rest of this backward -- only the optimiser reads them.
+        views = _grad_views(w_ih, w_hh, b_ih, b_hh) if (ns and gemm_ok(n) and not ctx.needs_input_grad[0]) else None
+        fork = views is not None and os.environ.get('STOVE_NO_OVERLAP', '0') != '1'
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if fork else main
 
-        def wgrad(dy, inp):
+        def wgrad(dy, inp, out=None):
             """dy^T @ inp over all rows: both operands are stored K-major for this product."""
             if ns and gemm_ok(dy.shape[0]):
-                return gemm_bf16(dy, inp, None, True, True, ns)
+                return gemm_bf16(dy, inp, None, True, True, ns, out=out)
             return _splitk_tn(dy, inp)
+
+        def on_side(fn, *bufs):
+            if fork:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    fn()
+                for b in bufs:
+                    b.record_stream(side)          # the caching allocator must not hand these out before `side` is done
+            else:
+                fn()
         with torch.cuda.device(dev):
             dgx = torch.empty_like(gx)
             # gate gradients of steps 1..K-1 are kept ((K-1) x 105 MB at 25 600 frames): dW_hh is ONE GEMM over all of
@@ -852,17 +913,28 @@ class _EncoderLstmFn(torch.autograd.Function):
             dg_all = torch.empty(max(K - 1, 1), n, 4 * H, dtype=torch.float32, device=dev)
             dc = [torch.empty(n, H, dtype=torch.float32, device=dev) for _ in range(2)]
             dh = dhs[K - 1]
+            d_whh = None
             for k in range(K - 1, -1, -1):
                 dg = dg_all[k - 1] if k > 0 else None
                 check(lib.stove_lstm_cell_bwd(ptr(gss[k]), None, ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(dh),
                                               ptr(dc[(k + 1) % 2]) if k < K - 1 else None, ptr(dg) if dg is not None else None,
                                               ptr(dc[k % 2]), ptr(dgx) if k == 0 else None, ptr(dg_all) if (k == 0 and K > 1) else None,
                                               K - 1 if k == 0 else 0, n, H, stream()), 'stove_lstm_cell_bwd')
+                if k == 1 and views is not None:
+                    # all gate gradients W_hh sees are written: its GEMM starts here, beside the last recurrent step
+                    on_side(lambda: wgrad(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H), out=views[1]), dg_all, hs)
                 if k > 0:
                     if ns:
                         dh = gemm_bf16(dg, w_hh, None, False, True, ns, 1, add=dhs[k - 1])     # dhs[k-1] + dg W_hh
                     else:
                         dh = torch.addmm(dhs[k - 1], dg, w_hh)
+            if views is not None:
+                on_side(lambda: wgrad(dgx, x, out=views[0]), dgx, x)
+                ws = torch.empty(lib.stove_colsum_ws_floats(n, 4 * H) + 1, dtype=torch.float32, device=dev)
+                check(lib.stove_colsum2(ptr(dgx), ptr(views[2]), ptr(views[3]), 1, ptr(ws), n, 4 * H, stream()), 'stove_colsum2')
+                if fork:
+                    torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_stream(side))
+                return None, None, None, None, None, None, None, None
             d_whh = wgrad(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H)) if K > 1 else None
             if d_whh is None:
                 d_whh = torch.zeros_like(w_hh)
@@ -889,17 +961,23 @@ def gemm_splitk(M, N, K):
     return s
 
 
-def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=None, add=None, tile=0):
+def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=None, add=None, tile=0, out=None):
     """C (M, N) = sum_k a(m,k) b(n,k) (+ bias) (+ add) on the bf16 matrix cores with fp32 in / out (csrc/gemm_bf16.hip).
     a: (M, K), or (K, M) when a_kmajor; b: (N, K), or (K, N) when b_kmajor.  nsplit 2 = hi+lo split (3 MFMAs), 1 = plain bf16.
-    splitk None = chosen from the shape (only without bias / add)."""
+    splitk None = chosen from the shape (only without bias / add).  out: a contiguous (M, N) tensor the product is ADDED to
+    (a gradient view; returned)."""
     a, b = _f32(a), _f32(b)
     M, K = (a.shape[1], a.shape[0]) if a_kmajor else a.shape
     N = b.shape[1] if b_kmajor else b.shape[0]
     if splitk is None:
         splitk = gemm_splitk(M, N, K) if bias is None and add is None else 1
     lib = _lib.load()
-    c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if out is not None:
+        if add is not None or bias is not None or out.shape != (M, N) or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError('gemm_bf16: out= takes a contiguous fp32 (M, N) tensor and no bias / add')
+        c = add = out
+    else:
+        c = torch.empty(M, N, dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device):
         ws = torch.empty(lib.stove_gemm_bf16_ws_floats(M, N, splitk), dtype=torch.float32, device=a.device) if splitk > 1 else None
         check(lib.stove_gemm_bf16(ptr(a), ptr(b), ptr(bias) if bias is not None else None, ptr(_f32(add)) if add is not None else None,
