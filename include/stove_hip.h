@@ -322,12 +322,13 @@ int stove_head_bwd(const float* dcodes, const float* h1, const float* W2, float*
  * fwd: h (rows, H) -> h1 = sigmoid(h W1^T + b1) (rows, HID) and codes (rows, OUT) = h1 W2^T + b2; W1 (HID, H), W2 (OUT, HID).
  * bwd: dcodes (rows, OUT), h1, h -> gh (rows, H) = dL/dh and the parameter gradients gW1 (HID, H), gb1 (HID), gW2 (OUT, HID),
  * gb2 (OUT); accumulate != 0: added to what the four tensors hold (gradient views of a flat arena).  ws:
- * stove_enc_head_bwd_ws_floats floats.  Fixed summation order. */
+ * stove_enc_head_bwd_ws_floats floats.  Fixed summation order.  frames > 0: h, h1, gh are step-major (row = step * frames + frame,
+ * as the LSTM writes them) while codes / dcodes are frame-major (row = frame * steps + step, encoder.py:57); 0: same row order. */
 int stove_enc_head_fwd(const float* h, const float* W1, const float* b1, const float* W2, const float* b2, float* h1, float* codes, int rows,
-                       int H, int HID, int OUT, void* stream);
+                       int H, int HID, int OUT, int frames, void* stream);
 size_t stove_enc_head_bwd_ws_floats(int rows, int HID);
 int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, const float* W1, const float* W2, float* gh, float* gW1,
-                       float* gb1, float* gW2, float* gb2, int accumulate, float* ws, int rows, int H, int HID, int OUT, void* stream);
+                       float* gb1, float* gW2, float* gb2, int accumulate, float* ws, int rows, int H, int HID, int OUT, int frames, void* stream);
 
 /* ---- measurement hooks (bench.py): when enabled, every kernel launch of this library is bracketed by
  * two HIP events recorded on the launch stream.  stove_profile_report() synchronises them, writes

@@ -91,9 +91,9 @@ def _declare(lib):
         'stove_head_fwd': (I, [P, P, P, P, P, I, I, I, P]),
         'stove_head_bwd_ws_floats': (S, [I, I, I]),
         'stove_head_bwd': (I, [P, P, P, P, P, P, I, I, I, P]),
-        'stove_enc_head_fwd': (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+        'stove_enc_head_fwd': (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
         'stove_enc_head_bwd_ws_floats': (S, [I, I]),
-        'stove_enc_head_bwd': (I, [P, P, P, P, P, P, P, P, P, P, I, P, I, I, I, I, P]),
+        'stove_enc_head_bwd': (I, [P, P, P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
         'stove_colsum2': (I, [P, P, P, I, P, I, I, P]),
         'stove_dynloop_bwd_ws_bytes_ts': (S, [I, I, I]),
         'stove_bw_transform': (I, [P, P, I, I, I, P]),

@@ -881,15 +881,15 @@ static int enc_head_groups(int rows) {
 }
 
 int stove_enc_head_fwd(const float* h, const float* W1, const float* b1, const float* W2, const float* b2, float* h1, float* codes, int rows,
-                       int H, int HID, int OUT, void* stream) {
-  if (H != kEhH || HID < 1 || HID > kEhHid || OUT != kEhOut) return (int)hipErrorInvalidValue;
+                       int H, int HID, int OUT, int frames, void* stream) {
+  if (H != kEhH || HID < 1 || HID > kEhHid || OUT != kEhOut || frames < 0 || (frames > 0 && rows % frames != 0)) return (int)hipErrorInvalidValue;
   if (rows == 0) return 0;
   const size_t lds = sizeof(float) * kEhHid * kEhLd;
   int rc = (int)hipFuncSetAttribute((const void*)enc_head_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (rc) return rc;
   const int tiles = (rows + 15) / 16;
   const int grid = (tiles + 3) / 4 < 512 ? (tiles + 3) / 4 : 512;
-  STOVE_LAUNCH(enc_head_fwd_k, dim3(grid), dim3(256), lds, (hipStream_t)stream, h, W1, b1, W2, b2, h1, codes, rows, HID);
+  STOVE_LAUNCH(enc_head_fwd_k, dim3(grid), dim3(256), lds, (hipStream_t)stream, h, W1, b1, W2, b2, h1, codes, rows, HID, frames);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -897,8 +897,8 @@ int stove_enc_head_fwd(const float* h, const float* W1, const float* b1, const f
 size_t stove_enc_head_bwd_ws_floats(int rows, int HID) { return (size_t)enc_head_groups(rows) * eh_part_floats(HID); }
 
 int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, const float* W1, const float* W2, float* gh, float* gW1,
-                       float* gb1, float* gW2, float* gb2, int accumulate, float* ws, int rows, int H, int HID, int OUT, void* stream) {
-  if (H != kEhH || HID < 1 || HID > kEhHid || OUT != kEhOut) return (int)hipErrorInvalidValue;
+                       float* gb1, float* gW2, float* gb2, int accumulate, float* ws, int rows, int H, int HID, int OUT, int frames, void* stream) {
+  if (H != kEhH || HID < 1 || HID > kEhHid || OUT != kEhOut || frames < 0 || (frames > 0 && rows % frames != 0)) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const int P = eh_part_floats(HID);
   if (rows == 0) {
@@ -916,11 +916,11 @@ int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, con
   if (HID <= 50) {
     rc = (int)hipFuncSetAttribute((const void*)enc_head_bwd_k<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc) return rc;
-    STOVE_LAUNCH(enc_head_bwd_k<14>, dim3(groups * 5), dim3(256), lds, st, dcodes, h1, h, W1, W2, gh, ws, rows, HID, groups);
+    STOVE_LAUNCH(enc_head_bwd_k<14>, dim3(groups * 5), dim3(256), lds, st, dcodes, h1, h, W1, W2, gh, ws, rows, HID, groups, frames);
   } else {
     rc = (int)hipFuncSetAttribute((const void*)enc_head_bwd_k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc) return rc;
-    STOVE_LAUNCH(enc_head_bwd_k<16>, dim3(groups * 5), dim3(256), lds, st, dcodes, h1, h, W1, W2, gh, ws, rows, HID, groups);
+    STOVE_LAUNCH(enc_head_bwd_k<16>, dim3(groups * 5), dim3(256), lds, st, dcodes, h1, h, W1, W2, gh, ws, rows, HID, groups, frames);
   }
   STOVE_LAUNCH_CHECK();
   (void)P;

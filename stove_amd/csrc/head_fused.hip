@@ -22,6 +22,9 @@ constexpr int kEhHid = 64;      // max hidden width (4 feature tiles)
 
 __device__ __forceinline__ f32x4 eh_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float eh_comp(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+// The LSTM hands over its outputs step-major (row = step * n + frame); the codes are wanted frame-major (frame * steps + step,
+// reference encoder.py:57: (n, num_obj, 8)).  pn = n > 0: the codes / their gradients live at the transposed row.
+__device__ __forceinline__ size_t eh_orow(int row, int pn, int pk) { return pn > 0 ? (size_t)(row % pn) * pk + row / pn : (size_t)row; }
 
 // ---- forward ----------------------------------------------------------------------------------------------------------------------
 // One wave = one tile of 16 batch rows x all HID features.  a1^T (feature x row) = W1 (feature x 256) h^T (256 x row):
@@ -31,7 +34,7 @@ __device__ __forceinline__ float eh_comp(const float4& v, int j) { return j == 0
 // every byte of h crosses the memory system once.
 __global__ __launch_bounds__(256, 2) void enc_head_fwd_k(const float* __restrict__ h, const float* __restrict__ W1, const float* __restrict__ b1,
                                                        const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ h1,
-                                                       float* __restrict__ codes, int rows, int HID) {
+                                                       float* __restrict__ codes, int rows, int HID, int pn) {
   extern __shared__ __attribute__((aligned(16))) float eh_lds[];      // W1 image [64][kEhLd], rows >= HID zero
   const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
   const int c = lane & 15, g = lane >> 4;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void enc_head_fwd_k(const float* __restrict
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
       for (int s = 0; s < 4; ++s) cd = eh_mfma(a2[jt][s], hv[jt][s], cd);
-    if (live && g < 2) st4(codes + (size_t)row * kEhOut + 4 * g, float4{cd[0] + bias2.x, cd[1] + bias2.y, cd[2] + bias2.z, cd[3] + bias2.w});
+    if (live && g < 2) st4(codes + eh_orow(row, pn, pn > 0 ? rows / pn : 0) * kEhOut + 4 * g, float4{cd[0] + bias2.x, cd[1] + bias2.y, cd[2] + bias2.z, cd[3] + bias2.w});
   }
 }
 
@@ -160,11 +163,12 @@ struct EhTileIn {      // what a column role fetches for one tile
   float hb[4][4];      // h[row g + 4 s][m0 + 16 mt + c]
 };
 __device__ __forceinline__ void eh_fetch(EhTileIn& x, const float* __restrict__ dcodes, const float* __restrict__ h1, const float* __restrict__ h,
-                                         int t, int rows, int HID, int m0, int c, int g, bool even, bool with_h) {
+                                         int t, int rows, int HID, int m0, int c, int g, bool even, bool with_h, int pn) {
   const int R0 = t * 16, row = R0 + c;
   const int rowc = row < rows ? row : rows - 1;
+  const size_t orow = eh_orow(rowc, pn, pn > 0 ? rows / pn : 0);
 #pragma unroll
-  for (int s = 0; s < 2; ++s) x.gv[s] = dcodes[(size_t)rowc * kEhOut + g + 4 * s];
+  for (int s = 0; s < 2; ++s) x.gv[s] = dcodes[orow * kEhOut + g + 4 * s];
   const float* hp = h1 + (size_t)rowc * HID;
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
@@ -206,7 +210,7 @@ __device__ __forceinline__ void eh_da(const EhTileIn& x, const float (&a1)[4][2]
 template <int KS>               // k-steps of product 3 = feature quadruples (jt, s) with 16 jt + s < HID, in (jt, s) order
 __global__ __launch_bounds__(256, 2) void enc_head_bwd_k(const float* __restrict__ dcodes, const float* __restrict__ h1, const float* __restrict__ h,
                                                           const float* __restrict__ W1, const float* __restrict__ W2, float* __restrict__ gh,
-                                                          float* __restrict__ part, int rows, int HID, int n_groups) {
+                                                          float* __restrict__ part, int rows, int HID, int n_groups, int pn) {
   extern __shared__ __attribute__((aligned(16))) float eh_lds[];
   const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
   const int c = lane & 15, g = lane >> 4;
@@ -236,13 +240,13 @@ __global__ __launch_bounds__(256, 2) void enc_head_bwd_k(const float* __restrict
     for (int t = grp * 4 + wv; t < n_tiles; t += n_groups * 4) {
       const int R0 = t * 16;
       EhTileIn x;
-      eh_fetch(x, dcodes, h1, h, t, rows, HID, 0, c, g, even, false);
+      eh_fetch(x, dcodes, h1, h, t, rows, HID, 0, c, g, even, false, pn);
       // gw2: A = dcodes[row g + 4 s][o = c], B = h1[row g + 4 s][feature c + 16 jt]
       float av[4], bv[4][4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int rr = R0 + g + 4 * s, rc = rr < rows ? rr : rows - 1;
-        av[s] = dcodes[(size_t)rc * kEhOut + (c & (kEhOut - 1))];
+        av[s] = dcodes[eh_orow(rc, pn, pn > 0 ? rows / pn : 0) * kEhOut + (c & (kEhOut - 1))];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) bv[jt][s] = h1[(size_t)rc * HID + (c + 16 * jt < HID ? c + 16 * jt : 0)];
       }
@@ -324,12 +328,12 @@ __global__ __launch_bounds__(256, 2) void enc_head_bwd_k(const float* __restrict
   __syncthreads();
   int t = grp * 4 + wv;
   EhTileIn nx;
-  if (t < n_tiles) eh_fetch(nx, dcodes, h1, h, t, rows, HID, m0, c, g, even, true);
+  if (t < n_tiles) eh_fetch(nx, dcodes, h1, h, t, rows, HID, m0, c, g, even, true, pn);
   for (; t < n_tiles; t += n_groups * 4) {
     const int R0 = t * 16, row = R0 + c;
     const bool live = row < rows;
     const EhTileIn x = nx;
-    if (t + n_groups * 4 < n_tiles) eh_fetch(nx, dcodes, h1, h, t + n_groups * 4, rows, HID, m0, c, g, even, true);
+    if (t + n_groups * 4 < n_tiles) eh_fetch(nx, dcodes, h1, h, t + n_groups * 4, rows, HID, m0, c, g, even, true, pn);
     float gv[2], da[4][4];
     eh_da(x, a1, live, g, HID, gv, da);
     // 3. gh

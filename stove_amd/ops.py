@@ -745,13 +745,14 @@ class _EncoderHeadFusedFn(torch.autograd.Function):
     instructions, h read once; the backward returns dL/dh and all four parameter gradients.  H = 256, HID <= 64, OUT = 8."""
 
     @staticmethod
-    def forward(ctx, h, w1, b1, w2, b2):
+    def forward(ctx, h, w1, b1, w2, b2, frames):
         lib = _lib.load()
         rows, H, HID, OUT = h.shape[0], h.shape[1], w1.shape[0], w2.shape[0]
+        ctx.frames = int(frames)
         h1 = torch.empty(rows, HID, dtype=torch.float32, device=h.device)
         codes = torch.empty(rows, OUT, dtype=torch.float32, device=h.device)
         with torch.cuda.device(h.device):
-            check(lib.stove_enc_head_fwd(ptr(h), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(h1), ptr(codes), rows, H, HID, OUT, stream()),
+            check(lib.stove_enc_head_fwd(ptr(h), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(h1), ptr(codes), rows, H, HID, OUT, ctx.frames, stream()),
                   'stove_enc_head_fwd')
         ctx.save_for_backward(h, w1, b1, w2, b2, h1)
         return codes
@@ -769,19 +770,27 @@ class _EncoderHeadFusedFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws = torch.empty(lib.stove_enc_head_bwd_ws_floats(rows, HID), dtype=torch.float32, device=dev)
             check(lib.stove_enc_head_bwd(ptr(g), ptr(h1), ptr(h), ptr(w1), ptr(w2), ptr(gh), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]),
-                                         ptr(outs[3]), int(views is not None), ptr(ws), rows, H, HID, OUT, stream()), 'stove_enc_head_bwd')
+                                         ptr(outs[3]), int(views is not None), ptr(ws), rows, H, HID, OUT, ctx.frames, stream()), 'stove_enc_head_bwd')
         if views is not None:
-            return gh, None, None, None, None
-        return (gh, *outs)
+            return gh, None, None, None, None, None
+        return (gh, *outs, None)
 
 
-def encoder_head(h, w1, b1, w2, b2, gemm='bf16x3'):
-    """(..., 256) -> (..., 8): fc2(sigmoid(fc1(h))).  gemm: 'bf16x3' | 'bf16' | 'fp32' for the fc1 products (see encoder_lstm)."""
+def encoder_head(h, w1, b1, w2, b2, gemm='bf16x3', step_major=False):
+    """(..., 256) -> (..., 8): fc2(sigmoid(fc1(h))).  gemm: 'bf16x3' | 'bf16' | 'fp32' for the fc1 products (see encoder_lstm).
+    step_major: h is (steps, n, 256) as the LSTM kernels write it and the result is (n, steps, 8) -- the kernels write the
+    small output transposed instead of a permute + copy each way."""
     shape = h.shape
+    fused = gemm != 'fp32' and shape[-1] == 256 and w2.shape[0] == 8 and w1.shape[0] <= 64
+    if step_major and h.dim() == 3 and fused:
+        out = _EncoderHeadFusedFn.apply(_f32(h.reshape(-1, 256)), _f32(w1), _f32(b1), _f32(w2), _f32(b2), shape[1])
+        return out.view(shape[1], shape[0], 8)
+    if step_major:
+        return encoder_head(h, w1, b1, w2, b2, gemm).transpose(0, 1)
     if w1.shape[0] > 64 or w2.shape[0] > 8:
         return linear(torch.sigmoid(linear(h, w1, b1)), w2, b2)
-    if gemm != 'fp32' and shape[-1] == 256 and w2.shape[0] == 8:       # the fused head; 'fp32' keeps the library GEMMs + head_*_k pair
-        out = _EncoderHeadFusedFn.apply(_f32(h.reshape(-1, shape[-1])), _f32(w1), _f32(b1), _f32(w2), _f32(b2))
+    if fused:       # the one-kernel head; 'fp32' keeps the library GEMMs + head_*_k pair
+        out = _EncoderHeadFusedFn.apply(_f32(h.reshape(-1, shape[-1])), _f32(w1), _f32(b1), _f32(w2), _f32(b2), 0)
         return out.view(*shape[:-1], w2.shape[0])
     out = _EncoderHeadFn.apply(_f32(h.reshape(-1, shape[-1])), _f32(w1), _f32(b1), _f32(w2), _f32(b2), gemm)
     return out.view(*shape[:-1], w2.shape[0])

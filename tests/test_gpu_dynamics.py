@@ -508,6 +508,28 @@ def test_encoder_head_kernels(rows, H1, OUT, gemm):
         assert torch.equal(a.grad, b.grad)
 
 
+@pytest.mark.parametrize('gemm', ['bf16x3', 'fp32'])
+def test_encoder_head_step_major(gemm):
+    """step_major: (steps, n, 256) in, (n, steps, 8) out, equal to the plain head followed by a transpose -- values and gradients."""
+    from stove_amd import ops
+    g = torch.Generator().manual_seed(1)
+    K, n = 3, 37
+    h = torch.randn(K, n, 256, generator=g).to(DEV)
+    ps = [torch.randn(50, 256, generator=g) * 0.1, torch.randn(50, generator=g), torch.randn(8, 50, generator=g) * 0.3, torch.randn(8, generator=g)]
+    wout = torch.randn(n, K, 8, generator=g).to(DEV)
+    res = []
+    for sm in (False, True):
+        ins = [h.clone().requires_grad_()] + [p.to(DEV).requires_grad_() for p in ps]
+        out = ops.encoder_head(*ins, gemm=gemm, step_major=sm)
+        if not sm:
+            out = out.transpose(0, 1)
+        assert out.shape == (n, K, 8)
+        (out * wout).sum().backward()
+        res.append([out.detach()] + [t.grad for t in ins])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('mode,bar', [('fp32', 1e-6), ('bf16x3', 1e-6), ('bf16', 2e-5)])
 def test_encoder_gemm_variants_elbo_delta(mode, bar):
     """config.encoder_gemm: the recognition network's products on library fp32 GEMMs, on the split-bf16 MFMA kernel (default)
