@@ -353,23 +353,28 @@ def main():
             return float(e)
 
         def time_of(mode):
+            """median device time per step (event pairs): one stall of the host or the allocator after the mode switch must not
+            decide a side measurement"""
             cfg.encoder_gemm = mode
-            for i in range(2):
+            for i in range(3):
                 step(i)
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+            ev[0].record()
             for i in range(a.steps):
                 step(i)
+                ev[i + 1].record()
             torch.cuda.synchronize()
-            return (time.perf_counter() - t1) / a.steps * 1e3
+            ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))
+            return ts[len(ts) // 2], ts[-1]
 
         e_ref = elbo_of('fp32')
         variants = {}
         for mode, label in (('bf16', 'bf16-operands (encoder GEMMs), fp32 accumulate'), ('bf16x3', 'split-bf16 x3 (default path)'),
                             ('fp32', 'fp32 library GEMMs')):
             e = elbo_of(mode)
-            ms = time_of(mode)
-            variants[mode] = {'dtype': label, 'ms_per_step': ms, 'value': a.batch * a.frames / ms * 1e3, 'unit': 'frames/s',
+            ms, ms_max = time_of(mode)
+            variants[mode] = {'dtype': label, 'ms_per_step': ms, 'ms_per_step_max': ms_max, 'value': a.batch * a.frames / ms * 1e3, 'unit': 'frames/s',
                               'elbo': e, 'elbo_rel_delta_vs_fp32_library': abs(e - e_ref) / abs(e_ref)}
             with torch.no_grad():       # the timing steps trained: put the parameters and the optimiser state back
                 bucket.data.copy_(snap[0])
