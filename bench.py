@@ -261,11 +261,11 @@ def main():
             if name.startswith('gemm_bf16'):
                 # recognition-network GEMMs (csrc/gemm_bf16.hip), all launches of a step together (they differ in shape):
                 # algorithmic flops = 2 M N K of the fp32 products -- x W_ih^T, (N-1) x h W_hh^T forward; (N-1) x dg W_hh,
-                # dg^T h over the N-1 recurrent steps, dgx^T x backward, and fc1 (256 -> 50) with its two gradient products over
-                # all N hidden states -- against the dense bf16 MFMA peak (2.5 PFLOP/s,
+                # dg^T h over the N-1 recurrent steps, dgx^T x backward (the head's 50-wide products run in enc_head_*_k on the fp32
+                # matrix cores) -- against the dense bf16 MFMA peak (2.5 PFLOP/s,
                 # MI355X_MICROARCH.md); the split-bf16 path issues 3 bf16 MFMA flops per algorithmic flop.
                 nfr, Hh, Dd = a.batch * a.frames, 256, 32 * 32
-                flops = 2.0 * nfr * (2 * Dd * 4 * Hh + 3 * (n_obj - 1) * Hh * 4 * Hh + 3 * n_obj * Hh * 50)
+                flops = 2.0 * nfr * (2 * Dd * 4 * Hh + 3 * (n_obj - 1) * Hh * 4 * Hh)
                 ms_step = total_ms / a.profile_steps
                 ach = flops / (ms_step * 1e-3) / 1e12
                 passes = {'bf16x3': 3, 'bf16': 1}.get(a.encoder_gemm, 3)
