@@ -18,6 +18,7 @@ Contract: build the arena AFTER the model is on its device / dtype, zero gradien
 kernels check that the views are intact and raise otherwise.
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -171,9 +172,48 @@ class ParamArena:
     def has_spn(self):
         return self._on_gpu and self._spn is not None
 
+    def prefetch_images(self, cores=(0,)):
+        """Bake the SPN tables and gather the GNN parameter image(s) on the second stream NOW (called at the top of
+        Stove.forward): they depend on the parameters only, so their two small launches leave the critical path between the
+        recognition network and the recursion / the scene likelihood.  Consumed once by spn_tables() / gnn_image()."""
+        if not self._on_gpu or os.environ.get('STOVE_NO_OVERLAP', '0') == '1':
+            return
+        dev = self.data.device
+        main, side = torch.cuda.current_stream(dev), ops._side_stream(dev)
+        side.wait_stream(main)                       # behind the optimiser's update of self.data
+        with torch.cuda.stream(side):
+            pre = {}
+            if self.has_spn:
+                pre['spn'] = self._bake_spn()
+            if self.has_gnn:
+                for k in cores:
+                    pre[('gnn', k)] = self._gather_gnn(k)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._pre = (pre, ev, side)
+
+    def _take(self, key):
+        pre = getattr(self, '_pre', None)
+        if pre is None or key not in pre[0]:
+            return None
+        out = pre[0].pop(key)
+        torch.cuda.current_stream(self.data.device).wait_event(pre[1])
+        for t in (out if isinstance(out, tuple) else (out,)):
+            t.record_stream(torch.cuda.current_stream(self.data.device))
+        return out
+
     def spn_tables(self):
         """-> obj_tabs (coef, wsum, wroot, scope, leaf_slot), bg_tabs (coef, wroot, side), baked by one launch."""
         self.check()
+        bufs = self._take('spn')
+        if bufs is None:
+            bufs = self._bake_spn()
+        oc, ow, orr, bc, bw = bufs
+        scope, slot, side = self._spn['ints']
+        return ((oc.view(24, 25, 10, 3), ow.view(12, 100, 10), orr.view(6, 100), scope, slot),
+                (bc.view(3, 1024, 6, 3), bw.view(3, 36), side))
+
+    def _bake_spn(self):
         lib = _lib.load()
         dev = self.data.device
         with torch.cuda.device(dev):
@@ -181,9 +221,7 @@ class ParamArena:
             oc, ow, orr, bc, bw = torch.split(buf, [18000, 12000, 600, 55296, 108])
             _lib.check(lib.stove_spn_bake(self.data.data_ptr(), ctypes.byref(self._spn['plan']), oc.data_ptr(), ow.data_ptr(),
                                           orr.data_ptr(), bc.data_ptr(), bw.data_ptr(), _lib.stream()), 'stove_spn_bake')
-        scope, slot, side = self._spn['ints']
-        return ((oc.view(24, 25, 10, 3), ow.view(12, 100, 10), orr.view(6, 100), scope, slot),
-                (bc.view(3, 1024, 6, 3), bw.view(3, 36), side))
+        return oc, ow, orr, bc, bw
 
     def spn_sink(self, grads):
         """grads = (obj_coef, obj_wsum, obj_wroot, bg_coef, bg_wroot) table gradients -> accumulated into self.grad."""
@@ -220,6 +258,10 @@ class ParamArena:
     def gnn_image(self, core_idx=0):
         """[W | W^T | vectors] image of one core, gathered from the arena by one launch."""
         self.check()
+        img = self._take(('gnn', core_idx))
+        return img if img is not None else self._gather_gnn(core_idx)
+
+    def _gather_gnn(self, core_idx):
         lib = _lib.load()
         src = self._gnn[core_idx][0]
         with torch.cuda.device(self.data.device):

@@ -326,14 +326,14 @@ __global__ __launch_bounds__(256, 2) void enc_head_bwd_k(const float* __restrict
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) accw[nt][mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   __syncthreads();
-  int t = grp * 4 + wv;
-  EhTileIn nx;
-  if (t < n_tiles) eh_fetch(nx, dcodes, h1, h, t, rows, HID, m0, c, g, even, true, pn);
-  for (; t < n_tiles; t += n_groups * 4) {
+  for (int t = grp * 4 + wv; t < n_tiles; t += n_groups * 4) {
     const int R0 = t * 16, row = R0 + c;
     const bool live = row < rows;
-    const EhTileIn x = nx;
-    if (t + n_groups * 4 < n_tiles) eh_fetch(nx, dcodes, h1, h, t + n_groups * 4, rows, HID, m0, c, g, even, true, pn);
+    // no tile-ahead fetch: its 34 registers would put the kernel above the 192 that gnn_dw_small_k (the recursion's
+    // weight-gradient pass on the side stream, 320 registers per lane, memory-bound) leaves on a SIMD -- sharing the SIMDs
+    // with it is worth more than hiding this kernel's own load latency
+    EhTileIn x;
+    eh_fetch(x, dcodes, h1, h, t, rows, HID, m0, c, g, even, true, pn);
     float gv[2], da[4][4];
     eh_da(x, a1, live, g, HID, gv, da);
     // 3. gh

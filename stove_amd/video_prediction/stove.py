@@ -162,6 +162,10 @@ class Stove(nn.Module):
         n, T = x.shape[:2]
         o, skip, cl = c.num_obj, c.skip, c.cl
 
+        arena = getattr(self.dyn, '_arena', None)
+        if arena is not None and torch.is_grad_enabled() and getattr(c, 'fused_dynamics', True):
+            arena.prefetch_images()          # parameter-only launches, off the critical path (second stream)
+
         # 1. SuPAIR states for every frame, consistent object order, smoothing, velocities.
         # Without appearance features the whole chain (constrain_zp, matching, gather, fix_supair, velocities) is the
         # fused state pipeline (csrc/state.hip); the PyTorch chain below it is the same computation op by op.
