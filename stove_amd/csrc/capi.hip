@@ -301,10 +301,10 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
 }
 
 int stove_glimpse_mean(const float* x_color, const float* z, float* emb, int n_frames, int n_obj, int channels, void* stream) {
-  const long long total = (long long)n_frames * n_obj * channels;
+  const long long total = (long long)n_frames * n_obj;
   if (total == 0) return 0;
-  if (total > 0x7fffffffLL || channels < 1) return (int)hipErrorInvalidValue;
-  STOVE_LAUNCH(glimpse_mean_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_color, z, emb,
+  if (total > 0x7fffffffLL || channels < 1 || channels > 4) return (int)hipErrorInvalidValue;
+  STOVE_LAUNCH(glimpse_mean_k, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x_color, z, emb,
                n_frames * n_obj, n_obj, channels);
   STOVE_LAUNCH_CHECK();
   return 0;

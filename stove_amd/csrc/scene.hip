@@ -162,29 +162,54 @@ __global__ void scene_finalize_bwd_k(const float* __restrict__ dll, const float*
 }
 
 // ---- object appearance embedding (Stove.object_embedding, stove.py:565-590): mean colour of every object's glimpse of
-// the colour frame.  thread = (glimpse, channel); the 100 bilinear samples of patches_from_z are taken on the fly, so the
+// the colour frame.  The 100 bilinear samples of patches_from_z are taken on the fly, so the
 // (frames x objects x channels x 32 x 32) expansion and the glimpse tensor of the PyTorch path never exist.
 // x_color [n_frames][C][1024], z [n_frames*n_obj][4] = [sx, sy, x, y] -> emb [n_frames*n_obj][C]
-__global__ void glimpse_mean_k(const float* __restrict__ x_color, const float* __restrict__ z, float* __restrict__ emb, int n_patches,
-                               int n_obj, int C) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_patches * C) return;
-  const int patch = t / C, c = t % C;
+// One wave per glimpse: lane = pixel (two passes cover the 100), the four taps of every channel as unconditional loads from
+// clamped coordinates with the in-bounds flag folded into the weight, then one wave reduction per channel.  (The first
+// version ran one THREAD per (glimpse, channel) through 400 taps, each load inside its own in-bounds branch: 246 us.)
+__global__ __launch_bounds__(256) void glimpse_mean_k(const float* __restrict__ x_color, const float* __restrict__ z, float* __restrict__ emb,
+                                                      int n_patches, int n_obj, int C) {
+  const int patch = blockIdx.x * (blockDim.x >> 6) + wave_id();
+  if (patch >= n_patches) return;           // wave-uniform
+  const int lane = lane_id();
   const int f = patch / n_obj;
   const float zk[4] = {z[(size_t)patch * 4], z[(size_t)patch * 4 + 1], z[(size_t)patch * 4 + 2], z[(size_t)patch * 4 + 3]};
-  const float* img = x_color + ((size_t)f * C + c) * kImg * kImg;
-  float acc = 0.0f;
-  for (int p = 0; p < kPD; ++p) {
-    const PatchPix q = patch_pix(zk, p);
+  const float* img = x_color + (size_t)f * C * kImg * kImg;
+  constexpr int CMAX = 4;
+  float acc[CMAX] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int p = lane + 64 * pass;
+    const bool live = p < kPD;
+    const PatchPix q = patch_pix(zk, live ? p : 0);
+    int off[4];
+    float wt[4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
+        const int iy = min(max(q.ty.i0 + a, 0), kImg - 1), ix = min(max(q.tx.i0 + b, 0), kImg - 1);
+        off[a * 2 + b] = iy * kImg + ix;
         const float inb = (a ? q.ty.in1 : q.ty.in0) * (b ? q.tx.in1 : q.tx.in0);
-        if (inb != 0.0f) acc = fmaf((a ? q.ty.t : 1.0f - q.ty.t) * (b ? q.tx.t : 1.0f - q.tx.t), img[(q.ty.i0 + a) * kImg + q.tx.i0 + b], acc);
+        wt[a * 2 + b] = live ? inb * (a ? q.ty.t : 1.0f - q.ty.t) * (b ? q.tx.t : 1.0f - q.tx.t) : 0.0f;
       }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      if (c < C) {
+        const float* ic = img + (size_t)c * kImg * kImg;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[c] = fmaf(wt[k], ic[off[k]], acc[c]);
+      }
+    }
   }
-  emb[t] = acc * (1.0f / kPD);
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    if (c < C) {
+      const float sum = wave_sum(acc[c]);
+      if (lane == c) emb[(size_t)patch * C + c] = sum * (1.0f / kPD);
+    }
+  }
 }
 
 // ---- frame rendering (Supair.reconstruct_from_z, supair.py:484-498): out = clamp(bg + sum_k paste(patch_k; z_k), 0, 1) with
