@@ -51,54 +51,65 @@ __global__ __launch_bounds__(256) void scene_tile_fwd_k(const float* __restrict_
   // workgroup = one batch of 64 glimpses, its 4 waves share the 100 pixels: the ~22 frames of a batch are then gathered by ONE
   // workgroup (one XCD's L2).  With (batch, pixel) items dealt round-robin over the whole grid every frame was pulled into
   // several L2s: 363 MB of HBM fetches per launch for 104 MB of frames (rocprofv3 FETCH_SIZE).
-  for (int item = 0;; ++item) {
-    const int b = blockIdx.x + (item / (kPD / 4)) * gridDim.x, p = wave_id() + 4 * (item % (kPD / 4));
-    if (b >= n_batches) break;
+  for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
     const int patch = b * 64 + lane;
-    float xv = 0.0f, wv = 0.0f;
-    if (patch < n_patches) {
-      const int f = patch / n_obj, k = patch % n_obj;
-      const float* zf = z + (size_t)f * n_obj * 4;
-      const float zk[4] = {zf[k * 4], zf[k * 4 + 1], zf[k * 4 + 2], zf[k * 4 + 3]};
+    const bool live = patch < n_patches;
+    const int pc = live ? patch : n_patches - 1;
+    const int f = pc / n_obj, k = pc % n_obj;
+    // per-glimpse constants of the 25 pixels this wave takes: the glimpse's transform and, for every EARLIER object of the
+    // frame (the occluders), its inverse transform -- two IEEE divisions each, which the per-(batch, pixel) item loop redid
+    // for every pixel
+    const float* zf = z + (size_t)f * n_obj * 4;
+    const float4 z4 = *reinterpret_cast<const float4*>(zf + k * 4);
+    const float zk[4] = {z4.x, z4.y, z4.z, z4.w};
+    float isx[NMAX], isy[NMAX], ox[NMAX], oy[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+      const float4 zj = *reinterpret_cast<const float4*>(zf + (j < n_obj ? j : 0) * 4);
+      isx[j] = 1.0f / zj.x;
+      isy[j] = 1.0f / zj.y;
+      ox[j] = -zj.z * isx[j];
+      oy[j] = -zj.w * isy[j];
+    }
+    const float* img = frames + fm.row(f) * (kImg * kImg);
+    for (int p = wave_id(); p < kPD; p += 4) {
       const PatchPix q = patch_pix(zk, p);
-      const float* img = frames + fm.row(f) * (kImg * kImg);
-      // earlier objects' coverage at the two tap columns / rows
-      float cx[NMAX][2], cy[NMAX][2];
+      // the four taps: unconditional loads from clamped coordinates, the in-bounds flags folded into the weights
+      float tap[4], wt[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int iy = min(max(q.ty.i0 + a, 0), kImg - 1), ix = min(max(q.tx.i0 + c, 0), kImg - 1);
+          tap[a * 2 + c] = img[iy * kImg + ix];
+          wt[a * 2 + c] = (a ? q.ty.in1 : q.ty.in0) * (c ? q.tx.in1 : q.tx.in0) * (a ? q.ty.t : 1.0f - q.ty.t) * (c ? q.tx.t : 1.0f - q.tx.t);
+        }
+      // earlier objects' coverage at the two tap columns / rows; run[a][c] = min(1, sum of their boxes) at tap (a, c)
+      float run[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int j = 0; j < NMAX; ++j) {
         if (j < k) {
-          const float isx = 1.0f / zf[j * 4], isy = 1.0f / zf[j * 4 + 1];
-          const float ox = -zf[j * 4 + 2] * isx, oy = -zf[j * 4 + 3] * isy;
           float d;
-          cx[j][0] = cover(inv_pix(isx, ox, q.tx.i0), kImg, &d);
-          cx[j][1] = cover(inv_pix(isx, ox, q.tx.i0 + 1), kImg, &d);
-          cy[j][0] = cover(inv_pix(isy, oy, q.ty.i0), kImg, &d);
-          cy[j][1] = cover(inv_pix(isy, oy, q.ty.i0 + 1), kImg, &d);
+          const float cx0 = cover(inv_pix(isx[j], ox[j], q.tx.i0), kImg, &d), cx1 = cover(inv_pix(isx[j], ox[j], q.tx.i0 + 1), kImg, &d);
+          const float cy0 = cover(inv_pix(isy[j], oy[j], q.ty.i0), kImg, &d), cy1 = cover(inv_pix(isy[j], oy[j], q.ty.i0 + 1), kImg, &d);
+          run[0] = fminf(run[0] + cx0 * cy0, 1.0f);
+          run[1] = fminf(run[1] + cx1 * cy0, 1.0f);
+          run[2] = fminf(run[2] + cx0 * cy1, 1.0f);
+          run[3] = fminf(run[3] + cx1 * cy1, 1.0f);
         }
       }
-      float seen = 0.0f;
+      float xv = 0.0f, seen = 0.0f;
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const float inb = (a ? q.ty.in1 : q.ty.in0) * (c ? q.tx.in1 : q.tx.in0);
-          if (inb != 0.0f) {
-            const float wt = (a ? q.ty.t : 1.0f - q.ty.t) * (c ? q.tx.t : 1.0f - q.tx.t);
-            xv = fmaf(wt, img[(q.ty.i0 + a) * kImg + q.tx.i0 + c], xv);
-            float run = 0.0f;
-#pragma unroll
-            for (int j = 0; j < NMAX; ++j)
-              if (j < k) run = fminf(run + cx[j][c] * cy[j][a], 1.0f);
-            seen = fmaf(wt, 1.0f - run, seen);
-          }
-        }
+      for (int t4 = 0; t4 < 4; ++t4) {
+        xv = fmaf(wt[t4], tap[t4], xv);
+        seen = fmaf(wt[t4], 1.0f - run[t4], seen);
       }
       const float mg = 1.0f - seen;                               // supair.py:331
-      wv = 1.0f - fminf(fmaxf(mg, 0.0f), 1.0f);                   // rat_torch.py:104-106
+      const float wv = 1.0f - fminf(fmaxf(mg, 0.0f), 1.0f);       // rat_torch.py:104-106
+      float* t = xw + ((size_t)b * kPD + p) * 2 * 64;
+      t[lane] = live ? xv : 0.0f;
+      t[64 + lane] = live ? wv : 0.0f;
     }
-    float* t = xw + ((size_t)b * kPD + p) * 2 * 64;
-    t[lane] = xv;
-    t[64 + lane] = wv;
   }
 }
 
