@@ -265,6 +265,35 @@ __global__ void sum_chunks4_k(const float* __restrict__ part, float* __restrict_
   reinterpret_cast<float4*>(out)[i] = a;
 }
 
+// The same for many chunks (split-K with 16+ slices): 256 threads = 64 float4 elements x 4 chunk slices, slice q adds chunks
+// q, q + 4, ..; the four slice sums are added in slice order (one thread walking 32 slices of a 1 MB product serially was
+// latency-bound: 50 us for 33 MB).
+__global__ __launch_bounds__(256) void sum_chunks4_par_k(const float* __restrict__ part, float* __restrict__ out, int n4, int chunks, int accumulate) {
+  __shared__ float4 red[4][64];
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
+  float4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (i < n4)
+    for (int c = q; c < chunks; c += 4) {
+      const float4 b = reinterpret_cast<const float4*>(part)[(size_t)c * n4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+  red[q][e] = a;
+  __syncthreads();
+  if (q == 0 && i < n4) {
+    float4 t = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      t.x += red[k][e].x; t.y += red[k][e].y; t.z += red[k][e].z; t.w += red[k][e].w;
+    }
+    if (accumulate) {
+      const float4 o = reinterpret_cast<const float4*>(out)[i];
+      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = t;
+  }
+}
+
 // Column sums of a row-major (rows, cols) matrix, stage 1: part[chunk][col] = sum of the chunk's rows (coalesced
 // float4 row reads); stage 2 is sum_chunks4_k.  (ATen's reduce_kernel runs this 105 MB reduction at 0.46 TB/s.)
 __global__ __launch_bounds__(256) void colsum_part_k(const float* __restrict__ a, float* __restrict__ part, int rows, int cols4, int rows_per_chunk) {

@@ -654,7 +654,10 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
   if (rc) return rc;
   if (splitk > 1) {
     const int n4 = (int)((size_t)M * N / 4);
-    STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, st, (const float*)ws, C, n4, splitk, acc_c ? 1 : 0);
+    if (splitk >= 16)
+      STOVE_LAUNCH(sum_chunks4_par_k, dim3((n4 + 63) / 64), dim3(256), 0, st, (const float*)ws, C, n4, splitk, acc_c ? 1 : 0);
+    else
+      STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, st, (const float*)ws, C, n4, splitk, acc_c ? 1 : 0);
     STOVE_LAUNCH_CHECK();
   }
   return 0;

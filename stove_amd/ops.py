@@ -938,9 +938,14 @@ class _EncoderLstmFn(torch.autograd.Function):
                     else:
                         dh = torch.addmm(dhs[k - 1], dg, w_hh)
             if views is not None:
-                on_side(lambda: wgrad(dgx, x, out=views[0]), dgx, x)
-                ws = torch.empty(lib.stove_colsum_ws_floats(n, 4 * H) + 1, dtype=torch.float32, device=dev)
-                check(lib.stove_colsum2(ptr(dgx), ptr(views[2]), ptr(views[3]), 1, ptr(ws), n, 4 * H, stream()), 'stove_colsum2')
+                # the bias sums join dW_hh on the second stream; dW_ih, the last and longest product, stays on this one, so the
+                # step's final join finds the second stream long finished (a join the main stream has to WAIT at costs ~40 us
+                # of inter-queue signalling on top of the work)
+                def bias_sums():
+                    ws = torch.empty(lib.stove_colsum_ws_floats(n, 4 * H) + 1, dtype=torch.float32, device=dev)
+                    check(lib.stove_colsum2(ptr(dgx), ptr(views[2]), ptr(views[3]), 1, ptr(ws), n, 4 * H, stream()), 'stove_colsum2')
+                on_side(bias_sums, dgx)
+                wgrad(dgx, x, out=views[0])
                 if fork:
                     torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_stream(side))
                 return None, None, None, None, None, None, None, None

@@ -17,7 +17,7 @@ def _ref(a, b, bias, ak, bk):
 
 @pytest.mark.parametrize('ak,bk', [(False, False), (False, True), (True, True), (True, False)])
 @pytest.mark.parametrize('M,N,K,splitk', [(256, 128, 32, 1), (512, 256, 96, 1), (300, 132, 100, 1), (20, 1024, 1024, 1),
-                                            (1024, 256, 3000, 8), (64, 64, 4, 3)])
+                                            (1024, 256, 3000, 8), (64, 64, 4, 3), (260, 256, 20000, 32)])
 def test_gemm_layouts_and_edges(ak, bk, M, N, K, splitk):
     from stove_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
