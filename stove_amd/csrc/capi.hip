@@ -139,9 +139,9 @@ int stove_bgspn_bwd(const StoveSpnTables* t, const float* inputs, const float* m
 }
 
 // ---------------------------------------------------------------- fused scene likelihood
-// saved = [ xw tile | obj_ll (np) | ovl (np) | bg_out (nf) | bg_ell | object-SPN forward state ]
+// saved = [ xw tile | obj_ll (np) | ovl (np) | bg_out (nf) | bg_ell | object-SPN forward state | box coverage tables ]
 struct SceneSaved {
-  size_t xw, obj_ll, ovl, bg_out, bg_ell, obj_state, total;
+  size_t xw, obj_ll, ovl, bg_out, bg_ell, obj_state, cover, total;
 };
 static SceneSaved scene_saved_layout(int nf, int n_obj) {
   const size_t np = (size_t)nf * n_obj;
@@ -152,7 +152,8 @@ static SceneSaved scene_saved_layout(int nf, int n_obj) {
   s.bg_out = s.ovl + align64(np);
   s.bg_ell = s.bg_out + align64(nf);
   s.obj_state = s.bg_ell + align64(bgspn_fwd_ws_floats(nf));
-  s.total = s.obj_state + align64(objspn_state_floats((int)np));
+  s.cover = s.obj_state + align64(objspn_state_floats((int)np));
+  s.total = s.cover + align64(bg_cover_floats(nf, n_obj));
   return s;
 }
 
@@ -201,6 +202,8 @@ int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z
                       saved + L.obj_state);
   if (rc) return rc;
   rc = bgspn_forward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, sb, fm);
+  if (rc) return rc;
+  rc = bg_cover_tables(z, saved + L.cover, n_frames, n_obj, sb);       // for the backward of this z
   if (rc) return rc;
   STOVE_TRY(jb.join());
   STOVE_LAUNCH(scene_assemble_fwd_k, dim3((n_frames + 255) / 256), dim3(256), 0, st, saved + L.bg_out, saved + L.obj_ll,
@@ -275,7 +278,7 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
     if (rc) return rc;
   }
   rc = bgspn_backward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, dll,
-                      nullptr, nullptr, ws + W.dz_bg, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, sb, sp == st ? sb : sp, fm);
+                      nullptr, nullptr, ws + W.dz_bg, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, sb, sp == st ? sb : sp, fm, saved + L.cover);
   if (rc) return rc;
   // the tail joins `sb` before its last kernel (dz_bg; without a parameter stream also the bg table grads)
   if (n_obj <= 3)

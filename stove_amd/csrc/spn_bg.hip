@@ -521,6 +521,17 @@ int bgspn_forward(const float* frames, const float* marg, const float* z, int n_
   return 0;
 }
 
+// the backward's per-(frame, object) coverage tables depend on z only: the scene forward makes them on its background stream,
+// where that chain has slack, instead of the backward making them at the head of its longest chain
+size_t bg_cover_floats(int n_frames, int n_obj) { return (size_t)n_frames * n_obj * kBgTab; }
+int bg_cover_tables(const float* z, float* T, int n_frames, int n_obj, hipStream_t st) {
+  const int pairs = n_frames * n_obj;
+  if (pairs == 0) return 0;
+  STOVE_LAUNCH(bg_cover_tables_k, dim3((pairs + 3) / 4), dim3(256), 0, st, z, T, pairs);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
 size_t bgspn_bwd_ws_floats(int n_frames, int n_obj = 0) {
   const size_t grid = bg_grid(n_frames);
   return (size_t)n_frames * (kBgNO + kBgR * (1 + 2 * kBgG)) + (size_t)n_frames * kBgHalves * 8 * 4 +
@@ -552,7 +563,7 @@ __global__ void bg_dz_halves_k(const float* __restrict__ dz_part, float* __restr
 int bgspn_backward(const float* frames, const float* marg, const float* z, int n_obj, const int* side, const float* coef,
                    const float* wroot, const float* ell_part, const float* out, const float* dout,
                    float* d_inputs, float* d_marg, float* dz, float* g_coef, float* g_wroot, float* ws,
-                   int n_frames, hipStream_t st, hipStream_t st_par = nullptr, FrameMap fm = FrameMap{0, 0}) {
+                   int n_frames, hipStream_t st, hipStream_t st_par = nullptr, FrameMap fm = FrameMap{0, 0}, const float* T_pre = nullptr) {
   if (st_par == nullptr) st_par = st;          // stream of the parameter-gradient reductions (see objspn_backward)
   if (n_frames == 0) {
     hipMemsetAsync(g_coef, 0, sizeof(float) * kBgR * kBgPix * kBgG * 3, st);
@@ -571,7 +582,9 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
   STOVE_LAUNCH((bgspn_root_bwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, dout, dell, rsc, n_frames, halves);
   STOVE_LAUNCH_CHECK();
   const bool scene = z != nullptr;
-  if (scene) {
+  if (scene && T_pre != nullptr) {
+    T = const_cast<float*>(T_pre);          // the coverage tables of this z, made by the forward (bg_cover_tables)
+  } else if (scene) {
     const int pairs = n_frames * n_obj;
     STOVE_LAUNCH(bg_cover_tables_k, dim3((pairs + 3) / 4), dim3(256), 0, st, z, T, pairs);
     STOVE_LAUNCH_CHECK();
