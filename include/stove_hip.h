@@ -264,6 +264,10 @@ int stove_bw_transform(const float* x, float* out, int n_frames, int channels, i
  * recognition network: 25 600 x 1024, 76 800 x 50, 76 800 x 8); ws: stove_colsum_ws_floats(rows, cols) floats.  Fixed summation order. */
 size_t stove_colsum_ws_floats(int rows, int cols);
 int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void* stream);
+/* out (M, N) = a^T b over the rows of a (rows, M), b (rows, N), M * N <= 256 (weight gradient of a narrow linear layer over
+ * many rows); ws: stove_small_tn_ws_floats floats; fixed summation order. */
+size_t stove_small_tn_ws_floats(int rows, int M, int N);
+int stove_small_tn(const float* a, const float* b, float* out, float* ws, int rows, int M, int N, void* stream);
 /* the same with a second output receiving the same sums (b_ih and b_hh of an LSTM) and accumulate != 0: added to the outputs */
 int stove_colsum2(const float* a, float* out, float* out2, int accumulate, float* ws, int rows, int cols, void* stream);
 

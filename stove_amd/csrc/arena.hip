@@ -294,6 +294,27 @@ __global__ __launch_bounds__(256) void sum_chunks4_par_k(const float* __restrict
   }
 }
 
+// out (M, N) = a^T b over the rows of a (rows, M) and b (rows, N) with M * N <= 256: weight gradient of a narrow linear layer
+// (the action embedding 9 -> 12, the reward heads) over ~25 000 rows.  As a library GEMM this is a 16 x 16 x 256 tile on one
+// or sixteen workgroups (83 us); here one thread per output walks a chunk of rows (both operands' rows are L1 lines shared by
+// the whole block), stage 2 is reduce_chunks_k.
+__global__ __launch_bounds__(256) void small_tn_part_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part,
+                                                        int rows, int M, int N, int rows_per_chunk) {
+  const int t = threadIdx.x;
+  if (t >= M * N) return;
+  const int m = t / N, n = t % N;
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+  float s0 = 0.0f, s1 = 0.0f;
+  int r = r0;
+  for (; r + 1 < r1; r += 2) {
+    s0 = fmaf(a[(size_t)r * M + m], b[(size_t)r * N + n], s0);
+    s1 = fmaf(a[(size_t)(r + 1) * M + m], b[(size_t)(r + 1) * N + n], s1);
+  }
+  if (r < r1) s0 = fmaf(a[(size_t)r * M + m], b[(size_t)r * N + n], s0);
+  part[(size_t)blockIdx.x * M * N + t] = s0 + s1;
+}
+
 // Column sums of a row-major (rows, cols) matrix, stage 1: part[chunk][col] = sum of the chunk's rows (coalesced
 // float4 row reads); stage 2 is sum_chunks4_k.  (ATen's reduce_kernel runs this 105 MB reduction at 0.46 TB/s.)
 __global__ __launch_bounds__(256) void colsum_part_k(const float* __restrict__ a, float* __restrict__ part, int rows, int cols4, int rows_per_chunk) {

@@ -725,6 +725,24 @@ int stove_colsum2(const float* a, float* out, float* out2, int accumulate, float
   return 0;
 }
 
+static int small_tn_chunks(int rows) { return rows < 64 ? 1 : (rows / 64 < 512 ? rows / 64 : 512); }
+size_t stove_small_tn_ws_floats(int rows, int M, int N) { return (size_t)small_tn_chunks(rows) * M * N; }
+
+int stove_small_tn(const float* a, const float* b, float* out, float* ws, int rows, int M, int N, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (M < 1 || N < 1 || M * N > 256) return (int)hipErrorInvalidValue;
+  if (rows == 0) {
+    hipMemsetAsync(out, 0, sizeof(float) * M * N, st);
+    return 0;
+  }
+  const int chunks = small_tn_chunks(rows), per = (rows + chunks - 1) / chunks;
+  STOVE_LAUNCH(small_tn_part_k, dim3(chunks), dim3(256), 0, st, a, b, ws, rows, M, N, per);
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH(reduce_chunks_k, dim3((M * N + 31) / 32), dim3(256), 0, st, (const float*)ws, out, M * N, chunks, 0);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
 size_t stove_flat_adam_ws_bytes(int nseg) { return (size_t)nseg * sizeof(int) + ADAM_SCAN_BLOCKS * sizeof(float); }
 
 int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, size_t numel,

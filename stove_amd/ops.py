@@ -635,6 +635,17 @@ def colsum(a):
     return out
 
 
+def small_tn(a, b):
+    """a^T @ b for a (rows, M), b (rows, N) with M * N <= 256 (csrc/arena.hip small_tn_part_k), fixed order."""
+    lib = _lib.load()
+    rows, M, N = a.shape[0], a.shape[1], b.shape[1]
+    with torch.cuda.device(a.device):
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        ws = torch.empty(lib.stove_small_tn_ws_floats(rows, M, N) + 1, dtype=torch.float32, device=a.device)
+        check(lib.stove_small_tn(ptr(a), ptr(b), ptr(out), ptr(ws), rows, M, N, stream()), 'stove_small_tn')
+    return out
+
+
 class _LinearFn(torch.autograd.Function):
     """torch.nn.functional.linear on a 2-D fp32 input with the bias gradient as a chunked column sum: ATen reduces the
     (76 800, 50) head gradients of the recognition network at 0.07 TB/s (226 us per step), csrc/arena.hip takes ~10 us."""
@@ -649,7 +660,12 @@ class _LinearFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
         gx = torch.mm(g, weight) if ctx.needs_input_grad[0] else None
-        gw = _splitk_tn(g, x) if ctx.needs_input_grad[1] else None          # (out, in) = g^T x over all rows: split-K
+        gw = None
+        if ctx.needs_input_grad[1]:
+            if g.shape[1] * x.shape[1] <= 256 and g.shape[0] >= 2048 and g.dtype == torch.float32 and x.dtype == torch.float32 and g.is_cuda:
+                gw = small_tn(g, x.contiguous())                              # narrow layer over many rows: one thread per output
+            else:
+                gw = _splitk_tn(g, x)                                         # (out, in) = g^T x over all rows: split-K
         gb = colsum(g) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
 

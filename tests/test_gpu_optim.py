@@ -86,3 +86,17 @@ def test_flat_adam_matches_torch_adam_with_late_and_frozen_parameters(amsgrad):
     assert opt2._seg_steps.tolist() == opt._seg_steps.tolist()
     for k in opt._flat:
         assert float((opt2._flat[k] - opt._flat[k]).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize('rows,M,N', [(25088, 12, 9), (3000, 1, 8), (2048, 16, 16), (5, 3, 4), (0, 2, 2)])
+def test_small_tn_weight_gradient(rows, M, N):
+    """a^T b for narrow operands over many rows (the action embedding's weight gradient): against float64, bit-reproducible."""
+    from stove_amd import ops
+    g = torch.Generator().manual_seed(rows + M)
+    a, b = torch.randn(rows, M, generator=g), torch.randn(rows, N, generator=g)
+    got = ops.small_tn(a.to(DEV), b.to(DEV))
+    ref = a.double().t() @ b.double()
+    assert got.shape == (M, N)
+    if rows:
+        assert float((got.cpu().double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(got, ops.small_tn(a.to(DEV), b.to(DEV)))
