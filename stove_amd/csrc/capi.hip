@@ -505,10 +505,10 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
     if (rc) return rc;
     if (em)
       STOVE_LAUNCH(dyn_loop_bwd_small_k<true>, dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, params,
-                   const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim, lim_enc, elu, kc);
+                   const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps);
     else
       STOVE_LAUNCH(dyn_loop_bwd_small_k<false>, dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, params,
-                   const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim, lim_enc, elu, kc);
+                   const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps);
     STOVE_LAUNCH_CHECK();
     rc = (int)hipFuncSetAttribute((const void*)gnn_dw_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDwLdsFloats * sizeof(float)));
     if (rc) return rc;

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     float* __restrict__ act, const float* __restrict__ dz, const float* __restrict__ dzdyn, const float* __restrict__ dmean,
     const float* __restrict__ dstd, const float* __restrict__ dpred, float* __restrict__ dz1, float* __restrict__ dzsup,
     float* __restrict__ dzsstd, float* __restrict__ dextra, float* __restrict__ dy, int B, int Ts, int N, int sin_dim, int lim_enc,
-    int elu, LoopConst kc) {
+    int elu, LoopConst kc, long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const SmBLds L = smb_carve(lds);
   const int b = blockIdx.x;
@@ -228,6 +228,8 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
   }
   WG_SYNC();
   for (int ts = Ts - 1; ts >= 0; --ts) {
+    cf.stamps = (ts == 1 && stamps != nullptr) ? stamps + 64 : nullptr;       // second half of the debug buffer
+    sm_stamp(cf, 0);
     const SmAct a = sm_act2(aseq, N, Ts, ts);
     const SmDy g = sm_dy(dseq, N, Ts, ts);
     const size_t o = ((size_t)b * Ts + ts) * N + r;
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
       }
       const float hi_from = sm_from_lane(hi, (lane & 32) + ((l + 16) & 31));      // lane l >= 16 takes hi of lane l - 16
       const float dres = l < 16 ? lo : hi_from;
+      sm_stamp(cf, 6);
       // b1. out.1
       wb = sm_wload<8>(L.W + W_O0, 64, l);
       const float db = (sm_dotw<8>(wa, dres) + dres) * (1.0f - cur.O1 * cur.O1);
@@ -324,7 +327,9 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
         g.dSD[r * 32 + l] = dSD;
       }
     }
+    sm_stamp(cf, 1);
     WG_SYNC();
+    sm_stamp(cf, 2);
     // ---- Q3: edges: half 0 = relation chain, half 1 = attention chain -----------------------------------------------
     if (EM) {
       smb_edge_phase_mfma(L, el, ein, g, elu);
@@ -382,7 +387,9 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
         if (lane == 0) g.dq[q] = dq;
       }
     }
+    sm_stamp(cf, 3);
     WG_SYNC();
+    sm_stamp(cf, 4);
     // ---- Q2: node rows: first edge layer, self-dynamics, encoder backwards ------------------------------------------
     if (node) {
       // dP[r][c], c = lane + 64 g: relation / attention, r as first (s_i) or second (s_j) argument
@@ -402,19 +409,30 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
         dpr[lane + 64 * gq] = dp[gq];
         g.dP[r * 256 + lane + 64 * gq] = dp[gq];
       }
+      sm_stamp(cf, 7);
       SmW<8> wa = sm_wload<8>(L.W + W_S1, 32, l);
       // dS from the edge layers: dP (256) W_ef (256 x 32); the two half-waves split the 256 terms
       v2f s0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f};
-#pragma unroll 4
-      for (int k4 = 0; k4 < 32; ++k4) {
-        const float4 w = *reinterpret_cast<const float4*>(L.W + W_EF + ((32 * h + k4) * 32 + l) * 4);
-        const float4 x = *reinterpret_cast<const float4*>(dpr + 128 * h + 4 * k4);
-        s0 = pk_fma(v2f{w.x, w.y}, v2f{x.x, x.y}, s0);
-        s1 = pk_fma(v2f{w.z, w.w}, v2f{x.z, x.w}, s1);
+      // four rounds of 8 weight + 8 operand reads, all of a round in flight before its FMAs (at 4 per round the loop was
+      // LDS latency: 3.0 k cycles of a 15.4 k step, profiles/r02_loop_stamps_bwd.txt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 w[8], x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          w[u] = *reinterpret_cast<const float4*>(L.W + W_EF + ((32 * h + 8 * q + u) * 32 + l) * 4);
+          x[u] = *reinterpret_cast<const float4*>(dpr + 128 * h + 4 * (8 * q + u));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          s0 = pk_fma(v2f{w[u].x, w[u].y}, v2f{x[u].x, x[u].y}, s0);
+          s1 = pk_fma(v2f{w[u].z, w[u].w}, v2f{x[u].z, x[u].w}, s1);
+        }
       }
       s0 += s1;
       float dS_edge = s0.x + s0.y;
       dS_edge += sm_from_lane(dS_edge, lane ^ 32);
+      sm_stamp(cf, 8);
       // b11. self.1:  SD = H1 W^T + b + H1
       SmW<8> wb = sm_wload<8>(L.W + W_S0, 32, l);
       const float dH1p = (sm_dotw<8>(wa, dSD) + dSD) * dphi_from_out(cur.H1, elu);
@@ -438,6 +456,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
       }
       car = (l < 16) ? dsin + (l < 2 ? pc : 0.0f) : 0.0f;
     }
+    sm_stamp(cf, 5);
   }
   if (node) {
     const float shifted = sm_from_lane(car, (lane + 62) & 63);      // all lanes take part: a bpermute reads 0 from inactive source lanes
