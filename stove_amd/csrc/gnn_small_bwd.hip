@@ -269,14 +269,17 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
       float lo = 0.0f, hi = 0.0f;
       if (l < 16) {
         const int d = l;
+        // reciprocals by v_rcp_f32 (1 ulp) instead of IEEE division sequences (~10 instructions each, four of them on the
+        // serial chain of every step): these values only scale gradients
         const float kd = std_scale(d, kc);
-        const float m = 2.0f * sigmoidf_(cur.RES) - 1.0f;
-        const float sd = kd * sigmoidf_(res_hi);
+        const float m = 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-cur.RES)) - 1.0f;
+        const float sg_hi = __builtin_amdgcn_rcpf(1.0f + __expf(-res_hi));
+        const float sd = kd * sg_hi;
         const float zd = m + (d < 2 ? cur.SIN : 0.0f);
         float gzd = cur.gzd_in, gsd;
         if (d < 4) {
           const float ms = cur.ms, ss = cur.ss;
-          const float sd2 = sd * sd, ss2 = ss * ss, D = sd2 + ss2, iD = 1.0f / D;
+          const float sd2 = sd * sd, ss2 = ss * ss, D = sd2 + ss2, iD = __builtin_amdgcn_rcpf(D);
           const float mu = (ss2 * zd + sd2 * ms) * iD;
           const float rD = rsqrtf(D);
           gzd += gmu * ss2 * iD;
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
         }
         if (d < 2) pc = gzd;                              // z_dyn position = previous position + delta
         lo = gzd * 0.5f * (1.0f - m * m);
-        hi = gsd * sd * (1.0f - sd / kd);
+        hi = gsd * sd * (1.0f - sg_hi);
       } else if (l < 18 && lane < 32) {
         dzsup[o * 6 + (l - 16)] = gmu;
         dzsstd[o * 6 + (l - 16)] = gsg;
