@@ -429,8 +429,9 @@ def test_elbo_assembly_against_torch():
         assert err(a, t.grad) < 1e-5
 
 
-@pytest.mark.parametrize('n_obj', [2, 4])
-def test_small_graph_recursion_matches_step_kernels(n_obj):
+@pytest.mark.parametrize('nonlinear', ['relu', 'leaky_relu'])      # the second one selects F.elu (the reference's quirk, dynamics.py:107-110)
+@pytest.mark.parametrize('n_obj', [2, 3, 4])
+def test_small_graph_recursion_matches_step_kernels(n_obj, nonlinear):
     """The small-graph time loop (csrc/gnn_small*.hip: N = 2 and 4 have no goldens) against the host loop over the
     single-step MFMA kernel + PyTorch autograd: ELBO, every gradient, and the rollout."""
     from stove_amd.video_prediction.stove import Stove
@@ -446,7 +447,7 @@ def test_small_graph_recursion_matches_step_kernels(n_obj):
         return noise[key]
     res = []
     for fused in (True, False):
-        st = fill_analytic(Stove(make_cfg(num_obj=n_obj, fused_dynamics=fused, debug_match_objects='greedy'))).to(DEV)
+        st = fill_analytic(Stove(make_cfg(num_obj=n_obj, fused_dynamics=fused, debug_match_objects='greedy', debug_nonlinear=nonlinear))).to(DEV)
         st.noise_fn = noise_fn
         elbo, prop, _ = st(x, 0, None)
         (-elbo).backward()
