@@ -436,14 +436,19 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
   if (N <= 4 && N >= 2) {      // small graphs: row-per-wave VALU formulation, two barriers per step (gnn_small.hip)
     // STOVE_LOOP_VALU=1: the all-VALU edge phase (A/B switch; the default runs the edge chains on the matrix cores)
     static const bool em = !(getenv("STOVE_LOOP_VALU") != nullptr && getenv("STOVE_LOOP_VALU")[0] == '1');
-#define STOVE_LOOP_LAUNCH_E(SAVE_, EM_, ELU_, STREAMS)                                                                          \
+#define STOVE_LOOP_LAUNCH_N(SAVE_, EM_, ELU_, NT_, STREAMS)                                                                     \
   do {                                                                                                                          \
-    int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_fwd_small_k<SAVE_, EM_, ELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_fwd_small_k<SAVE_, EM_, ELU_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)(kSmLdsFloats * sizeof(float)));                                                     \
     if (rc) return rc;                                                                                                          \
-    STOVE_LAUNCH((dyn_loop_fwd_small_k<SAVE_, EM_, ELU_>), dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream, \
+    STOVE_LAUNCH((dyn_loop_fwd_small_k<SAVE_, EM_, ELU_, NT_>), dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream, \
                  z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, \
                  g_sm_stamps, STREAMS);                                                                                         \
+  } while (0)
+#define STOVE_LOOP_LAUNCH_E(SAVE_, EM_, ELU_, STREAMS)                  \
+  do {                                                                  \
+    if (N == 3) STOVE_LOOP_LAUNCH_N(SAVE_, EM_, ELU_, 3, STREAMS);      \
+    else STOVE_LOOP_LAUNCH_N(SAVE_, EM_, ELU_, 0, STREAMS);             \
   } while (0)
 #define STOVE_LOOP_LAUNCH(SAVE_, EM_, STREAMS)                \
   do {                                                        \
@@ -459,6 +464,7 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
     }
 #undef STOVE_LOOP_LAUNCH
 #undef STOVE_LOOP_LAUNCH_E
+#undef STOVE_LOOP_LAUNCH_N
     STOVE_LAUNCH_CHECK();
     return 0;
   }
@@ -507,20 +513,26 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
     float* dy = gpart + (size_t)B * kGnnGrads;
     static const bool em = !(getenv("STOVE_LOOP_VALU") != nullptr && getenv("STOVE_LOOP_VALU")[0] == '1');     // as stove_dynloop_fwd
     int rc = 0;
-#define STOVE_LOOPB_LAUNCH(EM_, ELU_)                                                                                                 \
+#define STOVE_LOOPB_LAUNCH_N(EM_, ELU_, NT_)                                                                                               \
   do {                                                                                                                                \
-    rc = (int)hipFuncSetAttribute((const void*)dyn_loop_bwd_small_k<EM_, ELU_>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
+    rc = (int)hipFuncSetAttribute((const void*)dyn_loop_bwd_small_k<EM_, ELU_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                   (int)(kSmBLdsFloats * sizeof(float)));                                                              \
     if (rc) return rc;                                                                                                                \
-    STOVE_LAUNCH((dyn_loop_bwd_small_k<EM_, ELU_>), dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, \
+    STOVE_LAUNCH((dyn_loop_bwd_small_k<EM_, ELU_, NT_>), dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, \
                  params, const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim,   \
                  lim_enc, elu, kc, g_sm_stamps);                                                                                      \
+  } while (0)
+#define STOVE_LOOPB_LAUNCH(EM_, ELU_)                       \
+  do {                                                      \
+    if (N == 3) STOVE_LOOPB_LAUNCH_N(EM_, ELU_, 3);         \
+    else STOVE_LOOPB_LAUNCH_N(EM_, ELU_, 0);                \
   } while (0)
     if (em && elu) STOVE_LOOPB_LAUNCH(true, true);
     else if (em) STOVE_LOOPB_LAUNCH(true, false);
     else if (elu) STOVE_LOOPB_LAUNCH(false, true);
     else STOVE_LOOPB_LAUNCH(false, false);
 #undef STOVE_LOOPB_LAUNCH
+#undef STOVE_LOOPB_LAUNCH_N
     STOVE_LAUNCH_CHECK();
     rc = (int)hipFuncSetAttribute((const void*)gnn_dw_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDwLdsFloats * sizeof(float)));
     if (rc) return rc;
@@ -551,17 +563,23 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
   LoopConst kc{pos_var, vel_std, lat_std};
   if (N <= 4 && N >= 2) {
     int rc;
-#define STOVE_ROLL_LAUNCH(ELU_)                                                                                                      \
+#define STOVE_ROLL_LAUNCH_N(ELU_, NT_)                                                                                                   \
   do {                                                                                                                               \
-    rc = (int)hipFuncSetAttribute((const void*)rollout_fwd_small_k<true, ELU_>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+    rc = (int)hipFuncSetAttribute((const void*)rollout_fwd_small_k<true, ELU_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                   (int)(kSmLdsFloats * sizeof(float)));                                                              \
     if (rc) return rc;                                                                                                               \
-    STOVE_LAUNCH((rollout_fwd_small_k<true, ELU_>), dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream, \
+    STOVE_LAUNCH((rollout_fwd_small_k<true, ELU_, NT_>), dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream, \
                  z_last, extra, params, z_pred, zstd, pred, B, num, A < 1 ? 1 : A, N, sin_dim, lim_enc, elu, kc);                    \
+  } while (0)
+#define STOVE_ROLL_LAUNCH(ELU_)                      \
+  do {                                               \
+    if (N == 3) STOVE_ROLL_LAUNCH_N(ELU_, 3);        \
+    else STOVE_ROLL_LAUNCH_N(ELU_, 0);               \
   } while (0)
     if (elu) STOVE_ROLL_LAUNCH(true);
     else STOVE_ROLL_LAUNCH(false);
 #undef STOVE_ROLL_LAUNCH
+#undef STOVE_ROLL_LAUNCH_N
     STOVE_LAUNCH_CHECK();
     return 0;
   }

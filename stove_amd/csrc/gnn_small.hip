@@ -685,7 +685,7 @@ __device__ __forceinline__ float sm_from_lane(float v, int src_lane) {
 // =================================================================================================
 // inference recursion, same contract as dyn_loop_fwd_k (gnn.hip) with G = 1: grid = B sequences
 // =================================================================================================
-template <bool SAVE, bool EM, bool ELU>
+template <bool SAVE, bool EM, bool ELU, int NT>      // NT > 0: the number of objects at compile time (3: the headline shape)
 __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
@@ -697,6 +697,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
   const int b = blockIdx.x;
   const int wv = wave_id(), lane = lane_id(), l = lane & 31;
   elu = ELU ? 1 : 0;      // compile-time activation: with a run-time flag every phi carried the ocml expm1f path (code, registers, branches)
+  if (NT > 0) N = NT;       // loops over the objects unroll, their LDS reads go out together
   SmCfg cf{N, sin_dim, lim_enc, elu};
   cf.stamps = nullptr;
   sm_edges(cf);
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
 // =================================================================================================
 // generative rollout, same contract as rollout_fwd_k (gnn.hip) with G = 1
 // =================================================================================================
-template <bool EM, bool ELU>
+template <bool EM, bool ELU, int NT>
 __global__ __launch_bounds__(64 * kSmWaves) void rollout_fwd_small_k(const float* __restrict__ z_last, const float* __restrict__ extra,
                                                            const float* __restrict__ P, float* __restrict__ z_pred,
                                                            float* __restrict__ zstd, float* __restrict__ pred,
@@ -788,6 +789,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void rollout_fwd_small_k(const float
   const int b = blockIdx.x;
   const int wv = wave_id(), lane = lane_id(), l = lane & 31;
   elu = ELU ? 1 : 0;      // compile-time activation: with a run-time flag every phi carried the ocml expm1f path (code, registers, branches)
+  if (NT > 0) N = NT;       // loops over the objects unroll, their LDS reads go out together
   SmCfg cf{N, sin_dim, lim_enc, elu};
   cf.stamps = nullptr;
   sm_edges(cf);
