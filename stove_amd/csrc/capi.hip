@@ -443,7 +443,7 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
     if (rc) return rc;                                                                                                          \
     STOVE_LAUNCH((dyn_loop_fwd_small_k<SAVE_, EM_, ELU_, NT_>), dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream, \
                  z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, \
-                 g_sm_stamps, STREAMS);                                                                                         \
+                 g_sm_stamps);                                                                                                  \
   } while (0)
 #define STOVE_LOOP_LAUNCH_E(SAVE_, EM_, ELU_, STREAMS)                  \
   do {                                                                  \
@@ -456,11 +456,16 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
     else STOVE_LOOP_LAUNCH_E(SAVE_, EM_, false, STREAMS);     \
   } while (0)
     if (act != nullptr) {
-      if (em) STOVE_LOOP_LAUNCH(true, true, small_bwd_enabled());
-      else STOVE_LOOP_LAUNCH(true, false, small_bwd_enabled());
+      if (small_bwd_enabled()) {
+        if (em) STOVE_LOOP_LAUNCH(2, true, 0);
+        else STOVE_LOOP_LAUNCH(2, false, 0);
+      } else {
+        if (em) STOVE_LOOP_LAUNCH(1, true, 0);
+        else STOVE_LOOP_LAUNCH(1, false, 0);
+      }
     } else {
-      if (em) STOVE_LOOP_LAUNCH(false, true, 0);
-      else STOVE_LOOP_LAUNCH(false, false, 0);
+      if (em) STOVE_LOOP_LAUNCH(0, true, 0);
+      else STOVE_LOOP_LAUNCH(0, false, 0);
     }
 #undef STOVE_LOOP_LAUNCH
 #undef STOVE_LOOP_LAUNCH_E

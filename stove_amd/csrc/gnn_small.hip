@@ -685,13 +685,17 @@ __device__ __forceinline__ float sm_from_lane(float v, int src_lane) {
 // =================================================================================================
 // inference recursion, same contract as dyn_loop_fwd_k (gnn.hip) with G = 1: grid = B sequences
 // =================================================================================================
-template <bool SAVE, bool EM, bool ELU, int NT>      // NT > 0: the number of objects at compile time (3: the headline shape)
+// SAVEM: 0 = inference, 1 = save the activations as per-step blocks (the backward of gnn.hip), 2 = as per-sequence streams
+// (gnn_small_bwd.hip); NT > 0: the number of objects at compile time (3: the headline shape)
+template <int SAVEM, bool EM, bool ELU, int NT>
 __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
     float* __restrict__ z, float* __restrict__ zdyn, float* __restrict__ zdstd, float* __restrict__ mean,
     float* __restrict__ stdv, float* __restrict__ pred, float* __restrict__ act,
-    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc, long long* stamps, int streams) {
+    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc, long long* stamps) {
+  constexpr bool SAVE = SAVEM != 0;
+  constexpr int streams = SAVEM == 2 ? 1 : 0;       // compile-time: the two pointer sets were both built every step and selected
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const SmLds L = sm_carve(lds);
   const int b = blockIdx.x;
