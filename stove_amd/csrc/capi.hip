@@ -518,26 +518,28 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
     float* dy = gpart + (size_t)B * kGnnGrads;
     static const bool em = !(getenv("STOVE_LOOP_VALU") != nullptr && getenv("STOVE_LOOP_VALU")[0] == '1');     // as stove_dynloop_fwd
     int rc = 0;
-#define STOVE_LOOPB_LAUNCH_N(EM_, ELU_, NT_)                                                                                               \
+#define STOVE_LOOPB_LAUNCH_H(EM_, ELU_, NT_, HD_)                                                                                               \
   do {                                                                                                                                \
-    rc = (int)hipFuncSetAttribute((const void*)dyn_loop_bwd_small_k<EM_, ELU_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+    rc = (int)hipFuncSetAttribute((const void*)dyn_loop_bwd_small_k<EM_, ELU_, NT_, HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)(kSmBLdsFloats * sizeof(float)));                                                              \
     if (rc) return rc;                                                                                                                \
-    STOVE_LAUNCH((dyn_loop_bwd_small_k<EM_, ELU_, NT_>), dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, \
+    STOVE_LAUNCH((dyn_loop_bwd_small_k<EM_, ELU_, NT_, HD_>), dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, \
                  params, const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim,   \
                  lim_enc, elu, kc, g_sm_stamps);                                                                                      \
   } while (0)
-#define STOVE_LOOPB_LAUNCH(EM_, ELU_)                       \
-  do {                                                      \
-    if (N == 3) STOVE_LOOPB_LAUNCH_N(EM_, ELU_, 3);         \
-    else STOVE_LOOPB_LAUNCH_N(EM_, ELU_, 0);                \
+    const bool head = dz != nullptr && dzdyn != nullptr && dmean != nullptr && dstd != nullptr && dpred == nullptr && sin_dim == 16 && lim_enc == 2;
+#define STOVE_LOOPB_LAUNCH(EM_, ELU_)                                     \
+  do {                                                                    \
+    if (N == 3 && head && EM_) STOVE_LOOPB_LAUNCH_H(EM_, ELU_, 3, EM_);   \
+    else if (N == 3) STOVE_LOOPB_LAUNCH_H(EM_, ELU_, 3, false);           \
+    else STOVE_LOOPB_LAUNCH_H(EM_, ELU_, 0, false);                       \
   } while (0)
     if (em && elu) STOVE_LOOPB_LAUNCH(true, true);
     else if (em) STOVE_LOOPB_LAUNCH(true, false);
     else if (elu) STOVE_LOOPB_LAUNCH(false, true);
     else STOVE_LOOPB_LAUNCH(false, false);
 #undef STOVE_LOOPB_LAUNCH
-#undef STOVE_LOOPB_LAUNCH_N
+#undef STOVE_LOOPB_LAUNCH_H
     STOVE_LAUNCH_CHECK();
     rc = (int)hipFuncSetAttribute((const void*)gnn_dw_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDwLdsFloats * sizeof(float)));
     if (rc) return rc;
