@@ -455,7 +455,13 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
     if (elu) STOVE_LOOP_LAUNCH_E(SAVE_, EM_, true, STREAMS);  \
     else STOVE_LOOP_LAUNCH_E(SAVE_, EM_, false, STREAMS);     \
   } while (0)
-    if (act != nullptr) {
+    if (g_sm_stamps != nullptr && act != nullptr && small_bwd_enabled() && em && !elu && N == 3) {      // tools/loop_stamps.py
+      int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_fwd_small_k<2, true, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(kSmLdsFloats * sizeof(float)));
+      if (rc) return rc;
+      STOVE_LAUNCH((dyn_loop_fwd_small_k<2, true, false, 3, true>), dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
+                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps);
+    } else if (act != nullptr) {
       if (small_bwd_enabled()) {
         if (em) STOVE_LOOP_LAUNCH(2, true, 0);
         else STOVE_LOOP_LAUNCH(2, false, 0);
@@ -534,7 +540,14 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
     else if (N == 3) STOVE_LOOPB_LAUNCH_H(EM_, ELU_, 3, false);           \
     else STOVE_LOOPB_LAUNCH_H(EM_, ELU_, 0, false);                       \
   } while (0)
-    if (em && elu) STOVE_LOOPB_LAUNCH(true, true);
+    if (g_sm_stamps != nullptr && em && !elu && N == 3 && head) {       // tools/loop_stamps.py
+      rc = (int)hipFuncSetAttribute((const void*)dyn_loop_bwd_small_k<true, false, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kSmBLdsFloats * sizeof(float)));
+      if (rc) return rc;
+      STOVE_LAUNCH((dyn_loop_bwd_small_k<true, false, 3, true, true>), dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd,
+                   eps, params, const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim,
+                   lim_enc, elu, kc, g_sm_stamps);
+    } else if (em && elu) STOVE_LOOPB_LAUNCH(true, true);
     else if (em) STOVE_LOOPB_LAUNCH(true, false);
     else if (elu) STOVE_LOOPB_LAUNCH(false, true);
     else STOVE_LOOPB_LAUNCH(false, false);

@@ -687,7 +687,7 @@ __device__ __forceinline__ float sm_from_lane(float v, int src_lane) {
 // =================================================================================================
 // SAVEM: 0 = inference, 1 = save the activations as per-step blocks (the backward of gnn.hip), 2 = as per-sequence streams
 // (gnn_small_bwd.hip); NT > 0: the number of objects at compile time (3: the headline shape)
-template <int SAVEM, bool EM, bool ELU, int NT>
+template <int SAVEM, bool EM, bool ELU, int NT, bool STAMP = false>      // STAMP: the phase stamps of tools/loop_stamps.py (one debug instantiation)
 __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
@@ -695,6 +695,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     float* __restrict__ stdv, float* __restrict__ pred, float* __restrict__ act,
     int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc, long long* stamps) {
   constexpr bool SAVE = SAVEM != 0;
+  if (!STAMP) stamps = nullptr;      // the 16 stamp sites of a step vanish (a run-time null check each was ~50 instructions per step)
   constexpr int streams = SAVEM == 2 ? 1 : 0;       // compile-time: the two pointer sets were both built every step and selected
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const SmLds L = sm_carve(lds);

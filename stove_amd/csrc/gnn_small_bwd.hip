@@ -197,7 +197,7 @@ __device__ __forceinline__ void smb_edge_phase_mfma(const SmBLds& L, const SmEdg
   }
 }
 
-template <bool EM, bool ELU, int NT, bool HEAD>
+template <bool EM, bool ELU, int NT, bool HEAD, bool STAMP = false>
 __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     const float* __restrict__ zsup, const float* __restrict__ zsstd, const float* __restrict__ eps, const float* __restrict__ P,
     float* __restrict__ act, const float* __restrict__ dz, const float* __restrict__ dzdyn, const float* __restrict__ dmean,
@@ -210,6 +210,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
   const int wv = wave_id(), lane = lane_id(), l = lane & 31, h = lane >> 5;
   elu = ELU ? 1 : 0;      // compile-time activation (see dyn_loop_fwd_small_k)
   if (NT > 0) N = NT;
+  if (!STAMP) stamps = nullptr;
   if (HEAD) {      // the training call of the plain model: all four state gradients present, no reward head, no extra inputs
     __builtin_assume(dz != nullptr);
     __builtin_assume(dzdyn != nullptr);
