@@ -474,10 +474,12 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
     const int r = wv;
     wa = sm_wload<8>(L.W + W_ENC, 32, o);
     const float benc = V[V_ENC + o];
-    // first half of the edge-first weights (k4 = 0..3, four column groups of 64) while the encoder computes
-    float4 ef[4][4];
+    // first quarter of the edge-first weights (k4 = 0, 1; four column groups of 64) while the encoder computes; the other
+    // quarters arrive one round ahead of their FMAs (two halves of 16 float4 held 128 registers of weights in a kernel that
+    // already parks registers in AGPRs)
+    float4 ef[2][4];
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4)
+    for (int k4 = 0; k4 < 2; ++k4)
 #pragma unroll
       for (int g = 0; g < 4; ++g) ef[k4][g] = *reinterpret_cast<const float4*>(L.W + W_EF + (k4 * 256 + g * 64 + lane) * 4);
     float e;
@@ -500,19 +502,19 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
     for (int k4 = 0; k4 < 8; ++k4) sx[k4] = *reinterpret_cast<const float4*>(&sbuf[wv][4 * k4]);
     v2f p[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float4 nx[4][4];
-      if (half == 0) {
+    for (int q = 0; q < 4; ++q) {
+      float4 nx[2][4];
+      if (q < 3) {
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4)
+        for (int k4 = 0; k4 < 2; ++k4)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) nx[k4][g] = *reinterpret_cast<const float4*>(L.W + W_EF + ((4 + k4) * 256 + g * 64 + lane) * 4);
+          for (int g = 0; g < 4; ++g) nx[k4][g] = *reinterpret_cast<const float4*>(L.W + W_EF + ((2 * (q + 1) + k4) * 256 + g * 64 + lane) * 4);
       } else if (!EM) {
         wb = sm_wload<8>(L.W + W_S0, 32, o);        // self-dynamics layer 0, used right after the barrier
       }
 #pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const float4 xq = sx[4 * half + k4];
+      for (int k4 = 0; k4 < 2; ++k4) {
+        const float4 xq = sx[2 * q + k4];
         const v2f x01 = {xq.x, xq.y}, x23 = {xq.z, xq.w};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -520,9 +522,9 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
           p[g] = pk_fma(v2f{ef[k4][g].z, ef[k4][g].w}, x23, p[g]);
         }
       }
-      if (half == 0) {
+      if (q < 3) {
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4)
+        for (int k4 = 0; k4 < 2; ++k4)
 #pragma unroll
           for (int g = 0; g < 4; ++g) ef[k4][g] = nx[k4][g];
       }

@@ -24,7 +24,7 @@ for it in range(3):
     out = ops.dyn_loop(z1, zsup, zsstd, eps, None, image, 2, False, dyn.loop_consts())
     torch.cuda.synchronize()
     fw = stamps.cpu().view(2, 4, 16).clone()      # [fwd | bwd][wave][phase]
-    (out[0].sum() + out[3].sum()).backward()
+    (out[0].sum() + out[1].sum() + out[3].sum() + out[4].sum()).backward()      # all four state gradients: the headline instantiation
     torch.cuda.synchronize()
     bw = stamps.cpu().view(2, 4, 16).clone()
 lib.stove_debug_set_stamps(None)
