@@ -479,10 +479,21 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
     STOVE_LAUNCH_CHECK();
     return 0;
   }
-  int rc = gnn_lds_attr((const void*)dyn_loop_fwd_k);
-  if (rc) return rc;
-  STOVE_LAUNCH(dyn_loop_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
-                     z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
+  const int G = gnn_group_for(B, N);
+  int rc = 0;
+#define STOVE_MLOOP_LAUNCH(ELU_, N6_)                                                                                                  \
+  do {                                                                                                                                 \
+    rc = gnn_lds_attr((const void*)dyn_loop_fwd_k<ELU_, N6_>);                                                                         \
+    if (rc) return rc;                                                                                                                 \
+    STOVE_LAUNCH((dyn_loop_fwd_k<ELU_, N6_>), dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream, \
+                 z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, G, sin_dim, lim_enc, elu, kc);  \
+  } while (0)
+  const bool n6 = N == 6 && G == 1;
+  if (elu && n6) STOVE_MLOOP_LAUNCH(true, true);
+  else if (elu) STOVE_MLOOP_LAUNCH(true, false);
+  else if (n6) STOVE_MLOOP_LAUNCH(false, true);
+  else STOVE_MLOOP_LAUNCH(false, false);
+#undef STOVE_MLOOP_LAUNCH
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -563,11 +574,22 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
     STOVE_LAUNCH_CHECK();
     return 0;
   }
-  int rc = gnn_lds_attr((const void*)dyn_loop_bwd_k);
-  if (rc) return rc;
-  const int nb = stove_gnn_blocks(B, N);
-  STOVE_LAUNCH(dyn_loop_bwd_k, dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, z1, zsup, zsstd, eps, extra, params, z, act,
-                     dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, (float*)ws, B, Ts, N, gnn_group_for(B, N), sin_dim, lim_enc, elu, kc);
+  const int nb = stove_gnn_blocks(B, N), G = gnn_group_for(B, N);
+  int rc = 0;
+#define STOVE_MLOOPB_LAUNCH(ELU_, N6_)                                                                                                 \
+  do {                                                                                                                                 \
+    rc = gnn_lds_attr((const void*)dyn_loop_bwd_k<ELU_, N6_>);                                                                         \
+    if (rc) return rc;                                                                                                                 \
+    STOVE_LAUNCH((dyn_loop_bwd_k<ELU_, N6_>), dim3(nb), dim3(256), kGnnLdsFloats * sizeof(float), st, z1, zsup, zsstd, eps, extra,     \
+                 params, z, act, dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, (float*)ws, B, Ts, N, G, sin_dim, lim_enc, \
+                 elu, kc);                                                                                                             \
+  } while (0)
+  const bool n6 = N == 6 && G == 1;
+  if (elu && n6) STOVE_MLOOPB_LAUNCH(true, true);
+  else if (elu) STOVE_MLOOPB_LAUNCH(true, false);
+  else if (n6) STOVE_MLOOPB_LAUNCH(false, true);
+  else STOVE_MLOOPB_LAUNCH(false, false);
+#undef STOVE_MLOOPB_LAUNCH
   STOVE_LAUNCH_CHECK();
   STOVE_TRY(stream_after(sp, st));
   STOVE_LAUNCH(reduce_chunks_k, dim3((kGnnGrads + 31) / 32), dim3(256), 0, sp, (const float*)ws, g_params, kGnnGrads, nb, 0);

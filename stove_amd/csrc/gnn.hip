@@ -1041,12 +1041,18 @@ __device__ __forceinline__ void loop_epilogue_fwd(const GnnLds& L, const GnnShap
   }
 }
 
+template <bool ELU, bool N6>
 __global__ __launch_bounds__(256) void dyn_loop_fwd_k(
     const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
     float* __restrict__ z, float* __restrict__ zdyn, float* __restrict__ zdstd, float* __restrict__ mean,
     float* __restrict__ stdv, float* __restrict__ pred, float* __restrict__ act,
     int B, int Ts, int N, int G, int sin_dim, int lim_enc, int elu, LoopConst kc) {
+  elu = ELU ? 1 : 0;       // compile-time activation (the ocml expm1f path of ELU otherwise sits in every phi)
+  if (N6) {                // six objects, one sequence per workgroup: BASELINE.json's multibilliards shape
+    N = 6;
+    G = 1;
+  }
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GnnLds L = carve(lds);
   const int b0 = blockIdx.x * G;
@@ -1086,6 +1092,7 @@ __global__ __launch_bounds__(256) void dyn_loop_fwd_k(
 
 // backward of the recursion.  Upstream gradients (any may be null): dz, dzdyn, dmean, dstd (B,Ts,N,.), dpred.
 // Outputs: dz1 (B,N,18), dzsup, dzsstd (B,Ts,N,6), dextra (B,Ts,N,E), gpart[block][kGnnGrads].
+template <bool ELU, bool N6>
 __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
     const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
@@ -1095,6 +1102,11 @@ __global__ __launch_bounds__(256) void dyn_loop_bwd_k(
     float* __restrict__ dz1, float* __restrict__ dzsup, float* __restrict__ dzsstd, float* __restrict__ dextra,
     float* __restrict__ gpart,
     int B, int Ts, int N, int G, int sin_dim, int lim_enc, int elu, LoopConst kc) {
+  elu = ELU ? 1 : 0;
+  if (N6) {
+    N = 6;
+    G = 1;
+  }
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const GnnLds L = carve(lds);
   const int b0 = blockIdx.x * G;
