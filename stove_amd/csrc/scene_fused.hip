@@ -37,6 +37,9 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
   constexpr int DT = R * 4 * G * 64;
   constexpr int RED = SLOTS * NMAX * 4 * 64;
   constexpr int CFT = D * R * 32;            // per (pixel, replica): the leaf's G x 3 coefficients (30 floats), leaf index, pad
+  // occluders of object k are the objects j < k of its frame: the last object occludes nobody, so NMAX - 1 occluder slots
+  // cover every case (a third of the per-pixel coverage work at three objects)
+  constexpr int NOCC = NMAX > 1 ? NMAX - 1 : 1;
   extern __shared__ __attribute__((aligned(16))) float pt_lds[];          // [CFT] coefficient rows by pixel | max(DT, RED): leaf gradients, then the slot reduction
   float* cft = pt_lds;
   float* dl = pt_lds + CFT;
@@ -69,9 +72,9 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
     const float* img = frames + fm.row(f) * (kImg * kImg);
     const float govl = live ? d_ovl[patch] * (-1.0f / kPD) : 0.0f;   // d overlap / d seen = -1/100
     // occluders j < k: q(X) = isx (X - 15.5) + cxo;  j >= k: coverage 0 everywhere
-    float isx[NMAX], isy[NMAX], cxo[NMAX], cyo[NMAX], xj[NMAX], yj[NMAX];
+    float isx[NOCC], isy[NOCC], cxo[NOCC], cyo[NOCC], xj[NOCC], yj[NOCC];
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) {
+    for (int j = 0; j < NOCC; ++j) {
       const bool occ = live && j < k;
       const float sx = occ ? zf[j * 4] : 1.0f, sy = occ ? zf[j * 4 + 1] : 1.0f;
       xj[j] = occ ? zf[j * 4 + 2] : 0.0f;
@@ -82,9 +85,9 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
       cyo[j] = occ ? fmaf(-16.0f * yj[j], isy[j], 15.5f) : -100.0f;
     }
     float own[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    float sx0[NMAX], sx2[NMAX], sy1[NMAX], sy3[NMAX];      // raw occluder sums: dqx (uu - x_j), dqx, dqy (vv - y_j), dqy
+    float sx0[NOCC], sx2[NOCC], sy1[NOCC], sy3[NOCC];      // raw occluder sums: dqx (uu - x_j), dqx, dqy (vv - y_j), dqy
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) sx0[j] = sx2[j] = sy1[j] = sy3[j] = 0.0f;
+    for (int j = 0; j < NOCC; ++j) sx0[j] = sx2[j] = sy1[j] = sy3[j] = 0.0f;
     __syncthreads();
     const float* tile = xw + (size_t)b * (D * 2 * 64);
     for (int p = slot; p < D; p += SLOTS) {
@@ -128,11 +131,11 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
       const float inb00 = q.ty.in0 * q.tx.in0, inb01 = q.ty.in0 * q.tx.in1, inb10 = q.ty.in1 * q.tx.in0, inb11 = q.ty.in1 * q.tx.in1;
       const float im00 = img[r0 * kImg + c0] * inb00, im01 = img[r0 * kImg + c1] * inb01;
       const float im10 = img[r1 * kImg + c0] * inb10, im11 = img[r1 * kImg + c1] * inb11;
-      float cx[NMAX][2], cy[NMAX][2], dcx[NMAX][2], dcy[NMAX][2];
+      float cx[NOCC][2], cy[NOCC][2], dcx[NOCC][2], dcy[NOCC][2];
       float s00 = 0.0f, s01 = 0.0f, s10 = 0.0f, s11 = 0.0f;     // mask sum at tap (row a, column c): s_ac
       const float fx = (float)q.tx.i0 - 15.5f, fy = (float)q.ty.i0 - 15.5f;
 #pragma unroll
-      for (int j = 0; j < NMAX; ++j) {
+      for (int j = 0; j < NOCC; ++j) {
         const float qx = fmaf(isx[j], fx, cxo[j]), qy = fmaf(isy[j], fy, cyo[j]);
         cx[j][0] = cover_cf(qx, &dcx[j][0]);
         cx[j][1] = cover_cf(qx + isx[j], &dcx[j][1]);
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
       const float uu0 = (2.0f * q.tx.i0 + 1.0f) * (1.0f / kImg) - 1.0f, uu1 = uu0 + 2.0f / kImg;
       const float vv0 = (2.0f * q.ty.i0 + 1.0f) * (1.0f / kImg) - 1.0f, vv1 = vv0 + 2.0f / kImg;
 #pragma unroll
-      for (int j = 0; j < NMAX; ++j) {
+      for (int j = 0; j < NOCC; ++j) {
         const float gx0 = fmaf(nb00, cy[j][0], nb10 * cy[j][1]) * dcx[j][0];     // column c = 0: sum over the two rows
         const float gx1 = fmaf(nb01, cy[j][0], nb11 * cy[j][1]) * dcx[j][1];
         const float gy0 = fmaf(nb00, cx[j][0], nb01 * cx[j][1]) * dcy[j][0];     // row a = 0: sum over the two columns
@@ -185,7 +188,9 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
       const bool mine = (j == k);
       // d q / d(1/s) etc.: q = (X - 15.5)/s + 15.5 - 16 x/s  =>  dL/ds = -16 (uu - x)/s^2 dL/dq,  dL/dx = -16/s dL/dq
       const float h = -0.5f * kImg;
-      const float a0 = h * isx[j] * isx[j] * sx0[j], a1 = h * isy[j] * isy[j] * sy1[j], a2 = h * isx[j] * sx2[j], a3 = h * isy[j] * sy3[j];
+      const int jo = j < NOCC ? j : 0;                      // the last object is nobody's occluder: its sums are zeros
+      const float sc = j < NOCC ? 1.0f : 0.0f;
+      const float a0 = sc * h * isx[jo] * isx[jo] * sx0[jo], a1 = sc * h * isy[jo] * isy[jo] * sy1[jo], a2 = sc * h * isx[jo] * sx2[jo], a3 = sc * h * isy[jo] * sy3[jo];
       red[(slot * NMAX * 4 + j * 4 + 0) * 64 + lane] = mine ? own[0] : a0;
       red[(slot * NMAX * 4 + j * 4 + 1) * 64 + lane] = mine ? own[1] : a1;
       red[(slot * NMAX * 4 + j * 4 + 2) * 64 + lane] = mine ? own[2] : a2;

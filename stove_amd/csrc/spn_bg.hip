@@ -251,12 +251,13 @@ __global__ void bg_cover_tables_k(const float* __restrict__ z, float* __restrict
 // SCENE: dz_part[frame][half][n_obj][4] (dsx, dsy, dx, dy of the pasted boxes)
 // else : d_marg[frame][p] (and d_inputs if non-null)
 // gcoef_part[block][r][p_local][g][3]
-template <int R, int G, bool SCENE, int NMAX>
+template <int R, int G, bool SCENE, int NMAX, bool EXACT = false>
 __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
     const float* __restrict__ frames, const float* __restrict__ marg, const float* __restrict__ z, int n_obj,
     const int* __restrict__ side, const float* __restrict__ coef, const float* __restrict__ dell,
     float* __restrict__ d_inputs, float* __restrict__ d_marg, float* __restrict__ dz_part,
     float* __restrict__ gcoef_part, int n_frames, const float* __restrict__ T, FrameMap fm) {
+  if (EXACT) n_obj = NMAX;      // the object count at compile time: the per-object predicates around the table loads go, the loads batch
   constexpr int NO = R * 2 * G;
   constexpr int NW = kBgThreads / 64;
   // SCENE: d box (= -dL/dw where no clamp fired) of the last NW frames, [slot][pixel of this half]; every NW frames the
@@ -543,7 +544,10 @@ static int bg_bwd_launch(bool scene, int grid, hipStream_t st, const float* fram
                          int n_obj, const int* side, const float* coef, const float* dell, float* d_inputs,
                          float* d_marg, float* dz_part, float* gpart, int n_frames, const float* T, FrameMap fm) {
   if (scene)
-    STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, true, NMAX>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T, fm);
+    if (n_obj == NMAX)
+      STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, true, NMAX, true>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T, fm);
+    else
+      STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, true, NMAX, false>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T, fm);
   else
     STOVE_LAUNCH((bgspn_bwd_k<kBgR, kBgG, false, 1>), dim3(grid), dim3(kBgThreads), 0, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T, fm);
   STOVE_LAUNCH_CHECK();
