@@ -62,9 +62,10 @@ __global__ __launch_bounds__(256) void scene_tile_fwd_k(const float* __restrict_
     const float* zf = z + (size_t)f * n_obj * 4;
     const float4 z4 = *reinterpret_cast<const float4*>(zf + k * 4);
     const float zk[4] = {z4.x, z4.y, z4.z, z4.w};
-    float isx[NMAX], isy[NMAX], ox[NMAX], oy[NMAX];
+    constexpr int NOCC = NMAX > 1 ? NMAX - 1 : 1;      // the last object of a frame occludes nobody
+    float isx[NOCC], isy[NOCC], ox[NOCC], oy[NOCC];
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) {
+    for (int j = 0; j < NOCC; ++j) {
       const float4 zj = *reinterpret_cast<const float4*>(zf + (j < n_obj ? j : 0) * 4);
       isx[j] = 1.0f / zj.x;
       isy[j] = 1.0f / zj.y;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void scene_tile_fwd_k(const float* __restrict_
       // earlier objects' coverage at the two tap columns / rows; run[a][c] = min(1, sum of their boxes) at tap (a, c)
       float run[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int j = 0; j < NMAX; ++j) {
+      for (int j = 0; j < NOCC; ++j) {
         if (j < k) {
           float d;
           const float cx0 = cover(inv_pix(isx[j], ox[j], q.tx.i0), kImg, &d), cx1 = cover(inv_pix(isx[j], ox[j], q.tx.i0 + 1), kImg, &d);
