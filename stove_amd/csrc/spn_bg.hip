@@ -491,7 +491,9 @@ int bgspn_forward(const float* frames, const float* marg, const float* z, int n_
     float* Cf = bg_dense_of(ell_part, n_frames);
     STOVE_LAUNCH(bg_dense_fwd_k, dim3((kBgDenseF + 255) / 256), dim3(256), 0, st, side, coef, Cf);
     STOVE_LAUNCH_CHECK();
-    constexpr int TPW = 2;
+    // one 16-frame tile per wave: at two tiles a launch over 25 344 frames was 198 workgroups of 4 waves -- three quarters of
+    // the CUs with one wave per SIMD; 396 workgroups pay the coefficient stream twice (L2) and win 12 % (129 -> 113 us)
+    constexpr int TPW = 1;
     const int waves = n_obj <= 4 ? 4 : 2;                                    // coverage tables: waves * 32 * n_obj * 64 floats of LDS
     const size_t lds = (size_t)waves * TPW * 16 * (n_obj * 64 + 4 + n_obj * 4) * sizeof(float);
     const int per_block = waves * TPW * 16;
