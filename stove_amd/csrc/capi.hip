@@ -702,6 +702,8 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
   // split-K: no epilogue terms, except add == C (accumulate into C, e.g. a gradient view), applied by the slice sum
   const bool acc_c = splitk > 1 && add != nullptr && add == C;
   if (acc_c) add = nullptr;
+  const float* sum_bias = splitk > 1 ? bias : nullptr;      // split-K: the bias is added by the slice sum (fewer than 16 slices)
+  if (splitk > 1 && splitk < 16) bias = nullptr;
   if (splitk > 1 && (ws == nullptr || bias != nullptr || add != nullptr || ldc != N || (scalar_bits & 4))) return (int)hipErrorInvalidValue;
   if (scalar_bits & 2) return (int)hipErrorInvalidValue;           // B has to be float4-addressable
   float* out = splitk > 1 ? ws : C;
@@ -739,7 +741,7 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
     if (splitk >= 16)
       STOVE_LAUNCH(sum_chunks4_par_k, dim3((n4 + 63) / 64), dim3(256), 0, st, (const float*)ws, C, n4, splitk, acc_c ? 1 : 0);
     else
-      STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, st, (const float*)ws, C, n4, splitk, acc_c ? 1 : 0);
+      STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, st, (const float*)ws, C, n4, splitk, acc_c ? 1 : 0, sum_bias, N / 4);
     STOVE_LAUNCH_CHECK();
   }
   return 0;

@@ -873,7 +873,7 @@ class _EncoderLstmFn(torch.autograd.Function):
             ns = 0                               # odd sizes: library GEMMs
         with torch.cuda.device(dev):
             if ns:
-                gx = gemm_bf16(x, w_ih, bias=_f32(b_ih + b_hh), nsplit=ns, splitk=1)
+                gx = _gemm_rows_balanced(x, w_ih, _f32(b_ih + b_hh), ns)
             else:
                 with _blas('hipblas'):
                     gx = torch.addmm(b_ih + b_hh, x, w_ih.t())
@@ -1014,6 +1014,34 @@ def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=
                                   ptr(c), M, N, K, a.stride(0), b.stride(0), N, int(a_kmajor), int(b_kmajor), nsplit, splitk, tile,
                                   ptr(ws) if ws is not None else None, stream()), 'stove_gemm_bf16')
     return c
+
+
+def _gemm_rows_balanced(x, w, bias, ns):
+    """x W^T + bias for a tall x on the 256 x 128 tile.  The tile count is rarely a multiple of the CU count (25 600 frames:
+    800 tiles on 256 CUs = three full rounds and 32 tiles that keep an eighth of the chip busy for a fourth); the rows of the
+    incomplete round go through a second launch that splits K eight ways instead (256 short workgroups)."""
+    M, N = x.shape[0], w.shape[0]
+    cus = torch.cuda.get_device_properties(x.device).multi_processor_count
+    tiles_n = (N + 127) // 128
+    tiles_m = (M + 255) // 256
+    rounds = (tiles_m * tiles_n) // cus
+    main_m = (rounds * cus) // tiles_n                     # M-tiles of the complete rounds
+    tail_tiles = (tiles_m - main_m) * tiles_n
+    K = x.shape[1]
+    if rounds == 0 or tail_tiles == 0 or tail_tiles * 4 > cus or K % 256 != 0 or N % 4 != 0:
+        return gemm_bf16(x, w, bias=bias, nsplit=ns, splitk=1)
+    lib = _lib.load()
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    rows = main_m * 256
+    sk = 8
+    with torch.cuda.device(x.device):
+        check(lib.stove_gemm_bf16(ptr(x), ptr(w), ptr(bias), None, ptr(out), rows, N, K, x.stride(0), w.stride(0), N, 0, 0, ns, 1, 1, None,
+                                  stream()), 'stove_gemm_bf16')
+        xt, ot = x[rows:], out[rows:]
+        ws = torch.empty(lib.stove_gemm_bf16_ws_floats(M - rows, N, sk), dtype=torch.float32, device=x.device)
+        check(lib.stove_gemm_bf16(ptr(xt), ptr(w), ptr(bias), None, ptr(ot), M - rows, N, K, x.stride(0), w.stride(0), N, 0, 0, ns, sk, 1,
+                                  ptr(ws), stream()), 'stove_gemm_bf16')
+    return out
 
 
 def gemm_ok(*dims):

@@ -102,3 +102,28 @@ def test_gemm_unaligned_fc1_shapes():
     at.copy_(a.t())
     c = ops.gemm_bf16(at, b.t().contiguous().to(DEV), a_kmajor=True, b_kmajor=True, nsplit=1, splitk=1, tile=2)
     assert torch.equal(c.cpu(), a @ b.t())
+
+
+def test_gemm_splitk_bias_and_balanced_rows():
+    """A bias with split-K (added by the slice sum) and the row-balanced input projection of the recognition network (complete
+    rounds of 256 x 128 tiles + a split-K launch for the rows of the incomplete round) against fp64."""
+    from stove_amd import ops
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(1024, 512, generator=g).to(DEV)
+    b = torch.randn(256, 512, generator=g).to(DEV)
+    bias = torch.randn(256, generator=g).to(DEV)
+    ref = a.double() @ b.double().t() + bias.double()
+    got = ops.gemm_bf16(a, b, bias=bias, nsplit=2, splitk=8)
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1.5e-5
+    cus = torch.cuda.get_device_properties(DEV).multi_processor_count
+    n = (3 * cus // 8) * 256 + 4 * 256 + 37                 # three complete rounds of tiles + an incomplete one with a ragged end
+    x = torch.rand(n, 1024, generator=g).to(DEV)
+    w = (torch.randn(1024, 1024, generator=g) * 0.03).to(DEV)
+    bb = torch.randn(1024, generator=g).to(DEV)
+    got = ops._gemm_rows_balanced(x, w, bb, 2)
+    plain = ops.gemm_bf16(x, w, bias=bb, nsplit=2, splitk=1)
+    sel = torch.cat([torch.arange(0, 512), torch.arange(n - 1400, n)]).to(DEV)
+    ref = x[sel].double() @ w.double().t() + bb.double()
+    assert got.shape == plain.shape == (n, 1024)
+    assert float((got[sel].double() - ref).abs().max() / ref.abs().max()) < 1e-5
+    assert float((got - plain).abs().max() / plain.abs().max()) < 1e-5
