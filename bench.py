@@ -215,6 +215,9 @@ def main():
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    if a.warmup > 0 and not os.environ.get('STOVE_BENCH_NO_GC_SETTLE'):
+        from stove_amd.utils.utils import settle_host_gc
+        settle_host_gc()            # as the Trainer does after its first steps (train.py): see the function's note
     log('warm-up done')
     if world > 1:
         dist.barrier()
@@ -222,9 +225,32 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]       # device-side step boundaries (no host sync)
     t0 = time.perf_counter()
     marks[0].record()
+    host_t = [t0]
+    import gc
+    if os.environ.get('STOVE_BENCH_GCLOG'):
+        _g = {}
+        def _cb(phase, info):
+            if phase == 'start':
+                _g['t'] = time.perf_counter()
+            else:
+                log('gc gen%d %.2f ms collected %d' % (info['generation'], (time.perf_counter() - _g['t']) * 1e3, info['collected']))
+        gc.callbacks.append(_cb)
+    if os.environ.get('STOVE_BENCH_WATCH'):           # where is the host when a step stalls: sample the main thread's stack
+        import threading, traceback
+        main_id = threading.main_thread().ident
+        def _watch():
+            while len(host_t) <= a.steps:
+                time.sleep(0.005)
+                if time.perf_counter() - host_t[-1] > 0.02:
+                    fr = sys._current_frames().get(main_id)
+                    log('step %d stalled %.0f ms at:\n%s' % (len(host_t) - 1, (time.perf_counter() - host_t[-1]) * 1e3,
+                                                           ''.join(traceback.format_stack(fr)[-6:])))
+                    time.sleep(0.02)
+        threading.Thread(target=_watch, daemon=True).start()
     for i in range(a.steps):
         last = step(a.warmup + i)
         marks[i + 1].record()
+        host_t.append(time.perf_counter())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -235,7 +261,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     elbo_val = float(last.detach())
-    per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    series = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    per_step_ms = sorted(series)
+    if per_step_ms[-1] > 2.0 * per_step_ms[len(per_step_ms) // 2]:      # a stalled step: say which, and what the host was doing
+        log('stalled step(s): device ms ' + ' '.join('%.2f' % v for v in series))
+        log('                 host ms   ' + ' '.join('%.2f' % ((host_t[i + 1] - host_t[i]) * 1e3) for i in range(a.steps)))
     log('timed region done: %.1f ms/step' % (dt / a.steps * 1e3))
 
     # ---- per-kernel HIP-event timing of extra steps (profiling hooks off during the timed region)
@@ -401,7 +431,8 @@ def main():
             'config': {'workload': f'{a.workload} {cfg.num_obj}-object 32x32 T={a.frames} batch={a.batch}/GPU' + (' (BASELINE.json configs[1])' if a.workload == 'billiards' and a.batch == 256 and a.frames == 100 else ''),
                        'objects': cfg.num_obj, 'global_batch': a.batch * world,
                        'step': 'forward+backward+allreduce+clip+adam(amsgrad)', 'parallelism': f'dp{world}',
-                       'elbo_last_step': elbo_val},
+                       'elbo_last_step': elbo_val,
+                       'host_gc': 'collector enabled; long-lived objects frozen after warm-up (gc.collect + gc.freeze, as train.py does)'},
             'roofline': roofline, 'cpu_baseline': cpu, 'variants': variants,
         }
         print(json.dumps(out))

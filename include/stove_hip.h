@@ -218,6 +218,15 @@ int stove_supair_state_fwd(const float* codes, const float* span_low, float* zc,
 int stove_supair_state_bwd(const float* zc, const long long* idx, const unsigned char* hits, const float* zfix, const float* g_zfix,
                            const float* g_zl, const float* g_sl, const float* g_init6, const float* span_low, float* gfix_ws,
                            float* g_codes, int n, int T, int o, int skip, void* stream);
+/* The same with the recursion's whole initial state as output: init (n, o, init_ld) gets the six SuPAIR values in columns 0..5 and,
+ * with lat_noise (n, o, lat_dim) standard-normal draws, 0.01 x lat_noise in columns 6.. (stove.py:663-668); the backward reads
+ * g_init with the same row stride. */
+int stove_supair_state_fwd2(const float* codes, const float* span_low, float* zc, float* pos, long long* idx, float* zfix,
+                            unsigned char* hits, float* zl, float* sl, float* init, int init_ld, const float* lat_noise, int lat_dim,
+                            int n, int T, int o, int skip, int fix, int mode, void* stream);
+int stove_supair_state_bwd2(const float* zc, const long long* idx, const unsigned char* hits, const float* zfix, const float* g_zfix,
+                            const float* g_zl, const float* g_sl, const float* g_init6, int init_ld, const float* span_low, float* gfix_ws,
+                            float* g_codes, int n, int T, int o, int skip, void* stream);
 int stove_zall_fwd(const float* zfix, const float* zs, float* zall, int n, int T, int o, int skip, void* stream);
 int stove_zall_bwd(const float* zfix, const float* zs, const float* g_zall, float* g_zfix, float* g_zs, int n, int T, int o, int skip,
                    void* stream);

@@ -859,6 +859,14 @@ static ZpConst zp_const(const float* span_low) {
 int stove_supair_state_fwd(const float* codes, const float* span_low, float* zc, float* pos, long long* idx, float* zfix,
                            unsigned char* hits, float* zl, float* sl, float* init6, int n, int T, int o, int skip, int fix,
                            int mode, void* stream) {
+  return stove_supair_state_fwd2(codes, span_low, zc, pos, idx, zfix, hits, zl, sl, init6, 6, nullptr, 0, n, T, o, skip, fix, mode, stream);
+}
+
+int stove_supair_state_fwd2(const float* codes, const float* span_low, float* zc, float* pos, long long* idx, float* zfix,
+                            unsigned char* hits, float* zl, float* sl, float* init, int init_ld, const float* lat_noise, int lat_dim,
+                            int n, int T, int o, int skip, int fix, int mode, void* stream) {
+  if (init_ld < 6 + (lat_noise != nullptr ? lat_dim : 0) || lat_dim < 0) return (int)hipErrorInvalidValue;
+  float* init6 = init;
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) return 0;
   if (T < 2 || skip < 1 || skip >= T || o < 1 || o > kMatchN) return (int)hipErrorInvalidValue;
@@ -870,7 +878,7 @@ int stove_supair_state_fwd(const float* codes, const float* span_low, float* zc,
     if (rc) return rc;
   }
   STOVE_LAUNCH(supair_state_fwd_k, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)zc, (const long long*)idx, zfix, hits, zl, sl,
-               init6, n, T, o, skip, fix);
+               init6, n, T, o, skip, fix, init_ld, lat_noise, lat_dim);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -878,10 +886,16 @@ int stove_supair_state_fwd(const float* codes, const float* span_low, float* zc,
 int stove_supair_state_bwd(const float* zc, const long long* idx, const unsigned char* hits, const float* zfix, const float* g_zfix,
                            const float* g_zl, const float* g_sl, const float* g_init6, const float* span_low, float* gfix_ws,
                            float* g_codes, int n, int T, int o, int skip, void* stream) {
+  return stove_supair_state_bwd2(zc, idx, hits, zfix, g_zfix, g_zl, g_sl, g_init6, 6, span_low, gfix_ws, g_codes, n, T, o, skip, stream);
+}
+
+int stove_supair_state_bwd2(const float* zc, const long long* idx, const unsigned char* hits, const float* zfix, const float* g_zfix,
+                            const float* g_zl, const float* g_sl, const float* g_init6, int init_ld, const float* span_low, float* gfix_ws,
+                            float* g_codes, int n, int T, int o, int skip, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) return 0;
   const int M = n * T * o;
-  STOVE_LAUNCH(supair_state_bwd1_k, dim3((M + 255) / 256), dim3(256), 0, st, zfix, g_zfix, g_zl, g_sl, g_init6, gfix_ws, n, T, o, skip);
+  STOVE_LAUNCH(supair_state_bwd1_k, dim3((M + 255) / 256), dim3(256), 0, st, zfix, g_zfix, g_zl, g_sl, g_init6, gfix_ws, n, T, o, skip, init_ld);
   STOVE_LAUNCH_CHECK();
   STOVE_LAUNCH(supair_state_bwd2_k, dim3((M + 255) / 256), dim3(256), 0, st, zc, idx, hits, (const float*)gfix_ws, zp_const(span_low),
                g_codes, n, T, o);

@@ -56,7 +56,8 @@ __device__ __forceinline__ int fixed_state(const float* __restrict__ zc, const l
 //   zl / sl (n,Ts,o,6) = z_sup_full / z_sup_std_full [:, skip:],  init6 (n,o,6) = z_sup_full[:, skip-1]
 __global__ void supair_state_fwd_k(const float* __restrict__ zc, const long long* __restrict__ idx, float* __restrict__ zfix,
                                    unsigned char* __restrict__ hits, float* __restrict__ zl, float* __restrict__ sl,
-                                   float* __restrict__ init6, int n, int T, int o, int skip, int fix) {
+                                   float* __restrict__ init6, int n, int T, int o, int skip, int fix, int init_ld,
+                                   const float* __restrict__ lat_noise, int lat_dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * T * o) return;
   const int k = i % o, t = (i / o) % T, b = i / (o * T);
@@ -80,7 +81,11 @@ __global__ void supair_state_fwd_k(const float* __restrict__ zc, const long long
   }
   if (t == skip - 1) {
 #pragma unroll
-    for (int d = 0; d < 6; ++d) init6[((size_t)b * o + k) * 6 + d] = z6[d];
+    for (int d = 0; d < 6; ++d) init6[((size_t)b * o + k) * init_ld + d] = z6[d];
+    // the rest of the recursion's initial state: the unstructured latent = 0.01 x the caller's standard-normal draw (stove.py:663-668),
+    // written here instead of a scale and a concatenation launch behind this kernel
+    if (lat_noise != nullptr)
+      for (int d = 0; d < lat_dim; ++d) init6[((size_t)b * o + k) * init_ld + 6 + d] = 0.01f * lat_noise[((size_t)b * o + k) * lat_dim + d];
   } else {
     const size_t r = (((size_t)b * (T - skip) + (t - skip)) * o + k) * 6;
 #pragma unroll
@@ -93,14 +98,14 @@ __global__ void supair_state_fwd_k(const float* __restrict__ zc, const long long
 
 // gradient of the six-vectors of time t (0 where that time feeds nothing)
 __device__ __forceinline__ void g6_at(const float* __restrict__ g_zl, const float* __restrict__ g_sl, const float* __restrict__ g_init6,
-                                      int b, int t, int k, int T, int o, int skip, float* gz, float* gs) {
+                                      int b, int t, int k, int T, int o, int skip, float* gz, float* gs, int init_ld) {
 #pragma unroll
   for (int d = 0; d < 6; ++d) gz[d] = gs[d] = 0.0f;
   if (t < 1 || t > T - 1) return;
   if (t == skip - 1) {
     if (g_init6 != nullptr)
 #pragma unroll
-      for (int d = 0; d < 6; ++d) gz[d] = g_init6[((size_t)b * o + k) * 6 + d];
+      for (int d = 0; d < 6; ++d) gz[d] = g_init6[((size_t)b * o + k) * init_ld + d];
   } else if (t >= skip) {
     const size_t r = (((size_t)b * (T - skip) + (t - skip)) * o + k) * 6;
 #pragma unroll
@@ -114,7 +119,7 @@ __device__ __forceinline__ void g6_at(const float* __restrict__ g_zl, const floa
 // step 1 of the backward, thread (b, t, k): gradient w.r.t. the smoothed state zfix[b, t, k, :]
 __global__ void supair_state_bwd1_k(const float* __restrict__ zfix, const float* __restrict__ g_zfix, const float* __restrict__ g_zl,
                                     const float* __restrict__ g_sl, const float* __restrict__ g_init6, float* __restrict__ gfix,
-                                    int n, int T, int o, int skip) {
+                                    int n, int T, int o, int skip, int init_ld) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * T * o) return;
   const int k = i % o, t = (i / o) % T, b = i / (o * T);
@@ -122,8 +127,8 @@ __global__ void supair_state_bwd1_k(const float* __restrict__ zfix, const float*
 #pragma unroll
   for (int d = 0; d < 8; ++d) g[d] = g_zfix != nullptr ? g_zfix[(size_t)i * 8 + d] : 0.0f;
   float gz[6], gs[6], gzn[6], gsn[6];
-  g6_at(g_zl, g_sl, g_init6, b, t, k, T, o, skip, gz, gs);
-  g6_at(g_zl, g_sl, g_init6, b, t + 1, k, T, o, skip, gzn, gsn);
+  g6_at(g_zl, g_sl, g_init6, b, t, k, T, o, skip, gz, gs, init_ld);
+  g6_at(g_zl, g_sl, g_init6, b, t + 1, k, T, o, skip, gzn, gsn, init_ld);
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     g[d] += gz[d];

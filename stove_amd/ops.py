@@ -493,23 +493,29 @@ class _SupairStateFn(torch.autograd.Function):
     stove.py:172-198, 200-563): raw codes -> zfix (n,T,o,8), zl, sl (n,T-skip,o,6), init6 (n,o,6), idx."""
 
     @staticmethod
-    def forward(ctx, codes, span_low, n, T, o, skip, fix, mode):
+    def forward(ctx, codes, span_low, n, T, o, skip, fix, mode, lat_noise=None):
         lib = _lib.load()
         codes = _f32(codes)
         dev = codes.device
         Ts = T - skip
         kc = _host_floats(span_low, 16)
+        lat_dim = 0
+        if lat_noise is not None:               # the recursion's full initial state [six SuPAIR values | 0.01 x noise] from this launch
+            lat_noise = _f32(lat_noise).reshape(n, o, -1)
+            lat_dim = lat_noise.shape[-1]
+        ld = 6 + lat_dim
         with torch.cuda.device(dev):
             def f(*shape):
                 return torch.empty(*shape, dtype=torch.float32, device=dev)
             zc, pos, zfix = f(n, T, o, 8), f(n, T, o, 2), f(n, T, o, 8)
             idx = torch.empty(n, T, o, dtype=torch.int64, device=dev)
             hits = torch.empty(n, T, o, dtype=torch.uint8, device=dev)
-            zl, sl, init6 = f(n, Ts, o, 6), f(n, Ts, o, 6), f(n, o, 6)
-            check(lib.stove_supair_state_fwd(ptr(codes), kc, ptr(zc), ptr(pos), ptr(idx), ptr(zfix), ptr(hits), ptr(zl), ptr(sl),
-                                             ptr(init6), n, T, o, skip, int(bool(fix)), MATCH_MODES[mode], stream()),
-                  'stove_supair_state_fwd')
+            zl, sl, init6 = f(n, Ts, o, 6), f(n, Ts, o, 6), f(n, o, ld)
+            check(lib.stove_supair_state_fwd2(ptr(codes), kc, ptr(zc), ptr(pos), ptr(idx), ptr(zfix), ptr(hits), ptr(zl), ptr(sl),
+                                              ptr(init6), ld, ptr(lat_noise) if lat_noise is not None else None, lat_dim, n, T, o, skip,
+                                              int(bool(fix)), MATCH_MODES[mode], stream()), 'stove_supair_state_fwd2')
         ctx.save_for_backward(zc, idx, hits, zfix)
+        ctx.init_ld = ld
         ctx.cfg = (tuple(span_low), n, T, o, skip, codes.shape)
         ctx.set_materialize_grads(False)          # no zero tensors (one fill launch each) for the outputs nothing differentiates
         ctx.mark_non_differentiable(idx)
@@ -526,9 +532,9 @@ class _SupairStateFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws = torch.empty(n * T * o * 8, dtype=torch.float32, device=dev)
             g_codes = torch.empty(shape, dtype=torch.float32, device=dev)
-            check(lib.stove_supair_state_bwd(ptr(zc), ptr(idx), ptr(hits), ptr(zfix), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]),
-                                             kc, ptr(ws), ptr(g_codes), n, T, o, skip, stream()), 'stove_supair_state_bwd')
-        return g_codes, None, None, None, None, None, None, None
+            check(lib.stove_supair_state_bwd2(ptr(zc), ptr(idx), ptr(hits), ptr(zfix), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]),
+                                              ctx.init_ld, kc, ptr(ws), ptr(g_codes), n, T, o, skip, stream()), 'stove_supair_state_bwd2')
+        return g_codes, None, None, None, None, None, None, None, None
 
 
 class _ZallFn(torch.autograd.Function):
@@ -598,8 +604,10 @@ class _ElboFn(torch.autograd.Function):
         return g_zs, g_mean, g_std, g_zdyn, g_lik, None, None, None, None, None
 
 
-def supair_state(codes, span_low, n, T, o, skip, fix, mode):
-    return _SupairStateFn.apply(codes, tuple(float(v) for v in span_low), int(n), int(T), int(o), int(skip), bool(fix), mode)
+def supair_state(codes, span_low, n, T, o, skip, fix, mode, lat_noise=None):
+    """lat_noise (n, o, L) standard-normal draws: the fourth output is then the recursion's whole initial state (n, o, 6 + L) =
+    [z_sup_full[:, skip-1] | 0.01 lat_noise] instead of the six SuPAIR values alone."""
+    return _SupairStateFn.apply(codes, tuple(float(v) for v in span_low), int(n), int(T), int(o), int(skip), bool(fix), mode, lat_noise)
 
 
 def zall(zfix, zs, n, T, o, skip):

@@ -130,3 +130,14 @@ def match_states(predicted, true, match_idxs=(0, 1), time_frame=5):
     best = torch.stack(errs, 1).argmin(1)
     out = torch.stack([predicted[i][:, list(perms[j])] for i, j in enumerate(best.tolist())], 0)
     return out.numpy()
+
+
+def settle_host_gc():
+    """[amd] Keep the interpreter's full (generation-2) collections out of the step loop: a step is ~3 ms of device time that the
+    host feeds ~1 ms ahead, and one full collection walks every object torch has created (80-120 ms measured on the MI355X box's host),
+    which drains the device queue and shows up as one 80-120 ms step every few dozen.  Called once the loop is warm: collect what is
+    garbage now, then move the survivors (modules, parameters, the arena, the loaded library) to the permanent generation so later
+    collections only walk what the steps themselves allocate.  The collector stays enabled."""
+    import gc
+    gc.collect()
+    gc.freeze()

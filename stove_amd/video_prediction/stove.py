@@ -171,9 +171,19 @@ class Stove(nn.Module):
         # fused state pipeline (csrc/state.hip); the PyTorch chain below it is the same computation op by op.
         codes = self.sup.encoder(x.flatten(end_dim=1))
         fused_state = bool(getattr(c, 'fused_state', True)) and not c.debug_match_appearance
+        # device RNG: the three draws of the reference (latent prior, the unused std prior, the step noise) as ONE launch, made
+        # before the state pipeline so that it can write the recursion's initial state [SuPAIR | 0.01 latent noise] itself
+        Ts = T - skip
+        pooled = init_full = None
+        nl = n * o * (cl // 2 - 4)
+        if self.noise_fn is None and getattr(c, 'fused_dynamics', True):
+            pooled = self._noise('pooled', (2 * nl + n * Ts * o * (cl // 2 + 2),), codes)      # [latent | std | steps]
         if fused_state:
             zfix, zsup_loop, zsstd_loop, init6, idx = ops.supair_state(
-                codes.flatten(end_dim=1), self.sup.zp_span_low(), n, T, o, skip, c.debug_fix_supair, c.debug_match_objects)
+                codes.flatten(end_dim=1), self.sup.zp_span_low(), n, T, o, skip, c.debug_fix_supair, c.debug_match_objects,
+                lat_noise=pooled[:nl].view(n, o, cl // 2 - 4) if pooled is not None else None)
+            if pooled is not None:
+                init_full, init6 = init6, init6[..., :6]
             z_sup = zfix[..., :4]
             obj_appearances = None
             if c.debug_core_appearance:
@@ -195,17 +205,15 @@ class Stove(nn.Module):
             zsup_loop, zsstd_loop, init6 = z_sup_full[:, skip:], z_sup_std_full[:, skip:], z_sup_full[:, skip - 1]
 
         # 2. initial state at t = skip-1 and the inference recursion
-        Ts = T - skip
-        pooled = None
-        if self.noise_fn is None and getattr(c, 'fused_dynamics', True):
-            # device RNG: the three draws of the reference (latent prior, the unused std prior, the step noise) as ONE launch
-            nl = n * o * (cl // 2 - 4)
-            pooled = self._noise('pooled', (2 * nl + n * Ts * o * (cl // 2 + 2),), z_sup)      # [latent | std | steps]
-            lat0 = 0.01 * pooled[:nl].view(n, o, cl // 2 - 4)
+        if init_full is not None:
+            init_z = init_full
         else:
-            lat0 = 0.01 * self._noise('latent', (n, o, cl // 2 - 4), z_sup)
-            _ = 0.1 + 0.01 * self._noise('std', (n, o, cl // 2 - 4), z_sup)     # drawn as in the reference, unused
-        init_z = torch.cat([init6, lat0], -1)
+            if pooled is not None:
+                lat0 = 0.01 * pooled[:nl].view(n, o, cl // 2 - 4)
+            else:
+                lat0 = 0.01 * self._noise('latent', (n, o, cl // 2 - 4), z_sup)
+                _ = 0.1 + 0.01 * self._noise('std', (n, o, cl // 2 - 4), z_sup)     # drawn as in the reference, unused
+            init_z = torch.cat([init6, lat0], -1)
         use_app = bool(c.debug_core_appearance)
         if getattr(c, 'fused_dynamics', True):
             extra = []

@@ -23,7 +23,7 @@ from ..arena import ParamArena
 from .load_data import DeviceClipLoader, ShardedDataLoader
 from ..optim import FlatAdam
 from ..parallel import GradBucket, broadcast_int, broadcast_tensors
-from ..utils.utils import ExperimentLogger, bw_transform
+from ..utils.utils import ExperimentLogger, bw_transform, settle_host_gc
 
 
 class AbstractTrainer:
@@ -313,6 +313,8 @@ class Trainer(AbstractTrainer):
                 else:
                     elbo, prop_dict, rewards, min_ll, mse_rewards = self.train_step(data, step_counter)
                     elbo, min_ll = elbo.detach(), min_ll.detach()      # values only from here on: drop the autograd graph
+                if step_counter == self.step_start + 3:
+                    settle_host_gc()            # [amd] the loop is warm: full collections of the long-lived objects stay out of it
                 if step_counter % self.c.print_every == 0:
                     if self.world_size > 1:
                         # [amd] the logged ELBO / loss are the means over the global batch: one 3-float all-reduce
