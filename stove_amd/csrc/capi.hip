@@ -231,13 +231,17 @@ static SceneWs scene_ws_layout(int nf, int n_obj) {
 
 size_t stove_scene_bwd_ws_bytes(int n_frames, int n_obj) { return scene_ws_layout(n_frames, n_obj).total * sizeof(float); }
 
-// STOVE_PARAMS_LATE=1 holds the object-SPN table-gradient passes back until dz is out (A/B switch, see below; measured
-// 5.39 vs 5.34 ms per step: underneath the recursion backward they slow it down more than they cost next to pix / tile_bwd)
+// Where the object-SPN table gradients run when the caller gives a parameter stream.  Default: held back until dz is out, then
+// underneath the recursion's backward as objspn_tablegrad_under_k (one wave per SIMD in the registers and LDS that kernel
+// leaves free).  Measured (gpurun_out/late, B = 256): the SPN backward phase 600 -> 495 us without them, the recursion's
+// backward 470 -> 545 us with them on its SIMDs (MFMA pipe and L1 shared; raising the chain's wave priority changes
+// nothing), the step 3.273 -> 3.254 ms.  STOVE_PARAMS_EARLY=1: right behind their producer, next to pix / bgspn_bwd
+// (the round-1 placement, objspn_tablegrad_k).
 static int params_late() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("STOVE_PARAMS_LATE");
-    v = (e != nullptr && e[0] == '1') ? 1 : 0;
+    const char* e = getenv("STOVE_PARAMS_EARLY");
+    v = (e != nullptr && e[0] == '1') ? 0 : 1;
   }
   return v;
 }
@@ -269,8 +273,8 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
   int rc = objspn_backward_data(saved + L.xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot,
                                 saved + L.obj_ll, ws + W.d_obj, nullptr, ws + W.obj, np, st, saved + L.obj_state);
   if (rc) return rc;
-  // The object-SPN table gradients (coefgrad + wgrad + reductions, ~0.5 ms of throughput-bound work) start right behind
-  // their producer on the parameter stream, or (STOVE_PARAMS_LATE=1) only once dz is out.
+  // The object-SPN table gradients go to the parameter stream: once dz is out (underneath what the caller enqueues next,
+  // the recursion's backward), or (STOVE_PARAMS_EARLY=1) right behind their producer.
   const bool late = sp != st && params_late();
   if (!late) {
     STOVE_TRY(stream_after(sp, st));
@@ -296,7 +300,7 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
   jb.dismiss();                                 // scene_bwd_tail joined `sb`
   if (late) {
     STOVE_TRY(stream_after(sp, st));
-    rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, sp);
+    rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, sp, true);
     if (rc) return rc;
   }
   jp.dismiss();

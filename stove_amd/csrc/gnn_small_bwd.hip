@@ -205,6 +205,9 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     float* __restrict__ dzsstd, float* __restrict__ dextra, float* __restrict__ dy, int B, int Ts, int N, int sin_dim, int lim_enc,
     int elu, LoopConst kc, long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // the chain is issue-latency bound: where another kernel's wave shares the SIMD (the table gradients that run underneath,
+  // objspn_tablegrad_under_k) the arbiter picks this one whenever it is ready
+  __builtin_amdgcn_s_setprio(3);
   const SmBLds L = smb_carve(lds);
   const int b = blockIdx.x;
   const int wv = wave_id(), lane = lane_id(), l = lane & 31, h = lane >> 5;

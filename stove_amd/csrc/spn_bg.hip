@@ -251,70 +251,109 @@ __global__ void bg_cover_tables_k(const float* __restrict__ z, float* __restrict
 // SCENE: dz_part[frame][half][n_obj][4] (dsx, dsy, dx, dy of the pasted boxes)
 // else : d_marg[frame][p] (and d_inputs if non-null)
 // gcoef_part[block][r][p_local][g][3]
+//
+// A workgroup walks its frames in GROUPS of NW = 8.  What every pixel lane of the workgroup needs of a frame beyond its own
+// pixel -- the 36 leaf gradients and, in scene mode, the objects' coverage rows -- is the same few hundred floats for all 512
+// lanes, so it goes through LDS: while group g is processed, the group g + 1 rows arrive as ONE float4 per thread (three for
+// eight objects) and are parked in the other half of a double buffer at the group boundary, where the dz flush synchronises the
+// workgroup anyway.  The lanes then read them with LDS latency.  (Before: 9 + 6 global loads per lane and frame, issued one
+// frame ahead; at two waves per SIMD an iteration lasted what those loads took, ~2 600 cycles for ~100 instructions.)  The lane's
+// own pixels of the next group are fetched a whole group ahead as well.
 template <int R, int G, bool SCENE, int NMAX, bool EXACT = false>
 __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
     const float* __restrict__ frames, const float* __restrict__ marg, const float* __restrict__ z, int n_obj,
     const int* __restrict__ side, const float* __restrict__ coef, const float* __restrict__ dell,
     float* __restrict__ d_inputs, float* __restrict__ d_marg, float* __restrict__ dz_part,
     float* __restrict__ gcoef_part, int n_frames, const float* __restrict__ T, FrameMap fm) {
-  if (EXACT) n_obj = NMAX;      // the object count at compile time: the per-object predicates around the table loads go, the loads batch
+  if (EXACT) n_obj = NMAX;      // the object count at compile time: the per-object predicates go, the table reads batch
   constexpr int NO = R * 2 * G;
   constexpr int NW = kBgThreads / 64;
-  // SCENE: d box (= -dL/dw where no clamp fired) of the last NW frames, [slot][pixel of this half]; every NW frames the
+  static_assert(NO % 4 == 0 && G % 2 == 0, "leaf-gradient rows are staged as float4, Gaussians are processed in pairs");
+  constexpr int kDl4 = NW * (NO / 4);                                    // float4 items of a group: leaf-gradient rows ...
+  // ... and the objects' coverage tables: whole rows of bg_cover_tables_k (132 floats; the flush then reads LDS as well) while
+  // two buffers of them fit the 64 KB of static LDS, else just cover_x | cover_y (64 floats) and the flush reads global memory
+  constexpr bool FULLTAB = NMAX <= 3;
+  constexpr int TBW = FULLTAB ? kBgTab : 64, TB4 = TBW / 4, TBY = FULLTAB ? 64 : 32;
+  constexpr int kTb4 = SCENE ? NW * NMAX * TB4 : 0;
+  constexpr int NSTG = (kDl4 + kTb4 + kBgThreads - 1) / kBgThreads;
+  // SCENE: d box (= -dL/dw where no clamp fired) of the group's frames, [slot][pixel of this half]; at the end of the group the
   // block turns them into dz, one wave per frame (see flush below)
   __shared__ __attribute__((aligned(16))) float dbx[SCENE ? NW : 1][SCENE ? kBgThreads : 1];
+  __shared__ __attribute__((aligned(16))) float dl[2][NW][NO];
+  __shared__ __attribute__((aligned(16))) float tb[2][SCENE ? NW : 1][SCENE ? NMAX : 1][TBW];
   const int half = blockIdx.x % kBgHalves;
   const int p = half * kBgThreads + threadIdx.x;
   const int lane = lane_id(), wv = wave_id();
-  float cf[R][G][3], gc[R][G][3];
-  bool sd[R];
+  // Gaussians in pairs (g, g + 1): the inner products below are v_pk_fma_f32 -- two fp32 FMAs per lane and instruction --
+  // with the per-pixel factors (x, x^2, w x^2, w x, w) as splat operands
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  constexpr int GP = G / 2;
+  v2f cf[R][GP][3], gc[R][GP][3];
+  int doff[R];                  // where this lane's side of replica r starts in a leaf-gradient row
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    sd[r] = side[r * kBgPix + p] != 0;
+    doff[r] = (r * 2 + (side[r * kBgPix + p] != 0 ? 1 : 0)) * G;
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+    for (int j = 0; j < GP; ++j)
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        cf[r][g][k] = coef[((size_t)(r * kBgPix + p) * G + g) * 3 + k];
-        gc[r][g][k] = 0.0f;
+        cf[r][j][k] = v2f{coef[((size_t)(r * kBgPix + p) * G + 2 * j) * 3 + k], coef[((size_t)(r * kBgPix + p) * G + 2 * j + 1) * 3 + k]};
+        gc[r][j][k] = v2f{0.0f, 0.0f};
       }
   }
   const int col = p % kBgSide, row = p / kBgSide;
-  int it = 0;
-  // the pixel and the coverage-table entries of the NEXT frame are fetched while the current one is processed: with
-  // ~100 frames per block and a dependent global load at the top of every iteration, the load latency was the kernel
   const int fstep = gridDim.x / kBgHalves;
   const int f0 = blockIdx.x / kBgHalves;
-  float xn = 0.0f, fxn[NMAX], fyn[NMAX];
-  // this lane's leaf gradients of the next frame (per replica the side its pixel belongs to): R * G vector loads that were
-  // issued at the top of the iteration that uses them -- the pass over the frame waited for them
-  float den[R][G];
-  const float* de_lane[R];
+  const int n_it = f0 < n_frames ? (n_frames - f0 + fstep - 1) / fstep : 0;      // frames of this block: f0 + it * fstep
+
+  // ---- this thread's staging items (constant over the groups)
+  const float* s_src[NSTG];     // source of frame 0
+  int s_fstride[NSTG];          // floats per frame in the source; 0 = no item
+  int s_slot[NSTG];
+  float* s_dst[NSTG];           // destination in buffer 0
+  int s_bstride[NSTG];          // floats between the two buffers
+  const int n_items = kDl4 + (SCENE ? NW * n_obj * TB4 : 0);
 #pragma unroll
-  for (int r = 0; r < R; ++r) de_lane[r] = dell + (sd[r] ? (r * 2 + 1) * G : (r * 2) * G);
-  auto prefetch = [&](int f) {
-    xn = frames[fm.row(f) * kBgPix + p];
+  for (int u = 0; u < NSTG; ++u) {
+    const int i = threadIdx.x + u * kBgThreads;
+    s_src[u] = dell; s_fstride[u] = 0; s_slot[u] = 0; s_dst[u] = &dl[0][0][0]; s_bstride[u] = 0;
+    if (i < kDl4) {
+      const int j = i / (NO / 4), q = i % (NO / 4);
+      s_src[u] = dell + 4 * q; s_fstride[u] = NO; s_slot[u] = j; s_dst[u] = &dl[0][j][4 * q]; s_bstride[u] = NW * NO;
+    } else if (SCENE && i < n_items) {
+      const int i2 = i - kDl4;
+      const int j = i2 / (n_obj * TB4), rem = i2 % (n_obj * TB4), k = rem / TB4, q = rem % TB4;
+      s_src[u] = T + k * kBgTab + (FULLTAB ? 4 * q : (q < 8 ? 4 * q : 64 + 4 * (q - 8)));
+      s_fstride[u] = n_obj * kBgTab; s_slot[u] = j; s_dst[u] = &tb[0][j][k][4 * q]; s_bstride[u] = NW * NMAX * TBW;
+    }
+  }
+  float4 stg[NSTG];
+  float xcur[NW], xnext[NW];
+  auto group_load = [&](int g, float* xs) {       // global loads of group g: staging items + this lane's pixels
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+    for (int u = 0; u < NSTG; ++u) {
+      const int it = g * NW + s_slot[u];
+      stg[u] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (s_fstride[u] != 0 && it < n_it) stg[u] = *reinterpret_cast<const float4*>(s_src[u] + (size_t)(f0 + it * fstep) * s_fstride[u]);
+    }
 #pragma unroll
-      for (int g = 0; g < G; ++g) den[r][g] = de_lane[r][(size_t)f * NO + g];
-    if (SCENE) {
-#pragma unroll
-      for (int k = 0; k < NMAX; ++k) {
-        if (k < n_obj) {
-          const float* tk = T + ((size_t)f * n_obj + k) * kBgTab;
-          fxn[k] = tk[col];
-          fyn[k] = tk[64 + row];
-        }
-      }
+    for (int j = 0; j < NW; ++j) {
+      const int it = g * NW + j;
+      xs[j] = 0.0f;
+      if (it < n_it) xs[j] = frames[fm.row(f0 + it * fstep) * kBgPix + p];
     }
   };
-  // dz of the buffered frames.  The d box image of a frame enters the four gradients of object k only through three sums
+  auto group_store = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < NSTG; ++u)
+      if (s_fstride[u] != 0) *reinterpret_cast<float4*>(s_dst[u] + buf * s_bstride[u]) = stg[u];
+  };
+  // dz of the group's frames.  The d box image of a frame enters the four gradients of object k only through three sums
   // per image row,  Sx = sum_c d dcover_x(c),  Sxu = sum_c d dcover_x(c) u(c),  Sy = sum_c d cover_x(c)  (the row factors
   // cover_y, dcover_y, v come out of the column sum), so one wave takes one frame: lane = (row, quarter of the columns),
   // 8 columns each, then ONE wave reduction per gradient -- instead of twelve 16-lane reductions, an LDS stage and a
   // workgroup barrier per frame in the pixel-parallel layout above.
-  auto flush = [&](int n_buf, int f_first) {
+  auto flush = [&](int n_buf, int f_first, int buf) {
     __syncthreads();
     if (wv < n_buf) {
       const int f = f_first + wv * fstep;
@@ -327,7 +366,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
 #pragma unroll
       for (int k = 0; k < NMAX; ++k) {
         if (k < n_obj) {
-          const float* tk = T + ((size_t)f * n_obj + k) * kBgTab;
+          const float* tk = FULLTAB ? &tb[buf][wv][k][0] : T + ((size_t)f * n_obj + k) * kBgTab;
           const float4 ca = *reinterpret_cast<const float4*>(tk + q * 8), cb = *reinterpret_cast<const float4*>(tk + q * 8 + 4);
           const float4 ga = *reinterpret_cast<const float4*>(tk + 32 + q * 8), gb = *reinterpret_cast<const float4*>(tk + 32 + q * 8 + 4);
           const float cx[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
@@ -356,83 +395,101 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_k(
     }
     __syncthreads();
   };
-  if (f0 < n_frames) prefetch(f0);
-  int f_first = f0;
-  for (int f = f0; f < n_frames; f += fstep, ++it) {
-    const float x = xn;
-    float w, mraw = 0.0f;
-    // per-object box factors for the scene backward
-    float fx[NMAX], fy[NMAX];
+
+  if (n_it > 0) {
+    group_load(0, xcur);
+    group_store(0);
+  }
+  __syncthreads();
+  for (int g = 0; g * NW < n_it; ++g) {
+    const int buf = g & 1;
+    const bool more = (g + 1) * NW < n_it;
+    if (more) group_load(g + 1, xnext);
 #pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
-      fx[k] = fxn[k];
-      fy[k] = fyn[k];
-    }
-    float dcur[R][G];
+    for (int slot = 0; slot < NW; ++slot) {
+      const int it = g * NW + slot;
+      if (it < n_it) {            // block-uniform
+        const int f = f0 + it * fstep;
+        const float x = xcur[slot];
+        float w, mraw = 0.0f;
+        v2f dcur[R][GP];
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int g = 0; g < G; ++g) dcur[r][g] = den[r][g];
-    if (f + fstep < n_frames) prefetch(f + fstep);
-    bool pass = true;
-    if (SCENE) {
-      float run = 0.0f;
+          for (int j = 0; j < GP; ++j) dcur[r][j] = *reinterpret_cast<const v2f*>(&dl[buf][slot][doff[r] + 2 * j]);
+        bool pass = true;
+        if (SCENE) {
+          float run = 0.0f;
 #pragma unroll
-      for (int k = 0; k < NMAX; ++k) {
-        if (k < n_obj) {
-          run += fx[k] * fy[k];
-          if (run > 1.0f) {
-            run = 1.0f;
-            pass = false;
+          for (int k = 0; k < NMAX; ++k) {
+            if (k < n_obj) {
+              run += tb[buf][slot][k][col] * tb[buf][slot][k][TBY + row];
+              if (run > 1.0f) {
+                run = 1.0f;
+                pass = false;
+              }
+            }
+          }
+          w = 1.0f - run;
+        } else {
+          if (marg != nullptr) {
+            mraw = marg[(size_t)f * kBgPix + p];
+            w = 1.0f - fminf(fmaxf(mraw, 0.0f), 1.0f);
+          } else {
+            w = 1.0f;
           }
         }
-      }
-      w = 1.0f - run;
-    } else {
-      if (marg != nullptr) {
-        mraw = marg[(size_t)f * kBgPix + p];
-        w = 1.0f - fminf(fmaxf(mraw, 0.0f), 1.0f);
-      } else {
-        w = 1.0f;
+        const float wx = w * x, wxx = wx * x, x2 = x * x;
+        const v2f X{x, x}, X2{x2, x2}, XX{x + x, x + x}, W{w, w}, WX{wx, wx}, WXX{wxx, wxx};
+        v2f dwr[R], dxr{0.0f, 0.0f};  // one partial sum per replica: R short dependent FMA chains instead of one of R * G links
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          dwr[r] = v2f{0.0f, 0.0f};
+#pragma unroll
+          for (int j = 0; j < GP; ++j) {
+            const v2f d = dcur[r][j];
+            dwr[r] = __builtin_elementwise_fma(d, __builtin_elementwise_fma(cf[r][j][0], X2, __builtin_elementwise_fma(cf[r][j][1], X, cf[r][j][2])), dwr[r]);
+            if (!SCENE) dxr = __builtin_elementwise_fma(d, __builtin_elementwise_fma(cf[r][j][0], XX, cf[r][j][1]), dxr);
+            gc[r][j][0] = __builtin_elementwise_fma(d, WXX, gc[r][j][0]);
+            gc[r][j][1] = __builtin_elementwise_fma(d, WX, gc[r][j][1]);
+            gc[r][j][2] = __builtin_elementwise_fma(d, W, gc[r][j][2]);
+          }
+        }
+        v2f dw2 = dwr[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) dw2 += dwr[r];
+        const float dw = dw2.x + dw2.y, dx = dxr.x + dxr.y;
+        if (SCENE) {
+          // w = 1 - min(1, sum box): d box_k = -dw when no clamp fired
+          dbx[slot][threadIdx.x] = pass ? -dw : 0.0f;
+        } else {
+          if (d_marg != nullptr) d_marg[(size_t)f * kBgPix + p] = (mraw >= 0.0f && mraw <= 1.0f) ? -dw : 0.0f;
+          if (d_inputs != nullptr) d_inputs[(size_t)f * kBgPix + p] = dx * w;
+        }
       }
     }
-    const float wx = w * x, wxx = wx * x, x2 = x * x;
-    float dwr[R], dx = 0.0f;      // one partial sum per replica: R short dependent FMA chains instead of one of R * G links
-#pragma unroll                    // (0.30 -> 0.23 ms: at two waves per SIMD the serial chain was what each frame waited for)
-    for (int r = 0; r < R; ++r) {
-      dwr[r] = 0.0f;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float d = dcur[r][g];
-        dwr[r] = fmaf(d, fmaf(cf[r][g][0], x2, fmaf(cf[r][g][1], x, cf[r][g][2])), dwr[r]);
-        if (!SCENE) dx = fmaf(d, fmaf(cf[r][g][0], x + x, cf[r][g][1]), dx);
-        gc[r][g][0] = fmaf(d, wxx, gc[r][g][0]);
-        gc[r][g][1] = fmaf(d, wx, gc[r][g][1]);
-        gc[r][g][2] = fmaf(d, w, gc[r][g][2]);
-      }
-    }
-    float dw = dwr[0];
-#pragma unroll
-    for (int r = 1; r < R; ++r) dw += dwr[r];
+    // the next group's rows go into the other buffer (last read a group ago, two barriers back); the barriers of the flush
+    // (or the one below) publish them
+    if (more) group_store(buf ^ 1);
     if (SCENE) {
-      // w = 1 - min(1, sum box): d box_k = -dw when no clamp fired
-      const int slot = it % NW;
-      if (slot == 0) f_first = f;
-      dbx[slot][threadIdx.x] = pass ? -dw : 0.0f;
-      if (slot == NW - 1) flush(NW, f_first);
+      const int left = n_it - g * NW;
+      flush(left < NW ? left : NW, f0 + g * NW * fstep, buf);
     } else {
-      if (d_marg != nullptr) d_marg[(size_t)f * kBgPix + p] = (mraw >= 0.0f && mraw <= 1.0f) ? -dw : 0.0f;
-      if (d_inputs != nullptr) d_inputs[(size_t)f * kBgPix + p] = dx * w;
+      __syncthreads();
     }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) xcur[j] = xnext[j];
   }
-  if (SCENE && (it % NW) != 0) flush(it % NW, f_first);
   float* o = gcoef_part + ((size_t)blockIdx.x * R * kBgThreads) * G * 3;
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+    for (int j = 0; j < GP; ++j)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) o[((size_t)(r * kBgThreads + threadIdx.x) * G + g) * 3 + k] = gc[r][g][k];
+      for (int k = 0; k < 3; ++k) {
+        o[((size_t)(r * kBgThreads + threadIdx.x) * G + 2 * j) * 3 + k] = gc[r][j][k].x;
+        o[((size_t)(r * kBgThreads + threadIdx.x) * G + 2 * j + 1) * 3 + k] = gc[r][j][k].y;
+      }
 }
 
 // g_coef[r][p][g][3] = sum over the blocks that own pixel-half(p) of gcoef_part (fixed order).
@@ -577,7 +634,9 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
     return 0;
   }
   if (n_obj > 8) return (int)hipErrorInvalidValue;
-  const int grid = bg_grid(n_frames);
+  // the backward holds one 8-wave workgroup per CU (212 registers): 128 frame slices x 2 halves = one resident round (the
+  // workspace is sized for bg_grid, which is never smaller)
+  const int grid = n_frames < 128 ? bg_grid(n_frames) : 128 * kBgHalves;
   float* dell = ws;
   float* rsc = dell + (size_t)n_frames * kBgNO;
   float* dz_part = rsc + (size_t)n_frames * kBgR * (1 + 2 * kBgG);

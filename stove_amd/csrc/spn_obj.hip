@@ -788,6 +788,155 @@ __global__ __launch_bounds__(128 * R) void objspn_tablegrad_k(
   }
 }
 
+// The same three contractions shaped to run UNDERNEATH the recursion's backward (dyn_loop_bwd_small_k: one 4-wave workgroup per
+// CU for ~0.47 ms, 360 of a SIMD's 512 registers, bound by dependent-issue latency while the rest of the chip idles).  A
+// 12-wave workgroup of objspn_tablegrad_k (3 waves x 158 registers per SIMD) cannot be resident next to it, so held back
+// until then it simply ran afterwards; this variant is 4 waves -- ONE per SIMD -- well inside the 152 registers that are left:
+// workgroup = one replica (grid.y = R), wave = (side, half); half 0 owns the side's first leaf and sum-weight tiles 0..3,
+// half 1 the second leaf, tiles 4..6 and (side 0) the root: 36 accumulator registers per wave.  With one wave per SIMD
+// nothing hides an MFMA's latency but the wave's own independent accumulators, so the products go tile-innermost (5 / 4
+// independent MFMAs back to back).  Every workgroup stages the whole glimpse tile for its one replica: six times the tile
+// reads of the wide kernel, out of the MALL, at a time when HBM is nearly idle.  Same fixed summation order per output as
+// objspn_tablegrad_k over the same chunk count -> bitwise reproducible (the chunking differs between the two kernels).
+template <int R, int S, int G, int K>
+__global__ __launch_bounds__(256, 4) void objspn_tablegrad_under_k(
+    const float* __restrict__ xw, const float* __restrict__ Dscr, const float* __restrict__ Sscr, const float* __restrict__ Rscr,
+    const int* __restrict__ scope, float* __restrict__ part_c, float* __restrict__ part_w, float* __restrict__ part_r,
+    int n_batches, int n_chunks) {
+  constexpr int D = 4 * S, LD = 68, NS = K + 2 * G;
+  constexpr int TC = (3 * S + 15) / 16, TW = (G * G + 15) / 16, TWH = (TW + 1) / 2;
+  static_assert(G <= 16 && K <= 16, "one column tile");
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  extern __shared__ __attribute__((aligned(16))) float tg_lds[];
+  float* tileP = tg_lds;                         // [2 D][LD]: row 2 p = x of pixel p, 2 p + 1 = w -- ALL the LDS there is next
+                                                 // to the recursion's 107 KB: the sum-node rows are read from global memory
+  const int lane = lane_id(), wv = wave_id();
+  const int side = wv & 1, half = wv >> 1, r = blockIdx.y, node = 2 * r + side, L = side * 2 + half;
+  const int rr = lane & 15, kk = lane >> 4;
+  const int c = blockIdx.x;
+  int c_row[TC], c_feat[TC];
+#pragma unroll
+  for (int t = 0; t < TC; ++t) {
+    const int row = min(16 * t + rr, 3 * S - 1);
+    c_feat[t] = row / S;
+    c_row[t] = 2 * scope[(r * 4 + L) * S + row % S];
+  }
+  int w_e1[TWH], w_e2[TWH];
+#pragma unroll
+  for (int i = 0; i < TWH; ++i) {
+    const int row = min(16 * (half * TWH + i) + rr, G * G - 1);
+    w_e1[i] = K + row % G;
+    w_e2[i] = K + G + row / G;
+  }
+  f4 acc_c[TC], acc_w[TWH], acc_r = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int t = 0; t < TC; ++t) acc_c[t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < TWH; ++i) acc_w[i] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  for (int b = c; b < n_batches; b += n_chunks) {
+    {
+      const float4* src = reinterpret_cast<const float4*>(xw + (size_t)b * (D * 2 * 64));
+      for (int i = threadIdx.x; i < 2 * D * 16; i += 256)
+        *reinterpret_cast<float4*>(tileP + (i >> 4) * LD + 4 * (i & 15)) = src[i];
+    }
+    __syncthreads();
+    // ---- leaf coefficients of leaf L: A = features of its pixels, B = its gradients
+    {
+      const float4* dp = reinterpret_cast<const float4*>(Dscr + (((size_t)(b * R + r) * 4 + L) * G + min(rr, G - 1)) * 64 + 16 * kk);
+      const float4 d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3];
+      const float dv[16] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x, d3.y, d3.z, d3.w};
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        float fv[TC][4];
+#pragma unroll
+        for (int t = 0; t < TC; ++t) {
+          const float* xr = tileP + c_row[t] * LD + 16 * kk + 4 * h;
+          const float4 x4 = *reinterpret_cast<const float4*>(xr);
+          const float4 w4 = *reinterpret_cast<const float4*>(xr + LD);
+          const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float wx = ws[e] * xs[e];
+            fv[t][e] = c_feat[t] == 0 ? wx * xs[e] : (c_feat[t] == 1 ? wx : ws[e]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < TC; ++t) acc_c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[t][e], dv[4 * h + e], acc_c[t], 0, 0, 0);
+      }
+    }
+    // ---- this half's sum-node weight tiles: A = E1[j1] E2[j2], B = gamma
+    {
+      const float* nb = Sscr + (size_t)(b * R * 2 + node) * NS * 64 + 16 * kk;
+      const float* gp = nb + min(rr, K - 1) * 64;
+      float gv[16];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gp + 4 * h);
+        gv[4 * h] = g4.x; gv[4 * h + 1] = g4.y; gv[4 * h + 2] = g4.z; gv[4 * h + 3] = g4.w;
+      }
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        float pr[TWH][4];
+#pragma unroll
+        for (int i = 0; i < TWH; ++i) {
+          const float4 a4 = *reinterpret_cast<const float4*>(nb + w_e1[i] * 64 + 4 * h);
+          const float4 b4 = *reinterpret_cast<const float4*>(nb + w_e2[i] * 64 + 4 * h);
+          pr[i][0] = a4.x * b4.x; pr[i][1] = a4.y * b4.y; pr[i][2] = a4.z * b4.z; pr[i][3] = a4.w * b4.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TWH; ++i)      // (tile 7 of half 1 does not exist: its products are computed and never stored)
+            acc_w[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[i][e], gv[4 * h + e], acc_w[i], 0, 0, 0);
+      }
+    }
+    // ---- root weights of the replica (side 0, half 1): A = rho EB[j2], B = EA[j1]
+    if (side == 0 && half == 1) {
+      const float* rp = Rscr + (size_t)(b * R + r) * (1 + 2 * K) * 64 + 16 * kk;
+      const float4* rho = reinterpret_cast<const float4*>(rp);
+      const float4* ea = reinterpret_cast<const float4*>(rp + (1 + min(rr, K - 1)) * 64);
+      const float4* eb = reinterpret_cast<const float4*>(rp + (1 + K + min(rr, K - 1)) * 64);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const float4 q4 = rho[h], a4 = ea[h], b4 = eb[h];
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.x * b4.x, a4.x, acc_r, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.y * b4.y, a4.y, acc_r, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.z * b4.z, a4.z, acc_r, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.w * b4.w, a4.w, acc_r, 0, 0, 0);
+      }
+    }
+    __syncthreads();      // the LDS images are restaged for the next batch
+  }
+  const int col = lane & 15;
+#pragma unroll
+  for (int t = 0; t < TC; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 16 * t + 4 * kk + e;
+      if (row < 3 * S && col < G) {
+        const int feat = row / S, i = row % S;
+        part_c[((size_t)(c * R + r) * D + L * S + i) * G * 3 + col * 3 + feat] = acc_c[t][e];
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < TWH; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 16 * (half * TWH + i) + 4 * kk + e;
+      if (row < G * G && col < K) part_w[((size_t)(c * R * 2 + node) * G * G + row) * K + col] = acc_w[i][e];
+    }
+  if (side == 0 && half == 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 4 * kk + e;
+      if (row < K && col < K) part_r[((size_t)(c * R + r) * K + row) * K + col] = acc_r[e];
+    }
+  }
+}
+
 // ---- tile staging for the stand-alone RatSpn.forward(inputs, marginalized) operator --------
 // inputs/marg are (n, D) row-major; w = 1 - clamp(marg, 0, 1) (rat_torch.py:104-106).
 __global__ void objspn_tile_from_arrays_k(const float* __restrict__ inputs, const float* __restrict__ marg,
@@ -956,7 +1105,7 @@ static bool objspn_tablegrad_valu() {
 }
 
 int objspn_backward_params(const float* xw, const int* scope, float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n,
-                           hipStream_t st) {
+                           hipStream_t st, bool under = false) {
   const int nb = (n + 63) / 64;
   if (nb == 0) {
     hipMemsetAsync(g_coef, 0, kObjCoefN * 4, st);
@@ -970,8 +1119,16 @@ int objspn_backward_params(const float* xw, const int* scope, float* g_coef, flo
   float* pc = Rscr + (size_t)nb * kObjR;
   float* pw = pc + (size_t)kObjChunks * kObjCoefN;
   float* pr = pw + (size_t)kObjChunks * kObjWN;
-  const int chunks = nb < kObjChunks ? nb : kObjChunks;
-  if (objspn_tablegrad_valu()) {      // STOVE_TABLEGRAD_VALU=1: the VALU formulation (A/B switch, cross-check in tests)
+  int chunks = nb < kObjChunks ? nb : kObjChunks;
+  if (under && !objspn_tablegrad_valu()) {
+    // one resident round next to the recursion's workgroups: 6 workgroups (replicas) per chunk, one per CU
+    constexpr int kTgLdsU = 2 * 100 * 68 * (int)sizeof(float);      // + the recursion's 106 880 B + 512 B < 160 KB
+    if (chunks > kObjChunks / 6) chunks = kObjChunks / 6;
+    int rc = (int)hipFuncSetAttribute((const void*)objspn_tablegrad_under_k<6, 25, 10, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, kTgLdsU);
+    if (rc) return rc;
+    STOVE_LAUNCH((objspn_tablegrad_under_k<6, 25, 10, 10>), dim3(chunks, 6), dim3(256), kTgLdsU, st, xw, Dscr, Sscr, Rscr, scope, pc, pw, pr, nb, chunks);
+    STOVE_LAUNCH_CHECK();
+  } else if (objspn_tablegrad_valu()) {      // STOVE_TABLEGRAD_VALU=1: the VALU formulation (A/B switch, cross-check in tests)
     STOVE_LAUNCH((objspn_coefgrad_k<6, 25, 10>), dim3(6 * chunks), dim3(128), 0, st, xw, Dscr, scope, pc, nb, chunks);
     STOVE_LAUNCH_CHECK();
     STOVE_LAUNCH((objspn_wgrad_k<6, 10, 10>), dim3(chunks), dim3(6 * 2 * 10 * 2 + 64), 0, st, Sscr, Rscr, pw, pr, nb, chunks);

@@ -400,6 +400,17 @@ def test_state_pipeline_against_torch_chain(mode):
     assert err(zfix, fixed) < 1e-6 and err(zl, full[:, skip:]) < 1e-6 and err(sl, sfull[:, skip:]) < 1e-6
     assert err(init6, full[:, skip - 1]) < 1e-6
     assert err(codes.grad, ref.grad) < 1e-5
+    # with the latent prior draws handed over, the fourth output is the recursion's whole initial state (row stride 18) and
+    # its gradient is read back at that stride
+    noise = torch.randn(n, o, 12, generator=g).to(DEV)
+    w18 = torch.randn(n, o, 18, generator=g).to(DEV)
+    w18[..., :6] = ws[3]
+    c2 = codes.detach().clone().requires_grad_()
+    zfix2, zl2, sl2, init18, idx2 = ops.supair_state(c2, st.sup.zp_span_low(), n, T, o, skip, True, mode, lat_noise=noise)
+    ((zfix2 * ws[0]).sum() + (zl2 * ws[1]).sum() + (sl2 * ws[2]).sum() + (init18 * w18).sum()).backward()
+    assert init18.shape == (n, o, 18) and torch.equal(init18[..., :6], init6) and torch.equal(init18[..., 6:], 0.01 * noise)
+    assert torch.equal(zfix2, zfix) and torch.equal(zl2, zl) and torch.equal(idx2, idx)
+    assert torch.equal(c2.grad, codes.grad)
 
 
 def test_elbo_assembly_against_torch():
