@@ -49,7 +49,14 @@ typedef struct StoveSpnTables {
   const int32_t* bg_side;
   const float* bg_coef;
   const float* bg_wroot;
+  const float* bg_dense;   /* optional: bg_coef as the operand image of the scene forward's leaf GEMM (stove_bg_dense), made
+                            * ahead of time by the caller; NULL = stove_scene_fwd builds it itself at the head of its chain */
 } StoveSpnTables;
+
+/* bg_coef / bg_side -> the dense (3072 x 48, fragment-ordered) coefficient image StoveSpnTables.bg_dense points at;
+ * it depends on the parameters only.  dense: stove_bg_dense_floats() floats. */
+size_t stove_bg_dense_floats(void);
+int stove_bg_dense(const int32_t* bg_side, const float* bg_coef, float* dense, void* stream);
 
 /* Gradients w.r.t. the baked tables (same shapes as above). */
 typedef struct StoveSpnTableGrads {

@@ -20,14 +20,14 @@ EXPORTS = [
     'stove_gnn_bwd', 'stove_dynloop_act_floats', 'stove_dynloop_fwd', 'stove_dynloop_bwd_ws_bytes', 'stove_dynloop_bwd', 'stove_rollout_fwd', 'stove_match_objects', 'stove_profile_enable', 'stove_profile_report', 'stove_gnn_debug_stamps', 'stove_lstm_cell_fwd', 'stove_lstm_cell_bwd',
     'stove_spn_bake', 'stove_spn_bake_bwd', 'stove_arena_gather', 'stove_arena_scatter_add', 'stove_debug_set_stamps',
     'stove_supair_state_fwd', 'stove_supair_state_bwd', 'stove_zall_fwd', 'stove_zall_bwd', 'stove_elbo_fwd', 'stove_elbo_bwd', 'stove_flat_adam', 'stove_flat_adam_ws_bytes', 'stove_gemm_bf16', 'stove_gemm_bf16_ws_floats', 'stove_sum_chunks', 'stove_colsum_ws_floats', 'stove_colsum', 'stove_bw_transform', 'stove_dynloop_bwd_ws_bytes_ts', 'stove_scene_bwd_overlap', 'stove_dynloop_bwd_overlap', 'stove_glimpse_mean', 'stove_objspn_mpe', 'stove_render_frames', 'stove_head_fwd', 'stove_head_bwd_ws_floats', 'stove_head_bwd',
-    'stove_enc_head_fwd', 'stove_enc_head_bwd_ws_floats', 'stove_enc_head_bwd', 'stove_colsum2', 'stove_small_tn', 'stove_small_tn_ws_floats', 'stove_supair_state_fwd2', 'stove_supair_state_bwd2',
+    'stove_enc_head_fwd', 'stove_enc_head_bwd_ws_floats', 'stove_enc_head_bwd', 'stove_colsum2', 'stove_small_tn', 'stove_small_tn_ws_floats', 'stove_supair_state_fwd2', 'stove_supair_state_bwd2', 'stove_bg_dense', 'stove_bg_dense_floats',
 ]
 
 
 class SpnTables(Structure):
     _fields_ = [('obj_scope', c_void_p), ('obj_leaf_slot', c_void_p), ('obj_coef', c_void_p),
                 ('obj_wsum', c_void_p), ('obj_wroot', c_void_p),
-                ('bg_side', c_void_p), ('bg_coef', c_void_p), ('bg_wroot', c_void_p)]
+                ('bg_side', c_void_p), ('bg_coef', c_void_p), ('bg_wroot', c_void_p), ('bg_dense', c_void_p)]
 
 
 class SpnTableGrads(Structure):
@@ -108,6 +108,8 @@ def _declare(lib):
         'stove_flat_adam': (I, [P] * 5 + [S, P, P, P, I, P, P, P, F, F, F, F, F, I, P]),
         'stove_supair_state_fwd': (I, [P] * 10 + [I] * 6 + [P]),
         'stove_supair_state_bwd': (I, [P] * 11 + [I] * 4 + [P]),
+        'stove_bg_dense_floats': (S, []),
+        'stove_bg_dense': (I, [P, P, P, P]),
         'stove_supair_state_fwd2': (I, [P] * 10 + [I, P, I] + [I] * 6 + [P]),
         'stove_supair_state_bwd2': (I, [P] * 8 + [I] + [P] * 3 + [I] * 4 + [P]),
         'stove_zall_fwd': (I, [P, P, P, I, I, I, I, P]),

@@ -208,10 +208,10 @@ class ParamArena:
         bufs = self._take('spn')
         if bufs is None:
             bufs = self._bake_spn()
-        oc, ow, orr, bc, bw = bufs
+        oc, ow, orr, bc, bw, dense = bufs
         scope, slot, side = self._spn['ints']
         return ((oc.view(24, 25, 10, 3), ow.view(12, 100, 10), orr.view(6, 100), scope, slot),
-                (bc.view(3, 1024, 6, 3), bw.view(3, 36), side))
+                (bc.view(3, 1024, 6, 3), bw.view(3, 36), side, dense))
 
     def _bake_spn(self):
         lib = _lib.load()
@@ -221,7 +221,11 @@ class ParamArena:
             oc, ow, orr, bc, bw = torch.split(buf, [18000, 12000, 600, 55296, 108])
             _lib.check(lib.stove_spn_bake(self.data.data_ptr(), ctypes.byref(self._spn['plan']), oc.data_ptr(), ow.data_ptr(),
                                           orr.data_ptr(), bc.data_ptr(), bw.data_ptr(), _lib.stream()), 'stove_spn_bake')
-        return oc, ow, orr, bc, bw
+            # the background coefficients once more as the operand image of the scene forward's leaf GEMM: parameters only,
+            # so it is made here (ahead of time on the second stream when prefetched) and not at the head of the scene chain
+            dense = torch.empty(lib.stove_bg_dense_floats(), dtype=torch.float32, device=dev)
+            _lib.check(lib.stove_bg_dense(self._spn['ints'][2].data_ptr(), bc.data_ptr(), dense.data_ptr(), _lib.stream()), 'stove_bg_dense')
+        return oc, ow, orr, bc, bw, dense
 
     def spn_sink(self, grads):
         """grads = (obj_coef, obj_wsum, obj_wroot, bg_coef, bg_wroot) table gradients -> accumulated into self.grad."""

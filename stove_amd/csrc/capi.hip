@@ -201,7 +201,7 @@ int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z
   rc = objspn_forward(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl, np, st,
                       saved + L.obj_state);
   if (rc) return rc;
-  rc = bgspn_forward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, sb, fm);
+  rc = bgspn_forward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, sb, fm, t->bg_dense);
   if (rc) return rc;
   rc = bg_cover_tables(z, saved + L.cover, n_frames, n_obj, sb);       // for the backward of this z
   if (rc) return rc;
@@ -244,6 +244,13 @@ static int params_late() {
     v = (e != nullptr && e[0] == '1') ? 0 : 1;
   }
   return v;
+}
+
+size_t stove_bg_dense_floats(void) { return (size_t)kBgDenseF; }
+int stove_bg_dense(const int32_t* bg_side, const float* bg_coef, float* dense, void* stream) {
+  STOVE_LAUNCH(bg_dense_fwd_k, dim3((kBgDenseF + 255) / 256), dim3(256), 0, (hipStream_t)stream, bg_side, bg_coef, dense);
+  STOVE_LAUNCH_CHECK();
+  return 0;
 }
 
 int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,

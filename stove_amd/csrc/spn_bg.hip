@@ -539,15 +539,20 @@ static inline float* bg_dense_of(float* ell_part, int n_frames) { return ell_par
 
 // ell_part must stay alive until the backward (it is the saved activation).
 int bgspn_forward(const float* frames, const float* marg, const float* z, int n_obj, const int* side, const float* coef,
-                  const float* wroot, float* ell_part, float* out, int n_frames, hipStream_t st, FrameMap fm = FrameMap{0, 0}) {
+                  const float* wroot, float* ell_part, float* out, int n_frames, hipStream_t st, FrameMap fm = FrameMap{0, 0},
+                  const float* dense = nullptr) {      // dense: the coefficient image of the scene-mode GEMM if the caller has it
   if (n_frames == 0) return 0;
   const int grid = bg_grid(n_frames);
   int halves = kBgHalves;
   if (z != nullptr && n_obj >= 1 && n_obj <= 8) {
     // scene mode: leaf layer as a GEMM on the matrix cores (spn_bg_mfma.hip); ell is (n, 36), one "half"
-    float* Cf = bg_dense_of(ell_part, n_frames);
-    STOVE_LAUNCH(bg_dense_fwd_k, dim3((kBgDenseF + 255) / 256), dim3(256), 0, st, side, coef, Cf);
-    STOVE_LAUNCH_CHECK();
+    const float* Cf = dense;
+    if (Cf == nullptr) {
+      float* own = bg_dense_of(ell_part, n_frames);
+      STOVE_LAUNCH(bg_dense_fwd_k, dim3((kBgDenseF + 255) / 256), dim3(256), 0, st, side, coef, own);
+      STOVE_LAUNCH_CHECK();
+      Cf = own;
+    }
     // one 16-frame tile per wave: at two tiles a launch over 25 344 frames was 198 workgroups of 4 waves -- three quarters of
     // the CUs with one wave per SIMD; 396 workgroups pay the coefficient stream twice (L2) and win 12 % (129 -> 113 us)
     constexpr int TPW = 1;
@@ -559,7 +564,7 @@ int bgspn_forward(const float* frames, const float* marg, const float* z, int n_
   {                                                                                                                               \
     int rc = (int)hipFuncSetAttribute((const void*)bgspn_mfma_fwd_k<TPW, NOBJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     if (rc) return rc;                                                                                                            \
-    STOVE_LAUNCH((bgspn_mfma_fwd_k<TPW, NOBJ>), grid_m, block_m, lds, st, frames, z, n_obj, (const float*)Cf, ell_part, n_frames, fm);  \
+    STOVE_LAUNCH((bgspn_mfma_fwd_k<TPW, NOBJ>), grid_m, block_m, lds, st, frames, z, n_obj, Cf, ell_part, n_frames, fm);  \
   }
     if (n_obj == 3) STOVE_BG_FWD(3)
     else if (n_obj == 6) STOVE_BG_FWD(6)

@@ -24,13 +24,15 @@ def _f32(t):
     return t.contiguous()
 
 
-def _tables(obj=None, bg=None):
-    """obj = (scope, leaf_slot, coef, wsum, wroot), bg = (side, coef, wroot) device tensors."""
+def _tables(obj=None, bg=None, bg_dense=None):
+    """obj = (scope, leaf_slot, coef, wsum, wroot), bg = (side, coef, wroot) device tensors; bg_dense: the prebuilt operand
+    image of the scene forward's leaf GEMM (stove_bg_dense) or None."""
     t = SpnTables()
     if obj is not None:
         t.obj_scope, t.obj_leaf_slot, t.obj_coef, t.obj_wsum, t.obj_wroot = [ptr(x) for x in obj]
     if bg is not None:
         t.bg_side, t.bg_coef, t.bg_wroot = [ptr(x) for x in bg]
+    t.bg_dense = ptr(bg_dense) if bg_dense is not None else None
     return t
 
 
@@ -134,7 +136,7 @@ class _SceneFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, frames, z, obj_coef, obj_wsum, obj_wroot, bg_coef, bg_wroot,
-                obj_scope, obj_leaf_slot, bg_side, n_obj, beta, sink=None):
+                obj_scope, obj_leaf_slot, bg_side, n_obj, beta, sink=None, bg_dense=None):
         lib = _lib.load()
         z = _f32(z)
         tabs = [_f32(x) for x in (obj_coef, obj_wsum, obj_wroot, bg_coef, bg_wroot)]
@@ -158,7 +160,7 @@ class _SceneFn(torch.autograd.Function):
             ll = torch.empty(nf, dtype=torch.float32, device=dev)
             parts = torch.empty(nf, 3, dtype=torch.float32, device=dev)
             saved = torch.empty(lib.stove_scene_saved_floats(nf, n_obj) + 1, dtype=torch.float32, device=dev)
-            t = _tables(obj=(obj_scope, obj_leaf_slot, tabs[0], tabs[1], tabs[2]), bg=(bg_side, tabs[3], tabs[4]))
+            t = _tables(obj=(obj_scope, obj_leaf_slot, tabs[0], tabs[1], tabs[2]), bg=(bg_side, tabs[3], tabs[4]), bg_dense=bg_dense)
             check(lib.stove_scene_fwd(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, float(beta),
                                       ptr(ll), ptr(parts), ptr(saved), stream()), 'stove_scene_fwd')
         ctx.save_for_backward(frames, z, *tabs, obj_scope, obj_leaf_slot, bg_side, saved)
@@ -174,7 +176,7 @@ class _SceneFn(torch.autograd.Function):
         (nf, seq_frames, seq_stride), n_obj = ctx.frame_map, ctx.n_obj
         dev = frames.device
         if dll is None:
-            return (None,) * 13
+            return (None,) * 14
         dll = _f32(dll)
         with torch.cuda.device(dev):
             dz = torch.empty_like(z)
@@ -197,13 +199,13 @@ class _SceneFn(torch.autograd.Function):
                 for buf in (ws, saved, *grads):
                     buf.record_stream(side)          # the caching allocator must not hand these out before `side` is done
                 torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_stream(side))
-                return (None, dz, None, None, None, None, None, None, None, None, None, None, None)
+                return (None, dz, None, None, None, None, None, None, None, None, None, None, None, None)
             check(lib.stove_scene_bwd(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, ctx.beta,
                                       ptr(saved), ptr(dll), ptr(dz), ctypes.byref(g), ptr(ws), stream()), 'stove_scene_bwd')
         if ctx.sink is not None:               # flat parameter arena: table gradients go straight into the bucket
             ctx.sink(grads)
             grads = [None] * 5
-        return (None, dz, *grads, None, None, None, None, None, None)
+        return (None, dz, *grads, None, None, None, None, None, None, None)
 
 
 def objspn_apply(inputs, marg, coef, wsum, wroot, scope, leaf_slot):
@@ -250,13 +252,14 @@ def render_frames(bg, patches, frames_per_patch, z, n_obj):
 
 def scene_likelihood(frames, z, obj_tabs, bg_tabs, n_obj, beta, sink=None):
     """frames (nf,1024), z (nf*n_obj,4)=[sx,sy,x,y]; obj_tabs=(coef,wsum,wroot,scope,leaf_slot),
-    bg_tabs=(coef,wroot,side) -> ll (nf,), parts (nf,3)=(bg, patches, overlap).
+    bg_tabs=(coef,wroot,side[,dense]) -> ll (nf,), parts (nf,3)=(bg, patches, overlap).
     `sink(table_grads)`: receives the five table gradients in backward instead of autograd (ParamArena)."""
     oc, ow, orr, osc, ols = obj_tabs
-    bc, bw, bs = bg_tabs
+    bc, bw, bs = bg_tabs[:3]
+    dense = bg_tabs[3] if len(bg_tabs) > 3 else None      # ParamArena: made with the bake, ahead of the scene chain
     if sink is not None and not z.requires_grad and torch.is_grad_enabled():
         z = z.detach().requires_grad_()        # the sink needs the backward to run
-    return _SceneFn.apply(frames, z, oc, ow, orr, bc, bw, osc, ols, bs, int(n_obj), float(beta), sink)
+    return _SceneFn.apply(frames, z, oc, ow, orr, bc, bw, osc, ols, bs, int(n_obj), float(beta), sink, dense)
 
 
 def scene_glimpses(frames, z, n_obj):
