@@ -282,7 +282,9 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
   if (rc) return rc;
   // The object-SPN table gradients go to the parameter stream: once dz is out (underneath what the caller enqueues next,
   // the recursion's backward), or (STOVE_PARAMS_EARLY=1) right behind their producer.
-  const bool late = sp != st && params_late();
+  // ... for up to four objects: the small-graph recursion (gnn_small*.hip) is the latency-bound kernel with room beside it; the
+  // six/eight-object recursion (gnn.hip) fills the matrix pipe itself and was stretched 2.49 -> 3.20 ms by a co-runner
+  const bool late = sp != st && params_late() && n_obj <= 4;
   if (!late) {
     STOVE_TRY(stream_after(sp, st));
     rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, sp);
