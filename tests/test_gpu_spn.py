@@ -172,6 +172,46 @@ def test_scene_likelihood_vs_oracle_ragged(n_obj):
 
 
 @pytest.mark.parametrize('n_obj', [3, 6])
+def test_scene_backward_with_parameter_stream(n_obj):
+    """stove_scene_bwd_overlap (table gradients on a second stream: for N <= 4 held back and computed by the one-wave-per-SIMD
+    objspn_tablegrad_under_k, csrc/spn_obj.hip; the background GEMM's coefficient image handed over, stove_bg_dense) against
+    stove_scene_bwd (one stream, objspn_tablegrad_k) on the same inputs: same likelihood, dz and table gradients."""
+    from stove_amd import ops, _lib
+    extra = {'debug_match_objects': 'greedy'} if n_obj != 3 else {}
+    c, structs, params, sup = _supair_pair(n_obj, **extra)
+    g = torch.Generator().manual_seed(5 + n_obj)
+    nf = 363                                             # 17 / 34 ragged 64-glimpse batches
+    frames = (torch.rand(nf, 1024, generator=g) ** 2).to(DEV)
+    z = torch.zeros(nf, n_obj, 4)
+    z[..., 0] = 0.1 + 0.6 * torch.rand(nf, n_obj, generator=g)
+    z[..., 1] = z[..., 0] * (0.75 + 0.5 * torch.rand(nf, n_obj, generator=g))
+    z[..., 2:] = 1.9 * torch.rand(nf, n_obj, 2, generator=g) - 0.95
+    z = z.flatten(0, 1).to(DEV)
+    w = torch.linspace(0.5, 1.5, nf).to(DEV)
+    obj_tabs = tuple(t.detach() for t in sup.obj_spn.tables())
+    bg_tabs = tuple(t.detach() for t in sup.bg_spn.tables())
+    # (a) one stream, gradients through autograd
+    leaves = [t.clone().requires_grad_() for t in (*obj_tabs[:3], *bg_tabs[:2])]
+    za = z.clone().requires_grad_()
+    ll_a, _ = ops.scene_likelihood(frames, za, (*leaves[:3], *obj_tabs[3:]), (*leaves[3:], bg_tabs[2]), n_obj, c.overlap_beta)
+    (ll_a * w).sum().backward()
+    # (b) parameter stream + sink, coefficient image made ahead of time
+    lib = _lib.load()
+    dense = torch.empty(lib.stove_bg_dense_floats(), dtype=torch.float32, device=DEV)
+    _lib.check(lib.stove_bg_dense(bg_tabs[2].data_ptr(), bg_tabs[0].data_ptr(), dense.data_ptr(), _lib.stream()), 'stove_bg_dense')
+    got = []
+    zb = z.clone().requires_grad_()
+    ll_b, _ = ops.scene_likelihood(frames, zb, obj_tabs, (*bg_tabs, dense), n_obj, c.overlap_beta, sink=lambda gr: got.extend(t.clone() for t in gr))
+    (ll_b * w).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(ll_a, ll_b)
+    assert err(zb.grad, za.grad) < 1e-6
+    assert len(got) == 5
+    for a, b in zip(leaves, got):
+        assert err(b.view_as(a), a.grad) < 1e-5, (a.shape, err(b.view_as(a), a.grad))
+
+
+@pytest.mark.parametrize('n_obj', [3, 6])
 def test_glimpses_and_masks(n_obj):
     gold = load_golden(f'g3_scene_n{n_obj}')
     c, structs, params, sup = _supair_pair(n_obj, **({'debug_match_objects': 'greedy'} if n_obj == 6 else {}))

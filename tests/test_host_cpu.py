@@ -134,3 +134,19 @@ def test_prediction_error_permutation_gather():
     best = errs.argmin(1).tolist()
     want = torch.stack([pf[i][list(perms[j])] for i, j in enumerate(best)], 0).reshape(n, T, o, 2)
     assert torch.equal(res['pos_matched'], want)
+
+
+def test_settle_host_gc_keeps_the_collector_enabled():
+    """utils.settle_host_gc (called by Trainer.train and bench.py once the step loop is warm): a full collection, then the
+    survivors frozen -- the collector itself stays on, and a later full collection no longer walks the frozen objects."""
+    import gc
+    from stove_amd.utils.utils import settle_host_gc
+    keep = [[i] for i in range(1000)]
+    before = gc.get_freeze_count()
+    settle_host_gc()
+    try:
+        assert gc.isenabled()
+        assert gc.get_freeze_count() > before
+        assert len(keep) == 1000
+    finally:
+        gc.unfreeze()
