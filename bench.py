@@ -44,6 +44,9 @@ def parse():
                    help='recognition-network GEMMs: bf16x3 = fp32 products as 3 bf16 MFMAs on hi/lo-split operands (default), '
                         'fp32 = library GEMMs, bf16 = plain bf16 operands (reported variant, never the headline)')
     p.add_argument('--no-variants', action='store_true', help='skip the bf16-operand / fp32-library side measurements')
+    p.add_argument('--step-mode', default='graph', choices=['graph', 'eager'],
+                   help='graph (default): the step replayed as captured hipGraph(s), as Trainer.train runs its non-logging steps '
+                        '(stove_amd/graphed.py); eager: every launch enqueued by the host (reported as a variant)')
     return p.parse_args()
 
 
@@ -152,9 +155,32 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` with no rendezvous in the environment: start N ranks (one per GPU) with torch.distributed.run and
+    pass their output through.  Runs BEFORE this process touches the GPU (it never does: the workers are fresh processes)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    from stove_amd import build as _build
+    _build.build_library()                      # once, here, instead of N ranks racing for it
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    log('launching %d ranks: %s' % (a.gpus, ' '.join(cmd[1:])))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(a))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != a.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     # hipcc (if the library is stale; keyed on a content hash of the sources) runs BEFORE this process touches the GPU:
@@ -204,7 +230,7 @@ def main():
 
     minus_one = torch.tensor(-1.0, device=dev)
 
-    def step(i):
+    def eager_step(i):
         bucket.zero()
         elbo, _, rewards = model(x, i + 1, actions)
         elbo.backward(minus_one)                                 # d(-ELBO): the loss of train.py:452 without the neg / fill launches
@@ -212,6 +238,18 @@ def main():
         opt.step(max_norm=1.0)                                    # clip_grad_norm_(1) folded into the Adam launch
         return elbo
 
+    # the step as the Trainer runs it between logging steps: captured once, replayed (two graphs around the all-reduce for N > 1)
+    from stove_amd.graphed import GraphedTrainStep
+    graphed = GraphedTrainStep(model, bucket, opt, 1.0, world_size=world, alias_inputs=True)
+
+    def graph_step(i):
+        return graphed(x, actions)
+
+    step = graph_step if a.step_mode == 'graph' else eager_step
+    if a.step_mode == 'graph':
+        step(0)                                   # capture (restores parameters / optimiser / generator: not a training step)
+        torch.cuda.synchronize()
+        log('step captured')
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -235,18 +273,50 @@ def main():
             else:
                 log('gc gen%d %.2f ms collected %d' % (info['generation'], (time.perf_counter() - _g['t']) * 1e3, info['collected']))
         gc.callbacks.append(_cb)
-    if os.environ.get('STOVE_BENCH_WATCH'):           # where is the host when a step stalls: sample the main thread's stack
+    if os.environ.get('STOVE_BENCH_WATCH'):           # where is the host when a step stalls: sample every thread's stack
         import threading, traceback
-        main_id = threading.main_thread().ident
+        main = threading.main_thread()
+        pid = os.getpid()
+        thresh = float(os.environ.get('STOVE_BENCH_WATCH_MS', '6')) * 1e-3
+
+        def _proc(tid, name):
+            try:
+                with open('/proc/%d/task/%d/%s' % (pid, tid, name)) as f:
+                    return f.read().strip()[:200]
+            except OSError as e:
+                return 'n/a (%s)' % e.__class__.__name__
+
         def _watch():
+            seen = -1
             while len(host_t) <= a.steps:
-                time.sleep(0.005)
-                if time.perf_counter() - host_t[-1] > 0.02:
-                    fr = sys._current_frames().get(main_id)
-                    log('step %d stalled %.0f ms at:\n%s' % (len(host_t) - 1, (time.perf_counter() - host_t[-1]) * 1e3,
-                                                           ''.join(traceback.format_stack(fr)[-6:])))
-                    time.sleep(0.02)
-        threading.Thread(target=_watch, daemon=True).start()
+                time.sleep(0.001)
+                k = len(host_t) - 1
+                late = time.perf_counter() - host_t[-1]
+                if late > thresh and k != seen:
+                    seen = k
+                    out = ['step %d: host %.1f ms into it' % (k, late * 1e3)]
+                    frames = sys._current_frames()
+                    for th in threading.enumerate():
+                        if th is threading.current_thread():
+                            continue
+                        fr = frames.get(th.ident)
+                        out.append('  thread %s tid %s state/wchan %s / %s syscall %s' % (
+                            th.name, th.native_id, _proc(th.native_id, 'stat').split(') ')[-1][:1], _proc(th.native_id, 'wchan'),
+                            _proc(th.native_id, 'syscall')))
+                        if fr is not None:
+                            out.append(''.join('    ' + l for l in ''.join(traceback.format_stack(fr)[-7:]).splitlines(True)))
+                    # native threads python does not know (HIP / HSA workers, the autograd engine's pool)
+                    try:
+                        known = {th.native_id for th in threading.enumerate()}
+                        for tid in sorted(int(t) for t in os.listdir('/proc/%d/task' % pid)):
+                            if tid not in known:
+                                st = _proc(tid, 'stat')
+                                out.append('  native tid %d %s state %s wchan %s syscall %s' % (
+                                    tid, st[st.find('('):st.find(')') + 1], st.split(') ')[-1][:1], _proc(tid, 'wchan'), _proc(tid, 'syscall')[:60]))
+                    except OSError:
+                        pass
+                    log('\n'.join(out))
+        threading.Thread(target=_watch, daemon=True, name='watch').start()
     for i in range(a.steps):
         last = step(a.warmup + i)
         marks[i + 1].record()
@@ -277,7 +347,7 @@ def main():
         if rank == 0:
             lib.stove_profile_enable(1)
         for i in range(a.profile_steps):
-            step(a.warmup + a.steps + i)
+            eager_step(a.warmup + a.steps + i)       # event pairs around single launches: not through a captured graph
         torch.cuda.synchronize()
         if rank == 0:
             prof = _lib.profile_report()
@@ -382,17 +452,21 @@ def main():
             model.noise_fn = None
             return float(e)
 
-        def time_of(mode):
+        def time_of(mode, eager=False):
             """median device time per step (event pairs): one stall of the host or the allocator after the mode switch must not
             decide a side measurement"""
             cfg.encoder_gemm = mode
+            vstep = eager_step
+            if a.step_mode == 'graph' and not eager:
+                g_ = GraphedTrainStep(model, bucket, opt, 1.0, world_size=world, alias_inputs=True)
+                vstep = lambda i: g_(x, actions)
             for i in range(3):
-                step(i)
+                vstep(i)
             torch.cuda.synchronize()
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
             ev[0].record()
             for i in range(a.steps):
-                step(i)
+                vstep(i)
                 ev[i + 1].record()
             torch.cuda.synchronize()
             ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))
@@ -412,6 +486,14 @@ def main():
                     opt._flat[k].copy_(v)
                 opt._seg_steps.copy_(snap[2])
         cfg.encoder_gemm = a.encoder_gemm
+        ms, ms_max = time_of(a.encoder_gemm, eager=True)
+        variants['eager'] = {'dtype': 'default path, every launch enqueued by the host (no graph replay)', 'ms_per_step': ms, 'ms_per_step_max': ms_max,
+                             'value': a.batch * a.frames / ms * 1e3, 'unit': 'frames/s'}
+        with torch.no_grad():
+            bucket.data.copy_(snap[0])
+            for k, v in snap[1].items():
+                opt._flat[k].copy_(v)
+            opt._seg_steps.copy_(snap[2])
         log('variants done')
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -430,7 +512,9 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'{a.workload} {cfg.num_obj}-object 32x32 T={a.frames} batch={a.batch}/GPU' + (' (BASELINE.json configs[1])' if a.workload == 'billiards' and a.batch == 256 and a.frames == 100 else ''),
                        'objects': cfg.num_obj, 'global_batch': a.batch * world,
-                       'step': 'forward+backward+allreduce+clip+adam(amsgrad)', 'parallelism': f'dp{world}',
+                       'step': 'forward+backward+allreduce+clip+adam(amsgrad)', 'step_mode': a.step_mode + (
+                           ' (captured hipGraph replay, as Trainer.train runs its non-logging steps)' if a.step_mode == 'graph' else ''),
+                       'parallelism': f'dp{world}',
                        'elbo_last_step': elbo_val,
                        'host_gc': 'collector enabled; long-lived objects frozen after warm-up (gc.collect + gc.freeze, as train.py does)'},
             'roofline': roofline, 'cpu_baseline': cpu, 'variants': variants,

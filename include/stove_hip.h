@@ -273,8 +273,28 @@ int stove_arena_scatter_add(const float* gimage, const int32_t* src, float* grad
 /* out[j] = sum_c parts[c][j] in chunk order (n a multiple of 4): the split-K partials of the weight-gradient GEMMs. */
 int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void* stream);
 
+/* ---- stream ordering and graph replay (no reference counterpart: the reference enqueues ~6000 ATen launches per step from Python,
+ * train.py:443-473; here a step is ~70 launches that a trainer replays as captured hipGraphs, stove_amd/graphed.py).
+ * stove_stream_after: everything enqueued on `to` from now on runs after everything enqueued on `from` so far.  Plain streams: an
+ * event record + wait.  Both streams capturing in the SAME capture: the usual fork / join edge.  Capturing in two DIFFERENT captures:
+ * an event-record node in `from`'s graph and an event-wait node in `to`'s graph on a persistent event -- the graphs then order
+ * against each other at replay, provided the recording graph is launched first.  The *_overlap entry points order their streams
+ * with exactly this call, so they may be captured either way.
+ * stove_capture_begin / _end: capture what is enqueued on `stream` (relaxed mode) into a graph (n_nodes optional);
+ * stove_graph_instantiate: graph -> executable graph (consumes the graph; exec_out NULL-valued for an empty graph);
+ * stove_graph_launch / _destroy: replay / free it. */
+int stove_stream_after(void* to, void* from);
+int stove_capture_begin(void* stream);
+int stove_capture_end(void* stream, void** graph_out, int* n_nodes);
+int stove_graph_instantiate(void* graph, void** exec_out);
+int stove_graph_launch(void* exec, void* stream);
+int stove_graph_destroy(void* exec);
+
 /* bw_transform (reference utils.py): x (n_frames, channels, pixels) -> out (n_frames, pixels) = clamp(sum over channels, 0, 1). */
 int stove_bw_transform(const float* x, float* out, int n_frames, int channels, int pixels, void* stream);
+/* the same from an 8-bit frame store (load_data.py:60-113 keeps float frames on the host; here the training
+ * set may live on the device as uint8 = round(255 v)): out = clamp(sum_c (x_c / 255), 0, 1), fp32. */
+int stove_bw_transform_u8(const unsigned char* x, float* out, int n_frames, int channels, int pixels, void* stream);
 
 /* out[c] = sum_r a[r][c] of a row-major (rows, cols) matrix, cols a multiple of 4 or <= 64 (bias gradients of the
  * recognition network: 25 600 x 1024, 76 800 x 50, 76 800 x 8); ws: stove_colsum_ws_floats(rows, cols) floats.  Fixed summation order. */

@@ -21,6 +21,7 @@ EXPORTS = [
     'stove_spn_bake', 'stove_spn_bake_bwd', 'stove_arena_gather', 'stove_arena_scatter_add', 'stove_debug_set_stamps',
     'stove_supair_state_fwd', 'stove_supair_state_bwd', 'stove_zall_fwd', 'stove_zall_bwd', 'stove_elbo_fwd', 'stove_elbo_bwd', 'stove_flat_adam', 'stove_flat_adam_ws_bytes', 'stove_gemm_bf16', 'stove_gemm_bf16_ws_floats', 'stove_sum_chunks', 'stove_colsum_ws_floats', 'stove_colsum', 'stove_bw_transform', 'stove_dynloop_bwd_ws_bytes_ts', 'stove_scene_bwd_overlap', 'stove_dynloop_bwd_overlap', 'stove_glimpse_mean', 'stove_objspn_mpe', 'stove_render_frames', 'stove_head_fwd', 'stove_head_bwd_ws_floats', 'stove_head_bwd',
     'stove_enc_head_fwd', 'stove_enc_head_bwd_ws_floats', 'stove_enc_head_bwd', 'stove_colsum2', 'stove_small_tn', 'stove_small_tn_ws_floats', 'stove_supair_state_fwd2', 'stove_supair_state_bwd2', 'stove_bg_dense', 'stove_bg_dense_floats',
+    'stove_bw_transform_u8', 'stove_stream_after', 'stove_capture_begin', 'stove_capture_end', 'stove_graph_instantiate', 'stove_graph_launch', 'stove_graph_destroy',
 ]
 
 
@@ -99,6 +100,13 @@ def _declare(lib):
         'stove_small_tn': (I, [P, P, P, P, I, I, I, P]),
         'stove_dynloop_bwd_ws_bytes_ts': (S, [I, I, I]),
         'stove_bw_transform': (I, [P, P, I, I, I, P]),
+        'stove_bw_transform_u8': (I, [P, P, I, I, I, P]),
+        'stove_stream_after': (I, [P, P]),
+        'stove_capture_begin': (I, [P]),
+        'stove_capture_end': (I, [P, POINTER(c_void_p), POINTER(c_int)]),
+        'stove_graph_instantiate': (I, [P, POINTER(c_void_p)]),
+        'stove_graph_launch': (I, [P, P]),
+        'stove_graph_destroy': (I, [P]),
         'stove_colsum_ws_floats': (S, [I, I]),
         'stove_colsum': (I, [P, P, P, I, I, P]),
         'stove_sum_chunks': (I, [P, P, S, I, P]),
@@ -163,8 +171,20 @@ def ptr(t):
     return t.data_ptr()
 
 
+_FORCED_STREAM = None
+
+
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """The stream the C entry points enqueue on: torch's current stream, unless a section redirected the library's launches
+    (force_stream: work routed to the second stream while torch's allocator keeps seeing the current one, ops.run_on_side)."""
+    return _FORCED_STREAM if _FORCED_STREAM is not None else torch.cuda.current_stream().cuda_stream
+
+
+def force_stream(handle):
+    """Redirect the library's launches to the raw stream `handle` (None: back to torch's current stream); returns the previous setting."""
+    global _FORCED_STREAM
+    prev, _FORCED_STREAM = _FORCED_STREAM, handle
+    return prev
 
 
 def profile_report():

@@ -113,6 +113,11 @@ class ParamArena:
         self.grad.zero_()
         self._bind_grads()
 
+    def drop_prefetched(self):
+        """Forget tables / images baked ahead of time (prefetch_images) that nobody consumed: they were made from the
+        parameters as they were THEN.  Called at the end of Stove.forward and by everything that changes the parameters."""
+        self._pre = None
+
     zero = zero_grad
 
     def pack(self):
@@ -131,6 +136,7 @@ class ParamArena:
         """Every rank takes rank `src`'s parameters: ONE broadcast of the flat buffer (all parameters are views into it)."""
         if self.world_size > 1:
             dist.broadcast(self.data, src)
+        self.drop_prefetched()
 
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_(params, max_norm) on the flat buffer (pads are zero)."""
@@ -179,7 +185,7 @@ class ParamArena:
         if not self._on_gpu or os.environ.get('STOVE_NO_OVERLAP', '0') == '1':
             return
         dev = self.data.device
-        main, side = torch.cuda.current_stream(dev), ops._side_stream(dev)
+        main, side = torch.cuda.current_stream(dev), ops._side_stream(dev, 'pre')      # its own stream: joined again inside the forward
         side.wait_stream(main)                       # behind the optimiser's update of self.data
         with torch.cuda.stream(side):
             pre = {}

@@ -380,4 +380,25 @@ __global__ void bw_transform_k(const float* __restrict__ x, float* __restrict__ 
   reinterpret_cast<float4*>(out)[i] = s;
 }
 
+// the same from an 8-bit frame store (load_data.DeviceClipLoader, frame_store='u8'): x (N, C, P) uint8 holding round(255 v);
+// out = clamp(sum_c x_c / 255, 0, 1) -- the division per channel, summed in channel order, as the reference's
+// bw_transform computes it on the float frames u8 / 255 (utils.py:10-15).  One uchar4 (4 pixels) per channel and thread.
+__global__ void bw_transform_u8_k(const unsigned char* __restrict__ x, float* __restrict__ out, int N, int C, int P4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * P4) return;
+  const int n = i / P4, p = i % P4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < C; ++c) {
+    const uchar4 v = reinterpret_cast<const uchar4*>(x)[((size_t)n * C + c) * P4 + p];
+    const float4 f = make_float4((float)v.x / 255.0f, (float)v.y / 255.0f, (float)v.z / 255.0f, (float)v.w / 255.0f);
+    if (c == 0) s = f;
+    else { s.x += f.x; s.y += f.y; s.z += f.z; s.w += f.w; }
+  }
+  s.x = fminf(fmaxf(s.x, 0.0f), 1.0f);
+  s.y = fminf(fmaxf(s.y, 0.0f), 1.0f);
+  s.z = fminf(fmaxf(s.z, 0.0f), 1.0f);
+  s.w = fminf(fmaxf(s.w, 0.0f), 1.0f);
+  reinterpret_cast<float4*>(out)[i] = s;
+}
+
 }  // namespace stove

@@ -760,12 +760,60 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
   return 0;
 }
 
+// ---------------------------------------------------------------- stream ordering / graph replay helpers
+int stove_stream_after(void* to, void* from) { return (int)stream_after((hipStream_t)to, (hipStream_t)from); }
+
+int stove_capture_begin(void* stream) { return (int)hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed); }
+
+int stove_capture_end(void* stream, void** graph_out, int* n_nodes) {
+  hipGraph_t g = nullptr;
+  if (graph_out == nullptr) return (int)hipErrorInvalidValue;
+  *graph_out = nullptr;
+  hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g);
+  if (e != hipSuccess) return (int)e;
+  size_t n = 0;
+  e = hipGraphGetNodes(g, nullptr, &n);
+  if (n_nodes != nullptr) *n_nodes = (int)n;
+  *graph_out = (void*)g;
+  return (int)e;
+}
+
+int stove_graph_instantiate(void* graph, void** exec_out) {
+  if (exec_out == nullptr) return (int)hipErrorInvalidValue;
+  *exec_out = nullptr;
+  if (graph == nullptr) return 0;
+  hipGraph_t g = (hipGraph_t)graph;
+  size_t n = 0;
+  hipError_t e = hipGraphGetNodes(g, nullptr, &n);
+  if (e == hipSuccess && n > 0) {
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e == hipSuccess) *exec_out = (void*)x;
+  }
+  const hipError_t d = hipGraphDestroy(g);
+  return (int)(e != hipSuccess ? e : d);
+}
+
+int stove_graph_launch(void* exec, void* stream) { return (int)hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)stream); }
+
+int stove_graph_destroy(void* exec) { return exec == nullptr ? 0 : (int)hipGraphExecDestroy((hipGraphExec_t)exec); }
+
 int stove_bw_transform(const float* x, float* out, int n_frames, int channels, int pixels, void* stream) {
   if (n_frames == 0) return 0;
   if (pixels % 4 != 0 || channels < 1) return (int)hipErrorInvalidValue;
   const long long total = (long long)n_frames * (pixels / 4);
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   STOVE_LAUNCH(bw_transform_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, n_frames, channels, pixels / 4);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_bw_transform_u8(const unsigned char* x, float* out, int n_frames, int channels, int pixels, void* stream) {
+  if (n_frames == 0) return 0;
+  if (pixels % 4 != 0 || channels < 1) return (int)hipErrorInvalidValue;
+  const long long total = (long long)n_frames * (pixels / 4);
+  if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  STOVE_LAUNCH(bw_transform_u8_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, n_frames, channels, pixels / 4);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -82,8 +82,44 @@ __device__ __forceinline__ float cover(float q, int n, float* dq) {
 // make stream `to` wait for everything enqueued on `from` so far (no-op when they are the same stream).  A failed fork or
 // join would turn into an unordered race on saved tensors / workspaces, so every caller propagates the error code.
 namespace stove {
+// When the caller replays the step as hipGraphs it may capture `to` and `from` in two DIFFERENT captures (stove_amd/graphed.py:
+// the long parameter-gradient chain of the backward pass is its own graph, launched on its own stream, because the runtime's
+// scheduler of ONE multi-branch graph serialised it behind the main chain).  An event recorded in one capture cannot be
+// waited for in another, so the dependency becomes a pair of explicit graph nodes on a persistent event: an event-record node
+// behind `from`'s current capture dependencies, an event-wait node in front of whatever `to` captures next.  The graph that
+// records must be launched before the graph that waits (each replay re-records the event before the wait is enqueued).
+struct CaptureInfo {
+  bool active;
+  unsigned long long id;
+  hipGraph_t graph;
+  const hipGraphNode_t* deps;
+  size_t ndeps;
+};
+inline hipError_t capture_info(hipStream_t s, CaptureInfo* ci) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  ci->id = 0; ci->graph = nullptr; ci->deps = nullptr; ci->ndeps = 0;
+  const hipError_t e = hipStreamGetCaptureInfo_v2(s, &st, &ci->id, &ci->graph, &ci->deps, &ci->ndeps);
+  ci->active = e == hipSuccess && st == hipStreamCaptureStatusActive;
+  return e;
+}
+inline hipError_t capture_add_event_node(hipStream_t s, const CaptureInfo& ci, hipEvent_t ev, bool record) {
+  hipGraphNode_t n;
+  hipError_t e = record ? hipGraphAddEventRecordNode(&n, ci.graph, ci.deps, ci.ndeps, ev)
+                        : hipGraphAddEventWaitNode(&n, ci.graph, ci.deps, ci.ndeps, ev);
+  if (e != hipSuccess) return e;
+  return hipStreamUpdateCaptureDependencies(s, &n, 1, hipStreamSetCaptureDependencies);
+}
 inline hipError_t stream_after(hipStream_t to, hipStream_t from) {
   if (to == from) return hipSuccess;
+  CaptureInfo cf, ct;
+  if (capture_info(from, &cf) == hipSuccess && capture_info(to, &ct) == hipSuccess && cf.active && ct.active && cf.id != ct.id) {
+    hipEvent_t ev;                               // lives as long as the graphs that hold it: never destroyed
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+    e = capture_add_event_node(from, cf, ev, true);
+    if (e != hipSuccess) return e;
+    return capture_add_event_node(to, ct, ev, false);
+  }
   hipEvent_t ev;
   hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e != hipSuccess) return e;

@@ -1,47 +1,118 @@
-"""The training step as ONE captured hipGraph (torch.cuda.CUDAGraph on ROCm).
+"""The training step as captured hipGraphs (torch.cuda.CUDAGraph on ROCm).
 
-At the reference's default training shape (256 clips x 8 visible frames, config.py:17-21) the GPU needs ~0.7 ms per step and
-the host ~2.0 ms to enqueue its ~100 launches (tools/host_time.py): the step is launch-bound.  Capturing
-zero_grad + Stove.forward + backward + clip + Adam once and replaying it removes the host from the loop.  What varies from
-step to step enters through device memory: the batch (copied into static input tensors), the optimiser's step-dependent
-constants (`FlatAdam.hyper`, 5 floats: the learning rate and the fixed betas / eps / clip norm; step counts live on the device), the random draws (torch's graph-safe Philox offsets).
+A step is ~100 launches on three streams.  Enqueued one by one the host is part of the loop: at the reference's default
+training shape (256 clips x 8 visible frames, config.py:17-21) it needs 2 ms for 1 ms of device work, and at the
+100-frame shape any host hiccup (scheduler, allocator, collector) longer than the ~1.4 ms it runs ahead starves the device.
+Captured once and replayed, a step is ONE launch call and the host runs many steps ahead.
 
-Only steps that need nothing but the loss are replayed: logging steps (`step % print_every == 0`, which read prop_dict) and
-multi-process runs (the all-reduce sits between backward and the optimiser) go through the eager path.
+  one process:    [ zero_grad + Stove.forward + backward + clip + Adam ]                 one graph
+  data parallel:  [ zero_grad + Stove.forward + backward ]  all-reduce  [ clip + Adam ]   two graphs, the collective between them
+
+What varies from step to step enters through device memory:
+  * the batch: static input tensors (`alias_inputs=True` adopts the caller's tensors instead of copying into own ones: a
+    caller that refills the same buffers, like bench.py or a loader gathering into `static_images()`, pays no copy);
+  * the step-dependent scalars [lr, beta1, beta2, eps, max_norm, reward weight]: a ring of pinned host slots; slot (step mod
+    SLOTS) is written by the host and copied to the device buffer the kernels read by an asynchronous copy enqueued in front
+    of the replay, so the value travels in stream order and the host never waits for the device unless it is SLOTS steps ahead;
+  * the random draws: torch's graph-safe Philox offsets;
+  * Adam's step counts: on the device (`FlatAdam._seg_steps`).
+
+Steps that need more than the loss (logging steps read prop_dict) go through the eager path of `Trainer.train_step`.
 """
+import os
+
 import torch
+import torch.distributed as dist
+
+SLOTS = 32          # how many steps the host may run ahead of the device
+NHYPER = 8          # floats per slot: lr, beta1, beta2, eps, max_norm, reward weight, (2 spare)
 
 
 class GraphedTrainStep:
-    def __init__(self, stove, arena, optimizer, clip, supair_only=False, warmup=3):
+    def __init__(self, stove, arena, optimizer, clip, supair_only=False, warmup=3, world_size=1, reward_loss=None,
+                 alias_inputs=False):
+        """reward_loss: callable(pred, target) -> scalar for action-conditioned models (train.py:452-465); the loss is then
+        -ELBO + w * reward_loss(rewards, targets) with the host-computed weight w (factor x ramp) passed per step."""
         self.stove, self.arena, self.opt, self.clip = stove, arena, optimizer, clip
         self.supair_only, self.warmup = supair_only, warmup
-        self.graph = None
+        self.world_size = world_size
+        self.reward_loss = reward_loss
+        self.alias_inputs = alias_inputs
+        self.graphs = None
         self.key = None
+        self.reward_value = None
+        self._side_exec = None
 
-    def _eager(self, images, actions, hyper_dev=None):
+    def __del__(self):
+        try:
+            if self._side_exec:
+                from . import _lib
+                _lib.load().stove_graph_destroy(self._side_exec)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ the step, in the two pieces a collective may separate
+    def _fwd_bwd(self):
         self.arena.zero()
         # step_counter 1 with print_every / plot_every > 1: the no-logging branch of Stove.forward
-        elbo, _, _ = self.stove(images, 1, actions, self.supair_only)
-        (-1.0 * elbo).backward()
-        self.opt.step(max_norm=self.clip, hyper_dev=hyper_dev)
+        elbo, _, rewards = self.stove(self.x, 1, self.a, self.supair_only)
+        if self.reward_loss is not None and self.r is not None:
+            rl = self.reward_loss(rewards.flatten(), self.r.flatten())
+            (-1.0 * elbo + self.hyper_dev[5] * rl).backward()
+            self.reward_value = rl.detach()
+        else:
+            elbo.backward(self._minus_one)       # d(-ELBO)
         return elbo.detach()         # nothing may keep the autograd graph (and its AccumulateGrad nodes) alive
 
-    def _capture(self, images, actions):
+    def _update(self):
+        self.opt.step(max_norm=self.clip, hyper_dev=self.hyper_dev)
+
+    def _reduce(self):
+        if self.world_size > 1:
+            self.arena.all_reduce()
+
+    def _eager(self):
+        elbo = self._fwd_bwd()
+        self._reduce()
+        self._update()
+        return elbo
+
+    def _prepare(self, dev):
+        if getattr(self, 'hyper_dev', None) is None or self.hyper_dev.device != dev:
+            self._minus_one = torch.tensor(-1.0, device=dev, dtype=torch.float32)
+            self.hyper_dev = torch.zeros(NHYPER, dtype=torch.float32, device=dev)
+
+    def eager(self, images, actions=None, targets=None, reward_weight=0.0):
+        """The same step enqueued launch by launch on the current stream (what the replay is checked against)."""
+        self._prepare(images.device)
+        self.x, self.a, self.r = images, actions, targets
+        self.hyper_dev.copy_(torch.tensor(self._hyper_now(reward_weight), dtype=torch.float32))
+        elbo = self._eager()
+        self.opt.count_step()
+        self.graphs = None             # the static inputs were rebound: capture again before the next replay
+        return elbo
+
+    # ------------------------------------------------------------------ capture
+    def _capture(self, images, actions, targets):
         dev = images.device
-        self.x = images.clone()
-        self.a = actions.clone() if actions is not None else None
-        self.hyper_dev = torch.empty(5, dtype=torch.float32, device=dev)
-        # warm-up on a side stream (allocator pools, BLAS workspaces, lazily created streams); parameters, optimiser state
-        # and the generator are put back afterwards, so capturing does not count as training
+        own = (lambda t: t) if self.alias_inputs else (lambda t: t.clone())
+        self.x = own(images)
+        self.a = own(actions) if actions is not None else None
+        self.r = own(targets) if targets is not None else None
+        self._prepare(dev)
+        self.ring = torch.zeros(SLOTS, NHYPER, dtype=torch.float32).pin_memory()
+        self._events = [None] * SLOTS
+        self._n = 0
+        self.hyper_dev.copy_(torch.tensor(self._hyper_now(0.0), dtype=torch.float32))
+        # warm-up on a side stream (allocator pools, library workspaces, lazily created streams); parameters, optimiser
+        # state and the generator are put back afterwards, so capturing does not count as training
         snap = (self.arena.data.clone(), {k: v.clone() for k, v in self.opt._flat.items()}, torch.cuda.get_rng_state(dev),
                 self.opt._seg_steps.clone())
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             for _ in range(self.warmup):
-                self._set_hyper()
-                self._eager(self.x, self.a, self.hyper_dev)
+                self._eager()
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         with torch.no_grad():
@@ -50,26 +121,95 @@ class GraphedTrainStep:
                 self.opt._flat[k].copy_(v)
             self.opt._seg_steps.copy_(snap[3])
         torch.cuda.set_rng_state(snap[2], dev)
-        # capture on the stream the warm-up ran on: the autograd nodes then see one stream throughout
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=s):
-            self.elbo = self._eager(self.x, self.a, self.hyper_dev)
-        self.key = (tuple(images.shape), None if actions is None else tuple(actions.shape))
+        # Capture on the stream the warm-up ran on (the autograd nodes then see one stream throughout), as THREE graphs:
+        #   g_main  zero_grad + forward + backward, with its short fork / join episodes (table bake, background-SPN chain)
+        #   g_side  the parameter-gradient chain of the backward pass (SPN table gradients, the recursion's and the recognition
+        #           network's weight gradients): a separate capture of the side stream, ordered against g_main by event nodes
+        #           (stove_stream_after).  As branches of ONE graph the runtime put this chain on the main chain's queue, behind
+        #           it (3.6 instead of 3.1 ms per step); as its own graph on its own stream it runs where the eager step has it.
+        #   g_opt   clip + Adam, after the join of the side stream [and the all-reduce]
+        self._stream = s
+        from . import _lib, ops
+        lib = _lib.load()
+        self._side = ops._side_stream(dev)
+        dump = os.environ.get('STOVE_GRAPH_DUMP')         # debugging: write the captured main DAG (tools/graphdump) to this path
+        g1 = torch.cuda.CUDAGraph(keep_graph=True) if dump else torch.cuda.CUDAGraph()
+        split = os.environ.get('STOVE_GRAPH_ONE', '0') != '1'
+        self._side_exec = None
+        import ctypes
+        side_graph, side_nodes = ctypes.c_void_p(), ctypes.c_int()
+        with torch.cuda.graph(g1, stream=s):
+            # the side capture lives strictly INSIDE the main one: torch synchronises the device before it begins a capture and
+            # flushes deferred allocator events after it ends one -- either would invalidate a capture still open on the side stream
+            if split:
+                _lib.check(lib.stove_capture_begin(self._side.cuda_stream), 'stove_capture_begin')
+                ops.SideMode.split, ops.SideMode.keep = True, []
+            try:
+                self.elbo = self._fwd_bwd()
+            finally:
+                if split:
+                    ops.SideMode.split = False
+                    rc = lib.stove_capture_end(self._side.cuda_stream, ctypes.byref(side_graph), ctypes.byref(side_nodes))
+            if split:
+                _lib.check(rc, 'stove_capture_end')
+            elif self.world_size <= 1:
+                self._update()
+        ops.SideMode.keep = []
+        if split:
+            ex = ctypes.c_void_p()
+            _lib.check(lib.stove_graph_instantiate(side_graph, ctypes.byref(ex)), 'stove_graph_instantiate')
+            self._side_exec, self._side_nodes = ex.value, side_nodes.value
+        if dump:
+            here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            ctypes.CDLL(os.path.join(here, 'tools', 'graphdump', 'libgraphdump.so')).graph_dump(
+                ctypes.c_void_p(g1.raw_cuda_graph()), dump.encode())
+            g1.instantiate()
+        if split or self.world_size > 1:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=s, pool=g1.pool()):
+                self._update()
+            self.graphs = (g1, g2)
+        else:
+            self.graphs = (g1,)
+        self.key = self._key(images, actions, targets)
 
-    def _set_hyper(self):
-        # from pageable memory: the copy is staged before the call returns, so the next step's values cannot overtake it
-        # (a pinned buffer rewritten by a host that runs ahead of the device did exactly that)
-        self.hyper_dev.copy_(torch.tensor(self.opt.hyper(self.clip), dtype=torch.float32))
+    @staticmethod
+    def _key(images, actions, targets):
+        return tuple(None if t is None else (tuple(t.shape), t.dtype) for t in (images, actions, targets))
 
-    def __call__(self, images, actions=None):
+    def _hyper_now(self, reward_weight):
+        return self.opt.hyper(self.clip) + [float(reward_weight), 0.0, 0.0]
+
+    def static_images(self):
+        """The tensor the captured step reads its frames from (None before the first call): a loader that gathers its batch
+        straight into it and passes it back skips the copy."""
+        return getattr(self, 'x', None) if self.graphs is not None else None
+
+    def __call__(self, images, actions=None, targets=None, reward_weight=0.0):
         """One optimisation step on the batch; returns the ELBO (device scalar, overwritten by the next call)."""
-        key = (tuple(images.shape), None if actions is None else tuple(actions.shape))
-        if self.graph is None or key != self.key:
-            self._capture(images, actions)
-        self.x.copy_(images, non_blocking=True)
-        if actions is not None:
-            self.a.copy_(actions, non_blocking=True)
-        self._set_hyper()
-        self.graph.replay()
+        if self.graphs is None or self._key(images, actions, targets) != self.key:
+            self._capture(images, actions, targets)
+        for dst, src in ((self.x, images), (self.a, actions), (self.r, targets)):
+            if dst is not None and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        slot = self._n % SLOTS
+        if self._events[slot] is not None:
+            self._events[slot].synchronize()          # the step that last used this slot has run (blocks only SLOTS steps ahead)
+        else:
+            self._events[slot] = torch.cuda.Event()
+        self.ring[slot] = torch.tensor(self._hyper_now(reward_weight), dtype=torch.float32)
+        self.hyper_dev.copy_(self.ring[slot], non_blocking=True)
+        self.graphs[0].replay()
+        if self._side_exec:
+            from . import _lib
+            lib = _lib.load()
+            main = torch.cuda.current_stream(self.x.device).cuda_stream
+            _lib.check(lib.stove_graph_launch(self._side_exec, self._side.cuda_stream), 'stove_graph_launch')
+            _lib.check(lib.stove_stream_after(main, self._side.cuda_stream), 'stove_stream_after')      # the optimiser reads what it wrote
+        if len(self.graphs) > 1:
+            self._reduce()
+            self.graphs[1].replay()
+        self._events[slot].record()
+        self._n += 1
         self.opt.count_step()
         return self.elbo

@@ -123,12 +123,56 @@ class _BgSpnFn(torch.autograd.Function):
 _SIDE_STREAMS = {}
 
 
-def _side_stream(device):
-    """One extra stream per device for work that only feeds the optimiser (parameter-gradient passes)."""
-    key = str(device)
+def _side_stream(device, kind='side'):
+    """Extra streams per device: 'side' for the work that only feeds the optimiser (the parameter-gradient chain of the backward
+    pass), 'pre' for the parameter-only launches at the top of a step (table bake, GNN image gather)."""
+    key = (str(device), kind)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
+
+
+class SideMode:
+    """How the 'side' stream is driven.  Eager (default): torch's stream context, joined into the main stream when the backward
+    pass is over.  `split` (set by graphed.GraphedTrainStep while it captures): the side stream is under its OWN capture -- its
+    launches become a second graph that the replay launches on the side stream and joins before the optimiser's graph -- so
+    torch's current stream stays the main one (allocations come from the main capture's pool) and only the library's launches
+    are redirected; tensors allocated for side work are kept alive until the capture ends (`keep`), because a block freed
+    inside a capture may be handed out again to main-stream work that runs concurrently with the side graph."""
+    split = False
+    keep = []
+
+
+def _side_keep(*tensors):
+    if SideMode.split and _lib._FORCED_STREAM is not None:
+        SideMode.keep.extend(t for t in tensors if t is not None)
+
+
+def run_on_side(dev, fn, bufs=(), after_main=True):
+    """Enqueue the library launches of fn() on the side stream [after everything the main stream holds so far]; `bufs`: tensors
+    they touch that main-stream code owns (the allocator must not recycle them before the side stream is done)."""
+    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    if after_main:
+        check(_lib.load().stove_stream_after(side.cuda_stream, main.cuda_stream), 'stove_stream_after')
+    if SideMode.split:
+        prev = _lib.force_stream(side.cuda_stream)
+        try:
+            fn()
+        finally:
+            _lib.force_stream(prev)
+    else:
+        with torch.cuda.stream(side):
+            fn()
+    for b in bufs:
+        if b is not None:
+            b.record_stream(side)
+
+
+def join_side_after_backward(dev):
+    """The main stream waits for the side stream once, when the backward pass is over (eager mode; a split capture joins at replay)."""
+    if SideMode.split:
+        return
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_stream(_side_stream(dev)))
 
 
 class _SceneFn(torch.autograd.Function):
@@ -194,11 +238,8 @@ class _SceneFn(torch.autograd.Function):
                                                   ptr(saved), ptr(dll), ptr(dz), ctypes.byref(g), ptr(ws), main.cuda_stream,
                                                   side.cuda_stream),
                       'stove_scene_bwd_overlap')
-                with torch.cuda.stream(side):
-                    ctx.sink(grads)
-                for buf in (ws, saved, *grads):
-                    buf.record_stream(side)          # the caching allocator must not hand these out before `side` is done
-                torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_stream(side))
+                run_on_side(dev, lambda: ctx.sink(grads), (ws, saved, *grads), after_main=False)     # ordered by the C call above
+                join_side_after_backward(dev)
                 return (None, dz, None, None, None, None, None, None, None, None, None, None, None, None)
             check(lib.stove_scene_bwd(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, ctx.beta,
                                       ptr(saved), ptr(dll), ptr(dz), ctypes.byref(g), ptr(ws), stream()), 'stove_scene_bwd')
@@ -410,12 +451,8 @@ class _DynLoopFn(torch.autograd.Function):
                                                     ptr(up(dpred, z)), ptr(dz1), ptr(dzsup), ptr(dzsstd), ptr(dextra), ptr(g), ptr(ws),
                                                     B, Ts, N, sd, lim_enc, elu, *consts, main.cuda_stream, side.cuda_stream),
                       'stove_dynloop_bwd_overlap')
-                with torch.cuda.stream(side):
-                    ctx.sink(g)
-                for buf in (ws, g, act):
-                    if buf is not None:
-                        buf.record_stream(side)
-                torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_stream(side))
+                run_on_side(dev, lambda: ctx.sink(g), (ws, g, act), after_main=False)
+                join_side_after_backward(dev)
                 return (dz1, dzsup, dzsstd, None, dextra) + (None,) * 8
             check(lib.stove_dynloop_bwd(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z), ptr(act),
                                         ptr(up(dz, z)), ptr(up(dzdyn, z)), ptr(up(dmean, z)), ptr(up(dstd, z)),
@@ -623,13 +660,20 @@ def elbo(zs, mean, std, zdyn, lik, trans_std, n, T, o, skip):
 
 @torch.no_grad()
 def bw_transform(x):
-    """(n, T, C, w, h) frames -> (n, T, 1, w, h): channel sum clamped to [0, 1], one pass (reads 3 channels once)."""
+    """(n, T, C, w, h) frames -> (n, T, 1, w, h): channel sum clamped to [0, 1], one pass (reads the channels once).
+    fp32 frames, or uint8 frames holding round(255 v) (the 8-bit device frame store): then each channel is divided by 255 first."""
     lib = _lib.load()
-    x = _f32(x)
+    if not x.is_cuda:
+        raise RuntimeError('stove_amd HIP ops need tensors on a GPU (cuda:N); there is no CPU path')
+    u8 = x.dtype == torch.uint8
+    x = x.contiguous() if u8 else _f32(x)
     n, T, C, w, h = x.shape
     with torch.cuda.device(x.device):
         out = torch.empty(n, T, 1, w, h, dtype=torch.float32, device=x.device)
-        check(lib.stove_bw_transform(ptr(x), ptr(out), n * T, C, w * h, stream()), 'stove_bw_transform')
+        if u8:
+            check(lib.stove_bw_transform_u8(ptr(x), ptr(out), n * T, C, w * h, stream()), 'stove_bw_transform_u8')
+        else:
+            check(lib.stove_bw_transform(ptr(x), ptr(out), n * T, C, w * h, stream()), 'stove_bw_transform')
     return out
 
 
@@ -698,25 +742,43 @@ def linear(x, weight, bias):
 # switch it off (STOVE_DIRECT_GRADS=0 or ops.DIRECT_GRADS = False).
 # ------------------------------------------------------------------------------------------------
 DIRECT_GRADS = os.environ.get('STOVE_DIRECT_GRADS', '1') != '0'
-_GRAD_VIEWS = {}
+_GRAD_VIEWS = {}            # id(parameter) -> (weak reference to the parameter, its gradient view): dies with the parameter
 
 
 def register_grad_view(p, g):
-    """ParamArena: g is the flat-gradient view of parameter p (None: forget it)."""
+    """ParamArena: g is the flat-gradient view of parameter p (None: forget it).  Keyed on the parameter OBJECT (not its
+    address, which a later tensor may reuse): the entry goes away with the parameter or when a new arena rebinds it."""
+    import weakref
+    key = id(p)
     if g is None:
-        _GRAD_VIEWS.pop(p.data_ptr(), None)
-    else:
-        _GRAD_VIEWS[p.data_ptr()] = g
+        _GRAD_VIEWS.pop(key, None)
+        return
+
+    def _gone(ref, key=key):
+        ent = _GRAD_VIEWS.get(key)
+        if ent is not None and ent[0] is ref:
+            del _GRAD_VIEWS[key]
+    _GRAD_VIEWS[key] = (weakref.ref(p, _gone), g)
 
 
-def _grad_views(*params):
-    """The registered gradient views of all of `params`, or None if direct accumulation is off / any of them has none."""
+def _grad_views(*params, needs=None):
+    """The registered gradient views of all of `params`, or None if direct accumulation is off or any of them is not bound
+    to a live view: the view must belong to this very parameter object, still BE its `.grad` (an arena that was replaced,
+    an optimizer.zero_grad(set_to_none) or a plain Adam detach it) and the parameter must want a gradient (`needs`: the
+    ctx.needs_input_grad flags of the parameters; torch.autograd.grad() with other inputs leaves them False).  None sends the
+    gradients through autograd as usual."""
     if not DIRECT_GRADS:
+        return None
+    if needs is not None and not all(needs):
         return None
     out = []
     for p in params:
-        g = _GRAD_VIEWS.get(p.data_ptr())
-        if g is None or g.shape != p.shape or g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
+        ent = _GRAD_VIEWS.get(id(p))
+        if ent is None or ent[0]() is not p or not p.requires_grad:
+            return None
+        g = ent[1]
+        if p.grad is None or p.grad.data_ptr() != g.data_ptr() or g.shape != p.shape or g.dtype != torch.float32 \
+                or not g.is_contiguous() or g.device != p.device:
             return None
         out.append(g)
     return out
@@ -792,7 +854,7 @@ class _EncoderHeadFusedFn(torch.autograd.Function):
         g = _f32(g)
         dev = h.device
         gh = torch.empty_like(h)
-        views = _grad_views(w1, b1, w2, b2)
+        views = _grad_views(w1, b1, w2, b2, needs=ctx.needs_input_grad[1:5])
         outs = views if views is not None else [torch.empty_like(t) for t in (w1, b1, w2, b2)]
         with torch.cuda.device(dev):
             ws = torch.empty(lib.stove_enc_head_bwd_ws_floats(rows, HID), dtype=torch.float32, device=dev)
@@ -921,7 +983,7 @@ class _EncoderLstmFn(torch.autograd.Function):
         dhs = _f32(dhs if ctx.time_major else dhs.transpose(0, 1))                       # (K, n, H)
         # Parameter gradients straight into the arena's views (see _grad_views): no AccumulateGrad launches, and the two
         # weight-gradient GEMMs run on the second stream next to the rest of this backward -- only the optimiser reads them.
-        views = _grad_views(w_ih, w_hh, b_ih, b_hh) if (ns and gemm_ok(n) and not ctx.needs_input_grad[0]) else None
+        views = _grad_views(w_ih, w_hh, b_ih, b_hh, needs=ctx.needs_input_grad[1:5]) if (ns and gemm_ok(n) and not ctx.needs_input_grad[0]) else None
         fork = views is not None and os.environ.get('STOVE_NO_OVERLAP', '0') != '1'
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if fork else main
@@ -934,11 +996,7 @@ class _EncoderLstmFn(torch.autograd.Function):
 
         def on_side(fn, *bufs):
             if fork:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    fn()
-                for b in bufs:
-                    b.record_stream(side)          # the caching allocator must not hand these out before `side` is done
+                run_on_side(dev, fn, bufs)
             else:
                 fn()
         with torch.cuda.device(dev):
@@ -970,11 +1028,12 @@ class _EncoderLstmFn(torch.autograd.Function):
                 # of inter-queue signalling on top of the work)
                 def bias_sums():
                     ws = torch.empty(lib.stove_colsum_ws_floats(n, 4 * H) + 1, dtype=torch.float32, device=dev)
+                    _side_keep(ws)
                     check(lib.stove_colsum2(ptr(dgx), ptr(views[2]), ptr(views[3]), 1, ptr(ws), n, 4 * H, stream()), 'stove_colsum2')
                 on_side(bias_sums, dgx)
                 wgrad(dgx, x, out=views[0])
                 if fork:
-                    torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_stream(side))
+                    join_side_after_backward(dev)
                 return None, None, None, None, None, None, None, None
             d_whh = wgrad(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H)) if K > 1 else None
             if d_whh is None:
@@ -1021,6 +1080,7 @@ def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=
         c = torch.empty(M, N, dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device):
         ws = torch.empty(lib.stove_gemm_bf16_ws_floats(M, N, splitk), dtype=torch.float32, device=a.device) if splitk > 1 else None
+        _side_keep(ws, c)
         check(lib.stove_gemm_bf16(ptr(a), ptr(b), ptr(bias) if bias is not None else None, ptr(_f32(add)) if add is not None else None,
                                   ptr(c), M, N, K, a.stride(0), b.stride(0), N, int(a_kmajor), int(b_kmajor), nsplit, splitk, tile,
                                   ptr(ws) if ws is not None else None, stream()), 'stove_gemm_bf16')

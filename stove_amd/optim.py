@@ -18,7 +18,13 @@ class FlatAdam(torch.optim.Optimizer):
     step count, and a tensor steps only when it is trainable and received a gradient this step -- in the flat buffer "no
     gradient" is a slice that is exactly zero (frozen SuPAIR parameters under `supair_grad=False`, the dynamics cores 1-2
     that are never run, the dynamics network during `supair_only` pretraining).  So loaded moments of frozen parameters do
-    not move them, and parameters that start training late get their own bias corrections (include/stove_hip.h)."""
+    not move them, and parameters that start training late get their own bias corrections (include/stove_hip.h).
+
+    Deliberate deviation: a tensor whose gradient is exactly ZERO everywhere is treated like `grad is None` (no step, no moment
+    decay, no step-count tick).  torch.optim.Adam still steps a parameter whose `.grad` is a zero tensor (its momentum keeps
+    moving it) -- the reference reaches that state only through `optimizer.zero_grad()` leaving zero tensors on parameters that
+    then receive no gradient, which for its models means "never used" (dynamics cores 1-2) or "frozen by a training phase":
+    the cases listed above, where not moving is what torch does for `grad is None`.  tests/test_gpu_optim.py pins both readings."""
 
     def __init__(self, arena, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, amsgrad=False):
         if arena.data.dtype != torch.float32 or not arena.data.is_cuda:
@@ -76,6 +82,7 @@ class FlatAdam(torch.optim.Optimizer):
         vmax = self._flat.get('max_exp_avg_sq')
         if hyper_dev is None:
             self._steps += 1
+        ar.drop_prefetched()                # tables baked from the old parameters are stale from here on
         with torch.cuda.device(ar.data.device):
             _lib.check(_lib.load().stove_flat_adam(
                 ar.data.data_ptr(), ar.grad.data_ptr(), self._flat['exp_avg'].data_ptr(), self._flat['exp_avg_sq'].data_ptr(),
@@ -110,5 +117,6 @@ class FlatAdam(torch.optim.Optimizer):
                         view.zero_()
                 steps.append(float(st['step']) if 'step' in st else 0.0)
         self._seg_steps.copy_(torch.tensor(steps, dtype=torch.float32))
+        self.arena.drop_prefetched()
         self._steps = int(max(steps)) if steps else 0
         self._bind()

@@ -12,10 +12,14 @@ import torch
 
 
 def bw_transform(x):
-    """(n, T, 3, w, h) one-ball-per-channel frames -> (n, T, 1, w, h): channel sum clamped to [0, 1]."""
-    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and (x.shape[-1] * x.shape[-2]) % 4 == 0 and not x.requires_grad:
+    """(n, T, 3, w, h) one-ball-per-channel frames -> (n, T, 1, w, h): channel sum clamped to [0, 1].
+    [amd] uint8 frames (the 8-bit device frame store, values round(255 v)) are scaled by 1/255 per channel on the way."""
+    if x.is_cuda and x.dtype in (torch.float32, torch.uint8) and x.dim() == 5 and (x.shape[-1] * x.shape[-2]) % 4 == 0 \
+            and not x.requires_grad:
         from .. import ops
         return ops.bw_transform(x)               # one fused pass on the GPU (the training input path)
+    if x.dtype == torch.uint8:
+        x = x.to(torch.float32) / 255.0
     return torch.clamp(x.sum(2), 0, 1).unsqueeze(2)
 
 

@@ -48,7 +48,9 @@ _DEFAULTS = dict(
     fused_dynamics=True,     # run the inference recursion in the persistent HIP time-loop kernel
     fused_state=True,        # constrain_zp / matching / fix_supair / velocities as the fused state pipeline (csrc/state.hip)
     fused_elbo=True,         # log q, transition likelihood and the ELBO means in two launches
-    graph_step=False,        # Trainer: replay the non-logging training steps as one captured hipGraph (stove_amd/graphed.py)
+    graph_step=True,         # Trainer: replay the non-logging training steps as captured hipGraph(s) (stove_amd/graphed.py)
+    frame_store='auto',      # DeviceClipLoader: 'auto' (bw plane as fp32 when the model only sees bw frames, else colour fp32), 'bw32', 'u8', 'f32'
+    input_bw_plane=False,    # Stove.forward: single-channel input frames are already bw_transform(x) (set by the Trainer for frame_store bw32)
     device_dataset=True,     # Trainer: training set resident on the GPU, batches gathered there (load_data.DeviceClipLoader)
     device_dataset_gb=64.0,  # ... when it needs at most this much HBM
     encoder_gemm='bf16x3',   # recognition-network GEMMs: 'bf16x3' (fp32 as 3 bf16 MFMAs on hi/lo-split operands), 'fp32' (library), 'bf16'

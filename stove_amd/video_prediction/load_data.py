@@ -89,19 +89,45 @@ class DeviceClipLoader:
     world x batch_size (weak scaling, what bench.py measures); `last_clip_ids` is what the last batch was cut from.
     """
 
-    def __init__(self, dataset, batch_size, device, dtype, shuffle=True, drop_last=True, rank=0, world=1, seed=0):
+    def __init__(self, dataset, batch_size, device, dtype, shuffle=True, drop_last=True, rank=0, world=1, seed=0, frame_store='f32'):
+        """frame_store -- how the frames live in HBM (a compact device-resident frame store):
+          'f32'   colour frames in the model dtype, what the reference's loader hands over (12 KB per 32x32 frame);
+          'bw32'  the bw plane itself: bw_transform (utils.py:10-15), a deterministic per-frame function, applied ONCE at upload
+                  and kept as fp32 -- bit-identical model input, 4 KB per frame, no per-step transform pass; batches carry
+                  (n, T, 1, w, h) images and the model must be told (config.input_bw_plane, set by the Trainer);
+          'u8'    colour frames as uint8 = round(255 v), 3 KB per frame; the first kernel of the step converts on load
+                  (stove_bw_transform_u8).  Lossy for float renderings (|dv| <= 1/510 per channel), exact for 8-bit sources."""
         import torch
+        if frame_store not in ('f32', 'bw32', 'u8'):
+            raise ValueError("frame_store must be 'f32', 'bw32' or 'u8'")
         self.ds, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
         self.rank, self.world, self.seed, self.epoch = int(rank), int(world), int(seed), 0
         self.last_clip_ids = None
+        self.frame_store = frame_store
+        self.present_images_out = None        # optional (batch, nv, c, w, h) tensor that receives the gathered present_images
         c = dataset.c
         self.step, self.nv, self.nr = c.frame_step, c.num_visible, c.num_rollout
 
         def up(a):
             t = torch.as_tensor(np.ascontiguousarray(a)).to(device=device, dtype=dtype)
             return t.view(t.shape[0] * t.shape[1], *t.shape[2:])
+
+        def up_images(img):
+            if frame_store == 'f32':
+                return up(img)
+            if frame_store == 'u8':
+                q = np.rint(np.clip(np.asarray(img, dtype=np.float64), 0.0, 1.0) * 255.0).astype(np.uint8)
+                t = torch.as_tensor(np.ascontiguousarray(q)).to(device=device)
+                return t.view(t.shape[0] * t.shape[1], *t.shape[2:])
+            from ..utils.utils import bw_transform
+            parts = []
+            for e0 in range(0, img.shape[0], 64):           # 64 episodes at a time: the colour copy is transient
+                x = torch.as_tensor(np.ascontiguousarray(img[e0:e0 + 64])).to(device=device, dtype=dtype)
+                parts.append(bw_transform(x))
+            t = torch.cat(parts, 0)
+            return t.view(t.shape[0] * t.shape[1], *t.shape[2:])
         self.n_frames = dataset.total_img.shape[1]
-        self.store = {'images': up(dataset.total_img), 'labels': up(dataset.total_data)}
+        self.store = {'images': up_images(dataset.total_img), 'labels': up(dataset.total_data)}
         if dataset.rl:
             self.store.update(actions=up(dataset.total_actions), rewards=up(dataset.total_rewards), dones=up(dataset.total_dones))
         self.idxs = torch.as_tensor(dataset.idxs, dtype=torch.long)
@@ -110,13 +136,24 @@ class DeviceClipLoader:
         self._future = (self.nv + torch.arange(self.nr, device=device)) * self.step
 
     @staticmethod
-    def nbytes(dataset, dtype):
+    def nbytes(dataset, dtype, frame_store='f32'):
         import torch
         item = torch.empty((), dtype=dtype).element_size()
-        n = dataset.total_img.size + dataset.total_data.size
+        img = dataset.total_img
+        if frame_store == 'u8':
+            n_img = img.size
+        elif frame_store == 'bw32':
+            n_img = img.size // img.shape[2] * item
+        else:
+            n_img = img.size * item
+        n = dataset.total_data.size
         if dataset.rl:
             n += dataset.total_actions.size + dataset.total_rewards.size + dataset.total_dones.size
-        return n * item
+        return n_img + n * item
+
+    def store_bytes(self):
+        """Bytes of HBM the resident set occupies."""
+        return sum(t.numel() * t.element_size() for t in self.store.values())
 
     def __len__(self):
         n = len(self.idxs) // self.world
@@ -129,7 +166,14 @@ class DeviceClipLoader:
         pres, fut = base[:, None] + self._present, base[:, None] + self._future
         out = {}
         for name, t in self.store.items():
-            out['present_' + name] = t[pres]
+            dst = self.present_images_out if name == 'images' else None
+            if dst is not None and dst.dtype == t.dtype and tuple(dst.shape) == (pres.shape[0], pres.shape[1]) + tuple(t.shape[1:]):
+                import torch
+                # straight into the caller's static buffer (the captured step's input): no second copy of the batch
+                torch.index_select(t, 0, pres.reshape(-1), out=dst.view(-1, *t.shape[1:]))
+                out['present_' + name] = dst
+            else:
+                out['present_' + name] = t[pres]
             out['future_' + name] = t[fut]
         return out
 

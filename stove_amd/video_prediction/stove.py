@@ -339,10 +339,22 @@ class Stove(nn.Module):
         self.dyn.step_counter = step_counter
         x_color = x
         if self.c.debug_bw:
-            x = bw_transform(x)
+            # [amd] a loader that keeps the training set as the bw plane itself (load_data.DeviceClipLoader, frame_store='bw32':
+            # bw_transform applied once, at upload) hands over (n, T, 1, w, h) frames and says so in config.input_bw_plane
+            if not (x.shape[2] == 1 and x.dtype != torch.uint8 and getattr(self.c, 'input_bw_plane', False)):
+                x = bw_transform(x)
+        elif x.dtype == torch.uint8:
+            x = x.to(self.c.dtype) / 255.0
+        if x_color.dtype == torch.uint8 and (self.c.debug_core_appearance or self.c.debug_match_appearance):
+            x_color = x_color.to(x.dtype) / 255.0
         if pretrain:
             elbo, prop_dict = self.sup(x)
             return elbo, prop_dict, 0
-        if self.c.debug_core_appearance or self.c.debug_match_appearance:
-            return self.stove_forward(x, actions=actions, x_color=x_color)
-        return self.stove_forward(x, actions=actions)
+        try:
+            if self.c.debug_core_appearance or self.c.debug_match_appearance:
+                return self.stove_forward(x, actions=actions, x_color=x_color)
+            return self.stove_forward(x, actions=actions)
+        finally:
+            arena = getattr(self.dyn, '_arena', None)
+            if arena is not None:
+                arena.drop_prefetched()      # whatever was baked ahead and not consumed must not outlive this call

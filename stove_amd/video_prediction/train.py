@@ -39,7 +39,7 @@ class AbstractTrainer:
         self._graphed = None
         self.dataloader = train_dataset
         self.test_dataset = test_dataset
-        self.test_dataloader = self._make_loader(test_dataset)
+        self.test_dataloader = self._make_loader(test_dataset, test=True)
         self.optimizer = optim.Adam(self.stove.parameters(), lr=self.c.learning_rate, amsgrad=self.c.debug_amsgrad)
         if self.c.load_encoder is not None:
             self.load_encoder()
@@ -68,13 +68,21 @@ class AbstractTrainer:
             return
         self.bucket.sync(0)
         if isinstance(self.optimizer, FlatAdam):
-            broadcast_tensors(list(self.optimizer._flat.values()), 0)
+            broadcast_tensors(list(self.optimizer._flat.values()) + [self.optimizer._seg_steps], 0)   # moments AND per-tensor step counts
             self.optimizer._steps = broadcast_int(self.optimizer._steps)
+            self.optimizer._bind()
         else:
             broadcast_tensors([v for st in self.optimizer.state.values() for v in st.values() if torch.is_tensor(v)], 0)
         self.epoch_start, self.step_start = broadcast_int(self.epoch_start), broadcast_int(self.step_start)
         seed = int(getattr(self.c, 'dp_seed', 0)) + self.rank
         torch.manual_seed(seed)                 # CPU and every device generator: eps of rank r = stream (dp_seed + r)
+        self._resume_loader_epoch()
+
+    def _resume_loader_epoch(self):
+        """The per-epoch clip permutations are seeded dp_seed + epoch: a resumed run continues the sequence at epoch_start."""
+        for ld in (getattr(self, '_train_dataset', None),):
+            if ld is not None and hasattr(ld, 'epoch'):
+                ld.epoch = int(self.epoch_start)
 
     @property
     def dataloader(self):
@@ -84,16 +92,21 @@ class AbstractTrainer:
     def dataloader(self, train_dataset):
         self._train_dataset = self._make_loader(train_dataset)
 
-    def _make_loader(self, dataset):
+    def _make_loader(self, dataset, test=False):
         """Shuffled, drop-last batches of clips (reference train.py:39-44, 69-76).  [amd] The set lives on the GPU and batches are
         gathered there (no per-step host collate / PCIe copy) when it fits the budget; otherwise the reference's DataLoader."""
         dev = torch.device(self.c.device)
         budget = float(getattr(self.c, 'device_dataset_gb', 64.0)) * 2 ** 30
         seed = int(getattr(self.c, 'dp_seed', 0))
+        fs = self._frame_store()
         if dev.type == 'cuda' and getattr(self.c, 'device_dataset', True) \
-                and DeviceClipLoader.nbytes(dataset, self.c.dtype) <= budget:
+                and DeviceClipLoader.nbytes(dataset, self.c.dtype, fs) <= budget:
+            if test:        # evaluation: rank 0's pass over the WHOLE test set, in order (no shard, no shuffle)
+                return DeviceClipLoader(dataset, self.c.batch_size, dev, self.c.dtype, shuffle=False, drop_last=True, frame_store=fs)
             return DeviceClipLoader(dataset, self.c.batch_size, dev, self.c.dtype, shuffle=True, drop_last=True,
-                                    rank=self.rank, world=self.world_size, seed=seed)
+                                    rank=self.rank, world=self.world_size, seed=seed, frame_store=fs)
+        if test:
+            return DataLoader(dataset, batch_size=self.c.batch_size, shuffle=False, num_workers=self.c.num_workers, drop_last=True)
         if self.world_size > 1:
             return ShardedDataLoader(dataset, self.c.batch_size, self.c.num_workers, self.rank, self.world_size, seed)
         return DataLoader(dataset, batch_size=self.c.batch_size, shuffle=True, num_workers=self.c.num_workers, drop_last=True)
@@ -120,6 +133,7 @@ class AbstractTrainer:
         else:
             self.stove.load_state_dict(ckpt)
         print('Parameters loaded from {}.'.format(self.c.checkpoint_path))
+        self._resume_loader_epoch()
         self.sync_replicas()
 
     def load_encoder(self):
@@ -137,6 +151,26 @@ class AbstractTrainer:
 
     def init_t(self, tensor):
         return tensor.type(self.c.dtype).to(device=self.c.device)
+
+    def init_images(self, tensor):
+        """[amd] Frames for the model: uint8 frames of the 8-bit device store pass through (the step's first kernel converts them)."""
+        if tensor.dtype == torch.uint8:
+            return tensor.to(device=self.c.device)
+        return self.init_t(tensor)
+
+    def _frame_store(self):
+        """[amd] config.frame_store: 'auto' keeps the bw plane (fp32, bit-identical model input) when the model only ever sees
+        bw frames -- single-channel SPNs and no appearance features -- and colour fp32 otherwise; 'u8' / 'f32' / 'bw32' force one."""
+        fs = getattr(self.c, 'frame_store', 'auto')
+        bw_only = bool(self.c.debug_bw) and self.c.channels == 1 and not (self.c.debug_core_appearance or self.c.debug_match_appearance) \
+            and self.c.dtype == torch.float32
+        if fs == 'auto':
+            fs = 'bw32' if bw_only else 'f32'
+        if fs == 'bw32' and not bw_only:
+            raise ValueError("frame_store='bw32' needs a model that consumes bw frames only (debug_bw, channels=1, no appearance features, float32)")
+        if fs == 'bw32':
+            self.c.input_bw_plane = True          # Stove.forward: (n, T, 1, w, h) inputs are already bw_transform(x)
+        return fs
 
     def adjust_learning_rate(self, optimizer, value, step):
         lr = max(self.c.learning_rate * np.exp(-step / value), self.c.min_learning_rate)
@@ -250,8 +284,10 @@ class Trainer(AbstractTrainer):
 
     # ------------------------------------------------------------------ training
     def _graph_ok(self, step_counter):
-        """config.graph_step: replay the captured step when nothing but the loss is needed from it."""
-        if not getattr(self.c, 'graph_step', False) or self.world_size > 1 or self.c.action_conditioned:
+        """config.graph_step (default on): replay the captured step when nothing but the loss is needed from it -- every
+        step that does not log.  Data-parallel runs replay two graphs around the all-reduce; action-conditioned runs pass the
+        reward targets and the ramped reward weight through device memory (stove_amd/graphed.py)."""
+        if not getattr(self.c, 'graph_step', True):
             return False
         if not isinstance(self.optimizer, FlatAdam) or torch.device(self.c.device).type != 'cuda':
             return False
@@ -260,12 +296,27 @@ class Trainer(AbstractTrainer):
         if self._graphed is None:
             from ..graphed import GraphedTrainStep
             self._graphed = GraphedTrainStep(self.stove, self.bucket, self.optimizer, 1 if self.c.debug_gradient_clip else None,
-                                             self.c.supair_only)
+                                             self.c.supair_only, world_size=self.world_size,
+                                             reward_loss=self.reward_loss if self.c.action_conditioned else None)
         return True
+
+    def _graph_step(self, data, step_counter):
+        """One replayed step on a batch dict -> (elbo, min_ll, mse_rewards) as device scalars (values of THIS step until the next call)."""
+        images = self.init_images(data['present_images'])
+        if not self.c.action_conditioned:
+            elbo = self._graphed(images)
+            return elbo, -1.0 * elbo, torch.zeros(1)
+        actions = self.init_t(data['present_actions'])
+        target = self.init_t(data['present_rewards'][:, self.c.skip:])
+        ramp = self.c.debug_reward_rampup
+        weight = self.c.debug_reward_factor * (min(1, step_counter / ramp) if ramp is not False else 1)
+        elbo = self._graphed(images, actions, target, reward_weight=weight)
+        rl = self._graphed.reward_value
+        return elbo, -1.0 * elbo + weight * rl, rl
 
     def train_step(self, data, step_counter):
         """One optimisation step on a batch dict (present_images [, present_actions, present_rewards])."""
-        images = self.init_t(data['present_images'])
+        images = self.init_images(data['present_images'])
         actions = self.init_t(data['present_actions']) if self.c.action_conditioned else None
         self.bucket.zero()
         elbo, prop_dict, rewards = self.stove(images, step_counter, actions, self.c.supair_only)
@@ -306,10 +357,13 @@ class Trainer(AbstractTrainer):
                 if self.c.debug_anneal_lr:
                     self.adjust_learning_rate(self.optimizer, self.c.debug_anneal_lr, step_counter)
                 if self._graph_ok(step_counter):
-                    # [amd] launch-bound shapes: the whole step replayed as one captured hipGraph (stove_amd/graphed.py);
-                    # steps that log (they read prop_dict) stay eager
-                    elbo = self._graphed(self.init_t(data['present_images']))
-                    prop_dict, rewards, min_ll, mse_rewards = self.stove.prop_dict, None, -1.0 * elbo, torch.zeros(1)
+                    # [amd] the whole step replayed as captured hipGraph(s) (stove_amd/graphed.py): one launch call instead of ~100,
+                    # the host runs many steps ahead of the device; steps that log (they read prop_dict) stay eager
+                    elbo, min_ll, mse_rewards = self._graph_step(data, step_counter)
+                    prop_dict, rewards = self.stove.prop_dict, None
+                    out = self._graphed.static_images()
+                    if out is not None and hasattr(self.dataloader, 'present_images_out'):
+                        self.dataloader.present_images_out = out     # later batches are gathered straight into the step's input
                 else:
                     elbo, prop_dict, rewards, min_ll, mse_rewards = self.train_step(data, step_counter)
                     elbo, min_ll = elbo.detach(), min_ll.detach()      # values only from here on: drop the autograd graph
@@ -352,7 +406,7 @@ class Trainer(AbstractTrainer):
         self.stove.eval()
         for i, data in enumerate(self.test_dataloader):
             now = time.time() - start
-            present = self.init_t(data['present_images'])
+            present = self.init_images(data['present_images'])
             actions = future_actions = future_rewards = None
             if self.c.action_conditioned:
                 actions = self.init_t(data['present_actions'])

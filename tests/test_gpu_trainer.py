@@ -183,7 +183,7 @@ def test_graphed_train_step_matches_eager(tmp_path):
         p0 = arena.data.clone()
         elbos = []
         for b in batches:
-            e = step(b) if graphed else step._eager(b, None)
+            e = step(b) if graphed else step.eager(b)
             elbos.append(float(e))
             if len(elbos) == 1:
                 p1 = arena.data.clone()
@@ -212,7 +212,7 @@ def test_trainer_graph_step(tmp_path):
     trainer.train()
     n_steps = len(trainer.dataloader)
     assert n_steps >= 10 and trainer.optimizer._steps == n_steps
-    assert trainer._graphed is not None and trainer._graphed.graph is not None
+    assert trainer._graphed is not None and trainer._graphed.graphs is not None
     assert torch.isfinite(trainer.bucket.data).all() and not torch.equal(before, trainer.bucket.data)
 
 
