@@ -110,6 +110,14 @@ int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z
 int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
                     int seq_stride, float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g,
                     void* ws, void* stream, void* param_stream);
+/* The same with the stream the internal background-SPN chain forks from given explicitly (NULL = `stream`).  For callers that run the
+ * scene calls on a stream which is itself a fork inside a hipGraph capture: pass the capture's origin stream, where frames, z, saved
+ * and dll must then be ready (the HIP 7.0 runtime cannot end a capture in which two forked streams wait on each other). */
+int stove_scene_fwd_from(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
+                         int seq_stride, float overlap_beta, float* ll, float* parts, float* saved, void* stream, void* fork_from);
+int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
+                         int seq_stride, float overlap_beta, const float* saved, const float* dll, float* dz,
+                         StoveSpnTableGrads* g, void* ws, void* stream, void* param_stream, void* fork_from);
 
 /* Stove.object_embedding (stove.py:565-590): emb (n_frames*n_obj, channels) = mean over the 10x10 glimpse of object k of
  * colour frame x_color (n_frames, channels, 32, 32); z (n_frames*n_obj, 4) = [sx, sy, x, y].  No gradients. */
@@ -190,6 +198,24 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
                               float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
                               float pos_var, float vel_std, float lat_std, void* stream, void* param_stream);
 
+/* ---- the recursion in PIECES (pipelining it against the scene likelihood of the frames already inferred; the loop of stove.py:696-713
+ * is T-serial and latency-bound with one sequence per CU, the likelihood of frame t only needs z_t, stove.py:731-736).  All tensors
+ * keep their full (B, Ts, ...) layout; a call runs the steps [ts0, ts1).  Forward: a piece with ts0 > 0 starts from the state the
+ * previous piece left in z.  Backward: pieces are called from the last to the first; the gradient that flows from step ts0 into the
+ * state before it goes through `carry` (B, N, 18 floats, written when ts0 > 0, read when ts1 < Ts); dz1 is written by the piece with
+ * ts0 == 0, which also runs the weight-gradient pass (g_params, on param_stream) over the streams of ALL steps.  Small-graph kernels
+ * only (stove_dynloop_range_ok(N) != 0: 2 <= N <= 4 and the streamed backward enabled); otherwise only the whole range is accepted. */
+int stove_dynloop_range_ok(int N);
+int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+                            const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred, float* act,
+                            int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
+                            int ts0, int ts1, void* stream);
+int stove_dynloop_bwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+                            const float* params, const float* z, const float* act, const float* dz, const float* dzdyn,
+                            const float* dmean, const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd,
+                            float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
+                            float pos_var, float vel_std, float lat_std, int ts0, int ts1, float* carry, void* stream, void* param_stream);
+
 /* ---- Stove.rollout (stove.py:777-861), mean prediction: z_last (B,N,18) [sx,sy,...] ->
  * z_pred (B,num,N,18); zstd (B,num,N,16) and pred (B,num,N,32) optional; extra (B,A,N,E) cycled (t % A). */
 int stove_rollout_fwd(const float* z_last, const float* extra, const float* params, float* z_pred, float* zstd, float* pred,
@@ -237,6 +263,12 @@ int stove_supair_state_bwd2(const float* zc, const long long* idx, const unsigne
 int stove_zall_fwd(const float* zfix, const float* zs, float* zall, int n, int T, int o, int skip, void* stream);
 int stove_zall_bwd(const float* zfix, const float* zs, const float* g_zall, float* g_zfix, float* g_zs, int n, int T, int o, int skip,
                    void* stream);
+/* the same for the scored frames [f0, f1) of the T-1 only (zall (n, f1-f0, o, 4) dense): the likelihood in pieces.  The backward
+ * of a piece writes dz_tot = dz_in (NULL = 0) + the likelihood's part for ALL 18 dims of the piece's sampled steps (layout of zs) --
+ * the total gradient the recursion's backward consumes -- and, for the piece with f0 == 0, every element of g_zfix (n, T, o, 8). */
+int stove_zall_fwd_range(const float* zfix, const float* zs, float* zall, int n, int T, int o, int skip, int f0, int f1, void* stream);
+int stove_zall_bwd_range(const float* zfix, const float* zs, const float* g_zall, const float* dz_in, float* g_zfix, float* dz_tot,
+                         int n, int T, int o, int skip, int f0, int f1, void* stream);
 int stove_elbo_fwd(const float* zs, const float* mean, const float* std_, const float* zdyn, const float* lik, const float* trans_std16,
                    float* part_ws, float* out3, int n, int T, int o, int skip, void* stream);
 int stove_elbo_bwd(const float* zs, const float* mean, const float* std_, const float* zdyn, const float* trans_std16, const float* g_out,
@@ -272,6 +304,15 @@ int stove_arena_scatter_add(const float* gimage, const int32_t* src, float* grad
 
 /* out[j] = sum_c parts[c][j] in chunk order (n a multiple of 4): the split-K partials of the weight-gradient GEMMs. */
 int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void* stream);
+
+/* ---- auxiliary streams.  Every entry point only enqueues on the stream(s) it is given -- with ONE exception: the scene calls
+ * (stove_scene_fwd / _bwd and their variants) run their background-SPN chain next to the object-SPN chain on a per-device FORK stream
+ * that the library creates on first use (hipStreamNonBlocking), forks from the call's stream and joins back before the call's last
+ * kernel, so the caller sees single-stream semantics (STOVE_NO_OVERLAP=1 in the environment: no fork at all).  A caller that wants to
+ * own that stream -- several models per device, its own capture discipline -- hands it over here: stream != NULL = use this one,
+ * NULL = run the chain on the call's stream; restore_default != 0 = back to the library-owned stream.  Thread-safe; takes effect for
+ * calls enqueued afterwards.  The only other process-global state is the measurement hook at the end of this header. */
+int stove_set_fork_stream(int device, void* stream, int restore_default);
 
 /* ---- stream ordering and graph replay (no reference counterpart: the reference enqueues ~6000 ATen launches per step from Python,
  * train.py:443-473; here a step is ~70 launches that a trainer replays as captured hipGraphs, stove_amd/graphed.py).

@@ -22,6 +22,7 @@ EXPORTS = [
     'stove_supair_state_fwd', 'stove_supair_state_bwd', 'stove_zall_fwd', 'stove_zall_bwd', 'stove_elbo_fwd', 'stove_elbo_bwd', 'stove_flat_adam', 'stove_flat_adam_ws_bytes', 'stove_gemm_bf16', 'stove_gemm_bf16_ws_floats', 'stove_sum_chunks', 'stove_colsum_ws_floats', 'stove_colsum', 'stove_bw_transform', 'stove_dynloop_bwd_ws_bytes_ts', 'stove_scene_bwd_overlap', 'stove_dynloop_bwd_overlap', 'stove_glimpse_mean', 'stove_objspn_mpe', 'stove_render_frames', 'stove_head_fwd', 'stove_head_bwd_ws_floats', 'stove_head_bwd',
     'stove_enc_head_fwd', 'stove_enc_head_bwd_ws_floats', 'stove_enc_head_bwd', 'stove_colsum2', 'stove_small_tn', 'stove_small_tn_ws_floats', 'stove_supair_state_fwd2', 'stove_supair_state_bwd2', 'stove_bg_dense', 'stove_bg_dense_floats',
     'stove_bw_transform_u8', 'stove_stream_after', 'stove_capture_begin', 'stove_capture_end', 'stove_graph_instantiate', 'stove_graph_launch', 'stove_graph_destroy',
+    'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_bwd_from', 'stove_dynloop_range_ok', 'stove_dynloop_fwd_range', 'stove_dynloop_bwd_range', 'stove_zall_fwd_range', 'stove_zall_bwd_range',
 ]
 
 
@@ -61,6 +62,8 @@ def _declare(lib):
         'stove_bgspn_bwd': (I, [T, P, P, P, P, P, P, P, G, P, I, P]),
         'stove_scene_saved_floats': (S, [I, I]),
         'stove_scene_fwd': (I, [T, P, P, I, I, I, I, F, P, P, P, P]),
+        'stove_scene_fwd_from': (I, [T, P, P, I, I, I, I, F, P, P, P, P, P]),
+        'stove_scene_bwd_from': (I, [T, P, P, I, I, I, I, F, P, P, P, G, P, P, P, P]),
         'stove_scene_bwd_ws_bytes': (S, [I, I]),
         'stove_scene_bwd': (I, [T, P, P, I, I, I, I, F, P, P, P, G, P, P]),
         'stove_scene_bwd_overlap': (I, [T, P, P, I, I, I, I, F, P, P, P, G, P, P, P]),
@@ -102,6 +105,12 @@ def _declare(lib):
         'stove_bw_transform': (I, [P, P, I, I, I, P]),
         'stove_bw_transform_u8': (I, [P, P, I, I, I, P]),
         'stove_stream_after': (I, [P, P]),
+        'stove_set_fork_stream': (I, [I, P, I]),
+        'stove_dynloop_range_ok': (I, [I]),
+        'stove_dynloop_fwd_range': (I, [P] * 13 + [I] * 6 + [F] * 3 + [I, I, P]),
+        'stove_dynloop_bwd_range': (I, [P] * 19 + [I] * 6 + [F] * 3 + [I, I, P, P, P]),
+        'stove_zall_fwd_range': (I, [P, P, P, I, I, I, I, I, I, P]),
+        'stove_zall_bwd_range': (I, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
         'stove_capture_begin': (I, [P]),
         'stove_capture_end': (I, [P, POINTER(c_void_p), POINTER(c_int)]),
         'stove_graph_instantiate': (I, [P, POINTER(c_void_p)]),

@@ -162,19 +162,34 @@ size_t stove_scene_saved_floats(int n_frames, int n_obj) { return scene_saved_la
 // Internal fork stream (one per device, created on first use): the background-SPN chain of a scene call runs on it next
 // to the object-SPN chain -- they are independent until the assemble / tail kernels -- and is joined back before the call
 // returns, so callers see plain single-stream semantics.  STOVE_NO_OVERLAP=1 keeps everything on the caller's stream.
+static hipStream_t g_fork_user[16] = {nullptr};
+static bool g_fork_user_set[16] = {false};
+static std::mutex g_fork_mu;
+
 static hipStream_t scene_fork_stream(hipStream_t st) {
   static hipStream_t side[16] = {nullptr};
   static const bool off = [] {
     const char* e = getenv("STOVE_NO_OVERLAP");
     return e != nullptr && e[0] == '1';
   }();                                           // C++11 static initialisation: thread-safe
-  static std::mutex mu;
   if (off) return st;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return st;
-  std::lock_guard<std::mutex> lock(mu);           // backward is called from the autograd thread, forward from the main one
+  std::lock_guard<std::mutex> lock(g_fork_mu);    // backward is called from the autograd thread, forward from the main one
+  if (g_fork_user_set[dev]) return g_fork_user[dev] != nullptr ? g_fork_user[dev] : st;      // the caller's stream (NULL: no fork at all)
   if (side[dev] == nullptr && hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking) != hipSuccess) return st;
   return side[dev];
+}
+
+// The caller owns the fork stream of `device` from now on (the scene calls run their background-SPN chain on it, forked from and joined
+// into the call's stream): stream != NULL -- use this one; NULL -- no internal fork, everything on the call's stream.
+// restore_default != 0: back to the library-owned stream that is created on first use.
+int stove_set_fork_stream(int device, void* stream, int restore_default) {
+  if (device < 0 || device >= 16) return (int)hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_fork_mu);
+  g_fork_user_set[device] = restore_default == 0;
+  g_fork_user[device] = restore_default == 0 ? (hipStream_t)stream : nullptr;
+  return 0;
 }
 
 static int frame_map(int n_frames, int seq_frames, int seq_stride, FrameMap* fm) {
@@ -187,14 +202,24 @@ static int frame_map(int n_frames, int seq_frames, int seq_stride, FrameMap* fm)
 
 int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
                     int seq_stride, float overlap_beta, float* ll, float* parts, float* saved, void* stream) {
+  return stove_scene_fwd_from(t, frames, z, n_frames, n_obj, seq_frames, seq_stride, overlap_beta, ll, parts, saved, stream, stream);
+}
+
+// fork_from: the stream the internal background-SPN chain is ordered behind (its inputs -- frames, z, tables -- must be ready there).
+// Normally `stream` itself.  A caller that runs the call on a stream which is itself a fork of a stream under hipGraph capture passes
+// that capture's ORIGIN stream: the HIP 7.0 runtime cannot end a capture in which two forked streams wait on each other
+// (fork from X, join into X, with X not the origin: hip::Stream::EndCapture recurses forever; tools/ubench/graph_ext2.hip).
+int stove_scene_fwd_from(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
+                         int seq_stride, float overlap_beta, float* ll, float* parts, float* saved, void* stream, void* fork_from) {
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t root = fork_from != nullptr ? (hipStream_t)fork_from : st;
   if (n_frames == 0) return 0;
   FrameMap fm;
   if (frame_map(n_frames, seq_frames, seq_stride, &fm)) return (int)hipErrorInvalidValue;
   const SceneSaved L = scene_saved_layout(n_frames, n_obj);
   const int np = n_frames * n_obj;
   hipStream_t sb = scene_fork_stream(st);       // background chain (MFMA-bound) next to the object chain (VALU-bound)
-  STOVE_TRY(stream_after(sb, st));              // fork: inputs are ready in `st` order
+  STOVE_TRY(stream_after(sb, root));            // fork: inputs are ready in `root` order
   JoinGuard jb(st, sb);                         // joined on every exit path
   int rc = scene_tile_fwd_any(frames, z, saved + L.xw, n_obj, np, st, fm);
   if (rc) return rc;
@@ -262,7 +287,15 @@ int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z
 int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
                             int seq_stride, float overlap_beta, const float* saved, const float* dll, float* dz,
                             StoveSpnTableGrads* g, void* ws_, void* stream, void* param_stream) {
+  return stove_scene_bwd_from(t, frames, z, n_frames, n_obj, seq_frames, seq_stride, overlap_beta, saved, dll, dz, g, ws_, stream, param_stream, stream);
+}
+
+// fork_from: see stove_scene_fwd_from (the background chain's inputs -- frames, z, saved, dll -- must be ready in its order)
+int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
+                         int seq_stride, float overlap_beta, const float* saved, const float* dll, float* dz,
+                         StoveSpnTableGrads* g, void* ws_, void* stream, void* param_stream, void* fork_from) {
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t root = fork_from != nullptr ? (hipStream_t)fork_from : st;
   hipStream_t sp = param_stream != nullptr ? (hipStream_t)param_stream : st;
   if (n_frames == 0) return 0;
   FrameMap fm;
@@ -274,7 +307,7 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
   STOVE_LAUNCH(scene_assemble_bwd_k, dim3((np + 255) / 256), dim3(256), 0, st, dll, z, ws + W.d_obj, ws + W.d_ovl, n_obj, np, overlap_beta);
   STOVE_LAUNCH_CHECK();
   hipStream_t sb = scene_fork_stream(st);       // background chain next to the object chain, joined before the tail
-  STOVE_TRY(stream_after(sb, st));
+  STOVE_TRY(stream_after(sb, root));
   JoinGuard jb(st, sb);                         // error paths: the tail below is what joins `sb` normally
   JoinGuard jp(st, sp);                         // error paths only: the caller joins the parameter stream after a clean return
   int rc = objspn_backward_data(saved + L.xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot,
@@ -443,12 +476,23 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
                       const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred, float* act,
                       int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
                       void* stream) {
+  return stove_dynloop_fwd_range(z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu,
+                                 pos_var, vel_std, lat_std, 0, Ts, stream);
+}
+
+int stove_dynloop_range_ok(int N) { return (N >= 2 && N <= 4 && small_bwd_enabled()) ? 1 : 0; }
+
+int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+                            const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred, float* act,
+                            int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
+                            int ts0, int ts1, void* stream) {
   if (B == 0 || Ts == 0) return 0;
+  if (ts0 < 0 || ts1 > Ts || ts0 >= ts1) return (int)hipErrorInvalidValue;
+  if ((ts0 != 0 || ts1 != Ts) && !(N >= 2 && N <= 4)) return (int)hipErrorInvalidValue;      // pieces: small-graph kernels only
   if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && extra == nullptr)) return (int)hipErrorInvalidValue;
   LoopConst kc{pos_var, vel_std, lat_std};
   if (N <= 4 && N >= 2) {      // small graphs: row-per-wave VALU formulation, two barriers per step (gnn_small.hip)
-    // STOVE_LOOP_VALU=1: the all-VALU edge phase (A/B switch; the default runs the edge chains on the matrix cores)
-    static const bool em = !(getenv("STOVE_LOOP_VALU") != nullptr && getenv("STOVE_LOOP_VALU")[0] == '1');
+    constexpr bool em = true;        // edge chains on the matrix cores (the round-1 all-VALU edge phase, EM = false, is no longer instantiated)
 #define STOVE_LOOP_LAUNCH_N(SAVE_, EM_, ELU_, NT_, STREAMS)                                                                     \
   do {                                                                                                                          \
     int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_fwd_small_k<SAVE_, EM_, ELU_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -456,7 +500,7 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
     if (rc) return rc;                                                                                                          \
     STOVE_LAUNCH((dyn_loop_fwd_small_k<SAVE_, EM_, ELU_, NT_>), dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream, \
                  z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, \
-                 g_sm_stamps);                                                                                                  \
+                 g_sm_stamps, ts0, ts1);                                                                                        \
   } while (0)
 #define STOVE_LOOP_LAUNCH_E(SAVE_, EM_, ELU_, STREAMS)                  \
   do {                                                                  \
@@ -473,18 +517,16 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
                                         (int)(kSmLdsFloats * sizeof(float)));
       if (rc) return rc;
       STOVE_LAUNCH((dyn_loop_fwd_small_k<2, true, false, 3, true>), dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
-                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps);
+                   z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps,
+                   ts0, ts1);
     } else if (act != nullptr) {
       if (small_bwd_enabled()) {
-        if (em) STOVE_LOOP_LAUNCH(2, true, 0);
-        else STOVE_LOOP_LAUNCH(2, false, 0);
+        STOVE_LOOP_LAUNCH(2, true, 0);
       } else {
-        if (em) STOVE_LOOP_LAUNCH(1, true, 0);
-        else STOVE_LOOP_LAUNCH(1, false, 0);
+        STOVE_LOOP_LAUNCH(1, true, 0);
       }
     } else {
-      if (em) STOVE_LOOP_LAUNCH(0, true, 0);
-      else STOVE_LOOP_LAUNCH(0, false, 0);
+      STOVE_LOOP_LAUNCH(0, true, 0);
     }
 #undef STOVE_LOOP_LAUNCH
 #undef STOVE_LOOP_LAUNCH_E
@@ -536,7 +578,19 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
                               const float* dmean, const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd,
                               float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
                               float pos_var, float vel_std, float lat_std, void* stream, void* param_stream) {
+  return stove_dynloop_bwd_range(z1, zsup, zsstd, eps, extra, params, z, act, dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra,
+                                 g_params, ws, B, Ts, N, sin_dim, lim_enc, elu, pos_var, vel_std, lat_std, 0, Ts, nullptr, stream, param_stream);
+}
+
+int stove_dynloop_bwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+                            const float* params, const float* z, const float* act, const float* dz, const float* dzdyn,
+                            const float* dmean, const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd,
+                            float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
+                            float pos_var, float vel_std, float lat_std, int ts0, int ts1, float* carry, void* stream, void* param_stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (ts0 < 0 || ts1 > Ts || ts0 >= ts1) return (int)hipErrorInvalidValue;
+  const bool whole = ts0 == 0 && ts1 == Ts;
+  if (!whole && (!small_bwd_path(N, act) || carry == nullptr)) return (int)hipErrorInvalidValue;
   hipStream_t sp = param_stream != nullptr ? (hipStream_t)param_stream : st;
   if (B == 0 || Ts == 0) return (int)hipErrorInvalidValue;
   if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && (extra == nullptr || dextra == nullptr)))
@@ -546,7 +600,7 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
     // small graphs: T-serial data-gradient chain (gnn_small_bwd.hip), then the weight gradients as a throughput pass
     float* gpart = (float*)ws;
     float* dy = gpart + (size_t)B * kGnnGrads;
-    static const bool em = !(getenv("STOVE_LOOP_VALU") != nullptr && getenv("STOVE_LOOP_VALU")[0] == '1');     // as stove_dynloop_fwd
+    constexpr bool em = true;        // as stove_dynloop_fwd
     int rc = 0;
 #define STOVE_LOOPB_LAUNCH_H(EM_, ELU_, NT_, HD_)                                                                                               \
   do {                                                                                                                                \
@@ -555,7 +609,7 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
     if (rc) return rc;                                                                                                                \
     STOVE_LAUNCH((dyn_loop_bwd_small_k<EM_, ELU_, NT_, HD_>), dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, \
                  params, const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim,   \
-                 lim_enc, elu, kc, g_sm_stamps);                                                                                      \
+                 lim_enc, elu, kc, g_sm_stamps, ts0, ts1, carry);                                                                     \
   } while (0)
     const bool head = dz != nullptr && dzdyn != nullptr && dmean != nullptr && dstd != nullptr && dpred == nullptr && sin_dim == 16 && lim_enc == 2;
 #define STOVE_LOOPB_LAUNCH(EM_, ELU_)                                     \
@@ -570,14 +624,13 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
       if (rc) return rc;
       STOVE_LAUNCH((dyn_loop_bwd_small_k<true, false, 3, true, true>), dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd,
                    eps, params, const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim,
-                   lim_enc, elu, kc, g_sm_stamps);
-    } else if (em && elu) STOVE_LOOPB_LAUNCH(true, true);
-    else if (em) STOVE_LOOPB_LAUNCH(true, false);
-    else if (elu) STOVE_LOOPB_LAUNCH(false, true);
-    else STOVE_LOOPB_LAUNCH(false, false);
+                   lim_enc, elu, kc, g_sm_stamps, ts0, ts1, carry);
+    } else if (elu) STOVE_LOOPB_LAUNCH(true, true);
+    else STOVE_LOOPB_LAUNCH(true, false);
 #undef STOVE_LOOPB_LAUNCH
 #undef STOVE_LOOPB_LAUNCH_H
     STOVE_LAUNCH_CHECK();
+    if (ts0 > 0) return 0;           // the weight-gradient pass contracts the streams of ALL steps: behind the piece that ends the backward
     rc = (int)hipFuncSetAttribute((const void*)gnn_dw_small_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDwLdsFloats * sizeof(float)));
     if (rc) return rc;
     STOVE_TRY(stream_after(sp, st));        // the weight-gradient pass reads the dY streams; it only feeds the optimiser (second stream)
@@ -977,6 +1030,28 @@ int stove_zall_bwd(const float* zfix, const float* zs, const float* g_zall, floa
   if (n == 0) return 0;
   const int M = n * T * o + n * (T - skip) * o;
   STOVE_LAUNCH(zall_bwd_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, zfix, zs, g_zall, g_zfix, g_zs, n, T, o, skip);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_zall_fwd_range(const float* zfix, const float* zs, float* zall, int n, int T, int o, int skip, int f0, int f1, void* stream) {
+  if (n == 0) return 0;
+  if (f0 < 0 || f1 > T - 1 || f0 >= f1 || skip < 1) return (int)hipErrorInvalidValue;
+  const int M = n * (f1 - f0) * o;
+  STOVE_LAUNCH(zall_fwd_range_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, zfix, zs, zall, n, T, o, skip, f0, f1);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_zall_bwd_range(const float* zfix, const float* zs, const float* g_zall, const float* dz_in, float* g_zfix, float* dz_tot,
+                         int n, int T, int o, int skip, int f0, int f1, void* stream) {
+  if (n == 0) return 0;
+  if (f0 < 0 || f1 > T - 1 || f0 >= f1 || skip < 1) return (int)hipErrorInvalidValue;
+  const int s0 = (f0 > skip - 1 ? f0 : skip - 1) - (skip - 1), s1 = f1 - (skip - 1);
+  const int M = (f0 == 0 ? n * T * o : 0) + n * (s1 > s0 ? s1 - s0 : 0) * o;
+  if (M == 0) return 0;
+  STOVE_LAUNCH(zall_bwd_range_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, zfix, zs, g_zall, dz_in, g_zfix, dz_tot, n, T, o,
+               skip, f0, f1);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -695,7 +695,9 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
     float* __restrict__ z, float* __restrict__ zdyn, float* __restrict__ zdstd, float* __restrict__ mean,
     float* __restrict__ stdv, float* __restrict__ pred, float* __restrict__ act,
-    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc, long long* stamps) {
+    int B, int Ts, int N, int sin_dim, int lim_enc, int elu, LoopConst kc, long long* stamps, int ts0, int ts1) {
+  // steps [ts0, ts1) of the Ts the tensors are laid out for: a caller that pipelines the recursion against the scene likelihood of
+  // the frames already inferred runs it in pieces; a piece that does not start at 0 takes the state the previous one left in z
   constexpr bool SAVE = SAVEM != 0;
   if (!STAMP) stamps = nullptr;      // the 16 stamp sites of a step vanish (a run-time null check each was ~50 instructions per step)
   constexpr int streams = SAVEM == 2 ? 1 : 0;       // compile-time: the two pointer sets were both built every step and selected
@@ -716,11 +718,11 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
   float sinv = 0.0f;
   const int r = wv;
   if (wv < N) {
-    if (l < 16) sinv = z1[((size_t)b * N + r) * 18 + 2 + l];
-    else if (l < sin_dim) sinv = extra[(((size_t)b * Ts + 0) * N + r) * E + (l - 16)];
+    if (l < 16) sinv = ts0 == 0 ? z1[((size_t)b * N + r) * 18 + 2 + l] : z[(((size_t)b * Ts + ts0 - 1) * N + r) * 18 + 2 + l];
+    else if (l < sin_dim) sinv = extra[(((size_t)b * Ts + ts0) * N + r) * E + (l - 16)];
   }
   WG_SYNC();
-  for (int ts = 0; ts < Ts; ++ts) {
+  for (int ts = ts0; ts < ts1; ++ts) {
     const size_t o = ((size_t)b * Ts + ts) * N + r;
     // this step's epilogue inputs and the next step's extra inputs: issued now, consumed ~2 us later
     float ep = 0.0f, ms = 0.0f, ss = 1.0f, xnext = 0.0f;
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     }
     SmAct a{};
     if (SAVE) a = streams ? sm_act2(act + (size_t)b * sm_act2_floats(N, Ts), N, Ts, ts) : sm_act(act + ((size_t)b * Ts + ts) * act_stride, N);
-    cf.stamps = (ts == Ts - 1) ? stamps : nullptr;
+    cf.stamps = (ts == ts1 - 1) ? stamps : nullptr;
     float res = 0.0f, prd = 0.0f;
     sm_step<SAVE, EM>(L, cf, sinv, a, res, prd, el);
     if (wv < N) {

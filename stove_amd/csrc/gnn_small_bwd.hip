@@ -203,7 +203,9 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     float* __restrict__ act, const float* __restrict__ dz, const float* __restrict__ dzdyn, const float* __restrict__ dmean,
     const float* __restrict__ dstd, const float* __restrict__ dpred, float* __restrict__ dz1, float* __restrict__ dzsup,
     float* __restrict__ dzsstd, float* __restrict__ dextra, float* __restrict__ dy, int B, int Ts, int N, int sin_dim, int lim_enc,
-    int elu, LoopConst kc, long long* stamps) {
+    int elu, LoopConst kc, long long* stamps, int ts0, int ts1, float* __restrict__ carry) {
+  // steps ts1-1 .. ts0 of the Ts the tensors are laid out for (see dyn_loop_fwd_small_k).  The gradient that flows from step ts0
+  // into the state before it leaves through `carry` (B, N, 18; layout of dz1) when ts0 > 0 and enters there when ts1 < Ts.
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // the chain is issue-latency bound: where another kernel's wave shares the SIMD (the table gradients that run underneath,
   // objspn_tablegrad_under_k) the arbiter picks this one whenever it is ready
@@ -238,18 +240,19 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
   float car = 0.0f;                                   // lane d < 16: gradient carried into z[t][2 + d] from step t + 1
   SmBNodeIn nin{};
   if (node) {
-    const SmAct a = sm_act2(aseq, N, Ts, Ts - 1);
-    nin = smb_node_load(a, r, l, ((size_t)b * Ts + Ts - 1) * N + r, eps, zsup, zsstd, dz, dzdyn, dmean, dstd, dpred);
+    const SmAct a = sm_act2(aseq, N, Ts, ts1 - 1);
+    nin = smb_node_load(a, r, l, ((size_t)b * Ts + ts1 - 1) * N + r, eps, zsup, zsstd, dz, dzdyn, dmean, dstd, dpred);
+    if (ts1 < Ts && l < 16) car = carry[((size_t)b * N + r) * 18 + 2 + l];
   }
   WG_SYNC();
-  for (int ts = Ts - 1; ts >= 0; --ts) {
-    cf.stamps = (ts == 1 && stamps != nullptr) ? stamps + 64 : nullptr;       // second half of the debug buffer
+  for (int ts = ts1 - 1; ts >= ts0; --ts) {
+    cf.stamps = (ts == ts0 + 1 && stamps != nullptr) ? stamps + 64 : nullptr;       // second half of the debug buffer
     sm_stamp(cf, 0);
     const SmAct a = sm_act2(aseq, N, Ts, ts);
     const SmDy g = sm_dy(dseq, N, Ts, ts);
     const size_t o = ((size_t)b * Ts + ts) * N + r;
     const SmBNodeIn cur = nin;
-    if (node && ts > 0) {
+    if (node && ts > ts0) {
       const SmAct an = sm_act2(aseq, N, Ts, ts - 1);
       nin = smb_node_load(an, r, l, o - N, eps, zsup, zsstd, dz, dzdyn, dmean, dstd, dpred);
     }
@@ -478,7 +481,8 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
   }
   if (node) {
     const float shifted = sm_from_lane(car, (lane + 62) & 63);      // all lanes take part: a bpermute reads 0 from inactive source lanes
-    if (lane < 18) dz1[((size_t)b * N + r) * 18 + lane] = lane < 2 ? 0.0f : shifted;
+    float* dst = ts0 == 0 ? dz1 : carry;
+    if (lane < 18) dst[((size_t)b * N + r) * 18 + lane] = lane < 2 ? 0.0f : shifted;
   }
 }
 

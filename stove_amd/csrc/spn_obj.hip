@@ -480,155 +480,15 @@ __global__ __launch_bounds__(64 * SLOTS) void objspn_pix_k(
   }
 }
 
-// ---- backward (leaf coefficient grads): partial sums over a chunk of batches --------------
-// block = replica r of chunk c; thread = (leaf L, pixel i) of that replica.
-// part[c][r][L*S+i][g][3] = sum_samples dl[g] * (w x^2, w x, w)
-template <int R, int S, int G>
-__global__ __launch_bounds__(128) void objspn_coefgrad_k(
-    const float* __restrict__ xw, const float* __restrict__ Dscr, const int* __restrict__ scope,
-    float* __restrict__ part, int n_batches, int n_chunks) {
-  constexpr int D = 4 * S;
-  // XCD-aware block -> (replica, chunk) map.  The R replica blocks of a chunk read the same (x, w) tiles; consecutive
-  // block ids go round-robin over the 8 XCDs (each with its own L2), so with the plain map r = id % R every tile was
-  // fetched from HBM once per replica (880 MB per launch for 134 MB of input, rocprofv3 FETCH_SIZE, at the HBM
-  // roofline).  With chunks a multiple of 8, blocks id, id + 8, ..., id + 8 (R - 1) -- same XCD, dispatched together
-  // -- are the R replicas of one chunk, and five of the six reads hit that XCD's L2.
-  int r, c;
-  if (n_chunks % 8 == 0) {
-    const int grp = blockIdx.x / (8 * R), in = blockIdx.x % (8 * R);
-    c = grp * 8 + (in & 7);
-    r = in >> 3;
-  } else {
-    r = blockIdx.x % R;
-    c = blockIdx.x / R;
-  }
-  const int t = threadIdx.x;
-  if (t >= D) return;
-  const int L = t / S;
-  const int p = scope[r * D + t];
-  float acc[G][3];
-#pragma unroll
-  for (int g = 0; g < G; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0.0f;
-  for (int b = c; b < n_batches; b += n_chunks) {
-    const float4* xr = reinterpret_cast<const float4*>(xw + ((size_t)b * D + p) * 2 * 64);
-    const float4* dr = reinterpret_cast<const float4*>(Dscr + ((size_t)(b * R + r) * 4 + L) * G * 64);
-    for (int q = 0; q < 16; ++q) {
-      const float4 x4 = xr[q], w4 = xr[16 + q];
-      const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
-      const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
-      float f0[4], f1[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        f1[k] = ws[k] * xs[k];
-        f0[k] = f1[k] * xs[k];
-      }
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float4 d4 = dr[g * 16 + q];
-        const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          acc[g][0] = fmaf(ds[k], f0[k], acc[g][0]);
-          acc[g][1] = fmaf(ds[k], f1[k], acc[g][1]);
-          acc[g][2] = fmaf(ds[k], ws[k], acc[g][2]);
-        }
-      }
-    }
-  }
-  float* o = part + ((size_t)(c * R + r) * D + t) * G * 3;
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    o[g * 3] = acc[g][0];
-    o[g * 3 + 1] = acc[g][1];
-    o[g * 3 + 2] = acc[g][2];
-  }
-}
 
-// ---- backward (sum / root weight grads in the linear-weight domain) ------------------------
-// block = chunk c; threads 0 .. R*2*G*2-1 : (node, j2, half of j1) -> part_w[c][node][j2*G+j1][s]
-//                  next R*K threads       : (r, j2)                -> part_r[c][r][j2*K+j1]
-template <int R, int G, int K>
-__global__ __launch_bounds__(R * 2 * G * 2 + ((R * K + 63) / 64) * 64) void objspn_wgrad_k(
-    const float* __restrict__ Sscr, const float* __restrict__ Rscr,
-    float* __restrict__ part_w, float* __restrict__ part_r, int n_batches, int n_chunks) {
-  static_assert(G % 2 == 0, "G must be even");
-  constexpr int H = G / 2;
-  constexpr int NW = R * 2 * G * 2;
-  const int c = blockIdx.x;
-  const int t = threadIdx.x;
-  if (t < NW) {
-    const int node = t / (G * 2);
-    const int j2 = (t / 2) % G;
-    const int h = t % 2;
-    float acc[H][K];
-#pragma unroll
-    for (int a = 0; a < H; ++a)
-#pragma unroll
-      for (int s = 0; s < K; ++s) acc[a][s] = 0.0f;
-    for (int b = c; b < n_batches; b += n_chunks) {
-      const float4* sp = reinterpret_cast<const float4*>(Sscr + (size_t)(b * R * 2 + node) * (K + 2 * G) * 64);
-      for (int q = 0; q < 16; ++q) {
-        const float4 e2 = sp[(K + G + j2) * 16 + q];
-        const float e2s[4] = {e2.x, e2.y, e2.z, e2.w};
-        float gs[K][4];
-#pragma unroll
-        for (int s = 0; s < K; ++s) {
-          const float4 v = sp[s * 16 + q];
-          gs[s][0] = v.x; gs[s][1] = v.y; gs[s][2] = v.z; gs[s][3] = v.w;
-        }
-#pragma unroll
-        for (int a = 0; a < H; ++a) {
-          const float4 e1 = sp[(K + h * H + a) * 16 + q];
-          const float e1s[4] = {e1.x, e1.y, e1.z, e1.w};
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float pr = e1s[k] * e2s[k];
-#pragma unroll
-            for (int s = 0; s < K; ++s) acc[a][s] = fmaf(pr, gs[s][k], acc[a][s]);
-          }
-        }
-      }
-    }
-    float* o = part_w + ((size_t)(c * R * 2 + node) * G * G + j2 * G + h * H) * K;
-#pragma unroll
-    for (int a = 0; a < H; ++a)
-#pragma unroll
-      for (int s = 0; s < K; ++s) o[a * K + s] = acc[a][s];
-  } else if (t < NW + R * K) {
-    const int u = t - NW;
-    const int r = u / K, j2 = u % K;
-    float acc[K];
-#pragma unroll
-    for (int s = 0; s < K; ++s) acc[s] = 0.0f;
-    for (int b = c; b < n_batches; b += n_chunks) {
-      const float4* rp = reinterpret_cast<const float4*>(Rscr + (size_t)(b * R + r) * (1 + 2 * K) * 64);
-      for (int q = 0; q < 16; ++q) {
-        const float4 rho = rp[q];
-        const float4 eb = rp[(1 + K + j2) * 16 + q];
-        const float pr[4] = {rho.x * eb.x, rho.y * eb.y, rho.z * eb.z, rho.w * eb.w};
-#pragma unroll
-        for (int j1 = 0; j1 < K; ++j1) {
-          const float4 ea = rp[(1 + j1) * 16 + q];
-          acc[j1] = fmaf(pr[0], ea.x, acc[j1]);
-          acc[j1] = fmaf(pr[1], ea.y, acc[j1]);
-          acc[j1] = fmaf(pr[2], ea.z, acc[j1]);
-          acc[j1] = fmaf(pr[3], ea.w, acc[j1]);
-        }
-      }
-    }
-    float* o = part_r + ((size_t)(c * R + r) * K + j2) * K;
-#pragma unroll
-    for (int j1 = 0; j1 < K; ++j1) o[j1] = acc[j1];
-  }
-}
 
 // ---- backward (all table gradients) on the matrix cores ------------------------------------------------------------
 // The three table gradients are sums over the samples of outer products,
 //     d coef[r][L][i][g][c] = sum_s  f_c(x, w)[pixel(r, L, i)][s] * dl[r][L][g][s]          f = (w x^2, w x, w)
 //     d wsum[node][j2 G + j1][k] = sum_s  E1[j1][s] E2[j2][s] * gamma[k][s]
 //     d wroot[r][j2 K + j1]      = sum_s  rho[s] EB[j2][s] * EA[j1][s]
-// i.e. GEMMs with the sample index as K: M = 75 / 100 / 10 rows, N = 10 columns, K = 64 per batch -- what objspn_coefgrad_k
-// and objspn_wgrad_k (kept below for reference sizes other than the template's) do with one thread per output row on the
+// i.e. GEMMs with the sample index as K: M = 75 / 100 / 10 rows, N = 10 columns, K = 64 per batch -- what the round-1 kernels
+// (objspn_coefgrad_k / objspn_wgrad_k, removed) did with one thread per output row on the
 // VALU, which is also what every other kernel of this phase of the step is bound by.  Here they go through
 // v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, so the numerics stay those of an fp32 sum; the matrix pipe is otherwise idle
 // in the backward): a wave = one (replica, side) = its two leaves, its sum node and (side 0) the replica's root, 18 output
@@ -1096,14 +956,6 @@ int objspn_backward_data(const float* xw, const int* scope, const int* leaf_slot
   return 0;
 }
 
-static bool objspn_tablegrad_valu() {
-  static const bool v = [] {
-    const char* e = getenv("STOVE_TABLEGRAD_VALU");
-    return e != nullptr && e[0] == '1';
-  }();
-  return v;
-}
-
 int objspn_backward_params(const float* xw, const int* scope, float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n,
                            hipStream_t st, bool under = false) {
   const int nb = (n + 63) / 64;
@@ -1120,18 +972,13 @@ int objspn_backward_params(const float* xw, const int* scope, float* g_coef, flo
   float* pw = pc + (size_t)kObjChunks * kObjCoefN;
   float* pr = pw + (size_t)kObjChunks * kObjWN;
   int chunks = nb < kObjChunks ? nb : kObjChunks;
-  if (under && !objspn_tablegrad_valu()) {
+  if (under) {
     // one resident round next to the recursion's workgroups: 6 workgroups (replicas) per chunk, one per CU
     constexpr int kTgLdsU = 2 * 100 * 68 * (int)sizeof(float);      // + the recursion's 106 880 B + 512 B < 160 KB
     if (chunks > kObjChunks / 6) chunks = kObjChunks / 6;
     int rc = (int)hipFuncSetAttribute((const void*)objspn_tablegrad_under_k<6, 25, 10, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, kTgLdsU);
     if (rc) return rc;
     STOVE_LAUNCH((objspn_tablegrad_under_k<6, 25, 10, 10>), dim3(chunks, 6), dim3(256), kTgLdsU, st, xw, Dscr, Sscr, Rscr, scope, pc, pw, pr, nb, chunks);
-    STOVE_LAUNCH_CHECK();
-  } else if (objspn_tablegrad_valu()) {      // STOVE_TABLEGRAD_VALU=1: the VALU formulation (A/B switch, cross-check in tests)
-    STOVE_LAUNCH((objspn_coefgrad_k<6, 25, 10>), dim3(6 * chunks), dim3(128), 0, st, xw, Dscr, scope, pc, nb, chunks);
-    STOVE_LAUNCH_CHECK();
-    STOVE_LAUNCH((objspn_wgrad_k<6, 10, 10>), dim3(chunks), dim3(6 * 2 * 10 * 2 + 64), 0, st, Sscr, Rscr, pw, pr, nb, chunks);
     STOVE_LAUNCH_CHECK();
   } else {
     constexpr int kTgLds = (2 * 100 * 68 + 12 * 30 * 68) * (int)sizeof(float);

@@ -154,6 +154,11 @@ class GraphedTrainStep:
                 _lib.check(rc, 'stove_capture_end')
             elif self.world_size <= 1:
                 self._update()
+            if os.environ.get('STOVE_GRAPH_DUMP_OPEN'):          # debugging: the main DAG while its capture is still open
+                here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+                gd = ctypes.CDLL(os.path.join(here, 'tools', 'graphdump', 'libgraphdump.so'))
+                gd.graph_of_stream.restype = ctypes.c_void_p
+                gd.graph_dump(ctypes.c_void_p(gd.graph_of_stream(ctypes.c_void_p(s.cuda_stream))), os.environ['STOVE_GRAPH_DUMP_OPEN'].encode())
         ops.SideMode.keep = []
         if split:
             ex = ctypes.c_void_p()

@@ -47,6 +47,7 @@ _DEFAULTS = dict(
     align_corners=False,     # spatial-transformer convention; False = what the runnable reference computes
     fused_dynamics=True,     # run the inference recursion in the persistent HIP time-loop kernel
     fused_state=True,        # constrain_zp / matching / fix_supair / velocities as the fused state pipeline (csrc/state.hip)
+    pipeline_pieces=1,       # > 1: the recursion in pieces with the likelihood of the frames already inferred underneath it (ops._InferScoreFn; measured SLOWER on MI355X: DESIGN.md section 7)
     fused_elbo=True,         # log q, transition likelihood and the ELBO means in two launches
     graph_step=True,         # Trainer: replay the non-logging training steps as captured hipGraph(s) (stove_amd/graphed.py)
     frame_store='auto',      # DeviceClipLoader: 'auto' (bw plane as fp32 when the model only sees bw frames, else colour fp32), 'bw32', 'u8', 'f32'
@@ -54,7 +55,6 @@ _DEFAULTS = dict(
     device_dataset=True,     # Trainer: training set resident on the GPU, batches gathered there (load_data.DeviceClipLoader)
     device_dataset_gb=64.0,  # ... when it needs at most this much HBM
     encoder_gemm='bf16x3',   # recognition-network GEMMs: 'bf16x3' (fp32 as 3 bf16 MFMAs on hi/lo-split operands), 'fp32' (library), 'bf16'
-    param_arena=True,        # Trainer: parameters / gradients as views into one flat buffer (stove_amd/arena.py)
 )
 
 

@@ -17,6 +17,7 @@ tests inject the reference's draws: 'latent' (n,o,12), 'std' (n,o,12), 'steps' (
 otherwise they come from the device generator.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -215,6 +216,7 @@ class Stove(nn.Module):
                 _ = 0.1 + 0.01 * self._noise('std', (n, o, cl // 2 - 4), z_sup)     # drawn as in the reference, unused
             init_z = torch.cat([init6, lat0], -1)
         use_app = bool(c.debug_core_appearance)
+        lik_all = None
         if getattr(c, 'fused_dynamics', True):
             extra = []
             if actions is not None:
@@ -228,9 +230,26 @@ class Stove(nn.Module):
             else:
                 eps = self._noise('steps', (n, Ts, o, cl // 2 + 2), z_sup)
             image, sink = self.dyn.kernel_params(0)
-            z_s, z_dyn_s, z_dyn_std_s, mean_s, z_std_s, pred = ops.dyn_loop(
-                init_z, zsup_loop, zsstd_loop, eps, extra, image,
-                2, self.dyn.use_elu, self.dyn.loop_consts(), want_pred=bool(c.action_conditioned), sink=sink)
+            lik_all = None
+            pieces = int(getattr(c, 'pipeline_pieces', 1))
+            if (pieces > 1 and fused_state and sink is not None and arena is not None and arena.has_spn and Ts >= 2 * pieces
+                    and os.environ.get('STOVE_NO_OVERLAP', '0') != '1' and ops.dynloop_range_ok(o) and x.is_cuda
+                    and x.dtype == torch.float32 and c.channels == 1 and tuple(x.shape[-2:]) == (32, 32)
+                    and c.patch_width == 10 and c.patch_height == 10 and not bool(getattr(c, 'align_corners', False))):
+                # [amd] recursion and image likelihood as ONE pipelined node (ops._InferScoreFn): the likelihood of the frames a
+                # piece of the recursion has produced runs underneath the next piece (forward and backward)
+                obj_tabs, bg_tabs = arena.spn_tables()
+                cfg = dict(lim_enc=2, elu=self.dyn.use_elu, consts=self.dyn.loop_consts(), want_pred=bool(c.action_conditioned),
+                           beta=c.overlap_beta, skip=skip, pieces=pieces, spn_sink=arena.spn_sink, gnn_sink=sink)
+                z_s, z_dyn_s, z_dyn_std_s, mean_s, z_std_s, pred, lik_all, parts = ops.infer_and_score(
+                    init_z, zsup_loop, zsstd_loop, eps, extra, image[0], x, zfix, obj_tabs, bg_tabs, cfg)
+                if ((self.step_counter % c.print_every == 0) or (self.step_counter % c.plot_every == 0)) and c.debug:
+                    m = parts[:, skip - 1:].mean((0, 1))
+                    self.prop_dict['bg'], self.prop_dict['patch'], self.prop_dict['overlap'] = m[0], m[1], m[2]
+            else:
+                z_s, z_dyn_s, z_dyn_std_s, mean_s, z_std_s, pred = ops.dyn_loop(
+                    init_z, zsup_loop, zsstd_loop, eps, extra, image,
+                    2, self.dyn.use_elu, self.dyn.loop_consts(), want_pred=bool(c.action_conditioned), sink=sink)
             rewards = self.dyn.reward_from_pred(pred) if c.action_conditioned else torch.zeros(Ts)
         else:
             z_prev, zs, zd, zds, zm, zst, rew = init_z, [], [], [], [], [], []
@@ -253,13 +272,14 @@ class Stove(nn.Module):
         # 3. ELBO: image likelihood (SPNs), q(z|x) and the generative transition likelihood.
         # The reference scores frames skip..T-1 (sampled z) and frame 1..skip-1 (SuPAIR mean) in two
         # likelihood calls (stove.py:731-736); here both go through ONE fused scene launch.
-        if fused_state:
-            z_all = ops.zall(zfix, z_s, n, T, o, skip)
-        else:
-            z_all = torch.cat([z_sup[:, 1:skip], z_s[..., :4]], 1)             # (n, T-1, o, 4) [sx, sy/sx, x, y]
-            z_all = self.sup.sy_from_quotient(z_all.flatten(end_dim=2))
-        lik_all, sup_prop = self.sup.likelihood(x[:, 1:], z_all, log_from=skip - 1)
-        self.prop_dict.update(sup_prop)
+        if lik_all is None:
+            if fused_state:
+                z_all = ops.zall(zfix, z_s, n, T, o, skip)
+            else:
+                z_all = torch.cat([z_sup[:, 1:skip], z_s[..., :4]], 1)             # (n, T-1, o, 4) [sx, sy/sx, x, y]
+                z_all = self.sup.sy_from_quotient(z_all.flatten(end_dim=2))
+            lik_all, sup_prop = self.sup.likelihood(x[:, 1:], z_all, log_from=skip - 1)
+            self.prop_dict.update(sup_prop)
         lik_all = lik_all.view(n, T - 1)
         if getattr(c, 'fused_elbo', True):
             # log q(z), the transition likelihood and all the means in two launches (csrc/state.hip)

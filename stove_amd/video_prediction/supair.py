@@ -42,6 +42,11 @@ class Supair(nn.Module):
         if self.c.channels != 1 or x.shape[-1] != 32 or x.shape[-2] != 32 \
                 or self.c.patch_width != 10 or self.c.patch_height != 10:
             raise NotImplementedError('scene kernels are built for 1x32x32 frames and 10x10 glimpses')
+        if bool(getattr(self.c, 'align_corners', False)):
+            # the fused kernels sample with align_corners=False (what the runnable reference computes); the
+            # torch-1.0.1 convention is only available through the op-by-op API (patches_from_z / masks_from_z)
+            raise NotImplementedError('Supair.likelihood: config.align_corners=True has no gfx950 kernel (use the op-by-op '
+                                      'patches_from_z / masks_from_z API for that convention)')
         frames = x.flatten(start_dim=2)                 # (n, T', 1024) view: a time-slice of longer clips is NOT copied (ops._SceneFn)
         arena = getattr(self, '_arena', None)
         if arena is not None and arena.has_spn:         # flat parameter arena: one bake launch, gradients sunk

@@ -22,7 +22,7 @@ from torch.utils.data import DataLoader
 from ..arena import ParamArena
 from .load_data import DeviceClipLoader, ShardedDataLoader
 from ..optim import FlatAdam
-from ..parallel import GradBucket, broadcast_int, broadcast_tensors
+from ..parallel import broadcast_int, broadcast_tensors
 from ..utils.utils import ExperimentLogger, bw_transform, settle_host_gc
 
 
@@ -45,15 +45,12 @@ class AbstractTrainer:
             self.load_encoder()
         if not self.c.supair_grad:
             self.disable_supair_grad()
-        # [amd] flat parameter / gradient arena (one-launch table baking, gradient bucket == all-reduce buffer);
-        # the per-tensor GradBucket is the fallback for models that are not fp32 on a GPU
+        # [amd] flat parameter / gradient arena (one-launch table baking, gradient buffer == all-reduce bucket)
+        self.bucket = ParamArena(self.stove, self.world_size)
         p0 = next(self.stove.parameters())
-        if getattr(self.c, 'param_arena', True) and p0.is_cuda and p0.dtype == torch.float32:
-            self.bucket = ParamArena(self.stove, self.world_size)
+        if p0.is_cuda and p0.dtype == torch.float32:
             # same update rule and state-dict layout as the Adam above, one launch over the flat buffers
             self.optimizer = FlatAdam(self.bucket, lr=self.c.learning_rate, amsgrad=self.c.debug_amsgrad)
-        else:
-            self.bucket = GradBucket(self.stove, self.world_size)
         self.epoch_start, self.step_start = 0, 0
         if self.c.checkpoint_path is not None:
             self.load()

@@ -140,6 +140,21 @@ def _trainer_worker(rank, world, port, path, tmp):
     # a second step keeps the replicas together (moments and step counts are part of the state)
     trainer.train_step(next(it), 2)
     out['after2'] = trainer.bucket.data.clone().cpu()
+    # a third step as the Trainer runs its non-logging steps: two replayed graphs around the all-reduce (stove_amd/graphed.py)
+    trainer.c.print_every = 10 ** 9
+    del trainer.stove._noise                        # the recording wrapper copies to the host: not inside a capture
+    assert trainer._graph_ok(3)
+    trainer._graph_step(next(it), 3)
+    out['after3'] = trainer.bucket.data.clone().cpu()
+    out['graphs'] = len(trainer._graphed.graphs)
+    trainer.c.print_every = 1
+    # sync_replicas carries ALL of rank 0's optimiser state, the per-tensor step counts included
+    if rank == 1:
+        trainer.optimizer._seg_steps.add_(3.0)
+        trainer.optimizer._flat['exp_avg'].add_(1.0)
+    trainer.sync_replicas()
+    out['seg_steps'] = trainer.optimizer._seg_steps.clone().cpu()
+    out['exp_avg_sum'] = float(trainer.optimizer._flat['exp_avg'].double().sum())
     trainer.test(2, 0.0)                            # evaluation: rank 0 only, no collective inside
     torch.save(out, os.path.join(tmp, 'rank%d.pt' % rank))
     dist.barrier()
@@ -163,6 +178,8 @@ def test_trainer_data_parallel_step(tmp_path):
     assert torch.equal(r0['grad'], r1['grad'])                                        # the reduced gradient ...
     assert torch.equal(r0['after'], r1['after']) and torch.equal(r0['after2'], r1['after2'])     # ... and the replicas stay equal
     assert not torch.equal(r0['after'], r0['start']) and float(r0['steps']) == 1.0
+    assert torch.equal(r0['after3'], r1['after3']) and not torch.equal(r0['after3'], r0['after2']) and r0['graphs'] == 2
+    assert torch.equal(r0['seg_steps'], r1['seg_steps']) and float(r0['seg_steps'].max()) == 3.0 and r0['exp_avg_sum'] == r1['exp_avg_sum']
 
     # one process, the concatenated batch, the same noise: the same step
     import model.main as M

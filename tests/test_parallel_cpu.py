@@ -13,7 +13,8 @@ import torch.multiprocessing as mp
 import torch.nn as nn
 
 from stove_amd import parallel
-from stove_amd.parallel import GradBucket, shard_batch, shard_order
+from stove_amd.arena import ParamArena
+from stove_amd.parallel import shard_batch, shard_order
 
 
 def _free_port():
@@ -123,7 +124,7 @@ def test_single_process_helpers_are_noops():
     assert t.tolist() == [1, 1, 1]
 
 
-# ---- the per-tensor fallback bucket (models that are not fp32 on a GPU)
+# ---- the flat arena on a plain CPU fp64 module (what a Trainer on a non-GPU / non-fp32 model exchanges through)
 def _make_model():
     torch.manual_seed(0)
     return nn.Sequential(nn.Linear(6, 8), nn.Tanh(), nn.Linear(8, 3)).double()
@@ -143,22 +144,20 @@ def _bucket_worker(rank, world, port, out):
         with torch.no_grad():
             for p in model.parameters():
                 p.add_(1.0)
-    bucket = GradBucket(model, world)
+    bucket = ParamArena(model, world)
     bucket.sync(0)
     torch.manual_seed(1)
     x = torch.randn(8, 6, dtype=torch.float64)
     xs = shard_batch(x, rank, world)
-    for _ in range(2):                      # two steps: the bucket is re-packed every step
+    for _ in range(2):
         bucket.zero()
         _loss(model, xs).backward()
         bucket.all_reduce()
-        off = 0
-        for p in bucket.params:             # after the exchange every grad is a view into the one flat buffer
-            assert p.grad.data_ptr() == bucket.flat[off:].data_ptr()
-            off += p.numel()
+        for p in bucket.params:             # every grad is (and stays) a view into the one flat buffer
+            assert p.grad.data_ptr() == bucket.view_of(p, bucket.grad).data_ptr()
     torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)       # after the reduce, as train.py:471-472
     if rank == 0:
-        torch.save(bucket.flat.clone(), out)
+        torch.save(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone(), out)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -54,3 +54,10 @@ extern "C" int graph_dump(void* graph, const char* path) {
   fclose(f);
   return 0;
 }
+
+// the graph a capturing stream is building (NULL if it is not capturing): lets a DAG be dumped BEFORE hipStreamEndCapture
+extern "C" void* graph_of_stream(void* stream) {
+  hipStreamCaptureStatus st; unsigned long long id; hipGraph_t g = nullptr; const hipGraphNode_t* deps; size_t nd;
+  if (hipStreamGetCaptureInfo_v2((hipStream_t)stream, &st, &id, &g, &deps, &nd) != hipSuccess || st != hipStreamCaptureStatusActive) return nullptr;
+  return (void*)g;
+}

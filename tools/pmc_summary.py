@@ -8,7 +8,10 @@ used as is.  Values are averaged per launch of each kernel.
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(path, counter):
@@ -34,6 +37,9 @@ def main():
                   'fetch_bytes_per_launch': fb, 'write_bytes_per_launch': wb, 'hbm_bytes_per_launch': fb + wb}
     meta = {'_note': 'FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes, average per launch; '
                      'separate rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1`'}
+    # which sources the profiled library was built from: bench.py quotes these figures only for the same sources
+    from stove_amd import build
+    meta['_source_hash'] = build.source_hash()
     meta.update(res)
     json.dump(meta, open(out, 'w'), indent=1)
     print('wrote', out, len(res), 'kernels')

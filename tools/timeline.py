@@ -1,4 +1,4 @@
-"""Timeline of the MEDIAN training step from a rocprofv3 --kernel-trace CSV (steps are delimited by bw_transform_k launches):
+"""Timeline of the MEDIAN training step from a rocprofv3 --kernel-trace CSV (a step ends with the optimiser's adam_tick_k launch):
 start offset, duration, queue of every kernel of that step, the device's idle gaps, and p50 / p99 / max duration of every
 kernel over all traced steps (first step excluded: it carries one-time initialisation).
 Usage: python tools/timeline.py gpurun_out/rNN/ks/..._kernel_trace.csv [min_us]"""
@@ -9,7 +9,7 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 15.0
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-marks = [i for i, r in enumerate(rows) if 'bw_transform_k' in r['Kernel_Name']]
+marks = [i + 1 for i, r in enumerate(rows) if 'adam_tick_k' in r['Kernel_Name'] and i + 1 < len(rows)]          # first kernel after each step's end
 
 
 def short(name):
