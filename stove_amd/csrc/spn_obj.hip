@@ -671,9 +671,20 @@ __global__ __launch_bounds__(256, 4) void objspn_tablegrad_under_k(
   float* tileP = tg_lds;                         // [2 D][LD]: row 2 p = x of pixel p, 2 p + 1 = w -- ALL the LDS there is next
                                                  // to the recursion's 107 KB: the sum-node rows are read from global memory
   const int lane = lane_id(), wv = wave_id();
-  const int side = wv & 1, half = wv >> 1, r = blockIdx.y, node = 2 * r + side, L = side * 2 + half;
+  // workgroup -> (chunk c, replica r).  The R workgroups of a chunk stage the SAME glimpse tiles: when the chunk count is a multiple
+  // of 8 they are placed on one XCD (workgroup ids congruent mod 8 share an L2) and start together, so five of the six tile
+  // reads of a batch are L2 hits instead of HBM reads (round 2: 501 MB per launch, the tile six times over)
+  int c, r;
+  if ((n_chunks & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    c = xcd * (n_chunks >> 3) + j / R;
+    r = j % R;
+  } else {
+    c = blockIdx.x / R;
+    r = blockIdx.x % R;
+  }
+  const int side = wv & 1, half = wv >> 1, node = 2 * r + side, L = side * 2 + half;
   const int rr = lane & 15, kk = lane >> 4;
-  const int c = blockIdx.x;
   int c_row[TC], c_feat[TC];
 #pragma unroll
   for (int t = 0; t < TC; ++t) {
@@ -975,10 +986,10 @@ int objspn_backward_params(const float* xw, const int* scope, float* g_coef, flo
   if (under) {
     // one resident round next to the recursion's workgroups: 6 workgroups (replicas) per chunk, one per CU
     constexpr int kTgLdsU = 2 * 100 * 68 * (int)sizeof(float);      // + the recursion's 106 880 B + 512 B < 160 KB
-    if (chunks > kObjChunks / 6) chunks = kObjChunks / 6;
+    if (chunks > kObjChunks / 6) chunks = (kObjChunks / 6) & ~7;      // 40: a multiple of 8 (XCD-aware placement), 240 workgroups
     int rc = (int)hipFuncSetAttribute((const void*)objspn_tablegrad_under_k<6, 25, 10, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, kTgLdsU);
     if (rc) return rc;
-    STOVE_LAUNCH((objspn_tablegrad_under_k<6, 25, 10, 10>), dim3(chunks, 6), dim3(256), kTgLdsU, st, xw, Dscr, Sscr, Rscr, scope, pc, pw, pr, nb, chunks);
+    STOVE_LAUNCH((objspn_tablegrad_under_k<6, 25, 10, 10>), dim3(chunks * 6), dim3(256), kTgLdsU, st, xw, Dscr, Sscr, Rscr, scope, pc, pw, pr, nb, chunks);
     STOVE_LAUNCH_CHECK();
   } else {
     constexpr int kTgLds = (2 * 100 * 68 + 12 * 30 * 68) * (int)sizeof(float);

@@ -30,7 +30,7 @@ NHYPER = 8          # floats per slot: lr, beta1, beta2, eps, max_norm, reward w
 
 class GraphedTrainStep:
     def __init__(self, stove, arena, optimizer, clip, supair_only=False, warmup=3, world_size=1, reward_loss=None,
-                 alias_inputs=False):
+                 alias_inputs=False, force_reduce=False):
         """reward_loss: callable(pred, target) -> scalar for action-conditioned models (train.py:452-465); the loss is then
         -ELBO + w * reward_loss(rewards, targets) with the host-computed weight w (factor x ramp) passed per step."""
         self.stove, self.arena, self.opt, self.clip = stove, arena, optimizer, clip
@@ -38,6 +38,7 @@ class GraphedTrainStep:
         self.world_size = world_size
         self.reward_loss = reward_loss
         self.alias_inputs = alias_inputs
+        self.force_reduce = force_reduce          # send a single rank's gradient through the collective anyway (the 1-GPU RCCL test)
         self.graphs = None
         self.key = None
         self.reward_value = None
@@ -68,8 +69,8 @@ class GraphedTrainStep:
         self.opt.step(max_norm=self.clip, hyper_dev=self.hyper_dev)
 
     def _reduce(self):
-        if self.world_size > 1:
-            self.arena.all_reduce()
+        if self.world_size > 1 or self.force_reduce:
+            self.arena.all_reduce(force=self.force_reduce)
 
     def _eager(self):
         elbo = self._fwd_bwd()
@@ -152,7 +153,7 @@ class GraphedTrainStep:
                     rc = lib.stove_capture_end(self._side.cuda_stream, ctypes.byref(side_graph), ctypes.byref(side_nodes))
             if split:
                 _lib.check(rc, 'stove_capture_end')
-            elif self.world_size <= 1:
+            elif self.world_size <= 1 and not self.force_reduce:
                 self._update()
             if os.environ.get('STOVE_GRAPH_DUMP_OPEN'):          # debugging: the main DAG while its capture is still open
                 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -169,7 +170,7 @@ class GraphedTrainStep:
             ctypes.CDLL(os.path.join(here, 'tools', 'graphdump', 'libgraphdump.so')).graph_dump(
                 ctypes.c_void_p(g1.raw_cuda_graph()), dump.encode())
             g1.instantiate()
-        if split or self.world_size > 1:
+        if split or self.world_size > 1 or self.force_reduce:
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, stream=s, pool=g1.pool()):
                 self._update()

@@ -232,3 +232,43 @@ def test_arena_all_reduce_through_rccl(tmp_path):
     mp.spawn(_rccl_worker, args=(port, out), nprocs=1, join=True)
     got = torch.load(out)
     assert got['ok'] and got['backend'] == 'nccl'
+
+
+def _rccl_graph_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    from stove_amd.arena import ParamArena
+    from stove_amd.envs import envs
+    from stove_amd.graphed import GraphedTrainStep
+    from stove_amd.optim import FlatAdam
+    from stove_amd.video_prediction.stove import Stove
+    cfg = _cfg()
+    cfg.print_every, cfg.plot_every = 10 ** 9, 1e19
+    torch.manual_seed(0)
+    model = Stove(cfg).to('cuda:0')
+    arena = ParamArena(model, 1)
+    opt = FlatAdam(arena, lr=cfg.learning_rate, amsgrad=True)
+    x = torch.from_numpy(envs.synth_sequences('billiards', 8, 10, seed0=3)['X']).to('cuda:0').contiguous()
+    # the process group (and its watchdog thread) is alive while the step is captured; every replay sends the flat gradient
+    # through RCCL between the two graphs, as a data-parallel run does
+    step = GraphedTrainStep(model, arena, opt, clip=1.0, force_reduce=True)
+    before = arena.data.clone()
+    elbos = [float(step(x)) for _ in range(4)]
+    torch.cuda.synchronize()
+    ok = all(np.isfinite(elbos)) and not torch.equal(before, arena.data) and len(step.graphs) == 2 and opt._steps == 4
+    torch.save({'ok': bool(ok), 'elbos': elbos}, out)
+    dist.destroy_process_group()
+
+
+def test_graph_replay_with_rccl_between_the_graphs(tmp_path):
+    """The replayed data-parallel step on RCCL itself: capture with a live NCCL process group, all-reduce between the captured
+    graphs (a one-rank group on the 1-GPU box: the collective is the identity, the call path is the real one)."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'rccl_graph.pt')
+    mp.spawn(_rccl_graph_worker, args=(port, out), nprocs=1, join=True)
+    got = torch.load(out)
+    assert got['ok'], got

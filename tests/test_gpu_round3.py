@@ -174,10 +174,17 @@ def test_grad_view_registry_follows_the_live_arena():
     (-elbo).backward()
     assert w_hh.grad is not None and w_hh.grad.data_ptr() != new.view_of(w_hh, new.grad).data_ptr()
     assert float((w_hh.grad - g_hh).abs().max()) <= 1e-5 * float(g_hh.abs().max())
-    del model, new
+    # ... and die with their parameters: a model built and dropped inside a scope of its own leaves nothing behind
     import gc
+
+    def scoped():
+        m = Stove(cfg).to(dev)
+        ParamArena(m, 1)
+        return len(ops._GRAD_VIEWS)
+    before = len(ops._GRAD_VIEWS)
+    inside = scoped()
     gc.collect()
-    assert len(ops._GRAD_VIEWS) < n_live                                        # ... and die with them
+    assert inside > before and len(ops._GRAD_VIEWS) == before
 
 
 def test_flat_adam_zero_gradient_is_read_as_no_gradient():
