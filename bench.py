@@ -1,18 +1,20 @@
 #!/usr/bin/env python
 """Headline benchmark: frames/s of one STOVE training step on synthetic billiards video.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a rendezvous in the environment: starts N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one batch: Stove.forward (encoder, matching, fused
 inference recursion, both fused scene likelihoods) + elbo.backward() + [N>1: one RCCL all-reduce
 of the flat gradient] + clip_grad_norm_(1) + Adam(amsgrad) step, i.e. the reference's training
-step (train.py:443-473).  Workload (BASELINE.json configs[1]): 3-object billiards, 32x32,
-T=100, batch 256 per GPU (weak scaling), frames from the build's numpy simulator, model with
-default initialisation; inputs are resident in HBM before the timed region.
+step (train.py:443-473), run the way Trainer.train runs its non-logging steps: replayed as captured hipGraphs
+(stove_amd/graphed.py; --step-mode eager enqueues every launch from the host and is reported under `variants`).
+Workload (BASELINE.json configs[1]): 3-object billiards, 32x32, T=100, batch 256 per GPU (weak scaling), frames from the
+build's numpy simulator, model with default initialisation; inputs are resident in HBM before the timed region, in the
+format of the Trainer's device frame store (--frame-store: the bw plane by default, see load_data.DeviceClipLoader).
 Rank 0 prints ONE JSON line (contract in the task statement); `roofline` is measured with HIP
-events around the dominant kernel, `cpu_baseline` times the CPU oracle on a bounded sample.
+events around the dominant kernel, `cpu_baseline` times the CPU oracle at the quoted batch with the best of 8/32/64 threads.
 """
 import argparse
 import json
