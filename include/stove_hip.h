@@ -216,6 +216,26 @@ int stove_dynloop_bwd_range(const float* z1, const float* zsup, const float* zss
                             float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
                             float pos_var, float vel_std, float lat_std, int ts0, int ts1, float* carry, void* stream, void* param_stream);
 
+/* ---- reward head of the action-conditioned dynamics model (dynamics.py:62-70, 254-263):
+ *   reward = sigmoid(head1(sum over objects of head0(dynamic_pred))),  head0 = Linear(32,32) ReLU Linear(32,32),
+ *   head1 = Linear(32,16) ReLU Linear(16,8) ReLU Linear(8,1), one kernel each way (cl = 32).
+ * pred (items, n_obj, 32): the dynamics core's `dynamic_pred` rows, items = sequences x steps; reward (items).
+ * params: the ten tensors in module order, nn.Linear layout, one after the other (stove_reward_head_param_floats() = 2785 floats):
+ *   head0.0.weight (32,32) | .bias | head0.2.weight (32,32) | .bias | head1.0.weight (16,32) | .bias | head1.2.weight (8,16) | .bias |
+ *   head1.4.weight (1,8) | .bias.  saved: stove_reward_head_saved_floats(items, n_obj) floats written by the forward, read by the backward.
+ * bwd: d_reward (items) -> d_pred (items, n_obj, 32) and g_params (2785 floats, same layout; fixed summation order);
+ * ws: stove_reward_head_bwd_ws_floats(items) floats. */
+size_t stove_reward_head_param_floats(void);
+size_t stove_reward_head_saved_floats(int items, int n_obj);
+size_t stove_reward_head_bwd_ws_floats(int items);
+int stove_reward_head_fwd(const float* pred, const float* params, float* reward, float* saved, int items, int n_obj, void* stream);
+int stove_reward_head_bwd(const float* pred, const float* params, const float* reward, const float* saved, const float* d_reward, float* d_pred,
+                          float* g_params, float* ws, int items, int n_obj, void* stream);
+
+/* y (rows, out) = x (rows, in) W^T + b for a narrow layer (in, out <= 64; the action embedding Linear(action_space, 4 N) of
+ * dynamics.py:238-244), exact fp32 FMAs; b NULL = no bias; w_transposed != 0: W is (in, out) (the layer's backward dx = dy W). */
+int stove_small_linear(const float* x, const float* W, const float* b, float* y, int rows, int in_dim, int out_dim, int w_transposed, void* stream);
+
 /* ---- Stove.rollout (stove.py:777-861), mean prediction: z_last (B,N,18) [sx,sy,...] ->
  * z_pred (B,num,N,18); zstd (B,num,N,16) and pred (B,num,N,32) optional; extra (B,A,N,E) cycled (t % A). */
 int stove_rollout_fwd(const float* z_last, const float* extra, const float* params, float* z_pred, float* zstd, float* pred,

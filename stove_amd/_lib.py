@@ -22,7 +22,8 @@ EXPORTS = [
     'stove_supair_state_fwd', 'stove_supair_state_bwd', 'stove_zall_fwd', 'stove_zall_bwd', 'stove_elbo_fwd', 'stove_elbo_bwd', 'stove_flat_adam', 'stove_flat_adam_ws_bytes', 'stove_gemm_bf16', 'stove_gemm_bf16_ws_floats', 'stove_sum_chunks', 'stove_colsum_ws_floats', 'stove_colsum', 'stove_bw_transform', 'stove_dynloop_bwd_ws_bytes_ts', 'stove_scene_bwd_overlap', 'stove_dynloop_bwd_overlap', 'stove_glimpse_mean', 'stove_objspn_mpe', 'stove_render_frames', 'stove_head_fwd', 'stove_head_bwd_ws_floats', 'stove_head_bwd',
     'stove_enc_head_fwd', 'stove_enc_head_bwd_ws_floats', 'stove_enc_head_bwd', 'stove_colsum2', 'stove_small_tn', 'stove_small_tn_ws_floats', 'stove_supair_state_fwd2', 'stove_supair_state_bwd2', 'stove_bg_dense', 'stove_bg_dense_floats',
     'stove_bw_transform_u8', 'stove_stream_after', 'stove_capture_begin', 'stove_capture_end', 'stove_graph_instantiate', 'stove_graph_launch', 'stove_graph_destroy',
-    'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_bwd_from', 'stove_dynloop_range_ok', 'stove_dynloop_fwd_range', 'stove_dynloop_bwd_range', 'stove_zall_fwd_range', 'stove_zall_bwd_range',
+    'stove_reward_head_param_floats', 'stove_reward_head_saved_floats', 'stove_reward_head_bwd_ws_floats', 'stove_reward_head_fwd',
+    'stove_reward_head_bwd', 'stove_small_linear', 'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_bwd_from', 'stove_dynloop_range_ok', 'stove_dynloop_fwd_range', 'stove_dynloop_bwd_range', 'stove_zall_fwd_range', 'stove_zall_bwd_range',
 ]
 
 
@@ -105,6 +106,12 @@ def _declare(lib):
         'stove_bw_transform': (I, [P, P, I, I, I, P]),
         'stove_bw_transform_u8': (I, [P, P, I, I, I, P]),
         'stove_stream_after': (I, [P, P]),
+        'stove_small_linear': (I, [P, P, P, P, I, I, I, I, P]),
+        'stove_reward_head_param_floats': (S, []),
+        'stove_reward_head_saved_floats': (S, [I, I]),
+        'stove_reward_head_bwd_ws_floats': (S, [I]),
+        'stove_reward_head_fwd': (I, [P, P, P, P, I, I, P]),
+        'stove_reward_head_bwd': (I, [P] * 8 + [I, I, P]),
         'stove_set_fork_stream': (I, [I, P, I]),
         'stove_dynloop_range_ok': (I, [I]),
         'stove_dynloop_fwd_range': (I, [P] * 13 + [I] * 6 + [F] * 3 + [I, I, P]),

@@ -19,6 +19,7 @@
 #include "state.hip"
 #include "gemm_bf16.hip"
 #include "head_fused.hip"
+#include "reward_head.hip"
 
 namespace stove {
 
@@ -810,6 +811,58 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
       STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, st, (const float*)ws, C, n4, splitk, acc_c ? 1 : 0, sum_bias, N / 4);
     STOVE_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------- reward head of the action-conditioned model
+size_t stove_reward_head_param_floats(void) { return (size_t)kRhParams; }
+size_t stove_reward_head_saved_floats(int items, int n_obj) { return (size_t)items * ((size_t)n_obj * 32 + 32 + 16 + 8); }
+static int reward_head_blocks(int items) {
+  const int b = (items + kRhWaves - 1) / kRhWaves;
+  return b < 1 ? 1 : (b > 256 ? 256 : b);
+}
+size_t stove_reward_head_bwd_ws_floats(int items) { return (size_t)reward_head_blocks(items) * kRhWaves * kRhParams; }
+
+int stove_reward_head_fwd(const float* pred, const float* params, float* reward, float* saved, int items, int n_obj, void* stream) {
+  if (items == 0) return 0;
+  if (n_obj < 1 || pred == nullptr || params == nullptr || reward == nullptr || saved == nullptr) return (int)hipErrorInvalidValue;
+  float* H0 = saved;
+  float* Q = H0 + (size_t)items * n_obj * 32;
+  float* A1 = Q + (size_t)items * 32;
+  float* A2 = A1 + (size_t)items * 16;
+  STOVE_LAUNCH(reward_head_fwd_k, dim3(reward_head_blocks(items)), dim3(64 * kRhWaves), 0, (hipStream_t)stream, pred, params, reward, H0, Q, A1, A2,
+               items, n_obj);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_reward_head_bwd(const float* pred, const float* params, const float* reward, const float* saved, const float* d_reward, float* d_pred,
+                          float* g_params, float* ws, int items, int n_obj, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (items == 0) {
+    (void)hipMemsetAsync(g_params, 0, kRhParams * sizeof(float), st);
+    return 0;
+  }
+  if (n_obj < 1 || ws == nullptr || d_pred == nullptr || g_params == nullptr) return (int)hipErrorInvalidValue;
+  const float* H0 = saved;
+  const float* Q = H0 + (size_t)items * n_obj * 32;
+  const float* A1 = Q + (size_t)items * 32;
+  const float* A2 = A1 + (size_t)items * 16;
+  const int blocks = reward_head_blocks(items);
+  STOVE_LAUNCH(reward_head_bwd_k, dim3(blocks), dim3(64 * kRhWaves), 0, st, pred, params, reward, H0, Q, A1, A2, d_reward, d_pred, ws, items, n_obj);
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kRhParams + 31) / 32), dim3(256), 0, st, (const float*)ws, g_params, kRhParams, blocks * kRhWaves, 0);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_small_linear(const float* x, const float* W, const float* b, float* y, int rows, int in_dim, int out_dim, int w_transposed, void* stream) {
+  if (rows == 0) return 0;
+  if (in_dim < 1 || out_dim < 1 || in_dim > 64 || out_dim > 64) return (int)hipErrorInvalidValue;
+  const size_t total = (size_t)rows * out_dim;
+  if ((total + 255) / 256 > 0x7fffffffULL) return (int)hipErrorInvalidValue;
+  STOVE_LAUNCH(small_linear_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, W, b, y, rows, in_dim, out_dim, w_transposed);
+  STOVE_LAUNCH_CHECK();
   return 0;
 }
 

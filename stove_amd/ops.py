@@ -870,15 +870,35 @@ class _LinearFn(torch.autograd.Function):
     (76 800, 50) head gradients of the recognition network at 0.07 TB/s (226 us per step), csrc/arena.hip takes ~10 us."""
 
     @staticmethod
+    def _narrow(x, weight):
+        return x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.shape[0] <= 64 and weight.shape[1] <= 64
+
+    @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
+        if _LinearFn._narrow(x, weight):          # narrow layers (the action embedding): one thread per output, no library GEMM
+            lib = _lib.load()
+            y = torch.empty(x.shape[0], weight.shape[0], dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                check(lib.stove_small_linear(ptr(_f32(x)), ptr(_f32(weight)), ptr(_f32(bias)), ptr(y), x.shape[0], weight.shape[1], weight.shape[0], 0,
+                                             stream()), 'stove_small_linear')
+            return y
         return torch.addmm(bias, x, weight.t())
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
-        gx = torch.mm(g, weight) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if _LinearFn._narrow(x, weight):
+                lib = _lib.load()
+                gx = torch.empty_like(x)
+                with torch.cuda.device(x.device):      # dx = g W: the same kernel with W read as (in = out_features, out = in_features)
+                    check(lib.stove_small_linear(ptr(_f32(g)), ptr(_f32(weight)), None, ptr(gx), g.shape[0], weight.shape[0], weight.shape[1], 1,
+                                                 stream()), 'stove_small_linear')
+            else:
+                gx = torch.mm(g, weight)
         gw = None
         if ctx.needs_input_grad[1]:
             if g.shape[1] * x.shape[1] <= 256 and g.shape[0] >= 2048 and g.dtype == torch.float32 and x.dtype == torch.float32 and g.is_cuda:
@@ -887,6 +907,56 @@ class _LinearFn(torch.autograd.Function):
                 gw = _splitk_tn(g, x)                                         # (out, in) = g^T x over all rows: split-K
         gb = colsum(g) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
+
+
+class _RewardHeadFn(torch.autograd.Function):
+    """reward = sigmoid(head1(sum_objects head0(pred))) of the action-conditioned model (reference dynamics.py:254-263) as one kernel
+    each way (csrc/reward_head.hip).  pred (items, o, 32); the ten parameter tensors of the two heads in module order."""
+
+    @staticmethod
+    def forward(ctx, pred, *params):
+        lib = _lib.load()
+        pred = _f32(pred)
+        items, o = pred.shape[0], pred.shape[1]
+        dev = pred.device
+        flat = torch.cat([_f32(p).reshape(-1) for p in params])
+        if flat.numel() != lib.stove_reward_head_param_floats():
+            raise RuntimeError('reward head: unexpected parameter shapes')
+        with torch.cuda.device(dev):
+            reward = torch.empty(items, dtype=torch.float32, device=dev)
+            saved = torch.empty(lib.stove_reward_head_saved_floats(items, o) + 1, dtype=torch.float32, device=dev)
+            check(lib.stove_reward_head_fwd(ptr(pred), ptr(flat), ptr(reward), ptr(saved), items, o, stream()), 'stove_reward_head_fwd')
+        ctx.save_for_backward(pred, flat, reward, saved)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return reward
+
+    @staticmethod
+    def backward(ctx, d_reward):
+        lib = _lib.load()
+        pred, flat, reward, saved = ctx.saved_tensors
+        items, o = pred.shape[0], pred.shape[1]
+        dev = pred.device
+        with torch.cuda.device(dev):
+            d_pred = torch.empty_like(pred)
+            g = torch.empty_like(flat)
+            ws = torch.empty(lib.stove_reward_head_bwd_ws_floats(items) + 1, dtype=torch.float32, device=dev)
+            check(lib.stove_reward_head_bwd(ptr(pred), ptr(flat), ptr(reward), ptr(saved), ptr(_f32(d_reward)), ptr(d_pred), ptr(g), ptr(ws),
+                                            items, o, stream()), 'stove_reward_head_bwd')
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            grads.append(g[off:off + n].view(shp))
+            off += n
+        return (d_pred, *grads)
+
+
+def reward_head(pred, params):
+    """pred (..., o, 32) -> reward (..., 1) in (0, 1); params: head0.0.weight, head0.0.bias, head0.2.*, head1.0.*, head1.2.*, head1.4.*."""
+    shape = pred.shape
+    r = _RewardHeadFn.apply(pred.reshape(-1, shape[-2], shape[-1]), *params)
+    return r.view(*shape[:-2], 1)
 
 
 def linear(x, weight, bias):

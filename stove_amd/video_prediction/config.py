@@ -48,6 +48,7 @@ _DEFAULTS = dict(
     fused_dynamics=True,     # run the inference recursion in the persistent HIP time-loop kernel
     fused_state=True,        # constrain_zp / matching / fix_supair / velocities as the fused state pipeline (csrc/state.hip)
     pipeline_pieces=1,       # > 1: the recursion in pieces with the likelihood of the frames already inferred underneath it (ops._InferScoreFn; measured SLOWER on MI355X: DESIGN.md section 7)
+    fused_reward_head=True,  # action-conditioned model: the reward head as one HIP kernel each way (csrc/reward_head.hip) instead of ten library launches
     fused_elbo=True,         # log q, transition likelihood and the ELBO means in two launches
     graph_step=True,         # Trainer: replay the non-logging training steps as captured hipGraph(s) (stove_amd/graphed.py)
     frame_store='auto',      # DeviceClipLoader: 'auto' (bw plane as fp32 when the model only sees bw frames, else colour fp32), 'bw32', 'u8', 'f32'

@@ -133,14 +133,25 @@ class Dynamics(nn.Module):
     def core_inputs(self, s, actions=None, obj_appearances=None):
         """[state | action embedding | appearance] as the encoder expects it."""
         if actions is not None:
-            emb = self.action_embedding_layer(actions)
+            emb = self.embed_actions(actions)
             s = torch.cat([s, emb.view(*emb.shape[:-1], self.c.num_obj, self.n_action_enc)], -1)
         if obj_appearances is not None:
             s = torch.cat([s, obj_appearances], -1)
         return s
 
+    def embed_actions(self, actions):
+        """action_embedding_layer(actions) (dynamics.py:238-244); on the GPU the narrow-layer kernel instead of a library GEMM."""
+        lay = self.action_embedding_layer
+        if actions.is_cuda and actions.dtype == torch.float32 and lay.weight.dtype == torch.float32:
+            return ops.linear(actions, lay.weight, lay.bias)
+        return lay(actions)
+
     def reward_from_pred(self, dynamic_pred):
         """(…, o, cl) -> (…, 1) predicted reward in (0, 1)."""
+        if dynamic_pred.is_cuda and dynamic_pred.dtype == torch.float32 and self.c.cl == 32 and getattr(self.c, 'fused_reward_head', True):
+            h0, h1 = self.reward_head0, self.reward_head1
+            return ops.reward_head(dynamic_pred, [h0[0].weight, h0[0].bias, h0[2].weight, h0[2].bias,
+                                                  h1[0].weight, h1[0].bias, h1[2].weight, h1[2].bias, h1[4].weight, h1[4].bias])
         q = self.reward_head0(dynamic_pred).sum(-2)
         return torch.sigmoid(self.reward_head1(q))
 

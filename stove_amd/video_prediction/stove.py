@@ -220,7 +220,7 @@ class Stove(nn.Module):
         if getattr(c, 'fused_dynamics', True):
             extra = []
             if actions is not None:
-                emb = self.dyn.action_embedding_layer(actions[:, skip - 1:T - 1])
+                emb = self.dyn.embed_actions(actions[:, skip - 1:T - 1])
                 extra.append(emb.view(n, Ts, o, self.dyn.n_action_enc))
             if use_app:
                 extra.append(obj_appearances[:, skip - 1:T - 1])
@@ -322,7 +322,7 @@ class Stove(nn.Module):
         if not sample:
             extra = []
             if actions is not None:
-                emb = self.dyn.action_embedding_layer(actions)
+                emb = self.dyn.embed_actions(actions)
                 extra.append(emb.view(n, actions.shape[1], o, self.dyn.n_action_enc))
             if appearance is not None:
                 a_len = actions.shape[1] if actions is not None else 1

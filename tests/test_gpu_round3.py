@@ -359,3 +359,56 @@ def test_likelihood_refuses_align_corners():
     sup = Supair(cfg).to(dev)
     with pytest.raises(NotImplementedError):
         sup.likelihood(torch.zeros(1, 2, 1, 32, 32, device=dev), torch.rand(6, 4, device=dev))
+
+
+@pytest.mark.parametrize('items,n_obj', [(1, 3), (37, 3), (25088, 3), (1000, 6)])
+def test_reward_head_kernels_against_torch(items, n_obj):
+    """csrc/reward_head.hip == the reference's nn.Sequential reward head (dynamics.py:62-70, 254-263): values and every gradient."""
+    from stove_amd import ops
+    from stove_amd.video_prediction.config import StoveConfig
+    from stove_amd.video_prediction.dynamics import Dynamics
+    dev = torch.device('cuda:0')
+    cfg = StoveConfig()
+    cfg.num_obj, cfg.device, cfg.dtype, cfg.action_conditioned, cfg.action_space = n_obj, dev, torch.float32, True, 9
+    torch.manual_seed(items)
+    dyn = Dynamics(cfg).to(dev)
+    pred = (torch.randn(items, n_obj, 32, device=dev) * 1.5).requires_grad_()
+    w = torch.randn(items, 1, device=dev)
+    ps = list(dyn.reward_head0.parameters()) + list(dyn.reward_head1.parameters())
+
+    def run(fused):
+        cfg.fused_reward_head = fused
+        for p in ps + [pred]:
+            p.grad = None
+        r = dyn.reward_from_pred(pred)
+        (r * w).sum().backward()
+        return r.detach().clone(), pred.grad.clone(), [p.grad.clone() for p in ps]
+    r0, gp0, g0 = run(False)          # the library path, fp32
+    r1, gp1, g1 = run(True)
+    r2, gp2, g2 = run(True)
+    assert r1.shape == (items, 1) and float((r1 - r0).abs().max()) <= 2e-6
+    assert float((gp1 - gp0).abs().max()) <= 2e-5 * float(gp0.abs().max()) + 1e-9
+    for a, b in zip(g1, g0):
+        assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()) + 1e-7, (a.shape,)
+    assert torch.equal(r1, r2) and torch.equal(gp1, gp2) and all(torch.equal(a, b) for a, b in zip(g1, g2))      # fixed summation order
+
+
+def test_narrow_linear_against_torch():
+    """The action embedding Linear(9, 4 N) through ops.linear's narrow-layer kernel == F.linear, with all three gradients."""
+    from stove_amd import ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    for rows, i, o in ((25088, 9, 12), (5, 9, 24), (3000, 64, 64)):
+        x = torch.randn(rows, i, device=dev, requires_grad=True)
+        w = torch.randn(o, i, device=dev, requires_grad=True)
+        b = torch.randn(o, device=dev, requires_grad=True)
+        g = torch.randn(rows, o, device=dev)
+        y = ops.linear(x, w, b)
+        y.backward(g)
+        got = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+        x.grad = w.grad = b.grad = None
+        yr = torch.nn.functional.linear(x.double(), w.double(), b.double())
+        yr.backward(g.double())
+        ref = (yr.detach(), x.grad.double(), w.grad.double(), b.grad.double())
+        for a, c in zip(got, ref):
+            assert float((a.double() - c).abs().max()) <= 2e-5 * float(c.abs().max()) + 1e-6, (rows, i, o)

@@ -1,5 +1,5 @@
 """Training sanity run through the reference's entry point (model.main.main -> Trainer.train) on generated billiards data:
-prints the ELBO / position-error log lines and the wall time per training step.  python tools/train_demo.py [epochs [graph]]"""
+prints the ELBO / position-error log lines and the wall time per training step.  python tools/train_demo.py [epochs [eager]]"""
 import os
 import pickle
 import sys
@@ -14,7 +14,7 @@ from stove_amd.envs import envs  # noqa: E402
 import model.main as M  # noqa: E402
 
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-graph = len(sys.argv) > 2 and sys.argv[2] == 'graph'      # config.graph_step: non-logging steps as one captured hipGraph
+graph = not (len(sys.argv) > 2 and sys.argv[2] == 'eager')      # config.graph_step (default on): non-logging steps replayed as captured hipGraphs
 tmp = tempfile.mkdtemp()
 paths = {}
 for name, n_seq, seed0 in (('train', 300, 0), ('test', 40, 10 ** 5)):
