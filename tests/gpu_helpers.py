@@ -19,6 +19,32 @@ def err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def _np64(a):
+    return a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+
+
+def err_l2(a, b):
+    """||a - b||_2 / ||b||_2."""
+    a, b = _np64(a), _np64(b)
+    return float(np.sqrt(((a - b) ** 2).sum()) / (np.sqrt((b ** 2).sum()) + 1e-30))
+
+
+def err_small(a, b, floor=1e-3, q=0.99):
+    """The q-quantile over the entries of |a - b| / (|b| + floor max|b|): entries down to `floor` of the tensor's largest one are
+    checked RELATIVELY (the max-norm bar alone says nothing about them)."""
+    a, b = _np64(a).reshape(-1), _np64(b).reshape(-1)
+    if b.size == 0:
+        return 0.0
+    return float(np.quantile(np.abs(a - b) / (np.abs(b) + floor * (np.abs(b).max() + 1e-30)), q))
+
+
+def check_grad(key, a, b, bar_max, bar_l2, bar_small):
+    """A gradient tensor against its reference on three scales: largest entry, L2, and entry-wise relative (err_small)."""
+    check(key, err(a, b), bar_max)
+    check(key + '.l2', err_l2(a, b), bar_l2)
+    check(key + '.small', err_small(a, b), bar_small)
+
+
 _WORST = {}
 
 

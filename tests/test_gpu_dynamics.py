@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import stove_oracle as O
-from gpu_helpers import check, err, fill_analytic
+from gpu_helpers import check, check_grad, err, fill_analytic
 from helpers import load_golden, oracle_setup, t_
 
 pytestmark = pytest.mark.gpu
@@ -58,7 +58,7 @@ def test_dynamics_step(name, arena):
     for k, v in gold.items():
         if k.startswith('g_'):
             assert params[k[2:]].grad is not None, k
-            check('dyn_step.grad_param', err(params[k[2:]].grad, v), 2.5e-5)
+            check_grad('dyn_step.grad_param', params[k[2:]].grad, v, 2.5e-5, 2e-5, 1e-3)
             n += 1
     assert n >= 26
 
@@ -221,7 +221,7 @@ def test_stove_forward_elbo_and_grads(name, fused, arena):
             check('stove.grad_norm', abs(float(p.grad.norm()) - float(v)) / (float(v) + 1e-9), 1.5e-4)
             n += 1
         elif k.startswith('g_'):
-            check('stove.grad_tensor', err(params[k[2:]].grad, v), 3e-4)     # the reference's own fp32-vs-fp64 gap is 3.3e-4
+            check_grad('stove.grad_tensor', params[k[2:]].grad, v, 3e-4, 3.5e-4, 4e-3)     # the reference's own fp32-vs-fp64 gap is 3.3e-4 (max-norm)
     assert n > 50
     if arena:                                                  # cores 1-2 are never used: their gradients stay zero
         assert float(params['dyn.self_cores.1.0.weight'].grad.abs().max()) == 0.0
@@ -283,7 +283,7 @@ def test_encoder_lstm_against_oracle():
     check('encoder.codes', err(out_d, out_o), 1.2e-5)
     (out_d * w64.float().to(DEV)).sum().backward()
     for name, p in enc.named_parameters():
-        check('encoder.grad', err(p.grad, params['sup.encoder.' + name].grad), 4e-5)
+        check_grad('encoder.grad', p.grad, params['sup.encoder.' + name].grad, 4e-5, 3e-5, 1.2e-3)
 
 
 def test_match_volatile():
