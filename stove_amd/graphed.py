@@ -136,6 +136,8 @@ class GraphedTrainStep:
         dump = os.environ.get('STOVE_GRAPH_DUMP')         # debugging: write the captured main DAG (tools/graphdump) to this path
         g1 = torch.cuda.CUDAGraph(keep_graph=True) if dump else torch.cuda.CUDAGraph()
         split = os.environ.get('STOVE_GRAPH_ONE', '0') != '1'
+        if self._side_exec:                       # a re-capture (new batch shape): the previous side graph goes
+            lib.stove_graph_destroy(self._side_exec)
         self._side_exec = None
         import ctypes
         side_graph, side_nodes = ctypes.c_void_p(), ctypes.c_int()
@@ -160,7 +162,7 @@ class GraphedTrainStep:
                 gd = ctypes.CDLL(os.path.join(here, 'tools', 'graphdump', 'libgraphdump.so'))
                 gd.graph_of_stream.restype = ctypes.c_void_p
                 gd.graph_dump(ctypes.c_void_p(gd.graph_of_stream(ctypes.c_void_p(s.cuda_stream))), os.environ['STOVE_GRAPH_DUMP_OPEN'].encode())
-        ops.SideMode.keep = []
+        ops.SideMode.split, ops.SideMode.keep = False, []
         if split:
             ex = ctypes.c_void_p()
             _lib.check(lib.stove_graph_instantiate(side_graph, ctypes.byref(ex)), 'stove_graph_instantiate')

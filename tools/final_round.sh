@@ -1,0 +1,28 @@
+#!/bin/bash
+# Everything the round's profiles/ are made from, on ONE box.  Usage: gpurun --timeout 2400 -- 'bash tools/final_round.sh r03'
+TAG=${1:-r03}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+cd $R
+tools/stall_watch.sh
+bash tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1
+# timelines of the step captured as ONE graph and enqueued eagerly (the default three-graph replay is profile_round's timeline.txt)
+cd /tmp && export TMPDIR=/tmp
+STOVE_GRAPH_ONE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/one -o ks -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-variants --profile-steps 0 --step-mode graph > $OUT/one.log 2>&1
+python3 $R/tools/timeline.py $(find $OUT/one -name "*kernel_trace.csv" | head -1) 10 > $OUT/timeline_onegraph.txt; rm -rf $OUT/one
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eag -o ks -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-variants --profile-steps 0 --step-mode eager > $OUT/eag.log 2>&1
+python3 $R/tools/timeline.py $(find $OUT/eag -name "*kernel_trace.csv" | head -1) 10 > $OUT/timeline_eager.txt; rm -rf $OUT/eag
+cd $R
+for fs in f32 u8; do
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants --profile-steps 0 --frame-store $fs 2>/dev/null | tail -1 > $OUT/bench_store_$fs.json
+done
+STOVE_GRAPH_ONE=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants --profile-steps 0 2>/dev/null | tail -1 > $OUT/bench_onegraph.json
+bash tools/workloads_bench.sh $TAG > $OUT/workloads.log 2>&1
+python3 - <<PY
+import json
+for n in ('bench', 'bench_store_f32', 'bench_store_u8', 'bench_onegraph', 'bench_gravity', 'bench_avoidance', 'bench_multibilliards'):
+    try:
+        d = json.loads(open('$OUT/%s.json' % n).read().strip().splitlines()[-1])
+        print('%-24s %.3f ms/step  p50 %.3f  p99 %.3f  %.3f M frames/s' % (n, d['ms_per_step'], d['ms_per_step_p50'], d['ms_per_step_p99'], d['value'] / 1e6))
+    except Exception as e:
+        print(n, 'failed', e)
+PY
