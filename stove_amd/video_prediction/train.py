@@ -98,12 +98,12 @@ class AbstractTrainer:
         fs = self._frame_store()
         if dev.type == 'cuda' and getattr(self.c, 'device_dataset', True) \
                 and DeviceClipLoader.nbytes(dataset, self.c.dtype, fs) <= budget:
-            if test:        # evaluation: rank 0's pass over the WHOLE test set, in order (no shard, no shuffle)
-                return DeviceClipLoader(dataset, self.c.batch_size, dev, self.c.dtype, shuffle=False, drop_last=True, frame_store=fs)
+            if test:        # evaluation runs on rank 0 alone: ITS loader covers the whole test set (no shard), shuffled like the reference's (train.py:39-44)
+                return DeviceClipLoader(dataset, self.c.batch_size, dev, self.c.dtype, shuffle=True, drop_last=True, frame_store=fs)
             return DeviceClipLoader(dataset, self.c.batch_size, dev, self.c.dtype, shuffle=True, drop_last=True,
                                     rank=self.rank, world=self.world_size, seed=seed, frame_store=fs)
         if test:
-            return DataLoader(dataset, batch_size=self.c.batch_size, shuffle=False, num_workers=self.c.num_workers, drop_last=True)
+            return DataLoader(dataset, batch_size=self.c.batch_size, shuffle=True, num_workers=self.c.num_workers, drop_last=True)
         if self.world_size > 1:
             return ShardedDataLoader(dataset, self.c.batch_size, self.c.num_workers, self.rank, self.world_size, seed)
         return DataLoader(dataset, batch_size=self.c.batch_size, shuffle=True, num_workers=self.c.num_workers, drop_last=True)
