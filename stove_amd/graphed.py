@@ -3,10 +3,14 @@
 A step is ~100 launches on three streams.  Enqueued one by one the host is part of the loop: at the reference's default
 training shape (256 clips x 8 visible frames, config.py:17-21) it needs 2 ms for 1 ms of device work, and at the
 100-frame shape any host hiccup (scheduler, allocator, collector) longer than the ~1.4 ms it runs ahead starves the device.
-Captured once and replayed, a step is ONE launch call and the host runs many steps ahead.
+Captured once and replayed, a step is three launch calls and the host runs many steps ahead.
 
-  one process:    [ zero_grad + Stove.forward + backward + clip + Adam ]                 one graph
-  data parallel:  [ zero_grad + Stove.forward + backward ]  all-reduce  [ clip + Adam ]   two graphs, the collective between them
+  g_main  [ zero_grad + Stove.forward + backward ]          captured on the training stream, short fork / join episodes included
+  g_side  [ the parameter-gradient chain of the backward ]  its own capture of the side stream, launched on the side stream
+  (join the side stream; data parallel: all-reduce of the flat gradient)
+  g_opt   [ clip + Adam ]
+g_main and g_side are ordered against each other by event nodes (csrc/common.h: stream_after across two captures).  As branches
+of ONE graph (STOVE_GRAPH_ONE=1) the runtime queued the side chain behind the main chain: 3.6 instead of 3.1 ms per step.
 
 What varies from step to step enters through device memory:
   * the batch: static input tensors (`alias_inputs=True` adopts the caller's tensors instead of copying into own ones: a
