@@ -159,10 +159,15 @@ class DeviceClipLoader:
         n = len(self.idxs) // self.world
         return n // self.batch_size if self.drop_last or self.world > 1 else (n + self.batch_size - 1) // self.batch_size
 
-    def batch(self, clip_ids):
-        """The batch of the given clip numbers (indices into dataset.idxs)."""
+    def _base(self, clip_ids):
+        """flat (episode * frame) index of the first frame of every clip, on the host"""
         ij = self.idxs[clip_ids]
-        base = (ij[:, 0] * self.n_frames + ij[:, 1]).to(self.device)
+        return ij[:, 0] * self.n_frames + ij[:, 1]
+
+    def batch(self, clip_ids, base=None):
+        """The batch of the given clip numbers (indices into dataset.idxs); `base`: their first-frame indices already on the device."""
+        if base is None:
+            base = self._base(clip_ids).to(self.device)
         pres, fut = base[:, None] + self._present, base[:, None] + self._future
         out = {}
         for name, t in self.store.items():
@@ -188,9 +193,13 @@ class DeviceClipLoader:
             self.epoch += 1
         else:
             order = torch.randperm(n) if self.shuffle else torch.arange(n)
-        for b in range(len(self)):
+        # ONE host-to-device copy per epoch (the clip order of the whole epoch), not one per batch: a pageable copy waits for the stream,
+        # i.e. for the previous step -- it would tie the host to the device once per step and undo what the replayed step buys
+        nb = len(self)
+        base_all = self._base(order[:nb * self.batch_size] if self.drop_last or self.world > 1 else order).to(self.device)
+        for b in range(nb):
             self.last_clip_ids = order[b * self.batch_size:(b + 1) * self.batch_size]
-            yield self.batch(self.last_clip_ids)
+            yield self.batch(self.last_clip_ids, base_all[b * self.batch_size:(b + 1) * self.batch_size])
 
 
 class ShardedDataLoader:
