@@ -1319,6 +1319,20 @@ def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=
     N = b.shape[1] if b_kmajor else b.shape[0]
     if splitk is None:
         splitk = gemm_splitk(M, N, K) if bias is None and add is None else 1
+    if (splitk == 1 and out is None and not a_kmajor and (bias is not None or add is not None) and K >= 512 and K % 256 == 0
+            and M * N % 4 == 0 and os.environ.get('STOVE_GEMM_AUTO', '1') != '0'):
+        # Short activations x weights products (the reference's default training shape has 2 048 frames per step: 16-64 workgroups of
+        # the tile, each walking all of K at ~1.5 us per k-step): split K so that every CU gets a workgroup.  The add term becomes
+        # the initial value of C (split-K accumulates into C when add == C), a bias rides the slice sum (fewer than 16 slices).
+        bm, bn = (128, 128) if tile == 2 else (256, 128)
+        tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+        sk = 1
+        while tiles * sk * 2 <= 256 and K // (sk * 2) >= 128 and sk * 2 <= 8:
+            sk *= 2
+        if sk > 1 and not (bias is not None and add is not None):
+            splitk = sk
+            if add is not None:
+                out, add = _f32(add).clone(), None
     lib = _lib.load()
     if out is not None:
         if add is not None or bias is not None or out.shape != (M, N) or not out.is_contiguous() or out.dtype != torch.float32:
@@ -1348,7 +1362,7 @@ def _gemm_rows_balanced(x, w, bias, ns):
     tail_tiles = (tiles_m - main_m) * tiles_n
     K = x.shape[1]
     if rounds == 0 or tail_tiles == 0 or tail_tiles * 4 > cus or K % 256 != 0 or N % 4 != 0:
-        return gemm_bf16(x, w, bias=bias, nsplit=ns, splitk=1)
+        return gemm_bf16(x, w, bias=bias, nsplit=ns, splitk=1)             # tile chosen from the shape (gemm_tile)
     lib = _lib.load()
     out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     rows = main_m * 256
