@@ -146,7 +146,8 @@ int stove_scene_glimpses(const float* frames, const float* z, int n_frames, int 
 
 /* ---- Dynamics.forward / core (dynamics.py:181-265): one GNN step.
  * params: the parameter image of stove_gnn_param_floats() floats built by
- * stove_amd/video_prediction/dynamics.py (W | W^T | vectors; layout in csrc/gnn.hip).
+ * stove_amd/video_prediction/dynamics.py + ops._gnn_image (W | W^T | vectors | W packed | W^T packed: the last two hold every layer
+ * once more in the [K/4][OUT][4] order the small-graph recursion kernels copy into LDS; layout in csrc/gnn.hip).
  * s_in (B,N,sin_dim): [state 16 | action embedding 4 | appearance 3] as configured (16 <= sin_dim <= 32);
  * result (B,N,32) = means|stds (dynamics.py:216), pred (B,N,32) = dynamic_pred (:208), may be NULL.
  * elu: 0 = leaky_relu(0.01) (the reference default, dynamics.py:109), 1 = elu. */

@@ -257,7 +257,8 @@ class ParamArena:
         self._gnn = {}
         for k in range(3):
             w, v, wt = dyn.param_image(k, leaf=index_of, pad_value=-1.0)
-            self._gnn[k] = (torch.cat([w, wt, v]).to(torch.int32).to(dev), torch.cat([w, v]).to(torch.int32).to(dev))
+            pf, pt = ops.gnn_pack_perms(torch.device('cpu'))            # + the packed sections the small-graph kernels copy into LDS
+            self._gnn[k] = (torch.cat([w, wt, v, w[pf], wt[pt]]).to(torch.int32).to(dev), torch.cat([w, v]).to(torch.int32).to(dev))
         self._gnn_params = [p for n, p in dyn.named_parameters()
                             if n.split('.')[0] in ('state_enc', 'self_cores', 'rel_cores', 'att_net', 'affector', 'out')]
 

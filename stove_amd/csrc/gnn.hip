@@ -36,7 +36,11 @@ constexpr int W_ENC = 0, W_S0 = 1024, W_S1 = 2048, W_EF = 3072, W_R1 = 11264, W_
 constexpr int V_ENC = 0, V_S0 = 32, V_S1 = 64, V_BR0 = 96, V_WDR = 160, V_BA0 = 224, V_WDA = 288, V_BR1 = 352,
               V_BA1 = 384, V_BR2 = 416, V_WA2 = 448, V_BA2 = 480, V_F0 = 512, V_F1 = 544, V_F2 = 576, V_O0 = 608,
               V_O1 = 640, V_END = 672;
-constexpr int kGnnParams = 2 * W_END + V_END;      // forward image
+// forward image: [W | W^T | vectors | W packed | W^T packed].  The two packed sections hold every layer of W / W^T once more in the
+// [K/4][OUT][4] order the small-graph kernels keep in LDS (gnn_small.hip: sm_repack), so that their 256 workgroups fill LDS with
+// straight float4 copies instead of each redoing the scattered repack of 90 KB (round 3: ~10 us off every launch of the recursion).
+constexpr int P_WPACK = 2 * W_END + V_END, P_WTPACK = P_WPACK + W_END;
+constexpr int kGnnParams = 2 * W_END + V_END + 2 * W_END;
 constexpr int kGnnGrads = W_END + V_END;           // gradient image (W layout + VEC)
 
 constexpr int LDN = 36, LDC = 68, LDP = 260, NEMAX = 80;

@@ -36,26 +36,11 @@ __device__ __forceinline__ SmLds sm_carve(float* base) {
   return L;
 }
 
-// one layer of the W image -> [K/4][OUT][4]
-__device__ __forceinline__ void sm_repack(float* dst, const float* __restrict__ src, int OUT, int K) {
-  for (int idx = threadIdx.x; idx < OUT * K; idx += blockDim.x) {
-    const int o = idx / K, k = idx % K;
-    dst[((k >> 2) * OUT + o) * 4 + (k & 3)] = src[idx];
-  }
+__device__ __forceinline__ void sm_copy_packed(float* dst, const float* __restrict__ src, int n) {
+  for (int i = threadIdx.x; i < n / 4; i += blockDim.x) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
 }
 __device__ __forceinline__ void sm_setup(const SmLds& L, const float* __restrict__ P) {
-  sm_repack(L.W + W_ENC, P + W_ENC, 32, 32);
-  sm_repack(L.W + W_S0, P + W_S0, 32, 32);
-  sm_repack(L.W + W_S1, P + W_S1, 32, 32);
-  sm_repack(L.W + W_EF, P + W_EF, 256, 32);
-  sm_repack(L.W + W_R1, P + W_R1, 32, 64);
-  sm_repack(L.W + W_A1, P + W_A1, 32, 64);
-  sm_repack(L.W + W_R2, P + W_R2, 32, 32);
-  sm_repack(L.W + W_F0, P + W_F0, 32, 32);
-  sm_repack(L.W + W_F1, P + W_F1, 32, 32);
-  sm_repack(L.W + W_F2, P + W_F2, 32, 32);
-  sm_repack(L.W + W_O0, P + W_O0, 32, 64);
-  sm_repack(L.W + W_O1, P + W_O1, 32, 32);
+  sm_copy_packed(L.W, P + P_WPACK, W_END);          // every layer already in [K/4][OUT][4] order (the image's packed section)
   for (int i = threadIdx.x; i < V_END; i += blockDim.x) L.V[i] = P[2 * W_END + i];
 }
 

@@ -53,19 +53,7 @@ __device__ __forceinline__ SmBLds smb_carve(float* base) {
 }
 // transposed layer image (rows = layer inputs, K = layer outputs) -> [K/4][rows][4]
 __device__ __forceinline__ void smb_setup(const SmBLds& L, const float* __restrict__ P) {
-  const float* WT = P + W_END;
-  sm_repack(L.W + W_ENC, WT + W_ENC, 32, 32);
-  sm_repack(L.W + W_S0, WT + W_S0, 32, 32);
-  sm_repack(L.W + W_S1, WT + W_S1, 32, 32);
-  sm_repack(L.W + W_EF, WT + W_EF, 32, 256);
-  sm_repack(L.W + W_R1, WT + W_R1, 64, 32);
-  sm_repack(L.W + W_A1, WT + W_A1, 64, 32);
-  sm_repack(L.W + W_R2, WT + W_R2, 32, 32);
-  sm_repack(L.W + W_F0, WT + W_F0, 32, 32);
-  sm_repack(L.W + W_F1, WT + W_F1, 32, 32);
-  sm_repack(L.W + W_F2, WT + W_F2, 32, 32);
-  sm_repack(L.W + W_O0, WT + W_O0, 64, 32);
-  sm_repack(L.W + W_O1, WT + W_O1, 32, 32);
+  sm_copy_packed(L.W, P + P_WTPACK, W_END);         // the transposed layers, packed (image section 5)
   for (int i = threadIdx.x; i < V_END; i += blockDim.x) L.V[i] = P[2 * W_END + i];
 }
 

@@ -346,10 +346,37 @@ GNN_W_FLOATS = 22528
 GNN_V_FLOATS = 672
 
 
+# layers of the W image: (offset, OUT, K) as the forward uses them; the W^T image holds the same layers transposed (K, OUT swapped)
+_GNN_LAYERS = ((0, 32, 32), (1024, 32, 32), (2048, 32, 32), (3072, 256, 32), (11264, 32, 64), (13312, 32, 64), (15360, 32, 32),
+               (16384, 32, 32), (17408, 32, 32), (18432, 32, 32), (19456, 32, 64), (21504, 32, 32))
+_GNN_PERMS = {}
+
+
+def gnn_pack_perms(device):
+    """Index tensors p_f, p_t with packed_W = W[p_f], packed_WT = WT[p_t]: every layer in the [K/4][OUT][4] order the small-graph
+    kernels keep in LDS (csrc/gnn_small.hip: element (o, k) of an (OUT, K) layer at ((k >> 2) OUT + o) 4 + (k & 3))."""
+    key = str(device)
+    if key not in _GNN_PERMS:
+        import numpy as np
+        perms = []
+        for transposed in (False, True):
+            src = np.zeros(GNN_W_FLOATS, dtype=np.int64)
+            for off, out_f, k_f in _GNN_LAYERS:
+                OUT, K = (k_f, out_f) if transposed else (out_f, k_f)
+                o, k = np.meshgrid(np.arange(OUT), np.arange(K), indexing='ij')
+                src[off + ((k >> 2) * OUT + o) * 4 + (k & 3)] = off + o * K + k
+            perms.append(torch.from_numpy(src).to(device))
+        _GNN_PERMS[key] = tuple(perms)
+    return _GNN_PERMS[key]
+
+
 def _gnn_image(w_img, v_img, wt_img):
-    if v_img is None:                          # prebuilt [W | W^T | vectors] image (ParamArena.gnn_image)
+    if v_img is None:                          # prebuilt [W | W^T | vectors | W packed | W^T packed] image (ParamArena.gnn_image)
         return w_img
-    return torch.cat([w_img, wt_img, v_img]).contiguous()
+    pf, pt = gnn_pack_perms(w_img.device)
+    with torch.no_grad():
+        packed = torch.cat([w_img.detach()[pf], wt_img.detach()[pt]])
+    return torch.cat([w_img, wt_img, v_img, packed]).contiguous()
 
 
 class _GnnStepFn(torch.autograd.Function):
