@@ -6,6 +6,7 @@ import math
 import torch
 
 import stove_oracle as O  # noqa: F401  (conftest puts oracle/ on the path; only used for the config defaults)
+from stove_amd import ops
 from stove_amd.arena import ParamArena
 
 
@@ -79,7 +80,9 @@ def test_gnn_gather_table_addresses_the_param_image():
         arena = ParamArena(st)
         for k in range(3):
             w, v, wt = st.dyn.param_image(k)
-            want = torch.cat([w, wt, v]).detach()
+            pf, pt = ops.gnn_pack_perms(torch.device('cpu'))      # + both weight sections again in the small-graph kernels' LDS order
+            want = torch.cat([w, wt, v, w[pf], wt[pt]]).detach()
+            assert torch.equal(want, ops._gnn_image(w, v, wt).detach())      # what the non-arena path builds
             src, src_g = arena._gnn[k]
             got = torch.where(src >= 0, arena.data[src.clamp(min=0).long()], torch.zeros(()))
             assert torch.equal(got, want)
