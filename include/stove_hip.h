@@ -94,8 +94,13 @@ int stove_bgspn_bwd(const StoveSpnTables* t, const float* inputs, const float* m
  * seq_frames / seq_stride: the frames may be a time-slice of longer clips handed over WITHOUT a copy (Stove.forward scores
  * x[:, 1:], stove.py:731-736): frame f is row (f / seq_frames) * seq_stride + f % seq_frames behind `frames`; 0, 0 = dense.
  * ll: (n_frames,) log p(x,z); parts: (n_frames,3) = bg, patches, overlap (may be NULL).
- * saved: stove_scene_saved_floats() floats kept for the backward. */
+ * saved: stove_scene_saved_floats() floats kept for the backward.  The object SPN's backward is linear in the upstream
+ * gradient of a glimpse, so the forward runs it at once, at a gradient of 1, while the sample's leaf and sum-node values are
+ * still in registers, and leaves the per-glimpse scratch (2 904 B) in `saved`; stove_scene_bwd* applies dL/d(glimpse
+ * likelihood) where that scratch is consumed.  A caller that will never differentiate uses stove_scene_fwd_from(.., with_grad 0)
+ * with the smaller buffer of stove_scene_fwd_floats(.., 0): same ll / parts bit for bit, no backward from it. */
 size_t stove_scene_saved_floats(int n_frames, int n_obj);
+size_t stove_scene_fwd_floats(int n_frames, int n_obj, int with_grad);     /* with_grad != 0: == stove_scene_saved_floats */
 int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
                     int seq_stride, float overlap_beta, float* ll, float* parts, float* saved, void* stream);
 size_t stove_scene_bwd_ws_bytes(int n_frames, int n_obj);
@@ -114,7 +119,8 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
  * scene calls on a stream which is itself a fork inside a hipGraph capture: pass the capture's origin stream, where frames, z, saved
  * and dll must then be ready (the HIP 7.0 runtime cannot end a capture in which two forked streams wait on each other). */
 int stove_scene_fwd_from(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
-                         int seq_stride, float overlap_beta, float* ll, float* parts, float* saved, void* stream, void* fork_from);
+                         int seq_stride, float overlap_beta, float* ll, float* parts, float* saved, void* stream, void* fork_from,
+                         int with_grad);
 int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
                          int seq_stride, float overlap_beta, const float* saved, const float* dll, float* dz,
                          StoveSpnTableGrads* g, void* ws, void* stream, void* param_stream, void* fork_from);

@@ -23,7 +23,7 @@ EXPORTS = [
     'stove_enc_head_fwd', 'stove_enc_head_bwd_ws_floats', 'stove_enc_head_bwd', 'stove_colsum2', 'stove_small_tn', 'stove_small_tn_ws_floats', 'stove_supair_state_fwd2', 'stove_supair_state_bwd2', 'stove_bg_dense', 'stove_bg_dense_floats',
     'stove_bw_transform_u8', 'stove_stream_after', 'stove_capture_begin', 'stove_capture_end', 'stove_graph_instantiate', 'stove_graph_launch', 'stove_graph_destroy',
     'stove_reward_head_param_floats', 'stove_reward_head_saved_floats', 'stove_reward_head_bwd_ws_floats', 'stove_reward_head_fwd',
-    'stove_reward_head_bwd', 'stove_small_linear', 'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_bwd_from', 'stove_dynloop_range_ok', 'stove_dynloop_fwd_range', 'stove_dynloop_bwd_range', 'stove_zall_fwd_range', 'stove_zall_bwd_range',
+    'stove_reward_head_bwd', 'stove_small_linear', 'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_fwd_floats', 'stove_scene_bwd_from', 'stove_dynloop_range_ok', 'stove_dynloop_fwd_range', 'stove_dynloop_bwd_range', 'stove_zall_fwd_range', 'stove_zall_bwd_range',
 ]
 
 
@@ -63,7 +63,8 @@ def _declare(lib):
         'stove_bgspn_bwd': (I, [T, P, P, P, P, P, P, P, G, P, I, P]),
         'stove_scene_saved_floats': (S, [I, I]),
         'stove_scene_fwd': (I, [T, P, P, I, I, I, I, F, P, P, P, P]),
-        'stove_scene_fwd_from': (I, [T, P, P, I, I, I, I, F, P, P, P, P, P]),
+        'stove_scene_fwd_from': (I, [T, P, P, I, I, I, I, F, P, P, P, P, P, I]),
+        'stove_scene_fwd_floats': (S, [I, I, I]),
         'stove_scene_bwd_from': (I, [T, P, P, I, I, I, I, F, P, P, P, G, P, P, P, P]),
         'stove_scene_bwd_ws_bytes': (S, [I, I]),
         'stove_scene_bwd': (I, [T, P, P, I, I, I, I, F, P, P, P, G, P, P]),

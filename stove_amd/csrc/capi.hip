@@ -67,8 +67,9 @@ static inline int nmax_of(int n_obj) { return n_obj <= 3 ? 3 : (n_obj <= 6 ? 6 :
 template <int NMAX>
 static int scene_bwd_tail(const float* frames, const float* z, const float* xw, const float* Dscr, const int* leaf_slot,
                           const float* coef, const float* d_ovl, float* dzc, const float* dll, const float* obj_ll,
-                          const float* dz_bg, float* dz, int n_obj, int np, hipStream_t st, hipStream_t bg_stream, FrameMap fm) {
-  int rc = scene_pixtile_bwd<NMAX>(frames, z, xw, Dscr, leaf_slot, coef, d_ovl, dzc, n_obj, np, st, fm);
+                          const float* dz_bg, float* dz, int n_obj, int np, hipStream_t st, hipStream_t bg_stream, FrameMap fm,
+                          const float* d_obj) {      // Dscr is at unit upstream gradient: times d_obj[patch] as it is staged
+  int rc = scene_pixtile_bwd<NMAX>(frames, z, xw, Dscr, leaf_slot, coef, d_ovl, dzc, n_obj, np, st, fm, d_obj);
   if (rc) return rc;
   STOVE_TRY(stream_after(st, bg_stream));       // join: only the last kernel needs the background chain's dz_bg
   STOVE_LAUNCH((scene_finalize_bwd_k<NMAX>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, obj_ll, dz_bg, dzc, dz, n_obj, np);
@@ -140,11 +141,12 @@ int stove_bgspn_bwd(const StoveSpnTables* t, const float* inputs, const float* m
 }
 
 // ---------------------------------------------------------------- fused scene likelihood
-// saved = [ xw tile | obj_ll (np) | ovl (np) | bg_out (nf) | bg_ell | object-SPN forward state | box coverage tables ]
+// saved = [ xw tile | obj_ll (np) | ovl (np) | bg_out (nf) | bg_ell | box coverage tables | object-SPN backward scratch at unit gradient ]
+// (the last section only exists / is only written when the forward is asked for it: with_grad)
 struct SceneSaved {
-  size_t xw, obj_ll, ovl, bg_out, bg_ell, obj_state, cover, total;
+  size_t xw, obj_ll, ovl, bg_out, bg_ell, cover, obj_scratch, total;
 };
-static SceneSaved scene_saved_layout(int nf, int n_obj) {
+static SceneSaved scene_saved_layout(int nf, int n_obj, bool with_grad = true) {
   const size_t np = (size_t)nf * n_obj;
   SceneSaved s;
   s.xw = 0;
@@ -152,13 +154,14 @@ static SceneSaved scene_saved_layout(int nf, int n_obj) {
   s.ovl = s.obj_ll + align64(np);
   s.bg_out = s.ovl + align64(np);
   s.bg_ell = s.bg_out + align64(nf);
-  s.obj_state = s.bg_ell + align64(bgspn_fwd_ws_floats(nf));
-  s.cover = s.obj_state + align64(objspn_state_floats((int)np));
-  s.total = s.cover + align64(bg_cover_floats(nf, n_obj));
+  s.cover = s.bg_ell + align64(bgspn_fwd_ws_floats(nf));
+  s.obj_scratch = s.cover + align64(bg_cover_floats(nf, n_obj));
+  s.total = s.obj_scratch + (with_grad ? align64(objspn_scratch_floats((int)np)) : 0);
   return s;
 }
 
 size_t stove_scene_saved_floats(int n_frames, int n_obj) { return scene_saved_layout(n_frames, n_obj).total; }
+size_t stove_scene_fwd_floats(int n_frames, int n_obj, int with_grad) { return scene_saved_layout(n_frames, n_obj, with_grad != 0).total; }
 
 // Internal fork stream (one per device, created on first use): the background-SPN chain of a scene call runs on it next
 // to the object-SPN chain -- they are independent until the assemble / tail kernels -- and is joined back before the call
@@ -203,15 +206,19 @@ static int frame_map(int n_frames, int seq_frames, int seq_stride, FrameMap* fm)
 
 int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
                     int seq_stride, float overlap_beta, float* ll, float* parts, float* saved, void* stream) {
-  return stove_scene_fwd_from(t, frames, z, n_frames, n_obj, seq_frames, seq_stride, overlap_beta, ll, parts, saved, stream, stream);
+  return stove_scene_fwd_from(t, frames, z, n_frames, n_obj, seq_frames, seq_stride, overlap_beta, ll, parts, saved, stream, stream, 1);
 }
 
 // fork_from: the stream the internal background-SPN chain is ordered behind (its inputs -- frames, z, tables -- must be ready there).
 // Normally `stream` itself.  A caller that runs the call on a stream which is itself a fork of a stream under hipGraph capture passes
 // that capture's ORIGIN stream: the HIP 7.0 runtime cannot end a capture in which two forked streams wait on each other
 // (fork from X, join into X, with X not the origin: hip::Stream::EndCapture recurses forever; tools/ubench/graph_ext2.hip).
+// with_grad != 0: the object SPN runs forward + backward at unit upstream gradient in one pass (objspn_fwd_unit_k) and leaves
+// the per-glimpse backward scratch in `saved` (stove_scene_fwd_floats(.., 1) = stove_scene_saved_floats floats): what
+// stove_scene_bwd* needs.  0: likelihood only, `saved` of stove_scene_fwd_floats(.., 0) floats, no backward from it.
 int stove_scene_fwd_from(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
-                         int seq_stride, float overlap_beta, float* ll, float* parts, float* saved, void* stream, void* fork_from) {
+                         int seq_stride, float overlap_beta, float* ll, float* parts, float* saved, void* stream, void* fork_from,
+                         int with_grad) {
   hipStream_t st = (hipStream_t)stream;
   hipStream_t root = fork_from != nullptr ? (hipStream_t)fork_from : st;
   if (n_frames == 0) return 0;
@@ -224,8 +231,11 @@ int stove_scene_fwd_from(const StoveSpnTables* t, const float* frames, const flo
   JoinGuard jb(st, sb);                         // joined on every exit path
   int rc = scene_tile_fwd_any(frames, z, saved + L.xw, n_obj, np, st, fm);
   if (rc) return rc;
-  rc = objspn_forward(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl, np, st,
-                      saved + L.obj_state);
+  if (with_grad)
+    rc = objspn_forward_unit(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl,
+                             saved + L.obj_scratch, np, st);
+  else
+    rc = objspn_forward(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl, np, st);
   if (rc) return rc;
   rc = bgspn_forward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, sb, fm, t->bg_dense);
   if (rc) return rc;
@@ -238,7 +248,7 @@ int stove_scene_fwd_from(const StoveSpnTables* t, const float* frames, const flo
   return 0;
 }
 
-// ws = [ d_obj (np) | d_ovl (np) | dzc (np*NMAX*4) | dz_bg (np*4) | obj ws | bg ws ]
+// ws = [ d_obj (np) | d_ovl (np) | dzc (np*NMAX*4) | dz_bg (np*4) | obj table-gradient chunk partials | bg ws ]
 struct SceneWs {
   size_t d_obj, d_ovl, dzc, dz_bg, obj, bg, total;
 };
@@ -250,7 +260,7 @@ static SceneWs scene_ws_layout(int nf, int n_obj) {
   s.dzc = s.d_ovl + align64(np);
   s.dz_bg = s.dzc + align64(np * nmax_of(n_obj) * 4);
   s.obj = s.dz_bg + align64(np * 4);
-  s.bg = s.obj + align64(objspn_bwd_ws_floats((int)np));
+  s.bg = s.obj + align64(objspn_partial_floats());
   s.total = s.bg + align64(bgspn_bwd_ws_floats(nf, n_obj));
   return s;
 }
@@ -311,9 +321,9 @@ int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const flo
   STOVE_TRY(stream_after(sb, root));
   JoinGuard jb(st, sb);                         // error paths: the tail below is what joins `sb` normally
   JoinGuard jp(st, sp);                         // error paths only: the caller joins the parameter stream after a clean return
-  int rc = objspn_backward_data(saved + L.xw, t->obj_scope, t->obj_leaf_slot, t->obj_coef, t->obj_wsum, t->obj_wroot,
-                                saved + L.obj_ll, ws + W.d_obj, nullptr, ws + W.obj, np, st, saved + L.obj_state);
-  if (rc) return rc;
+  // The object SPN's backward already ran, at unit upstream gradient, inside the forward (objspn_fwd_unit_k): what is left is to
+  // apply d_obj[patch] where its scratch is consumed -- the tail below and the table gradients.
+  int rc = 0;
   // The object-SPN table gradients go to the parameter stream: once dz is out (underneath what the caller enqueues next,
   // the recursion's backward), or (STOVE_PARAMS_EARLY=1) right behind their producer.
   // ... for up to four objects: the small-graph recursion (gnn_small*.hip) is the latency-bound kernel with room beside it; the
@@ -321,7 +331,8 @@ int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const flo
   const bool late = sp != st && params_late() && n_obj <= 4;
   if (!late) {
     STOVE_TRY(stream_after(sp, st));
-    rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, sp);
+    rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, saved + L.obj_scratch, ws + W.obj,
+                                ws + W.d_obj, np, sp);
     if (rc) return rc;
   }
   rc = bgspn_backward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, dll,
@@ -329,21 +340,22 @@ int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const flo
   if (rc) return rc;
   // the tail joins `sb` before its last kernel (dz_bg; without a parameter stream also the bg table grads)
   if (n_obj <= 3)
-    rc = scene_bwd_tail<3>(frames, z, saved + L.xw, ws + W.obj, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
-                           ws + W.dz_bg, dz, n_obj, np, st, sb, fm);
+    rc = scene_bwd_tail<3>(frames, z, saved + L.xw, saved + L.obj_scratch, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
+                           ws + W.dz_bg, dz, n_obj, np, st, sb, fm, ws + W.d_obj);
   else if (n_obj <= 6)
-    rc = scene_bwd_tail<6>(frames, z, saved + L.xw, ws + W.obj, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
-                           ws + W.dz_bg, dz, n_obj, np, st, sb, fm);
+    rc = scene_bwd_tail<6>(frames, z, saved + L.xw, saved + L.obj_scratch, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
+                           ws + W.dz_bg, dz, n_obj, np, st, sb, fm, ws + W.d_obj);
   else if (n_obj <= 8)
-    rc = scene_bwd_tail<8>(frames, z, saved + L.xw, ws + W.obj, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
-                           ws + W.dz_bg, dz, n_obj, np, st, sb, fm);
+    rc = scene_bwd_tail<8>(frames, z, saved + L.xw, saved + L.obj_scratch, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
+                           ws + W.dz_bg, dz, n_obj, np, st, sb, fm, ws + W.d_obj);
   else
     rc = (int)hipErrorInvalidValue;
   if (rc) return rc;
   jb.dismiss();                                 // scene_bwd_tail joined `sb`
   if (late) {
     STOVE_TRY(stream_after(sp, st));
-    rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, ws + W.obj, np, sp, true);
+    rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, saved + L.obj_scratch, ws + W.obj,
+                                ws + W.d_obj, np, sp, true);
     if (rc) return rc;
   }
   jp.dismiss();

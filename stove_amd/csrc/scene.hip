@@ -144,7 +144,10 @@ __global__ void scene_assemble_bwd_k(const float* __restrict__ dll, const float*
                                      float* __restrict__ d_obj, float* __restrict__ d_ovl,
                                      int n_obj, int n_patches, float beta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_patches) return;
+  if (i >= n_patches) {          // d_obj is read per batch of 64 patches as the scale of the unit-gradient scratch: zeros for the tail
+    if (i < ((n_patches + 63) & ~63)) d_obj[i] = 0.0f;
+    return;
+  }
   const float g = dll[i / n_obj];
   d_obj[i] = g * z[(size_t)i * 4] * z[(size_t)i * 4 + 1];
   d_ovl[i] = -beta * g;

@@ -32,7 +32,7 @@ template <int R, int S, int G, int NMAX, int SLOTS>
 __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
     const float* __restrict__ frames, const float* __restrict__ z, const float* __restrict__ xw, const float* __restrict__ Dscr,
     const int* __restrict__ leaf_slot, const float* __restrict__ coef, const float* __restrict__ d_ovl, float* __restrict__ dzc,
-    int n_obj, int n_patches, int n_batches, FrameMap fm) {
+    int n_obj, int n_patches, int n_batches, FrameMap fm, const float* __restrict__ scale) {
   constexpr int D = 4 * S;
   constexpr int DT = R * 4 * G * 64;
   constexpr int RED = SLOTS * NMAX * 4 * 64;
@@ -62,7 +62,18 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
     {
       const float4* src = reinterpret_cast<const float4*>(Dscr + (size_t)b * DT);
       float4* dst = reinterpret_cast<float4*>(dl);
-      for (int i = threadIdx.x; i < DT / 4; i += 64 * SLOTS) dst[i] = src[i];
+      if (scale == nullptr) {
+        for (int i = threadIdx.x; i < DT / 4; i += 64 * SLOTS) dst[i] = src[i];
+      } else {
+        // leaf gradients written for an upstream gradient of 1 (objspn_fwd_unit_k): times dL/d root of the sample, here.
+        // 64 * SLOTS is a multiple of 16, so a thread keeps its four samples over the whole copy
+        const float4 sc = *reinterpret_cast<const float4*>(scale + b * 64 + ((4 * threadIdx.x) & 63));      // a multiple of 64 entries, zeros beyond the last patch
+        for (int i = threadIdx.x; i < DT / 4; i += 64 * SLOTS) {
+          float4 v = src[i];
+          v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+          dst[i] = v;
+        }
+      }
     }
     const int patch = b * 64 + lane;
     const bool live = patch < n_patches;
@@ -213,7 +224,8 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
 
 template <int NMAX>
 static int scene_pixtile_bwd(const float* frames, const float* z, const float* xw, const float* Dscr, const int* leaf_slot,
-                             const float* coef, const float* d_ovl, float* dzc, int n_obj, int np, hipStream_t st, FrameMap fm) {
+                             const float* coef, const float* d_ovl, float* dzc, int n_obj, int np, hipStream_t st, FrameMap fm,
+                             const float* scale) {      // scale: see the kernel's staging loop; nullptr = Dscr carries it
   // 16 waves (4 per SIMD) when the cross-slot reduction buffer allows: the per-pixel code is a chain of dependent instructions
   // (~9 cycles per instruction at 2 waves per SIMD), more resident waves hide it
   constexpr int SLOTS = NMAX <= 3 ? 16 : 8;
@@ -225,7 +237,7 @@ static int scene_pixtile_bwd(const float* frames, const float* z, const float* x
   if (rc) return rc;
   STOVE_LAUNCH((scene_pixtile_bwd_k<6, 25, 10, NMAX, SLOTS>), dim3(nb < 256 ? nb : 256), dim3(64 * SLOTS), LDS, st, frames, z, xw, Dscr,      // persistent: one workgroup per CU
               
-               leaf_slot, coef, d_ovl, dzc, n_obj, np, nb, fm);
+               leaf_slot, coef, d_ovl, dzc, n_obj, np, nb, fm, scale);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -123,13 +123,43 @@ __device__ __forceinline__ void side_forward(const float* __restrict__ tile, int
   for (int s = 0; s < K; ++s) st.o[s] = m1 + m2 + __logf(st.acc[s]);
 }
 
+// ---- root pieces shared by the forward, the backward and the fused forward + unit backward ------------------------
+// replica root (side-0 wave): sum_{j2, j1} EA[j1] EB[j2] wroot[j2 K + j1] on max-shifted exponentials
+template <int K>
+__device__ __forceinline__ float root_pair_sum(const float (&EA)[K], const float (&EB)[K], const float* __restrict__ wr) {
+  float sr = 0.0f;
+#pragma unroll
+  for (int j2 = 0; j2 < K; ++j2)
+#pragma unroll
+    for (int j1 = 0; j1 < K; ++j1) sr = fmaf(EA[j1] * EB[j2], wr[j2 * K + j1], sr);
+  return sr;
+}
+// root log-density of the lane's sample from the R replicas' (max, sum) pairs in LDS
+template <int R>
+__device__ __forceinline__ float root_value(const float* part, int lane) {
+  float M = part[lane];
+#pragma unroll
+  for (int q = 1; q < R; ++q) M = fmaxf(M, part[(q * 2) * 64 + lane]);
+  float Z = 0.0f;
+#pragma unroll
+  for (int q = 0; q < R; ++q) Z = fmaf(part[(q * 2 + 1) * 64 + lane], __expf(part[(q * 2) * 64 + lane] - M), Z);
+  return M + __logf(Z);
+}
+// mean over the pixels of (1 - w): the overlap statistic of the glimpse
+template <int D>
+__device__ __forceinline__ float tile_overlap(const float* __restrict__ tile, int lane) {
+  float s1 = 0.0f;
+  for (int p = 0; p < D; ++p) s1 += 1.0f - tile[(p * 2 + 1) * 64 + lane];
+  return s1 * (1.0f / D);
+}
+
 // ---- forward -------------------------------------------------------------------------------
 // out[sample] = root log-density; ovl[sample] = mean over pixels of (1 - w) (optional).
 template <int R, int S, int G, int K>
 __global__ __launch_bounds__(128 * R) void objspn_fwd_k(
     const float* __restrict__ xw, const int* __restrict__ scope, const float* __restrict__ coef,
     const float* __restrict__ wsum, const float* __restrict__ wroot,
-    float* __restrict__ out, float* __restrict__ ovl, int n_samples, int n_batches, float* __restrict__ st_save) {
+    float* __restrict__ out, float* __restrict__ ovl, int n_samples, int n_batches) {
   constexpr int D = 4 * S;
   __shared__ float xch[R * K * 64];        // side 1 -> side 0 of every replica (66 KB of LDS in all: two workgroups per CU)
   __shared__ float part[R * 2 * 64];
@@ -143,19 +173,6 @@ __global__ __launch_bounds__(128 * R) void objspn_fwd_k(
     const float* tile = xw + (size_t)b * (D * 2 * 64);
     SideState<S, G, K> st;
     side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3, W, st);
-    if (st_save != nullptr) {      // (replica, side) state for the backward: [batch][wave][E1 G | E2 G | acc K | o K][64]
-      float* sp = st_save + ((size_t)b * (R * 2) + wv) * (2 * G + 2 * K) * 64 + lane;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        sp[g * 64] = st.E1[g];
-        sp[(G + g) * 64] = st.E2[g];
-      }
-#pragma unroll
-      for (int s = 0; s < K; ++s) {
-        sp[(2 * G + s) * 64] = st.acc[s];
-        sp[(2 * G + K + s) * 64] = st.o[s];
-      }
-    }
     if (side == 1)
 #pragma unroll
       for (int s = 0; s < K; ++s) xch[(r * K + s) * 64 + lane] = st.o[s];
@@ -171,30 +188,18 @@ __global__ __launch_bounds__(128 * R) void objspn_fwd_k(
         EA[s] = __expf(st.o[s] - mA);
         EB[s] = __expf(oB[s] - mB);
       }
-      const float* wr = wroot + r * K * K;
-      float sr = 0.0f;
-#pragma unroll
-      for (int j2 = 0; j2 < K; ++j2)
-#pragma unroll
-        for (int j1 = 0; j1 < K; ++j1) sr = fmaf(EA[j1] * EB[j2], wr[j2 * K + j1], sr);
       part[(r * 2) * 64 + lane] = mA + mB;
-      part[(r * 2 + 1) * 64 + lane] = sr;
+      part[(r * 2 + 1) * 64 + lane] = root_pair_sum<K>(EA, EB, wroot + r * K * K);
     } else if (wv == 1 && ovl != nullptr) {
-      float s1 = 0.0f;
-      for (int p = 0; p < D; ++p) s1 += 1.0f - tile[(p * 2 + 1) * 64 + lane];
       const int smp = b * 64 + lane;
-      if (smp < n_samples) ovl[smp] = s1 * (1.0f / D);
+      const float v = tile_overlap<D>(tile, lane);
+      if (smp < n_samples) ovl[smp] = v;
     }
     __syncthreads();
     if (wv == 0) {
-      float M = part[lane];
-#pragma unroll
-      for (int q = 1; q < R; ++q) M = fmaxf(M, part[(q * 2) * 64 + lane]);
-      float Z = 0.0f;
-#pragma unroll
-      for (int q = 0; q < R; ++q) Z = fmaf(part[(q * 2 + 1) * 64 + lane], __expf(part[(q * 2) * 64 + lane] - M), Z);
       const int smp = b * 64 + lane;
-      if (smp < n_samples) out[smp] = M + __logf(Z);
+      const float ro = root_value<R>(part, lane);
+      if (smp < n_samples) out[smp] = ro;
     }
     // next iteration overwrites xch only after its own leaf sweep + barrier; part is re-read
     // only by wave 0 before it reaches the next first barrier, so no extra barrier is needed
@@ -313,17 +318,86 @@ __global__ __launch_bounds__(128 * R) void objspn_mpe_k(
 }
 
 // ---- backward (main): recompute forward, back-propagate to the leaf outputs ---------------
-// dout[sample] = dL/d root, out[sample] = root value saved by the forward.
 // Writes   Dscr[batch][r][4][G][64]        dL/d leaf log-densities
 //          Sscr[batch][r*2+side][K+2G][64] gamma[s] = g_s / acc_s, E1[G], E2[G]   (sum-weight grads)
 //          Rscr[batch][r][1+2K][64]        rho_r, EA[K], EB[K]                     (root-weight grads)
+// Everything below a sample's root is LINEAR in its upstream gradient go: rho, gamma and the leaf gradients carry one factor
+// go each, E1 / E2 / EA / EB none.  side_backward is handed rho = go exp(mO + mP - root) and does the rest.
+template <int R, int S, int G, int K>
+__device__ __forceinline__ void side_backward(const SideState<S, G, K>& st, const float (&EO)[K], const float (&EP)[K], float rho,
+                                              int b, int r, int side, int lane, const float* W, const LaneTable<K * K>& WR,
+                                              float* __restrict__ Dscr, float* __restrict__ Sscr, float* __restrict__ Rscr) {
+  // g[s] = dL/d o[s] of this side
+  float g[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) g[s] = 0.0f;
+  if (side == 0) {
+#pragma unroll
+    for (int j2 = 0; j2 < K; ++j2)
+#pragma unroll
+      for (int j1 = 0; j1 < K; ++j1) g[j1] = fmaf(EP[j2], WR.at(j2 * K + j1), g[j1]);
+  } else {
+#pragma unroll
+    for (int j2 = 0; j2 < K; ++j2)
+#pragma unroll
+      for (int j1 = 0; j1 < K; ++j1) g[j2] = fmaf(EP[j1], WR.at(j2 * K + j1), g[j2]);
+  }
+  float gam[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) {
+    g[s] *= rho * EO[s];
+    gam[s] = g[s] / st.acc[s];
+  }
+  float d1[G], d2[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) d1[j] = d2[j] = 0.0f;
+  v2f gam2[K / 2];
+#pragma unroll
+  for (int s = 0; s < K / 2; ++s) gam2[s] = v2f{gam[2 * s], gam[2 * s + 1]};
+#pragma unroll
+  for (int j2 = 0; j2 < G; ++j2) {
+#pragma unroll
+    for (int j1 = 0; j1 < G; ++j1) {
+      v2f tp = gam2[0] * lds_pair(W, (j2 * G + j1) * K);
+#pragma unroll
+      for (int s = 1; s < K / 2; ++s) tp = pk_fma(gam2[s], lds_pair(W, (j2 * G + j1) * K + 2 * s), tp);
+      const float t = tp.x + tp.y;
+      d1[j1] = fmaf(st.E2[j2], t, d1[j1]);
+      d2[j2] = fmaf(st.E1[j1], t, d2[j2]);
+    }
+  }
+  float* Dp = Dscr + ((size_t)(b * R + r) * 4 + side * 2) * G * 64;
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    Dp[j * 64 + lane] = d1[j] * st.E1[j];
+    Dp[(G + j) * 64 + lane] = d2[j] * st.E2[j];
+  }
+  float* Sp = Sscr + (size_t)(b * R * 2 + r * 2 + side) * (K + 2 * G) * 64;
+#pragma unroll
+  for (int s = 0; s < K; ++s) Sp[s * 64 + lane] = gam[s];
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    Sp[(K + j) * 64 + lane] = st.E1[j];
+    Sp[(K + G + j) * 64 + lane] = st.E2[j];
+  }
+  if (side == 0) {
+    float* Rp = Rscr + (size_t)(b * R + r) * (1 + 2 * K) * 64;
+    Rp[lane] = rho;
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      Rp[(1 + s) * 64 + lane] = EO[s];
+      Rp[(1 + K + s) * 64 + lane] = EP[s];
+    }
+  }
+}
+
+// dout[sample] = dL/d root, out[sample] = root value saved by the forward.
 template <int R, int S, int G, int K>
 __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
     const float* __restrict__ xw, const int* __restrict__ scope, const float* __restrict__ coef,
     const float* __restrict__ wsum, const float* __restrict__ wroot,
     const float* __restrict__ out, const float* __restrict__ dout,
-    float* __restrict__ Dscr, float* __restrict__ Sscr, float* __restrict__ Rscr, int n_samples, int n_batches,
-    const float* __restrict__ st_save) {
+    float* __restrict__ Dscr, float* __restrict__ Sscr, float* __restrict__ Rscr, int n_samples, int n_batches) {
   constexpr int D = 4 * S;
   __shared__ float xch[R * 2 * K * 64];
   const int lane = lane_id();
@@ -337,21 +411,7 @@ __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
   for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
     const float* tile = xw + (size_t)b * (D * 2 * 64);
     SideState<S, G, K> st;
-    if (st_save != nullptr) {      // written by objspn_fwd_k: 10 KB per wave instead of re-running leaves + sum node
-      const float* sp = st_save + ((size_t)b * (R * 2) + wv) * (2 * G + 2 * K) * 64 + lane;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        st.E1[g] = sp[g * 64];
-        st.E2[g] = sp[(G + g) * 64];
-      }
-#pragma unroll
-      for (int s = 0; s < K; ++s) {
-        st.acc[s] = sp[(2 * G + s) * 64];
-        st.o[s] = sp[(2 * G + K + s) * 64];
-      }
-    } else {
-      side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3, W, st);
-    }
+    side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3, W, st);
 #pragma unroll
     for (int s = 0; s < K; ++s) xch[((r * 2 + side) * K + s) * 64 + lane] = st.o[s];
     __syncthreads();
@@ -367,72 +427,68 @@ __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
     }
     const int smp = b * 64 + lane;
     const bool live = smp < n_samples;
-    const float go = live ? dout[smp] : 0.0f;
-    const float ro = live ? out[smp] : 0.0f;
-    const float rho = go * __expf(mO + mP - ro);
-    // g[s] = dL/d o[s] of this side
-    float g[K];
+    const float rho = live ? dout[smp] * __expf(mO + mP - out[smp]) : 0.0f;
+    side_backward<R, S, G, K>(st, EO, EP, rho, b, r, side, lane, W, WR, Dscr, Sscr, Rscr);
+    __syncthreads();   // xch reuse
+  }
+}
+
+// ---- forward + backward at UNIT upstream gradient in one pass (the training path of the scene likelihood) ----------------
+// The root value is formed inside the workgroup, so the backward of a sample can follow its forward while the leaf
+// exponentials and the sum-node accumulators are still in registers: no forward-state dump (1 920 B per glimpse written and
+// read back), no second sweep over the tile, one launch less on the step's critical path.  What the upstream gradient will
+// be is not known yet -- it does not have to be: Dscr / gamma / rho are written for go = 1 and their consumers
+// (scene_pixtile_bwd_k, objspn_tablegrad*_k) multiply by go[sample] while they stage them.  `out` is computed by the same
+// code as objspn_fwd_k's: bit-identical between the two.
+template <int R, int S, int G, int K>
+__global__ __launch_bounds__(128 * R) void objspn_fwd_unit_k(
+    const float* __restrict__ xw, const int* __restrict__ scope, const float* __restrict__ coef,
+    const float* __restrict__ wsum, const float* __restrict__ wroot,
+    float* __restrict__ out, float* __restrict__ ovl,
+    float* __restrict__ Dscr, float* __restrict__ Sscr, float* __restrict__ Rscr, int n_samples, int n_batches) {
+  constexpr int D = 4 * S;
+  __shared__ float xch[R * 2 * K * 64];
+  __shared__ float part[R * 2 * 64];
+  __shared__ __attribute__((aligned(16))) float wtab[R * 2][G * G * K];
+  const int lane = lane_id();
+  const int wv = wave_id();
+  const int r = wv >> 1, side = wv & 1;
+  const float* W = wtab[wv];
+  lds_table_load<G * G * K>(wtab[wv], wsum + (size_t)(r * 2 + side) * G * G * K, lane);
+  LaneTable<K * K> WR;
+  WR.load(wroot + r * K * K, lane);
+  for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
+    const float* tile = xw + (size_t)b * (D * 2 * 64);
+    SideState<S, G, K> st;
+    side_forward<S, G, K>(tile, lane, scope + (r * 4 + side * 2) * S, coef + (size_t)(r * 4 + side * 2) * S * G * 3, W, st);
 #pragma unroll
-    for (int s = 0; s < K; ++s) g[s] = 0.0f;
-    if (side == 0) {
+    for (int s = 0; s < K; ++s) xch[((r * 2 + side) * K + s) * 64 + lane] = st.o[s];
+    __syncthreads();
+    float oP[K];
 #pragma unroll
-      for (int j2 = 0; j2 < K; ++j2)
-#pragma unroll
-        for (int j1 = 0; j1 < K; ++j1) g[j1] = fmaf(EP[j2], WR.at(j2 * K + j1), g[j1]);
-    } else {
-#pragma unroll
-      for (int j2 = 0; j2 < K; ++j2)
-#pragma unroll
-        for (int j1 = 0; j1 < K; ++j1) g[j2] = fmaf(EP[j1], WR.at(j2 * K + j1), g[j2]);
-    }
-    float gam[K];
+    for (int s = 0; s < K; ++s) oP[s] = xch[((r * 2 + (1 - side)) * K + s) * 64 + lane];
+    const float mO = vmax<K>(st.o), mP = vmax<K>(oP);
+    float EO[K], EP[K];   // own side, partner side
 #pragma unroll
     for (int s = 0; s < K; ++s) {
-      g[s] *= rho * EO[s];
-      gam[s] = g[s] / st.acc[s];
+      EO[s] = __expf(st.o[s] - mO);
+      EP[s] = __expf(oP[s] - mP);
     }
-    float d1[G], d2[G];
-#pragma unroll
-    for (int j = 0; j < G; ++j) d1[j] = d2[j] = 0.0f;
-    v2f gam2[K / 2];
-#pragma unroll
-    for (int s = 0; s < K / 2; ++s) gam2[s] = v2f{gam[2 * s], gam[2 * s + 1]};
-#pragma unroll
-    for (int j2 = 0; j2 < G; ++j2) {
-#pragma unroll
-      for (int j1 = 0; j1 < G; ++j1) {
-        v2f tp = gam2[0] * lds_pair(W, (j2 * G + j1) * K);
-#pragma unroll
-        for (int s = 1; s < K / 2; ++s) tp = pk_fma(gam2[s], lds_pair(W, (j2 * G + j1) * K + 2 * s), tp);
-        const float t = tp.x + tp.y;
-        d1[j1] = fmaf(st.E2[j2], t, d1[j1]);
-        d2[j2] = fmaf(st.E1[j1], t, d2[j2]);
-      }
-    }
-    float* Dp = Dscr + ((size_t)(b * R + r) * 4 + side * 2) * G * 64;
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-      Dp[j * 64 + lane] = d1[j] * st.E1[j];
-      Dp[(G + j) * 64 + lane] = d2[j] * st.E2[j];
-    }
-    float* Sp = Sscr + (size_t)(b * R * 2 + r * 2 + side) * (K + 2 * G) * 64;
-#pragma unroll
-    for (int s = 0; s < K; ++s) Sp[s * 64 + lane] = gam[s];
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-      Sp[(K + j) * 64 + lane] = st.E1[j];
-      Sp[(K + G + j) * 64 + lane] = st.E2[j];
-    }
+    const int smp = b * 64 + lane;
+    const bool live = smp < n_samples;
     if (side == 0) {
-      float* Rp = Rscr + (size_t)(b * R + r) * (1 + 2 * K) * 64;
-      Rp[lane] = rho;
-#pragma unroll
-      for (int s = 0; s < K; ++s) {
-        Rp[(1 + s) * 64 + lane] = EO[s];
-        Rp[(1 + K + s) * 64 + lane] = EP[s];
-      }
+      part[(r * 2) * 64 + lane] = mO + mP;
+      part[(r * 2 + 1) * 64 + lane] = root_pair_sum<K>(EO, EP, wroot + r * K * K);
+    } else if (wv == 1 && ovl != nullptr) {
+      const float v = tile_overlap<D>(tile, lane);
+      if (live) ovl[smp] = v;
     }
-    __syncthreads();   // xch reuse
+    __syncthreads();      // (also orders this batch's xch reads before the next batch's xch writes)
+    const float ro = root_value<R>(part, lane);       // every wave for itself: the same arithmetic as wave 0's, no third barrier
+    if (wv == 0 && live) out[smp] = ro;
+    const float rho = live ? __expf(mO + mP - ro) : 0.0f;
+    side_backward<R, S, G, K>(st, EO, EP, rho, b, r, side, lane, W, WR, Dscr, Sscr, Rscr);
+    // part: rewritten only after the next batch's first barrier, which every wave reaches after it has read part here
   }
 }
 
@@ -482,6 +538,30 @@ __global__ __launch_bounds__(64 * SLOTS) void objspn_pix_k(
 
 
 
+// The scratch of objspn_fwd_unit_k is written for an upstream gradient of 1: the factor go[sample] that its three linear
+// pieces (leaf gradients, gamma, rho) still lack is applied here.  For the leaf-coefficient products it goes onto the OTHER
+// operand: all three features (w x^2, w x, w) are linear in the pixel's w, so the w rows of the staged tile are multiplied
+// by go[sample] once per batch; gamma and rho take it as they are fetched.  scale == nullptr: the scratch already carries
+// it (objspn_bwd_k).  `scale` holds a multiple of 64 entries, zeros beyond the last sample.
+__device__ __forceinline__ float4 tg_scale4(const float* __restrict__ scale, int first) {
+  return scale == nullptr ? float4{1.0f, 1.0f, 1.0f, 1.0f} : *reinterpret_cast<const float4*>(scale + first);
+}
+// stage the batch's glimpse tile as [2 D rows][LD]; NT = threads of the workgroup (a multiple of 32: a thread keeps its
+// four samples and its row parity over the whole copy)
+template <int D, int LD, int NT>
+__device__ __forceinline__ void tg_stage_tile(float* tileP, const float* __restrict__ xw_b, const float* __restrict__ scale,
+                                              int first_sample) {
+  static_assert(NT % 32 == 0, "row parity and sample slot per thread");
+  const float4* src = reinterpret_cast<const float4*>(xw_b);
+  const bool wrow = ((threadIdx.x >> 4) & 1) != 0;
+  const float4 sc = wrow ? tg_scale4(scale, first_sample + 4 * (threadIdx.x & 15)) : float4{1.0f, 1.0f, 1.0f, 1.0f};
+  for (int i = threadIdx.x; i < 2 * D * 16; i += NT) {
+    float4 v = src[i];
+    v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+    *reinterpret_cast<float4*>(tileP + (i >> 4) * LD + 4 * (i & 15)) = v;
+  }
+}
+
 // ---- backward (all table gradients) on the matrix cores ------------------------------------------------------------
 // The three table gradients are sums over the samples of outer products,
 //     d coef[r][L][i][g][c] = sum_s  f_c(x, w)[pixel(r, L, i)][s] * dl[r][L][g][s]          f = (w x^2, w x, w)
@@ -503,7 +583,7 @@ template <int R, int S, int G, int K>
 __global__ __launch_bounds__(128 * R) void objspn_tablegrad_k(
     const float* __restrict__ xw, const float* __restrict__ Dscr, const float* __restrict__ Sscr, const float* __restrict__ Rscr,
     const int* __restrict__ scope, float* __restrict__ part_c, float* __restrict__ part_w, float* __restrict__ part_r,
-    int n_batches, int n_chunks) {
+    int n_batches, int n_chunks, const float* __restrict__ scale) {
   constexpr int D = 4 * S, LD = 68, NS = K + 2 * G;
   constexpr int TC = (3 * S + 15) / 16, TW = (G * G + 15) / 16;       // 5 coefficient tiles per leaf, 7 sum-weight tiles
   static_assert(G <= 16 && K <= 16, "one column tile");
@@ -543,9 +623,7 @@ __global__ __launch_bounds__(128 * R) void objspn_tablegrad_k(
 
   for (int b = c; b < n_batches; b += n_chunks) {
     {   // stage the tile (all waves) and the wave's own sum-node scratch
-      const float4* src = reinterpret_cast<const float4*>(xw + (size_t)b * (D * 2 * 64));
-      for (int i = threadIdx.x; i < 2 * D * 16; i += 128 * R)
-        *reinterpret_cast<float4*>(tileP + (i >> 4) * LD + 4 * (i & 15)) = src[i];
+      tg_stage_tile<D, LD, 128 * R>(tileP, xw + (size_t)b * (D * 2 * 64), scale, b * 64);
       const float4* ss = reinterpret_cast<const float4*>(Sscr + (size_t)(b * R * 2 + node) * NS * 64);
       float* dst = nodeS + node * NS * LD;
       for (int i = lane; i < NS * 16; i += 64) *reinterpret_cast<float4*>(dst + (i >> 4) * LD + 4 * (i & 15)) = ss[i];
@@ -584,7 +662,8 @@ __global__ __launch_bounds__(128 * R) void objspn_tablegrad_k(
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         const float4 g4 = *reinterpret_cast<const float4*>(gp + 4 * h);
-        gv[4 * h] = g4.x; gv[4 * h + 1] = g4.y; gv[4 * h + 2] = g4.z; gv[4 * h + 3] = g4.w;
+        const float4 s4 = tg_scale4(scale, b * 64 + 16 * kk + 4 * h);
+        gv[4 * h] = g4.x * s4.x; gv[4 * h + 1] = g4.y * s4.y; gv[4 * h + 2] = g4.z * s4.z; gv[4 * h + 3] = g4.w * s4.w;
       }
 #pragma unroll
       for (int t = 0; t < TW; ++t) {
@@ -610,10 +689,11 @@ __global__ __launch_bounds__(128 * R) void objspn_tablegrad_k(
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         const float4 q4 = rho[h], a4 = ea[h], b4 = eb[h];
-        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.x * b4.x, a4.x, acc_r, 0, 0, 0);
-        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.y * b4.y, a4.y, acc_r, 0, 0, 0);
-        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.z * b4.z, a4.z, acc_r, 0, 0, 0);
-        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.w * b4.w, a4.w, acc_r, 0, 0, 0);
+        const float4 s4 = tg_scale4(scale, b * 64 + 16 * kk + 4 * h);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.x * s4.x * b4.x, a4.x, acc_r, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.y * s4.y * b4.y, a4.y, acc_r, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.z * s4.z * b4.z, a4.z, acc_r, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.w * s4.w * b4.w, a4.w, acc_r, 0, 0, 0);
       }
     }
     __syncthreads();      // the LDS images are restaged for the next batch
@@ -662,7 +742,7 @@ template <int R, int S, int G, int K>
 __global__ __launch_bounds__(256, 4) void objspn_tablegrad_under_k(
     const float* __restrict__ xw, const float* __restrict__ Dscr, const float* __restrict__ Sscr, const float* __restrict__ Rscr,
     const int* __restrict__ scope, float* __restrict__ part_c, float* __restrict__ part_w, float* __restrict__ part_r,
-    int n_batches, int n_chunks) {
+    int n_batches, int n_chunks, const float* __restrict__ scale) {
   constexpr int D = 4 * S, LD = 68, NS = K + 2 * G;
   constexpr int TC = (3 * S + 15) / 16, TW = (G * G + 15) / 16, TWH = (TW + 1) / 2;
   static_assert(G <= 16 && K <= 16, "one column tile");
@@ -706,11 +786,7 @@ __global__ __launch_bounds__(256, 4) void objspn_tablegrad_under_k(
   for (int i = 0; i < TWH; ++i) acc_w[i] = f4{0.0f, 0.0f, 0.0f, 0.0f};
 
   for (int b = c; b < n_batches; b += n_chunks) {
-    {
-      const float4* src = reinterpret_cast<const float4*>(xw + (size_t)b * (D * 2 * 64));
-      for (int i = threadIdx.x; i < 2 * D * 16; i += 256)
-        *reinterpret_cast<float4*>(tileP + (i >> 4) * LD + 4 * (i & 15)) = src[i];
-    }
+    tg_stage_tile<D, LD, 256>(tileP, xw + (size_t)b * (D * 2 * 64), scale, b * 64);
     __syncthreads();
     // ---- leaf coefficients of leaf L: A = features of its pixels, B = its gradients
     {
@@ -742,14 +818,11 @@ __global__ __launch_bounds__(256, 4) void objspn_tablegrad_under_k(
     {
       const float* nb = Sscr + (size_t)(b * R * 2 + node) * NS * 64 + 16 * kk;
       const float* gp = nb + min(rr, K - 1) * 64;
-      float gv[16];
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         const float4 g4 = *reinterpret_cast<const float4*>(gp + 4 * h);
-        gv[4 * h] = g4.x; gv[4 * h + 1] = g4.y; gv[4 * h + 2] = g4.z; gv[4 * h + 3] = g4.w;
-      }
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
+        const float4 s4 = tg_scale4(scale, b * 64 + 16 * kk + 4 * h);
+        const float gv[4] = {g4.x * s4.x, g4.y * s4.y, g4.z * s4.z, g4.w * s4.w};
         float pr[TWH][4];
 #pragma unroll
         for (int i = 0; i < TWH; ++i) {
@@ -761,7 +834,7 @@ __global__ __launch_bounds__(256, 4) void objspn_tablegrad_under_k(
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int i = 0; i < TWH; ++i)      // (tile 7 of half 1 does not exist: its products are computed and never stored)
-            acc_w[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[i][e], gv[4 * h + e], acc_w[i], 0, 0, 0);
+            acc_w[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[i][e], gv[e], acc_w[i], 0, 0, 0);
       }
     }
     // ---- root weights of the replica (side 0, half 1): A = rho EB[j2], B = EA[j1]
@@ -773,10 +846,11 @@ __global__ __launch_bounds__(256, 4) void objspn_tablegrad_under_k(
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         const float4 q4 = rho[h], a4 = ea[h], b4 = eb[h];
-        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.x * b4.x, a4.x, acc_r, 0, 0, 0);
-        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.y * b4.y, a4.y, acc_r, 0, 0, 0);
-        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.z * b4.z, a4.z, acc_r, 0, 0, 0);
-        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.w * b4.w, a4.w, acc_r, 0, 0, 0);
+        const float4 s4 = tg_scale4(scale, b * 64 + 16 * kk + 4 * h);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.x * s4.x * b4.x, a4.x, acc_r, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.y * s4.y * b4.y, a4.y, acc_r, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.z * s4.z * b4.z, a4.z, acc_r, 0, 0, 0);
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.w * s4.w * b4.w, a4.w, acc_r, 0, 0, 0);
       }
     }
     __syncthreads();      // the LDS images are restaged for the next batch
@@ -911,15 +985,12 @@ int objspn_tile_to_arrays(const float* dxw, const float* marg, float* d_inputs, 
   return 0;
 }
 
-// floats of the optional forward-state dump (per 64-sample batch: 12 waves x 40 values x 64 lanes)
-size_t objspn_state_floats(int n) { return (size_t)((n + 63) / 64) * 12 * 40 * 64; }
-
 int objspn_forward(const float* xw, const int* scope, const float* coef, const float* wsum, const float* wroot,
-                   float* out, float* ovl, int n, hipStream_t st, float* st_save = nullptr) {
+                   float* out, float* ovl, int n, hipStream_t st) {
   const int nb = (n + 63) / 64;
   if (nb == 0) return 0;
   STOVE_LAUNCH((objspn_fwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
-                     xw, scope, coef, wsum, wroot, out, ovl, n, nb, st_save);
+                     xw, scope, coef, wsum, wroot, out, ovl, n, nb);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -939,26 +1010,38 @@ constexpr size_t kObjD = 6 * 4 * 10 * 64, kObjS = 12 * 30 * 64, kObjR = 6 * 21 *
 constexpr int kObjChunks = 256;        // one workgroup of the table-gradient kernel per CU
 constexpr size_t kObjCoefN = 6 * 100 * 10 * 3, kObjWN = 12 * 100 * 10, kObjRootN = 6 * 100;
 
-size_t objspn_bwd_ws_floats(int n) {
-  const size_t nb = (n + 63) / 64;
-  return nb * (kObjD + kObjS + kObjR) + (size_t)kObjChunks * (kObjCoefN + kObjWN + kObjRootN);
+// per-sample scratch of the backward (leaf gradients, gamma | E1 | E2, rho | EA | EB) and the chunk partials of the table gradients
+size_t objspn_scratch_floats(int n) { return (size_t)((n + 63) / 64) * (kObjD + kObjS + kObjR); }
+size_t objspn_partial_floats() { return (size_t)kObjChunks * (kObjCoefN + kObjWN + kObjRootN); }
+size_t objspn_bwd_ws_floats(int n) { return objspn_scratch_floats(n) + objspn_partial_floats(); }
+
+// forward that also leaves the backward's per-sample scratch behind, for an upstream gradient of 1 (objspn_fwd_unit_k)
+int objspn_forward_unit(const float* xw, const int* scope, const float* coef, const float* wsum, const float* wroot,
+                        float* out, float* ovl, float* scratch, int n, hipStream_t st) {
+  const int nb = (n + 63) / 64;
+  if (nb == 0) return 0;
+  float* Dscr = scratch;
+  float* Sscr = Dscr + (size_t)nb * kObjD;
+  float* Rscr = Sscr + (size_t)nb * kObjS;
+  STOVE_LAUNCH((objspn_fwd_unit_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
+                     xw, scope, coef, wsum, wroot, out, ovl, Dscr, Sscr, Rscr, n, nb);
+  STOVE_LAUNCH_CHECK();
+  return 0;
 }
 
 // dxw: [nb][100][2][64] out.  g_coef/g_wsum/g_wroot: gradients w.r.t. the baked tables (overwritten).
 // The backward in two parts: `objspn_backward_data` (leaf gradients + dL/d tile, on `st`) and `objspn_backward_params`
-// (table gradients from the scratch the first part left in `ws`; they only feed the optimiser, so a caller may put them on
+// (table gradients from the per-sample scratch; they only feed the optimiser, so a caller may put them on
 // another stream, ordered after the data part, where they overlap with whatever runs on `st` next).
 int objspn_backward_data(const float* xw, const int* scope, const int* leaf_slot, const float* coef, const float* wsum,
-                         const float* wroot, const float* out, const float* dout, float* dxw, float* ws, int n, hipStream_t st,
-                         const float* st_save = nullptr) {      // dxw == nullptr: leaf gradients only (the scene path forms
-                                                                // dL/d tile inside scene_pixtile_bwd_k, csrc/scene_fused.hip)
+                         const float* wroot, const float* out, const float* dout, float* dxw, float* scratch, int n, hipStream_t st) {
   const int nb = (n + 63) / 64;
   if (nb == 0) return 0;
-  float* Dscr = ws;
+  float* Dscr = scratch;
   float* Sscr = Dscr + (size_t)nb * kObjD;
   float* Rscr = Sscr + (size_t)nb * kObjS;
   STOVE_LAUNCH((objspn_bwd_k<6, 25, 10, 10>), dim3(grid_for(nb, 4096)), dim3(768), 0, st,
-                     xw, scope, coef, wsum, wroot, out, dout, Dscr, Sscr, Rscr, n, nb, st_save);
+                     xw, scope, coef, wsum, wroot, out, dout, Dscr, Sscr, Rscr, n, nb);
   STOVE_LAUNCH_CHECK();
   if (dxw == nullptr) return 0;
   STOVE_LAUNCH((objspn_pix_k<6, 25, 10, 8>), dim3(grid_for(nb, 4096)), dim3(512), 0, st,
@@ -967,8 +1050,10 @@ int objspn_backward_data(const float* xw, const int* scope, const int* leaf_slot
   return 0;
 }
 
-int objspn_backward_params(const float* xw, const int* scope, float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n,
-                           hipStream_t st, bool under = false) {
+// scratch: objspn_scratch_floats(n) from objspn_backward_data (scale == nullptr) or from objspn_forward_unit (scale = the
+// upstream gradient per sample: a multiple of 64 floats, zeros beyond sample n); partial: objspn_partial_floats()
+int objspn_backward_params(const float* xw, const int* scope, float* g_coef, float* g_wsum, float* g_wroot, const float* scratch,
+                           float* partial, const float* scale, int n, hipStream_t st, bool under = false) {
   const int nb = (n + 63) / 64;
   if (nb == 0) {
     hipMemsetAsync(g_coef, 0, kObjCoefN * 4, st);
@@ -976,10 +1061,10 @@ int objspn_backward_params(const float* xw, const int* scope, float* g_coef, flo
     hipMemsetAsync(g_wroot, 0, kObjRootN * 4, st);
     return 0;
   }
-  float* Dscr = ws;
-  float* Sscr = Dscr + (size_t)nb * kObjD;
-  float* Rscr = Sscr + (size_t)nb * kObjS;
-  float* pc = Rscr + (size_t)nb * kObjR;
+  const float* Dscr = scratch;
+  const float* Sscr = Dscr + (size_t)nb * kObjD;
+  const float* Rscr = Sscr + (size_t)nb * kObjS;
+  float* pc = partial;
   float* pw = pc + (size_t)kObjChunks * kObjCoefN;
   float* pr = pw + (size_t)kObjChunks * kObjWN;
   int chunks = nb < kObjChunks ? nb : kObjChunks;
@@ -989,13 +1074,13 @@ int objspn_backward_params(const float* xw, const int* scope, float* g_coef, flo
     if (chunks > kObjChunks / 6) chunks = (kObjChunks / 6) & ~7;      // 40: a multiple of 8 (XCD-aware placement), 240 workgroups
     int rc = (int)hipFuncSetAttribute((const void*)objspn_tablegrad_under_k<6, 25, 10, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, kTgLdsU);
     if (rc) return rc;
-    STOVE_LAUNCH((objspn_tablegrad_under_k<6, 25, 10, 10>), dim3(chunks * 6), dim3(256), kTgLdsU, st, xw, Dscr, Sscr, Rscr, scope, pc, pw, pr, nb, chunks);
+    STOVE_LAUNCH((objspn_tablegrad_under_k<6, 25, 10, 10>), dim3(chunks * 6), dim3(256), kTgLdsU, st, xw, Dscr, Sscr, Rscr, scope, pc, pw, pr, nb, chunks, scale);
     STOVE_LAUNCH_CHECK();
   } else {
     constexpr int kTgLds = (2 * 100 * 68 + 12 * 30 * 68) * (int)sizeof(float);
     int rc = (int)hipFuncSetAttribute((const void*)objspn_tablegrad_k<6, 25, 10, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, kTgLds);
     if (rc) return rc;
-    STOVE_LAUNCH((objspn_tablegrad_k<6, 25, 10, 10>), dim3(chunks), dim3(768), kTgLds, st, xw, Dscr, Sscr, Rscr, scope, pc, pw, pr, nb, chunks);
+    STOVE_LAUNCH((objspn_tablegrad_k<6, 25, 10, 10>), dim3(chunks), dim3(768), kTgLds, st, xw, Dscr, Sscr, Rscr, scope, pc, pw, pr, nb, chunks, scale);
     STOVE_LAUNCH_CHECK();
   }
   STOVE_LAUNCH(reduce_chunks_k, dim3((kObjCoefN + 31) / 32), dim3(256), 0, st, pc, g_coef, (int)kObjCoefN, chunks, 0);
@@ -1005,12 +1090,13 @@ int objspn_backward_params(const float* xw, const int* scope, float* g_coef, flo
   return 0;
 }
 
+// ws: objspn_bwd_ws_floats(n) = [ per-sample scratch | chunk partials ]
 int objspn_backward(const float* xw, const int* scope, const int* leaf_slot, const float* coef, const float* wsum,
                     const float* wroot, const float* out, const float* dout, float* dxw,
-                    float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n, hipStream_t st, const float* st_save = nullptr) {
-  int rc = objspn_backward_data(xw, scope, leaf_slot, coef, wsum, wroot, out, dout, dxw, ws, n, st, st_save);
+                    float* g_coef, float* g_wsum, float* g_wroot, float* ws, int n, hipStream_t st) {
+  int rc = objspn_backward_data(xw, scope, leaf_slot, coef, wsum, wroot, out, dout, dxw, ws, n, st);
   if (rc) return rc;
-  return objspn_backward_params(xw, scope, g_coef, g_wsum, g_wroot, ws, n, st);
+  return objspn_backward_params(xw, scope, g_coef, g_wsum, g_wroot, ws, ws + objspn_scratch_floats(n), nullptr, n, st);
 }
 
 }  // namespace stove

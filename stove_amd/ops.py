@@ -180,7 +180,7 @@ class _SceneFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, frames, z, obj_coef, obj_wsum, obj_wroot, bg_coef, bg_wroot,
-                obj_scope, obj_leaf_slot, bg_side, n_obj, beta, sink=None, bg_dense=None):
+                obj_scope, obj_leaf_slot, bg_side, n_obj, beta, sink=None, bg_dense=None, with_grad=True):
         lib = _lib.load()
         z = _f32(z)
         tabs = [_f32(x) for x in (obj_coef, obj_wsum, obj_wroot, bg_coef, bg_wroot)]
@@ -203,10 +203,13 @@ class _SceneFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             ll = torch.empty(nf, dtype=torch.float32, device=dev)
             parts = torch.empty(nf, 3, dtype=torch.float32, device=dev)
-            saved = torch.empty(lib.stove_scene_saved_floats(nf, n_obj) + 1, dtype=torch.float32, device=dev)
+            # with a backward to come, the object SPN runs forward + backward (at unit upstream gradient) in one pass
+            # (grad mode is off inside a Function's forward: the caller says whether it was on)
+            grad = int(bool(with_grad) and any(ctx.needs_input_grad))
+            saved = torch.empty(lib.stove_scene_fwd_floats(nf, n_obj, grad) + 1, dtype=torch.float32, device=dev)
             t = _tables(obj=(obj_scope, obj_leaf_slot, tabs[0], tabs[1], tabs[2]), bg=(bg_side, tabs[3], tabs[4]), bg_dense=bg_dense)
-            check(lib.stove_scene_fwd(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, float(beta),
-                                      ptr(ll), ptr(parts), ptr(saved), stream()), 'stove_scene_fwd')
+            check(lib.stove_scene_fwd_from(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, float(beta),
+                                           ptr(ll), ptr(parts), ptr(saved), stream(), None, grad), 'stove_scene_fwd_from')
         ctx.save_for_backward(frames, z, *tabs, obj_scope, obj_leaf_slot, bg_side, saved)
         ctx.n_obj, ctx.beta, ctx.sink = n_obj, float(beta), sink
         ctx.set_materialize_grads(False)          # no zero tensors (one fill launch each) for the outputs nothing differentiates
@@ -220,7 +223,7 @@ class _SceneFn(torch.autograd.Function):
         (nf, seq_frames, seq_stride), n_obj = ctx.frame_map, ctx.n_obj
         dev = frames.device
         if dll is None:
-            return (None,) * 14
+            return (None,) * 15
         dll = _f32(dll)
         with torch.cuda.device(dev):
             dz = torch.empty_like(z)
@@ -240,13 +243,13 @@ class _SceneFn(torch.autograd.Function):
                       'stove_scene_bwd_overlap')
                 run_on_side(dev, lambda: ctx.sink(grads), (ws, saved, *grads), after_main=False)     # ordered by the C call above
                 join_side_after_backward(dev)
-                return (None, dz, None, None, None, None, None, None, None, None, None, None, None, None)
+                return (None, dz, None, None, None, None, None, None, None, None, None, None, None, None, None)
             check(lib.stove_scene_bwd(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, ctx.beta,
                                       ptr(saved), ptr(dll), ptr(dz), ctypes.byref(g), ptr(ws), stream()), 'stove_scene_bwd')
         if ctx.sink is not None:               # flat parameter arena: table gradients go straight into the bucket
             ctx.sink(grads)
             grads = [None] * 5
-        return (None, dz, *grads, None, None, None, None, None, None, None)
+        return (None, dz, *grads, None, None, None, None, None, None, None, None)
 
 
 def objspn_apply(inputs, marg, coef, wsum, wroot, scope, leaf_slot):
@@ -300,7 +303,7 @@ def scene_likelihood(frames, z, obj_tabs, bg_tabs, n_obj, beta, sink=None):
     dense = bg_tabs[3] if len(bg_tabs) > 3 else None      # ParamArena: made with the bake, ahead of the scene chain
     if sink is not None and not z.requires_grad and torch.is_grad_enabled():
         z = z.detach().requires_grad_()        # the sink needs the backward to run
-    return _SceneFn.apply(frames, z, oc, ow, orr, bc, bw, osc, ols, bs, int(n_obj), float(beta), sink, dense)
+    return _SceneFn.apply(frames, z, oc, ow, orr, bc, bw, osc, ols, bs, int(n_obj), float(beta), sink, dense, torch.is_grad_enabled())
 
 
 def scene_glimpses(frames, z, n_obj):
@@ -531,7 +534,7 @@ class _InferScoreFn(torch.autograd.Function):
                 zalls.append(torch.empty(nf * N, 4, dtype=torch.float32, device=dev))
                 lls.append(torch.empty(B, f1 - f0, dtype=torch.float32, device=dev))
                 partss.append(torch.empty(B, f1 - f0, 3, dtype=torch.float32, device=dev))
-                saveds.append(torch.empty(lib.stove_scene_saved_floats(nf, N) + 1, dtype=torch.float32, device=dev))
+                saveds.append(torch.empty(lib.stove_scene_fwd_floats(nf, N, int(grad)) + 1, dtype=torch.float32, device=dev))
             for i, ((a, b), (f0, f1)) in enumerate(zip(steps, frames)):
                 check(lib.stove_dynloop_fwd_range(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z), ptr(zdyn),
                                                   ptr(zdstd), ptr(mean), ptr(std), ptr(pred), ptr(act), B, Ts, N, sd, int(cfg['lim_enc']),
@@ -543,7 +546,7 @@ class _InferScoreFn(torch.autograd.Function):
                 check(lib.stove_stream_after(pipe.cuda_stream, main.cuda_stream), 'stove_stream_after')
                 check(lib.stove_scene_fwd_from(ctypes.byref(tab), x.data_ptr() + (1 + f0) * 1024 * 4, ptr(zalls[i]), nf, N, f1 - f0, T,
                                                float(cfg['beta']), ptr(lls[i]), ptr(partss[i]), ptr(saveds[i]), pipe.cuda_stream,
-                                               main.cuda_stream), 'stove_scene_fwd_from')
+                                               main.cuda_stream, int(grad)), 'stove_scene_fwd_from')
             check(lib.stove_stream_after(main.cuda_stream, pipe.cuda_stream), 'stove_stream_after')
             ll = torch.cat(lls, 1) if len(lls) > 1 else lls[0]
             parts = torch.cat(partss, 1) if len(partss) > 1 else partss[0]

@@ -172,6 +172,34 @@ def test_scene_likelihood_vs_oracle_ragged(n_obj):
 
 
 @pytest.mark.parametrize('n_obj', [3, 6])
+def test_scene_forward_with_and_without_the_unit_backward(n_obj):
+    """The training forward runs the object SPN forward + backward at unit upstream gradient in one kernel
+    (objspn_fwd_unit_k, csrc/spn_obj.hip) and leaves the backward scratch in `saved`; without a backward to come the plain
+    forward kernel runs and `saved` is smaller: the likelihood and its parts must be the same bit for bit."""
+    from stove_amd import _lib
+    extra = {'debug_match_objects': 'greedy'} if n_obj != 3 else {}
+    c, structs, params, sup = _supair_pair(n_obj, **extra)
+    g = torch.Generator().manual_seed(23 + n_obj)
+    nb, t = 3, 15                                       # 45 frames: ragged 64-glimpse batches
+    x = (torch.rand(nb, t, 1, 32, 32, generator=g) ** 2).to(DEV)
+    z = torch.zeros(nb * t * n_obj, 4)
+    z[:, 0] = 0.1 + 0.5 * torch.rand(nb * t * n_obj, generator=g)
+    z[:, 1] = z[:, 0] * (0.75 + 0.5 * torch.rand(nb * t * n_obj, generator=g))
+    z[:, 2:] = 1.8 * torch.rand(nb * t * n_obj, 2, generator=g) - 0.9
+    z = z.to(DEV)
+    lib = _lib.load()
+    assert lib.stove_scene_fwd_floats(nb * t, n_obj, 0) < lib.stove_scene_fwd_floats(nb * t, n_obj, 1) == lib.stove_scene_saved_floats(nb * t, n_obj)
+    sup.step_counter = 0
+    lp_g, prop_g = sup.likelihood(x, z.clone().requires_grad_())
+    with torch.no_grad():
+        lp_n, prop_n = sup.likelihood(x, z)
+    assert lp_g.requires_grad and not lp_n.requires_grad
+    assert torch.equal(lp_g.detach(), lp_n)
+    for k in prop_n:
+        assert torch.equal(torch.as_tensor(prop_g[k]).detach(), torch.as_tensor(prop_n[k])), k
+
+
+@pytest.mark.parametrize('n_obj', [3, 6])
 def test_scene_backward_with_parameter_stream(n_obj):
     """stove_scene_bwd_overlap (table gradients on a second stream: for N <= 4 held back and computed by the one-wave-per-SIMD
     objspn_tablegrad_under_k, csrc/spn_obj.hip; the background GEMM's coefficient image handed over, stove_bg_dense) against
