@@ -475,10 +475,14 @@ static int small_bwd_enabled() {
   return v;
 }
 
+// The small-graph recursion (gnn_small*.hip): kernels built for up to four objects (one node row per wave) and for up to six
+// (two).  Five and six objects need its streams-layout backward: with STOVE_SMALL_BWD=0 they stay on the general kernels.
+static bool small_graph(int N) { return N >= 2 && (N <= 4 || (N <= 6 && small_bwd_enabled())); }
+
 size_t stove_dynloop_act_floats(int B, int Ts, int N) {
   const int g = gnn_group_for(B, N);
   const size_t blockwise = (size_t)stove_gnn_blocks(B, N) * Ts * gnn_act_floats(N, g);
-  if (N >= 2 && N <= 4) {
+  if (small_graph(N)) {
     const size_t streams = (size_t)B * sm_act2_floats(N, Ts);
     return streams > blockwise ? streams : blockwise;
   }
@@ -493,7 +497,7 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
                                  pos_var, vel_std, lat_std, 0, Ts, stream);
 }
 
-int stove_dynloop_range_ok(int N) { return (N >= 2 && N <= 4 && small_bwd_enabled()) ? 1 : 0; }
+int stove_dynloop_range_ok(int N) { return (small_graph(N) && small_bwd_enabled()) ? 1 : 0; }
 
 int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                             const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred, float* act,
@@ -501,45 +505,52 @@ int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zss
                             int ts0, int ts1, void* stream) {
   if (B == 0 || Ts == 0) return 0;
   if (ts0 < 0 || ts1 > Ts || ts0 >= ts1) return (int)hipErrorInvalidValue;
-  if ((ts0 != 0 || ts1 != Ts) && !(N >= 2 && N <= 4)) return (int)hipErrorInvalidValue;      // pieces: small-graph kernels only
+  if ((ts0 != 0 || ts1 != Ts) && !small_graph(N)) return (int)hipErrorInvalidValue;      // pieces: small-graph kernels only
   if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && extra == nullptr)) return (int)hipErrorInvalidValue;
   LoopConst kc{pos_var, vel_std, lat_std};
-  if (N <= 4 && N >= 2) {      // small graphs: row-per-wave VALU formulation, two barriers per step (gnn_small.hip)
-    constexpr bool em = true;        // edge chains on the matrix cores (the round-1 all-VALU edge phase, EM = false, is no longer instantiated)
-#define STOVE_LOOP_LAUNCH_N(SAVE_, EM_, ELU_, NT_, STREAMS)                                                                     \
+  if (small_graph(N)) {      // small graphs: (half-)wave-per-node-row formulation, two barriers per step (gnn_small.hip)
+#define STOVE_LOOP_LAUNCH_N(SAVE_, NMX_, ELU_, NT_)                                                                             \
   do {                                                                                                                          \
-    int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_fwd_small_k<SAVE_, EM_, ELU_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)(kSmLdsFloats * sizeof(float)));                                                     \
+    int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_fwd_small_k<SAVE_, NMX_, ELU_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)(SmShape<NMX_>::kLdsFloats * sizeof(float)));                                        \
     if (rc) return rc;                                                                                                          \
-    STOVE_LAUNCH((dyn_loop_fwd_small_k<SAVE_, EM_, ELU_, NT_>), dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream, \
-                 z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, \
-                 g_sm_stamps, ts0, ts1);                                                                                        \
+    STOVE_LAUNCH((dyn_loop_fwd_small_k<SAVE_, NMX_, ELU_, NT_>), dim3(B), dim3(64 * kSmWaves), SmShape<NMX_>::kLdsFloats * sizeof(float), \
+                 (hipStream_t)stream, z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, \
+                 elu, kc, g_sm_stamps, ts0, ts1);                                                                               \
   } while (0)
-#define STOVE_LOOP_LAUNCH_E(SAVE_, EM_, ELU_, STREAMS)                  \
-  do {                                                                  \
-    if (N == 3) STOVE_LOOP_LAUNCH_N(SAVE_, EM_, ELU_, 3, STREAMS);      \
-    else STOVE_LOOP_LAUNCH_N(SAVE_, EM_, ELU_, 0, STREAMS);             \
+#define STOVE_LOOP_LAUNCH_E(SAVE_, ELU_)                          \
+  do {                                                            \
+    if (N == 3) STOVE_LOOP_LAUNCH_N(SAVE_, 4, ELU_, 3);           \
+    else if (N <= 4) STOVE_LOOP_LAUNCH_N(SAVE_, 4, ELU_, 0);      \
+    else if (N == 6) STOVE_LOOP_LAUNCH_N(SAVE_, 6, ELU_, 6);      \
+    else STOVE_LOOP_LAUNCH_N(SAVE_, 6, ELU_, 0);                  \
   } while (0)
-#define STOVE_LOOP_LAUNCH(SAVE_, EM_, STREAMS)                \
-  do {                                                        \
-    if (elu) STOVE_LOOP_LAUNCH_E(SAVE_, EM_, true, STREAMS);  \
-    else STOVE_LOOP_LAUNCH_E(SAVE_, EM_, false, STREAMS);     \
+#define STOVE_LOOP_LAUNCH(SAVE_)                      \
+  do {                                                \
+    if (elu) STOVE_LOOP_LAUNCH_E(SAVE_, true);        \
+    else STOVE_LOOP_LAUNCH_E(SAVE_, false);           \
   } while (0)
-    if (g_sm_stamps != nullptr && act != nullptr && small_bwd_enabled() && em && !elu && N == 3) {      // tools/loop_stamps.py
-      int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_fwd_small_k<2, true, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(kSmLdsFloats * sizeof(float)));
+    if (g_sm_stamps != nullptr && act != nullptr && small_bwd_enabled() && !elu && N == 3) {      // tools/loop_stamps.py
+      int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_fwd_small_k<2, 4, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(SmShape<4>::kLdsFloats * sizeof(float)));
       if (rc) return rc;
-      STOVE_LAUNCH((dyn_loop_fwd_small_k<2, true, false, 3, true>), dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream,
+      STOVE_LAUNCH((dyn_loop_fwd_small_k<2, 4, false, 3, true>), dim3(B), dim3(64 * kSmWaves), SmShape<4>::kLdsFloats * sizeof(float), (hipStream_t)stream,
                    z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps,
                    ts0, ts1);
     } else if (act != nullptr) {
       if (small_bwd_enabled()) {
-        STOVE_LOOP_LAUNCH(2, true, 0);
-      } else {
-        STOVE_LOOP_LAUNCH(1, true, 0);
+        STOVE_LOOP_LAUNCH(2);
+      } else {                        // block-layout activations for the general backward: up to four objects (small_graph)
+        if (elu) {
+          if (N == 3) STOVE_LOOP_LAUNCH_N(1, 4, true, 3);
+          else STOVE_LOOP_LAUNCH_N(1, 4, true, 0);
+        } else {
+          if (N == 3) STOVE_LOOP_LAUNCH_N(1, 4, false, 3);
+          else STOVE_LOOP_LAUNCH_N(1, 4, false, 0);
+        }
       }
     } else {
-      STOVE_LOOP_LAUNCH(0, true, 0);
+      STOVE_LOOP_LAUNCH(0);
     }
 #undef STOVE_LOOP_LAUNCH
 #undef STOVE_LOOP_LAUNCH_E
@@ -568,12 +579,12 @@ int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zss
 
 size_t stove_dynloop_bwd_ws_bytes(int B, int N) { return stove_gnn_bwd_ws_bytes(B, N); }
 
-static bool small_bwd_path(int N, const float* act) { return N >= 2 && N <= 4 && act != nullptr && small_bwd_enabled(); }
+static bool small_bwd_path(int N, const float* act) { return small_graph(N) && act != nullptr && small_bwd_enabled(); }
 
 // workspace of stove_dynloop_bwd for Ts steps: per-workgroup partial weight gradients, plus (small-graph path) the dY streams
 size_t stove_dynloop_bwd_ws_bytes_ts(int B, int Ts, int N) {
   size_t f = stove_gnn_bwd_ws_bytes(B, N) / sizeof(float);
-  if (N >= 2 && N <= 4 && small_bwd_enabled()) f = (size_t)B * kGnnGrads + (size_t)B * sm_dy_floats(N, Ts);
+  if (small_graph(N) && small_bwd_enabled()) f = (size_t)B * kGnnGrads + (size_t)B * sm_dy_floats(N, Ts);
   return f * sizeof(float);
 }
 
@@ -613,33 +624,34 @@ int stove_dynloop_bwd_range(const float* z1, const float* zsup, const float* zss
     // small graphs: T-serial data-gradient chain (gnn_small_bwd.hip), then the weight gradients as a throughput pass
     float* gpart = (float*)ws;
     float* dy = gpart + (size_t)B * kGnnGrads;
-    constexpr bool em = true;        // as stove_dynloop_fwd
     int rc = 0;
-#define STOVE_LOOPB_LAUNCH_H(EM_, ELU_, NT_, HD_)                                                                                               \
+#define STOVE_LOOPB_LAUNCH_H(NMX_, ELU_, NT_, HD_)                                                                                    \
   do {                                                                                                                                \
-    rc = (int)hipFuncSetAttribute((const void*)dyn_loop_bwd_small_k<EM_, ELU_, NT_, HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)(kSmBLdsFloats * sizeof(float)));                                                              \
+    rc = (int)hipFuncSetAttribute((const void*)dyn_loop_bwd_small_k<NMX_, ELU_, NT_, HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)(smb_lds_floats<NMX_>() * sizeof(float)));                                                     \
     if (rc) return rc;                                                                                                                \
-    STOVE_LAUNCH((dyn_loop_bwd_small_k<EM_, ELU_, NT_, HD_>), dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd, eps, \
-                 params, const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim,   \
-                 lim_enc, elu, kc, g_sm_stamps, ts0, ts1, carry);                                                                     \
+    STOVE_LAUNCH((dyn_loop_bwd_small_k<NMX_, ELU_, NT_, HD_>), dim3(B), dim3(64 * kSmWaves), smb_lds_floats<NMX_>() * sizeof(float), st, zsup, \
+                 zsstd, eps, params, const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, \
+                 sin_dim, lim_enc, elu, kc, g_sm_stamps, ts0, ts1, carry);                                                            \
   } while (0)
     const bool head = dz != nullptr && dzdyn != nullptr && dmean != nullptr && dstd != nullptr && dpred == nullptr && sin_dim == 16 && lim_enc == 2;
-#define STOVE_LOOPB_LAUNCH(EM_, ELU_)                                     \
+#define STOVE_LOOPB_LAUNCH(ELU_)                                          \
   do {                                                                    \
-    if (N == 3 && head && EM_) STOVE_LOOPB_LAUNCH_H(EM_, ELU_, 3, EM_);   \
-    else if (N == 3) STOVE_LOOPB_LAUNCH_H(EM_, ELU_, 3, false);           \
-    else STOVE_LOOPB_LAUNCH_H(EM_, ELU_, 0, false);                       \
+    if (N == 3 && head) STOVE_LOOPB_LAUNCH_H(4, ELU_, 3, true);           \
+    else if (N == 3) STOVE_LOOPB_LAUNCH_H(4, ELU_, 3, false);             \
+    else if (N <= 4) STOVE_LOOPB_LAUNCH_H(4, ELU_, 0, false);             \
+    else if (N == 6 && head) STOVE_LOOPB_LAUNCH_H(6, ELU_, 6, true);      \
+    else STOVE_LOOPB_LAUNCH_H(6, ELU_, 0, false);                         \
   } while (0)
-    if (g_sm_stamps != nullptr && em && !elu && N == 3 && head) {       // tools/loop_stamps.py
-      rc = (int)hipFuncSetAttribute((const void*)dyn_loop_bwd_small_k<true, false, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(kSmBLdsFloats * sizeof(float)));
+    if (g_sm_stamps != nullptr && !elu && N == 3 && head) {       // tools/loop_stamps.py
+      rc = (int)hipFuncSetAttribute((const void*)dyn_loop_bwd_small_k<4, false, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(smb_lds_floats<4>() * sizeof(float)));
       if (rc) return rc;
-      STOVE_LAUNCH((dyn_loop_bwd_small_k<true, false, 3, true, true>), dim3(B), dim3(64 * kSmWaves), kSmBLdsFloats * sizeof(float), st, zsup, zsstd,
+      STOVE_LAUNCH((dyn_loop_bwd_small_k<4, false, 3, true, true>), dim3(B), dim3(64 * kSmWaves), smb_lds_floats<4>() * sizeof(float), st, zsup, zsstd,
                    eps, params, const_cast<float*>(act), dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra, dy, B, Ts, N, sin_dim,
                    lim_enc, elu, kc, g_sm_stamps, ts0, ts1, carry);
-    } else if (elu) STOVE_LOOPB_LAUNCH(true, true);
-    else STOVE_LOOPB_LAUNCH(true, false);
+    } else if (elu) STOVE_LOOPB_LAUNCH(true);
+    else STOVE_LOOPB_LAUNCH(false);
 #undef STOVE_LOOPB_LAUNCH
 #undef STOVE_LOOPB_LAUNCH_H
     STOVE_LAUNCH_CHECK();
@@ -682,20 +694,21 @@ int stove_rollout_fwd(const float* z_last, const float* extra, const float* para
   if (B == 0 || num == 0) return 0;
   if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && (extra == nullptr || A < 1))) return (int)hipErrorInvalidValue;
   LoopConst kc{pos_var, vel_std, lat_std};
-  if (N <= 4 && N >= 2) {
+  if (N >= 2 && N <= 6) {
     int rc;
-#define STOVE_ROLL_LAUNCH_N(ELU_, NT_)                                                                                                   \
+#define STOVE_ROLL_LAUNCH_N(NMX_, ELU_, NT_)                                                                                         \
   do {                                                                                                                               \
-    rc = (int)hipFuncSetAttribute((const void*)rollout_fwd_small_k<true, ELU_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                  (int)(kSmLdsFloats * sizeof(float)));                                                              \
+    rc = (int)hipFuncSetAttribute((const void*)rollout_fwd_small_k<NMX_, ELU_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                  (int)(SmShape<NMX_>::kLdsFloats * sizeof(float)));                                                 \
     if (rc) return rc;                                                                                                               \
-    STOVE_LAUNCH((rollout_fwd_small_k<true, ELU_, NT_>), dim3(B), dim3(64 * kSmWaves), kSmLdsFloats * sizeof(float), (hipStream_t)stream, \
+    STOVE_LAUNCH((rollout_fwd_small_k<NMX_, ELU_, NT_>), dim3(B), dim3(64 * kSmWaves), SmShape<NMX_>::kLdsFloats * sizeof(float), (hipStream_t)stream, \
                  z_last, extra, params, z_pred, zstd, pred, B, num, A < 1 ? 1 : A, N, sin_dim, lim_enc, elu, kc);                    \
   } while (0)
-#define STOVE_ROLL_LAUNCH(ELU_)                      \
-  do {                                               \
-    if (N == 3) STOVE_ROLL_LAUNCH_N(ELU_, 3);        \
-    else STOVE_ROLL_LAUNCH_N(ELU_, 0);               \
+#define STOVE_ROLL_LAUNCH(ELU_)                         \
+  do {                                                  \
+    if (N == 3) STOVE_ROLL_LAUNCH_N(4, ELU_, 3);        \
+    else if (N <= 4) STOVE_ROLL_LAUNCH_N(4, ELU_, 0);   \
+    else STOVE_ROLL_LAUNCH_N(6, ELU_, 0);               \
   } while (0)
     if (elu) STOVE_ROLL_LAUNCH(true);
     else STOVE_ROLL_LAUNCH(false);

@@ -1,15 +1,19 @@
-// Small-graph variant of the GNN time loop (N <= 4 objects, one sequence per workgroup), gfx950.
+// Small-graph variant of the GNN time loop (N <= 6 objects, one sequence per workgroup), gfx950.
 //
 // Why a second formulation.  With N = 3 the MFMA path (gnn.hip) fills 3 of the 16 rows of every node tile and
 // 9 of 16 of every edge tile, and -- what actually bounds the T-serial recursion -- every dense layer is a
 // workgroup-wide stage: LDS write, barrier, LDS read, MFMA chain, epilogue; 11 such stages per step.  But the
 // node MLPs (encoder, self-dynamics, affector, output) act on every node row independently, and the edge MLPs
 // on every edge independently; rows only mix at the edge gather and at the aggregation.  So here
-//   * one WAVE owns one node row for the whole step (and 1-3 edges in the edge phase);
-//   * a 32-wide activation vector lives in ONE VGPR (lane k holds x[k]); a dense layer sends it through a per-wave
+//   * one WAVE owns one node row for the whole step -- or two, one per HALF-wave, in the kernels built for five or six
+//     objects (the node layers are 32 wide: the second half-wave, which otherwise mirrors the first, carries row wave + 4
+//     through the same instructions);
+//   * a 32-wide activation vector lives in ONE VGPR (lane k of the half holds x[k]); a dense layer sends it through a per-wave
 //     LDS scratch, reads it back as 8 broadcast float4 and runs 16 v_pk_fma_f32 against the lane's weight row, which
 //     streams from LDS as float4 ([K/4][OUT][4] layout, conflict-free) one layer ahead; layers chain inside the
 //     wave with no workgroup barrier (a first version broadcast x with 32 v_readlane per layer: 391 vs 255 cycles);
+//   * the edge MLPs and the self-dynamics run on the matrix cores with the edges (nodes) as the 16 columns of an MFMA chain,
+//     one chain per wave (sm_edge_phase_mfma); 30 edges (N = 6) are two column tiles through the same weights;
 //   * the workgroup synchronises exactly twice per step (before the edge phase, before the aggregation).
 // All forward weights (90 KB) sit in LDS for the whole launch.
 // The kernel writes the same saved-activation block as dyn_loop_fwd_k, so dyn_loop_bwd_k consumes it unchanged.
@@ -19,20 +23,29 @@ namespace stove {
 
 constexpr int kSmW = W_END;                                   // [layer][K/4][OUT][4]
 constexpr int kSmWaves = 4;     // waves per workgroup; more than 4 halves the register budget (2 waves per SIMD) and the kernels spill
-constexpr int kSmLdsFloats = kSmW + V_END + 4 * 256 + 16 + kSmWaves * 128 + 16 * 32 + 16;
+
+// A kernel is built for up to NMX objects: 4 (one node row per wave, one tile of edge columns) or 6 (two rows per wave, two tiles)
+template <int NMX>
+struct SmShape {
+  static_assert(NMX == 4 || NMX == 6, "built for up to four or up to six objects");
+  static constexpr int RP = NMX > 4 ? 2 : 1;                        // node rows per wave
+  static constexpr int ET = (NMX * (NMX - 1) + 15) / 16;            // 16-column tiles of the edge chains
+  static constexpr int NE = NMX * NMX;                              // edge rows i N + j of the LDS exchange buffers
+  static constexpr int kLdsFloats = kSmW + V_END + NMX * 256 + NMX * 4 + NE * 32 + ((NE + 3) & ~3);
+};
 
 struct SmLds {
-  float *W, *V, *PR, *POS, *X1, *R3, *ATT;
+  float *W, *V, *PR, *POS, *R3, *ATT;
 };
+template <int NMX>
 __device__ __forceinline__ SmLds sm_carve(float* base) {
   SmLds L;
   L.W = base;
   L.V = L.W + kSmW;
-  L.PR = L.V + V_END;        // [4][256]  W_a s_i | W_b s_j | A_a s_i | A_b s_j of every node
-  L.POS = L.PR + 4 * 256;    // [4][4]    encoder outputs 0, 1 (the positions the distances use)
-  L.X1 = L.POS + 16;         // [waves][R1 act 64 | A1 act 64] of the edge a wave is working on
-  L.R3 = L.X1 + kSmWaves * 128;     // [16][32]  relation outputs by edge row i*N + j
-  L.ATT = L.R3 + 16 * 32;    // [16]
+  L.PR = L.V + V_END;        // [NMX][256]  W_a s_i | W_b s_j | A_a s_i | A_b s_j of every node
+  L.POS = L.PR + NMX * 256;  // [NMX][4]    encoder outputs 0, 1 (the positions the distances use)
+  L.R3 = L.POS + NMX * 4;    // [NMX^2][32] relation outputs by edge row i*N + j
+  L.ATT = L.R3 + SmShape<NMX>::NE * 32;    // [NMX^2]
   return L;
 }
 
@@ -46,27 +59,8 @@ __device__ __forceinline__ void sm_setup(const SmLds& L, const float* __restrict
 
 struct SmCfg {
   int N, sin_dim, lim_enc, elu;
-  int ne;                // edges of this wave (<= 3), ei/ej their node rows -- constant over the time loop
-  int ei[3], ej[3], eq[3];     // eq: index q of the edge (row in the compact saved streams)
   long long* stamps;     // debug: [4 waves][16] cycle stamps of workgroup 0 (normally null)
 };
-// edges (i -> j, i != j) q = 0 .. N(N-1)-1 are dealt out round-robin from the LAST wave down: the waves without a node
-// row (waves N .. kSmWaves-1) get theirs first, so with N = 3 all six edges run concurrently, one per wave
-__device__ __forceinline__ void sm_edges(SmCfg& cf) {
-  const int wv = wave_id();
-  cf.ne = 0;
-  for (int k = 0; k < 3; ++k) {
-    const int q = kSmWaves - 1 - wv + kSmWaves * k;
-    cf.ei[k] = cf.ej[k] = 0;
-    cf.eq[k] = q;
-    if (q < cf.N * (cf.N - 1)) {
-      const int i = q / (cf.N - 1), jj = q % (cf.N - 1);
-      cf.ei[k] = i;
-      cf.ej[k] = jj + (jj >= i ? 1 : 0);
-      cf.ne = k + 1;
-    }
-  }
-}
 __device__ __forceinline__ void sm_stamp(const SmCfg& cf, int k) {
   if (cf.stamps != nullptr && blockIdx.x == 0 && lane_id() == 0) cf.stamps[wave_id() * 16 + k] = (long long)__builtin_readcyclecounter();
 }
@@ -139,11 +133,14 @@ __device__ __forceinline__ SmW<K4> sm_wload(const float* Wl, int OUT, int o, int
 // float4 reads (every lane reads the same address: one LDS pass), then K/2 packed FMAs on four independent chains.
 // Measured per 32 x 32 layer on one wave per SIMD (tools/ubench/dot_variants.hip): 255 cycles, against 391 for
 // 32 v_readlane feeding the FMAs through SGPRs (every FMA then waits on the SGPR its readlane has just written).
+// Each HALF-wave is a row of its own: lane k of the half holds x[k], lane o gets y[o] of its half's row (both halves use the
+// same weight rows W[o]).  With one node row per wave the upper half mirrors the lower one and computes the same numbers.
 template <int K4>
 __device__ __forceinline__ float sm_dotw(const SmW<K4>& W, float x) {
-  __shared__ __attribute__((aligned(16))) float xb[kSmWaves][32];
+  __shared__ __attribute__((aligned(16))) float xb[kSmWaves][64];
   float* p = xb[wave_id()];
-  if (lane_id() < 32) p[lane_id()] = x;        // x[k] is lane k's value (the upper half-wave may hold something else)
+  p[lane_id()] = x;
+  p += lane_id() & 32;
   float4 xv[K4];
 #pragma unroll
   for (int k4 = 0; k4 < K4; ++k4) xv[k4] = *reinterpret_cast<const float4*>(p + 4 * k4);
@@ -275,10 +272,10 @@ struct SmEdgeLane {
   int node32;                // self-dynamics wave: r * 32 + 4 g
   int i32;                   // i * 32 + 4 g        (row of the edge's target node in [node][32] LDS buffers)
 };
-__device__ __forceinline__ SmEdgeLane sm_edge_lane(int N, int compact_streams) {
+__device__ __forceinline__ SmEdgeLane sm_edge_lane(int N, int compact_streams, int tile = 0) {      // tile: columns 16 tile .. 16 tile + 15
   SmEdgeLane el;
   const int wv = wave_id(), lane = lane_id();
-  const int c = lane & 15, g = lane >> 4;
+  const int c = 16 * tile + (lane & 15), g = lane >> 4;
   const int E = N * (N - 1);
   const int h = wv == 2 ? 1 : 0;
   const int q = c < E ? c : (E > 0 ? E - 1 : 0);
@@ -338,43 +335,12 @@ __device__ __forceinline__ void sm_edge_prefetch(const SmLds& L, SmEdgePre& pre)
   }
 }
 
-// sbuf [4][32]: encoder outputs S of the node rows (written in P1); sdx [4][32]: SD of the node rows (read in P4)
+// One 16-column tile of the relation (wave 3, h = 0) / attention (wave 2, h = 1) chain: columns = edges (i -> j, i != j)
 template <bool SAVE>
-__device__ __forceinline__ void sm_edge_phase_mfma(const SmLds& L, const SmCfg& cf, const SmAct& act, const float* sbuf, float* sdx,
-                                                   const SmEdgeLane& el, const SmEdgePre& pre) {
-  const int wv = wave_id(), lane = lane_id();
-  const int g = lane >> 4;
+__device__ __forceinline__ void sm_edge_chain_tile(const SmLds& L, const SmCfg& cf, const SmAct& act, const SmEdgeLane& el,
+                                                   const SmEdgePre& pre, int h) {
+  const int g = lane_id() >> 4;
   const float* V = L.V;
-  if (wv == 1) {
-    // ---- self-dynamics, columns = node rows
-    SmMW<2> ws0, ws1;
-    smf4 x[2], acc[2], h1[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      ws0.w[t][0] = pre.w1.w[t][0]; ws0.w[t][1] = pre.w1.w[t][1];
-      ws1.w[t][0] = pre.w1.w[2 + t][0]; ws1.w[t][1] = pre.w1.w[2 + t][1];
-      x[t] = sm_ld4(sbuf + el.node32 + 16 * t);
-      acc[t] = pre.bl2[t];
-    }
-    sm_mfma_layer<2>(ws0, x, acc);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      h1[t] = sm_phi4(acc[t], cf.elu);
-      acc[t] = pre.bl3[t];
-    }
-    sm_mfma_layer<2>(ws1, h1, acc);
-    if (el.valid) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        sm_st4(sdx + el.node32 + 16 * t, acc[t] + h1[t]);
-        if (SAVE) sm_st4(act.H1 + el.node32 + 16 * t, h1[t]);
-      }
-    }
-    return;
-  }
-  if ((wv != 2 && wv != 3) || cf.N < 2) return;
-  // ---- relation (wave 3, h = 0) / attention (wave 2, h = 1) chain, columns = edges q = 0 .. E-1 (i -> j, i != j)
-  const int h = wv == 2 ? 1 : 0;
   const float dx = L.POS[el.pos_i] - L.POS[el.pos_j], dy = L.POS[el.pos_i + 1] - L.POS[el.pos_j + 1];
   const float d = dx * dx + dy * dy;
   float* s1p = h ? act.A1 : act.R1;
@@ -439,24 +405,67 @@ __device__ __forceinline__ void sm_edge_phase_mfma(const SmLds& L, const SmCfg& 
   }
 }
 
-// One GNN step.  Node wave r (< N): `sinv` = input row (lane k and k+32 hold s_in[r][k], zero beyond sin_dim);
-// returns RES[o] / PRED[o] in lane o (and o+32).  SAVE: write the activation block (act.* valid).
-template <bool SAVE, bool EM>      // EM: edge phase + self-dynamics on the matrix cores (sm_edge_phase_mfma)
+// sbuf [NMX][32]: encoder outputs S of the node rows (written in P1); sdx [NMX][32]: SD of the node rows (read in P4)
+template <bool SAVE, int ET>
+__device__ __forceinline__ void sm_edge_phase_mfma(const SmLds& L, const SmCfg& cf, const SmAct& act, const float* sbuf, float* sdx,
+                                                   const SmEdgeLane (&el)[ET], const SmEdgePre& pre) {
+  const int wv = wave_id();
+  if (wv == 1) {
+    // ---- self-dynamics, columns = node rows (at most 16: one tile)
+    SmMW<2> ws0, ws1;
+    smf4 x[2], acc[2], h1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      ws0.w[t][0] = pre.w1.w[t][0]; ws0.w[t][1] = pre.w1.w[t][1];
+      ws1.w[t][0] = pre.w1.w[2 + t][0]; ws1.w[t][1] = pre.w1.w[2 + t][1];
+      x[t] = sm_ld4(sbuf + el[0].node32 + 16 * t);
+      acc[t] = pre.bl2[t];
+    }
+    sm_mfma_layer<2>(ws0, x, acc);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      h1[t] = sm_phi4(acc[t], cf.elu);
+      acc[t] = pre.bl3[t];
+    }
+    sm_mfma_layer<2>(ws1, h1, acc);
+    if (el[0].valid) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        sm_st4(sdx + el[0].node32 + 16 * t, acc[t] + h1[t]);
+        if (SAVE) sm_st4(act.H1 + el[0].node32 + 16 * t, h1[t]);
+      }
+    }
+    return;
+  }
+  if ((wv != 2 && wv != 3) || cf.N < 2) return;
+  // the tiles are independent chains through the same weights: unrolled, their MFMAs interleave
+#pragma unroll
+  for (int tile = 0; tile < ET; ++tile)
+    if (tile == 0 || 16 * tile < cf.N * (cf.N - 1)) sm_edge_chain_tile<SAVE>(L, cf, act, el[tile], pre, wv == 2 ? 1 : 0);
+}
+
+// One GNN step.  The lane's node row is r = wave (+ 4 for the upper half-wave of a two-rows-per-wave kernel); lane k of the half
+// holds s_in[r][k] in `sinv` (zero beyond sin_dim) and gets RES[o] / PRED[o] of that row back in lane o.  With one row per wave
+// the upper half mirrors the lower.  SAVE: write the activation block (act.* valid).
+template <bool SAVE, int NMX>
 __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float sinv, const SmAct& act, float& res_out, float& pred_out,
-                                        const SmEdgeLane& el) {
-  __shared__ __attribute__((aligned(16))) float sbuf[4][32];       // S back as broadcast float4 reads (see sm_dotw)
-  __shared__ __attribute__((aligned(16))) float sdx[4][32];        // EM: SD of every node row, from the self-dynamics wave
+                                        const SmEdgeLane (&el)[SmShape<NMX>::ET]) {
+  constexpr int RP = SmShape<NMX>::RP, ET = SmShape<NMX>::ET;
+  __shared__ __attribute__((aligned(16))) float sbuf[NMX][32];     // S back as broadcast float4 reads (see sm_dotw)
+  __shared__ __attribute__((aligned(16))) float sdx[NMX][32];      // SD of every node row, from the self-dynamics wave
   const int wv = wave_id();
   const int lane = lane_id();
-  const int o = lane & 31, h = lane >> 5;
+  const int o = lane & 31;
   const int N = cf.N;
+  const int r = RP == 2 ? wv + 4 * (lane >> 5) : wv;               // the lane's node row
+  const bool own = RP == 2 ? r < N : (lane < 32 && r < N);          // one lane per element of a valid row: the stores
+  const int rs = r < N ? r : wv;                                    // a row that exists, for the reads of the lanes without one
   const float* V = L.V;
-  float S = 0.0f, SD = 0.0f, H1 = 0.0f;
+  float S = 0.0f;
   SmW<8> wa, wb;
   sm_stamp(cf, 0);
   // ---- P1: node rows: encoder, factorised first edge layer ------------------------------------------------------
   if (wv < N) {
-    const int r = wv;
     wa = sm_wload<8>(L.W + W_ENC, 32, o);
     const float benc = V[V_ENC + o];
     // first quarter of the edge-first weights (k4 = 0, 1; four column groups of 64) while the encoder computes; the other
@@ -477,144 +486,75 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
       e = sm_dotw<8>(wa, sinv);
     }
     S = (o < cf.lim_enc) ? sinv : e + benc;
-    if (lane < 32) sbuf[wv][lane] = S;
-    if (EM && SAVE && lane < 32) {
-      act.SIN[wv * 32 + o] = sinv;
-      act.S[wv * act.cat_ld + o] = S;
+    if (own) {
+      sbuf[r][o] = S;
+      if (SAVE) {
+        act.SIN[r * 32 + o] = sinv;
+        act.S[r * act.cat_ld + o] = S;
+      }
+      if (o < 2) L.POS[r * 4 + o] = S;
     }
-    float4 sx[8];
+    // the 256 first-layer outputs of a row take all 64 lanes: the wave's rows one after the other
 #pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4) sx[k4] = *reinterpret_cast<const float4*>(&sbuf[wv][4 * k4]);
-    v2f p[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 nx[2][4];
-      if (q < 3) {
+    for (int rq = 0; rq < RP; ++rq) {
+      const int row = wv + 4 * rq;
+      if (rq > 0) {
+        if (row >= N) break;
 #pragma unroll
         for (int k4 = 0; k4 < 2; ++k4)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) nx[k4][g] = *reinterpret_cast<const float4*>(L.W + W_EF + ((2 * (q + 1) + k4) * 256 + g * 64 + lane) * 4);
-      } else if (!EM) {
-        wb = sm_wload<8>(L.W + W_S0, 32, o);        // self-dynamics layer 0, used right after the barrier
+          for (int g = 0; g < 4; ++g) ef[k4][g] = *reinterpret_cast<const float4*>(L.W + W_EF + (k4 * 256 + g * 64 + lane) * 4);
       }
+      float4 sx[8];
 #pragma unroll
-      for (int k4 = 0; k4 < 2; ++k4) {
-        const float4 xq = sx[2 * q + k4];
-        const v2f x01 = {xq.x, xq.y}, x23 = {xq.z, xq.w};
+      for (int k4 = 0; k4 < 8; ++k4) sx[k4] = *reinterpret_cast<const float4*>(&sbuf[row][4 * k4]);
+      v2f p[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          p[g] = pk_fma(v2f{ef[k4][g].x, ef[k4][g].y}, x01, p[g]);
-          p[g] = pk_fma(v2f{ef[k4][g].z, ef[k4][g].w}, x23, p[g]);
+      for (int q = 0; q < 4; ++q) {
+        float4 nx[2][4];
+        if (q < 3) {
+#pragma unroll
+          for (int k4 = 0; k4 < 2; ++k4)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) nx[k4][g] = *reinterpret_cast<const float4*>(L.W + W_EF + ((2 * (q + 1) + k4) * 256 + g * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < 2; ++k4) {
+          const float4 xq = sx[2 * q + k4];
+          const v2f x01 = {xq.x, xq.y}, x23 = {xq.z, xq.w};
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            p[g] = pk_fma(v2f{ef[k4][g].x, ef[k4][g].y}, x01, p[g]);
+            p[g] = pk_fma(v2f{ef[k4][g].z, ef[k4][g].w}, x23, p[g]);
+          }
+        }
+        if (q < 3) {
+#pragma unroll
+          for (int k4 = 0; k4 < 2; ++k4)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ef[k4][g] = nx[k4][g];
         }
       }
-      if (q < 3) {
-#pragma unroll
-        for (int k4 = 0; k4 < 2; ++k4)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) ef[k4][g] = nx[k4][g];
-      }
+      float* pr = L.PR + row * 256 + lane;
+      pr[0] = p[0].x + p[0].y;
+      pr[64] = p[1].x + p[1].y;
+      pr[128] = p[2].x + p[2].y;
+      pr[192] = p[3].x + p[3].y;
     }
-    float* pr = L.PR + r * 256 + lane;
-    pr[0] = p[0].x + p[0].y;
-    pr[64] = p[1].x + p[1].y;
-    pr[128] = p[2].x + p[2].y;
-    pr[192] = p[3].x + p[3].y;
-    if (lane < 2) L.POS[r * 4 + lane] = S;
   }
   // waves without a node row idle in front of the barrier: they fetch their chain's operands there; node waves (on the critical
   // path of P1) fetch theirs behind it
   SmEdgePre pre;
-  if (EM && wv >= N) sm_edge_prefetch(L, pre);
+  if (wv >= N) sm_edge_prefetch(L, pre);
   sm_stamp(cf, 1);
   WG_SYNC();
   sm_stamp(cf, 2);
-  if (EM && wv < N) sm_edge_prefetch(L, pre);
-  // ---- P3: edges (i -> j, i != j); half 0 = relation chain, half 1 = attention chain ----------------------------------
-  // Wave 3 (no node row when N = 3) takes edges first.  Node waves interleave their self-dynamics layers (independent
-  // of the edges) with the LDS round trip of their first edge's activation row.
-  if (EM) sm_edge_phase_mfma<SAVE>(L, cf, act, &sbuf[0][0], &sdx[0][0], el, pre);
-  bool self_done = EM || !(wv < N);
-  const int vwd = h ? V_WDA : V_WDR, vb0 = h ? V_BA0 : V_BR0;
-  const float wd_lo = V[vwd + o], wd_hi = V[vwd + o + 32], b0_lo = V[vb0 + o], b0_hi = V[vb0 + o + 32];
-  const float b1 = V[(h ? V_BA1 : V_BR1) + o], br2 = V[V_BR2 + o], wa2 = V[V_WA2 + o], ba2 = V[V_BA2];
-  const float* Wl2 = L.W + (h ? W_A1 : W_R1);
-#pragma unroll
-  for (int it = 0; it < 3 && !EM; ++it) {
-    if (it >= cf.ne && self_done) break;
-    const bool has_edge = it < cf.ne;
-    int e = 0, eg = 0;          // LDS edge row (i N + j); row in the saved-activation buffers
-    float d = 0.0f, a_lo = 0.0f, a_hi = 0.0f;
-    float* x1 = L.X1 + wv * 128 + 64 * h;
-    SmW<16> w2;
-    if (has_edge) {
-      const int i = cf.ei[it], j = cf.ej[it];
-      e = i * N + j;
-      eg = (SAVE && act.compact) ? cf.eq[it] : e;
-      w2 = sm_wload<16>(Wl2, 32, o);
-      const float dx = L.POS[i * 4] - L.POS[j * 4], dy = L.POS[i * 4 + 1] - L.POS[j * 4 + 1];
-      d = dx * dx + dy * dy;
-      const float* pi = L.PR + i * 256 + 128 * h;
-      const float* pj = L.PR + j * 256 + 128 * h + 64;
-      a_lo = act_phi(pi[o] + pj[o] + wd_lo * d + b0_lo, cf.elu);
-      a_hi = act_phi(pi[o + 32] + pj[o + 32] + wd_hi * d + b0_hi, cf.elu);
-      x1[o] = a_lo;
-      x1[o + 32] = a_hi;
-    }
-    sm_stamp(cf, 8);
-    if (!self_done) {            // node wave: self-dynamics (wb = W_S0 from before the barrier)
-      wa = sm_wload<8>(L.W + W_S1, 32, o);
-      const float bs0 = V[V_S0 + o], bs1 = V[V_S1 + o];
-      H1 = act_phi(sm_dotw<8>(wb, S) + bs0, cf.elu);
-      SD = sm_dotw<8>(wa, H1) + bs1 + H1;
-      if (SAVE && lane < 32) {
-        act.SIN[wv * 32 + o] = sinv;
-        act.H1[wv * 32 + o] = H1;
-        act.S[wv * act.cat_ld + o] = S;
-      }
-      self_done = true;
-    }
-    sm_stamp(cf, 9);
-    if (!has_edge) break;
-    // second layer 64 -> 32: the activation row comes back as LDS broadcast reads (one address per half)
-    float4 xr[16];
-#pragma unroll
-    for (int k4 = 0; k4 < 16; ++k4) xr[k4] = *reinterpret_cast<const float4*>(x1 + 4 * k4);
-    wb = sm_wload<8>(L.W + W_R2, 32, o);
-    if (SAVE) {
-      float* g1 = (h ? act.A1 : act.R1) + eg * 64;
-      g1[o] = a_lo;
-      g1[o + 32] = a_hi;
-    }
-    v2f y0 = {0.0f, 0.0f}, y1 = {0.0f, 0.0f}, y2 = {0.0f, 0.0f}, y3 = {0.0f, 0.0f};      // four independent chains
-#pragma unroll
-    for (int k4 = 0; k4 < 16; k4 += 2) {
-      y0 = pk_fma(v2f{w2.w[k4].x, w2.w[k4].y}, v2f{xr[k4].x, xr[k4].y}, y0);
-      y1 = pk_fma(v2f{w2.w[k4].z, w2.w[k4].w}, v2f{xr[k4].z, xr[k4].w}, y1);
-      y2 = pk_fma(v2f{w2.w[k4 + 1].x, w2.w[k4 + 1].y}, v2f{xr[k4 + 1].x, xr[k4 + 1].y}, y2);
-      y3 = pk_fma(v2f{w2.w[k4 + 1].z, w2.w[k4 + 1].w}, v2f{xr[k4 + 1].z, xr[k4 + 1].w}, y3);
-    }
-    y0 += y1;
-    y2 += y3;
-    y0 += y2;
-    const float a2 = act_phi(y0.x + y0.y + b1, cf.elu);
-    sm_stamp(cf, 10);
-    // third layer: relation 32 -> 32 + skip (x = lanes 0..31 of a2); attention 32 -> 1 -> exp
-    const float r3 = sm_dotw<8>(wb, a2) + br2 + a2;
-    const float att = __expf(wave_sum(h ? a2 * wa2 : 0.0f) + ba2);
-    sm_stamp(cf, 11);
-    if (h == 0) L.R3[e * 32 + o] = r3;
-    if (lane == 0) L.ATT[e] = att;
-    if (SAVE) {
-      ((h ? act.A2 : act.R2) + eg * 32)[o] = a2;
-      if (h == 0) act.R3[eg * 32 + o] = r3;
-      if (lane == 0) {
-        act.ATT[eg] = att;
-        act.DIST[eg] = d;
-      }
-    }
-  }
-  if (SAVE && wv < N && !act.compact) {             // self-edge rows (masked out of the model): finite zeros for the backward's restore
-    const int e = wv * N + wv;
+  if (wv < N) sm_edge_prefetch(L, pre);
+  // ---- P3: edges (i -> j, i != j) as the columns of the relation chain (wave 3) and the attention chain (wave 2); the
+  // self-dynamics of all node rows as the columns of wave 1's
+  sm_edge_phase_mfma<SAVE, ET>(L, cf, act, &sbuf[0][0], &sdx[0][0], el, pre);
+  if (RP == 1 && SAVE && wv < N && !act.compact) {      // self-edge rows (masked out of the model): finite zeros for the backward's restore
+    const int e = wv * N + wv, h = lane >> 5;             // (block layout: the kernels for up to four objects only)
     act.R1[e * 64 + lane] = 0.0f;
     act.A1[e * 64 + lane] = 0.0f;
     (h ? act.A2 : act.R2)[e * 32 + o] = 0.0f;
@@ -630,12 +570,11 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
   sm_stamp(cf, 5);
   // ---- P4: node rows: aggregation, affector, output ------------------------------------------------------------------
   if (wv < N) {
-    const int r = wv;
     wb = sm_wload<8>(L.W + W_F1, 32, o);
     const float bf0 = V[V_F0 + o], bf1 = V[V_F1 + o], bf2 = V[V_F2 + o], bo0 = V[V_O0 + o], bo1 = V[V_O1 + o];
-    float pred = EM ? sdx[r][o] : SD;
+    float pred = sdx[rs][o];
     for (int j = 0; j < N; ++j)
-      if (j != r) pred = fmaf(L.R3[(r * N + j) * 32 + o], L.ATT[r * N + j], pred);
+      if (j != rs) pred = fmaf(L.R3[(rs * N + j) * 32 + o], L.ATT[rs * N + j], pred);
     sm_stamp(cf, 12);
     const float F1 = fast_tanh(sm_dotw<8>(wa, pred) + bf0);
     sm_stamp(cf, 13);
@@ -651,7 +590,7 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
     sm_stamp(cf, 14);
     const float RES = sm_dotw<8>(wb, O1) + bo1 + O1;
     sm_stamp(cf, 15);
-    if (SAVE && lane < 32) {
+    if (SAVE && own) {
       act.PRED[r * 32 + o] = pred;
       act.F1[r * 32 + o] = F1;
       act.F2[r * 32 + o] = F2;
@@ -673,8 +612,8 @@ __device__ __forceinline__ float sm_from_lane(float v, int src_lane) {
 // inference recursion, same contract as dyn_loop_fwd_k (gnn.hip) with G = 1: grid = B sequences
 // =================================================================================================
 // SAVEM: 0 = inference, 1 = save the activations as per-step blocks (the backward of gnn.hip), 2 = as per-sequence streams
-// (gnn_small_bwd.hip); NT > 0: the number of objects at compile time (3: the headline shape)
-template <int SAVEM, bool EM, bool ELU, int NT, bool STAMP = false>      // STAMP: the phase stamps of tools/loop_stamps.py (one debug instantiation)
+// (gnn_small_bwd.hip); NT > 0: the number of objects at compile time (3: the headline shape); NMX: 4 or 6 (SmShape)
+template <int SAVEM, int NMX, bool ELU, int NT, bool STAMP = false>      // STAMP: the phase stamps of tools/loop_stamps.py (one debug instantiation)
 __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
     const float* __restrict__ eps, const float* __restrict__ extra, const float* __restrict__ P,
@@ -684,25 +623,31 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
   // steps [ts0, ts1) of the Ts the tensors are laid out for: a caller that pipelines the recursion against the scene likelihood of
   // the frames already inferred runs it in pieces; a piece that does not start at 0 takes the state the previous one left in z
   constexpr bool SAVE = SAVEM != 0;
+  constexpr int RP = SmShape<NMX>::RP, ET = SmShape<NMX>::ET;
+  static_assert(SAVEM != 1 || NMX == 4, "block-layout activations: the kernels for up to four objects");
+  static_assert(NT <= NMX, "object count beyond what the kernel is built for");
   if (!STAMP) stamps = nullptr;      // the 16 stamp sites of a step vanish (a run-time null check each was ~50 instructions per step)
   constexpr int streams = SAVEM == 2 ? 1 : 0;       // compile-time: the two pointer sets were both built every step and selected
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const SmLds L = sm_carve(lds);
+  const SmLds L = sm_carve<NMX>(lds);
   const int b = blockIdx.x;
   const int wv = wave_id(), lane = lane_id(), l = lane & 31;
   elu = ELU ? 1 : 0;      // compile-time activation: with a run-time flag every phi carried the ocml expm1f path (code, registers, branches)
   if (NT > 0) N = NT;       // loops over the objects unroll, their LDS reads go out together
   SmCfg cf{N, sin_dim, lim_enc, elu};
   cf.stamps = nullptr;
-  sm_edges(cf);
   const int E = sin_dim - 16;
   const size_t act_stride = gnn_act_floats(N, 1);
-  const SmEdgeLane el = sm_edge_lane(N, SAVE && streams);
+  SmEdgeLane el[ET];
+#pragma unroll
+  for (int t = 0; t < ET; ++t) el[t] = sm_edge_lane(N, SAVE && streams, t);
   sm_setup(L, P);
-  // node wave r: lane l (and l+32) holds s_in[l]; dims 0..15 come from the running state z[t-1][2..17]
+  // the lane's node row r: lane l of its half holds s_in[r][l]; dims 0..15 come from the running state z[t-1][2..17]
   float sinv = 0.0f;
-  const int r = wv;
-  if (wv < N) {
+  const int r = RP == 2 ? wv + 4 * (lane >> 5) : wv;
+  const bool row = r < N;                                           // lanes of the upper half of a one-row wave mirror the lower
+  const bool own = RP == 2 ? row : (lane < 32 && row);              // one lane per element of a valid row: the stores
+  if (row) {
     if (l < 16) sinv = ts0 == 0 ? z1[((size_t)b * N + r) * 18 + 2 + l] : z[(((size_t)b * Ts + ts0 - 1) * N + r) * 18 + 2 + l];
     else if (l < sin_dim) sinv = extra[(((size_t)b * Ts + ts0) * N + r) * E + (l - 16)];
   }
@@ -711,7 +656,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     const size_t o = ((size_t)b * Ts + ts) * N + r;
     // this step's epilogue inputs and the next step's extra inputs: issued now, consumed ~2 us later
     float ep = 0.0f, ms = 0.0f, ss = 1.0f, xnext = 0.0f;
-    if (wv < N) {
+    if (row) {
       if (l < 16) ep = eps[o * 18 + 2 + l];
       else if (l < 18) ep = eps[o * 18 + (l - 16)];
       if (l < 4) {
@@ -727,7 +672,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     if (SAVE) a = streams ? sm_act2(act + (size_t)b * sm_act2_floats(N, Ts), N, Ts, ts) : sm_act(act + ((size_t)b * Ts + ts) * act_stride, N);
     cf.stamps = (ts == ts1 - 1) ? stamps : nullptr;
     float res = 0.0f, prd = 0.0f;
-    sm_step<SAVE, EM>(L, cf, sinv, a, res, prd, el);
+    sm_step<SAVE, NMX>(L, cf, sinv, a, res, prd, el);
     if (wv < N) {
       // epilogue (stove.py:103-170 + constrain_z_dyn): lane d < 16 owns state dim d, lanes 16/17 the two scale dims
       const float res_s = sm_from_lane(res, (lane & 32) + ((l + 16) & 31));      // RES[16 + d] for d < 16
@@ -747,7 +692,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
           sg = sd;
         }
         zv = fmaf(sg, ep, mu);
-        if (lane < 32) {
+        if (own) {
           zdyn[o * 16 + d] = zd;
           zdstd[o * 16 + d] = sd;
           z[o * 18 + 2 + d] = zv;
@@ -756,14 +701,14 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
         }
       } else {
         zv = xnext;                                   // becomes s_in[l] of the next step (0 beyond sin_dim)
-        if (l < 18 && lane < 32) {
+        if (l < 18 && own) {
           const int q = l - 16;
           z[o * 18 + q] = fmaf(ss, ep, ms);
           mean[o * 18 + q] = ms;
           stdv[o * 18 + q] = ss;
         }
       }
-      if (pred != nullptr && lane < 32) pred[o * 32 + l] = prd;
+      if (pred != nullptr && own) pred[o * 32 + l] = prd;
       sinv = zv;
     }
     sm_stamp(cf, 7);
@@ -773,26 +718,31 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
 // =================================================================================================
 // generative rollout, same contract as rollout_fwd_k (gnn.hip) with G = 1
 // =================================================================================================
-template <bool EM, bool ELU, int NT>
+template <int NMX, bool ELU, int NT>
 __global__ __launch_bounds__(64 * kSmWaves) void rollout_fwd_small_k(const float* __restrict__ z_last, const float* __restrict__ extra,
                                                            const float* __restrict__ P, float* __restrict__ z_pred,
                                                            float* __restrict__ zstd, float* __restrict__ pred,
                                                            int B, int num, int A, int N, int sin_dim, int lim_enc, int elu, LoopConst kc) {
+  constexpr int RP = SmShape<NMX>::RP, ET = SmShape<NMX>::ET;
+  static_assert(NT <= NMX, "object count beyond what the kernel is built for");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const SmLds L = sm_carve(lds);
+  const SmLds L = sm_carve<NMX>(lds);
   const int b = blockIdx.x;
   const int wv = wave_id(), lane = lane_id(), l = lane & 31;
   elu = ELU ? 1 : 0;      // compile-time activation: with a run-time flag every phi carried the ocml expm1f path (code, registers, branches)
   if (NT > 0) N = NT;       // loops over the objects unroll, their LDS reads go out together
   SmCfg cf{N, sin_dim, lim_enc, elu};
   cf.stamps = nullptr;
-  sm_edges(cf);
   const int E = sin_dim - 16;
-  const SmEdgeLane el = sm_edge_lane(N, 0);
+  SmEdgeLane el[ET];
+#pragma unroll
+  for (int t = 0; t < ET; ++t) el[t] = sm_edge_lane(N, 0, t);
   sm_setup(L, P);
   float sinv = 0.0f, scale = 0.0f;
-  const int r = wv;
-  if (wv < N) {
+  const int r = RP == 2 ? wv + 4 * (lane >> 5) : wv;
+  const bool row = r < N;
+  const bool own = RP == 2 ? row : (lane < 32 && row);
+  if (row) {
     if (l < 16) sinv = z_last[((size_t)b * N + r) * 18 + 2 + l];
     else if (l < sin_dim) sinv = extra[(((size_t)b * A + 0) * N + r) * E + (l - 16)];
     if (l >= 16 && l < 18) scale = z_last[((size_t)b * N + r) * 18 + (l - 16)];       // sx, sy stay constant
@@ -801,24 +751,24 @@ __global__ __launch_bounds__(64 * kSmWaves) void rollout_fwd_small_k(const float
   for (int t = 0; t < num; ++t) {
     const size_t o = ((size_t)b * num + t) * N + r;
     float xnext = 0.0f;
-    if (wv < N && l >= 16 && l < sin_dim && t + 1 < num) xnext = extra[(((size_t)b * A + ((t + 1) % A)) * N + r) * E + (l - 16)];
+    if (row && l >= 16 && l < sin_dim && t + 1 < num) xnext = extra[(((size_t)b * A + ((t + 1) % A)) * N + r) * E + (l - 16)];
     SmAct a{};
     float res = 0.0f, prd = 0.0f;
-    sm_step<false, EM>(L, cf, sinv, a, res, prd, el);
+    sm_step<false, NMX>(L, cf, sinv, a, res, prd, el);
     if (wv < N) {
       const float res_s = sm_from_lane(res, (lane & 32) + ((l + 16) & 31));
       float zv;
       if (l < 16) {
         zv = 2.0f * sigmoidf_(res) - 1.0f + (l < 2 ? sinv : 0.0f);
-        if (lane < 32) {
+        if (own) {
           z_pred[o * 18 + 2 + l] = zv;
           if (zstd != nullptr) zstd[o * 16 + l] = std_scale(l, kc) * sigmoidf_(res_s);
         }
       } else {
         zv = xnext;
-        if (l < 18 && lane < 32) z_pred[o * 18 + (l - 16)] = scale;
+        if (l < 18 && own) z_pred[o * 18 + (l - 16)] = scale;
       }
-      if (pred != nullptr && lane < 32) pred[o * 32 + l] = prd;
+      if (pred != nullptr && own) pred[o * 32 + l] = prd;
       sinv = zv;
     }
   }

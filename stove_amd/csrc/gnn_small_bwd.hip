@@ -1,5 +1,5 @@
-// Backward of the small-graph time loop (N <= 4 objects), gfx950: the adjoint of gnn_small.hip in the same
-// wave-per-node-row, register-chained form, split in two launches:
+// Backward of the small-graph time loop (N <= 6 objects), gfx950: the adjoint of gnn_small.hip in the same
+// wave-per-node-row (half-wave-per-node-row in the kernels for five or six objects), register-chained form, split in two launches:
 //   dyn_loop_bwd_small_k  walks the T-serial chain backwards (data gradients only: dz1, dzsup, dzsstd, dextra) and
 //                         streams every layer's pre-activation gradient ("dY") to HBM;
 //   gnn_dw_small_k        turns the saved layer inputs and the dY streams into weight gradients as a throughput
@@ -36,19 +36,21 @@ __device__ __forceinline__ SmDy sm_dy(float* seq, int N, int Ts, int ts) {
 
 // LDS of the backward kernel (floats): W^T images repacked for row-per-lane dots, vectors, exchange buffers
 struct SmBLds {
-  float *W, *V, *DSD, *EG, *DD, *POS, *X1, *DP;
+  float *W, *V, *DSD, *EG, *DD, *POS, *DP;
 };
-constexpr int kSmBLdsFloats = W_END + V_END + 4 * 32 + 16 * 128 + 32 + 2 * 16 + kSmWaves * 64 + 4 * 256;
+template <int NMX>
+constexpr int smb_lds_floats() { return W_END + V_END + NMX * 32 + SmShape<NMX>::NE * 128 + 2 * ((SmShape<NMX>::NE + 3) & ~3) + 2 * NMX * 4 + NMX * 256; }
+template <int NMX>
 __device__ __forceinline__ SmBLds smb_carve(float* base) {
+  constexpr int NE = SmShape<NMX>::NE, NE4 = (NE + 3) & ~3;
   SmBLds L;
   L.W = base;
   L.V = L.W + W_END;
-  L.DSD = L.V + V_END;        // [4][32]   dL/dPRED of every node row
-  L.EG = L.DSD + 4 * 32;      // [16][dR1pre 64 | dA1pre 64] by edge row i*N + j
-  L.DD = L.EG + 16 * 128;     // [2][16]   dL/d dist of every edge: relation-chain part | attention-chain part
-  L.POS = L.DD + 32;          // [2][4][4] positions (two parities: a fast wave may already write the next step's)
-  L.X1 = L.POS + 32;          // [4 waves][E32 32 | dA2pre 32]
-  L.DP = L.X1 + kSmWaves * 64;       // [4][256]  dP rows for the edge-first transpose product
+  L.DSD = L.V + V_END;          // [NMX][32]   dL/dPRED of every node row
+  L.EG = L.DSD + NMX * 32;      // [NMX^2][dR1pre 64 | dA1pre 64] by edge row i*N + j
+  L.DD = L.EG + NE * 128;       // [2][NMX^2]  dL/d dist of every edge: relation-chain part | attention-chain part
+  L.POS = L.DD + 2 * NE4;       // [2][NMX][4] positions (two parities: a fast wave may already write the next step's)
+  L.DP = L.POS + 2 * NMX * 4;   // [NMX][256]  dP rows for the edge-first transpose product
   return L;
 }
 // transposed layer image (rows = layer inputs, K = layer outputs) -> [K/4][rows][4]
@@ -117,7 +119,7 @@ __device__ __forceinline__ SmBEdgeIn smb_edge_load(const SmAct& a, const SmEdgeL
   in.att = a.ATT[el.s1];
   return in;
 }
-__device__ __forceinline__ void smb_edge_phase_mfma(const SmBLds& L, const SmEdgeLane& el, const SmBEdgeIn& in, const SmDy& g, int elu) {
+__device__ __forceinline__ void smb_edge_phase_mfma(const SmBLds& L, const SmEdgeLane& el, const SmBEdgeIn& in, const SmDy& g, int elu, int dd_stride) {
   const int wv = wave_id(), lane = lane_id(), gq = lane >> 4;
   if (wv < 2) return;
   const int h = wv == 2 ? 1 : 0;
@@ -181,11 +183,11 @@ __device__ __forceinline__ void smb_edge_phase_mfma(const SmBLds& L, const SmEdg
       sm_st4(eg + 16 * u, d1[u]);
       sm_st4(g1 + 16 * u, d1[u]);
     }
-    if (gq == 0) L.DD[16 * h + el.e] = dd;
+    if (gq == 0) L.DD[dd_stride * h + el.e] = dd;
   }
 }
 
-template <bool EM, bool ELU, int NT, bool HEAD, bool STAMP = false>
+template <int NMX, bool ELU, int NT, bool HEAD, bool STAMP = false>
 __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     const float* __restrict__ zsup, const float* __restrict__ zsstd, const float* __restrict__ eps, const float* __restrict__ P,
     float* __restrict__ act, const float* __restrict__ dz, const float* __restrict__ dzdyn, const float* __restrict__ dmean,
@@ -194,11 +196,13 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     int elu, LoopConst kc, long long* stamps, int ts0, int ts1, float* __restrict__ carry) {
   // steps ts1-1 .. ts0 of the Ts the tensors are laid out for (see dyn_loop_fwd_small_k).  The gradient that flows from step ts0
   // into the state before it leaves through `carry` (B, N, 18; layout of dz1) when ts0 > 0 and enters there when ts1 < Ts.
+  constexpr int RP = SmShape<NMX>::RP, ET = SmShape<NMX>::ET, NE4 = (SmShape<NMX>::NE + 3) & ~3;
+  static_assert(NT <= NMX, "object count beyond what the kernel is built for");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // the chain is issue-latency bound: where another kernel's wave shares the SIMD (the table gradients that run underneath,
   // objspn_tablegrad_under_k) the arbiter picks this one whenever it is ready
   __builtin_amdgcn_s_setprio(3);
-  const SmBLds L = smb_carve(lds);
+  const SmBLds L = smb_carve<NMX>(lds);
   const int b = blockIdx.x;
   const int wv = wave_id(), lane = lane_id(), l = lane & 31, h = lane >> 5;
   elu = ELU ? 1 : 0;      // compile-time activation (see dyn_loop_fwd_small_k)
@@ -215,19 +219,23 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
   }
   SmCfg cf{N, sin_dim, lim_enc, elu};
   cf.stamps = nullptr;
-  sm_edges(cf);
   const int E = sin_dim - 16;
-  const int NEo = N * (N - 1);
   const float* V = L.V;
-  const SmEdgeLane el = sm_edge_lane(N, 1);
+  SmEdgeLane el[ET];
+#pragma unroll
+  for (int t = 0; t < ET; ++t) el[t] = sm_edge_lane(N, 1, t);
   smb_setup(L, P);
   float* aseq = act + (size_t)b * sm_act2_floats(N, Ts);
   float* dseq = dy + (size_t)b * sm_dy_floats(N, Ts);
-  const int r = wv;
+  // the lane's node row (see sm_step, gnn_small.hip): one per wave, or one per half-wave
+  const int r = RP == 2 ? wv + 4 * h : wv;
+  const bool row = r < N;
+  const bool own = RP == 2 ? row : (lane < 32 && row);
+  const int rs = row ? r : wv;
   const bool node = wv < N;
   float car = 0.0f;                                   // lane d < 16: gradient carried into z[t][2 + d] from step t + 1
   SmBNodeIn nin{};
-  if (node) {
+  if (row) {
     const SmAct a = sm_act2(aseq, N, Ts, ts1 - 1);
     nin = smb_node_load(a, r, l, ((size_t)b * Ts + ts1 - 1) * N + r, eps, zsup, zsstd, dz, dzdyn, dmean, dstd, dpred);
     if (ts1 < Ts && l < 16) car = carry[((size_t)b * N + r) * 18 + 2 + l];
@@ -240,34 +248,19 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     const SmDy g = sm_dy(dseq, N, Ts, ts);
     const size_t o = ((size_t)b * Ts + ts) * N + r;
     const SmBNodeIn cur = nin;
-    if (node && ts > ts0) {
+    if (row && ts > ts0) {
       const SmAct an = sm_act2(aseq, N, Ts, ts - 1);
       nin = smb_node_load(an, r, l, o - N, eps, zsup, zsstd, dz, dzdyn, dmean, dstd, dpred);
     }
-    // this wave's edges of the step: saved forward values, in flight across the node phase
-    float eR3[3], eATT[3], eR2[3], eA2[3], eX_lo[3], eX_hi[3];
+    // this wave's edges of the step (first column tile): saved forward values, in flight across the node phase
     SmBEdgeIn ein{};
-    if (EM && wv >= 2) ein = smb_edge_load(a, el, wv == 2 ? 1 : 0);
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      eR3[it] = eATT[it] = eR2[it] = eA2[it] = eX_lo[it] = eX_hi[it] = 0.0f;
-      if (!EM && it < cf.ne) {
-        const int q = cf.eq[it];
-        eR3[it] = a.R3[q * 32 + l];
-        eATT[it] = a.ATT[q];
-        eR2[it] = a.R2[q * 32 + l];
-        eA2[it] = a.A2[q * 32 + l];
-        const float* x1 = (h ? a.A1 : a.R1) + q * 64;
-        eX_lo[it] = x1[l];
-        eX_hi[it] = x1[l + 32];
-      }
-    }
-    float* pos = L.POS + (ts & 1) * 16;
+    if (wv >= 2) ein = smb_edge_load(a, el[0], wv == 2 ? 1 : 0);
+    float* pos = L.POS + (ts & 1) * (NMX * 4);
     float dS_o0 = 0.0f, dSD = 0.0f, pc = 0.0f;
     // ---- Q4: node rows: epilogue, output and affector MLPs backwards ----------------------------------------------
     if (node) {
       SmW<8> wa = sm_wload<8>(L.W + W_O1, 32, l), wb;
-      if (l < 2) pos[r * 4 + l] = cur.S;
+      if (l < 2 && own) pos[r * 4 + l] = cur.S;
       // epilogue backward (dyn_loop_bwd_k of gnn.hip, per (row, q)): lane d < 16 owns q = d + 2, lanes 16/17 q = 0/1
       const float res_hi = sm_from_lane(cur.RES, (lane & 32) + ((l + 16) & 31));
       const float gz = cur.gz + (l < 16 ? car : 0.0f);
@@ -290,7 +283,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
           const float rD = rsqrtf(D);
           gzd += gmu * ss2 * iD;
           gsd = gmu * (ms - mu) * iD * 2.0f * sd + gsg * ss * ss2 * iD * rD;
-          if (lane < 32) {
+          if (own) {
             dzsup[o * 6 + 2 + d] = gmu * sd2 * iD;
             dzsstd[o * 6 + 2 + d] = gmu * (zd - mu) * iD * 2.0f * ss + gsg * sd * sd2 * iD * rD;
           }
@@ -301,7 +294,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
         if (d < 2) pc = gzd;                              // z_dyn position = previous position + delta
         lo = gzd * 0.5f * (1.0f - m * m);
         hi = gsd * sd * (1.0f - sg_hi);
-      } else if (l < 18 && lane < 32) {
+      } else if (l < 18 && own) {
         dzsup[o * 6 + (l - 16)] = gmu;
         dzsstd[o * 6 + (l - 16)] = gsg;
       }
@@ -326,7 +319,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
       const float dbf = (sm_dotw<8>(wa, du) + dF2) * (1.0f - cur.F1 * cur.F1);
       // b5. affector.0
       dSD = sm_dotw<8>(wb, dbf) + cur.dpred;
-      if (lane < 32) {
+      if (own) {
         L.DSD[r * 32 + l] = dSD;
         g.dRES[r * 32 + l] = dres;
         g.dO1[r * 32 + l] = db;
@@ -339,109 +332,65 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     sm_stamp(cf, 1);
     WG_SYNC();
     sm_stamp(cf, 2);
-    // ---- Q3: edges: half 0 = relation chain, half 1 = attention chain -----------------------------------------------
-    if (EM) {
-      smb_edge_phase_mfma(L, el, ein, g, elu);
-    } else {
-      const float wa2 = V[V_WA2 + l];
-      const int vwd = h ? V_WDA : V_WDR;
-      const float wd_lo = V[vwd + l], wd_hi = V[vwd + l + 32];
+    // ---- Q3: edges as the columns of the relation chain (wave 3) / the attention chain (wave 2), one 16-column tile at a time
+    smb_edge_phase_mfma(L, el[0], ein, g, elu, NE4);
 #pragma unroll
-      for (int it = 0; it < 3; ++it) {
-        if (it >= cf.ne) break;
-        const int i = cf.ei[it], j = cf.ej[it], e = i * N + j, q = cf.eq[it];
-        SmW<8> w2 = sm_wload<8>(L.W + W_R2, 32, l);
-        const float* Wl = L.W + (h ? W_A1 : W_R1);
-        SmW<8> wlo = sm_wload<8>(Wl, 64, l), whi = sm_wload<8>(Wl, 64, l + 32);
-        const float dsd_i = L.DSD[i * 32 + l];
-        const float att = eATT[it];
-        const float dq = wave_sum(h == 0 ? dsd_i * eR3[it] : 0.0f) * att;
-        const float dR3 = dsd_i * att;
-        const float e32 = (sm_dotw<8>(w2, dR3) + dR3) * dphi_from_out(eR2[it], elu);
-        const float dA2p = dq * wa2 * dphi_from_out(eA2[it], elu);
-        float* x1 = L.X1 + wv * 64 + 32 * h;
-        x1[l] = h ? dA2p : e32;
-        float4 xr[8];
-#pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4) xr[k4] = *reinterpret_cast<const float4*>(x1 + 4 * k4);
-        v2f y0 = {0.0f, 0.0f}, y1 = {0.0f, 0.0f}, y2 = {0.0f, 0.0f}, y3 = {0.0f, 0.0f};
-#pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4) {
-          y0 = pk_fma(v2f{wlo.w[k4].x, wlo.w[k4].y}, v2f{xr[k4].x, xr[k4].y}, y0);
-          y1 = pk_fma(v2f{wlo.w[k4].z, wlo.w[k4].w}, v2f{xr[k4].z, xr[k4].w}, y1);
-          y2 = pk_fma(v2f{whi.w[k4].x, whi.w[k4].y}, v2f{xr[k4].x, xr[k4].y}, y2);
-          y3 = pk_fma(v2f{whi.w[k4].z, whi.w[k4].w}, v2f{xr[k4].z, xr[k4].w}, y3);
-        }
-        y0 += y1;
-        y2 += y3;
-        const float d1_lo = (y0.x + y0.y) * dphi_from_out(eX_lo[it], elu);
-        const float d1_hi = (y2.x + y2.y) * dphi_from_out(eX_hi[it], elu);
-        const float dd = wave_sum(d1_lo * wd_lo + d1_hi * wd_hi);
-        float* eg = L.EG + e * 128 + 64 * h;
-        eg[l] = d1_lo;
-        eg[l + 32] = d1_hi;
-        if (lane == 0) {
-          L.DD[e] = dd;
-          L.DD[16 + e] = 0.0f;
-        }
-        float* g1 = (h ? g.dA1p : g.dR1p) + q * 64;
-        g1[l] = d1_lo;
-        g1[l + 32] = d1_hi;
-        if (h == 0) {
-          g.dR3[q * 32 + l] = dR3;
-          g.E32[q * 32 + l] = e32;
-        } else {
-          g.dA2p[q * 32 + l] = dA2p;
-        }
-        if (lane == 0) g.dq[q] = dq;
-      }
-    }
+    for (int t = 1; t < ET; ++t)
+      if (wv >= 2 && 16 * t < N * (N - 1)) smb_edge_phase_mfma(L, el[t], smb_edge_load(a, el[t], wv == 2 ? 1 : 0), g, elu, NE4);
     sm_stamp(cf, 3);
     WG_SYNC();
     sm_stamp(cf, 4);
     // ---- Q2: node rows: first edge layer, self-dynamics, encoder backwards ------------------------------------------
     if (node) {
-      // dP[r][c], c = lane + 64 g: relation / attention, r as first (s_i) or second (s_j) argument
-      float dp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      for (int j = 0; j < N; ++j) {
-        if (j == r) continue;
-        const float* e1 = L.EG + (r * N + j) * 128;
-        const float* e2 = L.EG + (j * N + r) * 128;
-        dp[0] += e1[lane];
-        dp[1] += e2[lane];
-        dp[2] += e1[64 + lane];
-        dp[3] += e2[64 + lane];
-      }
-      float* dpr = L.DP + r * 256;
+      float dS_edge = 0.0f;
+      // a row's dP (256 wide) and its product with the edge-first weights take all 64 lanes: the wave's rows one after the other
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        dpr[lane + 64 * gq] = dp[gq];
-        g.dP[r * 256 + lane + 64 * gq] = dp[gq];
-      }
-      sm_stamp(cf, 7);
-      SmW<8> wa = sm_wload<8>(L.W + W_S1, 32, l);
-      // dS from the edge layers: dP (256) W_ef (256 x 32); the two half-waves split the 256 terms
-      v2f s0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f};
-      // four rounds of 8 weight + 8 operand reads, all of a round in flight before its FMAs (at 4 per round the loop was
-      // LDS latency: 3.0 k cycles of a 15.4 k step, profiles/r02_loop_stamps_bwd.txt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 w[8], x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          w[u] = *reinterpret_cast<const float4*>(L.W + W_EF + ((32 * h + 8 * q + u) * 32 + l) * 4);
-          x[u] = *reinterpret_cast<const float4*>(dpr + 128 * h + 4 * (8 * q + u));
+      for (int rq = 0; rq < RP; ++rq) {
+        const int rw = wv + 4 * rq;
+        if (rq > 0 && rw >= N) break;
+        // dP[rw][c], c = lane + 64 g: relation / attention, rw as first (s_i) or second (s_j) argument
+        float dp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < N; ++j) {
+          if (j == rw) continue;
+          const float* e1 = L.EG + (rw * N + j) * 128;
+          const float* e2 = L.EG + (j * N + rw) * 128;
+          dp[0] += e1[lane];
+          dp[1] += e2[lane];
+          dp[2] += e1[64 + lane];
+          dp[3] += e2[64 + lane];
         }
+        float* dpr = L.DP + rw * 256;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          s0 = pk_fma(v2f{w[u].x, w[u].y}, v2f{x[u].x, x[u].y}, s0);
-          s1 = pk_fma(v2f{w[u].z, w[u].w}, v2f{x[u].z, x[u].w}, s1);
+        for (int gq = 0; gq < 4; ++gq) {
+          dpr[lane + 64 * gq] = dp[gq];
+          g.dP[rw * 256 + lane + 64 * gq] = dp[gq];
         }
+        sm_stamp(cf, 7);
+        // dS from the edge layers: dP (256) W_ef (256 x 32); the two half-waves split the 256 terms
+        v2f s0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f};
+        // four rounds of 8 weight + 8 operand reads, all of a round in flight before its FMAs (at 4 per round the loop was
+        // LDS latency: 3.0 k cycles of a 15.4 k step, profiles/r02_loop_stamps_bwd.txt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 w[8], x[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            w[u] = *reinterpret_cast<const float4*>(L.W + W_EF + ((32 * h + 8 * q + u) * 32 + l) * 4);
+            x[u] = *reinterpret_cast<const float4*>(dpr + 128 * h + 4 * (8 * q + u));
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            s0 = pk_fma(v2f{w[u].x, w[u].y}, v2f{x[u].x, x[u].y}, s0);
+            s1 = pk_fma(v2f{w[u].z, w[u].w}, v2f{x[u].z, x[u].w}, s1);
+          }
+        }
+        s0 += s1;
+        float de = s0.x + s0.y;
+        de += sm_from_lane(de, lane ^ 32);
+        if (RP == 1 || rq == h) dS_edge = de;           // element l of row rw: kept by the half-wave that carries the row
       }
-      s0 += s1;
-      float dS_edge = s0.x + s0.y;
-      dS_edge += sm_from_lane(dS_edge, lane ^ 32);
       sm_stamp(cf, 8);
+      SmW<8> wa = sm_wload<8>(L.W + W_S1, 32, l);
       // b11. self.1:  SD = H1 W^T + b + H1
       SmW<8> wb = sm_wload<8>(L.W + W_S0, 32, l);
       const float dH1p = (sm_dotw<8>(wa, dSD) + dSD) * dphi_from_out(cur.H1, elu);
@@ -451,14 +400,14 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
       if (l < 2) {
         float dd = 0.0f;
         for (int j = 0; j < N; ++j)
-          if (j != r) dd += 2.0f * (pos[r * 4 + l] - pos[j * 4 + l]) * ((L.DD[r * N + j] + L.DD[16 + r * N + j]) + (L.DD[j * N + r] + L.DD[16 + j * N + r]));
+          if (j != rs) dd += 2.0f * (pos[rs * 4 + l] - pos[j * 4 + l]) * ((L.DD[rs * N + j] + L.DD[NE4 + rs * N + j]) + (L.DD[j * N + rs] + L.DD[NE4 + j * N + rs]));
         tot += dd;
       }
       const bool raw = l < lim_enc;
       const float dEnc = raw ? 0.0f : tot;
       // b13. encoder
       const float dsin = sm_dotw<8>(wa, dEnc) + (raw ? tot : 0.0f);
-      if (lane < 32) {
+      if (own) {
         g.dH1p[r * 32 + l] = dH1p;
         g.dEnc[r * 32 + l] = dEnc;
         if (l >= 16 && l < sin_dim) dextra[o * E + (l - 16)] = dsin;
@@ -470,7 +419,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
   if (node) {
     const float shifted = sm_from_lane(car, (lane + 62) & 63);      // all lanes take part: a bpermute reads 0 from inactive source lanes
     float* dst = ts0 == 0 ? dz1 : carry;
-    if (lane < 18) dst[((size_t)b * N + r) * 18 + lane] = lane < 2 ? 0.0f : shifted;
+    if (l < 18 && own) dst[((size_t)b * N + r) * 18 + l] = l < 2 ? 0.0f : shifted;
   }
 }
 
