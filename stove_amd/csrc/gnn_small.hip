@@ -213,6 +213,35 @@ __device__ __forceinline__ void sm_mfma_layer(const SmMW<KT>& m, const smf4 (&x)
   acc[0] += p0;
   acc[1] += p1;
 }
+// The same for ET column tiles at once (the 30 edges of six objects are two): one set of A operands, the tiles' chains interleaved
+// MFMA by MFMA -- 4 ET independent accumulators, so the chain is bound by the issue rate instead of the accumulator latency.
+template <int KT, int ET>
+__device__ __forceinline__ void sm_mfma_layer_tiles(const SmMW<KT>& m, const smf4 (&x)[ET][KT], smf4 (&acc)[ET][2]) {
+  static_assert(KT % 2 == 0, "input tiles are taken in pairs");
+  smf4 p0[ET], p1[ET];
+#pragma unroll
+  for (int c = 0; c < ET; ++c) p0[c] = p1[c] = smf4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int t = 0; t < KT; t += 2) {
+    const float4 a0 = m.w[t][0], a1 = m.w[t][1], b0 = m.w[t + 1][0], b1 = m.w[t + 1][1];
+    const float a0s[4] = {a0.x, a0.y, a0.z, a0.w}, a1s[4] = {a1.x, a1.y, a1.z, a1.w};
+    const float b0s[4] = {b0.x, b0.y, b0.z, b0.w}, b1s[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < ET; ++c) {
+        acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0s[e], x[c][t][e], acc[c][0], 0, 0, 0);
+        acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1s[e], x[c][t][e], acc[c][1], 0, 0, 0);
+        p0[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0s[e], x[c][t + 1][e], p0[c], 0, 0, 0);
+        p1[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1s[e], x[c][t + 1][e], p1[c], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < ET; ++c) {
+    acc[c][0] += p0[c];
+    acc[c][1] += p1[c];
+  }
+}
 // The general form (backward: transposed weight images with ROWS = the layer's input width as output rows): OT output tiles,
 // one accumulation chain each, KT input tiles; weights fetched inside.  Wl = [K/4][ROWS][4] LDS image.
 template <int KT, int OT>
@@ -335,70 +364,90 @@ __device__ __forceinline__ void sm_edge_prefetch(const SmLds& L, SmEdgePre& pre)
   }
 }
 
-// One 16-column tile of the relation (wave 3, h = 0) / attention (wave 2, h = 1) chain: columns = edges (i -> j, i != j)
-template <bool SAVE>
-__device__ __forceinline__ void sm_edge_chain_tile(const SmLds& L, const SmCfg& cf, const SmAct& act, const SmEdgeLane& el,
-                                                   const SmEdgePre& pre, int h) {
+// The relation (wave 3, h = 0) / attention (wave 2, h = 1) chain: columns = edges (i -> j, i != j), ET tiles of 16 columns taken
+// through every layer together (a kernel built for ET tiles is only used where the last tile has edges in it)
+template <bool SAVE, int ET>
+__device__ __forceinline__ void sm_edge_chain(const SmLds& L, const SmCfg& cf, const SmAct& act, const SmEdgeLane (&el)[ET],
+                                              const SmEdgePre& pre, int h) {
   const int g = lane_id() >> 4;
   const float* V = L.V;
-  const float dx = L.POS[el.pos_i] - L.POS[el.pos_j], dy = L.POS[el.pos_i + 1] - L.POS[el.pos_j + 1];
-  const float d = dx * dx + dy * dy;
   float* s1p = h ? act.A1 : act.R1;
   float* s2p = h ? act.A2 : act.R2;
-  smf4 x1[4];
+  float d[ET];
+  smf4 x1[ET][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const smf4 a = sm_ld4(L.PR + el.pi + 16 * t), b = sm_ld4(L.PR + el.pj + 16 * t);
-    x1[t] = sm_phi4(a + b + pre.wd[t] * d + pre.b0[t], cf.elu);
+  for (int c = 0; c < ET; ++c) {
+    const float dx = L.POS[el[c].pos_i] - L.POS[el[c].pos_j], dy = L.POS[el[c].pos_i + 1] - L.POS[el[c].pos_j + 1];
+    d[c] = dx * dx + dy * dy;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const smf4 a = sm_ld4(L.PR + el[c].pi + 16 * t), b = sm_ld4(L.PR + el[c].pj + 16 * t);
+      x1[c][t] = sm_phi4(a + b + pre.wd[t] * d[c] + pre.b0[t], cf.elu);
+    }
   }
   sm_stamp(cf, 8);
-  smf4 acc[2], a2[2];
+  smf4 acc[ET][2], a2[ET][2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) acc[t] = pre.bl2[t];
-  sm_mfma_layer<4>(pre.w1, x1, acc);
-  if (SAVE && el.valid) {          // the stores of the layer input go out behind the MFMAs that consumed it
+  for (int c = 0; c < ET; ++c)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) sm_st4(s1p + el.s64 + 16 * t, x1[t]);
+    for (int t = 0; t < 2; ++t) acc[c][t] = pre.bl2[t];
+  sm_mfma_layer_tiles<4, ET>(pre.w1, x1, acc);
+  if (SAVE) {          // the stores of the layer input go out behind the MFMAs that consumed it
+#pragma unroll
+    for (int c = 0; c < ET; ++c)
+      if (el[c].valid) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sm_st4(s1p + el[c].s64 + 16 * t, x1[c][t]);
+      }
   }
   sm_stamp(cf, 9);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) a2[t] = sm_phi4(acc[t], cf.elu);
+  for (int c = 0; c < ET; ++c)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) a2[c][t] = sm_phi4(acc[c][t], cf.elu);
   sm_stamp(cf, 10);
   if (h == 0) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) acc[t] = pre.bl3[t];
-    sm_mfma_layer<2>(pre.w2, a2, acc);
-    sm_stamp(cf, 11);
-    if (el.valid) {
+    for (int c = 0; c < ET; ++c)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const smf4 r3 = acc[t] + a2[t];
-        sm_st4(L.R3 + el.e32 + 16 * t, r3);
-        if (SAVE) {
-          sm_st4(act.R3 + el.s32 + 16 * t, r3);
-          sm_st4(s2p + el.s32 + 16 * t, a2[t]);
+      for (int t = 0; t < 2; ++t) acc[c][t] = pre.bl3[t];
+    sm_mfma_layer_tiles<2, ET>(pre.w2, a2, acc);
+    sm_stamp(cf, 11);
+#pragma unroll
+    for (int c = 0; c < ET; ++c)
+      if (el[c].valid) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const smf4 r3 = acc[c][t] + a2[c][t];
+          sm_st4(L.R3 + el[c].e32 + 16 * t, r3);
+          if (SAVE) {
+            sm_st4(act.R3 + el[c].s32 + 16 * t, r3);
+            sm_st4(s2p + el[c].s32 + 16 * t, a2[c][t]);
+          }
         }
       }
-    }
   } else {
-    float p = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int c = 0; c < ET; ++c) {
+      float p = 0.0f;
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) p = fmaf(pre.bl3[t][s2], a2[t][s2], p);
-    p += __shfl_xor(p, 16);
-    p += __shfl_xor(p, 32);
-    const float att = __expf(p + V[V_BA2]);
-    if (el.valid) {
-      if (SAVE) {
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) sm_st4(s2p + el.s32 + 16 * t, a2[t]);
-      }
-      if (g == 0) {
-        L.ATT[el.e] = att;
+        for (int s2 = 0; s2 < 4; ++s2) p = fmaf(pre.bl3[t][s2], a2[c][t][s2], p);
+      p += __shfl_xor(p, 16);
+      p += __shfl_xor(p, 32);
+      const float att = __expf(p + V[V_BA2]);
+      if (el[c].valid) {
         if (SAVE) {
-          act.ATT[el.s1] = att;
-          act.DIST[el.s1] = d;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) sm_st4(s2p + el[c].s32 + 16 * t, a2[c][t]);
+        }
+        if (g == 0) {
+          L.ATT[el[c].e] = att;
+          if (SAVE) {
+            act.ATT[el[c].s1] = att;
+            act.DIST[el[c].s1] = d[c];
+          }
         }
       }
     }
@@ -438,10 +487,7 @@ __device__ __forceinline__ void sm_edge_phase_mfma(const SmLds& L, const SmCfg& 
     return;
   }
   if ((wv != 2 && wv != 3) || cf.N < 2) return;
-  // the tiles are independent chains through the same weights: unrolled, their MFMAs interleave
-#pragma unroll
-  for (int tile = 0; tile < ET; ++tile)
-    if (tile == 0 || 16 * tile < cf.N * (cf.N - 1)) sm_edge_chain_tile<SAVE>(L, cf, act, el[tile], pre, wv == 2 ? 1 : 0);
+  sm_edge_chain<SAVE, ET>(L, cf, act, el, pre, wv == 2 ? 1 : 0);
 }
 
 // One GNN step.  The lane's node row is r = wave (+ 4 for the upper half-wave of a two-rows-per-wave kernel); lane k of the half

@@ -119,71 +119,112 @@ __device__ __forceinline__ SmBEdgeIn smb_edge_load(const SmAct& a, const SmEdgeL
   in.att = a.ATT[el.s1];
   return in;
 }
-__device__ __forceinline__ void smb_edge_phase_mfma(const SmBLds& L, const SmEdgeLane& el, const SmBEdgeIn& in, const SmDy& g, int elu, int dd_stride) {
+// OT output tiles x ET column tiles through the transposed image Wl = [K/4][16 OT][4]: one fetch of the A operands, the column
+// tiles' chains interleaved (see sm_mfma_layer_tiles, gnn_small.hip)
+template <int KT, int OT, int ET>
+__device__ __forceinline__ void smb_mfma_layer_t(const float* Wl, const smf4 (&x)[ET][KT], smf4 (&acc)[ET][OT], int lane) {
+  constexpr int ROWS = 16 * OT;
+  const int i = lane & 15, g = lane >> 4;
+  float4 w[KT][OT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int u = 0; u < OT; ++u) w[t][u] = *reinterpret_cast<const float4*>(Wl + ((4 * t + g) * ROWS + 16 * u + i) * 4);
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int u = 0; u < OT; ++u) {
+        const float wv = e == 0 ? w[t][u].x : (e == 1 ? w[t][u].y : (e == 2 ? w[t][u].z : w[t][u].w));
+#pragma unroll
+        for (int c = 0; c < ET; ++c) acc[c][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, x[c][t][e], acc[c][u], 0, 0, 0);
+      }
+  }
+}
+template <int ET>
+__device__ __forceinline__ void smb_edge_phase_mfma(const SmBLds& L, const SmEdgeLane (&el)[ET], const SmBEdgeIn (&in)[ET], const SmDy& g,
+                                                    int elu, int dd_stride) {
   const int wv = wave_id(), lane = lane_id(), gq = lane >> 4;
   if (wv < 2) return;
   const int h = wv == 2 ? 1 : 0;
   const float* V = L.V;
-  smf4 dsd[2];
-  float pq = 0.0f;
+  smf4 dsd[ET][2], y[ET][2], d1[ET][4];
+  float dq[ET];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    dsd[t] = sm_ld4(L.DSD + el.i32 + 16 * t);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) pq = fmaf(dsd[t][e], in.r3[t][e], pq);
-  }
-  pq += __shfl_xor(pq, 16);
-  pq += __shfl_xor(pq, 32);
-  const float dq = pq * in.att;
-  smf4 y[2], d1[4];
-  if (h == 0) {
-    smf4 dr3[2], acc[2];
+  for (int c = 0; c < ET; ++c) {
+    float pq = 0.0f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      dr3[t] = dsd[t] * in.att;
-      acc[t] = smf4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-    sm_mfma_layer_t<2, 2>(L.W + W_R2, dr3, acc, lane);
+      dsd[c][t] = sm_ld4(L.DSD + el[c].i32 + 16 * t);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) y[t] = (acc[t] + dr3[t]) * sm_dphi4(in.y2[t], elu);
-    if (el.valid) {
+      for (int e = 0; e < 4; ++e) pq = fmaf(dsd[c][t][e], in[c].r3[t][e], pq);
+    }
+    pq += __shfl_xor(pq, 16);
+    pq += __shfl_xor(pq, 32);
+    dq[c] = pq * in[c].att;
+  }
+  if (h == 0) {
+    smf4 dr3[ET][2], acc[ET][2];
+#pragma unroll
+    for (int c = 0; c < ET; ++c)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        sm_st4(g.dR3 + el.s32 + 16 * t, dr3[t]);
-        sm_st4(g.E32 + el.s32 + 16 * t, y[t]);
+        dr3[c][t] = dsd[c][t] * in[c].att;
+        acc[c][t] = smf4{0.0f, 0.0f, 0.0f, 0.0f};
       }
-      if (gq == 0) g.dq[el.s1] = dq;
+    smb_mfma_layer_t<2, 2, ET>(L.W + W_R2, dr3, acc, lane);
+#pragma unroll
+    for (int c = 0; c < ET; ++c) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) y[c][t] = (acc[c][t] + dr3[c][t]) * sm_dphi4(in[c].y2[t], elu);
+      if (el[c].valid) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          sm_st4(g.dR3 + el[c].s32 + 16 * t, dr3[c][t]);
+          sm_st4(g.E32 + el[c].s32 + 16 * t, y[c][t]);
+        }
+        if (gq == 0) g.dq[el[c].s1] = dq[c];
+      }
     }
   } else {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) y[t] = sm_ld4(V + V_WA2 + 16 * t + 4 * gq) * dq * sm_dphi4(in.y2[t], elu);
-    if (el.valid) {
+    for (int c = 0; c < ET; ++c) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) sm_st4(g.dA2p + el.s32 + 16 * t, y[t]);
+      for (int t = 0; t < 2; ++t) y[c][t] = sm_ld4(V + V_WA2 + 16 * t + 4 * gq) * dq[c] * sm_dphi4(in[c].y2[t], elu);
+      if (el[c].valid) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) sm_st4(g.dA2p + el[c].s32 + 16 * t, y[c][t]);
+      }
     }
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u) d1[u] = smf4{0.0f, 0.0f, 0.0f, 0.0f};
-  sm_mfma_layer_t<2, 4>(L.W + (h ? W_A1 : W_R1), y, d1, lane);
-  float dd = 0.0f;
+  for (int c = 0; c < ET; ++c)
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    d1[u] = d1[u] * sm_dphi4(in.x1[u], elu);
-    const smf4 wd = sm_ld4(V + (h ? V_WDA : V_WDR) + 16 * u + 4 * gq);
+    for (int u = 0; u < 4; ++u) d1[c][u] = smf4{0.0f, 0.0f, 0.0f, 0.0f};
+  smb_mfma_layer_t<2, 4, ET>(L.W + (h ? W_A1 : W_R1), y, d1, lane);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dd = fmaf(d1[u][e], wd[e], dd);
-  }
-  dd += __shfl_xor(dd, 16);
-  dd += __shfl_xor(dd, 32);
-  if (el.valid) {
-    float* eg = L.EG + el.e * 128 + 64 * h + 4 * gq;
-    float* g1 = (h ? g.dA1p : g.dR1p) + el.s64;
+  for (int c = 0; c < ET; ++c) {
+    float dd = 0.0f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      sm_st4(eg + 16 * u, d1[u]);
-      sm_st4(g1 + 16 * u, d1[u]);
+      d1[c][u] = d1[c][u] * sm_dphi4(in[c].x1[u], elu);
+      const smf4 wd = sm_ld4(V + (h ? V_WDA : V_WDR) + 16 * u + 4 * gq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dd = fmaf(d1[c][u][e], wd[e], dd);
     }
-    if (gq == 0) L.DD[dd_stride * h + el.e] = dd;
+    dd += __shfl_xor(dd, 16);
+    dd += __shfl_xor(dd, 32);
+    if (el[c].valid) {
+      float* eg = L.EG + el[c].e * 128 + 64 * h + 4 * gq;
+      float* g1 = g.dR1p + (h ? g.dA1p - g.dR1p : (ptrdiff_t)0) + el[c].s64;      // (a select between the two pointers went through scratch memory)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sm_st4(eg + 16 * u, d1[c][u]);
+        sm_st4(g1 + 16 * u, d1[c][u]);
+      }
+      if (gq == 0) L.DD[dd_stride * h + el[c].e] = dd;
+    }
   }
 }
 
@@ -252,9 +293,12 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
       const SmAct an = sm_act2(aseq, N, Ts, ts - 1);
       nin = smb_node_load(an, r, l, o - N, eps, zsup, zsstd, dz, dzdyn, dmean, dstd, dpred);
     }
-    // this wave's edges of the step (first column tile): saved forward values, in flight across the node phase
-    SmBEdgeIn ein{};
-    if (wv >= 2) ein = smb_edge_load(a, el[0], wv == 2 ? 1 : 0);
+    // this wave's edges of the step: saved forward values, in flight across the node phase
+    SmBEdgeIn ein[ET] = {};
+    if (wv >= 2) {
+#pragma unroll
+      for (int t = 0; t < ET; ++t) ein[t] = smb_edge_load(a, el[t], wv == 2 ? 1 : 0);
+    }
     float* pos = L.POS + (ts & 1) * (NMX * 4);
     float dS_o0 = 0.0f, dSD = 0.0f, pc = 0.0f;
     // ---- Q4: node rows: epilogue, output and affector MLPs backwards ----------------------------------------------
@@ -332,11 +376,8 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     sm_stamp(cf, 1);
     WG_SYNC();
     sm_stamp(cf, 2);
-    // ---- Q3: edges as the columns of the relation chain (wave 3) / the attention chain (wave 2), one 16-column tile at a time
-    smb_edge_phase_mfma(L, el[0], ein, g, elu, NE4);
-#pragma unroll
-    for (int t = 1; t < ET; ++t)
-      if (wv >= 2 && 16 * t < N * (N - 1)) smb_edge_phase_mfma(L, el[t], smb_edge_load(a, el[t], wv == 2 ? 1 : 0), g, elu, NE4);
+    // ---- Q3: edges as the columns of the relation chain (wave 3) / the attention chain (wave 2), all column tiles together
+    smb_edge_phase_mfma<ET>(L, el, ein, g, elu, NE4);
     sm_stamp(cf, 3);
     WG_SYNC();
     sm_stamp(cf, 4);
