@@ -178,11 +178,12 @@ int stove_gnn_debug_stamps(const float* s_in, const float* params, const float* 
  * t=skip..T-1; eps (B,Ts,N,18) standard-normal draws; extra (B,Ts,N,sin_dim-16) or NULL.
  * outputs (B,Ts,N,.): z 18, zdyn 16, zdstd 16, mean 18, std 18, pred 32 (NULL to skip). */
 /* act: saved activations (stove_dynloop_act_floats() floats, ~9 KB per sequence-step at N=3), written by the forward and
- * read by the backward.  With 2 <= N <= 4 objects the small-graph kernels run (one wave per node row, csrc/gnn_small*.hip):
- * act is then REQUIRED by the backward (the layout is a set of per-sequence streams), and the backward consists of a
- * T-serial data-gradient launch plus a weight-gradient launch over the streams; its workspace is sized by
- * stove_dynloop_bwd_ws_bytes_ts.  For N > 4 (MFMA kernels of csrc/gnn.hip) act may be NULL in both calls: the backward
- * then recomputes each step.  STOVE_SMALL_BWD=0 in the environment selects the MFMA backward for small graphs too. */
+ * read by the backward.  With 2 <= N <= 6 objects the small-graph kernels run (csrc/gnn_small*.hip: one wave per node row up to
+ * four objects, one HALF-wave per node row and two tiles of edge columns for five and six): act is then REQUIRED by the backward
+ * (the layout is a set of per-sequence streams), and the backward consists of a T-serial data-gradient launch plus a
+ * weight-gradient launch over the streams; its workspace is sized by stove_dynloop_bwd_ws_bytes_ts.  For N > 6 (MFMA kernels of
+ * csrc/gnn.hip) act may be NULL in both calls: the backward then recomputes each step.  STOVE_SMALL_BWD=0 in the environment
+ * selects the MFMA backward for small graphs too (and, for five and six objects, the MFMA forward with it). */
 size_t stove_dynloop_act_floats(int B, int Ts, int N);
 int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                       const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred,
@@ -211,7 +212,7 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
  * previous piece left in z.  Backward: pieces are called from the last to the first; the gradient that flows from step ts0 into the
  * state before it goes through `carry` (B, N, 18 floats, written when ts0 > 0, read when ts1 < Ts); dz1 is written by the piece with
  * ts0 == 0, which also runs the weight-gradient pass (g_params, on param_stream) over the streams of ALL steps.  Small-graph kernels
- * only (stove_dynloop_range_ok(N) != 0: 2 <= N <= 4 and the streamed backward enabled); otherwise only the whole range is accepted. */
+ * only (stove_dynloop_range_ok(N) != 0: 2 <= N <= 6 and the streamed backward enabled); otherwise only the whole range is accepted. */
 int stove_dynloop_range_ok(int N);
 int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                             const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred, float* act,

@@ -441,14 +441,19 @@ def test_elbo_assembly_against_torch():
 
 
 @pytest.mark.parametrize('nonlinear', ['relu', 'leaky_relu'])      # the second one selects F.elu (the reference's quirk, dynamics.py:107-110)
-@pytest.mark.parametrize('n_obj', [2, 3, 4])
-def test_small_graph_recursion_matches_step_kernels(n_obj, nonlinear):
-    """The small-graph time loop (csrc/gnn_small*.hip: N = 2 and 4 have no goldens) against the host loop over the
-    single-step MFMA kernel + PyTorch autograd: ELBO, every gradient, and the rollout."""
+@pytest.mark.parametrize('n_obj,ac', [(2, False), (3, False), (4, False), (5, False), (6, False), (5, True), (6, True)])
+def test_small_graph_recursion_matches_step_kernels(n_obj, ac, nonlinear):
+    """The small-graph time loop (csrc/gnn_small*.hip: N = 2, 4 and 5 have no goldens; five and six objects run two node rows
+    per wave and two tiles of edge columns; `ac`: action-conditioned, 23 inputs per node and the reward head) against the host
+    loop over the single-step MFMA kernel + PyTorch autograd: ELBO, every gradient, and the rollout."""
+    from stove_amd import _lib
     from stove_amd.video_prediction.stove import Stove
+    assert _lib.load().stove_dynloop_range_ok(n_obj) == 1          # the kernels under test are the ones that run
     n, T = 3, 6
     g = torch.Generator(device='cpu').manual_seed(11)
     x = (torch.rand(n, T, 3, 32, 32, generator=g) < 0.04).float().to(DEV)
+    extra = dict(action_conditioned=True, action_space=9, debug_core_appearance=True) if ac else {}
+    actions = torch.nn.functional.one_hot(torch.randint(0, 9, (n, T), generator=g), 9).float().to(DEV) if ac else None
     noise = {}
 
     def noise_fn(kind, shape):
@@ -458,12 +463,16 @@ def test_small_graph_recursion_matches_step_kernels(n_obj, nonlinear):
         return noise[key]
     res = []
     for fused in (True, False):
-        st = fill_analytic(Stove(make_cfg(num_obj=n_obj, fused_dynamics=fused, debug_match_objects='greedy', debug_nonlinear=nonlinear))).to(DEV)
+        st = fill_analytic(Stove(make_cfg(num_obj=n_obj, fused_dynamics=fused, debug_match_objects='greedy', debug_nonlinear=nonlinear, **extra))).to(DEV)
         st.noise_fn = noise_fn
-        elbo, prop, _ = st(x, 0, None)
-        (-elbo).backward()
+        elbo, prop, rewards = st(x, 0, actions)
+        loss = -elbo
+        if ac:
+            loss = loss + 3.0 * (rewards ** 2).sum()
+        loss.backward()
         with torch.no_grad():
-            zp, _ = st.rollout(prop['z'][:, -1], num=7)
+            zp, _ = st.rollout(prop['z'][:, -1], num=7, actions=actions[:, :4] if ac else None,
+                               appearance=prop['obj_appearances'][:, -1] if ac else None)
         res.append((float(elbo.detach()), {k: p.grad.clone() for k, p in st.named_parameters() if p.grad is not None}, zp))
     (e1, g1, z1), (e2, g2, z2) = res
     assert abs(e1 - e2) < 1e-5 * abs(e2), (e1, e2)
