@@ -739,7 +739,8 @@ __global__ __launch_bounds__(128 * R) void objspn_tablegrad_k(
 // reads of the wide kernel, out of the MALL, at a time when HBM is nearly idle.  Same fixed summation order per output as
 // objspn_tablegrad_k over the same chunk count -> bitwise reproducible (the chunking differs between the two kernels).
 template <int R, int S, int G, int K>
-__global__ __launch_bounds__(256, 4) void objspn_tablegrad_under_k(
+__global__ __launch_bounds__(256, 3) void objspn_tablegrad_under_k(      // <= 168 registers: the recursion's backward (N <= 4) holds at most 306 of a SIMD's 512
+   
     const float* __restrict__ xw, const float* __restrict__ Dscr, const float* __restrict__ Sscr, const float* __restrict__ Rscr,
     const int* __restrict__ scope, float* __restrict__ part_c, float* __restrict__ part_w, float* __restrict__ part_r,
     int n_batches, int n_chunks, const float* __restrict__ scale) {
@@ -750,6 +751,7 @@ __global__ __launch_bounds__(256, 4) void objspn_tablegrad_under_k(
   extern __shared__ __attribute__((aligned(16))) float tg_lds[];
   float* tileP = tg_lds;                         // [2 D][LD]: row 2 p = x of pixel p, 2 p + 1 = w -- ALL the LDS there is next
                                                  // to the recursion's 107 KB: the sum-node rows are read from global memory
+  float* scl = tileP + 2 * D * LD;               // [64] dL/d root of the batch's samples
   const int lane = lane_id(), wv = wave_id();
   // workgroup -> (chunk c, replica r).  The R workgroups of a chunk stage the SAME glimpse tiles: when the chunk count is a multiple
   // of 8 they are placed on one XCD (workgroup ids congruent mod 8 share an L2) and start together, so five of the six tile
@@ -787,6 +789,9 @@ __global__ __launch_bounds__(256, 4) void objspn_tablegrad_under_k(
 
   for (int b = c; b < n_batches; b += n_chunks) {
     tg_stage_tile<D, LD, 256>(tileP, xw + (size_t)b * (D * 2 * 64), scale, b * 64);
+    // the batch's 64 scale values go through LDS as well: gamma and rho take them from there (as global loads inside this
+    // one-wave-per-SIMD chain they stretched the kernel 514 -> 570 us)
+    if (threadIdx.x < 16) *reinterpret_cast<float4*>(scl + 4 * threadIdx.x) = tg_scale4(scale, b * 64 + 4 * threadIdx.x);
     __syncthreads();
     // ---- leaf coefficients of leaf L: A = features of its pixels, B = its gradients
     {
@@ -821,7 +826,7 @@ __global__ __launch_bounds__(256, 4) void objspn_tablegrad_under_k(
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         const float4 g4 = *reinterpret_cast<const float4*>(gp + 4 * h);
-        const float4 s4 = tg_scale4(scale, b * 64 + 16 * kk + 4 * h);
+        const float4 s4 = *reinterpret_cast<const float4*>(scl + 16 * kk + 4 * h);
         const float gv[4] = {g4.x * s4.x, g4.y * s4.y, g4.z * s4.z, g4.w * s4.w};
         float pr[TWH][4];
 #pragma unroll
@@ -846,7 +851,7 @@ __global__ __launch_bounds__(256, 4) void objspn_tablegrad_under_k(
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         const float4 q4 = rho[h], a4 = ea[h], b4 = eb[h];
-        const float4 s4 = tg_scale4(scale, b * 64 + 16 * kk + 4 * h);
+        const float4 s4 = *reinterpret_cast<const float4*>(scl + 16 * kk + 4 * h);
         acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.x * s4.x * b4.x, a4.x, acc_r, 0, 0, 0);
         acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.y * s4.y * b4.y, a4.y, acc_r, 0, 0, 0);
         acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.z * s4.z * b4.z, a4.z, acc_r, 0, 0, 0);
@@ -1070,7 +1075,7 @@ int objspn_backward_params(const float* xw, const int* scope, float* g_coef, flo
   int chunks = nb < kObjChunks ? nb : kObjChunks;
   if (under) {
     // one resident round next to the recursion's workgroups: 6 workgroups (replicas) per chunk, one per CU
-    constexpr int kTgLdsU = 2 * 100 * 68 * (int)sizeof(float);      // + the recursion's 106 880 B + 512 B < 160 KB
+    constexpr int kTgLdsU = (2 * 100 * 68 + 64) * (int)sizeof(float);      // + the recursion's 106 880 B + 512 B < 160 KB
     if (chunks > kObjChunks / 6) chunks = (kObjChunks / 6) & ~7;      // 40: a multiple of 8 (XCD-aware placement), 240 workgroups
     int rc = (int)hipFuncSetAttribute((const void*)objspn_tablegrad_under_k<6, 25, 10, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, kTgLdsU);
     if (rc) return rc;
