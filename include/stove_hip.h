@@ -182,8 +182,7 @@ int stove_gnn_debug_stamps(const float* s_in, const float* params, const float* 
  * four objects, one HALF-wave per node row and two tiles of edge columns for five and six): act is then REQUIRED by the backward
  * (the layout is a set of per-sequence streams), and the backward consists of a T-serial data-gradient launch plus a
  * weight-gradient launch over the streams; its workspace is sized by stove_dynloop_bwd_ws_bytes_ts.  For N > 6 (MFMA kernels of
- * csrc/gnn.hip) act may be NULL in both calls: the backward then recomputes each step.  STOVE_SMALL_BWD=0 in the environment
- * selects the MFMA backward for small graphs too (and, for five and six objects, the MFMA forward with it). */
+ * csrc/gnn.hip) act may be NULL in both calls: the backward then recomputes each step. */
 size_t stove_dynloop_act_floats(int B, int Ts, int N);
 int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                       const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred,

@@ -465,19 +465,8 @@ int stove_gnn_debug_stamps(const float* s_in, const float* params, const float* 
 static long long* g_sm_stamps = nullptr;
 void stove_debug_set_stamps(long long* device_buffer) { g_sm_stamps = device_buffer; }
 
-// STOVE_SMALL_BWD=0 keeps the MFMA backward of gnn.hip for small graphs too (A/B switch of the small-graph backward)
-static int small_bwd_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("STOVE_SMALL_BWD");
-    v = (e != nullptr && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
-// The small-graph recursion (gnn_small*.hip): kernels built for up to four objects (one node row per wave) and for up to six
-// (two).  Five and six objects need its streams-layout backward: with STOVE_SMALL_BWD=0 they stay on the general kernels.
-static bool small_graph(int N) { return N >= 2 && (N <= 4 || (N <= 6 && small_bwd_enabled())); }
+// The small-graph recursion (gnn_small*.hip): kernels built for up to four objects (one node row per wave) and for up to six (two).
+static bool small_graph(int N) { return N >= 2 && N <= 6; }
 
 size_t stove_dynloop_act_floats(int B, int Ts, int N) {
   const int g = gnn_group_for(B, N);
@@ -497,7 +486,7 @@ int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, co
                                  pos_var, vel_std, lat_std, 0, Ts, stream);
 }
 
-int stove_dynloop_range_ok(int N) { return (small_graph(N) && small_bwd_enabled()) ? 1 : 0; }
+int stove_dynloop_range_ok(int N) { return small_graph(N) ? 1 : 0; }
 
 int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                             const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred, float* act,
@@ -530,7 +519,7 @@ int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zss
     if (elu) STOVE_LOOP_LAUNCH_E(SAVE_, true);        \
     else STOVE_LOOP_LAUNCH_E(SAVE_, false);           \
   } while (0)
-    if (g_sm_stamps != nullptr && act != nullptr && small_bwd_enabled() && !elu && N == 3) {      // tools/loop_stamps.py
+    if (g_sm_stamps != nullptr && act != nullptr && !elu && N == 3) {      // tools/loop_stamps.py
       int rc = (int)hipFuncSetAttribute((const void*)dyn_loop_fwd_small_k<2, 4, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)(SmShape<4>::kLdsFloats * sizeof(float)));
       if (rc) return rc;
@@ -538,17 +527,7 @@ int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zss
                    z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu, kc, g_sm_stamps,
                    ts0, ts1);
     } else if (act != nullptr) {
-      if (small_bwd_enabled()) {
-        STOVE_LOOP_LAUNCH(2);
-      } else {                        // block-layout activations for the general backward: up to four objects (small_graph)
-        if (elu) {
-          if (N == 3) STOVE_LOOP_LAUNCH_N(1, 4, true, 3);
-          else STOVE_LOOP_LAUNCH_N(1, 4, true, 0);
-        } else {
-          if (N == 3) STOVE_LOOP_LAUNCH_N(1, 4, false, 3);
-          else STOVE_LOOP_LAUNCH_N(1, 4, false, 0);
-        }
-      }
+      STOVE_LOOP_LAUNCH(2);
     } else {
       STOVE_LOOP_LAUNCH(0);
     }
@@ -579,12 +558,12 @@ int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zss
 
 size_t stove_dynloop_bwd_ws_bytes(int B, int N) { return stove_gnn_bwd_ws_bytes(B, N); }
 
-static bool small_bwd_path(int N, const float* act) { return small_graph(N) && act != nullptr && small_bwd_enabled(); }
+static bool small_bwd_path(int N, const float* act) { return small_graph(N) && act != nullptr; }
 
 // workspace of stove_dynloop_bwd for Ts steps: per-workgroup partial weight gradients, plus (small-graph path) the dY streams
 size_t stove_dynloop_bwd_ws_bytes_ts(int B, int Ts, int N) {
   size_t f = stove_gnn_bwd_ws_bytes(B, N) / sizeof(float);
-  if (small_graph(N) && small_bwd_enabled()) f = (size_t)B * kGnnGrads + (size_t)B * sm_dy_floats(N, Ts);
+  if (small_graph(N)) f = (size_t)B * kGnnGrads + (size_t)B * sm_dy_floats(N, Ts);
   return f * sizeof(float);
 }
 

@@ -16,7 +16,6 @@
 //     one chain per wave (sm_edge_phase_mfma); 30 edges (N = 6) are two column tiles through the same weights;
 //   * the workgroup synchronises exactly twice per step (before the edge phase, before the aggregation).
 // All forward weights (90 KB) sit in LDS for the whole launch.
-// The kernel writes the same saved-activation block as dyn_loop_fwd_k, so dyn_loop_bwd_k consumes it unchanged.
 #include "common.h"
 
 namespace stove {
@@ -64,28 +63,12 @@ struct SmCfg {
 __device__ __forceinline__ void sm_stamp(const SmCfg& cf, int k) {
   if (cf.stamps != nullptr && blockIdx.x == 0 && lane_id() == 0) cf.stamps[wave_id() * 16 + k] = (long long)__builtin_readcyclecounter();
 }
-// Saved activations.  Two layouts behind the same per-step pointer set:
-//  * "block" (gnn_act_floats(N, 1), what dyn_loop_bwd_k of gnn.hip restores): dense block per (sequence, step), edge
-//    rows e = i N + j including the (zeroed) self edges, CAT = [F3 | S] 64 wide;
-//  * "streams" (sm_act2_floats, what the small-graph backward and its weight-gradient pass read): per sequence one
-//    stream per buffer over all steps -- row (t N + r) of a node buffer, row (t N(N-1) + q) of an edge buffer -- so that
-//    16 consecutive rows of any layer input are one contiguous tile for the weight-gradient MFMAs.
+// Saved activations ("streams", sm_act2_floats: what the small-graph backward and its weight-gradient pass read): per sequence
+// one stream per buffer over all steps -- row (t N + r) of a node buffer, row (t N(N-1) + q) of an edge buffer -- so that
+// 16 consecutive rows of any layer input are one contiguous tile for the weight-gradient MFMAs.
 struct SmAct {
   float *SIN, *H1, *PRED, *F1, *F2, *O1, *RES, *S, *F3, *R1, *A1, *R2, *A2, *R3, *ATT, *DIST;
-  int cat_ld;        // 64 (block: S = CAT + 32) or 32 (streams)
-  int compact;       // edge rows indexed by q (streams) or by e = i N + j (block)
 };
-__device__ __forceinline__ SmAct sm_act(float* g, int N) {
-  SmAct a;
-  const int nr = N, ne = N * N;
-  a.SIN = g; a.H1 = g + nr * 32; a.PRED = g + 2 * nr * 32; a.F1 = g + 3 * nr * 32; a.F2 = g + 4 * nr * 32;
-  a.O1 = g + 5 * nr * 32; a.RES = g + 6 * nr * 32; a.F3 = g + 7 * nr * 32; a.S = a.F3 + 32;
-  a.R1 = a.F3 + nr * 64; a.A1 = a.R1 + ne * 64; a.R2 = a.A1 + ne * 64; a.A2 = a.R2 + ne * 32; a.R3 = a.A2 + ne * 32;
-  a.ATT = a.R3 + ne * 32; a.DIST = a.ATT + ne;
-  a.cat_ld = 64;
-  a.compact = 0;
-  return a;
-}
 constexpr int kSmNodeBufs = 9;      // SIN, S, H1, PRED, F1, F2, F3, O1, RES
 __host__ __device__ inline size_t sm_act2_floats(int N, int Ts) {
   const size_t f = (size_t)Ts * ((size_t)N * kSmNodeBufs * 32 + (size_t)N * (N - 1) * (64 + 64 + 32 + 32 + 32 + 2));
@@ -105,8 +88,6 @@ __device__ __forceinline__ SmAct sm_act2(float* seq, int N, int Ts, int ts) {
   a.R2 = e32 + eo * 32; a.A2 = e32 + erows * 32 + eo * 32; a.R3 = e32 + 2 * erows * 32 + eo * 32;
   float* e1 = e32 + 3 * erows * 32;
   a.ATT = e1 + eo; a.DIST = e1 + erows + eo;
-  a.cat_ld = 32;
-  a.compact = 1;
   return a;
 }
 
@@ -536,7 +517,7 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
       sbuf[r][o] = S;
       if (SAVE) {
         act.SIN[r * 32 + o] = sinv;
-        act.S[r * act.cat_ld + o] = S;
+        act.S[r * 32 + o] = S;
       }
       if (o < 2) L.POS[r * 4 + o] = S;
     }
@@ -599,17 +580,6 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
   // ---- P3: edges (i -> j, i != j) as the columns of the relation chain (wave 3) and the attention chain (wave 2); the
   // self-dynamics of all node rows as the columns of wave 1's
   sm_edge_phase_mfma<SAVE, ET>(L, cf, act, &sbuf[0][0], &sdx[0][0], el, pre);
-  if (RP == 1 && SAVE && wv < N && !act.compact) {      // self-edge rows (masked out of the model): finite zeros for the backward's restore
-    const int e = wv * N + wv, h = lane >> 5;             // (block layout: the kernels for up to four objects only)
-    act.R1[e * 64 + lane] = 0.0f;
-    act.A1[e * 64 + lane] = 0.0f;
-    (h ? act.A2 : act.R2)[e * 32 + o] = 0.0f;
-    if (h == 0) act.R3[e * 32 + o] = 0.0f;
-    if (lane == 0) {
-      act.ATT[e] = 0.0f;
-      act.DIST[e] = 0.0f;
-    }
-  }
   if (wv < N) wa = sm_wload<8>(L.W + W_F0, 32, o);        // affector.0, in flight across the barrier
   sm_stamp(cf, 4);
   WG_SYNC();
@@ -640,7 +610,7 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
       act.PRED[r * 32 + o] = pred;
       act.F1[r * 32 + o] = F1;
       act.F2[r * 32 + o] = F2;
-      act.F3[r * act.cat_ld + o] = F3;
+      act.F3[r * 32 + o] = F3;
       act.O1[r * 32 + o] = O1;
       act.RES[r * 32 + o] = RES;
     }
@@ -657,8 +627,8 @@ __device__ __forceinline__ float sm_from_lane(float v, int src_lane) {
 // =================================================================================================
 // inference recursion, same contract as dyn_loop_fwd_k (gnn.hip) with G = 1: grid = B sequences
 // =================================================================================================
-// SAVEM: 0 = inference, 1 = save the activations as per-step blocks (the backward of gnn.hip), 2 = as per-sequence streams
-// (gnn_small_bwd.hip); NT > 0: the number of objects at compile time (3: the headline shape); NMX: 4 or 6 (SmShape)
+// SAVEM: 0 = inference, 2 = save the activations as per-sequence streams (gnn_small_bwd.hip); NT > 0: the number of objects at
+// compile time (3: the headline shape); NMX: 4 or 6 (SmShape)
 template <int SAVEM, int NMX, bool ELU, int NT, bool STAMP = false>      // STAMP: the phase stamps of tools/loop_stamps.py (one debug instantiation)
 __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     const float* __restrict__ z1, const float* __restrict__ zsup, const float* __restrict__ zsstd,
@@ -670,10 +640,9 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
   // the frames already inferred runs it in pieces; a piece that does not start at 0 takes the state the previous one left in z
   constexpr bool SAVE = SAVEM != 0;
   constexpr int RP = SmShape<NMX>::RP, ET = SmShape<NMX>::ET;
-  static_assert(SAVEM != 1 || NMX == 4, "block-layout activations: the kernels for up to four objects");
+  static_assert(SAVEM == 0 || SAVEM == 2, "no saved activations, or the streams layout");
   static_assert(NT <= NMX, "object count beyond what the kernel is built for");
   if (!STAMP) stamps = nullptr;      // the 16 stamp sites of a step vanish (a run-time null check each was ~50 instructions per step)
-  constexpr int streams = SAVEM == 2 ? 1 : 0;       // compile-time: the two pointer sets were both built every step and selected
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const SmLds L = sm_carve<NMX>(lds);
   const int b = blockIdx.x;
@@ -683,10 +652,9 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
   SmCfg cf{N, sin_dim, lim_enc, elu};
   cf.stamps = nullptr;
   const int E = sin_dim - 16;
-  const size_t act_stride = gnn_act_floats(N, 1);
   SmEdgeLane el[ET];
 #pragma unroll
-  for (int t = 0; t < ET; ++t) el[t] = sm_edge_lane(N, SAVE && streams, t);
+  for (int t = 0; t < ET; ++t) el[t] = sm_edge_lane(N, SAVE, t);
   sm_setup(L, P);
   // the lane's node row r: lane l of its half holds s_in[r][l]; dims 0..15 come from the running state z[t-1][2..17]
   float sinv = 0.0f;
@@ -715,7 +683,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
       if (l >= 16 && l < sin_dim && ts + 1 < Ts) xnext = extra[(((size_t)b * Ts + ts + 1) * N + r) * E + (l - 16)];
     }
     SmAct a{};
-    if (SAVE) a = streams ? sm_act2(act + (size_t)b * sm_act2_floats(N, Ts), N, Ts, ts) : sm_act(act + ((size_t)b * Ts + ts) * act_stride, N);
+    if (SAVE) a = sm_act2(act + (size_t)b * sm_act2_floats(N, Ts), N, Ts, ts);
     cf.stamps = (ts == ts1 - 1) ? stamps : nullptr;
     float res = 0.0f, prd = 0.0f;
     sm_step<SAVE, NMX>(L, cf, sinv, a, res, prd, el);

@@ -76,7 +76,7 @@ __device__ __forceinline__ SmBNodeIn smb_node_load(const SmAct& a, int r, int l,
   n.F1 = a.F1[r * 32 + l];
   n.F2 = a.F2[r * 32 + l];
   n.H1 = a.H1[r * 32 + l];
-  n.S = a.S[r * a.cat_ld + l];
+  n.S = a.S[r * 32 + l];
   n.ep = n.gz = n.gmu_in = n.gsg_in = n.gzd_in = 0.0f;
   n.ms = 0.0f;
   n.ss = 1.0f;
