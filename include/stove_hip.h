@@ -8,8 +8,10 @@
  * Conventions:
  *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller
  *     (PyTorch allocates), float32 unless noted; `stream` is a hipStream_t passed as void*.
- *   - functions only enqueue work on `stream`: no allocation, no free, no synchronisation,
- *     no global state; re-entrant and thread-safe; safe under hipGraph capture.
+ *   - functions only enqueue work on `stream`: no allocation, no free, no synchronisation;
+ *     re-entrant and thread-safe; safe under hipGraph capture.  The library reads nothing from
+ *     the environment; its only process state is listed in one place ("process state" below):
+ *     the per-device fork stream, two measurement switches, the open event list, the profiler.
  *   - workspaces are sized by the matching *_ws_bytes() query and need no initialisation.
  *   - return value: 0 on success, otherwise the hipError_t of the failed launch
  *     (stove_error_string() names it).
@@ -335,11 +337,19 @@ int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void*
 /* ---- auxiliary streams.  Every entry point only enqueues on the stream(s) it is given -- with ONE exception: the scene calls
  * (stove_scene_fwd / _bwd and their variants) run their background-SPN chain next to the object-SPN chain on a per-device FORK stream
  * that the library creates on first use (hipStreamNonBlocking), forks from the call's stream and joins back before the call's last
- * kernel, so the caller sees single-stream semantics (STOVE_NO_OVERLAP=1 in the environment: no fork at all).  A caller that wants to
+ * kernel, so the caller sees single-stream semantics (stove_set_overlap(0): no fork at all).  A caller that wants to
  * own that stream -- several models per device, its own capture discipline -- hands it over here: stream != NULL = use this one,
  * NULL = run the chain on the call's stream; restore_default != 0 = back to the library-owned stream.  Thread-safe; takes effect for
- * calls enqueued afterwards.  The only other process-global state is the measurement hook at the end of this header. */
+ * calls enqueued afterwards.
+ * ---- process state.  Everything the library keeps between calls: the fork streams above; the two switches below (A/B
+ * measurements; the Python binding sets them once from STOVE_NO_OVERLAP / STOVE_PARAMS_EARLY, the library itself never reads the
+ * environment); the open event list (stove_event_list_*); the profiler at the end of this header. */
 int stove_set_fork_stream(int device, void* stream, int restore_default);
+/* on = 0: no internal fork stream, every chain of a scene call on the call's stream (default 1). */
+int stove_set_overlap(int on);
+/* late = 1 (default): stove_scene_bwd_overlap / _from with a parameter stream and n_obj <= 4 hold the object SPN's table
+ * gradients back until dz is out (they then run underneath whatever the caller enqueues next); 0: right behind their producer. */
+int stove_set_tablegrad_placement(int late);
 
 /* ---- stream ordering and graph replay (no reference counterpart: the reference enqueues ~6000 ATen launches per step from Python,
  * train.py:443-473; here a step is ~70 launches that a trainer replays as captured hipGraphs, stove_amd/graphed.py).
@@ -350,7 +360,13 @@ int stove_set_fork_stream(int device, void* stream, int restore_default);
  * with exactly this call, so they may be captured either way.
  * stove_capture_begin / _end: capture what is enqueued on `stream` (relaxed mode) into a graph (n_nodes optional);
  * stove_graph_instantiate: graph -> executable graph (consumes the graph; exec_out NULL-valued for an empty graph);
- * stove_graph_launch / _destroy: replay / free it. */
+ * stove_graph_launch / _destroy: replay / free it.
+ * stove_event_list_begin / _end / _destroy: who owns the events of the two-capture case.  begin opens a list (one at a time per
+ * process) that every such event created from now on is appended to, end closes it (returns the number of events), destroy
+ * frees the events -- call it when the graphs that hold their nodes are gone.  Without an open list the events are leaked. */
+void* stove_event_list_begin(void);
+int stove_event_list_end(void* list);
+int stove_event_list_destroy(void* list);
 int stove_stream_after(void* to, void* from);
 int stove_capture_begin(void* stream);
 int stove_capture_end(void* stream, void** graph_out, int* n_nodes);
@@ -445,6 +461,9 @@ int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, con
  * This is the only process-global state of the library and it is off by default. */
 void stove_profile_enable(int on);
 size_t stove_profile_report(char* buf, size_t cap);
+
+/* test / debugging utility: n_words 32-bit words at p <- value (tests poison a captured step's memory between replays) */
+int stove_fill_words(void* p, uint32_t value, size_t n_words, void* stream);
 
 /* self-test hooks used by tests/ (wave reduction) */
 int stove_selftest_wave_sum(const float* in, float* out, int n_waves, void* stream);

@@ -9,6 +9,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libstove_hip.so')
 _lib = None
+ABI_VERSION = 2
 
 EXPORTS = [
     'stove_abi_version', 'stove_error_string', 'stove_selftest_wave_sum',
@@ -23,6 +24,7 @@ EXPORTS = [
     'stove_enc_head_fwd', 'stove_enc_head_bwd_ws_floats', 'stove_enc_head_bwd', 'stove_colsum2', 'stove_small_tn', 'stove_small_tn_ws_floats', 'stove_supair_state_fwd2', 'stove_supair_state_bwd2', 'stove_bg_dense', 'stove_bg_dense_floats',
     'stove_bw_transform_u8', 'stove_stream_after', 'stove_capture_begin', 'stove_capture_end', 'stove_graph_instantiate', 'stove_graph_launch', 'stove_graph_destroy',
     'stove_reward_head_param_floats', 'stove_reward_head_saved_floats', 'stove_reward_head_bwd_ws_floats', 'stove_reward_head_fwd',
+    'stove_set_overlap', 'stove_set_tablegrad_placement', 'stove_event_list_begin', 'stove_event_list_end', 'stove_event_list_destroy', 'stove_fill_words',
     'stove_reward_head_bwd', 'stove_small_linear', 'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_fwd_floats', 'stove_scene_bwd_from', 'stove_dynloop_range_ok', 'stove_dynloop_fwd_range', 'stove_dynloop_bwd_range', 'stove_zall_fwd_range', 'stove_zall_bwd_range',
 ]
 
@@ -114,6 +116,12 @@ def _declare(lib):
         'stove_reward_head_fwd': (I, [P, P, P, P, I, I, P]),
         'stove_reward_head_bwd': (I, [P] * 8 + [I, I, P]),
         'stove_set_fork_stream': (I, [I, P, I]),
+        'stove_set_overlap': (I, [I]),
+        'stove_set_tablegrad_placement': (I, [I]),
+        'stove_event_list_begin': (P, []),
+        'stove_event_list_end': (I, [P]),
+        'stove_event_list_destroy': (I, [P]),
+        'stove_fill_words': (I, [P, ctypes.c_uint32, S, P]),
         'stove_dynloop_range_ok': (I, [I]),
         'stove_dynloop_fwd_range': (I, [P] * 13 + [I] * 6 + [F] * 3 + [I, I, P]),
         'stove_dynloop_bwd_range': (I, [P] * 19 + [I] * 6 + [F] * 3 + [I, I, P, P, P]),
@@ -167,6 +175,12 @@ def load():
                 '(hipcc --offload-arch=gfx950). stove_amd has no CPU fallback.')
         lib = ctypes.CDLL(LIB_PATH)
         _declare(lib)
+        if lib.stove_abi_version() != ABI_VERSION:
+            raise RuntimeError(f'{LIB_PATH} has ABI version {lib.stove_abi_version()}, this binding needs {ABI_VERSION}: '
+                               'rebuild it with `python -m stove_amd.build --force`')
+        # the A/B measurement switches live in the binding, not in the library (which never reads the environment)
+        lib.stove_set_overlap(0 if os.environ.get('STOVE_NO_OVERLAP', '0') == '1' else 1)
+        lib.stove_set_tablegrad_placement(0 if os.environ.get('STOVE_PARAMS_EARLY', '0') == '1' else 1)
         _lib = lib
     return _lib
 

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <math.h>
+#include <atomic>
 #include "spn_obj.hip"
 #include "spn_bg.hip"
 #include "scene.hip"
@@ -77,6 +78,10 @@ static int scene_bwd_tail(const float* frames, const float* z, const float* xw, 
   return 0;
 }
 
+__global__ void fill_words_k(uint32_t* __restrict__ p, uint32_t v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 static inline size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
 
 }  // namespace stove
@@ -85,7 +90,11 @@ using namespace stove;
 
 extern "C" {
 
-int stove_abi_version(void) { return 1; }
+// 2: the GNN parameter image carries the LDS-order weight sections ([W | W^T | vectors | W packed | W^T packed],
+//    stove_gnn_param_floats() floats); the measurement switches are explicit setters (stove_set_overlap,
+//    stove_set_tablegrad_placement) instead of environment reads; cross-capture events are owned by the caller
+//    (stove_event_list_*).
+int stove_abi_version(void) { return 2; }
 
 const char* stove_error_string(int code) { return hipGetErrorString((hipError_t)code); }
 
@@ -170,19 +179,31 @@ static hipStream_t g_fork_user[16] = {nullptr};
 static bool g_fork_user_set[16] = {false};
 static std::mutex g_fork_mu;
 
+static std::atomic<int> g_overlap{1};            // stove_set_overlap
+static std::atomic<int> g_tablegrad_late{1};     // stove_set_tablegrad_placement
+
 static hipStream_t scene_fork_stream(hipStream_t st) {
   static hipStream_t side[16] = {nullptr};
-  static const bool off = [] {
-    const char* e = getenv("STOVE_NO_OVERLAP");
-    return e != nullptr && e[0] == '1';
-  }();                                           // C++11 static initialisation: thread-safe
-  if (off) return st;
+  if (!g_overlap.load(std::memory_order_relaxed)) return st;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return st;
   std::lock_guard<std::mutex> lock(g_fork_mu);    // backward is called from the autograd thread, forward from the main one
   if (g_fork_user_set[dev]) return g_fork_user[dev] != nullptr ? g_fork_user[dev] : st;      // the caller's stream (NULL: no fork at all)
   if (side[dev] == nullptr && hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking) != hipSuccess) return st;
   return side[dev];
+}
+
+// Measurement switches (explicit state instead of environment reads; defaults 1 / 1).
+// overlap 0: the scene calls run their background-SPN chain on the call's stream (no internal fork at all).
+int stove_set_overlap(int on) {
+  g_overlap.store(on != 0, std::memory_order_relaxed);
+  return 0;
+}
+// late 1 (default): with a parameter stream and up to four objects the object SPN's table gradients are held back until dz is
+// out and run underneath what the caller enqueues next (objspn_tablegrad_under_k); 0: right behind their producer.
+int stove_set_tablegrad_placement(int late) {
+  g_tablegrad_late.store(late != 0, std::memory_order_relaxed);
+  return 0;
 }
 
 // The caller owns the fork stream of `device` from now on (the scene calls run their background-SPN chain on it, forked from and joined
@@ -273,14 +294,7 @@ size_t stove_scene_bwd_ws_bytes(int n_frames, int n_obj) { return scene_ws_layou
 // backward 470 -> 545 us with them on its SIMDs (MFMA pipe and L1 shared; raising the chain's wave priority changes
 // nothing), the step 3.273 -> 3.254 ms.  STOVE_PARAMS_EARLY=1: right behind their producer, next to pix / bgspn_bwd
 // (the round-1 placement, objspn_tablegrad_k).
-static int params_late() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("STOVE_PARAMS_EARLY");
-    v = (e != nullptr && e[0] == '1') ? 0 : 1;
-  }
-  return v;
-}
+static int params_late() { return g_tablegrad_late.load(std::memory_order_relaxed); }
 
 size_t stove_bg_dense_floats(void) { return (size_t)kBgDenseF; }
 int stove_bg_dense(const int32_t* bg_side, const float* bg_coef, float* dense, void* stream) {
@@ -872,6 +886,43 @@ int stove_small_linear(const float* x, const float* W, const float* b, float* y,
 
 // ---------------------------------------------------------------- stream ordering / graph replay helpers
 int stove_stream_after(void* to, void* from) { return (int)stream_after((hipStream_t)to, (hipStream_t)from); }
+
+// Events that order two DIFFERENT captures against each other (stream_after) must live as long as the graphs holding their
+// record / wait nodes.  A caller that captures opens a list first: every such event created while it is open is appended, and
+// the caller destroys the list together with its graphs (stove_amd/graphed.py).  With no list open they are never destroyed.
+void* stove_event_list_begin(void) {
+  std::lock_guard<std::mutex> g(event_list_mu());
+  auto* v = new std::vector<hipEvent_t>();
+  event_list_current() = v;
+  return (void*)v;
+}
+int stove_event_list_end(void* list) {
+  std::lock_guard<std::mutex> g(event_list_mu());
+  if (event_list_current() == (std::vector<hipEvent_t>*)list) event_list_current() = nullptr;
+  return list == nullptr ? 0 : (int)((std::vector<hipEvent_t>*)list)->size();
+}
+int stove_event_list_destroy(void* list) {
+  if (list == nullptr) return 0;
+  std::lock_guard<std::mutex> g(event_list_mu());
+  auto* v = (std::vector<hipEvent_t>*)list;
+  if (event_list_current() == v) event_list_current() = nullptr;
+  hipError_t e = hipSuccess;
+  for (hipEvent_t ev : *v) {
+    const hipError_t d = hipEventDestroy(ev);
+    if (e == hipSuccess) e = d;
+  }
+  delete v;
+  return (int)e;
+}
+
+// test / debugging utility: n 32-bit words at p <- value (tests poison a captured step's memory pool between replays)
+int stove_fill_words(void* p, uint32_t value, size_t n_words, void* stream) {
+  if (n_words == 0) return 0;
+  const size_t blocks = (n_words + 256 * 8 - 1) / (256 * 8);
+  STOVE_LAUNCH(fill_words_k, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, (uint32_t*)p, value, n_words);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
 
 int stove_capture_begin(void* stream) { return (int)hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed); }
 

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+#include <vector>
 
 namespace stove {
 
@@ -109,15 +111,28 @@ inline hipError_t capture_add_event_node(hipStream_t s, const CaptureInfo& ci, h
   if (e != hipSuccess) return e;
   return hipStreamUpdateCaptureDependencies(s, &n, 1, hipStreamSetCaptureDependencies);
 }
+// the open event list of the capturing caller (stove_event_list_begin): cross-capture events are appended to it
+inline std::mutex& event_list_mu() {
+  static std::mutex m;
+  return m;
+}
+inline std::vector<hipEvent_t>*& event_list_current() {
+  static std::vector<hipEvent_t>* cur = nullptr;
+  return cur;
+}
 inline hipError_t stream_after(hipStream_t to, hipStream_t from) {
   if (to == from) return hipSuccess;
   CaptureInfo cf, ct;
   if (capture_info(from, &cf) == hipSuccess && capture_info(to, &ct) == hipSuccess && cf.active && ct.active && cf.id != ct.id) {
-    hipEvent_t ev;                               // lives as long as the graphs that hold it: never destroyed
+    hipEvent_t ev;                               // lives as long as the graphs that hold it: owned by the caller's event list
     hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e != hipSuccess) return e;
+    {
+      std::lock_guard<std::mutex> g(event_list_mu());
+      if (event_list_current() != nullptr) event_list_current()->push_back(ev);      // else: leaked (no owner announced)
+    }
     e = capture_add_event_node(from, cf, ev, true);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) return e;               // the record node stays in `from`'s graph; the event dies with the list
     return capture_add_event_node(to, ct, ev, false);
   }
   hipEvent_t ev;

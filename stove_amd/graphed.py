@@ -47,12 +47,23 @@ class GraphedTrainStep:
         self.key = None
         self.reward_value = None
         self._side_exec = None
+        self._events = None          # the list of cross-capture events that order g_main and g_side (owned with the graphs)
+
+    def _drop_side(self):
+        """The side graph and the events that order it against the main graph go together (a re-capture, eager(), __del__)."""
+        from . import _lib
+        lib = _lib.load()
+        if self._side_exec:
+            lib.stove_graph_destroy(self._side_exec)
+        self._side_exec = None
+        if self._events:
+            lib.stove_event_list_destroy(self._events)
+        self._events = None
 
     def __del__(self):
         try:
-            if self._side_exec:
-                from . import _lib
-                _lib.load().stove_graph_destroy(self._side_exec)
+            self.graphs = None       # the main graph's event nodes go first
+            self._drop_side()
         except Exception:
             pass
 
@@ -94,7 +105,10 @@ class GraphedTrainStep:
         self.hyper_dev.copy_(torch.tensor(self._hyper_now(reward_weight), dtype=torch.float32))
         elbo = self._eager()
         self.opt.count_step()
-        self.graphs = None             # the static inputs were rebound: capture again before the next replay
+        if self.graphs is not None:
+            torch.cuda.synchronize(images.device)     # replays still in flight hold the graphs' event nodes
+            self.graphs = None         # the static inputs were rebound: capture again before the next replay
+            self._drop_side()
         return elbo
 
     # ------------------------------------------------------------------ capture
@@ -106,7 +120,7 @@ class GraphedTrainStep:
         self.r = own(targets) if targets is not None else None
         self._prepare(dev)
         self.ring = torch.zeros(SLOTS, NHYPER, dtype=torch.float32).pin_memory()
-        self._events = [None] * SLOTS
+        self._slot_events = [None] * SLOTS
         self._n = 0
         self.hyper_dev.copy_(torch.tensor(self._hyper_now(0.0), dtype=torch.float32))
         # warm-up on a side stream (allocator pools, library workspaces, lazily created streams); parameters, optimiser
@@ -137,14 +151,38 @@ class GraphedTrainStep:
         from . import _lib, ops
         lib = _lib.load()
         self._side = ops._side_stream(dev)
-        dump = os.environ.get('STOVE_GRAPH_DUMP')         # debugging: write the captured main DAG (tools/graphdump) to this path
+        # debugging hooks (tools/graphdump, not part of the package): checked BEFORE the capture begins
+        dump, dump_open = os.environ.get('STOVE_GRAPH_DUMP'), os.environ.get('STOVE_GRAPH_DUMP_OPEN')
+        gd = None
+        if dump or dump_open:
+            import ctypes
+            so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'graphdump', 'libgraphdump.so')
+            if not os.path.exists(so):
+                raise RuntimeError('STOVE_GRAPH_DUMP* needs %s (hipcc -shared -fPIC tools/graphdump/graphdump.hip): a debugging aid of '
+                                   'the source tree, not of an installed package' % so)
+            gd = ctypes.CDLL(so)
         g1 = torch.cuda.CUDAGraph(keep_graph=True) if dump else torch.cuda.CUDAGraph()
         split = os.environ.get('STOVE_GRAPH_ONE', '0') != '1'
-        if self._side_exec:                       # a re-capture (new batch shape): the previous side graph goes
-            lib.stove_graph_destroy(self._side_exec)
-        self._side_exec = None
+        torch.cuda.synchronize(dev)
+        self.graphs = None                        # a re-capture (new batch shape): the previous graphs and their events go
+        self._drop_side()
         import ctypes
         side_graph, side_nodes = ctypes.c_void_p(), ctypes.c_int()
+        events = lib.stove_event_list_begin()     # the events that order the two captures: created below, destroyed with the graphs
+        try:
+            self._capture_graphs(g1, s, split, lib, ops, side_graph, side_nodes, dump, dump_open, gd)
+        except BaseException:
+            lib.stove_event_list_end(events)
+            lib.stove_event_list_destroy(events)
+            raise
+        lib.stove_event_list_end(events)
+        self._events = events
+        self.key = self._key(images, actions, targets)
+
+    def _capture_graphs(self, g1, s, split, lib, ops, side_graph, side_nodes, dump, dump_open, gd):
+        import ctypes
+        from . import _lib
+        rc = 0
         with torch.cuda.graph(g1, stream=s):
             # the side capture lives strictly INSIDE the main one: torch synchronises the device before it begins a capture and
             # flushes deferred allocator events after it ends one -- either would invalidate a capture still open on the side stream
@@ -153,28 +191,30 @@ class GraphedTrainStep:
                 ops.SideMode.split, ops.SideMode.keep = True, []
             try:
                 self.elbo = self._fwd_bwd()
-            finally:
-                if split:
+            except BaseException:
+                if split:            # the step failed inside the capture: end the side capture, free what it produced, keep the error
                     ops.SideMode.split = False
-                    rc = lib.stove_capture_end(self._side.cuda_stream, ctypes.byref(side_graph), ctypes.byref(side_nodes))
+                    lib.stove_capture_end(self._side.cuda_stream, ctypes.byref(side_graph), ctypes.byref(side_nodes))
+                    if side_graph.value:
+                        lib.stove_graph_instantiate(side_graph, ctypes.byref(ctypes.c_void_p()))      # consumes (destroys) the graph
+                    ops.SideMode.keep = []
+                raise
             if split:
+                ops.SideMode.split = False
+                rc = lib.stove_capture_end(self._side.cuda_stream, ctypes.byref(side_graph), ctypes.byref(side_nodes))
                 _lib.check(rc, 'stove_capture_end')
             elif self.world_size <= 1 and not self.force_reduce:
                 self._update()
-            if os.environ.get('STOVE_GRAPH_DUMP_OPEN'):          # debugging: the main DAG while its capture is still open
-                here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-                gd = ctypes.CDLL(os.path.join(here, 'tools', 'graphdump', 'libgraphdump.so'))
+            if dump_open:          # debugging: the main DAG while its capture is still open
                 gd.graph_of_stream.restype = ctypes.c_void_p
-                gd.graph_dump(ctypes.c_void_p(gd.graph_of_stream(ctypes.c_void_p(s.cuda_stream))), os.environ['STOVE_GRAPH_DUMP_OPEN'].encode())
+                gd.graph_dump(ctypes.c_void_p(gd.graph_of_stream(ctypes.c_void_p(s.cuda_stream))), dump_open.encode())
         ops.SideMode.split, ops.SideMode.keep = False, []
         if split:
             ex = ctypes.c_void_p()
             _lib.check(lib.stove_graph_instantiate(side_graph, ctypes.byref(ex)), 'stove_graph_instantiate')
             self._side_exec, self._side_nodes = ex.value, side_nodes.value
         if dump:
-            here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-            ctypes.CDLL(os.path.join(here, 'tools', 'graphdump', 'libgraphdump.so')).graph_dump(
-                ctypes.c_void_p(g1.raw_cuda_graph()), dump.encode())
+            gd.graph_dump(ctypes.c_void_p(g1.raw_cuda_graph()), dump.encode())
             g1.instantiate()
         if split or self.world_size > 1 or self.force_reduce:
             g2 = torch.cuda.CUDAGraph()
@@ -183,7 +223,6 @@ class GraphedTrainStep:
             self.graphs = (g1, g2)
         else:
             self.graphs = (g1,)
-        self.key = self._key(images, actions, targets)
 
     @staticmethod
     def _key(images, actions, targets):
@@ -205,10 +244,10 @@ class GraphedTrainStep:
             if dst is not None and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         slot = self._n % SLOTS
-        if self._events[slot] is not None:
-            self._events[slot].synchronize()          # the step that last used this slot has run (blocks only SLOTS steps ahead)
+        if self._slot_events[slot] is not None:
+            self._slot_events[slot].synchronize()     # the step that last used this slot has run (blocks only SLOTS steps ahead)
         else:
-            self._events[slot] = torch.cuda.Event()
+            self._slot_events[slot] = torch.cuda.Event()
         self.ring[slot] = torch.tensor(self._hyper_now(reward_weight), dtype=torch.float32)
         self.hyper_dev.copy_(self.ring[slot], non_blocking=True)
         self.graphs[0].replay()
@@ -221,7 +260,7 @@ class GraphedTrainStep:
         if len(self.graphs) > 1:
             self._reduce()
             self.graphs[1].replay()
-        self._events[slot].record()
+        self._slot_events[slot].record()
         self._n += 1
         self.opt.count_step()
         return self.elbo

@@ -375,6 +375,9 @@ def gnn_pack_perms(device):
 
 def _gnn_image(w_img, v_img, wt_img):
     if v_img is None:                          # prebuilt [W | W^T | vectors | W packed | W^T packed] image (ParamArena.gnn_image)
+        need = _lib.load().stove_gnn_param_floats()
+        if w_img.numel() != need:              # an image in an older layout would be read past its end by the kernels
+            raise ValueError('GNN parameter image has %d floats, libstove_hip.so expects %d (stove_gnn_param_floats)' % (w_img.numel(), need))
         return w_img
     pf, pt = gnn_pack_perms(w_img.device)
     with torch.no_grad():

@@ -269,7 +269,7 @@ def test_rollout_std_and_sampling_api():
 
 
 def test_encoder_lstm_against_oracle():
-    """Fused LSTM cell (csrc/lstm.hip) + rocBLAS GEMMs against the oracle's restatement of RnnStates."""
+    """The recognition network (MFMA GEMMs of csrc/gemm_bf16.hip, gate math of csrc/lstm.hip, fused head) against the oracle's restatement of RnnStates."""
     from stove_amd.video_prediction.encoder import RnnStates
     c, structs, params = oracle_setup(torch.float64)
     enc = fill_analytic(RnnStates(make_cfg()), 'sup.encoder.').to(DEV)
@@ -441,14 +441,17 @@ def test_elbo_assembly_against_torch():
 
 
 @pytest.mark.parametrize('nonlinear', ['relu', 'leaky_relu'])      # the second one selects F.elu (the reference's quirk, dynamics.py:107-110)
-@pytest.mark.parametrize('n_obj,ac', [(2, False), (3, False), (4, False), (5, False), (6, False), (5, True), (6, True)])
+@pytest.mark.parametrize('n_obj,ac', [(2, False), (3, False), (4, False), (5, False), (6, False), (5, True), (6, True),
+                                      (7, False), (8, False), (7, True), (8, True)])
 def test_small_graph_recursion_matches_step_kernels(n_obj, ac, nonlinear):
-    """The small-graph time loop (csrc/gnn_small*.hip: N = 2, 4 and 5 have no goldens; five and six objects run two node rows
-    per wave and two tiles of edge columns; `ac`: action-conditioned, 23 inputs per node and the reward head) against the host
-    loop over the single-step MFMA kernel + PyTorch autograd: ELBO, every gradient, and the rollout."""
+    """The persistent time loops against the host loop over the single-step MFMA kernel + PyTorch autograd: ELBO, every gradient,
+    and the rollout.  N <= 6: the small-graph kernels (csrc/gnn_small*.hip: N = 2, 4 and 5 have no goldens; five and six objects
+    run two node rows per wave and two tiles of edge columns).  N = 7, 8: the workgroup-wide MFMA loops of csrc/gnn.hip
+    (dyn_loop_fwd_k / dyn_loop_bwd_k / rollout_fwd_k), which no BASELINE configuration reaches since six objects moved to the
+    small-graph path -- this test is what keeps them honest.  `ac`: action-conditioned, 23 inputs per node and the reward head."""
     from stove_amd import _lib
     from stove_amd.video_prediction.stove import Stove
-    assert _lib.load().stove_dynloop_range_ok(n_obj) == 1          # the kernels under test are the ones that run
+    assert _lib.load().stove_dynloop_range_ok(n_obj) == int(n_obj <= 6)          # the kernels under test are the ones that run
     n, T = 3, 6
     g = torch.Generator(device='cpu').manual_seed(11)
     x = (torch.rand(n, T, 3, 32, 32, generator=g) < 0.04).float().to(DEV)

@@ -7,6 +7,7 @@ tools/stall_watch.sh
 bash tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1
 # timelines of the step captured as ONE graph and enqueued eagerly (the default three-graph replay is profile_round's timeline.txt)
 cd /tmp && export TMPDIR=/tmp
+export STOVE_BENCH_NO_PARITY=1
 STOVE_GRAPH_ONE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/one -o ks -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-variants --profile-steps 0 --step-mode graph > $OUT/one.log 2>&1
 python3 $R/tools/timeline.py $(find $OUT/one -name "*kernel_trace.csv" | head -1) 10 > $OUT/timeline_onegraph.txt; rm -rf $OUT/one
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eag -o ks -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-variants --profile-steps 0 --step-mode eager > $OUT/eag.log 2>&1

@@ -7,6 +7,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export STOVE_BENCH_NO_PARITY=1      # the profiled passes hold the timed workload only (no golden-fixture leg)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -o ks -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-variants --profile-steps 0 --step-mode graph > $OUT/ks.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --profile-steps 0 --step-mode eager > $OUT/fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --profile-steps 0 --step-mode eager > $OUT/write.log 2>&1
@@ -18,5 +19,6 @@ s=$(find $OUT/ks -name "*kernel_stats.csv" | head -1); [ -n "$s" ] && cp $s $OUT
 python3 tools/pmc_summary.py $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $(find $OUT/write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json
 python3 tools/pmc_sq_summary.py $(find $OUT/sq -name "*counter_collection.csv" | head -1) $OUT/pmc_sq.json
 rm -rf $OUT/ks $OUT/fetch $OUT/write $OUT/sq
+unset STOVE_BENCH_NO_PARITY
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.log
 tail -c 900 $OUT/bench.json
