@@ -60,7 +60,12 @@ __device__ __forceinline__ void split4(const float4 v, u32x2& hi, u32x2& lo) {
 
 // Where one thread's NLD float4 pieces of an operand tile (ROWS x 32) come from: a running pointer per piece, advanced by one
 // k-step per tile, plus the piece's k offset inside the tile and whether its rows exist (edge tiles).
-template <int ROWS, bool KMAJOR, int THREADS, bool SCALAR = false>
+// PERM (the unit-interleaved gate layout of the fused LSTM path, csrc/lstm.hip): the operand's rows in HBM keep torch's gate-major
+// order (row e H + u) while the GEMM walks them unit-major.  1 (K-contiguous operand, rows = gate columns, forward): tile row
+// [wn:1][j:2][q:2][e:2] of a 128-row tile is gate e of unit 16 wn + 4 q + j of the tile's 32 units -- the MFMA hands lane group q
+// the columns 16 j + 4 q + e, so a lane ends up with all four gates of four CONSECUTIVE units.  2 (K-major operand, k = gate
+// column, backward): k-row k'' = 4 u + e is fetched from row e (K / 4) + u.
+template <int ROWS, bool KMAJOR, int THREADS, bool SCALAR = false, int PERM = 0>
 struct TileSrc {
   static constexpr int NLD = ROWS * kGemmBK / 4 / THREADS;
   const float* p[NLD];
@@ -71,11 +76,12 @@ struct TileSrc {
   // SCALAR: the operand is not float4-addressable (odd leading dimension / extent, e.g. fc1's 50 columns): every element is
   // loaded and predicated on its own (a compile-time variant, so that the vector path keeps its branch-free loads)
   size_t step;
-  __device__ __forceinline__ void init(const float* __restrict__ P, int ld, int row0, int n_rows, int k_begin, int tid) {
+  __device__ __forceinline__ void init(const float* __restrict__ P, int ld, int row0, int n_rows, int k_begin, int tid, int k_total = 0) {
+    static_assert(PERM == 0 || (PERM == 1 && !KMAJOR && ROWS == 128) || (PERM == 2 && KMAJOR), "operand permutation / layout mismatch");
     rowmask = 0u;
     rowsleft = 0u;
     safe = P;
-    step = KMAJOR ? (size_t)kGemmBK * ld : (size_t)kGemmBK;
+    step = KMAJOR ? (PERM == 2 ? (size_t)(kGemmBK / 4) * ld : (size_t)kGemmBK * ld) : (size_t)kGemmBK;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int f = tid + THREADS * j;
@@ -88,7 +94,13 @@ struct TileSrc {
         kloc[j] = 4 * (f & 7);
       }
       const int k = k_begin + kloc[j];
-      p[j] = KMAJOR ? P + (size_t)k * ld + row : P + (size_t)row * ld + k;
+      int ksrc = k, rsrc = row;
+      if (PERM == 2) ksrc = (k & 3) * (k_total >> 2) + (k >> 2);
+      if (PERM == 1) {
+        const int rl = row - row0;
+        rsrc = (rl & 3) * (n_rows >> 2) + (row0 >> 2) + 16 * (rl >> 6) + 4 * ((rl >> 2) & 3) + ((rl >> 4) & 3);
+      }
+      p[j] = KMAJOR ? P + (size_t)ksrc * ld + row : P + (size_t)rsrc * ld + k;
       rowmask |= row < n_rows ? (1u << j) : 0u;
       const int left = n_rows - row;
       rowsleft |= (unsigned)(left < 0 ? 0 : (left > 4 ? 4 : left)) << (3 * j);
@@ -104,7 +116,8 @@ struct TileLoad {
   unsigned okmask;      // bit j: piece j is inside the operand (the zeroing of edge pieces is deferred to store_piece: a
                         // select right behind the load would make the wave wait for it at once)
   // loads the tile whose first k is `k0` and advances the source by one k-step
-  __device__ __forceinline__ void load(TileSrc<ROWS, KMAJOR, THREADS, SCALAR>& src, int k0, int k_end) {
+  template <class Src>
+  __device__ __forceinline__ void load(Src& src, int k0, int k_end) {
     okmask = 0u;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
@@ -169,10 +182,31 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int r0, int lane) {
 
 // DEBUG (tools only): 1 = no loads in the loop, 2 = no MFMAs.  A_SCALAR: A is read element-wise (see TileSrc); bit 2 of `scalar_bits`
 // (run time): C / bias / add are written and read element-wise.
-template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT, int BM, int BN, int DEBUG = 0, bool A_SCALAR = false>
-__global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+// EPI: 0 = C (+ bias) (+ add); 1 = LSTM cell forward behind the product (C = saved pre-activations, unit-interleaved; see LstmEpi);
+// 2 = LSTM cell backward behind dh = add + A B (nothing of dh is stored).  PERM bits: 1 = B rows gathered gate -> unit order
+// (TileSrc PERM 1), 2 = B k-rows gathered likewise (TileSrc PERM 2), 4 = row m of C is stored at row (m & 3)(M / 4) + (m >> 2) (the weight
+// gradients dg^T x come out unit-major and go back to torch's gate-major rows).
+struct LstmEpi {
+  // EPI 1: c_prev (M, H) or null (zero state) -> c, h (M, H); bias (if any) is indexed in torch's order
+  const float* c_prev;
+  float* c;
+  float* h;
+  // EPI 2: gs (M, 4H) unit-interleaved pre-activations of the step whose cell is differentiated, its c_prev (or null) and c,
+  // dc_in (or null) -> dg (M, 4H) (or null), dc_out (M, H), dgx (or null) = dg + the n_more tensors dg_more[i] (M, 4H each)
+  const float* gs;
+  const float* c_cur;
+  const float* dc_in;
+  float* dg;
+  float* dc_out;
+  float* dgx;
+  const float* dg_more;
+  int n_more;
+};
+
+template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT, int BM, int BN, int DEBUG = 0, bool A_SCALAR = false, int EPI = 0, int PERM = 0>
+__global__ __launch_bounds__(BM * BN / 64, 2) void gemm_bf16_k(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                                                const float* __restrict__ add, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
-                                                               int tiles_m, int tiles_n, int splitk, int k_per_slice, int scalar_bits) {
+                                                               int tiles_m, int tiles_n, int splitk, int k_per_slice, int scalar_bits, LstmEpi ep) {
   extern __shared__ __attribute__((aligned(16))) char gemm_lds[];
   constexpr int kGemmBM = BM, kGemmBN = BN, THREADS = BM * BN / 64;      // one wave per 64 x 64 of the tile
   constexpr int kGemmAPart = gemm_part_bytes(BM), kGemmBPart = gemm_part_bytes(BN);
@@ -207,9 +241,9 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restr
   TileLoad<kGemmBM, A_KMAJOR, THREADS, A_SCALAR> la0, la1;
   TileLoad<kGemmBN, B_KMAJOR, THREADS> lb0, lb1;
   TileSrc<kGemmBM, A_KMAJOR, THREADS, A_SCALAR> sa;
-  TileSrc<kGemmBN, B_KMAJOR, THREADS> sb;
+  TileSrc<kGemmBN, B_KMAJOR, THREADS, false, (PERM & 1) ? 1 : ((PERM & 2) ? 2 : 0)> sb;
   sa.init(A, lda, m0, M, k_begin, tid);
-  sb.init(B, ldb, n0, N, k_begin, tid);
+  sb.init(B, ldb, n0, N, k_begin, tid, K);
   if (nt > 0) {
     la0.load(sa, k_begin, k_end);
     lb0.load(sb, k_begin, k_end);
@@ -268,10 +302,93 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restr
     if (t + 1 < nt) kstep(t + 1, la0, lb0, la1, lb1);
   }
   // epilogue: lane holds C[m][n .. n+3], m = tile row (lane & 15), n = 4 (lane >> 4) + reg
+  if constexpr (EPI == 1) {
+    // LSTM cell forward.  Under PERM 1 the four registers of acc[i][j] are the gates (i, f, g, o) of unit u0 + j, u0 = the first of
+    // this lane's four consecutive units; in memory (unit-interleaved, ldc = 4H) they sit at column 4 (u0 + j): 64 contiguous
+    // bytes per lane and tile row.  All loads of a tile row (add: 4 x 16 B, c_prev: 16 B) go out before its arithmetic.
+    const int Hh = N >> 2;
+    const int u0 = (n0 >> 2) + 16 * wn + 4 * (lane >> 4);
+    float bi[4][4];                 // bias of this lane's 4 units x 4 gates (torch's order in memory: one float4 per gate)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float4 b4 = bias != nullptr ? *reinterpret_cast<const float4*>(bias + e * Hh + u0) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+      bi[0][e] = b4.x; bi[1][e] = b4.y; bi[2][e] = b4.z; bi[3][e] = b4.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+      if (m >= M) continue;
+      float4 ad[4], cp = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        ad[j] = add != nullptr ? *reinterpret_cast<const float4*>(add + (size_t)m * ldc + 4 * (u0 + j)) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (ep.c_prev != nullptr) cp = *reinterpret_cast<const float4*>(ep.c_prev + (size_t)m * Hh + u0);
+      const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+      float cn[4], hn[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 g = {acc[i][j].x + bi[j][0] + ad[j].x, acc[i][j].y + bi[j][1] + ad[j].y, acc[i][j].z + bi[j][2] + ad[j].z,
+                          acc[i][j].w + bi[j][3] + ad[j].w};
+        *reinterpret_cast<float4*>(C + (size_t)m * ldc + 4 * (u0 + j)) = g;
+        cell_fwd_unit(g, cpv[j], cn[j], hn[j]);
+      }
+      *reinterpret_cast<float4*>(ep.c + (size_t)m * Hh + u0) = float4{cn[0], cn[1], cn[2], cn[3]};
+      *reinterpret_cast<float4*>(ep.h + (size_t)m * Hh + u0) = float4{hn[0], hn[1], hn[2], hn[3]};
+    }
+    return;
+  }
+  if constexpr (EPI == 2) {
+    // LSTM cell backward of the step in front: acc + add = dh of units n .. n+3 (N = H here); everything else is streamed per
+    // (tile row, 16-column block): 4 x 16 B of pre-activations, c_prev, c, dc_in -> 4 x 16 B of gate gradients, dc_out.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+        if (n >= N) continue;
+        const size_t ho = (size_t)m * N + n, go = 4 * ho;
+        float4 pre[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pre[e] = *reinterpret_cast<const float4*>(ep.gs + go + 4 * e);
+        const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float4 a4 = add != nullptr ? *reinterpret_cast<const float4*>(add + (size_t)m * ldc + n) : z4;
+        const float4 cp4 = ep.c_prev != nullptr ? *reinterpret_cast<const float4*>(ep.c_prev + ho) : z4;
+        const float4 cc4 = *reinterpret_cast<const float4*>(ep.c_cur + ho);
+        const float4 di4 = ep.dc_in != nullptr ? *reinterpret_cast<const float4*>(ep.dc_in + ho) : z4;
+        float4 more[4] = {z4, z4, z4, z4};
+        if (ep.dgx != nullptr) {
+          for (int q = 0; q < ep.n_more; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float4 p4 = *reinterpret_cast<const float4*>(ep.dg_more + (size_t)q * M * N * 4 + go + 4 * e);
+              more[e].x += p4.x; more[e].y += p4.y; more[e].z += p4.z; more[e].w += p4.w;
+            }
+          }
+        }
+        const float dh[4] = {acc[i][j].x + a4.x, acc[i][j].y + a4.y, acc[i][j].z + a4.z, acc[i][j].w + a4.w};
+        const float cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w}, cc[4] = {cc4.x, cc4.y, cc4.z, cc4.w}, di[4] = {di4.x, di4.y, di4.z, di4.w};
+        float dcp[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float4 d = cell_bwd_unit(pre[e], cp[e], cc[e], dh[e], di[e], dcp[e]);
+          if (ep.dg != nullptr) *reinterpret_cast<float4*>(ep.dg + go + 4 * e) = d;
+          if (ep.dgx != nullptr) {
+            d.x += more[e].x; d.y += more[e].y; d.z += more[e].z; d.w += more[e].w;
+            *reinterpret_cast<float4*>(ep.dgx + go + 4 * e) = d;
+          }
+        }
+        *reinterpret_cast<float4*>(ep.dc_out + ho) = float4{dcp[0], dcp[1], dcp[2], dcp[3]};
+      }
+    }
+    return;
+  }
   float* out = C + (splitk > 1 ? (size_t)z * M * ldc : 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    const int ms = (PERM & 4) ? (m & 3) * (M >> 2) + (m >> 2) : m;       // where row m of the product is stored (and added from)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
@@ -283,18 +400,18 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restr
             v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
           }
           if (add != nullptr && splitk == 1) {
-            const float4 d4 = *reinterpret_cast<const float4*>(add + (size_t)m * ldc + n);
+            const float4 d4 = *reinterpret_cast<const float4*>(add + (size_t)ms * ldc + n);
             v.x += d4.x; v.y += d4.y; v.z += d4.z; v.w += d4.w;
           }
-          *reinterpret_cast<f32x4*>(out + (size_t)m * ldc + n) = v;
+          *reinterpret_cast<f32x4*>(out + (size_t)ms * ldc + n) = v;
         } else {        // N or ldc not a multiple of 4: element-wise epilogue
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (n + e < N) {
               float t = v[e];
               if (bias != nullptr && splitk == 1) t += bias[n + e];
-              if (add != nullptr && splitk == 1) t += add[(size_t)m * ldc + n + e];
-              out[(size_t)m * ldc + n + e] = t;
+              if (add != nullptr && splitk == 1) t += add[(size_t)ms * ldc + n + e];
+              out[(size_t)ms * ldc + n + e] = t;
             }
           }
         }
@@ -306,16 +423,16 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restr
 // LDS bytes of the kernel
 constexpr int gemm_lds_bytes(int nsplit, int bm, int bn) { return 2 * nsplit * (gemm_part_bytes(bm) + gemm_part_bytes(bn)); }
 
-template <bool AK, bool BK_, int NS, int BM = 256, int BN = 128, int DEBUG = 0, bool A_SCALAR = false>
+template <bool AK, bool BK_, int NS, int BM = 256, int BN = 128, int DEBUG = 0, bool A_SCALAR = false, int EPI = 0, int PERM = 0>
 static int gemm_launch(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                       int splitk, hipStream_t st, int scalar_bits = 0) {
+                       int splitk, hipStream_t st, int scalar_bits = 0, LstmEpi ep = LstmEpi{}) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   int kper = ((K + splitk - 1) / splitk + kGemmBK - 1) / kGemmBK * kGemmBK;
-  const void* fn = (const void*)gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR>;
+  const void* fn = (const void*)gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR, EPI, PERM>;
   int rc = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(NS, BM, BN));
   if (rc) return rc;
-  STOVE_LAUNCH((gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR>), dim3(tiles_m * tiles_n * splitk), dim3(BM * BN / 64), gemm_lds_bytes(NS, BM, BN), st, A, B, bias, add, C,
-               M, N, K, lda, ldb, ldc, tiles_m, tiles_n, splitk, kper, scalar_bits);
+  STOVE_LAUNCH((gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR, EPI, PERM>), dim3(tiles_m * tiles_n * splitk), dim3(BM * BN / 64), gemm_lds_bytes(NS, BM, BN), st, A, B, bias, add, C,
+               M, N, K, lda, ldb, ldc, tiles_m, tiles_n, splitk, kper, scalar_bits, ep);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

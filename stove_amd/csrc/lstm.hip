@@ -109,6 +109,77 @@ __global__ void lstm_cell_bwd_k(const float* __restrict__ gx, const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Unit-interleaved gate layout (round 4).  The MFMA GEMMs of csrc/gemm_bf16.hip run the cell as their epilogue (forward: behind
+// h W_hh^T + gx; backward: the cell backward of step k-1 behind dh_{k-1} = dhs[k-1] + dg_k W_hh), which needs the four gates of a
+// unit in ONE lane.  Inside that path every (rows, 4H) gate tensor -- gx, the saved pre-activations gs_k, the gate gradients dg_k,
+// dgx -- is stored unit-major:  column 4u + e  holds gate e (0..3 = i, f, g, o) of unit u; torch's layout is column e H + u.
+// W_ih / W_hh / the biases keep torch's layout in HBM: the GEMM loaders gather their rows through the same map.
+//
+// Activations in that path: sigmoid and tanh on v_exp_f32 / v_rcp_f32 (absolute error ~1e-7; the ocml tanhf of the stand-alone
+// cell kernels above is ~100 instructions per call, which as a GEMM epilogue ran exposed: +255 us per step in round 2).
+__device__ __forceinline__ float fsig_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float ftanh_(float x) {
+  const float t = __builtin_amdgcn_exp2f(-2.8853900817779268f * fabsf(x));      // e^(-2|x|) in (0, 1]
+  return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
+}
+// forward cell of one unit: pre-activations (i, f, g, o), previous cell -> new cell, hidden
+__device__ __forceinline__ void cell_fwd_unit(const float4 g, float cp, float& cn, float& hn) {
+  cn = fsig_(g.y) * cp + fsig_(g.x) * ftanh_(g.z);
+  hn = fsig_(g.w) * ftanh_(cn);
+}
+// backward cell of one unit: pre-activations, c_prev, c, dh, dc_in -> gate gradients (i, f, g, o), gradient of c_prev
+__device__ __forceinline__ float4 cell_bwd_unit(const float4 pre, float cp, float c, float dh, float dci, float& dcp) {
+  const float i = fsig_(pre.x), f = fsig_(pre.y), g = ftanh_(pre.z), o = fsig_(pre.w);
+  const float tc = ftanh_(c);
+  const float dc = dci + dh * o * (1.0f - tc * tc);
+  dcp = dc * f;
+  return float4{dc * g * i * (1.0f - i), dc * cp * f * (1.0f - f), dc * i * (1.0f - g * g), dh * tc * o * (1.0f - o)};
+}
+
+// Stand-alone backward cell on the unit-interleaved layout (the LAST step's cell, whose dh comes from the head, not from a
+// GEMM): gs (n, 4H) interleaved pre-activations; c_prev / dc_in may be null (zero); dg (n, 4H) interleaved; dc_out (n, H).
+// dgx: if not null, receives dg + the n_more tensors dg_more[m] (single-step networks: the input projection's gradient).
+__global__ __launch_bounds__(256) void lstm_cell_bwd_il_k(const float* __restrict__ gs, const float* __restrict__ c_prev, const float* __restrict__ c,
+                                                           const float* __restrict__ dh, const float* __restrict__ dc_in, float* __restrict__ dg,
+                                                           float* __restrict__ dc_out, float* __restrict__ dgx, const float* __restrict__ dg_more,
+                                                           int n_more, size_t total) {
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const float4 pre = ld4(gs + 4 * t);
+    const float cp = c_prev != nullptr ? c_prev[t] : 0.0f;
+    const float dci = dc_in != nullptr ? dc_in[t] : 0.0f;
+    float dcp;
+    float4 d = cell_bwd_unit(pre, cp, c[t], dh[t], dci, dcp);
+    if (dg != nullptr) st4(dg + 4 * t, d);
+    if (dgx != nullptr) {
+      for (int m = 0; m < n_more; ++m) {
+        const float4 p = ld4(dg_more + (size_t)m * total * 4 + 4 * t);
+        d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w;
+      }
+      st4(dgx + 4 * t, d);
+    }
+    dc_out[t] = dcp;
+  }
+}
+
+// Forward cell from pre-activations in TORCH's layout (rows, 4H: column e H + u) -- the rows of the input projection that the
+// split-K tail launch produces -- writing them unit-interleaved (gs) next to the new state.  c_prev null = zero state.
+__global__ __launch_bounds__(256) void lstm_cell_fwd_to_il_k(const float* __restrict__ g_std, const float* __restrict__ c_prev, float* __restrict__ gs,
+                                                              float* __restrict__ c, float* __restrict__ h, int rows, int H) {
+  const size_t total = (size_t)rows * H;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = t / H;
+    const int u = (int)(t % H);
+    const float* g0 = g_std + row * 4 * H + u;
+    const float4 pre = {g0[0], g0[H], g0[2 * H], g0[3 * H]};
+    float cn, hn;
+    cell_fwd_unit(pre, c_prev != nullptr ? c_prev[t] : 0.0f, cn, hn);
+    st4(gs + 4 * t, pre);
+    c[t] = cn;
+    h[t] = hn;
+  }
+}
+
 // ---- output head of the recognition network: zps = fc2(sigmoid(fc1(h)))  (encoder.py:53-56) ---------------------------------
 // fc1 (256 -> 50) stays a library GEMM; everything behind it is narrow (50 -> 8) and HBM-bound: as library calls the
 // backward is a (rows x 8)(8 x 50) GEMM on 16x16 tiles, an elementwise sigmoid', a split-K GEMM for the 8 x 50 weight
