@@ -769,7 +769,7 @@ int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void*
 }
 
 // ---------------------------------------------------------------- fused LSTM steps (GEMM + cell), unit-interleaved gate layout
-static bool lstm_fused_shape_ok(int M, int H, int K) { return M > 0 && H > 0 && (H % 32) == 0 && K > 0 && (K % 4) == 0; }
+static bool lstm_fused_shape_ok(int M, int H, int K) { return M > 0 && H > 0 && (H % 32) == 0 && K > 0 && (K % 4) == 0; }      // 32: one 128-column tile = 32 whole units
 
 int stove_lstm_gemm_cell_fwd(const float* A, const float* W, const float* bias, const float* add, const float* c_prev, float* gs, float* c,
                              float* h, int M, int H, int K, int lda, int nsplit, int tile, void* stream) {
@@ -811,7 +811,7 @@ int stove_lstm_cell_bwd_il(const float* gs, const float* c_prev, const float* c,
   if (total == 0) return 0;
   const size_t blocks = (total + 255) / 256;
   STOVE_LAUNCH(lstm_cell_bwd_il_k, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, gs, c_prev, c, dh, dc_in, dg,
-               dc_out, dgx, dg_more, n_more, total);
+               dc_out, dgx, dg_more, n_more, total, H);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

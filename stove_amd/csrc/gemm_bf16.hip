@@ -61,10 +61,10 @@ __device__ __forceinline__ void split4(const float4 v, u32x2& hi, u32x2& lo) {
 // Where one thread's NLD float4 pieces of an operand tile (ROWS x 32) come from: a running pointer per piece, advanced by one
 // k-step per tile, plus the piece's k offset inside the tile and whether its rows exist (edge tiles).
 // PERM (the unit-interleaved gate layout of the fused LSTM path, csrc/lstm.hip): the operand's rows in HBM keep torch's gate-major
-// order (row e H + u) while the GEMM walks them unit-major.  1 (K-contiguous operand, rows = gate columns, forward): tile row
-// [wn:1][j:2][q:2][e:2] of a 128-row tile is gate e of unit 16 wn + 4 q + j of the tile's 32 units -- the MFMA hands lane group q
-// the columns 16 j + 4 q + e, so a lane ends up with all four gates of four CONSECUTIVE units.  2 (K-major operand, k = gate
-// column, backward): k-row k'' = 4 u + e is fetched from row e (K / 4) + u.
+// order (row e H + u) while the GEMM walks them in the interleaved order (float4 position p = gate_unit_swz(u), element e).
+// 1 (K-contiguous operand, rows = gate columns, forward): row r of the operand as the GEMM sees it is gate r & 3 of unit
+// gate_unit_swz(r >> 2).  2 (K-major operand, k = gate column, backward): k-row k likewise; the unit is not linear in k, so the
+// source address is recomputed per k-step instead of advanced.
 template <int ROWS, bool KMAJOR, int THREADS, bool SCALAR = false, int PERM = 0>
 struct TileSrc {
   static constexpr int NLD = ROWS * kGemmBK / 4 / THREADS;
@@ -76,12 +76,23 @@ struct TileSrc {
   // SCALAR: the operand is not float4-addressable (odd leading dimension / extent, e.g. fc1's 50 columns): every element is
   // loaded and predicated on its own (a compile-time variant, so that the vector path keeps its branch-free loads)
   size_t step;
+  int kcur[NLD], ldm, hq;      // PERM 2: current k of each piece, leading dimension, rows per gate
+  __device__ __forceinline__ const float* addr(int j) const {
+    if (PERM == 2) return p[j] + (size_t)((kcur[j] & 3) * hq + gate_unit_swz(kcur[j] >> 2)) * ldm;
+    return p[j];
+  }
+  __device__ __forceinline__ void advance(int j) {
+    if (PERM == 2) kcur[j] += kGemmBK;
+    else p[j] += step;
+  }
   __device__ __forceinline__ void init(const float* __restrict__ P, int ld, int row0, int n_rows, int k_begin, int tid, int k_total = 0) {
     static_assert(PERM == 0 || (PERM == 1 && !KMAJOR && ROWS == 128) || (PERM == 2 && KMAJOR), "operand permutation / layout mismatch");
     rowmask = 0u;
     rowsleft = 0u;
     safe = P;
-    step = KMAJOR ? (PERM == 2 ? (size_t)(kGemmBK / 4) * ld : (size_t)kGemmBK * ld) : (size_t)kGemmBK;
+    step = KMAJOR ? (size_t)kGemmBK * ld : (size_t)kGemmBK;
+    ldm = ld;
+    hq = k_total >> 2;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int f = tid + THREADS * j;
@@ -94,13 +105,10 @@ struct TileSrc {
         kloc[j] = 4 * (f & 7);
       }
       const int k = k_begin + kloc[j];
-      int ksrc = k, rsrc = row;
-      if (PERM == 2) ksrc = (k & 3) * (k_total >> 2) + (k >> 2);
-      if (PERM == 1) {
-        const int rl = row - row0;
-        rsrc = (rl & 3) * (n_rows >> 2) + (row0 >> 2) + 16 * (rl >> 6) + 4 * ((rl >> 2) & 3) + ((rl >> 4) & 3);
-      }
-      p[j] = KMAJOR ? P + (size_t)ksrc * ld + row : P + (size_t)rsrc * ld + k;
+      int rsrc = row;
+      if (PERM == 1) rsrc = (row & 3) * (n_rows >> 2) + gate_unit_swz(row >> 2);
+      kcur[j] = k;
+      p[j] = KMAJOR ? (PERM == 2 ? P + row : P + (size_t)k * ld + row) : P + (size_t)rsrc * ld + k;
       rowmask |= row < n_rows ? (1u << j) : 0u;
       const int left = n_rows - row;
       rowsleft |= (unsigned)(left < 0 ? 0 : (left > 4 ? 4 : left)) << (3 * j);
@@ -124,18 +132,18 @@ struct TileLoad {
       // branch-free edge predication: out-of-range pieces read the operand's first float4 (always valid) and are zeroed later
       const bool ok = ((src.rowmask >> j) & 1u) && (k0 + src.kloc[j] < k_end);
       if constexpr (!SCALAR) {
-        v[j] = *reinterpret_cast<const float4*>(ok ? src.p[j] : src.safe);
+        v[j] = *reinterpret_cast<const float4*>(ok ? src.addr(j) : src.safe);
         okmask |= ok ? (1u << j) : 0u;
       } else {
         // element-wise: along k (K-contiguous: the K tail) or along the rows (K-major: the row tail)
         const int n_ok = !ok ? 0 : (KMAJOR ? (int)((src.rowsleft >> (3 * j)) & 7u) : (k_end - (k0 + src.kloc[j]) > 4 ? 4 : k_end - (k0 + src.kloc[j])));
         float e[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) e[q] = q < n_ok ? src.p[j][q] : 0.0f;
+        for (int q = 0; q < 4; ++q) e[q] = q < n_ok ? src.addr(j)[q] : 0.0f;
         v[j] = float4{e[0], e[1], e[2], e[3]};
         okmask |= 1u << j;
       }
-      src.p[j] += src.step;
+      src.advance(j);
     }
   }
   template <int NSPLIT>
@@ -184,8 +192,8 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int r0, int lane) {
 // (run time): C / bias / add are written and read element-wise.
 // EPI: 0 = C (+ bias) (+ add); 1 = LSTM cell forward behind the product (C = saved pre-activations, unit-interleaved; see LstmEpi);
 // 2 = LSTM cell backward behind dh = add + A B (nothing of dh is stored).  PERM bits: 1 = B rows gathered gate -> unit order
-// (TileSrc PERM 1), 2 = B k-rows gathered likewise (TileSrc PERM 2), 4 = row m of C is stored at row (m & 3)(M / 4) + (m >> 2) (the weight
-// gradients dg^T x come out unit-major and go back to torch's gate-major rows).
+// (TileSrc PERM 1), 2 = B k-rows gathered likewise (TileSrc PERM 2), 4 = row m of C is stored at row (m & 3)(M / 4) + gate_unit_swz(m >> 2)
+// (the weight gradients dg^T x come out in the interleaved order and go back to torch's gate-major rows).
 struct LstmEpi {
   // EPI 1: c_prev (M, H) or null (zero state) -> c, h (M, H); bias (if any) is indexed in torch's order
   const float* c_prev;
@@ -304,32 +312,40 @@ __global__ __launch_bounds__(BM * BN / 64, 2) void gemm_bf16_k(const float* __re
   // epilogue: lane holds C[m][n .. n+3], m = tile row (lane & 15), n = 4 (lane >> 4) + reg
   if constexpr (EPI == 1) {
     // LSTM cell forward.  Under PERM 1 the four registers of acc[i][j] are the gates (i, f, g, o) of unit u0 + j, u0 = the first of
-    // this lane's four consecutive units; in memory (unit-interleaved, ldc = 4H) they sit at column 4 (u0 + j): 64 contiguous
-    // bytes per lane and tile row.  All loads of a tile row (add: 4 x 16 B, c_prev: 16 B) go out before its arithmetic.
+    // this lane's four consecutive units; in memory (unit-interleaved, ldc = 4H) they sit where the plain product would put its
+    // columns n .. n+3 (float4 position gate_unit_swz(u0 + j)): 64 contiguous bytes per tile row and instruction.  ALL loads of the epilogue (per tile row: add 4 x 16 B, c_prev 16 B) are issued before the first
+    // use: at two waves per SIMD an epilogue that loads, computes and stores row by row pays a memory latency per row.
     const int Hh = N >> 2;
     const int u0 = (n0 >> 2) + 16 * wn + 4 * (lane >> 4);
+    const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float4 ad[4][4], cp[4];
+    int mrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+      mrow[i] = m < M ? m : M - 1;                      // rows past the edge read the last row (discarded below): no branches here
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        ad[i][j] = add != nullptr ? *reinterpret_cast<const float4*>(add + (size_t)mrow[i] * ldc + n0 + wn * 64 + j * 16 + 4 * (lane >> 4)) : z4;
+      cp[i] = ep.c_prev != nullptr ? *reinterpret_cast<const float4*>(ep.c_prev + (size_t)mrow[i] * Hh + u0) : z4;
+    }
     float bi[4][4];                 // bias of this lane's 4 units x 4 gates (torch's order in memory: one float4 per gate)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float4 b4 = bias != nullptr ? *reinterpret_cast<const float4*>(bias + e * Hh + u0) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+      const float4 b4 = bias != nullptr ? *reinterpret_cast<const float4*>(bias + e * Hh + u0) : z4;
       bi[0][e] = b4.x; bi[1][e] = b4.y; bi[2][e] = b4.z; bi[3][e] = b4.w;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + wm * 64 + i * 16 + (lane & 15);
       if (m >= M) continue;
-      float4 ad[4], cp = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        ad[j] = add != nullptr ? *reinterpret_cast<const float4*>(add + (size_t)m * ldc + 4 * (u0 + j)) : float4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (ep.c_prev != nullptr) cp = *reinterpret_cast<const float4*>(ep.c_prev + (size_t)m * Hh + u0);
-      const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+      const float cpv[4] = {cp[i].x, cp[i].y, cp[i].z, cp[i].w};
       float cn[4], hn[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float4 g = {acc[i][j].x + bi[j][0] + ad[j].x, acc[i][j].y + bi[j][1] + ad[j].y, acc[i][j].z + bi[j][2] + ad[j].z,
-                          acc[i][j].w + bi[j][3] + ad[j].w};
-        *reinterpret_cast<float4*>(C + (size_t)m * ldc + 4 * (u0 + j)) = g;
+        const float4 g = {acc[i][j].x + bi[j][0] + ad[i][j].x, acc[i][j].y + bi[j][1] + ad[i][j].y, acc[i][j].z + bi[j][2] + ad[i][j].z,
+                          acc[i][j].w + bi[j][3] + ad[i][j].w};
+        *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0 + wn * 64 + j * 16 + 4 * (lane >> 4)) = g;
         cell_fwd_unit(g, cpv[j], cn[j], hn[j]);
       }
       *reinterpret_cast<float4*>(ep.c + (size_t)m * Hh + u0) = float4{cn[0], cn[1], cn[2], cn[3]};
@@ -338,48 +354,60 @@ __global__ __launch_bounds__(BM * BN / 64, 2) void gemm_bf16_k(const float* __re
     return;
   }
   if constexpr (EPI == 2) {
-    // LSTM cell backward of the step in front: acc + add = dh of units n .. n+3 (N = H here); everything else is streamed per
-    // (tile row, 16-column block): 4 x 16 B of pre-activations, c_prev, c, dc_in -> 4 x 16 B of gate gradients, dc_out.
+    // LSTM cell backward of the step in front: acc + add = dh of units n .. n+3 (N = H here); everything else is streamed: per
+    // (tile row, 16-column block) 4 x 16 B of pre-activations, c_prev, c, dc_in -> 4 x 16 B of gate gradients, dc_out.  The 32
+    // loads of a tile row go out together (one exposed latency per row instead of one per block).
+    const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-      if (m >= M) continue;
+      const int mr = m < M ? m : M - 1;
+      float4 pre[4][4], a4[4], cp4[4], cc4[4], di4[4];
+      size_t ho[4], hg[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+        n = n < N ? n : N - 4;
+        ho[j] = (size_t)mr * N + n;
+        // gates of unit n + e: float4 position gate_unit_swz(n + e) = (n & ~15) + 4 e + (lane >> 4) of the row (n & 15 = 4 (lane >> 4))
+        hg[j] = (size_t)mr * N + (n & ~15) + (lane >> 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pre[j][e] = *reinterpret_cast<const float4*>(ep.gs + 4 * hg[j] + 16 * e);
+        a4[j] = add != nullptr ? *reinterpret_cast<const float4*>(add + (size_t)mr * ldc + n) : z4;
+        cp4[j] = ep.c_prev != nullptr ? *reinterpret_cast<const float4*>(ep.c_prev + ho[j]) : z4;
+        cc4[j] = *reinterpret_cast<const float4*>(ep.c_cur + ho[j]);
+        di4[j] = ep.dc_in != nullptr ? *reinterpret_cast<const float4*>(ep.dc_in + ho[j]) : z4;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-        if (n >= N) continue;
-        const size_t ho = (size_t)m * N + n, go = 4 * ho;
-        float4 pre[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pre[e] = *reinterpret_cast<const float4*>(ep.gs + go + 4 * e);
-        const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float4 a4 = add != nullptr ? *reinterpret_cast<const float4*>(add + (size_t)m * ldc + n) : z4;
-        const float4 cp4 = ep.c_prev != nullptr ? *reinterpret_cast<const float4*>(ep.c_prev + ho) : z4;
-        const float4 cc4 = *reinterpret_cast<const float4*>(ep.c_cur + ho);
-        const float4 di4 = ep.dc_in != nullptr ? *reinterpret_cast<const float4*>(ep.dc_in + ho) : z4;
+        const size_t go = 4 * hg[j];
         float4 more[4] = {z4, z4, z4, z4};
         if (ep.dgx != nullptr) {
           for (int q = 0; q < ep.n_more; ++q) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float4 p4 = *reinterpret_cast<const float4*>(ep.dg_more + (size_t)q * M * N * 4 + go + 4 * e);
+              const float4 p4 = *reinterpret_cast<const float4*>(ep.dg_more + (size_t)q * M * N * 4 + go + 16 * e);
               more[e].x += p4.x; more[e].y += p4.y; more[e].z += p4.z; more[e].w += p4.w;
             }
           }
         }
-        const float dh[4] = {acc[i][j].x + a4.x, acc[i][j].y + a4.y, acc[i][j].z + a4.z, acc[i][j].w + a4.w};
-        const float cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w}, cc[4] = {cc4.x, cc4.y, cc4.z, cc4.w}, di[4] = {di4.x, di4.y, di4.z, di4.w};
+        const float dh[4] = {acc[i][j].x + a4[j].x, acc[i][j].y + a4[j].y, acc[i][j].z + a4[j].z, acc[i][j].w + a4[j].w};
+        const float cp[4] = {cp4[j].x, cp4[j].y, cp4[j].z, cp4[j].w}, cc[4] = {cc4[j].x, cc4[j].y, cc4[j].z, cc4[j].w};
+        const float di[4] = {di4[j].x, di4[j].y, di4[j].z, di4[j].w};
         float dcp[4];
+        float4 d[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float4 d = cell_bwd_unit(pre[e], cp[e], cc[e], dh[e], di[e], dcp[e]);
-          if (ep.dg != nullptr) *reinterpret_cast<float4*>(ep.dg + go + 4 * e) = d;
-          if (ep.dgx != nullptr) {
-            d.x += more[e].x; d.y += more[e].y; d.z += more[e].z; d.w += more[e].w;
-            *reinterpret_cast<float4*>(ep.dgx + go + 4 * e) = d;
+        for (int e = 0; e < 4; ++e) d[e] = cell_bwd_unit(pre[j][e], cp[e], cc[e], dh[e], di[e], dcp[e]);
+        if (m < M && n < N) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (ep.dg != nullptr) *reinterpret_cast<float4*>(ep.dg + go + 16 * e) = d[e];
+            if (ep.dgx != nullptr)
+              *reinterpret_cast<float4*>(ep.dgx + go + 16 * e) = float4{d[e].x + more[e].x, d[e].y + more[e].y, d[e].z + more[e].z, d[e].w + more[e].w};
           }
+          *reinterpret_cast<float4*>(ep.dc_out + ho[j]) = float4{dcp[0], dcp[1], dcp[2], dcp[3]};
         }
-        *reinterpret_cast<float4*>(ep.dc_out + ho) = float4{dcp[0], dcp[1], dcp[2], dcp[3]};
       }
     }
     return;
@@ -388,7 +416,7 @@ __global__ __launch_bounds__(BM * BN / 64, 2) void gemm_bf16_k(const float* __re
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-    const int ms = (PERM & 4) ? (m & 3) * (M >> 2) + (m >> 2) : m;       // where row m of the product is stored (and added from)
+    const int ms = (PERM & 4) ? (m & 3) * (M >> 2) + gate_unit_swz(m >> 2) : m;       // where row m of the product is stored (and added from)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);

@@ -118,6 +118,8 @@ __global__ void lstm_cell_bwd_k(const float* __restrict__ gx, const float* __res
 //
 // Activations in that path: sigmoid and tanh on v_exp_f32 / v_rcp_f32 (absolute error ~1e-7; the ocml tanhf of the stand-alone
 // cell kernels above is ~100 instructions per call, which as a GEMM epilogue ran exposed: +255 us per step in round 2).
+// float4 position <-> unit inside a row of a unit-interleaved gate tensor (an involution: swaps bits [1:0] and [3:2])
+__host__ __device__ __forceinline__ int gate_unit_swz(int p) { return (p & ~15) | ((p & 3) << 2) | ((p >> 2) & 3); }
 __device__ __forceinline__ float fsig_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float ftanh_(float x) {
   const float t = __builtin_amdgcn_exp2f(-2.8853900817779268f * fabsf(x));      // e^(-2|x|) in (0, 1]
@@ -143,13 +145,15 @@ __device__ __forceinline__ float4 cell_bwd_unit(const float4 pre, float cp, floa
 __global__ __launch_bounds__(256) void lstm_cell_bwd_il_k(const float* __restrict__ gs, const float* __restrict__ c_prev, const float* __restrict__ c,
                                                            const float* __restrict__ dh, const float* __restrict__ dc_in, float* __restrict__ dg,
                                                            float* __restrict__ dc_out, float* __restrict__ dgx, const float* __restrict__ dg_more,
-                                                           int n_more, size_t total) {
+                                                           int n_more, size_t total, int H) {
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-    const float4 pre = ld4(gs + 4 * t);
-    const float cp = c_prev != nullptr ? c_prev[t] : 0.0f;
-    const float dci = dc_in != nullptr ? dc_in[t] : 0.0f;
+    const float4 pre = ld4(gs + 4 * t);               // thread = float4 position: fully coalesced gate streams
+    const size_t row = t / H;
+    const size_t u = row * H + gate_unit_swz((int)(t - row * H));      // its unit: the same 64-byte segment of the (n, H) tensors
+    const float cp = c_prev != nullptr ? c_prev[u] : 0.0f;
+    const float dci = dc_in != nullptr ? dc_in[u] : 0.0f;
     float dcp;
-    float4 d = cell_bwd_unit(pre, cp, c[t], dh[t], dci, dcp);
+    float4 d = cell_bwd_unit(pre, cp, c[u], dh[u], dci, dcp);
     if (dg != nullptr) st4(dg + 4 * t, d);
     if (dgx != nullptr) {
       for (int m = 0; m < n_more; ++m) {
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_il_k(const float* __restric
       }
       st4(dgx + 4 * t, d);
     }
-    dc_out[t] = dcp;
+    dc_out[u] = dcp;
   }
 }
 
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_to_il_k(const float* __rest
     const float4 pre = {g0[0], g0[H], g0[2 * H], g0[3 * H]};
     float cn, hn;
     cell_fwd_unit(pre, c_prev != nullptr ? c_prev[t] : 0.0f, cn, hn);
-    st4(gs + 4 * t, pre);
+    st4(gs + 4 * (row * H + gate_unit_swz(u)), pre);
     c[t] = cn;
     h[t] = hn;
   }

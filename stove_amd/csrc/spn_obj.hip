@@ -977,7 +977,8 @@ __global__ __launch_bounds__(256) void reduce_chunks_gates_k(const float* __rest
     float t = red[0][e];
 #pragma unroll
     for (int k = 1; k < 8; ++k) t += red[k][e];
-    const int o = (j & 3) * (n >> 2) + (j >> 2);
+    const int pj = j >> 2;                                       // float4 position -> unit (csrc/lstm.hip gate_unit_swz)
+    const int o = (j & 3) * (n >> 2) + ((pj & ~15) | ((pj & 3) << 2) | ((pj >> 2) & 3));
     out[o] = accumulate ? out[o] + t : t;
     if (out2 != nullptr) out2[o] = accumulate ? out2[o] + t : t;
   }

@@ -1441,7 +1441,11 @@ class _EncoderLstmFusedFn(torch.autograd.Function):
             bias_sums(d_b, None, 0)
             dx = None
             if ctx.needs_input_grad[0]:
-                dx = torch.mm(dgx.view(n, H, 4).permute(0, 2, 1).reshape(n, 4 * H), w_ih)
+                pos = torch.arange(H, device=dev)
+                unit = (pos & ~15) | ((pos & 3) << 2) | ((pos >> 2) & 3)           # float4 position -> unit (csrc/lstm.hip gate_unit_swz)
+                std = torch.empty(n, 4, H, dtype=torch.float32, device=dev)
+                std[:, :, unit] = dgx.view(n, H, 4).permute(0, 2, 1)
+                dx = torch.mm(std.view(n, 4 * H), w_ih)
         return dx, d_wih, d_whh, d_b, d_b, None, None, None
 
 
