@@ -374,6 +374,11 @@ int stove_graph_instantiate(void* graph, void** exec_out);
 int stove_graph_launch(void* exec, void* stream);
 int stove_graph_destroy(void* exec);
 
+/* ---- reparameterisation noise (stove.py:667, 679, 146/167): out[0..n) <- standard normal draws, Philox-4x32-10 + Box-Muller, a pure
+ * function of (state[0] = seed, state[1] = call number, element index); state: two 64-bit words in DEVICE memory, state[1] is advanced by
+ * one behind the draw (a captured launch therefore replays with fresh noise; no host-side generator state).  out 16-byte aligned. */
+int stove_noise_normal(float* out, size_t n, unsigned long long* state, void* stream);
+
 /* bw_transform (reference utils.py): x (n_frames, channels, pixels) -> out (n_frames, pixels) = clamp(sum over channels, 0, 1). */
 int stove_bw_transform(const float* x, float* out, int n_frames, int channels, int pixels, void* stream);
 /* the same from an 8-bit frame store (load_data.py:60-113 keeps float frames on the host; here the training
@@ -427,42 +432,12 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
  * the full sum with the recurrent term (the recurrent GEMM adds gx in its epilogue) and then gh NULL; gh (n,4H): h_prev W_hh^T
  * or NULL; c_prev (n,H) or NULL (zero state).  bwd: dh, dc_in (NULL = 0) -> dg (n,4H) (NULL: not stored), dc_out (n,H);
  * dgx_sum (n,4H) or NULL = dg of this step + the n_more gate gradients dg_more[m][n][4H] of other steps: the gradient of the
- * input projection shared by all steps, formed once (by the last backward step) and feeding dW_ih. */
-int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, float* c, float* h, int n, int H, void* stream);
+ * input projection shared by all steps, formed once (by the last backward step) and feeding dW_ih.
+ * fast != 0: sigmoid / tanh on v_exp_f32 / v_rcp_f32 (absolute error ~1e-7) instead of an IEEE division and ocml's tanhf. */
+int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, float* c, float* h, int n, int H, int fast, void* stream);
 int stove_lstm_cell_bwd(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
                         const float* dc_in, float* dg, float* dc_out, float* dgx_sum, const float* dg_more, int n_more, int n, int H,
-                        void* stream);
-
-/* ---- the LSTM steps of RnnStates with the cell INSIDE the products (round 4; encoder.py:43-51).  Between the products the
- * stand-alone cells above are pure HBM round trips (the forward cell re-reads the pre-activations the product has just written,
- * the backward cell writes gate gradients the next product reads back); here the cell is the product's epilogue.  That needs the
- * four gates of a unit in one lane, so inside this path every (rows, 4H) gate tensor is UNIT-INTERLEAVED: column 4 u + e holds gate
- * e (0..3 = i, f, g, o) of unit u (torch: column e H + u).  The weights and biases keep torch's layout; the loaders gather through
- * the map.  sigmoid / tanh on v_exp_f32 / v_rcp_f32 (absolute error ~1e-7).  H % 32 == 0, K % 4 == 0, all pointers 16-byte aligned.
- * fwd: gs (M, 4H) = A (M, K; row stride lda) W^T (+ bias) (+ add), W (4H, K) and bias (4H) in torch's order, add (M, 4H)
- *      interleaved (the shared input projection gx); then the cell: c_prev (M, H) or NULL (zero) -> c, h (M, H).  gs is what the
- *      backward of this step reads.  tile: 1 = 256 x 128 workgroups, 2 = 128 x 128.
- * bwd: dh = dh_add (M, H) + dg_next (M, 4H; interleaved gate gradients of the step behind) W_hh, W_hh (4H, H) in torch's order;
- *      then the cell backward of THIS step from gs, c_prev (or NULL), c, dc_in (or NULL): dg (M, 4H) (or NULL), dc_out (M, H),
- *      dgx (or NULL) = this step's dg + the n_more tensors dg_more[i] (M, 4H each, consecutive): the gradient of the shared input
- *      projection, formed by the last backward step.  dh itself is never stored.
- * stove_lstm_cell_bwd_il: the same cell backward stand-alone (the last step's, whose dh comes from the head); n rows.
- * stove_lstm_cell_fwd_to_il: forward cell from pre-activations in TORCH's layout (rows of the input projection made by a split-K
- *      launch), writing them interleaved next to c, h.
- * stove_gemm_bf16_gate_rows: C (M, N) [+]= A^T B for K-major A (K, M; interleaved gate columns) and B (K, N): row 4 u + e of the
- *      product goes to row e (M / 4) + u of C -- dW_ih = dgx^T x and dW_hh = dg^T h in torch's row order; add == C accumulates.
- * stove_colsum2_gates: stove_colsum2 over interleaved columns, sums stored in torch's order (the bias gradients). */
-int stove_lstm_gemm_cell_fwd(const float* A, const float* W, const float* bias, const float* add, const float* c_prev, float* gs, float* c,
-                             float* h, int M, int H, int K, int lda, int nsplit, int tile, void* stream);
-int stove_lstm_gemm_cell_bwd(const float* dg_next, const float* W_hh, const float* dh_add, const float* gs, const float* c_prev, const float* c,
-                             const float* dc_in, float* dg, float* dc_out, float* dgx, const float* dg_more, int n_more, int M, int H,
-                             int nsplit, int tile, void* stream);
-int stove_lstm_cell_bwd_il(const float* gs, const float* c_prev, const float* c, const float* dh, const float* dc_in, float* dg, float* dc_out,
-                           float* dgx, const float* dg_more, int n_more, int n, int H, void* stream);
-int stove_lstm_cell_fwd_to_il(const float* g_std, const float* c_prev, float* gs, float* c, float* h, int rows, int H, void* stream);
-int stove_gemm_bf16_gate_rows(const float* A, const float* B, const float* add, float* C, int M, int N, int K, int lda, int ldb, int nsplit,
-                              int splitk, float* ws, void* stream);
-int stove_colsum2_gates(const float* a, float* out, float* out2, int accumulate, float* ws, int rows, int cols, void* stream);
+                        int fast, void* stream);
 
 /* ---- output head of RnnStates behind fc1 (encoder.py:53-56: zps = fc2(sigmoid(fc1(output)))).  a1 (rows, H1) = fc1
  * pre-activations (library GEMM) -> h1 = sigmoid(a1) (rows, H1) and codes (rows, OUT) = h1 W2^T + b2; W2 (OUT, H1).

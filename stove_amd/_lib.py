@@ -24,8 +24,7 @@ EXPORTS = [
     'stove_enc_head_fwd', 'stove_enc_head_bwd_ws_floats', 'stove_enc_head_bwd', 'stove_colsum2', 'stove_small_tn', 'stove_small_tn_ws_floats', 'stove_supair_state_fwd2', 'stove_supair_state_bwd2', 'stove_bg_dense', 'stove_bg_dense_floats',
     'stove_bw_transform_u8', 'stove_stream_after', 'stove_capture_begin', 'stove_capture_end', 'stove_graph_instantiate', 'stove_graph_launch', 'stove_graph_destroy',
     'stove_reward_head_param_floats', 'stove_reward_head_saved_floats', 'stove_reward_head_bwd_ws_floats', 'stove_reward_head_fwd',
-    'stove_lstm_gemm_cell_fwd', 'stove_lstm_gemm_cell_bwd', 'stove_lstm_cell_bwd_il', 'stove_lstm_cell_fwd_to_il', 'stove_gemm_bf16_gate_rows', 'stove_colsum2_gates',
-    'stove_set_overlap', 'stove_set_tablegrad_placement', 'stove_event_list_begin', 'stove_event_list_end', 'stove_event_list_destroy', 'stove_fill_words',
+    'stove_noise_normal', 'stove_set_overlap', 'stove_set_tablegrad_placement', 'stove_event_list_begin', 'stove_event_list_end', 'stove_event_list_destroy', 'stove_fill_words',
     'stove_reward_head_bwd', 'stove_small_linear', 'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_fwd_floats', 'stove_scene_bwd_from', 'stove_dynloop_range_ok', 'stove_dynloop_fwd_range', 'stove_dynloop_bwd_range', 'stove_zall_fwd_range', 'stove_zall_bwd_range',
 ]
 
@@ -87,8 +86,8 @@ def _declare(lib):
         'stove_rollout_fwd': (I, [P] * 6 + [I] * 7 + [F] * 3 + [P]),
         'stove_match_objects': (I, [P, P, P, I, I, I, I, I, P]),
         'stove_profile_enable': (None, [I]),
-        'stove_lstm_cell_fwd': (I, [P, P, P, P, P, I, I, P]),
-        'stove_lstm_cell_bwd': (I, [P] * 10 + [I, I, I, P]),
+        'stove_lstm_cell_fwd': (I, [P, P, P, P, P, I, I, I, P]),
+        'stove_lstm_cell_bwd': (I, [P] * 10 + [I, I, I, I, P]),
         'stove_gnn_debug_stamps': (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
         'stove_profile_report': (S, [c_char_p, S]),
         'stove_spn_bake': (I, [P, A, P, P, P, P, P, P]),
@@ -117,12 +116,7 @@ def _declare(lib):
         'stove_reward_head_fwd': (I, [P, P, P, P, I, I, P]),
         'stove_reward_head_bwd': (I, [P] * 8 + [I, I, P]),
         'stove_set_fork_stream': (I, [I, P, I]),
-        'stove_lstm_gemm_cell_fwd': (I, [P] * 8 + [I] * 6 + [P]),
-        'stove_lstm_gemm_cell_bwd': (I, [P] * 11 + [I] * 5 + [P]),
-        'stove_lstm_cell_bwd_il': (I, [P] * 9 + [I, I, I, P]),
-        'stove_lstm_cell_fwd_to_il': (I, [P] * 5 + [I, I, P]),
-        'stove_gemm_bf16_gate_rows': (I, [P, P, P, P] + [I] * 7 + [P, P]),
-        'stove_colsum2_gates': (I, [P, P, P, I, P, I, I, P]),
+        'stove_noise_normal': (I, [P, S, P, P]),
         'stove_set_overlap': (I, [I]),
         'stove_set_tablegrad_placement': (I, [I]),
         'stove_event_list_begin': (P, []),

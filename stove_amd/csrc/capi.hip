@@ -768,83 +768,10 @@ int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void*
   return 0;
 }
 
-// ---------------------------------------------------------------- fused LSTM steps (GEMM + cell), unit-interleaved gate layout
-static bool lstm_fused_shape_ok(int M, int H, int K) { return M > 0 && H > 0 && (H % 32) == 0 && K > 0 && (K % 4) == 0; }      // 32: one 128-column tile = 32 whole units
-
-int stove_lstm_gemm_cell_fwd(const float* A, const float* W, const float* bias, const float* add, const float* c_prev, float* gs, float* c,
-                             float* h, int M, int H, int K, int lda, int nsplit, int tile, void* stream) {
-  if (M == 0) return 0;
-  if (!lstm_fused_shape_ok(M, H, K) || (lda & 3) || (nsplit != 1 && nsplit != 2)) return (int)hipErrorInvalidValue;
-  for (const void* p : {(const void*)A, (const void*)W, (const void*)bias, (const void*)add, (const void*)c_prev, (const void*)gs, (const void*)c, (const void*)h})
-    if (((uintptr_t)p & 15) != 0) return (int)hipErrorInvalidValue;
-  LstmEpi ep{};
-  ep.c_prev = c_prev; ep.c = c; ep.h = h;
-  const int N = 4 * H;
-  hipStream_t st = (hipStream_t)stream;
-  if (tile == 2)
-    return nsplit == 2 ? gemm_launch<false, false, 2, 128, 128, 0, false, 1, 1>(A, W, bias, add, gs, M, N, K, lda, K, N, 1, st, 0, ep)
-                       : gemm_launch<false, false, 1, 128, 128, 0, false, 1, 1>(A, W, bias, add, gs, M, N, K, lda, K, N, 1, st, 0, ep);
-  return nsplit == 2 ? gemm_launch<false, false, 2, 256, 128, 0, false, 1, 1>(A, W, bias, add, gs, M, N, K, lda, K, N, 1, st, 0, ep)
-                     : gemm_launch<false, false, 1, 256, 128, 0, false, 1, 1>(A, W, bias, add, gs, M, N, K, lda, K, N, 1, st, 0, ep);
-}
-
-int stove_lstm_gemm_cell_bwd(const float* dg_next, const float* W_hh, const float* dh_add, const float* gs, const float* c_prev, const float* c,
-                             const float* dc_in, float* dg, float* dc_out, float* dgx, const float* dg_more, int n_more, int M, int H,
-                             int nsplit, int tile, void* stream) {
-  if (M == 0) return 0;
-  if (!lstm_fused_shape_ok(M, H, 4 * H) || (nsplit != 1 && nsplit != 2) || n_more < 0 || (dg == nullptr && dgx == nullptr)) return (int)hipErrorInvalidValue;
-  LstmEpi ep{};
-  ep.gs = gs; ep.c_prev = c_prev; ep.c_cur = c; ep.dc_in = dc_in; ep.dg = dg; ep.dc_out = dc_out; ep.dgx = dgx; ep.dg_more = dg_more; ep.n_more = n_more;
-  const int N = H, K = 4 * H;
-  hipStream_t st = (hipStream_t)stream;
-  // A = dg_next (M, 4H) unit-interleaved, B = W_hh (4H, H) read K-major with its rows gathered unit-major; nothing is written to C
-  if (tile == 2)
-    return nsplit == 2 ? gemm_launch<false, true, 2, 128, 128, 0, false, 2, 2>(dg_next, W_hh, nullptr, dh_add, nullptr, M, N, K, K, H, N, 1, st, 0, ep)
-                       : gemm_launch<false, true, 1, 128, 128, 0, false, 2, 2>(dg_next, W_hh, nullptr, dh_add, nullptr, M, N, K, K, H, N, 1, st, 0, ep);
-  return nsplit == 2 ? gemm_launch<false, true, 2, 256, 128, 0, false, 2, 2>(dg_next, W_hh, nullptr, dh_add, nullptr, M, N, K, K, H, N, 1, st, 0, ep)
-                     : gemm_launch<false, true, 1, 256, 128, 0, false, 2, 2>(dg_next, W_hh, nullptr, dh_add, nullptr, M, N, K, K, H, N, 1, st, 0, ep);
-}
-
-int stove_lstm_cell_bwd_il(const float* gs, const float* c_prev, const float* c, const float* dh, const float* dc_in, float* dg, float* dc_out,
-                           float* dgx, const float* dg_more, int n_more, int n, int H, void* stream) {
-  const size_t total = (size_t)n * H;
-  if (total == 0) return 0;
-  const size_t blocks = (total + 255) / 256;
-  STOVE_LAUNCH(lstm_cell_bwd_il_k, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, gs, c_prev, c, dh, dc_in, dg,
-               dc_out, dgx, dg_more, n_more, total, H);
-  STOVE_LAUNCH_CHECK();
-  return 0;
-}
-
-int stove_lstm_cell_fwd_to_il(const float* g_std, const float* c_prev, float* gs, float* c, float* h, int rows, int H, void* stream) {
-  const size_t total = (size_t)rows * H;
-  if (total == 0) return 0;
-  const size_t blocks = (total + 255) / 256;
-  STOVE_LAUNCH(lstm_cell_fwd_to_il_k, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, g_std, c_prev, gs, c, h, rows, H);
-  STOVE_LAUNCH_CHECK();
-  return 0;
-}
-
 size_t stove_gemm_bf16_ws_floats(int M, int N, int splitk) { return splitk > 1 ? (size_t)splitk * M * N : 0; }
-
-static int gemm_bf16_any(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda,
-                         int ldb, int ldc, int a_kmajor, int b_kmajor, int nsplit, int splitk, int tile, float* ws, void* stream, int gate_rows);
 
 int stove_gemm_bf16(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda,
                     int ldb, int ldc, int a_kmajor, int b_kmajor, int nsplit, int splitk, int tile, float* ws, void* stream) {
-  return gemm_bf16_any(A, B, bias, add, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, nsplit, splitk, tile, ws, stream, 0);
-}
-
-// dW = dg^T x with dg unit-interleaved (csrc/lstm.hip): both operands K-major, row m = 4 u + e of the product is stored at (and,
-// with add == C, accumulated into) row e (M / 4) + u of C -- torch's gate-major rows of W_ih / W_hh.  Otherwise stove_gemm_bf16.
-int stove_gemm_bf16_gate_rows(const float* A, const float* B, const float* add, float* C, int M, int N, int K, int lda, int ldb, int nsplit,
-                              int splitk, float* ws, void* stream) {
-  if ((M & 3) != 0) return (int)hipErrorInvalidValue;
-  return gemm_bf16_any(A, B, nullptr, add, C, M, N, K, lda, ldb, N, 1, 1, nsplit, splitk, 1, ws, stream, 1);
-}
-
-static int gemm_bf16_any(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda,
-                         int ldb, int ldc, int a_kmajor, int b_kmajor, int nsplit, int splitk, int tile, float* ws, void* stream, int gate_rows) {
   hipStream_t st = (hipStream_t)stream;
   if (M == 0 || N == 0) return 0;
   if (K <= 0 || splitk < 1 || (nsplit != 1 && nsplit != 2) || tile < 0 || (tile > 2 && tile != 11 && tile != 12)) return (int)hipErrorInvalidValue;
@@ -868,11 +795,7 @@ static int gemm_bf16_any(const float* A, const float* B, const float* bias, cons
   const int ldo = splitk > 1 ? N : ldc;
   if (tile == 0) tile = 1;
   int rc;
-  if (gate_rows) {
-    if (scalar_bits) return (int)hipErrorInvalidValue;
-    rc = nsplit == 2 ? gemm_launch<true, true, 2, 256, 128, 0, false, 0, 4>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, 0)
-                     : gemm_launch<true, true, 1, 256, 128, 0, false, 0, 4>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, 0);
-  } else if (scalar_bits & 1) {        // element-wise A: the two layouts fc1's backward needs (d_a1 W1 and d_a1^T h), 128 x 128 tile
+  if (scalar_bits & 1) {        // element-wise A: the two layouts fc1's backward needs (d_a1 W1 and d_a1^T h), 128 x 128 tile
     if (!b_kmajor) return (int)hipErrorInvalidValue;
     if (a_kmajor) rc = nsplit == 2 ? gemm_launch<true, true, 2, 128, 128, 0, true>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits)
                                    : gemm_launch<true, true, 1, 128, 128, 0, true>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits);
@@ -1078,16 +1001,7 @@ static int colsum_level(const float* a, float* part, int rows, int cols, int max
 
 int stove_colsum(const float* a, float* out, float* ws, int rows, int cols, void* stream) { return stove_colsum2(a, out, nullptr, 0, ws, rows, cols, stream); }
 
-static int colsum2_any(const float* a, float* out, float* out2, int accumulate, float* ws, int rows, int cols, void* stream, int gates);
 int stove_colsum2(const float* a, float* out, float* out2, int accumulate, float* ws, int rows, int cols, void* stream) {
-  return colsum2_any(a, out, out2, accumulate, ws, rows, cols, stream, 0);
-}
-// the same over a unit-interleaved gate tensor (column 4 u + e): the sums land in torch's order, out[e (cols / 4) + u]
-int stove_colsum2_gates(const float* a, float* out, float* out2, int accumulate, float* ws, int rows, int cols, void* stream) {
-  if (cols % 4 != 0) return (int)hipErrorInvalidValue;
-  return colsum2_any(a, out, out2, accumulate, ws, rows, cols, stream, 1);
-}
-static int colsum2_any(const float* a, float* out, float* out2, int accumulate, float* ws, int rows, int cols, void* stream, int gates) {
   hipStream_t st = (hipStream_t)stream;
   if (cols <= 0 || (cols % 4 != 0 && cols > 64)) return (int)hipErrorInvalidValue;
   if (rows == 0) {
@@ -1108,12 +1022,8 @@ static int colsum2_any(const float* a, float* out, float* out2, int accumulate, 
     STOVE_LAUNCH_CHECK();
     src = ws2;
   }
-  if (gates) {
-    STOVE_LAUNCH(reduce_chunks_gates_k, dim3((cols + 31) / 32), dim3(256), 0, st, src, out, out2, cols, used, accumulate);
-  } else {
-    STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, src, out, cols, used, accumulate);
-    if (out2 != nullptr) STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, src, out2, cols, used, accumulate);
-  }
+  STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, src, out, cols, used, accumulate);
+  if (out2 != nullptr) STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, src, out2, cols, used, accumulate);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -1211,6 +1121,17 @@ int stove_supair_state_bwd2(const float* zc, const long long* idx, const unsigne
   STOVE_LAUNCH_CHECK();
   STOVE_LAUNCH(supair_state_bwd2_k, dim3((M + 255) / 256), dim3(256), 0, st, zc, idx, hits, (const float*)gfix_ws, zp_const(span_low),
                g_codes, n, T, o);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_noise_normal(float* out, size_t n, unsigned long long* state, void* stream) {
+  if (n == 0) return 0;
+  if (((uintptr_t)out & 15) != 0 || state == nullptr) return (int)hipErrorInvalidValue;
+  const size_t threads = (n + 3) / 4;
+  if ((threads + 255) / 256 > 0x7fffffffULL) return (int)hipErrorInvalidValue;
+  STOVE_LAUNCH(noise_normal_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n, (const unsigned long long*)state);
+  STOVE_LAUNCH(noise_tick_k, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -1382,25 +1303,28 @@ int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, con
   return 0;
 }
 
-int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, float* c, float* h, int n, int H, void* stream) {
+int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, float* c, float* h, int n, int H, int fast, void* stream) {
   if (n == 0) return 0;
   if (H % 4) return (int)hipErrorInvalidValue;
   const size_t total = (size_t)n * (H / 4);
   const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  STOVE_LAUNCH(lstm_cell_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, gx, gh, c_prev, c, h, n, H);
+  if (fast) STOVE_LAUNCH(lstm_cell_fwd_k<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gx, gh, c_prev, c, h, n, H);
+  else STOVE_LAUNCH(lstm_cell_fwd_k<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gx, gh, c_prev, c, h, n, H);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
 
 int stove_lstm_cell_bwd(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
                         const float* dc_in, float* dg, float* dc_out, float* dgx_sum, const float* dg_more, int n_more, int n, int H,
-                        void* stream) {
+                        int fast, void* stream) {
   if (n == 0) return 0;
   if (H % 4 || n_more < 0 || (n_more > 0 && dg_more == nullptr)) return (int)hipErrorInvalidValue;
   const size_t total = (size_t)n * (H / 4);
   const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  STOVE_LAUNCH(lstm_cell_bwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, gx, gh, c_prev, c, dh, dc_in, dg, dc_out, dgx_sum, dg_more,
-               n_more, n, H);
+  if (fast) STOVE_LAUNCH(lstm_cell_bwd_k<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gx, gh, c_prev, c, dh, dc_in, dg, dc_out, dgx_sum, dg_more,
+                         n_more, n, H);
+  else STOVE_LAUNCH(lstm_cell_bwd_k<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gx, gh, c_prev, c, dh, dc_in, dg, dc_out, dgx_sum, dg_more,
+                    n_more, n, H);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

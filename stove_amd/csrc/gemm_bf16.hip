@@ -60,12 +60,7 @@ __device__ __forceinline__ void split4(const float4 v, u32x2& hi, u32x2& lo) {
 
 // Where one thread's NLD float4 pieces of an operand tile (ROWS x 32) come from: a running pointer per piece, advanced by one
 // k-step per tile, plus the piece's k offset inside the tile and whether its rows exist (edge tiles).
-// PERM (the unit-interleaved gate layout of the fused LSTM path, csrc/lstm.hip): the operand's rows in HBM keep torch's gate-major
-// order (row e H + u) while the GEMM walks them in the interleaved order (float4 position p = gate_unit_swz(u), element e).
-// 1 (K-contiguous operand, rows = gate columns, forward): row r of the operand as the GEMM sees it is gate r & 3 of unit
-// gate_unit_swz(r >> 2).  2 (K-major operand, k = gate column, backward): k-row k likewise; the unit is not linear in k, so the
-// source address is recomputed per k-step instead of advanced.
-template <int ROWS, bool KMAJOR, int THREADS, bool SCALAR = false, int PERM = 0>
+template <int ROWS, bool KMAJOR, int THREADS, bool SCALAR = false>
 struct TileSrc {
   static constexpr int NLD = ROWS * kGemmBK / 4 / THREADS;
   const float* p[NLD];
@@ -76,23 +71,11 @@ struct TileSrc {
   // SCALAR: the operand is not float4-addressable (odd leading dimension / extent, e.g. fc1's 50 columns): every element is
   // loaded and predicated on its own (a compile-time variant, so that the vector path keeps its branch-free loads)
   size_t step;
-  int kcur[NLD], ldm, hq;      // PERM 2: current k of each piece, leading dimension, rows per gate
-  __device__ __forceinline__ const float* addr(int j) const {
-    if (PERM == 2) return p[j] + (size_t)((kcur[j] & 3) * hq + gate_unit_swz(kcur[j] >> 2)) * ldm;
-    return p[j];
-  }
-  __device__ __forceinline__ void advance(int j) {
-    if (PERM == 2) kcur[j] += kGemmBK;
-    else p[j] += step;
-  }
-  __device__ __forceinline__ void init(const float* __restrict__ P, int ld, int row0, int n_rows, int k_begin, int tid, int k_total = 0) {
-    static_assert(PERM == 0 || (PERM == 1 && !KMAJOR && ROWS == 128) || (PERM == 2 && KMAJOR), "operand permutation / layout mismatch");
+  __device__ __forceinline__ void init(const float* __restrict__ P, int ld, int row0, int n_rows, int k_begin, int tid) {
     rowmask = 0u;
     rowsleft = 0u;
     safe = P;
     step = KMAJOR ? (size_t)kGemmBK * ld : (size_t)kGemmBK;
-    ldm = ld;
-    hq = k_total >> 2;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int f = tid + THREADS * j;
@@ -105,10 +88,7 @@ struct TileSrc {
         kloc[j] = 4 * (f & 7);
       }
       const int k = k_begin + kloc[j];
-      int rsrc = row;
-      if (PERM == 1) rsrc = (row & 3) * (n_rows >> 2) + gate_unit_swz(row >> 2);
-      kcur[j] = k;
-      p[j] = KMAJOR ? (PERM == 2 ? P + row : P + (size_t)k * ld + row) : P + (size_t)rsrc * ld + k;
+      p[j] = KMAJOR ? P + (size_t)k * ld + row : P + (size_t)row * ld + k;
       rowmask |= row < n_rows ? (1u << j) : 0u;
       const int left = n_rows - row;
       rowsleft |= (unsigned)(left < 0 ? 0 : (left > 4 ? 4 : left)) << (3 * j);
@@ -124,26 +104,25 @@ struct TileLoad {
   unsigned okmask;      // bit j: piece j is inside the operand (the zeroing of edge pieces is deferred to store_piece: a
                         // select right behind the load would make the wave wait for it at once)
   // loads the tile whose first k is `k0` and advances the source by one k-step
-  template <class Src>
-  __device__ __forceinline__ void load(Src& src, int k0, int k_end) {
+  __device__ __forceinline__ void load(TileSrc<ROWS, KMAJOR, THREADS, SCALAR>& src, int k0, int k_end) {
     okmask = 0u;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       // branch-free edge predication: out-of-range pieces read the operand's first float4 (always valid) and are zeroed later
       const bool ok = ((src.rowmask >> j) & 1u) && (k0 + src.kloc[j] < k_end);
       if constexpr (!SCALAR) {
-        v[j] = *reinterpret_cast<const float4*>(ok ? src.addr(j) : src.safe);
+        v[j] = *reinterpret_cast<const float4*>(ok ? src.p[j] : src.safe);
         okmask |= ok ? (1u << j) : 0u;
       } else {
         // element-wise: along k (K-contiguous: the K tail) or along the rows (K-major: the row tail)
         const int n_ok = !ok ? 0 : (KMAJOR ? (int)((src.rowsleft >> (3 * j)) & 7u) : (k_end - (k0 + src.kloc[j]) > 4 ? 4 : k_end - (k0 + src.kloc[j])));
         float e[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) e[q] = q < n_ok ? src.addr(j)[q] : 0.0f;
+        for (int q = 0; q < 4; ++q) e[q] = q < n_ok ? src.p[j][q] : 0.0f;
         v[j] = float4{e[0], e[1], e[2], e[3]};
         okmask |= 1u << j;
       }
-      src.advance(j);
+      src.p[j] += src.step;
     }
   }
   template <int NSPLIT>
@@ -190,31 +169,10 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int r0, int lane) {
 
 // DEBUG (tools only): 1 = no loads in the loop, 2 = no MFMAs.  A_SCALAR: A is read element-wise (see TileSrc); bit 2 of `scalar_bits`
 // (run time): C / bias / add are written and read element-wise.
-// EPI: 0 = C (+ bias) (+ add); 1 = LSTM cell forward behind the product (C = saved pre-activations, unit-interleaved; see LstmEpi);
-// 2 = LSTM cell backward behind dh = add + A B (nothing of dh is stored).  PERM bits: 1 = B rows gathered gate -> unit order
-// (TileSrc PERM 1), 2 = B k-rows gathered likewise (TileSrc PERM 2), 4 = row m of C is stored at row (m & 3)(M / 4) + gate_unit_swz(m >> 2)
-// (the weight gradients dg^T x come out in the interleaved order and go back to torch's gate-major rows).
-struct LstmEpi {
-  // EPI 1: c_prev (M, H) or null (zero state) -> c, h (M, H); bias (if any) is indexed in torch's order
-  const float* c_prev;
-  float* c;
-  float* h;
-  // EPI 2: gs (M, 4H) unit-interleaved pre-activations of the step whose cell is differentiated, its c_prev (or null) and c,
-  // dc_in (or null) -> dg (M, 4H) (or null), dc_out (M, H), dgx (or null) = dg + the n_more tensors dg_more[i] (M, 4H each)
-  const float* gs;
-  const float* c_cur;
-  const float* dc_in;
-  float* dg;
-  float* dc_out;
-  float* dgx;
-  const float* dg_more;
-  int n_more;
-};
-
-template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT, int BM, int BN, int DEBUG = 0, bool A_SCALAR = false, int EPI = 0, int PERM = 0>
-__global__ __launch_bounds__(BM * BN / 64, 2) void gemm_bf16_k(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT, int BM, int BN, int DEBUG = 0, bool A_SCALAR = false>
+__global__ __launch_bounds__(BM * BN / 64) void gemm_bf16_k(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                                                const float* __restrict__ add, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
-                                                               int tiles_m, int tiles_n, int splitk, int k_per_slice, int scalar_bits, LstmEpi ep) {
+                                                               int tiles_m, int tiles_n, int splitk, int k_per_slice, int scalar_bits) {
   extern __shared__ __attribute__((aligned(16))) char gemm_lds[];
   constexpr int kGemmBM = BM, kGemmBN = BN, THREADS = BM * BN / 64;      // one wave per 64 x 64 of the tile
   constexpr int kGemmAPart = gemm_part_bytes(BM), kGemmBPart = gemm_part_bytes(BN);
@@ -249,9 +207,9 @@ __global__ __launch_bounds__(BM * BN / 64, 2) void gemm_bf16_k(const float* __re
   TileLoad<kGemmBM, A_KMAJOR, THREADS, A_SCALAR> la0, la1;
   TileLoad<kGemmBN, B_KMAJOR, THREADS> lb0, lb1;
   TileSrc<kGemmBM, A_KMAJOR, THREADS, A_SCALAR> sa;
-  TileSrc<kGemmBN, B_KMAJOR, THREADS, false, (PERM & 1) ? 1 : ((PERM & 2) ? 2 : 0)> sb;
+  TileSrc<kGemmBN, B_KMAJOR, THREADS> sb;
   sa.init(A, lda, m0, M, k_begin, tid);
-  sb.init(B, ldb, n0, N, k_begin, tid, K);
+  sb.init(B, ldb, n0, N, k_begin, tid);
   if (nt > 0) {
     la0.load(sa, k_begin, k_end);
     lb0.load(sb, k_begin, k_end);
@@ -310,113 +268,10 @@ __global__ __launch_bounds__(BM * BN / 64, 2) void gemm_bf16_k(const float* __re
     if (t + 1 < nt) kstep(t + 1, la0, lb0, la1, lb1);
   }
   // epilogue: lane holds C[m][n .. n+3], m = tile row (lane & 15), n = 4 (lane >> 4) + reg
-  if constexpr (EPI == 1) {
-    // LSTM cell forward.  Under PERM 1 the four registers of acc[i][j] are the gates (i, f, g, o) of unit u0 + j, u0 = the first of
-    // this lane's four consecutive units; in memory (unit-interleaved, ldc = 4H) they sit where the plain product would put its
-    // columns n .. n+3 (float4 position gate_unit_swz(u0 + j)): 64 contiguous bytes per tile row and instruction.  ALL loads of the epilogue (per tile row: add 4 x 16 B, c_prev 16 B) are issued before the first
-    // use: at two waves per SIMD an epilogue that loads, computes and stores row by row pays a memory latency per row.
-    const int Hh = N >> 2;
-    const int u0 = (n0 >> 2) + 16 * wn + 4 * (lane >> 4);
-    const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    float4 ad[4][4], cp[4];
-    int mrow[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-      mrow[i] = m < M ? m : M - 1;                      // rows past the edge read the last row (discarded below): no branches here
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        ad[i][j] = add != nullptr ? *reinterpret_cast<const float4*>(add + (size_t)mrow[i] * ldc + n0 + wn * 64 + j * 16 + 4 * (lane >> 4)) : z4;
-      cp[i] = ep.c_prev != nullptr ? *reinterpret_cast<const float4*>(ep.c_prev + (size_t)mrow[i] * Hh + u0) : z4;
-    }
-    float bi[4][4];                 // bias of this lane's 4 units x 4 gates (torch's order in memory: one float4 per gate)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float4 b4 = bias != nullptr ? *reinterpret_cast<const float4*>(bias + e * Hh + u0) : z4;
-      bi[0][e] = b4.x; bi[1][e] = b4.y; bi[2][e] = b4.z; bi[3][e] = b4.w;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-      if (m >= M) continue;
-      const float cpv[4] = {cp[i].x, cp[i].y, cp[i].z, cp[i].w};
-      float cn[4], hn[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 g = {acc[i][j].x + bi[j][0] + ad[i][j].x, acc[i][j].y + bi[j][1] + ad[i][j].y, acc[i][j].z + bi[j][2] + ad[i][j].z,
-                          acc[i][j].w + bi[j][3] + ad[i][j].w};
-        *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0 + wn * 64 + j * 16 + 4 * (lane >> 4)) = g;
-        cell_fwd_unit(g, cpv[j], cn[j], hn[j]);
-      }
-      *reinterpret_cast<float4*>(ep.c + (size_t)m * Hh + u0) = float4{cn[0], cn[1], cn[2], cn[3]};
-      *reinterpret_cast<float4*>(ep.h + (size_t)m * Hh + u0) = float4{hn[0], hn[1], hn[2], hn[3]};
-    }
-    return;
-  }
-  if constexpr (EPI == 2) {
-    // LSTM cell backward of the step in front: acc + add = dh of units n .. n+3 (N = H here); everything else is streamed: per
-    // (tile row, 16-column block) 4 x 16 B of pre-activations, c_prev, c, dc_in -> 4 x 16 B of gate gradients, dc_out.  The 32
-    // loads of a tile row go out together (one exposed latency per row instead of one per block).
-    const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-      const int mr = m < M ? m : M - 1;
-      float4 pre[4][4], a4[4], cp4[4], cc4[4], di4[4];
-      size_t ho[4], hg[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-        n = n < N ? n : N - 4;
-        ho[j] = (size_t)mr * N + n;
-        // gates of unit n + e: float4 position gate_unit_swz(n + e) = (n & ~15) + 4 e + (lane >> 4) of the row (n & 15 = 4 (lane >> 4))
-        hg[j] = (size_t)mr * N + (n & ~15) + (lane >> 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pre[j][e] = *reinterpret_cast<const float4*>(ep.gs + 4 * hg[j] + 16 * e);
-        a4[j] = add != nullptr ? *reinterpret_cast<const float4*>(add + (size_t)mr * ldc + n) : z4;
-        cp4[j] = ep.c_prev != nullptr ? *reinterpret_cast<const float4*>(ep.c_prev + ho[j]) : z4;
-        cc4[j] = *reinterpret_cast<const float4*>(ep.c_cur + ho[j]);
-        di4[j] = ep.dc_in != nullptr ? *reinterpret_cast<const float4*>(ep.dc_in + ho[j]) : z4;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-        const size_t go = 4 * hg[j];
-        float4 more[4] = {z4, z4, z4, z4};
-        if (ep.dgx != nullptr) {
-          for (int q = 0; q < ep.n_more; ++q) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float4 p4 = *reinterpret_cast<const float4*>(ep.dg_more + (size_t)q * M * N * 4 + go + 16 * e);
-              more[e].x += p4.x; more[e].y += p4.y; more[e].z += p4.z; more[e].w += p4.w;
-            }
-          }
-        }
-        const float dh[4] = {acc[i][j].x + a4[j].x, acc[i][j].y + a4[j].y, acc[i][j].z + a4[j].z, acc[i][j].w + a4[j].w};
-        const float cp[4] = {cp4[j].x, cp4[j].y, cp4[j].z, cp4[j].w}, cc[4] = {cc4[j].x, cc4[j].y, cc4[j].z, cc4[j].w};
-        const float di[4] = {di4[j].x, di4[j].y, di4[j].z, di4[j].w};
-        float dcp[4];
-        float4 d[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = cell_bwd_unit(pre[j][e], cp[e], cc[e], dh[e], di[e], dcp[e]);
-        if (m < M && n < N) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (ep.dg != nullptr) *reinterpret_cast<float4*>(ep.dg + go + 16 * e) = d[e];
-            if (ep.dgx != nullptr)
-              *reinterpret_cast<float4*>(ep.dgx + go + 16 * e) = float4{d[e].x + more[e].x, d[e].y + more[e].y, d[e].z + more[e].z, d[e].w + more[e].w};
-          }
-          *reinterpret_cast<float4*>(ep.dc_out + ho[j]) = float4{dcp[0], dcp[1], dcp[2], dcp[3]};
-        }
-      }
-    }
-    return;
-  }
   float* out = C + (splitk > 1 ? (size_t)z * M * ldc : 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-    const int ms = (PERM & 4) ? (m & 3) * (M >> 2) + gate_unit_swz(m >> 2) : m;       // where row m of the product is stored (and added from)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
@@ -428,18 +283,18 @@ __global__ __launch_bounds__(BM * BN / 64, 2) void gemm_bf16_k(const float* __re
             v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
           }
           if (add != nullptr && splitk == 1) {
-            const float4 d4 = *reinterpret_cast<const float4*>(add + (size_t)ms * ldc + n);
+            const float4 d4 = *reinterpret_cast<const float4*>(add + (size_t)m * ldc + n);
             v.x += d4.x; v.y += d4.y; v.z += d4.z; v.w += d4.w;
           }
-          *reinterpret_cast<f32x4*>(out + (size_t)ms * ldc + n) = v;
+          *reinterpret_cast<f32x4*>(out + (size_t)m * ldc + n) = v;
         } else {        // N or ldc not a multiple of 4: element-wise epilogue
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (n + e < N) {
               float t = v[e];
               if (bias != nullptr && splitk == 1) t += bias[n + e];
-              if (add != nullptr && splitk == 1) t += add[(size_t)ms * ldc + n + e];
-              out[(size_t)ms * ldc + n + e] = t;
+              if (add != nullptr && splitk == 1) t += add[(size_t)m * ldc + n + e];
+              out[(size_t)m * ldc + n + e] = t;
             }
           }
         }
@@ -451,16 +306,16 @@ __global__ __launch_bounds__(BM * BN / 64, 2) void gemm_bf16_k(const float* __re
 // LDS bytes of the kernel
 constexpr int gemm_lds_bytes(int nsplit, int bm, int bn) { return 2 * nsplit * (gemm_part_bytes(bm) + gemm_part_bytes(bn)); }
 
-template <bool AK, bool BK_, int NS, int BM = 256, int BN = 128, int DEBUG = 0, bool A_SCALAR = false, int EPI = 0, int PERM = 0>
+template <bool AK, bool BK_, int NS, int BM = 256, int BN = 128, int DEBUG = 0, bool A_SCALAR = false>
 static int gemm_launch(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                       int splitk, hipStream_t st, int scalar_bits = 0, LstmEpi ep = LstmEpi{}) {
+                       int splitk, hipStream_t st, int scalar_bits = 0) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   int kper = ((K + splitk - 1) / splitk + kGemmBK - 1) / kGemmBK * kGemmBK;
-  const void* fn = (const void*)gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR, EPI, PERM>;
+  const void* fn = (const void*)gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR>;
   int rc = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(NS, BM, BN));
   if (rc) return rc;
-  STOVE_LAUNCH((gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR, EPI, PERM>), dim3(tiles_m * tiles_n * splitk), dim3(BM * BN / 64), gemm_lds_bytes(NS, BM, BN), st, A, B, bias, add, C,
-               M, N, K, lda, ldb, ldc, tiles_m, tiles_n, splitk, kper, scalar_bits, ep);
+  STOVE_LAUNCH((gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR>), dim3(tiles_m * tiles_n * splitk), dim3(BM * BN / 64), gemm_lds_bytes(NS, BM, BN), st, A, B, bias, add, C,
+               M, N, K, lda, ldb, ldc, tiles_m, tiles_n, splitk, kper, scalar_bits);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

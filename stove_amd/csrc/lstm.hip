@@ -13,9 +13,25 @@ namespace stove {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float sig_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// FAST: sigmoid / tanh on v_exp_f32 / v_rcp_f32 (absolute error ~1e-7) instead of an IEEE division and ocml's tanhf (~100
+// instructions per call): the backward cell is then bound by its HBM streams alone
+template <bool FAST>
+__device__ __forceinline__ float sigm(float x) {
+  if (FAST) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+  return sig_(x);
+}
+template <bool FAST>
+__device__ __forceinline__ float tanh_(float x) {
+  if (FAST) {
+    const float t = __builtin_amdgcn_exp2f(-2.8853900817779268f * fabsf(x));      // e^(-2|x|) in (0, 1]
+    return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
+  }
+  return tanhf(x);
+}
 
 // gx (n,4H) input-side pre-activations (with both biases), gh (n,4H) recurrent pre-activations or null (h = 0),
 // c_prev (n,H) or null (zero) -> c, h (n,H)
+template <bool FAST>
 __global__ void lstm_cell_fwd_k(const float* __restrict__ gx, const float* __restrict__ gh, const float* __restrict__ c_prev,
                                 float* __restrict__ c, float* __restrict__ h, int n, int H) {
   const int q = H / 4;
@@ -36,14 +52,14 @@ __global__ void lstm_cell_fwd_k(const float* __restrict__ gx, const float* __res
     float4 cp = {0.0f, 0.0f, 0.0f, 0.0f};
     if (c_prev != nullptr) cp = ld4(c_prev + row * H + j);
     float4 cn, hn;
-    cn.x = sig_(gf.x) * cp.x + sig_(gi.x) * tanhf(gg.x);
-    cn.y = sig_(gf.y) * cp.y + sig_(gi.y) * tanhf(gg.y);
-    cn.z = sig_(gf.z) * cp.z + sig_(gi.z) * tanhf(gg.z);
-    cn.w = sig_(gf.w) * cp.w + sig_(gi.w) * tanhf(gg.w);
-    hn.x = sig_(go.x) * tanhf(cn.x);
-    hn.y = sig_(go.y) * tanhf(cn.y);
-    hn.z = sig_(go.z) * tanhf(cn.z);
-    hn.w = sig_(go.w) * tanhf(cn.w);
+    cn.x = sigm<FAST>(gf.x) * cp.x + sigm<FAST>(gi.x) * tanh_<FAST>(gg.x);
+    cn.y = sigm<FAST>(gf.y) * cp.y + sigm<FAST>(gi.y) * tanh_<FAST>(gg.y);
+    cn.z = sigm<FAST>(gf.z) * cp.z + sigm<FAST>(gi.z) * tanh_<FAST>(gg.z);
+    cn.w = sigm<FAST>(gf.w) * cp.w + sigm<FAST>(gi.w) * tanh_<FAST>(gg.w);
+    hn.x = sigm<FAST>(go.x) * tanh_<FAST>(cn.x);
+    hn.y = sigm<FAST>(go.y) * tanh_<FAST>(cn.y);
+    hn.z = sigm<FAST>(go.z) * tanh_<FAST>(cn.z);
+    hn.w = sigm<FAST>(go.w) * tanh_<FAST>(cn.w);
     st4(c + row * H + j, cn);
     st4(h + row * H + j, hn);
   }
@@ -55,6 +71,7 @@ __global__ void lstm_cell_fwd_k(const float* __restrict__ gx, const float* __res
 //    dgx_sum (n,4H) or null: this step's dg + the dg of `n_more` other steps, dg_more[m][n][4H] -- the input projection is
 //    shared by all steps, so its gradient is the sum over the steps; it is formed ONCE, by the last backward step (step 0),
 //    from the stored gate gradients of the others, instead of a read-modify-write of a running sum in every step.
+template <bool FAST>
 __global__ void lstm_cell_bwd_k(const float* __restrict__ gx, const float* __restrict__ gh, const float* __restrict__ c_prev,
                                 const float* __restrict__ c, const float* __restrict__ dh, const float* __restrict__ dc_in,
                                 float* __restrict__ dg, float* __restrict__ dc_out, float* __restrict__ dgx_sum,
@@ -83,8 +100,8 @@ __global__ void lstm_cell_bwd_k(const float* __restrict__ gx, const float* __res
     float out[4][4], dcp[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float i = sig_(pre[0][e]), f = sig_(pre[1][e]), g = tanhf(pre[2][e]), o = sig_(pre[3][e]);
-      const float tc = tanhf(cc[e]);
+      const float i = sigm<FAST>(pre[0][e]), f = sigm<FAST>(pre[1][e]), g = tanh_<FAST>(pre[2][e]), o = sigm<FAST>(pre[3][e]);
+      const float tc = tanh_<FAST>(cc[e]);
       const float dc = dci[e] + dhh[e] * o * (1.0f - tc * tc);
       out[0][e] = dc * g * i * (1.0f - i);
       out[1][e] = dc * cp[e] * f * (1.0f - f);
@@ -106,81 +123,6 @@ __global__ void lstm_cell_bwd_k(const float* __restrict__ gx, const float* __res
       }
     }
     st4(dc_out + ho, float4{dcp[0], dcp[1], dcp[2], dcp[3]});
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Unit-interleaved gate layout (round 4).  The MFMA GEMMs of csrc/gemm_bf16.hip run the cell as their epilogue (forward: behind
-// h W_hh^T + gx; backward: the cell backward of step k-1 behind dh_{k-1} = dhs[k-1] + dg_k W_hh), which needs the four gates of a
-// unit in ONE lane.  Inside that path every (rows, 4H) gate tensor -- gx, the saved pre-activations gs_k, the gate gradients dg_k,
-// dgx -- is stored unit-major:  column 4u + e  holds gate e (0..3 = i, f, g, o) of unit u; torch's layout is column e H + u.
-// W_ih / W_hh / the biases keep torch's layout in HBM: the GEMM loaders gather their rows through the same map.
-//
-// Activations in that path: sigmoid and tanh on v_exp_f32 / v_rcp_f32 (absolute error ~1e-7; the ocml tanhf of the stand-alone
-// cell kernels above is ~100 instructions per call, which as a GEMM epilogue ran exposed: +255 us per step in round 2).
-// float4 position <-> unit inside a row of a unit-interleaved gate tensor (an involution: swaps bits [1:0] and [3:2])
-__host__ __device__ __forceinline__ int gate_unit_swz(int p) { return (p & ~15) | ((p & 3) << 2) | ((p >> 2) & 3); }
-__device__ __forceinline__ float fsig_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
-__device__ __forceinline__ float ftanh_(float x) {
-  const float t = __builtin_amdgcn_exp2f(-2.8853900817779268f * fabsf(x));      // e^(-2|x|) in (0, 1]
-  return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
-}
-// forward cell of one unit: pre-activations (i, f, g, o), previous cell -> new cell, hidden
-__device__ __forceinline__ void cell_fwd_unit(const float4 g, float cp, float& cn, float& hn) {
-  cn = fsig_(g.y) * cp + fsig_(g.x) * ftanh_(g.z);
-  hn = fsig_(g.w) * ftanh_(cn);
-}
-// backward cell of one unit: pre-activations, c_prev, c, dh, dc_in -> gate gradients (i, f, g, o), gradient of c_prev
-__device__ __forceinline__ float4 cell_bwd_unit(const float4 pre, float cp, float c, float dh, float dci, float& dcp) {
-  const float i = fsig_(pre.x), f = fsig_(pre.y), g = ftanh_(pre.z), o = fsig_(pre.w);
-  const float tc = ftanh_(c);
-  const float dc = dci + dh * o * (1.0f - tc * tc);
-  dcp = dc * f;
-  return float4{dc * g * i * (1.0f - i), dc * cp * f * (1.0f - f), dc * i * (1.0f - g * g), dh * tc * o * (1.0f - o)};
-}
-
-// Stand-alone backward cell on the unit-interleaved layout (the LAST step's cell, whose dh comes from the head, not from a
-// GEMM): gs (n, 4H) interleaved pre-activations; c_prev / dc_in may be null (zero); dg (n, 4H) interleaved; dc_out (n, H).
-// dgx: if not null, receives dg + the n_more tensors dg_more[m] (single-step networks: the input projection's gradient).
-__global__ __launch_bounds__(256) void lstm_cell_bwd_il_k(const float* __restrict__ gs, const float* __restrict__ c_prev, const float* __restrict__ c,
-                                                           const float* __restrict__ dh, const float* __restrict__ dc_in, float* __restrict__ dg,
-                                                           float* __restrict__ dc_out, float* __restrict__ dgx, const float* __restrict__ dg_more,
-                                                           int n_more, size_t total, int H) {
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-    const float4 pre = ld4(gs + 4 * t);               // thread = float4 position: fully coalesced gate streams
-    const size_t row = t / H;
-    const size_t u = row * H + gate_unit_swz((int)(t - row * H));      // its unit: the same 64-byte segment of the (n, H) tensors
-    const float cp = c_prev != nullptr ? c_prev[u] : 0.0f;
-    const float dci = dc_in != nullptr ? dc_in[u] : 0.0f;
-    float dcp;
-    float4 d = cell_bwd_unit(pre, cp, c[u], dh[u], dci, dcp);
-    if (dg != nullptr) st4(dg + 4 * t, d);
-    if (dgx != nullptr) {
-      for (int m = 0; m < n_more; ++m) {
-        const float4 p = ld4(dg_more + (size_t)m * total * 4 + 4 * t);
-        d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w;
-      }
-      st4(dgx + 4 * t, d);
-    }
-    dc_out[u] = dcp;
-  }
-}
-
-// Forward cell from pre-activations in TORCH's layout (rows, 4H: column e H + u) -- the rows of the input projection that the
-// split-K tail launch produces -- writing them unit-interleaved (gs) next to the new state.  c_prev null = zero state.
-__global__ __launch_bounds__(256) void lstm_cell_fwd_to_il_k(const float* __restrict__ g_std, const float* __restrict__ c_prev, float* __restrict__ gs,
-                                                              float* __restrict__ c, float* __restrict__ h, int rows, int H) {
-  const size_t total = (size_t)rows * H;
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-    const size_t row = t / H;
-    const int u = (int)(t % H);
-    const float* g0 = g_std + row * 4 * H + u;
-    const float4 pre = {g0[0], g0[H], g0[2 * H], g0[3 * H]};
-    float cn, hn;
-    cell_fwd_unit(pre, c_prev != nullptr ? c_prev[t] : 0.0f, cn, hn);
-    st4(gs + 4 * (row * H + gate_unit_swz(u)), pre);
-    c[t] = cn;
-    h[t] = hn;
   }
 }
 

@@ -961,29 +961,6 @@ __global__ __launch_bounds__(256) void reduce_chunks_k(const float* __restrict__
   }
 }
 
-// the same with the result index mapped unit-interleaved -> gate-major (column j = 4 u + e of the partials -> out[e (n / 4) + u]) and an
-// optional second output (b_ih and b_hh of an LSTM receive the same sums): the bias gradients of the fused LSTM path (csrc/lstm.hip)
-__global__ __launch_bounds__(256) void reduce_chunks_gates_k(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ out2, int n,
-                                                              int n_chunks, int accumulate) {
-  __shared__ float red[8][32];
-  const int e = threadIdx.x & 31, q = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + e;
-  float s = 0.0f;
-  if (j < n)
-    for (int c = q; c < n_chunks; c += 8) s += part[(size_t)c * n + j];
-  red[q][e] = s;
-  __syncthreads();
-  if (q == 0 && j < n) {
-    float t = red[0][e];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) t += red[k][e];
-    const int pj = j >> 2;                                       // float4 position -> unit (csrc/lstm.hip gate_unit_swz)
-    const int o = (j & 3) * (n >> 2) + ((pj & ~15) | ((pj & 3) << 2) | ((pj >> 2) & 3));
-    out[o] = accumulate ? out[o] + t : t;
-    if (out2 != nullptr) out2[o] = accumulate ? out2[o] + t : t;
-  }
-}
-
 }  // namespace stove
 
 // =============================================================================================

@@ -285,6 +285,45 @@ __global__ void zall_bwd_k(const float* __restrict__ zfix, const float* __restri
   }
 }
 
+// ---- reparameterisation noise (stove.py:667, 679, 146/167: latent_prior.rsample, z_std_prior.rsample, one draw per step): all of a
+// step's standard-normal draws as ONE counter-based launch.  Philox-4x32-10 keyed by state[0] (the seed), counter = (state[1] = the
+// call number, thread index): thread i makes elements 4 i .. 4 i + 3 (two Box-Muller pairs on v_log / v_sin / v_cos), so a draw
+// depends on (seed, call, element) only -- independent of the launch geometry, bitwise reproducible.  The call counter lives in device
+// memory and is advanced by noise_tick_k behind the draw: a captured launch replays with fresh noise, and no host-side generator state
+// (torch's graph-safe Philox costs two fill launches in front of every replay, on the step's serial chain) is involved.
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+  c1 = (uint32_t)p1;
+  c3 = (uint32_t)p0;
+  c0 = n0;
+  c2 = n2;
+}
+__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }      // (0, 1)
+__global__ __launch_bounds__(256) void noise_normal_k(float* __restrict__ out, size_t n, const unsigned long long* __restrict__ state) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (4 * i >= n) return;
+  const unsigned long long seed = state[0], call = state[1];
+  uint32_t c0 = (uint32_t)call, c1 = (uint32_t)(call >> 32), c2 = (uint32_t)i, c3 = (uint32_t)(i >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  // Box-Muller: radius from v_log_f32 (log2), angle in revolutions straight into v_sin_f32 / v_cos_f32
+  const float r0 = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c0))), r1 = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c2)));
+  const float a0 = u01(c1), a1 = u01(c3);
+  const float v[4] = {r0 * __builtin_amdgcn_cosf(a0), r0 * __builtin_amdgcn_sinf(a0), r1 * __builtin_amdgcn_cosf(a1), r1 * __builtin_amdgcn_sinf(a1)};
+  if (4 * i + 3 < n) {
+    *reinterpret_cast<float4*>(out + 4 * i) = float4{v[0], v[1], v[2], v[3]};
+  } else {
+    for (size_t e = 4 * i; e < n; ++e) out[e] = v[e - 4 * i];
+  }
+}
+__global__ void noise_tick_k(unsigned long long* __restrict__ state) { state[1] += 1ull; }
+
 // ---- ELBO (stove.py:738-748): per sequence b
 //   part[b] = { sum_t (trans - logq + lik[b, skip-1+t]),  sum_{j<skip-1} lik[b, j],  sum_t trans,  sum_t logq }
 // with trans = sum_{k,d<16} log N(z[2+d]; zdyn[d], tstd[d]), logq = sum_{k,q<18} log N(z[q]; mean[q], std[q])

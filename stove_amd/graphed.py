@@ -127,6 +127,8 @@ class GraphedTrainStep:
         # state and the generator are put back afterwards, so capturing does not count as training
         snap = (self.arena.data.clone(), {k: v.clone() for k, v in self.opt._flat.items()}, torch.cuda.get_rng_state(dev),
                 self.opt._seg_steps.clone())
+        ns = getattr(self.stove, '_noise_source', None)         # the library's generator (ops.NoiseSource): its call counter is put back too
+        snap_noise = ns.state.clone() if ns is not None and ns.state is not None else None
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -140,6 +142,13 @@ class GraphedTrainStep:
                 self.opt._flat[k].copy_(v)
             self.opt._seg_steps.copy_(snap[3])
         torch.cuda.set_rng_state(snap[2], dev)
+        ns = getattr(self.stove, '_noise_source', None)
+        if ns is not None and ns.state is not None:
+            if snap_noise is not None:
+                ns.state.copy_(snap_noise)
+            else:
+                ns.state[1] = 0                  # created by the warm-up: no draw has counted yet
+        torch.cuda.synchronize(dev)
         # Capture on the stream the warm-up ran on (the autograd nodes then see one stream throughout), as THREE graphs:
         #   g_main  zero_grad + forward + backward, with its short fork / join episodes (table bake, background-SPN chain)
         #   g_side  the parameter-gradient chain of the backward pass (SPN table gradients, the recursion's and the recognition
@@ -249,12 +258,12 @@ class GraphedTrainStep:
         else:
             self._slot_events[slot] = torch.cuda.Event()
         self.ring[slot] = torch.tensor(self._hyper_now(reward_weight), dtype=torch.float32)
+        from . import _lib
+        lib = _lib.load()
+        main = torch.cuda.current_stream(self.x.device).cuda_stream
         self.hyper_dev.copy_(self.ring[slot], non_blocking=True)
         self.graphs[0].replay()
         if self._side_exec:
-            from . import _lib
-            lib = _lib.load()
-            main = torch.cuda.current_stream(self.x.device).cuda_stream
             _lib.check(lib.stove_graph_launch(self._side_exec, self._side.cuda_stream), 'stove_graph_launch')
             _lib.check(lib.stove_stream_after(main, self._side.cuda_stream), 'stove_stream_after')      # the optimiser reads what it wrote
         if len(self.graphs) > 1:

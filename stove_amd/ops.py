@@ -334,6 +334,38 @@ def glimpse_mean(x_color, z, n_obj):
     return emb
 
 
+class NoiseSource:
+    """Standard-normal draws from the library's counter-based generator (csrc/state.hip noise_normal_k): the state -- [seed, call
+    number] -- lives in device memory and is advanced on the device, so a captured draw replays with fresh noise and costs nothing on
+    the host.  Seeded from torch's generator of the device (torch.manual_seed reaches it); a reseed of that generator reseeds this."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._seed = None
+        self.state = None
+
+    def _sync_seed(self):
+        torch.cuda.init()
+        gen = torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()]
+        seed = int(gen.initial_seed())
+        if seed != self._seed:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('NoiseSource: the generator was reseeded inside a stream capture')
+            self._seed = seed
+            self.state = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, 0], dtype=torch.int64, device=self.device)
+
+    def normal(self, numel):
+        """(numel,) fp32 draws, enqueued on the library's current stream (ops run it on the parameter stream ahead of its consumer)."""
+        if not torch.cuda.is_current_stream_capturing():
+            self._sync_seed()
+        elif self.state is None:
+            raise RuntimeError('NoiseSource: first use inside a stream capture (run one eager step first)')
+        out = torch.empty(int(numel), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(_lib.load().stove_noise_normal(ptr(out), int(numel), self.state.data_ptr(), stream()), 'stove_noise_normal')
+        return out
+
+
 def wave_sum_selftest(x):
     lib = _lib.load()
     x = _f32(x)
@@ -1206,6 +1238,10 @@ class _blas:
         return False
 
 
+# gate activations of the LSTM cell kernels on v_exp_f32 / v_rcp_f32 (absolute error ~1e-7; STOVE_LSTM_FAST_CELL=0: IEEE division + ocml tanhf)
+FAST_CELL = int(os.environ.get('STOVE_LSTM_FAST_CELL', '1') != '0')
+
+
 class _EncoderLstmFn(torch.autograd.Function):
     """num_steps LSTM steps on the SAME input x (reference encoder.py:43-51): hs (n, num_steps, H).
 
@@ -1242,7 +1278,7 @@ class _EncoderLstmFn(torch.autograd.Function):
                         gs = torch.addmm(gx, hs[k - 1], w_hh.t())
                 gss.append(gs)
                 check(lib.stove_lstm_cell_fwd(ptr(gs), None, ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(hs[k]),
-                                              n, H, stream()), 'stove_lstm_cell_fwd')
+                                              n, H, FAST_CELL, stream()), 'stove_lstm_cell_fwd')
         ctx.save_for_backward(x, w_ih, w_hh, gx, hs, cs, b_ih, b_hh, *gss[1:])
         ctx.num_steps = num_steps
         ctx.time_major = bool(time_major)
@@ -1291,7 +1327,7 @@ class _EncoderLstmFn(torch.autograd.Function):
                 check(lib.stove_lstm_cell_bwd(ptr(gss[k]), None, ptr(cs[k - 1]) if k > 0 else None, ptr(cs[k]), ptr(dh),
                                               ptr(dc[(k + 1) % 2]) if k < K - 1 else None, ptr(dg) if dg is not None else None,
                                               ptr(dc[k % 2]), ptr(dgx) if k == 0 else None, ptr(dg_all) if (k == 0 and K > 1) else None,
-                                              K - 1 if k == 0 else 0, n, H, stream()), 'stove_lstm_cell_bwd')
+                                              K - 1 if k == 0 else 0, n, H, FAST_CELL, stream()), 'stove_lstm_cell_bwd')
                 if k == 1 and views is not None:
                     # all gate gradients W_hh sees are written: its GEMM starts here, beside the last recurrent step
                     on_side(lambda: wgrad(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H), out=views[1]), dg_all, hs)
@@ -1322,149 +1358,11 @@ class _EncoderLstmFn(torch.autograd.Function):
         return dx, d_wih, d_whh, d_b, d_b, None, None, None
 
 
-def _complete_round_rows(M, N, device):
-    """Rows of a tall x W^T product that fill COMPLETE rounds of 256 x 128 tiles on the chip (see _gemm_rows_balanced); the rest
-    (and everything, when the product has fewer tiles than CUs) is better served by a split-K launch."""
-    cus = torch.cuda.get_device_properties(device).multi_processor_count
-    tiles_n, tiles_m = (N + 127) // 128, (M + 255) // 256
-    rounds = (tiles_m * tiles_n) // cus
-    main_m = (rounds * cus) // tiles_n
-    tail_tiles = (tiles_m - main_m) * tiles_n
-    if rounds == 0:
-        return 0
-    if tail_tiles == 0 or tail_tiles * 4 > cus:
-        return M
-    return main_m * 256
-
-
-class _EncoderLstmFusedFn(torch.autograd.Function):
-    """The same LSTM with the cells inside the products (csrc/gemm_bf16.hip EPI 1 / 2, csrc/lstm.hip): no stand-alone cell
-    between two GEMMs in either direction, the gate tensors unit-interleaved (column 4 u + e).  Forward: x W_ih^T + b with cell 0
-    as its epilogue, then per step h W_hh^T + gx with the cell as epilogue.  Backward: the last step's cell stand-alone (its dh
-    comes from the head), then per step ONE launch = dh_{k-1} = dhs[k-1] + dg_k W_hh followed by the cell backward of step k-1 in
-    the epilogue (dh never reaches memory); the first step's epilogue also forms dgx = sum_k dg_k.  dW_ih / dW_hh come out of the
-    K-major products with their rows mapped back to torch's gate-major order, the bias sums likewise."""
-
-    @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major, ns):
-        lib = _lib.load()
-        x, w_ih, w_hh = _f32(x), _f32(w_ih), _f32(w_hh)
-        n, D, H = x.shape[0], x.shape[1], w_hh.shape[1]
-        dev = x.device
-        K = num_steps
-        with torch.cuda.device(dev):
-            bias = _f32(b_ih + b_hh)
-            hs = torch.empty(K, n, H, dtype=torch.float32, device=dev)
-            cs = torch.empty(K, n, H, dtype=torch.float32, device=dev)
-            gss = [torch.empty(n, 4 * H, dtype=torch.float32, device=dev) for _ in range(K)]      # gss[0] = gx
-            rows = _complete_round_rows(n, 4 * H, dev) if D % 256 == 0 else n
-            if rows > 0:
-                check(lib.stove_lstm_gemm_cell_fwd(ptr(x), ptr(w_ih), ptr(bias), None, None, ptr(gss[0]), ptr(cs[0]), ptr(hs[0]),
-                                                   rows, H, D, x.stride(0), ns, 1, stream()), 'stove_lstm_gemm_cell_fwd')
-            if rows < n:
-                # the incomplete last round (or a product with fewer tiles than CUs): K split over workgroups, the cell behind it
-                pre = gemm_bf16(x[rows:], w_ih, bias=bias, nsplit=ns, splitk=8)
-                check(lib.stove_lstm_cell_fwd_to_il(ptr(pre), None, gss[0][rows:].data_ptr(), cs[0][rows:].data_ptr(), hs[0][rows:].data_ptr(),
-                                                    n - rows, H, stream()), 'stove_lstm_cell_fwd_to_il')
-            for k in range(1, K):
-                check(lib.stove_lstm_gemm_cell_fwd(ptr(hs[k - 1]), ptr(w_hh), None, ptr(gss[0]), ptr(cs[k - 1]), ptr(gss[k]), ptr(cs[k]), ptr(hs[k]),
-                                                   n, H, H, H, ns, 2, stream()), 'stove_lstm_gemm_cell_fwd')
-        ctx.save_for_backward(x, w_ih, w_hh, hs, cs, b_ih, b_hh, *gss)
-        ctx.num_steps, ctx.time_major, ctx.ns = K, bool(time_major), ns
-        return hs if time_major else hs.transpose(0, 1)
-
-    @staticmethod
-    def backward(ctx, dhs):
-        lib = _lib.load()
-        x, w_ih, w_hh, hs, cs, b_ih, b_hh = ctx.saved_tensors[:7]
-        gss = list(ctx.saved_tensors[7:])
-        K, ns = ctx.num_steps, ctx.ns
-        n, H = x.shape[0], w_hh.shape[1]
-        dev = x.device
-        dhs = _f32(dhs if ctx.time_major else dhs.transpose(0, 1))                       # (K, n, H)
-        views = _grad_views(w_ih, w_hh, b_ih, b_hh, needs=ctx.needs_input_grad[1:5]) if not ctx.needs_input_grad[0] else None
-        fork = views is not None and os.environ.get('STOVE_NO_OVERLAP', '0') != '1'
-
-        def wgrad(dy, inp, out=None):
-            """dy^T @ inp over all rows (dy unit-interleaved) -> torch's gate-major rows; out: accumulated into."""
-            M, N, Kr = dy.shape[1], inp.shape[1], dy.shape[0]
-            sk = gemm_splitk(M, N, Kr)
-            c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=dev)
-            ws = torch.empty(lib.stove_gemm_bf16_ws_floats(M, N, sk), dtype=torch.float32, device=dev) if sk > 1 else None
-            _side_keep(ws, c)
-            check(lib.stove_gemm_bf16_gate_rows(ptr(dy), ptr(inp), ptr(c) if out is not None else None, ptr(c), M, N, Kr, dy.stride(0), inp.stride(0),
-                                                ns, sk, ptr(ws) if ws is not None else None, stream()), 'stove_gemm_bf16_gate_rows')
-            return c
-
-        def on_side(fn, *bufs):
-            if fork:
-                run_on_side(dev, fn, bufs)
-            else:
-                fn()
-        with torch.cuda.device(dev):
-            dgx = torch.empty(n, 4 * H, dtype=torch.float32, device=dev)
-            dg_all = torch.empty(max(K - 1, 1), n, 4 * H, dtype=torch.float32, device=dev)        # gate gradients of steps 1..K-1
-            dc = [torch.empty(n, H, dtype=torch.float32, device=dev) for _ in range(2)]
-            last = K - 1
-            check(lib.stove_lstm_cell_bwd_il(ptr(gss[last]), ptr(cs[last - 1]) if last > 0 else None, ptr(cs[last]), ptr(dhs[last]), None,
-                                             ptr(dg_all[last - 1]) if last > 0 else None, ptr(dc[last % 2]), ptr(dgx) if last == 0 else None, None, 0,
-                                             n, H, stream()), 'stove_lstm_cell_bwd_il')
-
-            def start_whh():
-                if K > 1 and views is not None:
-                    # all gate gradients W_hh sees are written: its product starts here, beside the rest of the chain
-                    on_side(lambda: wgrad(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H), out=views[1]), dg_all, hs)
-            if K == 2:
-                start_whh()
-            for k in range(K - 1, 0, -1):
-                first = k == 1              # this launch differentiates the cell of step 0
-                check(lib.stove_lstm_gemm_cell_bwd(ptr(dg_all[k - 1]), ptr(w_hh), ptr(dhs[k - 1]), ptr(gss[k - 1]), ptr(cs[k - 2]) if k >= 2 else None,
-                                                   ptr(cs[k - 1]), ptr(dc[k % 2]), ptr(dg_all[k - 2]) if k >= 2 else None, ptr(dc[(k - 1) % 2]),
-                                                   ptr(dgx) if first else None, ptr(dg_all) if first else None, K - 1 if first else 0, n, H, ns,
-                                                   int(os.environ.get('STOVE_LSTM_BWD_TILE', '2')), stream()), 'stove_lstm_gemm_cell_bwd')
-                if k == 2 and K > 2:
-                    start_whh()
-
-            def bias_sums(o1, o2, acc):
-                ws = torch.empty(lib.stove_colsum_ws_floats(n, 4 * H) + 1, dtype=torch.float32, device=dev)
-                _side_keep(ws)
-                check(lib.stove_colsum2_gates(ptr(dgx), ptr(o1), ptr(o2), acc, ptr(ws), n, 4 * H, stream()), 'stove_colsum2_gates')
-            if views is not None:
-                on_side(lambda: bias_sums(views[2], views[3], 1), dgx)
-                wgrad(dgx, x, out=views[0])
-                if fork:
-                    join_side_after_backward(dev)
-                return None, None, None, None, None, None, None, None
-            d_whh = wgrad(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H)) if K > 1 else torch.zeros_like(w_hh)
-            d_wih = wgrad(dgx, x)
-            d_b = torch.empty(4 * H, dtype=torch.float32, device=dev)
-            bias_sums(d_b, None, 0)
-            dx = None
-            if ctx.needs_input_grad[0]:
-                pos = torch.arange(H, device=dev)
-                unit = (pos & ~15) | ((pos & 3) << 2) | ((pos >> 2) & 3)           # float4 position -> unit (csrc/lstm.hip gate_unit_swz)
-                std = torch.empty(n, 4, H, dtype=torch.float32, device=dev)
-                std[:, :, unit] = dgx.view(n, H, 4).permute(0, 2, 1)
-                dx = torch.mm(std.view(n, 4 * H), w_ih)
-        return dx, d_wih, d_whh, d_b, d_b, None, None, None
-
-
-def encoder_lstm_fused_ok(x, w_hh, gemm, num_steps):
-    """Shapes the fused path takes: 4H a multiple of 128 (one 128-column tile = 32 whole units), float4-addressable operands."""
-    H = w_hh.shape[1]
-    return (gemm in ('bf16x3', 'bf16') and H % 32 == 0 and x.shape[1] % 4 == 0 and x.shape[0] > 0 and num_steps >= 1
-            and os.environ.get('STOVE_LSTM_FUSED', '1') != '0')
-
-
-def encoder_lstm(x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major=False, gemm='bf16x3', fused=True):
+def encoder_lstm(x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major=False, gemm='bf16x3'):
     """-> hs (n, num_steps, H), or (num_steps, n, H) with time_major=True: the layout the kernels produce; the row-wise
     head can run on it directly, which saves two 78 MB transposes per step (only its 8-wide output is permuted).
     gemm: 'bf16x3' = fp32 products as three bf16 MFMAs on hi/lo-split operands (csrc/gemm_bf16.hip, ~2^-17 relative),
-    'fp32' = library fp32 GEMMs, 'bf16' = plain bf16 operands with fp32 accumulation (the reported, never default, variant).
-    fused (default, MFMA paths only): the cells run as epilogues of the products (_EncoderLstmFusedFn); False = the round-3 chain of
-    products and stand-alone cell kernels (config.encoder_fused_cell, STOVE_LSTM_FUSED=0)."""
-    if fused and encoder_lstm_fused_ok(x, w_hh, gemm, num_steps):
-        return _EncoderLstmFusedFn.apply(x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major, {'bf16x3': 2, 'bf16': 1}[gemm])
+    'fp32' = library fp32 GEMMs, 'bf16' = plain bf16 operands with fp32 accumulation (the reported, never default, variant)."""
     return _EncoderLstmFn.apply(x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major, gemm)
 
 

@@ -35,7 +35,7 @@ class RnnStates(nn.Module):
         rnn = self.rnn
         gemm = getattr(self.c, 'encoder_gemm', 'bf16x3')
         hs = ops.encoder_lstm(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, self.c.num_obj,
-                              time_major=True, gemm=gemm, fused=bool(getattr(self.c, 'encoder_fused_cell', True)))     # (num_obj, n, 256), as the LSTM kernels write it
+                              time_major=True, gemm=gemm)     # (num_obj, n, 256), as the LSTM kernels write it
         fc1, fc2 = self.fc1, self.fc2
         # (n, num_obj, 8): the head writes its small output frame-major itself
         return ops.encoder_head(hs, fc1.weight, fc1.bias, fc2.weight, fc2.bias, gemm=gemm, step_major=True)

@@ -68,6 +68,30 @@ class Stove(nn.Module):
             return self.noise_fn(kind, shape).to(device=like.device, dtype=like.dtype)
         return torch.randn(shape, device=like.device, dtype=like.dtype)
 
+    def reset_noise(self):
+        """Restart the library generator's stream (call number 0) -- torch.manual_seed(s) with a NEW s reseeds it by itself, the same s
+        again cannot be told from no call at all."""
+        src = getattr(self, '_noise_source', None)
+        if src is not None and src.state is not None:
+            src.state[1] = 0
+
+    def _draw_ahead(self, numel, dev):
+        """All of a step's standard-normal draws from the library's generator, on the parameter stream (ops 'pre'), behind nothing:
+        -> (tensor, event to wait for before reading it)."""
+        src = getattr(self, '_noise_source', None)
+        if src is None or src.device != dev:
+            src = self._noise_source = ops.NoiseSource(dev)
+        main, side = torch.cuda.current_stream(dev), ops._side_stream(dev, 'pre')
+        if os.environ.get('STOVE_NO_OVERLAP', '0') == '1':
+            return src.normal(numel), None
+        side.wait_stream(main)                   # allocator order (the block may have been in use on `main`); nothing of this step is on `main` yet
+        with torch.cuda.stream(side):
+            out = src.normal(numel)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        out.record_stream(main)
+        return out, ev
+
     # ------------------------------------------------------------------ SuPAIR state helpers
     def v_from_state(self, z_sup):
         """(n,T,o,4) [sx,sy/sx,x,y] -> (n,T,o,6) with velocities x_t - x_{t-1}; the t=0 row is zero."""
@@ -170,15 +194,23 @@ class Stove(nn.Module):
         # 1. SuPAIR states for every frame, consistent object order, smoothing, velocities.
         # Without appearance features the whole chain (constrain_zp, matching, gather, fix_supair, velocities) is the
         # fused state pipeline (csrc/state.hip); the PyTorch chain below it is the same computation op by op.
+        # device RNG: the three draws of the reference (latent prior, the unused std prior, the step noise) as ONE launch, made
+        # before the state pipeline so that it can write the recursion's initial state [SuPAIR | 0.01 latent noise] itself.
+        # [amd] With the library's counter-based generator (config.device_noise = 'philox') the draw depends on nothing of this
+        # step: it is enqueued on the parameter stream BEFORE the recognition network and joined where the state pipeline reads it.
+        Ts = T - skip
+        pooled = init_full = pooled_ev = None
+        nl = n * o * (cl // 2 - 4)
+        n_pool = 2 * nl + n * Ts * o * (cl // 2 + 2)
+        draw = self.noise_fn is None and getattr(c, 'fused_dynamics', True)
+        if draw and x.is_cuda and getattr(c, 'device_noise', 'philox') == 'philox':
+            pooled, pooled_ev = self._draw_ahead(n_pool, x.device)
         codes = self.sup.encoder(x.flatten(end_dim=1))
         fused_state = bool(getattr(c, 'fused_state', True)) and not c.debug_match_appearance
-        # device RNG: the three draws of the reference (latent prior, the unused std prior, the step noise) as ONE launch, made
-        # before the state pipeline so that it can write the recursion's initial state [SuPAIR | 0.01 latent noise] itself
-        Ts = T - skip
-        pooled = init_full = None
-        nl = n * o * (cl // 2 - 4)
-        if self.noise_fn is None and getattr(c, 'fused_dynamics', True):
-            pooled = self._noise('pooled', (2 * nl + n * Ts * o * (cl // 2 + 2),), codes)      # [latent | std | steps]
+        if pooled_ev is not None:
+            torch.cuda.current_stream(x.device).wait_event(pooled_ev)
+        elif draw:
+            pooled = self._noise('pooled', (n_pool,), codes)      # [latent | std | steps]
         if fused_state:
             zfix, zsup_loop, zsstd_loop, init6, idx = ops.supair_state(
                 codes.flatten(end_dim=1), self.sup.zp_span_low(), n, T, o, skip, c.debug_fix_supair, c.debug_match_objects,

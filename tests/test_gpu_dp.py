@@ -108,13 +108,20 @@ def _args(path, tmp, **kw):
 
 
 def _spy_noise(stove):
-    rec, orig = {}, stove._noise
+    """records the step's draws: torch's (Stove._noise) or the library generator's (Stove._draw_ahead, config.device_noise 'philox')"""
+    rec, orig, orig_ahead = {}, stove._noise, stove._draw_ahead
 
     def spy(kind, shape, like):
         t = orig(kind, shape, like)
         rec[kind] = t.detach().clone().cpu()
         return t
-    stove._noise = spy
+
+    def spy_ahead(numel, dev):
+        t, ev = orig_ahead(numel, dev)
+        torch.cuda.synchronize()
+        rec['pooled'] = t.detach().clone().cpu()
+        return t, ev
+    stove._noise, stove._draw_ahead = spy, spy_ahead
     return rec
 
 
@@ -142,7 +149,7 @@ def _trainer_worker(rank, world, port, path, tmp):
     out['after2'] = trainer.bucket.data.clone().cpu()
     # a third step as the Trainer runs its non-logging steps: two replayed graphs around the all-reduce (stove_amd/graphed.py)
     trainer.c.print_every = 10 ** 9
-    del trainer.stove._noise                        # the recording wrapper copies to the host: not inside a capture
+    del trainer.stove._noise, trainer.stove._draw_ahead            # the recording wrappers copy to the host: not inside a capture
     assert trainer._graph_ok(3)
     trainer._graph_step(next(it), 3)
     out['after3'] = trainer.bucket.data.clone().cpu()
