@@ -1382,7 +1382,11 @@ int stove_match_objects(const float* feat, long long* idx, float* perm, int B, i
     STOVE_LAUNCH((match3_table_k<2>), dim3(B), dim3(64), lds, st, feat, idx, B, T);
   else if (!serial && mode == 0 && N == 3 && F == 5)
     STOVE_LAUNCH((match3_table_k<5>), dim3(B), dim3(64), lds, st, feat, idx, B, T);
-  else if (mode == 1 || N > 3)
+  else if (mode == 1 && perm == nullptr && (size_t)T * N * 5 + T + 8 <= 64 * 1024) {
+    // greedy: per-frame assignments in parallel, then the composition walk (match.hip); scratch = the tail bytes of idx itself
+    STOVE_LAUNCH(match_greedy_frames_k, dim3((B * T + 255) / 256), dim3(256), 0, st, feat, idx, B, T, N, F);
+    STOVE_LAUNCH(match_greedy_compose_k, dim3(B), dim3(64), (size_t)((T * N + T + 3) & ~3) + (size_t)T * N * sizeof(int), st, feat, idx, B, T, N, F);
+  } else if (mode == 1 || N > 3)
     STOVE_LAUNCH(match_objects_par_k, dim3(B), dim3(64), lds, st, feat, idx, B, T, N, F, mode);
   else if (N == 3 && F == 2)
     STOVE_LAUNCH((match_objects_k<3, 2>), dim3(B), dim3(64), lds, st, feat, idx, perm, B, T, N, F, mode);

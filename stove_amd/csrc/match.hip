@@ -203,6 +203,128 @@ __global__ __launch_bounds__(64) void match_objects_par_k(const float* __restric
   for (int i = lane; i < T * N; i += 64) idx_out[(size_t)b * T * N + i] = ibuf[i];
 }
 
+// ---- greedy matcher, any N: the walk through time as a composition of per-frame assignments --------------------------------
+// The greedy rule (stove.py:432-514: N rounds of global arg-min over the N x N distance table with row / column knock-out) picks its
+// pairs by VALUE: which previous object goes with which current one does not depend on the order the previous objects sit in the
+// slots -- unless two remaining entries tie exactly for a round's minimum (then the first in slot-major order wins).  So every frame
+// computes, on the RAW object order and with no dependence on other frames, its assignment A_t: raw object i of frame t-1 -> raw
+// object of frame t, plus a flag "a round had a tie" (match_greedy_frames_k: one LANE per frame, the table in registers); the walk
+// (match_greedy_compose_k: one wave per sequence) is idx_t[a] = A_t[idx_{t-1}[a]], one dependent LDS read per frame, and redoes a
+// flagged frame with the serial rule in slot order.  Same float operations on the same values as the serial walk: identical indices
+// (the tests compare them on tracks full of exact ties).  Six objects, T = 100, 256 sequences: 175 us -> ~15 us.
+__device__ __forceinline__ float match_err(const float* __restrict__ p, const float* __restrict__ c, int F) {
+  float e = 0.0f;
+  for (int f = 0; f < F; ++f) {
+    const float d = (p[f] + 1.0f) * 0.5f - (c[f] + 1.0f) * 0.5f;
+    e = fmaf(d, d, e);
+  }
+  return e;
+}
+// greedy on a table in registers (rows = holders of the previous objects in the given order); returns true if a round's minimum was
+// attained more than once.  assign[a] = column of row a.
+__device__ __forceinline__ bool greedy_rounds(float (&e)[kMatchN][kMatchN], int N, int* assign) {
+  bool tie = false;
+  for (int round = 0; round < N; ++round) {
+    float bv = __builtin_inff();
+    int ba = 0, bj = 0, cnt = 0;
+#pragma unroll
+    for (int a = 0; a < kMatchN; ++a)
+#pragma unroll
+      for (int j = 0; j < kMatchN; ++j) {
+        if (a < N && j < N) {
+          const float v = e[a][j];
+          cnt = v < bv ? 1 : (v == bv ? cnt + 1 : cnt);
+          if (v < bv) {
+            bv = v;
+            ba = a;
+            bj = j;
+          }
+        }
+      }
+    tie = tie || (cnt > 1 && bv < 3.0e38f);
+    assign[ba] = bj;
+#pragma unroll
+    for (int a = 0; a < kMatchN; ++a)
+#pragma unroll
+      for (int j = 0; j < kMatchN; ++j)
+        if (a == ba || j == bj) e[a][j] = 3.0e38f;
+  }
+  return tie;
+}
+// scratch layout inside the idx block of sequence b (T N int64): the last T N + T bytes = [A (T x N bytes) | tie flags (T bytes)]
+__device__ __forceinline__ unsigned char* greedy_scratch(long long* idx_out, int b, int T, int N) {
+  return reinterpret_cast<unsigned char*>(idx_out + (size_t)(b + 1) * T * N) - (size_t)T * N - T;
+}
+__global__ __launch_bounds__(256) void match_greedy_frames_k(const float* __restrict__ feat, long long* __restrict__ idx_out, int B, int T, int N, int F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * T) return;
+  const int b = i / T, t = i % T;
+  unsigned char* sc = greedy_scratch(idx_out, b, T, N);
+  if (t == 0) {
+    for (int a = 0; a < N; ++a) sc[a] = (unsigned char)a;
+    sc[(size_t)T * N] = 0;
+    return;
+  }
+  const float* prev = feat + ((size_t)b * T + t - 1) * N * F;
+  const float* cur = prev + (size_t)N * F;
+  float e[kMatchN][kMatchN];
+#pragma unroll
+  for (int a = 0; a < kMatchN; ++a)
+#pragma unroll
+    for (int j = 0; j < kMatchN; ++j) e[a][j] = (a < N && j < N) ? match_err(prev + a * F, cur + j * F, F) : 3.0e38f;
+  int assign[kMatchN];
+#pragma unroll
+  for (int a = 0; a < kMatchN; ++a) assign[a] = 0;
+  const bool tie = greedy_rounds(e, N, assign);
+#pragma unroll
+  for (int a = 0; a < kMatchN; ++a)
+    if (a < N) sc[(size_t)t * N + a] = (unsigned char)assign[a];
+  sc[(size_t)T * N + t] = tie ? 1 : 0;
+}
+__global__ __launch_bounds__(64) void match_greedy_compose_k(const float* __restrict__ feat, long long* __restrict__ idx_out, int B, int T, int N, int F) {
+  extern __shared__ unsigned char glds[];          // [T*N] assignments, [T] tie flags, then (4-byte aligned) [T*N] int indices
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const unsigned char* sc = greedy_scratch(idx_out, b, T, N);
+  const int nsc = T * N + T;
+  for (int i = lane; i < nsc; i += 64) glds[i] = sc[i];
+  int* ibuf = reinterpret_cast<int*>(glds + ((nsc + 3) & ~3));
+  __shared__ int slot[kMatchN];
+  __syncthreads();
+  int r = lane < N ? lane : 0;                     // raw object of the current frame held by slot `lane`
+  if (lane < N) ibuf[lane] = r;
+  for (int t = 1; t < T; ++t) {
+    if (glds[T * N + t] == 0) {                    // wave-uniform
+      r = glds[t * N + r];
+    } else {
+      // a tie somewhere in this frame's table: the reference's rule in SLOT order (lane 0 walks the table)
+      if (lane < N) slot[lane] = r;
+      __syncthreads();
+      if (lane == 0) {
+        const float* prev = feat + ((size_t)b * T + t - 1) * N * F;
+        const float* cur = prev + (size_t)N * F;
+        float e[kMatchN][kMatchN];
+#pragma unroll
+        for (int a = 0; a < kMatchN; ++a)
+#pragma unroll
+          for (int j = 0; j < kMatchN; ++j) e[a][j] = (a < N && j < N) ? match_err(prev + slot[a < N ? a : 0] * F, cur + j * F, F) : 3.0e38f;
+        int assign[kMatchN];
+#pragma unroll
+        for (int a = 0; a < kMatchN; ++a) assign[a] = 0;
+        greedy_rounds(e, N, assign);
+#pragma unroll
+        for (int a = 0; a < kMatchN; ++a)
+          if (a < N) slot[a] = assign[a];
+      }
+      __syncthreads();
+      if (lane < N) r = slot[lane];
+      __syncthreads();
+    }
+    if (lane < N) ibuf[t * N + lane] = r;
+  }
+  __syncthreads();
+  for (int i = lane; i < T * N; i += 64) idx_out[(size_t)b * T * N + i] = ibuf[i];
+}
+
 // ---- three objects, '3_only': the walk through time as a composition of per-frame transition tables -------------------
 // The slot contents before frame t are the objects of frame t-1 under one of the 6 permutations P of (0, 1, 2), and the
 // distances the matcher looks at are D_t[P(a)][j] with D_t[i][j] = |x_{t-1,i} - x_{t,j}|^2 on the RAW object order -- a

@@ -58,3 +58,39 @@ def test_model_draws_from_the_library_generator_by_default():
         e3 = float(model(x, 1)[0])
         assert np.isfinite(e1) and e1 != e2 and e1 == e3, (mode, e1, e2, e3)
     assert model._noise_source.state is not None
+
+
+def _greedy_serial(feat):
+    """Stove._greedy_match_objects (reference stove.py:432-514) on one track, slot order, first minimum wins: numpy, exact inputs"""
+    T, N, _ = feat.shape
+    idx = np.zeros((T, N), dtype=np.int64)
+    idx[0] = np.arange(N)
+    for t in range(1, T):
+        prev = (feat[t - 1][idx[t - 1]] + 1.0) * 0.5
+        cur = (feat[t] + 1.0) * 0.5
+        e = ((prev[:, None, :] - cur[None, :, :]) ** 2).sum(-1)
+        for _ in range(N):
+            a, j = np.unravel_index(np.argmin(e), e.shape)       # first occurrence in row-major (slot-major) order
+            idx[t, a] = j
+            e[a, :] = 3.0e38
+            e[:, j] = 3.0e38
+    return idx
+
+
+@pytest.mark.parametrize('N,T,F', [(6, 100, 2), (6, 7, 2), (2, 2, 2), (8, 33, 2), (5, 100, 5), (4, 50, 2)])
+def test_greedy_matcher_frames_in_parallel_equals_the_serial_walk(N, T, F):
+    """csrc/match.hip match_greedy_frames_k + match_greedy_compose_k against the serial rule on tracks that sit on a coarse grid
+    (every distance exact in fp32, exact ties in most frames: the tie flag and the slot-order redo are exercised) and on generic tracks."""
+    from stove_amd import ops
+    g = torch.Generator().manual_seed(N * 100 + T)
+    B = 48
+    coarse = torch.randint(-8, 9, (B, T, N, F), generator=g).float() / 8.0
+    smooth = (torch.rand(B, 1, N, F, generator=g) * 2 - 1) + 0.02 * torch.randn(B, T, N, F, generator=g).cumsum(1)
+    smooth = (smooth * 4096).round() / 4096              # exact products: the numpy rule decides on the same numbers
+    for name, feat in (('ties', coarse), ('generic', smooth)):
+        idx, _ = ops.match_objects(feat.to(DEV), 'greedy')
+        want = np.stack([_greedy_serial(feat[b].double().numpy()) for b in range(B)])
+        got = idx.cpu().numpy()
+        assert got.shape == (B, T, N) and (np.sort(got, -1) == np.arange(N)).all(), name        # permutations
+        assert (got == want).all(), (name, int((got != want).sum()))
+    # the fused state pipeline runs the same kernels (stove_supair_state_fwd2): exercised by the N = 6 goldens (g6 / g7_stove_n6)
