@@ -90,6 +90,15 @@ int stove_bgspn_bwd(const StoveSpnTables* t, const float* inputs, const float* m
                     const float* dout, float* d_inputs, float* d_marg, StoveSpnTableGrads* g, void* ws, int n,
                     void* stream);
 
+/* The same operator over n_pix input dimensions (the reference builds the background SPN over c x w x h, probabilistic_models.py:25-39;
+ * its stock gravity / multibilliards frames are 50 x 50): tables bg_side [R][n_pix], bg_coef [R][n_pix][G][3], bg_wroot [R][G*G];
+ * inputs / marg / d_inputs / d_marg (n, n_pix).  General-size kernels (csrc/spn_bg_generic.hip), not the tuned 1024-pixel ones. */
+size_t stove_bgspn_saved_floats_d(int n, int n_pix);
+int stove_bgspn_fwd_d(const StoveSpnTables* t, const float* inputs, const float* marg, float* ell, float* out, int n, int n_pix, void* stream);
+size_t stove_bgspn_bwd_ws_bytes_d(int n, int n_pix);
+int stove_bgspn_bwd_d(const StoveSpnTables* t, const float* inputs, const float* marg, const float* ell, const float* out, const float* dout,
+                      float* d_inputs, float* d_marg, StoveSpnTableGrads* g, void* ws, int n, int n_pix, void* stream);
+
 /* ---- Supair.likelihood (supair.py:44-110), fused: masks_from_z (:278-356), patches_from_z
  * (:241-276), both SPN sweeps, patch scaling + Exponential(beta) overlap prior (:79-94).
  * frames: (n_frames,1024) one-channel frames; z: (n_frames*n_obj,4) = [sx,sy,x,y].

@@ -561,12 +561,96 @@ def g9_optimiser_steps():
          eps_steps=torch.stack([e[2] for e in all_eps]), **checks)
 
 
+# ------------------------------------------------------------------ G13 beyond the 32 x 32 / align_corners=False contract
+def gravity_frames_res(n_seq, t_len, res):
+    """the reference's stock gravity generator (envs.py:841-844: res = 50)"""
+    xs = []
+    for seed in range(n_seq):
+        env = ref_envs.GravityEnv(n=3, r=2, m=4., hw=30, granularity=50, res=res, t=1.,
+                                  init_v_factor=0.55, friction_coefficient=0., seed=seed)
+        xs.append(np.stack([env.step()[0].copy() for _ in range(t_len)]))
+    return np.transpose(np.stack(xs), (0, 1, 4, 2, 3))
+
+
+class _AlignCorners:
+    """The torch 1.0.1 sampling convention the reference was written for (requirements.txt:103): its calls pass no flag
+    (supair.py:272-275, 321-341), torch >= 1.3 then samples with align_corners=False; this context makes them sample with True."""
+
+    def __enter__(self):
+        import torch.nn.functional as Fn
+        self.Fn, self.ag, self.gs = Fn, Fn.affine_grid, Fn.grid_sample
+        Fn.affine_grid = lambda theta, size, align_corners=None: self.ag(theta, size, align_corners=True)
+        Fn.grid_sample = lambda inp, grid, mode='bilinear', padding_mode='zeros', align_corners=None: self.gs(
+            inp, grid, mode=mode, padding_mode=padding_mode, align_corners=True)
+
+    def __exit__(self, *exc):
+        self.Fn.affine_grid, self.Fn.grid_sample = self.ag, self.gs
+        return False
+
+
+class _Nothing:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def g13_wide():
+    """Supair.likelihood and the full Stove.forward (a) on 50 x 50 frames (the reference's stock gravity data) and (b) on 32 x 32
+    frames under align_corners=True.  float64 only (the GPU tests compare against float64)."""
+    dtype, tag = torch.float64, 'f64'
+    for name, res, ac in (('res50', 50, False), ('ac32', 32, True)):
+        ctx = _AlignCorners() if ac else _Nothing()
+        with ctx:
+            # likelihood (as g4)
+            c = ref_config(dtype, num_obj=3, width=res, height=res)
+            c.debug = True
+            sup = Supair(c)
+            fill(sup, 'sup.')
+            g = torch.Generator().manual_seed(4)
+            n, t = 2, 3
+            x = (torch.rand(n, t, 1, res, res, generator=g, dtype=torch.float64) ** 3).to(dtype)
+            z = crafted_z(n * t, 3, g, dtype).flatten(end_dim=1).requires_grad_()
+            sup.step_counter = 0
+            lp, prop = sup.likelihood(x, z)
+            w = torch.linspace(0.5, 1.5, n * t, dtype=dtype)
+            (lp * w).sum().backward()
+            grads = {f'gn_{k}': p.grad.norm() for k, p in sup.named_parameters() if p.grad is not None}
+            small = {f'g_{k}': p.grad for k, p in sup.named_parameters() if p.grad is not None and p.numel() <= 700}
+            save(f'g13_likelihood_{name}_{tag}', x=x, z=z, log_p=lp, w=w, gz=z.grad, bg=prop['bg'], patch=prop['patch'],
+                 overlap=prop['overlap'], **grads, **small)
+            # full model (as g7)
+            c = ref_config(dtype, num_obj=3, width=res, height=res)
+            c.debug = True
+            st = Stove(c)
+            fill(st)
+            B, T, N = 2, 6, 3
+            x = torch.from_numpy(gravity_frames_res(B, T, res)).to(dtype)
+            g = torch.Generator().manual_seed(123)
+            lat = torch.randn(B, N, 12, 1, generator=g, dtype=torch.float64)
+            sd = torch.randn(B, N, 12, 1, generator=g, dtype=torch.float64)
+            steps = [torch.randn(B, N, 18, generator=g, dtype=torch.float64) for _ in range(2, T)]
+            saved = tdn._standard_normal
+            tdn._standard_normal = EpsFeeder([lat, sd] + steps)
+            elbo, prop, _ = st(x, 0, None)
+            tdn._standard_normal = saved
+            (-elbo).backward()
+            gnorm = {f'gn_{k}': p.grad.norm() for k, p in st.named_parameters() if p.grad is not None}
+            small = {f'g_{k}': p.grad for k, p in st.named_parameters() if p.grad is not None and p.numel() <= 700}
+            props = {f'p_{k}': v for k, v in prop.items() if v is not None and torch.is_tensor(v)}
+            with torch.no_grad():
+                rec = st.reconstruct_from_z(prop['z'])
+            save(f'g13_stove_{name}_{tag}', x=x.to(torch.float32), eps_lat=lat, eps_std=sd, eps_steps=torch.stack(steps, 0), elbo=elbo,
+                 recon=rec.to(torch.float32), **props, **gnorm, **small)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7', 'g6b', 'g11', 'g9', 'g12']
+    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7', 'g6b', 'g11', 'g9', 'g12', 'g13']
     os.makedirs(OUT, exist_ok=True)
     table = {'g0': g0_envs, 'g1': g1_structures, 'g2': g2_ratspn, 'g3': g3_masks_glimpses,
              'g4': g4_likelihood, 'g5': g5_dynamics, 'g6': g6_matchers, 'g10': g10_units, 'g7': g7_g8_full,
-             'g6b': g6b_volatile, 'g11': g11_supair_only, 'g9': g9_optimiser_steps, 'g12': g12_reconstruct}
+             'g6b': g6b_volatile, 'g11': g11_supair_only, 'g9': g9_optimiser_steps, 'g12': g12_reconstruct, 'g13': g13_wide}
     for k in which:
         torch.manual_seed(0)
         np.random.seed(0)

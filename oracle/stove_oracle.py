@@ -51,6 +51,7 @@ def default_config(**overrides):
         debug_appearance_dim=3, debug_bw=True,
         action_conditioned=False, action_space=None,
         random_seed=42,
+        align_corners=False,     # the runnable reference (torch >= 1.3); True = the torch 1.0.1 convention the reference was written for
     )
     for k, v in overrides.items():
         setattr(c, k, v)
@@ -263,7 +264,7 @@ def reconstruct_from_z(c, params, structs, z, x=None, max_activation=True, singl
             patches = patches.unsqueeze(1).repeat(1, T, 1, 1, 1, 1).flatten(0, 1)
     z_img = z.flatten(0, 1)
     for k in range(o):
-        rec = rec + _sample(patches[:, k].contiguous(), _theta(_z_inverse(z_img[:, k])), c.width, c.height)
+        rec = rec + _sample(patches[:, k].contiguous(), _theta(_z_inverse(z_img[:, k])), c.width, c.height, _ac(c))
     return torch.clamp(rec.view(n, T, c.channels, c.width, c.height), 0, 1)
 
 
@@ -295,16 +296,20 @@ def _z_inverse(z):
     return torch.stack([1.0 / z[:, 0], 1.0 / z[:, 1], -z[:, 2] / z[:, 0], -z[:, 3] / z[:, 1]], 1)
 
 
-def _sample(img, theta, out_h, out_w):
-    grid = F.affine_grid(theta, (img.shape[0], img.shape[1], out_h, out_w), align_corners=False)
-    return F.grid_sample(img, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+def _sample(img, theta, out_h, out_w, ac=False):
+    grid = F.affine_grid(theta, (img.shape[0], img.shape[1], out_h, out_w), align_corners=bool(ac))
+    return F.grid_sample(img, grid, mode='bilinear', padding_mode='zeros', align_corners=bool(ac))
+
+
+def _ac(c):
+    return bool(getattr(c, 'align_corners', False))
 
 
 def glimpses(c, x_img, z_obj):
     """patches_from_z, supair.py:241-276: (nT,ch,H,W),(nT*N,4) -> (nT*N,ch,ph,pw)."""
     n_obj = z_obj.shape[0] // x_img.shape[0]
     x_rep = x_img.unsqueeze(1).expand(-1, n_obj, -1, -1, -1).reshape(-1, *x_img.shape[1:])
-    return _sample(x_rep, _theta(z_obj), c.patch_width, c.patch_height)
+    return _sample(x_rep, _theta(z_obj), c.patch_width, c.patch_height, _ac(c))
 
 
 def masks_from_z(c, z_img):
@@ -315,9 +320,9 @@ def masks_from_z(c, z_img):
     per_obj = []
     for k in range(z_img.shape[1]):
         zk = z_img[:, k]
-        seen = _sample(1.0 - bg, _theta(zk), c.patch_width, c.patch_height)
+        seen = _sample(1.0 - bg, _theta(zk), c.patch_width, c.patch_height, _ac(c))
         per_obj.append(1.0 - seen)
-        box = _sample(ones, _theta(_z_inverse(zk)), c.width, c.height)
+        box = _sample(ones, _theta(_z_inverse(zk)), c.width, c.height, _ac(c))
         bg = torch.clamp(bg + box, 0, 1)
     marg = torch.stack(per_obj, 1)
     overlap = marg.flatten(2).mean(2)

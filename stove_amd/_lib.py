@@ -24,7 +24,7 @@ EXPORTS = [
     'stove_enc_head_fwd', 'stove_enc_head_bwd_ws_floats', 'stove_enc_head_bwd', 'stove_colsum2', 'stove_small_tn', 'stove_small_tn_ws_floats', 'stove_supair_state_fwd2', 'stove_supair_state_bwd2', 'stove_bg_dense', 'stove_bg_dense_floats',
     'stove_bw_transform_u8', 'stove_stream_after', 'stove_capture_begin', 'stove_capture_end', 'stove_graph_instantiate', 'stove_graph_launch', 'stove_graph_destroy',
     'stove_reward_head_param_floats', 'stove_reward_head_saved_floats', 'stove_reward_head_bwd_ws_floats', 'stove_reward_head_fwd',
-    'stove_noise_normal', 'stove_set_overlap', 'stove_set_tablegrad_placement', 'stove_event_list_begin', 'stove_event_list_end', 'stove_event_list_destroy', 'stove_fill_words',
+    'stove_bgspn_saved_floats_d', 'stove_bgspn_fwd_d', 'stove_bgspn_bwd_ws_bytes_d', 'stove_bgspn_bwd_d', 'stove_noise_normal', 'stove_set_overlap', 'stove_set_tablegrad_placement', 'stove_event_list_begin', 'stove_event_list_end', 'stove_event_list_destroy', 'stove_fill_words',
     'stove_reward_head_bwd', 'stove_small_linear', 'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_fwd_floats', 'stove_scene_bwd_from', 'stove_dynloop_range_ok', 'stove_dynloop_fwd_range', 'stove_dynloop_bwd_range', 'stove_zall_fwd_range', 'stove_zall_bwd_range',
 ]
 
@@ -117,6 +117,10 @@ def _declare(lib):
         'stove_reward_head_bwd': (I, [P] * 8 + [I, I, P]),
         'stove_set_fork_stream': (I, [I, P, I]),
         'stove_noise_normal': (I, [P, S, P, P]),
+        'stove_bgspn_saved_floats_d': (S, [I, I]),
+        'stove_bgspn_fwd_d': (I, [T, P, P, P, P, I, I, P]),
+        'stove_bgspn_bwd_ws_bytes_d': (S, [I, I]),
+        'stove_bgspn_bwd_d': (I, [T, P, P, P, P, P, P, P, G, P, I, I, P]),
         'stove_set_overlap': (I, [I]),
         'stove_set_tablegrad_placement': (I, [I]),
         'stove_event_list_begin': (P, []),

@@ -147,8 +147,8 @@ class ParamArena:
     # ------------------------------------------------------------------ SPN tables
     def _plan_spn(self, sup):
         obj, bg = sup.obj_spn, sup.bg_spn
-        if obj._kind != 'obj' or bg._kind != 'bg':
-            return
+        if obj._kind != 'obj' or bg._kind != 'bg' or bg.num_dims != 1024:
+            return                      # other frame sizes: the SPN tables are baked / differentiated per tensor (RatSpn.tables + autograd)
         dev = self.data.device
         off = self.offset
         oleaves, osums = list(obj.vector_list[0]), list(obj.vector_list[2])

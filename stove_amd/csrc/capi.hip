@@ -9,6 +9,7 @@
 #include <atomic>
 #include "spn_obj.hip"
 #include "spn_bg.hip"
+#include "spn_bg_generic.hip"
 #include "scene.hip"
 #include "scene_fused.hip"
 #include "gnn.hip"
@@ -147,6 +148,19 @@ int stove_bgspn_bwd(const StoveSpnTables* t, const float* inputs, const float* m
   if (d_marg != nullptr && marg == nullptr) return (int)hipErrorInvalidValue;
   return bgspn_backward(inputs, marg, nullptr, 0, t->bg_side, t->bg_coef, t->bg_wroot, ell, out, dout, d_inputs, d_marg,
                         nullptr, g->bg_coef, g->bg_wroot, (float*)ws, n, (hipStream_t)stream);
+}
+
+// the same operator for any number of input dimensions (frame sizes other than 32 x 32): csrc/spn_bg_generic.hip
+size_t stove_bgspn_saved_floats_d(int n, int n_pix) { return bgspn_any_saved_floats(n, n_pix); }
+int stove_bgspn_fwd_d(const StoveSpnTables* t, const float* inputs, const float* marg, float* ell, float* out, int n, int n_pix, void* stream) {
+  return bgspn_any_forward(inputs, marg, t->bg_side, t->bg_coef, t->bg_wroot, ell, out, n, n_pix, (hipStream_t)stream);
+}
+size_t stove_bgspn_bwd_ws_bytes_d(int n, int n_pix) { return bgspn_any_bwd_ws_floats(n, n_pix) * sizeof(float); }
+int stove_bgspn_bwd_d(const StoveSpnTables* t, const float* inputs, const float* marg, const float* ell, const float* out, const float* dout,
+                      float* d_inputs, float* d_marg, StoveSpnTableGrads* g, void* ws, int n, int n_pix, void* stream) {
+  if (d_marg != nullptr && marg == nullptr) return (int)hipErrorInvalidValue;
+  return bgspn_any_backward(inputs, marg, t->bg_side, t->bg_coef, t->bg_wroot, ell, out, dout, d_inputs, d_marg, g->bg_coef, g->bg_wroot,
+                            (float*)ws, n, n_pix, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------- fused scene likelihood

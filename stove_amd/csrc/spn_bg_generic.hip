@@ -1,0 +1,217 @@
+// Background RAT-SPN operator for ANY frame size (round 4).  The reference builds the background SPN over c x w x h dimensions
+// (probabilistic_models.py:25-39: three one-level random binary splits, six Gaussians per leaf) and its stock gravity /
+// multibilliards data are 50 x 50 (envs.py:771-773, 841-844); the tuned kernels of spn_bg.hip / spn_bg_mfma.hip are laid out for
+// 32 x 32 = 1024 pixels (two 512-lane halves, 16-pixel MFMA blocks, 32-entry coverage tables).  These are the same RatSpn.forward /
+// backward (rat_torch.py:83-109, 147-163, 202-222, 354-357) with the pixel count at run time: lane = pixel, ceil(n_pix / 512) "halves",
+// coefficients of the lane's pixel in registers for the whole walk over the frames, lanes past the last pixel contribute zeros.
+// Correctness first (the operator behind Supair.likelihood for frame sizes other than 32 x 32); the root / root-gradient
+// kernels are those of spn_bg.hip, which take the number of halves as an argument.
+#include "common.h"
+
+namespace stove {
+
+template <int R, int G>
+__global__ __launch_bounds__(kBgThreads) void bgspn_fwd_any_k(const float* __restrict__ inputs, const float* __restrict__ marg,
+                                                              const int* __restrict__ side, const float* __restrict__ coef,
+                                                              float* __restrict__ ell_part, int n_frames, int n_pix, int halves) {
+  constexpr int NO = R * 2 * G;
+  constexpr int NW = kBgThreads / 64;
+  __shared__ float part[2][NW * 4][NO];     // one partial per 16-lane row of every wave
+  const int half = blockIdx.x % halves;
+  const int p = half * kBgThreads + threadIdx.x;
+  const bool live = p < n_pix;
+  const int pc = live ? p : n_pix - 1;
+  const int lane = lane_id(), wv = wave_id();
+  float cf[R][G][3];
+  bool sd[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    sd[r] = side[(size_t)r * n_pix + pc] != 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cf[r][g][k] = coef[(((size_t)r * n_pix + pc) * G + g) * 3 + k];
+  }
+  int it = 0;
+  for (int f = blockIdx.x / halves; f < n_frames; f += gridDim.x / halves, ++it) {
+    const float x = inputs[(size_t)f * n_pix + pc];
+    float w = (marg != nullptr) ? 1.0f - fminf(fmaxf(marg[(size_t)f * n_pix + pc], 0.0f), 1.0f) : 1.0f;
+    if (!live) w = 0.0f;
+    const float wx = w * x, wxx = wx * x;
+    float* pp = part[it & 1][wv * 4 + (lane >> 4)];
+    const bool row_last = (lane & 15) == 15;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float val = fmaf(wxx, cf[r][g][0], fmaf(wx, cf[r][g][1], w * cf[r][g][2]));
+        const float v1 = sd[r] ? val : 0.0f;
+        const float s0 = row_sum_lane15(val - v1);
+        const float s1 = row_sum_lane15(v1);
+        if (row_last) {
+          pp[(r * 2) * G + g] = s0;
+          pp[(r * 2 + 1) * G + g] = s1;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < NO) {
+      float s = 0.0f;
+#pragma unroll
+      for (int q = 0; q < NW * 4; ++q) s += part[it & 1][q][threadIdx.x];
+      ell_part[((size_t)f * halves + half) * NO + threadIdx.x] = s;
+    }
+  }
+}
+
+// dell[frame][(r*2+side)*G+g] = dL/d leaf (bgspn_root_bwd_k) -> d_inputs / d_marg [frame][pixel] (either may be null) and the
+// per-block coefficient gradients gcoef_part[block][r][lane][g][3] (summed over the block's frames in frame order)
+template <int R, int G>
+__global__ __launch_bounds__(kBgThreads) void bgspn_bwd_any_k(const float* __restrict__ inputs, const float* __restrict__ marg,
+                                                              const int* __restrict__ side, const float* __restrict__ coef,
+                                                              const float* __restrict__ dell, float* __restrict__ d_inputs,
+                                                              float* __restrict__ d_marg, float* __restrict__ gcoef_part, int n_frames,
+                                                              int n_pix, int halves) {
+  constexpr int NO = R * 2 * G;
+  const int half = blockIdx.x % halves;
+  const int p = half * kBgThreads + threadIdx.x;
+  const bool live = p < n_pix;
+  const int pc = live ? p : n_pix - 1;
+  float cf[R][G][3], gc[R][G][3];
+  int doff[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    doff[r] = (r * 2 + (side[(size_t)r * n_pix + pc] != 0 ? 1 : 0)) * G;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        cf[r][g][k] = coef[(((size_t)r * n_pix + pc) * G + g) * 3 + k];
+        gc[r][g][k] = 0.0f;
+      }
+  }
+  for (int f = blockIdx.x / halves; f < n_frames; f += gridDim.x / halves) {
+    const float x = inputs[(size_t)f * n_pix + pc];
+    float mraw = 0.0f, w = 1.0f;
+    if (marg != nullptr) {
+      mraw = marg[(size_t)f * n_pix + pc];
+      w = 1.0f - fminf(fmaxf(mraw, 0.0f), 1.0f);
+    }
+    if (!live) w = 0.0f;
+    const float wx = w * x, wxx = wx * x, x2 = x * x;
+    const float* dl = dell + (size_t)f * NO;
+    float dwr[R], dx = 0.0f;            // one partial sum per replica (short dependent chains), replicas added in order
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      dwr[r] = 0.0f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float d = dl[doff[r] + g];
+        dwr[r] = fmaf(d, fmaf(cf[r][g][0], x2, fmaf(cf[r][g][1], x, cf[r][g][2])), dwr[r]);
+        dx = fmaf(d, fmaf(cf[r][g][0], x + x, cf[r][g][1]), dx);
+        gc[r][g][0] = fmaf(d, wxx, gc[r][g][0]);
+        gc[r][g][1] = fmaf(d, wx, gc[r][g][1]);
+        gc[r][g][2] = fmaf(d, w, gc[r][g][2]);
+      }
+    }
+    float dw = dwr[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) dw += dwr[r];
+    if (live) {
+      if (d_marg != nullptr) d_marg[(size_t)f * n_pix + p] = (mraw >= 0.0f && mraw <= 1.0f) ? -dw : 0.0f;      // boundaries pass, as ATen's clamp
+      if (d_inputs != nullptr) d_inputs[(size_t)f * n_pix + p] = dx * w;
+    }
+  }
+  float* o = gcoef_part + ((size_t)blockIdx.x * R * kBgThreads) * G * 3;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) o[((size_t)(r * kBgThreads + threadIdx.x) * G + g) * 3 + k] = gc[r][g][k];
+}
+
+// g_coef[r][p][g][3] = sum over the blocks that own pixel-half(p) of gcoef_part, in block order
+template <int R, int G>
+__global__ __launch_bounds__(256) void bgspn_coef_reduce_any_k(const float* __restrict__ gcoef_part, float* __restrict__ g_coef, int n_blocks,
+                                                                int n_pix, int halves) {
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const size_t j = (size_t)blockIdx.x * 32 + el;               // over R * n_pix * G * 3
+  float s = 0.0f;
+  const bool live = j < (size_t)R * n_pix * G * 3;
+  if (live) {
+    const int e = (int)(j % (G * 3));
+    const int p = (int)((j / (G * 3)) % n_pix);
+    const int r = (int)(j / ((size_t)G * 3 * n_pix));
+    const int half = p / kBgThreads, pl = p % kBgThreads;
+    for (int b = half + q * halves; b < n_blocks; b += 8 * halves)
+      s += gcoef_part[(((size_t)b * R + r) * kBgThreads + pl) * G * 3 + e];
+  }
+  red[q][el] = s;
+  __syncthreads();
+  if (q == 0 && live) {
+    float t = red[0][el];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][el];
+    g_coef[j] = t;
+  }
+}
+
+static inline int bg_halves_any(int n_pix) { return (n_pix + kBgThreads - 1) / kBgThreads; }
+static inline int bg_grid_any(int n_frames, int n_pix) {
+  int g = n_frames < 128 ? n_frames : 128;
+  if (g < 1) g = 1;
+  return g * bg_halves_any(n_pix);
+}
+size_t bgspn_any_saved_floats(int n_frames, int n_pix) { return (size_t)n_frames * bg_halves_any(n_pix) * kBgNO; }
+size_t bgspn_any_bwd_ws_floats(int n_frames, int n_pix) {
+  return (size_t)n_frames * (kBgNO + kBgR * (1 + 2 * kBgG)) + (size_t)bg_grid_any(n_frames, n_pix) * kBgR * kBgThreads * kBgG * 3 +
+         (size_t)kBgRootChunks * kBgR * kBgG * kBgG;
+}
+
+int bgspn_any_forward(const float* inputs, const float* marg, const int* side, const float* coef, const float* wroot, float* ell_part,
+                      float* out, int n_frames, int n_pix, hipStream_t st) {
+  if (n_frames == 0) return 0;
+  if (n_pix < 1) return (int)hipErrorInvalidValue;
+  const int halves = bg_halves_any(n_pix);
+  STOVE_LAUNCH((bgspn_fwd_any_k<kBgR, kBgG>), dim3(bg_grid_any(n_frames, n_pix)), dim3(kBgThreads), 0, st, inputs, marg, side, coef, ell_part,
+               n_frames, n_pix, halves);
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH((bgspn_root_fwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, n_frames, halves);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+// g_coef [R][n_pix][G][3], g_wroot [R*G*G] overwritten
+int bgspn_any_backward(const float* inputs, const float* marg, const int* side, const float* coef, const float* wroot, const float* ell_part,
+                       const float* out, const float* dout, float* d_inputs, float* d_marg, float* g_coef, float* g_wroot, float* ws,
+                       int n_frames, int n_pix, hipStream_t st) {
+  if (n_pix < 1) return (int)hipErrorInvalidValue;
+  if (n_frames == 0) {
+    hipMemsetAsync(g_coef, 0, sizeof(float) * kBgR * (size_t)n_pix * kBgG * 3, st);
+    hipMemsetAsync(g_wroot, 0, sizeof(float) * kBgR * kBgG * kBgG, st);
+    return 0;
+  }
+  const int halves = bg_halves_any(n_pix), grid = bg_grid_any(n_frames, n_pix);
+  float* dell = ws;
+  float* rsc = dell + (size_t)n_frames * kBgNO;
+  float* gpart = rsc + (size_t)n_frames * kBgR * (1 + 2 * kBgG);
+  float* rpart = gpart + (size_t)grid * kBgR * kBgThreads * kBgG * 3;
+  STOVE_LAUNCH((bgspn_root_bwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, dout, dell, rsc, n_frames, halves);
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH((bgspn_bwd_any_k<kBgR, kBgG>), dim3(grid), dim3(kBgThreads), 0, st, inputs, marg, side, coef, (const float*)dell, d_inputs, d_marg,
+               gpart, n_frames, n_pix, halves);
+  STOVE_LAUNCH_CHECK();
+  const size_t nc = (size_t)kBgR * n_pix * kBgG * 3;
+  STOVE_LAUNCH((bgspn_coef_reduce_any_k<kBgR, kBgG>), dim3((unsigned)((nc + 31) / 32)), dim3(256), 0, st, (const float*)gpart, g_coef, grid, n_pix, halves);
+  STOVE_LAUNCH_CHECK();
+  const int chunks = n_frames < kBgRootChunks ? n_frames : kBgRootChunks;
+  STOVE_LAUNCH((bgspn_rootgrad_k<kBgR, kBgG>), dim3(chunks), dim3(128), 0, st, (const float*)rsc, rpart, n_frames, chunks);
+  STOVE_LAUNCH_CHECK();
+  STOVE_LAUNCH(reduce_chunks_k, dim3((kBgR * kBgG * kBgG + 31) / 32), dim3(256), 0, st, (const float*)rpart, g_wroot, kBgR * kBgG * kBgG, chunks, 0);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace stove

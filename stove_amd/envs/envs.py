@@ -237,19 +237,23 @@ ENV_PRESETS = {
 }
 
 
-def make_env(preset, seed):
+def make_env(preset, seed, res=None):
+    """res: frame side override (the presets are BASELINE.json's 32 x 32; the reference's stock gravity / multibilliards generators
+    render 50 x 50, envs.py:771-773, 841-844)."""
     cfg = dict(ENV_PRESETS[preset])
+    if res is not None:
+        cfg['res'] = int(res)
     cls = {'billiards': BillardsEnv, 'gravity': GravityEnv}[cfg.pop('cls')]
     return cls(seed=seed, **cfg)
 
 
-def synth_sequences(preset, n_seq, t_len, seed0=0, with_actions=None):
+def synth_sequences(preset, n_seq, t_len, seed0=0, with_actions=None, res=None):
     """One environment per sequence (seed = seed0 + i), t_len steps.
     -> dict(X (B,T,3,res,res) f32, y (B,T,n,4) f64 [, action (B,T,9), reward (B,T,1)])."""
     with_actions = (preset == 'avoidance') if with_actions is None else with_actions
     X, Y, A, R = [], [], [], []
     for i in range(n_seq):
-        env = make_env(preset, seed0 + i)
+        env = make_env(preset, seed0 + i, res)
         imgs, states = [], []
         if with_actions:
             task = AvoidanceTask(env, 4, greyscale=False, action_force=0.6)

@@ -82,20 +82,26 @@ class _ObjSpnFn(torch.autograd.Function):
 
 
 class _BgSpnFn(torch.autograd.Function):
-    """RatSpn.forward of the background SPN."""
+    """RatSpn.forward of the background SPN: the tuned 1024-dimension kernels (32 x 32 frames) or, for any other number of
+    dimensions, the general-size ones (csrc/spn_bg_generic.hip)."""
 
     @staticmethod
     def forward(ctx, inputs, marg, coef, wroot, side):
         lib = _lib.load()
         inputs, marg, coef, wroot = _f32(inputs), _f32(marg), _f32(coef), _f32(wroot)
-        n = inputs.shape[0]
+        n, D = inputs.shape[0], inputs.shape[1]
+        if side.shape[-1] != D or coef.shape[1] != D:
+            raise ValueError('background SPN tables are for %d dimensions, inputs have %d' % (side.shape[-1], D))
         dev = inputs.device
         with torch.cuda.device(dev):
-            ell = torch.empty(lib.stove_bgspn_saved_floats(n) + 1, dtype=torch.float32, device=dev)
             out = torch.empty(n, dtype=torch.float32, device=dev)
             t = _tables(bg=(side, coef, wroot))
-            check(lib.stove_bgspn_fwd(ctypes.byref(t), ptr(inputs), ptr(marg), ptr(ell), ptr(out), n, stream()),
-                  'stove_bgspn_fwd')
+            if D == 1024:
+                ell = torch.empty(lib.stove_bgspn_saved_floats(n) + 1, dtype=torch.float32, device=dev)
+                check(lib.stove_bgspn_fwd(ctypes.byref(t), ptr(inputs), ptr(marg), ptr(ell), ptr(out), n, stream()), 'stove_bgspn_fwd')
+            else:
+                ell = torch.empty(lib.stove_bgspn_saved_floats_d(n, D) + 1, dtype=torch.float32, device=dev)
+                check(lib.stove_bgspn_fwd_d(ctypes.byref(t), ptr(inputs), ptr(marg), ptr(ell), ptr(out), n, D, stream()), 'stove_bgspn_fwd_d')
         ctx.save_for_backward(inputs, marg, coef, wroot, side, ell, out)
         return out.unsqueeze(1)
 
@@ -103,7 +109,7 @@ class _BgSpnFn(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib.load()
         inputs, marg, coef, wroot, side, ell, out = ctx.saved_tensors
-        n = inputs.shape[0]
+        n, D = inputs.shape[0], inputs.shape[1]
         dev = inputs.device
         dout = _f32(dout.reshape(-1))
         with torch.cuda.device(dev):
@@ -113,10 +119,15 @@ class _BgSpnFn(torch.autograd.Function):
             g_coef, g_wroot = torch.empty_like(coef), torch.empty_like(wroot)
             g = SpnTableGrads()
             g.bg_coef, g.bg_wroot = ptr(g_coef), ptr(g_wroot)
-            ws = _ws(lib.stove_bgspn_bwd_ws_bytes(n), dev)
             t = _tables(bg=(side, coef, wroot))
-            check(lib.stove_bgspn_bwd(ctypes.byref(t), ptr(inputs), ptr(marg), ptr(ell), ptr(out), ptr(dout), ptr(d_in),
-                                      ptr(d_m), ctypes.byref(g), ptr(ws), n, stream()), 'stove_bgspn_bwd')
+            if D == 1024:
+                ws = _ws(lib.stove_bgspn_bwd_ws_bytes(n), dev)
+                check(lib.stove_bgspn_bwd(ctypes.byref(t), ptr(inputs), ptr(marg), ptr(ell), ptr(out), ptr(dout), ptr(d_in),
+                                          ptr(d_m), ctypes.byref(g), ptr(ws), n, stream()), 'stove_bgspn_bwd')
+            else:
+                ws = _ws(lib.stove_bgspn_bwd_ws_bytes_d(n, D), dev)
+                check(lib.stove_bgspn_bwd_d(ctypes.byref(t), ptr(inputs), ptr(marg), ptr(ell), ptr(out), ptr(dout), ptr(d_in),
+                                            ptr(d_m), ctypes.byref(g), ptr(ws), n, D, stream()), 'stove_bgspn_bwd_d')
         return d_in, d_m, g_coef, g_wroot, None
 
 

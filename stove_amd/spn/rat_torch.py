@@ -287,28 +287,39 @@ class RatSpn(nn.Module):
             self._plan_cpu = {'scope': scope, 'leaf_slot': slot, 'leaf_order': torch.tensor(leaf_order),
                               'sum_order': torch.tensor(sum_order)}
             self._kind = 'obj'
-        elif len(vl) == 3 and self.num_dims == 1024 and a.num_gauss == 6:
-            R = len(root.inputs)
+        elif len(vl) == 3 and a.num_gauss == 6:
+            # background SPN over any number of dimensions D (c x w x h: probabilistic_models.py:25-39): three replicas, each a
+            # product of two Gaussian leaves that split the D pixels between them (512 / 512 for 32 x 32 frames, 1250 / 1250 for
+            # the reference's stock 50 x 50 data).  gidx: row of pixel p of replica r in the concatenated leaf coefficients.
+            R, D = len(root.inputs), self.num_dims
             if R != 3 or len(leaves) != 2 * R:
                 return
-            side = torch.zeros(R, 1024, dtype=torch.int32)
-            gidx = torch.zeros(R, 1024, dtype=torch.long)
+            start, off = {}, 0
+            for i, leaf in enumerate(leaves):
+                start[i] = off
+                off += len(leaf.scope)
+            side = torch.zeros(R, D, dtype=torch.int32)
+            gidx = torch.full((R, D), -1, dtype=torch.long)
             for r, prod in enumerate(root.inputs):
-                for s, leaf in enumerate(prod.inputs):
-                    if len(leaf.scope) != 512:
-                        return
+                if len(prod.inputs) != 2 or any(not isinstance(v, GaussVector) for v in prod.inputs):
+                    return
+                for s_, leaf in enumerate(prod.inputs):
                     li = leaf_idx[id(leaf)]
                     for i, p in enumerate(leaf.scope):
-                        side[r, p] = s
-                        gidx[r, p] = li * 512 + i
+                        side[r, p] = s_
+                        gidx[r, p] = start[li] + i
+            if int(gidx.min()) < 0:
+                return
             self._plan_cpu = {'side': side, 'gidx': gidx}
             self._kind = 'bg'
 
-    def _leaf_coef(self):
-        """(n_leaves, S, G, 3) = (a, b, c) with leaf log-density sum_p w_p (a x^2 + b x + c)."""
+    def _leaf_coef(self, flat=False):
+        """(n_leaves, S, G, 3) = (a, b, c) with leaf log-density sum_p w_p (a x^2 + b x + c); flat: leaves of different scope
+        sizes concatenated along their pixel rows -> (sum of S, G, 3)."""
         a = self.args
-        mu = torch.stack([v.means for v in self.vector_list[0]])
-        rho = torch.stack([v.sigma_params for v in self.vector_list[0]])
+        comb = torch.cat if flat else torch.stack
+        mu = comb([v.means for v in self.vector_list[0]])
+        rho = comb([v.sigma_params for v in self.vector_list[0]])
         var = a.gauss_min_sigma + (a.gauss_max_sigma - a.gauss_min_sigma) * torch.sigmoid(rho)
         inv = 1.0 / var
         return torch.stack([-0.5 * inv, mu * inv, -0.5 * mu * mu * inv - 0.5 * torch.log(2.0 * math.pi * var)], -1)
@@ -330,12 +341,12 @@ class RatSpn(nn.Module):
             return (coef.contiguous(), wsum.contiguous(), wroot.contiguous(), pl['scope'], pl['leaf_slot'])
         if self._kind == 'bg':
             pl = self._plan(self.output_vector.params.device)
-            coef = self._leaf_coef().reshape(6 * 512, 6, 3)[pl['gidx']]                   # (3,1024,6,3)
+            coef = self._leaf_coef(flat=True)[pl['gidx']]                                # (3, D, 6, 3)
             wroot = torch.softmax(self.output_vector.params, 0).view(3, 36)
             return (coef.contiguous(), wroot.contiguous(), pl['side'])
         raise NotImplementedError(
             'RatSpn: no gfx950 kernel for this SPN shape (dims=%d); kernels exist for the STOVE '
-            'object (100-dim, 6x random_split(2,2)) and background (1024-dim, 3x random_split(2,1)) SPNs'
+            'object (100-dim, 6x random_split(2,2)) and background (any dims, 3x random_split(2,1), 6 gaussians) SPNs'
             % self.num_dims)
 
     # ------------------------------------------------------------------ evaluation

@@ -262,3 +262,45 @@ def test_reconstruct_from_z(tag, dtype, tol):
         r = O.reconstruct_from_z(c, params, structs, z, **kw)
         assert r.shape == g[key].shape and r.dtype == dtype
         assert np.abs(r.numpy() - g[key]).max() < tol * 10, key
+
+
+WIDE = {'res50': dict(width=50, height=50), 'ac32': dict(align_corners=True)}
+
+
+@pytest.mark.parametrize('name', list(WIDE))
+def test_likelihood_and_forward_beyond_the_32x32_contract(name):
+    """g13: the reference on its stock 50 x 50 gravity frames (envs.py:841-844) and under the torch-1.0.1 sampling convention
+    (align_corners=True), float64: Supair.likelihood with its gradients and the whole Stove.forward."""
+    dtype, tol = torch.float64, 1e-9
+    g = load_golden(f'g13_likelihood_{name}_f64')
+    c, structs, params = oracle_setup(dtype, **WIDE[name])
+    x, z, w = t_(g['x'], dtype), t_(g['z'], dtype).requires_grad_(), t_(g['w'], dtype)
+    lp, bg, pl, ol = O.scene_likelihood(c, params, structs, x, z, parts=True)
+    assert rel_err(lp.detach(), g['log_p']) < tol
+    assert abs(float(bg.mean().detach()) - float(g['bg'])) < tol * abs(float(g['bg'])) + 1e-9
+    (lp * w).sum().backward()
+    assert rel_err(z.grad, g['gz']) < tol * 100
+    n = 0
+    for k, v in g.items():
+        if k.startswith('gn_'):
+            p = params['sup.' + k[3:]] if not k[3:].startswith('sup.') else params[k[3:]]
+            assert abs(float(p.grad.norm()) - float(v)) <= 1e-6 * float(v) + 1e-12, k
+            n += 1
+    assert n > 10
+    g = load_golden(f'g13_stove_{name}_f64')
+    c, structs, params = oracle_setup(dtype, **WIDE[name])
+    eps = {'latent': t_(g['eps_lat'], dtype), 'std': t_(g['eps_std'], dtype), 'steps': [t_(e, dtype) for e in g['eps_steps']]}
+    elbo, _, info = O.stove_forward(c, params, structs, t_(g['x'], dtype), eps, None, detail=True)
+    assert abs(float(elbo) - float(g['elbo'])) < tol * abs(float(g['elbo']))
+    for k in ('z', 'z_dyn', 'z_sup', 'log_q', 'translik'):
+        assert rel_err(info[k].detach(), g['p_' + k]) < tol * 10, k
+    (-elbo).backward()
+    n = 0
+    for k, v in g.items():
+        if k.startswith('gn_'):
+            assert abs(float(params[k[3:]].grad.norm()) - float(v)) <= 1e-6 * float(v) + 1e-12, k
+            n += 1
+    assert n > 50
+    with torch.no_grad():
+        rec = O.reconstruct_from_z(c, params, structs, info['z'])
+    assert rel_err(rec, g['recon']) < 1e-6
