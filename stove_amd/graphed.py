@@ -46,6 +46,7 @@ class GraphedTrainStep:
         self.graphs = None
         self.key = None
         self.reward_value = None
+        self._draws = 0
         self._side_exec = None
         self._events = None          # the list of cross-capture events that order g_main and g_side (owned with the graphs)
 
@@ -127,8 +128,7 @@ class GraphedTrainStep:
         # state and the generator are put back afterwards, so capturing does not count as training
         snap = (self.arena.data.clone(), {k: v.clone() for k, v in self.opt._flat.items()}, torch.cuda.get_rng_state(dev),
                 self.opt._seg_steps.clone())
-        ns = getattr(self.stove, '_noise_source', None)         # the library's generator (ops.NoiseSource): its call counter is put back too
-        snap_noise = ns.state.clone() if ns is not None and ns.state is not None else None
+
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -141,14 +141,7 @@ class GraphedTrainStep:
             for k, v in snap[1].items():
                 self.opt._flat[k].copy_(v)
             self.opt._seg_steps.copy_(snap[3])
-        torch.cuda.set_rng_state(snap[2], dev)
-        ns = getattr(self.stove, '_noise_source', None)
-        if ns is not None and ns.state is not None:
-            if snap_noise is not None:
-                ns.state.copy_(snap_noise)
-            else:
-                ns.state[1] = 0                  # created by the warm-up: no draw has counted yet
-        torch.cuda.synchronize(dev)
+        torch.cuda.set_rng_state(snap[2], dev)      # ... which also puts the library's noise stream back (ops.NoiseSource shadows it)
         # Capture on the stream the warm-up ran on (the autograd nodes then see one stream throughout), as THREE graphs:
         #   g_main  zero_grad + forward + backward, with its short fork / join episodes (table bake, background-SPN chain)
         #   g_side  the parameter-gradient chain of the backward pass (SPN table gradients, the recursion's and the recognition
@@ -178,6 +171,9 @@ class GraphedTrainStep:
         import ctypes
         side_graph, side_nodes = ctypes.c_void_p(), ctypes.c_int()
         events = lib.stove_event_list_begin()     # the events that order the two captures: created below, destroyed with the graphs
+        ns = getattr(self.stove, '_noise_source', None)          # exists after the warm-up steps if the step draws from it
+        if ns is not None:
+            ns.captured = 0
         try:
             self._capture_graphs(g1, s, split, lib, ops, side_graph, side_nodes, dump, dump_open, gd)
         except BaseException:
@@ -186,6 +182,7 @@ class GraphedTrainStep:
             raise
         lib.stove_event_list_end(events)
         self._events = events
+        self._draws = ns.captured if ns is not None else 0       # draws from the library's generator inside the captured step
         self.key = self._key(images, actions, targets)
 
     def _capture_graphs(self, g1, s, split, lib, ops, side_graph, side_nodes, dump, dump_open, gd):
@@ -262,6 +259,9 @@ class GraphedTrainStep:
         lib = _lib.load()
         main = torch.cuda.current_stream(self.x.device).cuda_stream
         self.hyper_dev.copy_(self.ring[slot], non_blocking=True)
+        ns = getattr(self.stove, '_noise_source', None)
+        if ns is not None and self._draws:
+            ns.prepare(self._draws)        # the captured draw(s) of this replay: host generator in step, device state rewritten after a reseed
         self.graphs[0].replay()
         if self._side_exec:
             _lib.check(lib.stove_graph_launch(self._side_exec, self._side.cuda_stream), 'stove_graph_launch')

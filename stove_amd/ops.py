@@ -347,30 +347,45 @@ def glimpse_mean(x_color, z, n_obj):
 
 class NoiseSource:
     """Standard-normal draws from the library's counter-based generator (csrc/state.hip noise_normal_k): the state -- [seed, call
-    number] -- lives in device memory and is advanced on the device, so a captured draw replays with fresh noise and costs nothing on
-    the host.  Seeded from torch's generator of the device (torch.manual_seed reaches it); a reseed of that generator reseeds this."""
+    number] -- lives in device memory and is advanced on the device, so a captured draw replays with fresh noise and costs nothing
+    on the device's serial chain.  It shadows torch's generator of the device: seed = its seed, call number = its Philox offset / 4,
+    and every draw advances that offset by 4 on the host -- so torch.manual_seed (also with the same value again),
+    torch.cuda.set_rng_state and per-rank seeding restart / restore this stream exactly as they do torch's own."""
 
     def __init__(self, device):
         self.device = torch.device(device)
-        self._seed = None
+        self._seed = self._expected = None
         self.state = None
+        self.captured = 0            # draws enqueued under stream capture since the capturing caller last cleared this
 
-    def _sync_seed(self):
+    def _gen(self):
         torch.cuda.init()
-        gen = torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()]
-        seed = int(gen.initial_seed())
-        if seed != self._seed:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError('NoiseSource: the generator was reseeded inside a stream capture')
+        return torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()]
+
+    def prepare(self, n_draws=1):
+        """Host side of n_draws draws that are about to be enqueued (eagerly, or by replaying a graph that holds them): if torch's
+        generator was reseeded / restored since the last draw, the device state is rewritten from it (one 16-byte copy in stream
+        order); then the generator's offset moves on as the device counter will."""
+        gen = self._gen()
+        seed, off = int(gen.initial_seed()), int(gen.get_offset())
+        if self.state is None or seed != self._seed or off != self._expected:
+            val = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, off // 4], dtype=torch.int64)
+            if self.state is None:
+                self.state = val.to(self.device)
+            else:
+                self.state.copy_(val, non_blocking=False)
             self._seed = seed
-            self.state = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, 0], dtype=torch.int64, device=self.device)
+        gen.set_offset(off + 4 * n_draws)
+        self._expected = off + 4 * n_draws
 
     def normal(self, numel):
-        """(numel,) fp32 draws, enqueued on the library's current stream (ops run it on the parameter stream ahead of its consumer)."""
+        """(numel,) fp32 draws, enqueued on the library's current stream (Stove runs it on the parameter stream ahead of its consumer)."""
         if not torch.cuda.is_current_stream_capturing():
-            self._sync_seed()
+            self.prepare(1)
         elif self.state is None:
             raise RuntimeError('NoiseSource: first use inside a stream capture (run one eager step first)')
+        else:
+            self.captured += 1
         out = torch.empty(int(numel), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             check(_lib.load().stove_noise_normal(ptr(out), int(numel), self.state.data_ptr(), stream()), 'stove_noise_normal')

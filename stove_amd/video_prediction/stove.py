@@ -68,13 +68,6 @@ class Stove(nn.Module):
             return self.noise_fn(kind, shape).to(device=like.device, dtype=like.dtype)
         return torch.randn(shape, device=like.device, dtype=like.dtype)
 
-    def reset_noise(self):
-        """Restart the library generator's stream (call number 0) -- torch.manual_seed(s) with a NEW s reseeds it by itself, the same s
-        again cannot be told from no call at all."""
-        src = getattr(self, '_noise_source', None)
-        if src is not None and src.state is not None:
-            src.state[1] = 0
-
     def _draw_ahead(self, numel, dev):
         """All of a step's standard-normal draws from the library's generator, on the parameter stream (ops 'pre'), behind nothing:
         -> (tensor, event to wait for before reading it)."""

@@ -350,16 +350,7 @@ def test_caller_owned_fork_stream():
     assert lib.stove_set_fork_stream(99, None, 1) != 0
 
 
-def test_likelihood_refuses_align_corners():
-    from stove_amd.video_prediction.config import StoveConfig
-    from stove_amd.video_prediction.supair import Supair
-    dev = torch.device('cuda:0')
-    cfg = StoveConfig()
-    cfg.num_obj, cfg.width, cfg.height, cfg.random_seed, cfg.channels = 3, 32, 32, 42, 1
-    cfg.device, cfg.dtype, cfg.align_corners = dev, torch.float32, True
-    sup = Supair(cfg).to(dev)
-    with pytest.raises(NotImplementedError):
-        sup.likelihood(torch.zeros(1, 2, 1, 32, 32, device=dev), torch.rand(6, 4, device=dev))
+# config.align_corners=True is served by the general likelihood path since round 4: tests/test_gpu_round4.py (g13 goldens)
 
 
 @pytest.mark.parametrize('items,n_obj', [(1, 3), (37, 3), (25088, 3), (1000, 6)])

@@ -28,15 +28,22 @@ def test_noise_source_statistics_and_reproducibility():
     assert abs(float((a[:-1] * a[1:]).double().mean())) < 2e-3                    # neighbours (the two halves of a Box-Muller pair) uncorrelated
     assert abs(float((a * b).double().mean())) < 2e-3                             # successive calls uncorrelated
     assert int(src.state[1]) == 2
-    # same seed, same call -> same numbers, whatever the length of the draw
+    # same seed, same call -> same numbers, whatever the length of the draw, also from another source object
     torch.manual_seed(123)
     src2 = ops.NoiseSource(DEV)
     c = src2.normal(1003)
     assert torch.equal(c, a[:1003])
-    # a reseed of torch's generator reseeds the source
+    assert torch.equal(src2.normal(1003), b[:1003])
+    # reseeding torch's generator -- with another value or the same one again -- restarts the stream, restoring its state resumes it
     torch.manual_seed(124)
     d = src2.normal(1003)
     assert not torch.equal(d, c) and int(src2.state[1]) == 1
+    torch.manual_seed(123)
+    assert torch.equal(src.normal(1003), a[:1003])
+    keep = torch.cuda.get_rng_state(DEV)
+    e1 = src.normal(64)
+    torch.cuda.set_rng_state(keep, DEV)
+    assert torch.equal(src.normal(64), e1) and torch.equal(e1, b[:64])
 
 
 def test_model_draws_from_the_library_generator_by_default():
@@ -58,7 +65,6 @@ def test_model_draws_from_the_library_generator_by_default():
         e1 = float(model(x, 1)[0])
         e2 = float(model(x, 1)[0])
         torch.manual_seed(5)
-        model.reset_noise()
         e3 = float(model(x, 1)[0])
         assert np.isfinite(e1) and e1 != e2 and e1 == e3, (mode, e1, e2, e3)
     assert model._noise_source.state is not None
