@@ -165,7 +165,9 @@ class DeviceClipLoader:
         return ij[:, 0] * self.n_frames + ij[:, 1]
 
     def batch(self, clip_ids, base=None):
-        """The batch of the given clip numbers (indices into dataset.idxs); `base`: their first-frame indices already on the device."""
+        """The batch of the given clip numbers (indices into dataset.idxs); `base`: their first-frame indices already on the device.
+        While `present_images_out` is set (Trainer.train sets it to its captured step's input for the duration of its loop and
+        clears it afterwards) every batch returns THAT tensor as present_images: such a batch is valid until the next one is made."""
         if base is None:
             base = self._base(clip_ids).to(self.device)
         pres, fut = base[:, None] + self._present, base[:, None] + self._future

@@ -347,6 +347,22 @@ class Trainer(AbstractTrainer):
             self.test(step_counter, start)
         num_epochs = self.c.num_epochs if num_epochs is None else num_epochs
         epoch = self.epoch_start
+        try:
+            epoch, step_counter = self._train_epochs(num_epochs, step_counter, start)
+        finally:
+            # the loader gathered its batches straight into the captured step's input while this loop ran (below): outside of it a
+            # batch it hands out must not alias that buffer (a second consumer, the mcts loop swapping loaders, a direct batch() call)
+            if hasattr(self.dataloader, 'present_images_out'):
+                self.dataloader.present_images_out = None
+        if not self.c.debug_test_mode and not self.c.supair_only:
+            self.long_rollout(step_counter=step_counter)
+        if not self.c.nolog and self.rank == 0:
+            self.save(epoch, step_counter)
+            open(os.path.join(self.logger.exp_dir, 'success'), 'w').close()
+        print('Finished Training!')
+
+    def _train_epochs(self, num_epochs, step_counter, start):
+        epoch = self.epoch_start
         for epoch in range(self.epoch_start, num_epochs):
             for data in self.dataloader:
                 now = time.time() - start
@@ -388,12 +404,7 @@ class Trainer(AbstractTrainer):
             print('Epoch: ', epoch, ' finished.')
             if self.c.debug_test_mode:
                 break
-        if not self.c.debug_test_mode and not self.c.supair_only:
-            self.long_rollout(step_counter=step_counter)
-        if not self.c.nolog and self.rank == 0:
-            self.save(epoch, step_counter)
-            open(os.path.join(self.logger.exp_dir, 'success'), 'w').close()
-        print('Finished Training!')
+        return epoch, step_counter
 
     @torch.no_grad()
     def test(self, step_counter, start):
