@@ -38,6 +38,8 @@ def parse():
     p.add_argument('--batch', type=int, default=256, help='sequences per GPU')
     p.add_argument('--frames', type=int, default=100, help='T, frames per sequence')
     p.add_argument('--workload', default='billiards', choices=['billiards', 'multibilliards', 'gravity', 'avoidance'])
+    p.add_argument('--res', type=int, default=32, help='frame side; 32 = BASELINE.json (fused scene pipeline), anything else runs the general-size '
+                   'likelihood path (the reference\'s stock gravity / multibilliards data are 50 x 50): a side measurement, never the headline')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-batch', type=int, default=32)
     p.add_argument('--cpu-iters', type=int, default=8)
@@ -56,10 +58,10 @@ def parse():
     return p.parse_args()
 
 
-def build_config(workload, device):
+def build_config(workload, device, res=32):
     from stove_amd.video_prediction.config import StoveConfig
     c = StoveConfig()
-    c.width, c.height, c.channels = 32, 32, 1
+    c.width, c.height, c.channels = res, res, 1
     c.device, c.dtype = device, torch.float32
     c.random_seed = 42
     c.skip = 2
@@ -72,13 +74,13 @@ def build_config(workload, device):
     return c
 
 
-def make_batch(workload, n_seq, T, seed0):
+def make_batch(workload, n_seq, T, seed0, res=32):
     from stove_amd.envs import envs
-    cache = os.path.join('/tmp', f'stove_bench_{workload}_{n_seq}_{T}_{seed0}.npz')
+    cache = os.path.join('/tmp', f'stove_bench_{workload}_{n_seq}_{T}_{seed0}' + ('' if res == 32 else f'_r{res}') + '.npz')
     if os.path.exists(cache):
         d = dict(np.load(cache))
     else:
-        d = envs.synth_sequences(workload, n_seq, T, seed0=seed0)
+        d = envs.synth_sequences(workload, n_seq, T, seed0=seed0, res=None if res == 32 else res)
         try:
             np.savez(cache, **d)
         except OSError:
@@ -256,7 +258,7 @@ def main():
     from stove_amd.arena import ParamArena
     from stove_amd.video_prediction.stove import Stove
 
-    cfg = build_config(a.workload, dev)
+    cfg = build_config(a.workload, dev, a.res)
     cfg.encoder_gemm = a.encoder_gemm
     if os.environ.get('STOVE_PIECES'):
         cfg.pipeline_pieces = int(os.environ['STOVE_PIECES'])
@@ -268,7 +270,7 @@ def main():
     opt = FlatAdam(bucket, lr=cfg.learning_rate, amsgrad=cfg.debug_amsgrad)       # torch.optim.Adam's update as one launch
 
     log('model built; generating data')
-    data = make_batch(a.workload, a.batch, a.frames, rank * a.batch)
+    data = make_batch(a.workload, a.batch, a.frames, rank * a.batch, a.res)
     log('data ready')
     x = torch.from_numpy(data['X']).to(dev).contiguous()       # a batch as the DataLoader collates it (contiguous n,T,C,w,h)
     # ... and as the Trainer's device-resident frame store hands it over (load_data.DeviceClipLoader, config.frame_store)
@@ -532,7 +534,7 @@ def main():
     # (BASELINE.json configs[1] says "bf16"; SURVEY section 7: reported, not assumed) and on the fp32 library path, each with
     # its ELBO difference against the fp32 library path on THIS batch under identical noise.  Never the headline `value`.
     variants = None
-    if rank == 0 and world == 1 and not a.no_variants:
+    if rank == 0 and world == 1 and not a.no_variants and a.res == 32:
         g = torch.Generator(device='cpu').manual_seed(99)
         o = cfg.num_obj
         fixed = {'latent': torch.randn(a.batch, o, 12, generator=g).to(dev), 'std': torch.randn(a.batch, o, 12, generator=g).to(dev),
@@ -642,7 +644,7 @@ def main():
             parity = {'error': repr(exc)}
         log('reference parity done')
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.res == 32:
         cpu = cpu_baseline(a.workload, a.frames, a.cpu_batch, a.cpu_iters, full_batch=a.batch)
         log('cpu baseline done')
 
@@ -657,7 +659,9 @@ def main():
             'vs_baseline': None,          # the reference publishes no number for this metric (its section 1)
             'dtype': 'f32' + ({'bf16x3': ' (encoder GEMMs: fp32 as 3 bf16 MFMAs on hi/lo-split operands, fp32 accumulate)', 'fp32': '', 'bf16': ' + bf16 encoder operands'}[a.encoder_gemm]),
             'data': 'synthetic',
-            'config': {'workload': f'{a.workload} {cfg.num_obj}-object 32x32 T={a.frames} batch={a.batch}/GPU' + (' (BASELINE.json configs[1])' if a.workload == 'billiards' and a.batch == 256 and a.frames == 100 else ''),
+            'config': {'workload': f'{a.workload} {cfg.num_obj}-object {a.res}x{a.res} T={a.frames} batch={a.batch}/GPU' + (
+                           ' (BASELINE.json configs[1])' if a.workload == 'billiards' and a.batch == 256 and a.frames == 100 and a.res == 32 else '') + (
+                           '' if a.res == 32 else ' (general-size likelihood path: not a BASELINE.json configuration)'),
                        'objects': cfg.num_obj, 'global_batch': a.batch * world,
                        'step': 'forward+backward+allreduce+clip+adam(amsgrad)', 'step_mode': a.step_mode + (
                            ' (captured hipGraph replay, as Trainer.train runs its non-logging steps)' if a.step_mode == 'graph' else ''),

@@ -126,6 +126,21 @@ int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z
 int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
                     int seq_stride, float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g,
                     void* ws, void* stream, void* param_stream);
+/* The same likelihood for any frame size and either sampling convention of the spatial transformer (reference supair.py:44-110 with
+ * config width/height != 32 -- the reference's stock gravity / multibilliards data are 50 x 50, envs.py:771-773 -- or the
+ * torch-1.0.1 convention align_corners=True its published runs used).  frames: rows of W*H floats (W = the size of the last
+ * tensor dimension, the x direction of grid_sample); 10 x 10 glimpses and single-channel frames as above.  The object side runs the
+ * 32 x 32 path's kernels with the geometry at run time; the background side the general-size SPN operator (stove_bgspn_fwd_d) on
+ * the closed-form mask.  t->bg_coef is [3][W*H][6][3], t->bg_side (W*H) int32, t->bg_dense unused.  saved / ws sizes below;
+ * *g complete in `param_stream` order (NULL = `stream`), dz in `stream` order. */
+size_t stove_scene_saved_floats_any(int n_frames, int n_obj, int n_pix, int with_grad);
+size_t stove_scene_bwd_ws_bytes_any(int n_frames, int n_obj, int n_pix);
+int stove_scene_fwd_any(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
+                        int seq_stride, int W, int H, int align_corners, float overlap_beta, float* ll, float* parts, float* saved,
+                        void* stream, int with_grad);
+int stove_scene_bwd_any(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
+                        int seq_stride, int W, int H, int align_corners, float overlap_beta, const float* saved, const float* dll,
+                        float* dz, StoveSpnTableGrads* g, void* ws, void* stream, void* param_stream);
 /* The same with the stream the internal background-SPN chain forks from given explicitly (NULL = `stream`).  For callers that run the
  * scene calls on a stream which is itself a fork inside a hipGraph capture: pass the capture's origin stream, where frames, z, saved
  * and dll must then be ready (the HIP 7.0 runtime cannot end a capture in which two forked streams wait on each other). */

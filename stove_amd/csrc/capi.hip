@@ -50,9 +50,34 @@ template <int NMAX>
 static int scene_tile_fwd(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st, FrameMap fm) {
   const int nb = (np + 63) / 64;
   const int grid = nb < 8192 ? nb : 8192;          // one workgroup per batch of 64 glimpses
-  STOVE_LAUNCH((scene_tile_fwd_k<NMAX>), dim3(grid), dim3(256), 0, st, frames, z, xw, n_obj, np, nb, fm);
+  STOVE_LAUNCH((scene_tile_fwd_k<NMAX>), dim3(grid), dim3(256), 0, st, frames, z, xw, n_obj, np, nb, fm, SceneGeom{});
   STOVE_LAUNCH_CHECK();
   return 0;
+}
+// the same kernels with the frame size / sampling convention at run time (stove_scene_fwd_any)
+template <int NMAX>
+static int scene_tile_fwd_g(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st, FrameMap fm, SceneGeom gm) {
+  const int nb = (np + 63) / 64;
+  const int grid = nb < 8192 ? nb : 8192;
+  STOVE_LAUNCH((scene_tile_fwd_k<NMAX, true>), dim3(grid), dim3(256), 0, st, frames, z, xw, n_obj, np, nb, fm, gm);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+// SceneGeom of a W x H frame under either sampling convention of affine_grid / grid_sample (common.h)
+static SceneGeom scene_geom(int W, int H, int align_corners) {
+  SceneGeom g;
+  g.W = W; g.H = H;
+  g.cx = 0.5f * (W - 1); g.cy = 0.5f * (H - 1);
+  if (align_corners) {
+    g.pa = 2.0f / (kPatch - 1); g.pb = -1.0f;
+    g.sxa = 0.5f * (W - 1); g.sya = 0.5f * (H - 1);
+    g.fax = 2.0f / (W - 1); g.fbx = -1.0f; g.fay = 2.0f / (H - 1); g.fby = -1.0f;
+  } else {
+    g.pa = 2.0f / kPatch; g.pb = 1.0f / kPatch - 1.0f;
+    g.sxa = 0.5f * W; g.sya = 0.5f * H;
+    g.fax = 2.0f / W; g.fbx = 1.0f / W - 1.0f; g.fay = 2.0f / H; g.fby = 1.0f / H - 1.0f;
+  }
+  return g;
 }
 
 static int scene_tile_fwd_any(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st, FrameMap fm = FrameMap{0, 0}) {
@@ -386,6 +411,129 @@ int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const flo
                                 ws + W.d_obj, np, sp, true);
     if (rc) return rc;
   }
+  jp.dismiss();
+  return 0;
+}
+
+// ---------------------------------------------------------------- fused scene likelihood, any frame size / sampling convention
+// The object side is the 32 x 32 path's own kernels with the geometry at run time (scene_tile_fwd_k / scene_pixtile_bwd_k <.., ANY>,
+// objspn_fwd_unit_k, the table-gradient kernels); the background side is the mask in closed form (bg_mask_any_k), the general-size
+// operator of spn_bg_generic.hip, and the mask's backward to z (bg_mask_bwd_any_k).
+// saved = [ xw tile | obj_ll | ovl | bg_out | bg_ell (n x halves x 36) | mask (n x n_pix) | object-SPN scratch at unit gradient ]
+struct SceneSavedAny {
+  size_t xw, obj_ll, ovl, bg_out, bg_ell, mask, obj_scratch, total;
+};
+static SceneSavedAny scene_saved_layout_any(int nf, int n_obj, int n_pix, bool with_grad) {
+  const size_t np = (size_t)nf * n_obj;
+  SceneSavedAny s;
+  s.xw = 0;
+  s.obj_ll = align64(stove_objspn_tile_floats((int)np));
+  s.ovl = s.obj_ll + align64(np);
+  s.bg_out = s.ovl + align64(np);
+  s.bg_ell = s.bg_out + align64(nf);
+  s.mask = s.bg_ell + align64(bgspn_any_saved_floats(nf, n_pix));
+  s.obj_scratch = s.mask + align64((size_t)nf * n_pix);
+  s.total = s.obj_scratch + (with_grad ? align64(objspn_scratch_floats((int)np)) : 0);
+  return s;
+}
+struct SceneWsAny {
+  size_t d_obj, d_ovl, dzc, dz_bg, obj, d_mask, bg, total;
+};
+static SceneWsAny scene_ws_layout_any(int nf, int n_obj, int n_pix) {
+  const size_t np = (size_t)nf * n_obj;
+  SceneWsAny s;
+  s.d_obj = 0;
+  s.d_ovl = s.d_obj + align64(np);
+  s.dzc = s.d_ovl + align64(np);
+  s.dz_bg = s.dzc + align64(np * nmax_of(n_obj) * 4);
+  s.obj = s.dz_bg + align64(np * 4);
+  s.d_mask = s.obj + align64(objspn_partial_floats());
+  s.bg = s.d_mask + align64((size_t)nf * n_pix);
+  s.total = s.bg + align64(bgspn_any_bwd_ws_floats(nf, n_pix));
+  return s;
+}
+size_t stove_scene_saved_floats_any(int n_frames, int n_obj, int n_pix, int with_grad) { return scene_saved_layout_any(n_frames, n_obj, n_pix, with_grad != 0).total; }
+size_t stove_scene_bwd_ws_bytes_any(int n_frames, int n_obj, int n_pix) { return scene_ws_layout_any(n_frames, n_obj, n_pix).total * sizeof(float); }
+
+int stove_scene_fwd_any(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames, int seq_stride,
+                        int W, int H, int align_corners, float overlap_beta, float* ll, float* parts, float* saved, void* stream, int with_grad) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_frames == 0) return 0;
+  if (W < 2 || H < 2 || n_obj < 1 || n_obj > 8) return (int)hipErrorInvalidValue;
+  FrameMap fm;
+  if (frame_map(n_frames, seq_frames, seq_stride, &fm)) return (int)hipErrorInvalidValue;
+  const int n_pix = W * H, np = n_frames * n_obj;
+  const SceneGeom gm = scene_geom(W, H, align_corners);
+  const SceneSavedAny L = scene_saved_layout_any(n_frames, n_obj, n_pix, true);
+  hipStream_t sb = scene_fork_stream(st);
+  STOVE_TRY(stream_after(sb, st));
+  JoinGuard jb(st, sb);
+  int rc = n_obj <= 3 ? scene_tile_fwd_g<3>(frames, z, saved + L.xw, n_obj, np, st, fm, gm)
+                      : (n_obj <= 6 ? scene_tile_fwd_g<6>(frames, z, saved + L.xw, n_obj, np, st, fm, gm) : scene_tile_fwd_g<8>(frames, z, saved + L.xw, n_obj, np, st, fm, gm));
+  if (rc) return rc;
+  if (with_grad)
+    rc = objspn_forward_unit(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl,
+                             saved + L.obj_scratch, np, st);
+  else
+    rc = objspn_forward(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl, np, st);
+  if (rc) return rc;
+  const size_t tot = (size_t)n_frames * n_pix;
+  STOVE_LAUNCH(bg_mask_any_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, sb, z, saved + L.mask, n_frames, n_obj, gm);
+  STOVE_LAUNCH_CHECK();
+  rc = bgspn_any_forward(frames, saved + L.mask, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, n_pix, sb, fm);
+  if (rc) return rc;
+  STOVE_TRY(jb.join());
+  STOVE_LAUNCH(scene_assemble_fwd_k, dim3((n_frames + 255) / 256), dim3(256), 0, st, saved + L.bg_out, saved + L.obj_ll,
+               saved + L.ovl, z, ll, parts, n_obj, n_frames, overlap_beta, logf(overlap_beta));
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+
+int stove_scene_bwd_any(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames, int seq_stride,
+                        int W, int H, int align_corners, float overlap_beta, const float* saved, const float* dll, float* dz,
+                        StoveSpnTableGrads* g, void* ws_, void* stream, void* param_stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipStream_t sp = param_stream != nullptr ? (hipStream_t)param_stream : st;
+  if (n_frames == 0) return 0;
+  if (W < 2 || H < 2 || n_obj < 1 || n_obj > 8) return (int)hipErrorInvalidValue;
+  FrameMap fm;
+  if (frame_map(n_frames, seq_frames, seq_stride, &fm)) return (int)hipErrorInvalidValue;
+  float* ws = (float*)ws_;
+  const int n_pix = W * H, np = n_frames * n_obj;
+  const SceneGeom gm = scene_geom(W, H, align_corners);
+  const SceneSavedAny L = scene_saved_layout_any(n_frames, n_obj, n_pix, true);
+  const SceneWsAny Wl = scene_ws_layout_any(n_frames, n_obj, n_pix);
+  STOVE_LAUNCH(scene_assemble_bwd_k, dim3((np + 255) / 256), dim3(256), 0, st, dll, z, ws + Wl.d_obj, ws + Wl.d_ovl, n_obj, np, overlap_beta);
+  STOVE_LAUNCH_CHECK();
+  hipStream_t sb = scene_fork_stream(st);
+  STOVE_TRY(stream_after(sb, st));
+  JoinGuard jb(st, sb);
+  JoinGuard jp(st, sp);
+  // background chain: operator backward (d mask, table gradients), then the mask's backward to z
+  int rc = bgspn_any_backward(frames, saved + L.mask, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, dll, nullptr,
+                              ws + Wl.d_mask, g->bg_coef, g->bg_wroot, ws + Wl.bg, n_frames, n_pix, sb, fm);
+  if (rc) return rc;
+  if (n_obj <= 3) STOVE_LAUNCH((bg_mask_bwd_any_k<3>), dim3(n_frames), dim3(256), 0, sb, z, (const float*)(ws + Wl.d_mask), ws + Wl.dz_bg, n_frames, n_obj, gm);
+  else STOVE_LAUNCH((bg_mask_bwd_any_k<8>), dim3(n_frames), dim3(256), 0, sb, z, (const float*)(ws + Wl.d_mask), ws + Wl.dz_bg, n_frames, n_obj, gm);
+  STOVE_LAUNCH_CHECK();
+  // object chain: pixel / transformer backward from the unit-gradient scratch, then the per-object sums with dz_bg
+  const float* d_obj = ws + Wl.d_obj;
+  if (n_obj <= 3)
+    rc = scene_pixtile_bwd<3, true>(frames, z, saved + L.xw, saved + L.obj_scratch, t->obj_leaf_slot, t->obj_coef, ws + Wl.d_ovl, ws + Wl.dzc, n_obj, np, st, fm, d_obj, gm);
+  else if (n_obj <= 6)
+    rc = scene_pixtile_bwd<6, true>(frames, z, saved + L.xw, saved + L.obj_scratch, t->obj_leaf_slot, t->obj_coef, ws + Wl.d_ovl, ws + Wl.dzc, n_obj, np, st, fm, d_obj, gm);
+  else
+    rc = scene_pixtile_bwd<8, true>(frames, z, saved + L.xw, saved + L.obj_scratch, t->obj_leaf_slot, t->obj_coef, ws + Wl.d_ovl, ws + Wl.dzc, n_obj, np, st, fm, d_obj, gm);
+  if (rc) return rc;
+  STOVE_TRY(jb.join());
+  if (n_obj <= 3) STOVE_LAUNCH((scene_finalize_bwd_k<3>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, saved + L.obj_ll, ws + Wl.dz_bg, ws + Wl.dzc, dz, n_obj, np);
+  else if (n_obj <= 6) STOVE_LAUNCH((scene_finalize_bwd_k<6>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, saved + L.obj_ll, ws + Wl.dz_bg, ws + Wl.dzc, dz, n_obj, np);
+  else STOVE_LAUNCH((scene_finalize_bwd_k<8>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, saved + L.obj_ll, ws + Wl.dz_bg, ws + Wl.dzc, dz, n_obj, np);
+  STOVE_LAUNCH_CHECK();
+  // table gradients of the object SPN on the parameter stream (the background's are complete in `st` order: ordered into it as well)
+  STOVE_TRY(stream_after(sp, st));
+  rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, saved + L.obj_scratch, ws + Wl.obj, ws + Wl.d_obj, np, sp);
+  if (rc) return rc;
   jp.dismiss();
   return 0;
 }

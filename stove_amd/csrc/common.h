@@ -72,6 +72,18 @@ struct FrameMap {
   }
 };
 
+// Geometry of the spatial transformer for frames other than 32 x 32 and for the torch-1.0.1 sampling convention
+// (align_corners=True), csrc/capi.hip scene_geom().  A normalised coordinate g maps to the pixel coordinate sxa g + cx (columns;
+// sya g + cy for rows) with cx = (W - 1) / 2 in both conventions and sxa = W / 2 (align_corners False) or (W - 1) / 2 (True);
+// glimpse pixel j sits at the normalised coordinate pa j + pb ((2j + 1)/10 - 1, or -1 + 2j/9), frame column X at fax X + fbx.
+// The kernels that take it are templates on ANY: false = the 32 x 32 / align_corners=False constants at compile time (the
+// expressions below are then exactly the ones the tuned path was validated with), true = everything from this struct.
+struct SceneGeom {
+  int W, H;
+  float pa, pb;
+  float sxa, sya, cx, cy;
+  float fax, fbx, fay, fby;
+};
 // Coverage of a ones-image sampled at q (zero padding): value and d/dq.
 __device__ __forceinline__ float cover(float q, int n, float* dq) {
   const Tap1 t = make_tap(q, n);

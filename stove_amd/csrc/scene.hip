@@ -41,12 +41,32 @@ __device__ __forceinline__ float inv_pix(float inv_s, float off, int idx) {
   const float u = (2.0f * idx + 1.0f) * (1.0f / kImg) - 1.0f;
   return ((fmaf(inv_s, u, off) + 1.0f) * kImg - 1.0f) * 0.5f;
 }
+// the same from the geometry struct
+__device__ __forceinline__ PatchPix patch_pix_g(const float* zk, int p, const SceneGeom& gm) {
+  PatchPix q;
+  const int i = p / kPatch, j = p % kPatch;
+  q.u = fmaf(gm.pa, (float)j, gm.pb);
+  q.v = fmaf(gm.pa, (float)i, gm.pb);
+  const float gx = fmaf(zk[0], q.u, zk[2]);
+  const float gy = fmaf(zk[1], q.v, zk[3]);
+  q.tx = make_tap(fmaf(gm.sxa, gx, gm.cx), gm.W);
+  q.ty = make_tap(fmaf(gm.sya, gy, gm.cy), gm.H);
+  return q;
+}
+__device__ __forceinline__ float inv_pix_x(float inv_s, float off, int idx, const SceneGeom& gm) {
+  return fmaf(gm.sxa, fmaf(inv_s, fmaf(gm.fax, (float)idx, gm.fbx), off), gm.cx);
+}
+__device__ __forceinline__ float inv_pix_y(float inv_s, float off, int idx, const SceneGeom& gm) {
+  return fmaf(gm.sya, fmaf(inv_s, fmaf(gm.fay, (float)idx, gm.fby), off), gm.cy);
+}
 
 // ---- tile forward: thread = (patch lane, pixel) -------------------------------------------
 // frames [n_frames][1024], z [n_frames*n_obj][4] = [sx, sy, x, y]; xw [n_batches][100][2][64]
-template <int NMAX>
+template <int NMAX, bool ANY = false>
 __global__ __launch_bounds__(256) void scene_tile_fwd_k(const float* __restrict__ frames, const float* __restrict__ z,
-                                                        float* __restrict__ xw, int n_obj, int n_patches, int n_batches, FrameMap fm) {
+                                                        float* __restrict__ xw, int n_obj, int n_patches, int n_batches, FrameMap fm,
+                                                        SceneGeom gm = SceneGeom{}) {
+  const int IW = ANY ? gm.W : kImg, IH = ANY ? gm.H : kImg;
   const int lane = lane_id();
   // workgroup = one batch of 64 glimpses, its 4 waves share the 100 pixels: the ~22 frames of a batch are then gathered by ONE
   // workgroup (one XCD's L2).  With (batch, pixel) items dealt round-robin over the whole grid every frame was pulled into
@@ -72,17 +92,17 @@ __global__ __launch_bounds__(256) void scene_tile_fwd_k(const float* __restrict_
       ox[j] = -zj.z * isx[j];
       oy[j] = -zj.w * isy[j];
     }
-    const float* img = frames + fm.row(f) * (kImg * kImg);
+    const float* img = frames + fm.row(f) * (size_t)(IW * IH);
     for (int p = wave_id(); p < kPD; p += 4) {
-      const PatchPix q = patch_pix(zk, p);
+      const PatchPix q = ANY ? patch_pix_g(zk, p, gm) : patch_pix(zk, p);
       // the four taps: unconditional loads from clamped coordinates, the in-bounds flags folded into the weights
       float tap[4], wt[4];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          const int iy = min(max(q.ty.i0 + a, 0), kImg - 1), ix = min(max(q.tx.i0 + c, 0), kImg - 1);
-          tap[a * 2 + c] = img[iy * kImg + ix];
+          const int iy = min(max(q.ty.i0 + a, 0), IH - 1), ix = min(max(q.tx.i0 + c, 0), IW - 1);
+          tap[a * 2 + c] = img[iy * IW + ix];
           wt[a * 2 + c] = (a ? q.ty.in1 : q.ty.in0) * (c ? q.tx.in1 : q.tx.in0) * (a ? q.ty.t : 1.0f - q.ty.t) * (c ? q.tx.t : 1.0f - q.tx.t);
         }
       // earlier objects' coverage at the two tap columns / rows; run[a][c] = min(1, sum of their boxes) at tap (a, c)
@@ -90,9 +110,14 @@ __global__ __launch_bounds__(256) void scene_tile_fwd_k(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < NOCC; ++j) {
         if (j < k) {
-          float d;
-          const float cx0 = cover(inv_pix(isx[j], ox[j], q.tx.i0), kImg, &d), cx1 = cover(inv_pix(isx[j], ox[j], q.tx.i0 + 1), kImg, &d);
-          const float cy0 = cover(inv_pix(isy[j], oy[j], q.ty.i0), kImg, &d), cy1 = cover(inv_pix(isy[j], oy[j], q.ty.i0 + 1), kImg, &d);
+          float d, cx0, cx1, cy0, cy1;
+          if (ANY) {
+            cx0 = cover(inv_pix_x(isx[j], ox[j], q.tx.i0, gm), IW, &d), cx1 = cover(inv_pix_x(isx[j], ox[j], q.tx.i0 + 1, gm), IW, &d);
+            cy0 = cover(inv_pix_y(isy[j], oy[j], q.ty.i0, gm), IH, &d), cy1 = cover(inv_pix_y(isy[j], oy[j], q.ty.i0 + 1, gm), IH, &d);
+          } else {
+            cx0 = cover(inv_pix(isx[j], ox[j], q.tx.i0), kImg, &d), cx1 = cover(inv_pix(isx[j], ox[j], q.tx.i0 + 1), kImg, &d);
+            cy0 = cover(inv_pix(isy[j], oy[j], q.ty.i0), kImg, &d), cy1 = cover(inv_pix(isy[j], oy[j], q.ty.i0 + 1), kImg, &d);
+          }
           run[0] = fminf(run[0] + cx0 * cy0, 1.0f);
           run[1] = fminf(run[1] + cx1 * cy0, 1.0f);
           run[2] = fminf(run[2] + cx0 * cy1, 1.0f);

@@ -21,18 +21,22 @@
 namespace stove {
 
 // coverage of a ones image of kImg samples (bilinear, zero padding) at pixel coordinate q, and d/dq
-__device__ __forceinline__ float cover_cf(float q, float* dq) {
-  const float a = q + 1.0f, b = (float)kImg - q;
+__device__ __forceinline__ float cover_cf(float q, float* dq, float n = (float)kImg) {
+  const float a = q + 1.0f, b = n - q;
   const float m = fminf(a, b);
   *dq = (m > 0.0f && m < 1.0f) ? (a < b ? 1.0f : -1.0f) : 0.0f;
   return fminf(fmaxf(m, 0.0f), 1.0f);
 }
 
-template <int R, int S, int G, int NMAX, int SLOTS>
+template <int R, int S, int G, int NMAX, int SLOTS, bool ANY = false>
 __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
     const float* __restrict__ frames, const float* __restrict__ z, const float* __restrict__ xw, const float* __restrict__ Dscr,
     const int* __restrict__ leaf_slot, const float* __restrict__ coef, const float* __restrict__ d_ovl, float* __restrict__ dzc,
-    int n_obj, int n_patches, int n_batches, FrameMap fm, const float* __restrict__ scale) {
+    int n_obj, int n_patches, int n_batches, FrameMap fm, const float* __restrict__ scale, SceneGeom gm = SceneGeom{}) {
+  // ANY: frame size and sampling convention from `gm` (scene.hip SceneGeom); else the 32 x 32 / align_corners=False constants
+  const int IW = ANY ? gm.W : kImg, IH = ANY ? gm.H : kImg;
+  const float SXA = ANY ? gm.sxa : 0.5f * kImg, SYA = ANY ? gm.sya : 0.5f * kImg;          // d pixel / d normalised coordinate
+  const float CXc = ANY ? gm.cx : 15.5f, CYc = ANY ? gm.cy : 15.5f;                        // pixel coordinate of the frame centre
   constexpr int D = 4 * S;
   constexpr int DT = R * 4 * G * 64;
   constexpr int RED = SLOTS * NMAX * 4 * 64;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
     const int f = live ? patch / n_obj : 0, k = live ? patch % n_obj : 0;
     const float* zf = z + (size_t)f * n_obj * 4;
     const float zk[4] = {zf[k * 4], zf[k * 4 + 1], zf[k * 4 + 2], zf[k * 4 + 3]};
-    const float* img = frames + fm.row(f) * (kImg * kImg);
+    const float* img = frames + fm.row(f) * (size_t)(IW * IH);
     const float govl = live ? d_ovl[patch] * (-1.0f / kPD) : 0.0f;   // d overlap / d seen = -1/100
     // occluders j < k: q(X) = isx (X - 15.5) + cxo;  j >= k: coverage 0 everywhere
     float isx[NOCC], isy[NOCC], cxo[NOCC], cyo[NOCC], xj[NOCC], yj[NOCC];
@@ -92,8 +96,8 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
       yj[j] = occ ? zf[j * 4 + 3] : 0.0f;
       isx[j] = occ ? 1.0f / sx : 0.0f;
       isy[j] = occ ? 1.0f / sy : 0.0f;
-      cxo[j] = occ ? fmaf(-16.0f * xj[j], isx[j], 15.5f) : -100.0f;
-      cyo[j] = occ ? fmaf(-16.0f * yj[j], isy[j], 15.5f) : -100.0f;
+      cxo[j] = occ ? (ANY ? fmaf(-SXA * xj[j], isx[j], CXc) : fmaf(-16.0f * xj[j], isx[j], 15.5f)) : -100.0f;
+      cyo[j] = occ ? (ANY ? fmaf(-SYA * yj[j], isy[j], CYc) : fmaf(-16.0f * yj[j], isy[j], 15.5f)) : -100.0f;
     }
     float own[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float sx0[NOCC], sx2[NOCC], sy1[NOCC], sy3[NOCC];      // raw occluder sums: dqx (uu - x_j), dqx, dqy (vv - y_j), dqy
@@ -136,22 +140,23 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
       const float gX = fmaf(x + x, A, Bq) * w;
       const float gW = fmaf(x, fmaf(x, A, Bq), C);
       // ---- transformer / mask backward of the pixel
-      const PatchPix q = patch_pix(zk, p);
-      const int c0 = min(max(q.tx.i0, 0), kImg - 1), c1 = min(max(q.tx.i0 + 1, 0), kImg - 1);
-      const int r0 = min(max(q.ty.i0, 0), kImg - 1), r1 = min(max(q.ty.i0 + 1, 0), kImg - 1);
+      const PatchPix q = ANY ? patch_pix_g(zk, p, gm) : patch_pix(zk, p);
+      const int c0 = min(max(q.tx.i0, 0), IW - 1), c1 = min(max(q.tx.i0 + 1, 0), IW - 1);
+      const int r0 = min(max(q.ty.i0, 0), IH - 1), r1 = min(max(q.ty.i0 + 1, 0), IH - 1);
       const float inb00 = q.ty.in0 * q.tx.in0, inb01 = q.ty.in0 * q.tx.in1, inb10 = q.ty.in1 * q.tx.in0, inb11 = q.ty.in1 * q.tx.in1;
-      const float im00 = img[r0 * kImg + c0] * inb00, im01 = img[r0 * kImg + c1] * inb01;
-      const float im10 = img[r1 * kImg + c0] * inb10, im11 = img[r1 * kImg + c1] * inb11;
+      const float im00 = img[r0 * IW + c0] * inb00, im01 = img[r0 * IW + c1] * inb01;
+      const float im10 = img[r1 * IW + c0] * inb10, im11 = img[r1 * IW + c1] * inb11;
       float cx[NOCC][2], cy[NOCC][2], dcx[NOCC][2], dcy[NOCC][2];
       float s00 = 0.0f, s01 = 0.0f, s10 = 0.0f, s11 = 0.0f;     // mask sum at tap (row a, column c): s_ac
-      const float fx = (float)q.tx.i0 - 15.5f, fy = (float)q.ty.i0 - 15.5f;
+      const float fx = (float)q.tx.i0 - CXc, fy = (float)q.ty.i0 - CYc;
+      const float nW = (float)IW, nH = (float)IH;
 #pragma unroll
       for (int j = 0; j < NOCC; ++j) {
         const float qx = fmaf(isx[j], fx, cxo[j]), qy = fmaf(isy[j], fy, cyo[j]);
-        cx[j][0] = cover_cf(qx, &dcx[j][0]);
-        cx[j][1] = cover_cf(qx + isx[j], &dcx[j][1]);
-        cy[j][0] = cover_cf(qy, &dcy[j][0]);
-        cy[j][1] = cover_cf(qy + isy[j], &dcy[j][1]);
+        cx[j][0] = cover_cf(qx, &dcx[j][0], nW);
+        cx[j][1] = cover_cf(qx + isx[j], &dcx[j][1], nW);
+        cy[j][0] = cover_cf(qy, &dcy[j][0], nH);
+        cy[j][1] = cover_cf(qy + isy[j], &dcy[j][1], nH);
         s00 = fmaf(cx[j][0], cy[j][0], s00);
         s01 = fmaf(cx[j][1], cy[j][0], s01);
         s10 = fmaf(cx[j][0], cy[j][1], s10);
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
       // own object: through the sample location
       const float dpx = gX * (wy0 * (im01 - im00) + wy1 * (im11 - im10)) + dseen * (wy0 * (vis01 - vis00) + wy1 * (vis11 - vis10));
       const float dpy = gX * (wx0 * (im10 - im00) + wx1 * (im11 - im01)) + dseen * (wx0 * (vis10 - vis00) + wx1 * (vis11 - vis01));
-      const float dgx = dpx * (0.5f * kImg), dgy = dpy * (0.5f * kImg);
+      const float dgx = dpx * SXA, dgy = dpy * SYA;
       own[0] = fmaf(dgx, q.u, own[0]);
       own[1] = fmaf(dgy, q.v, own[1]);
       own[2] += dgx;
@@ -178,8 +183,10 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
       const float nb01 = (inb01 != 0.0f && s01 <= 1.0f) ? -dseen * wy0 * wx1 : 0.0f;
       const float nb10 = (inb10 != 0.0f && s10 <= 1.0f) ? -dseen * wy1 * wx0 : 0.0f;
       const float nb11 = (inb11 != 0.0f && s11 <= 1.0f) ? -dseen * wy1 * wx1 : 0.0f;
-      const float uu0 = (2.0f * q.tx.i0 + 1.0f) * (1.0f / kImg) - 1.0f, uu1 = uu0 + 2.0f / kImg;
-      const float vv0 = (2.0f * q.ty.i0 + 1.0f) * (1.0f / kImg) - 1.0f, vv1 = vv0 + 2.0f / kImg;
+      const float uu0 = ANY ? fmaf(gm.fax, (float)q.tx.i0, gm.fbx) : (2.0f * q.tx.i0 + 1.0f) * (1.0f / kImg) - 1.0f;
+      const float uu1 = uu0 + (ANY ? gm.fax : 2.0f / kImg);
+      const float vv0 = ANY ? fmaf(gm.fay, (float)q.ty.i0, gm.fby) : (2.0f * q.ty.i0 + 1.0f) * (1.0f / kImg) - 1.0f;
+      const float vv1 = vv0 + (ANY ? gm.fay : 2.0f / kImg);
 #pragma unroll
       for (int j = 0; j < NOCC; ++j) {
         const float gx0 = fmaf(nb00, cy[j][0], nb10 * cy[j][1]) * dcx[j][0];     // column c = 0: sum over the two rows
@@ -198,10 +205,10 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
     for (int j = 0; j < NMAX; ++j) {
       const bool mine = (j == k);
       // d q / d(1/s) etc.: q = (X - 15.5)/s + 15.5 - 16 x/s  =>  dL/ds = -16 (uu - x)/s^2 dL/dq,  dL/dx = -16/s dL/dq
-      const float h = -0.5f * kImg;
+      const float h = -SXA, hy = -SYA;
       const int jo = j < NOCC ? j : 0;                      // the last object is nobody's occluder: its sums are zeros
       const float sc = j < NOCC ? 1.0f : 0.0f;
-      const float a0 = sc * h * isx[jo] * isx[jo] * sx0[jo], a1 = sc * h * isy[jo] * isy[jo] * sy1[jo], a2 = sc * h * isx[jo] * sx2[jo], a3 = sc * h * isy[jo] * sy3[jo];
+      const float a0 = sc * h * isx[jo] * isx[jo] * sx0[jo], a1 = sc * hy * isy[jo] * isy[jo] * sy1[jo], a2 = sc * h * isx[jo] * sx2[jo], a3 = sc * hy * isy[jo] * sy3[jo];
       red[(slot * NMAX * 4 + j * 4 + 0) * 64 + lane] = mine ? own[0] : a0;
       red[(slot * NMAX * 4 + j * 4 + 1) * 64 + lane] = mine ? own[1] : a1;
       red[(slot * NMAX * 4 + j * 4 + 2) * 64 + lane] = mine ? own[2] : a2;
@@ -222,10 +229,10 @@ __global__ __launch_bounds__(64 * SLOTS) void scene_pixtile_bwd_k(
   }
 }
 
-template <int NMAX>
+template <int NMAX, bool ANY = false>
 static int scene_pixtile_bwd(const float* frames, const float* z, const float* xw, const float* Dscr, const int* leaf_slot,
                              const float* coef, const float* d_ovl, float* dzc, int n_obj, int np, hipStream_t st, FrameMap fm,
-                             const float* scale) {      // scale: see the kernel's staging loop; nullptr = Dscr carries it
+                             const float* scale, SceneGeom gm = SceneGeom{}) {      // scale: see the kernel's staging loop; nullptr = Dscr carries it
   // 16 waves (4 per SIMD) when the cross-slot reduction buffer allows: the per-pixel code is a chain of dependent instructions
   // (~9 cycles per instruction at 2 waves per SIMD), more resident waves hide it
   constexpr int SLOTS = NMAX <= 3 ? 16 : 8;
@@ -233,11 +240,10 @@ static int scene_pixtile_bwd(const float* frames, const float* z, const float* x
   constexpr int LDS = (CFT + (DT > RED ? DT : RED)) * (int)sizeof(float);
   const int nb = (np + 63) / 64;
   if (nb == 0) return 0;
-  int rc = (int)hipFuncSetAttribute((const void*)scene_pixtile_bwd_k<6, 25, 10, NMAX, SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  int rc = (int)hipFuncSetAttribute((const void*)scene_pixtile_bwd_k<6, 25, 10, NMAX, SLOTS, ANY>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (rc) return rc;
-  STOVE_LAUNCH((scene_pixtile_bwd_k<6, 25, 10, NMAX, SLOTS>), dim3(nb < 256 ? nb : 256), dim3(64 * SLOTS), LDS, st, frames, z, xw, Dscr,      // persistent: one workgroup per CU
-              
-               leaf_slot, coef, d_ovl, dzc, n_obj, np, nb, fm, scale);
+  STOVE_LAUNCH((scene_pixtile_bwd_k<6, 25, 10, NMAX, SLOTS, ANY>), dim3(nb < 256 ? nb : 256), dim3(64 * SLOTS), LDS, st, frames, z, xw, Dscr,      // persistent: one workgroup per CU
+               leaf_slot, coef, d_ovl, dzc, n_obj, np, nb, fm, scale, gm);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

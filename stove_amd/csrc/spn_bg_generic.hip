@@ -13,7 +13,7 @@ namespace stove {
 template <int R, int G>
 __global__ __launch_bounds__(kBgThreads) void bgspn_fwd_any_k(const float* __restrict__ inputs, const float* __restrict__ marg,
                                                               const int* __restrict__ side, const float* __restrict__ coef,
-                                                              float* __restrict__ ell_part, int n_frames, int n_pix, int halves) {
+                                                              float* __restrict__ ell_part, int n_frames, int n_pix, int halves, FrameMap fm) {
   constexpr int NO = R * 2 * G;
   constexpr int NW = kBgThreads / 64;
   __shared__ float part[2][NW * 4][NO];     // one partial per 16-lane row of every wave
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_fwd_any_k(const float* __res
   }
   int it = 0;
   for (int f = blockIdx.x / halves; f < n_frames; f += gridDim.x / halves, ++it) {
-    const float x = inputs[(size_t)f * n_pix + pc];
+    const float x = inputs[fm.row(f) * n_pix + pc];
     float w = (marg != nullptr) ? 1.0f - fminf(fmaxf(marg[(size_t)f * n_pix + pc], 0.0f), 1.0f) : 1.0f;
     if (!live) w = 0.0f;
     const float wx = w * x, wxx = wx * x;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_any_k(const float* __res
                                                               const int* __restrict__ side, const float* __restrict__ coef,
                                                               const float* __restrict__ dell, float* __restrict__ d_inputs,
                                                               float* __restrict__ d_marg, float* __restrict__ gcoef_part, int n_frames,
-                                                              int n_pix, int halves) {
+                                                              int n_pix, int halves, FrameMap fm) {
   constexpr int NO = R * 2 * G;
   const int half = blockIdx.x % halves;
   const int p = half * kBgThreads + threadIdx.x;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_any_k(const float* __res
       }
   }
   for (int f = blockIdx.x / halves; f < n_frames; f += gridDim.x / halves) {
-    const float x = inputs[(size_t)f * n_pix + pc];
+    const float x = inputs[fm.row(f) * n_pix + pc];
     float mraw = 0.0f, w = 1.0f;
     if (marg != nullptr) {
       mraw = marg[(size_t)f * n_pix + pc];
@@ -158,6 +158,85 @@ __global__ __launch_bounds__(256) void bgspn_coef_reduce_any_k(const float* __re
   }
 }
 
+// ---- the background's marginalisation mask of a scene and its backward, any frame size (Supair.masks_from_z, supair.py:304-356) -----
+// mask[f][Y][X] = min(1, sum_k cover_x,k(X) cover_y,k(Y)): a pasted unit box is separable and the sequential clamps collapse (scene.hip).
+// cover(q) is the bilinear sample of a ones image with zero padding at pixel coordinate q = (X - cx) / sx_k + cx - sxa x_k / sx_k.
+__device__ __forceinline__ float cover_n(float q, float n, float* dq) {
+  const float a = q + 1.0f, b = n - q;
+  const float m = fminf(a, b);
+  *dq = (m > 0.0f && m < 1.0f) ? (a < b ? 1.0f : -1.0f) : 0.0f;
+  return fminf(fmaxf(m, 0.0f), 1.0f);
+}
+__global__ __launch_bounds__(256) void bg_mask_any_k(const float* __restrict__ z, float* __restrict__ mask, int n_frames, int n_obj, SceneGeom gm) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_pix = gm.W * gm.H;
+  if (t >= (size_t)n_frames * n_pix) return;
+  const int f = (int)(t / n_pix), p = (int)(t % n_pix);
+  const float X = (float)(p % gm.W) - gm.cx, Y = (float)(p / gm.W) - gm.cy;
+  float run = 0.0f;
+  for (int k = 0; k < n_obj; ++k) {
+    const float4 zk = *reinterpret_cast<const float4*>(z + ((size_t)f * n_obj + k) * 4);
+    const float isx = 1.0f / zk.x, isy = 1.0f / zk.y;
+    float d;
+    const float cxv = cover_n(fmaf(isx, X, fmaf(-gm.sxa * zk.z, isx, gm.cx)), (float)gm.W, &d);
+    const float cyv = cover_n(fmaf(isy, Y, fmaf(-gm.sya * zk.w, isy, gm.cy)), (float)gm.H, &d);
+    run += cxv * cyv;
+  }
+  mask[t] = fminf(run, 1.0f);
+}
+// d_mask[f][p] (= dL/d mask, from the background SPN's backward) -> dz_bg[f][k][4] = dL/d(sx, sy, x, y) of every pasted box.
+// One workgroup per frame, thread = pixels p, p + 256, ...; the 4 n_obj sums are reduced over the workgroup in a fixed order.
+template <int NMAX>
+__global__ __launch_bounds__(256) void bg_mask_bwd_any_k(const float* __restrict__ z, const float* __restrict__ d_mask, float* __restrict__ dz_bg,
+                                                         int n_frames, int n_obj, SceneGeom gm) {
+  __shared__ float red[4][NMAX * 4];
+  const int f = blockIdx.x;
+  const int n_pix = gm.W * gm.H;
+  float isx[NMAX], isy[NMAX], ox[NMAX], oy[NMAX], zx[NMAX], zy[NMAX], acc[NMAX][4];
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    const float4 zk = *reinterpret_cast<const float4*>(z + ((size_t)f * n_obj + (k < n_obj ? k : 0)) * 4);
+    isx[k] = 1.0f / zk.x; isy[k] = 1.0f / zk.y; zx[k] = zk.z; zy[k] = zk.w;
+    ox[k] = fmaf(-gm.sxa * zk.z, isx[k], gm.cx);
+    oy[k] = fmaf(-gm.sya * zk.w, isy[k], gm.cy);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[k][e] = 0.0f;
+  }
+  for (int p = threadIdx.x; p < n_pix; p += 256) {
+    const int Xi = p % gm.W, Yi = p / gm.W;
+    const float X = (float)Xi - gm.cx, Y = (float)Yi - gm.cy;
+    const float u = fmaf(gm.fax, (float)Xi, gm.fbx), v = fmaf(gm.fay, (float)Yi, gm.fby);
+    float cxv[NMAX], cyv[NMAX], dcx[NMAX], dcy[NMAX], run = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      cxv[k] = cover_n(fmaf(isx[k], X, ox[k]), (float)gm.W, &dcx[k]);
+      cyv[k] = cover_n(fmaf(isy[k], Y, oy[k]), (float)gm.H, &dcy[k]);
+      if (k < n_obj) run += cxv[k] * cyv[k];
+    }
+    const float d = run <= 1.0f ? d_mask[(size_t)f * n_pix + p] : 0.0f;        // min(1, .): the gradient passes while the sum is not clamped
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      if (k < n_obj) {
+        // q_x = (X - cx) / sx + cx - sxa x / sx:  dq/d(1/sx) = sxa (u - x),  dq/dx = -sxa / sx,  d(1/sx)/dsx = -1/sx^2
+        const float gx = d * cyv[k] * dcx[k], gy = d * cxv[k] * dcy[k];
+        acc[k][0] = fmaf(gx, -gm.sxa * (u - zx[k]) * isx[k] * isx[k], acc[k][0]);
+        acc[k][1] = fmaf(gy, -gm.sya * (v - zy[k]) * isy[k] * isy[k], acc[k][1]);
+        acc[k][2] = fmaf(gx, -gm.sxa * isx[k], acc[k][2]);
+        acc[k][3] = fmaf(gy, -gm.sya * isy[k], acc[k][3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float s = wave_sum(acc[k][e]);
+      if (lane_id() == 0) red[wave_id()][k * 4 + e] = s;
+    }
+  __syncthreads();
+  if (threadIdx.x < n_obj * 4) dz_bg[(size_t)f * n_obj * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 static inline int bg_halves_any(int n_pix) { return (n_pix + kBgThreads - 1) / kBgThreads; }
 static inline int bg_grid_any(int n_frames, int n_pix) {
   int g = n_frames < 128 ? n_frames : 128;
@@ -171,12 +250,12 @@ size_t bgspn_any_bwd_ws_floats(int n_frames, int n_pix) {
 }
 
 int bgspn_any_forward(const float* inputs, const float* marg, const int* side, const float* coef, const float* wroot, float* ell_part,
-                      float* out, int n_frames, int n_pix, hipStream_t st) {
+                      float* out, int n_frames, int n_pix, hipStream_t st, FrameMap fm = FrameMap{0, 0}) {
   if (n_frames == 0) return 0;
   if (n_pix < 1) return (int)hipErrorInvalidValue;
   const int halves = bg_halves_any(n_pix);
   STOVE_LAUNCH((bgspn_fwd_any_k<kBgR, kBgG>), dim3(bg_grid_any(n_frames, n_pix)), dim3(kBgThreads), 0, st, inputs, marg, side, coef, ell_part,
-               n_frames, n_pix, halves);
+               n_frames, n_pix, halves, fm);
   STOVE_LAUNCH_CHECK();
   STOVE_LAUNCH((bgspn_root_fwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, n_frames, halves);
   STOVE_LAUNCH_CHECK();
@@ -186,7 +265,7 @@ int bgspn_any_forward(const float* inputs, const float* marg, const int* side, c
 // g_coef [R][n_pix][G][3], g_wroot [R*G*G] overwritten
 int bgspn_any_backward(const float* inputs, const float* marg, const int* side, const float* coef, const float* wroot, const float* ell_part,
                        const float* out, const float* dout, float* d_inputs, float* d_marg, float* g_coef, float* g_wroot, float* ws,
-                       int n_frames, int n_pix, hipStream_t st) {
+                       int n_frames, int n_pix, hipStream_t st, FrameMap fm = FrameMap{0, 0}) {
   if (n_pix < 1) return (int)hipErrorInvalidValue;
   if (n_frames == 0) {
     hipMemsetAsync(g_coef, 0, sizeof(float) * kBgR * (size_t)n_pix * kBgG * 3, st);
@@ -201,7 +280,7 @@ int bgspn_any_backward(const float* inputs, const float* marg, const int* side, 
   STOVE_LAUNCH((bgspn_root_bwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, dout, dell, rsc, n_frames, halves);
   STOVE_LAUNCH_CHECK();
   STOVE_LAUNCH((bgspn_bwd_any_k<kBgR, kBgG>), dim3(grid), dim3(kBgThreads), 0, st, inputs, marg, side, coef, (const float*)dell, d_inputs, d_marg,
-               gpart, n_frames, n_pix, halves);
+               gpart, n_frames, n_pix, halves, fm);
   STOVE_LAUNCH_CHECK();
   const size_t nc = (size_t)kBgR * n_pix * kBgG * 3;
   STOVE_LAUNCH((bgspn_coef_reduce_any_k<kBgR, kBgG>), dim3((unsigned)((nc + 31) / 32)), dim3(256), 0, st, (const float*)gpart, g_coef, grid, n_pix, halves);

@@ -191,7 +191,8 @@ class _SceneFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, frames, z, obj_coef, obj_wsum, obj_wroot, bg_coef, bg_wroot,
-                obj_scope, obj_leaf_slot, bg_side, n_obj, beta, sink=None, bg_dense=None, with_grad=True):
+                obj_scope, obj_leaf_slot, bg_side, n_obj, beta, sink=None, bg_dense=None, with_grad=True, geom=None):
+        # geom = (W, H, align_corners) for frames other than 32 x 32 / align_corners=False (stove_scene_fwd_any), else None
         lib = _lib.load()
         z = _f32(z)
         tabs = [_f32(x) for x in (obj_coef, obj_wsum, obj_wroot, bg_coef, bg_wroot)]
@@ -217,12 +218,21 @@ class _SceneFn(torch.autograd.Function):
             # with a backward to come, the object SPN runs forward + backward (at unit upstream gradient) in one pass
             # (grad mode is off inside a Function's forward: the caller says whether it was on)
             grad = int(bool(with_grad) and any(ctx.needs_input_grad))
-            saved = torch.empty(lib.stove_scene_fwd_floats(nf, n_obj, grad) + 1, dtype=torch.float32, device=dev)
             t = _tables(obj=(obj_scope, obj_leaf_slot, tabs[0], tabs[1], tabs[2]), bg=(bg_side, tabs[3], tabs[4]), bg_dense=bg_dense)
-            check(lib.stove_scene_fwd_from(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, float(beta),
-                                           ptr(ll), ptr(parts), ptr(saved), stream(), None, grad), 'stove_scene_fwd_from')
+            if geom is not None:
+                W, H, ac = geom
+                if frames.shape[-1] != W * H or tabs[3].numel() != 3 * W * H * 6 * 3:
+                    raise ValueError('scene_likelihood: frames %s / background tables %s do not match a %d x %d frame'
+                                     % (tuple(frames.shape), tuple(tabs[3].shape), W, H))
+                saved = torch.empty(lib.stove_scene_saved_floats_any(nf, n_obj, W * H, grad) + 1, dtype=torch.float32, device=dev)
+                check(lib.stove_scene_fwd_any(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, W, H, int(ac),
+                                              float(beta), ptr(ll), ptr(parts), ptr(saved), stream(), grad), 'stove_scene_fwd_any')
+            else:
+                saved = torch.empty(lib.stove_scene_fwd_floats(nf, n_obj, grad) + 1, dtype=torch.float32, device=dev)
+                check(lib.stove_scene_fwd_from(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, float(beta),
+                                               ptr(ll), ptr(parts), ptr(saved), stream(), None, grad), 'stove_scene_fwd_from')
         ctx.save_for_backward(frames, z, *tabs, obj_scope, obj_leaf_slot, bg_side, saved)
-        ctx.n_obj, ctx.beta, ctx.sink = n_obj, float(beta), sink
+        ctx.n_obj, ctx.beta, ctx.sink, ctx.geom = n_obj, float(beta), sink, geom
         ctx.set_materialize_grads(False)          # no zero tensors (one fill launch each) for the outputs nothing differentiates
         ctx.mark_non_differentiable(parts)
         return ll, parts
@@ -234,15 +244,31 @@ class _SceneFn(torch.autograd.Function):
         (nf, seq_frames, seq_stride), n_obj = ctx.frame_map, ctx.n_obj
         dev = frames.device
         if dll is None:
-            return (None,) * 15
+            return (None,) * 16
         dll = _f32(dll)
         with torch.cuda.device(dev):
             dz = torch.empty_like(z)
             grads = [torch.empty_like(x) for x in (oc, ow, orr, bc, bw)]
             g = SpnTableGrads()
             g.obj_coef, g.obj_wsum, g.obj_wroot, g.bg_coef, g.bg_wroot = [ptr(x) for x in grads]
-            ws = _ws(lib.stove_scene_bwd_ws_bytes(nf, n_obj), dev)
             t = _tables(obj=(obj_scope, obj_leaf_slot, oc, ow, orr), bg=(bg_side, bc, bw))
+            if ctx.geom is not None:
+                W, H, ac = ctx.geom
+                ws = _ws(lib.stove_scene_bwd_ws_bytes_any(nf, n_obj, W * H), dev)
+                overlap = ctx.sink is not None and os.environ.get('STOVE_NO_OVERLAP', '0') != '1'
+                main, side = torch.cuda.current_stream(dev), (_side_stream(dev) if overlap else None)
+                check(lib.stove_scene_bwd_any(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, W, H, int(ac),
+                                              ctx.beta, ptr(saved), ptr(dll), ptr(dz), ctypes.byref(g), ptr(ws), main.cuda_stream,
+                                              side.cuda_stream if overlap else None), 'stove_scene_bwd_any')
+                if overlap:
+                    run_on_side(dev, lambda: ctx.sink(grads), (ws, saved, *grads), after_main=False)     # ordered by the C call above
+                    join_side_after_backward(dev)
+                    return (None, dz) + (None,) * 14
+                if ctx.sink is not None:
+                    ctx.sink(grads)
+                    grads = [None] * 5
+                return (None, dz, *grads) + (None,) * 9
+            ws = _ws(lib.stove_scene_bwd_ws_bytes(nf, n_obj), dev)
             if ctx.sink is not None and os.environ.get('STOVE_NO_OVERLAP', '0') != '1':
                 # Flat-arena path: the table gradients only feed the optimiser.  Their passes (and the arena sink) go to a
                 # second stream and overlap with what autograd enqueues next on this one: the recursion's backward,
@@ -254,13 +280,13 @@ class _SceneFn(torch.autograd.Function):
                       'stove_scene_bwd_overlap')
                 run_on_side(dev, lambda: ctx.sink(grads), (ws, saved, *grads), after_main=False)     # ordered by the C call above
                 join_side_after_backward(dev)
-                return (None, dz, None, None, None, None, None, None, None, None, None, None, None, None, None)
+                return (None, dz) + (None,) * 14
             check(lib.stove_scene_bwd(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, ctx.beta,
                                       ptr(saved), ptr(dll), ptr(dz), ctypes.byref(g), ptr(ws), stream()), 'stove_scene_bwd')
         if ctx.sink is not None:               # flat parameter arena: table gradients go straight into the bucket
             ctx.sink(grads)
             grads = [None] * 5
-        return (None, dz, *grads, None, None, None, None, None, None, None, None)
+        return (None, dz, *grads) + (None,) * 9
 
 
 def objspn_apply(inputs, marg, coef, wsum, wroot, scope, leaf_slot):
@@ -305,16 +331,18 @@ def render_frames(bg, patches, frames_per_patch, z, n_obj):
     return out
 
 
-def scene_likelihood(frames, z, obj_tabs, bg_tabs, n_obj, beta, sink=None):
+def scene_likelihood(frames, z, obj_tabs, bg_tabs, n_obj, beta, sink=None, geom=None):
     """frames (nf,1024), z (nf*n_obj,4)=[sx,sy,x,y]; obj_tabs=(coef,wsum,wroot,scope,leaf_slot),
     bg_tabs=(coef,wroot,side[,dense]) -> ll (nf,), parts (nf,3)=(bg, patches, overlap).
-    `sink(table_grads)`: receives the five table gradients in backward instead of autograd (ParamArena)."""
+    `sink(table_grads)`: receives the five table gradients in backward instead of autograd (ParamArena).
+    `geom` = (W, H, align_corners): frames of W*H pixels / the other sampling convention (stove_scene_fwd_any); None = 32 x 32, False."""
     oc, ow, orr, osc, ols = obj_tabs
     bc, bw, bs = bg_tabs[:3]
     dense = bg_tabs[3] if len(bg_tabs) > 3 else None      # ParamArena: made with the bake, ahead of the scene chain
     if sink is not None and not z.requires_grad and torch.is_grad_enabled():
         z = z.detach().requires_grad_()        # the sink needs the backward to run
-    return _SceneFn.apply(frames, z, oc, ow, orr, bc, bw, osc, ols, bs, int(n_obj), float(beta), sink, dense, torch.is_grad_enabled())
+    return _SceneFn.apply(frames, z, oc, ow, orr, bc, bw, osc, ols, bs, int(n_obj), float(beta), sink, dense, torch.is_grad_enabled(),
+                          geom)
 
 
 def scene_glimpses(frames, z, n_obj):

@@ -8,6 +8,7 @@ every SPN parameter.  The stand-alone `patches_from_z` / `masks_from_z` API meth
 plots, appearance embedding; not on the hot path) stay PyTorch-ROCm host code.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -43,11 +44,15 @@ class Supair(nn.Module):
         """
         if self.c.channels != 1 or self.c.patch_width != 10 or self.c.patch_height != 10:
             raise NotImplementedError('SPN kernels are built for single-channel frames and 10x10 glimpses')
+        geom = None
         if x.shape[-1] != 32 or x.shape[-2] != 32 or bool(getattr(self.c, 'align_corners', False)):
             # [amd] any other frame size (the reference's stock gravity / multibilliards data are 50 x 50, envs.py:771-773, 841-844)
-            # and the torch-1.0.1 sampling convention (align_corners=True): the reference's own op sequence with the two SPNs on
-            # their HIP operators; the fused scene pipeline below is laid out for 32 x 32 frames sampled with align_corners=False
-            return self._likelihood_general(x, z_obj, log_from)
+            # and the torch-1.0.1 sampling convention (align_corners=True): the same fused pipeline with the geometry at run time and
+            # the general-size background operator (stove_scene_fwd_any).  STOVE_SCENE_COMPOSED=1: the reference's own op sequence
+            # on ATen's sampler instead (_likelihood_general, the cross-check of the tests; ~10x slower).
+            if os.environ.get('STOVE_SCENE_COMPOSED', '0') == '1':
+                return self._likelihood_general(x, z_obj, log_from)
+            geom = (int(x.shape[-1]), int(x.shape[-2]), bool(getattr(self.c, 'align_corners', False)))
         frames = x.flatten(start_dim=2)                 # (n, T', 1024) view: a time-slice of longer clips is NOT copied (ops._SceneFn)
         arena = getattr(self, '_arena', None)
         if arena is not None and arena.has_spn:         # flat parameter arena: one bake launch, gradients sunk
@@ -56,7 +61,7 @@ class Supair(nn.Module):
         else:
             obj_tabs, bg_tabs, sink = self.obj_spn.tables(), self.bg_spn.tables(), None
         log_p_xz, parts = ops.scene_likelihood(
-            frames, z_obj.reshape(-1, 4), obj_tabs, bg_tabs, self.c.num_obj, self.c.overlap_beta, sink)
+            frames, z_obj.reshape(-1, 4), obj_tabs, bg_tabs, self.c.num_obj, self.c.overlap_beta, sink, geom)
         if ((self.step_counter % self.c.print_every == 0)
                 or (self.step_counter % self.c.plot_every == 0)):
             if self.c.debug:

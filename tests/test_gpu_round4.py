@@ -162,9 +162,13 @@ def test_background_spn_operator_over_any_number_of_dimensions(side, n):
 WIDE = {'res50': dict(width=50, height=50), 'ac32': dict(align_corners=True)}
 
 
+@pytest.mark.parametrize('composed', [False, True])
 @pytest.mark.parametrize('name', list(WIDE))
-def test_likelihood_beyond_the_32x32_contract(name):
+def test_likelihood_beyond_the_32x32_contract(name, composed, monkeypatch):
+    """composed=False: the fused pipeline with run-time geometry (stove_scene_fwd_any / _bwd_any); True: the reference's op
+    sequence on ATen's sampler + the HIP SPN operators (Supair._likelihood_general), both against the reference's own numbers."""
     from stove_amd.video_prediction.supair import Supair
+    monkeypatch.setenv('STOVE_SCENE_COMPOSED', '1' if composed else '0')
     g = load_golden(f'g13_likelihood_{name}_f64')
     sup = fill_analytic(Supair(_cfg(**WIDE[name])), 'sup.').to(DEV)
     sup.step_counter = 0
@@ -185,6 +189,46 @@ def test_likelihood_beyond_the_32x32_contract(name):
         elif k.startswith('g_'):
             check('wide.grad_tensor', err(params[k[2:]].grad, v), 3e-4)
     assert n > 10
+
+
+@pytest.mark.parametrize('shape', [(50, 50, False, 3), (40, 28, False, 3), (28, 40, True, 5), (64, 64, True, 8), (32, 32, True, 6)])
+def test_fused_scene_of_any_geometry_against_the_oracle(shape):
+    """Frames that are not square, more objects than the goldens hold, both conventions: the fused any-size pipeline against the
+    float64 oracle on the same seeded inputs (the oracle itself is pinned on 50 x 50 / align_corners goldens of the reference,
+    tests/test_oracle_goldens.py), a time-slice of longer clips handed over as a view, and two runs bit for bit."""
+    from stove_amd.video_prediction.supair import Supair
+    h, w, ac, n_obj = shape              # frames (.., c, width, height): the last dimension is grid_sample's x
+    c = _cfg(width=h, height=w, align_corners=ac, num_obj=n_obj)
+    sup = fill_analytic(Supair(c), 'sup.').to(DEV)
+    sup.step_counter = 1
+    gen = torch.Generator().manual_seed(100 + h + w)
+    n, T = 3, 4
+    x = torch.rand(n, T + 1, 1, h, w, generator=gen)
+    z = torch.empty(n * T * n_obj, 4)
+    z[:, 0] = 0.12 + 0.3 * torch.rand(z.shape[0], generator=gen)
+    z[:, 1] = z[:, 0] * (0.8 + 0.4 * torch.rand(z.shape[0], generator=gen))
+    z[:, 2:] = 1.9 * torch.rand(z.shape[0], 2, generator=gen) - 0.95            # some glimpses hang over the frame's edge
+    wgt = torch.randn(n * T, generator=gen)
+    xs = x.to(DEV)[:, 1:]                                                           # a view with a sequence stride
+    zd = z.to(DEV).requires_grad_()
+    lp, _ = sup.likelihood(xs, zd)
+    (lp * wgt.to(DEV)).sum().backward()
+    cfg, structs, params = oracle_setup(torch.float64, num_obj=n_obj, width=h, height=w, align_corners=ac)
+    params = {k: v for k, v in params.items() if k.startswith('sup.')}
+    z64 = z.double().requires_grad_()
+    ref = O.scene_likelihood(cfg, params, structs, x[:, 1:].double(), z64)
+    (ref * wgt.double()).sum().backward()
+    check('any.log_p', err(lp, ref), 6e-6)
+    check_grad('any.dz', zd.grad, z64.grad, 3e-4, 3e-4, 5e-3)
+    got = dict(sup.named_parameters())
+    for k, v in params.items():
+        if v.grad is not None and float(v.grad.abs().max()) > 0:
+            check_grad('any.grad', got[k[4:]].grad, v.grad, 3e-4, 3.5e-4, 1.5e-2)
+    g1 = zd.grad.clone()
+    zd.grad = None
+    lp2, _ = sup.likelihood(xs, zd)
+    (lp2 * wgt.to(DEV)).sum().backward()
+    assert torch.equal(lp, lp2) and torch.equal(g1, zd.grad)
 
 
 @pytest.mark.parametrize('name', list(WIDE))
