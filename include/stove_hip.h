@@ -442,7 +442,8 @@ int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* ex
  * accumulation (~2^-16 relative per product); nsplit = 1: plain bf16 operands (2^-8), fp32 accumulate.  A, B, bias, C stay fp32.
  * splitk > 1: K is cut into `splitk` slices computed by different workgroups into ws (stove_gemm_bf16_ws_floats floats), then
  * summed in slice order into C (needs ldc == N, bias and add NULL): fills the chip when M x N is small and K huge (weight gradients).
- * tile: workgroup tile, 0 = chosen by the library, 1 = 256 x 128 (8 waves), 2 = 128 x 128 (4 waves).
+ * tile: workgroup tile, 0 = chosen by the library, 1 = 256 x 128 (8 waves), 2 = 128 x 128 (4 waves), 3 = 256 x 256 (8 waves of
+ * 64 x 128; needs 136 KB of LDS: one workgroup per CU).
  * Operands / outputs whose leading dimension, contiguous extent or base address is not a multiple of 4 floats (fc1 of the
  * recognition network: 50 columns) are handled element-wise (slow path, meant for small operands); split-K needs an aligned C and
  * takes no add, except add == C: the product is accumulated into C (a gradient view); a bias is allowed with 2..15 slices (added by

@@ -1326,7 +1326,9 @@ class _EncoderLstmFn(torch.autograd.Function):
             for k in range(num_steps):
                 gs = gx
                 if k > 0 and ns:
-                    gs = gemm_bf16(hs[k - 1], w_hh, nsplit=ns, splitk=1, add=gx, tile=2)      # K = 256: the 128 x 128 tile (8 k-steps, 1600 workgroups) wins
+                    # K = 256 (8 k-steps): the 128 x 128 tile (1600 workgroups) beats 256 x 128; the 256 x 256 tile is level with it
+                    # warm and 5 % ahead from cold caches
+                    gs = gemm_bf16(hs[k - 1], w_hh, nsplit=ns, splitk=1, add=gx, tile=3 if (GEMM_WIDE and (4 * H) % 256 == 0) else 2)
                 elif k > 0:
                     with _blas('hipblas'):
                         gs = torch.addmm(gx, hs[k - 1], w_hh.t())
@@ -1359,6 +1361,12 @@ class _EncoderLstmFn(torch.autograd.Function):
         def wgrad(dy, inp, out=None):
             """dy^T @ inp over all rows: both operands are stored K-major for this product."""
             if ns and gemm_ok(dy.shape[0]):
+                M_, N_, K_ = dy.shape[1], inp.shape[1], dy.shape[0]
+                wide_tiles = (M_ // 256) * (N_ // 256)
+                if GEMM_WIDE and M_ % 256 == 0 and N_ % 256 == 0 and 8 <= wide_tiles <= 128 and K_ // (256 // wide_tiles) >= 512:
+                    # dW_ih (1024 x 1024 over 25 600 frames): sixteen 256 x 256 tiles x 16 K-slices, 147 us from cold caches
+                    # against 192 for thirty-two 256 x 128 tiles x 8 (tools/gemm_tile_ab.py, GEMM_COLD=1)
+                    return gemm_bf16(dy, inp, None, True, True, ns, splitk=256 // wide_tiles, out=out, tile=3)
                 return gemm_bf16(dy, inp, None, True, True, ns, out=out)
             return _splitk_tn(dy, inp)
 
@@ -1472,11 +1480,18 @@ def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=
     return c
 
 
+GEMM_WIDE = os.environ.get('STOVE_GEMM_WIDE', '1') != '0'      # A/B switch of the 256 x 256 tile for the input projection
+
+
 def _gemm_rows_balanced(x, w, bias, ns):
     """x W^T + bias for a tall x on the 256 x 128 tile.  The tile count is rarely a multiple of the CU count (25 600 frames:
     800 tiles on 256 CUs = three full rounds and 32 tiles that keep an eighth of the chip busy for a fourth); the rows of the
     incomplete round go through a second launch that splits K eight ways instead (256 short workgroups)."""
     M, N = x.shape[0], w.shape[0]
+    if GEMM_WIDE and N % 256 == 0 and M >= 4096 and x.shape[1] >= 512:
+        # 256 x 256 workgroup tile (eight waves of 64 x 128): 2/3 of the operand bytes per flop through L2 and LDS, half the
+        # barriers; 25 600 x 1024 x 1024 isolated 183 us against 229 (256 x 128) / 211 (128 x 128), profiles/r04_gemm_tiles.txt
+        return gemm_bf16(x, w, bias=bias, nsplit=ns, splitk=1, tile=3)
     cus = torch.cuda.get_device_properties(x.device).multi_processor_count
     tiles_n = (N + 127) // 128
     tiles_m = (M + 255) // 256

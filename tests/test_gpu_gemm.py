@@ -15,10 +15,11 @@ def _ref(a, b, bias, ak, bk):
     return c + bias.double() if bias is not None else c
 
 
+@pytest.mark.parametrize('tile', [0, 3])          # 0: chosen from the shape (256 x 128 / 128 x 128); 3: 256 x 256, eight waves of 64 x 128
 @pytest.mark.parametrize('ak,bk', [(False, False), (False, True), (True, True), (True, False)])
 @pytest.mark.parametrize('M,N,K,splitk', [(256, 128, 32, 1), (512, 256, 96, 1), (300, 132, 100, 1), (20, 1024, 1024, 1),
                                             (1024, 256, 3000, 8), (64, 64, 4, 3), (260, 256, 20000, 32)])
-def test_gemm_layouts_and_edges(ak, bk, M, N, K, splitk):
+def test_gemm_layouts_and_edges(ak, bk, M, N, K, splitk, tile):
     from stove_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     a = torch.randn((K, M) if ak else (M, K), generator=g).to(DEV)
@@ -27,23 +28,24 @@ def test_gemm_layouts_and_edges(ak, bk, M, N, K, splitk):
     ref = _ref(a, b, bias, ak, bk)
     scale = float(ref.abs().max())
     for nsplit, tol in ((2, 1.5e-5), (1, 2e-2)):
-        c = ops.gemm_bf16(a, b, bias, ak, bk, nsplit, splitk)
+        c = ops.gemm_bf16(a, b, bias, ak, bk, nsplit, splitk, tile=tile)
         err = float((c.double() - ref).abs().max()) / scale
         assert err < tol, (nsplit, err)
 
 
+@pytest.mark.parametrize('tile', [0, 3])
 @pytest.mark.parametrize('ak,bk', [(False, False), (False, True), (True, True), (True, False)])
-def test_gemm_exact_on_small_integers(ak, bk):
+def test_gemm_exact_on_small_integers(ak, bk, tile):
     """bf16 holds integers up to 256 exactly and fp32 accumulation of such products is exact: any wrong lane / k map shows
     as a non-zero difference.  B is asymmetric (not a function of |row - col| or row + col)."""
     from stove_amd import ops
-    M, N, K = 256 + 16, 128 + 4, 64 + 8
+    M, N, K = 256 + 16, (256 if tile >= 3 else 128) + 4, 64 + 8
     m, n, k = torch.arange(M).view(-1, 1), torch.arange(N).view(-1, 1), torch.arange(K).view(1, -1)
     a = ((m * 3 + k * 5) % 17 - 8).float()
     b = ((n * 7 + k * 11 + (n * k) % 5) % 13 - 6).float()
     at, bt = (a.t().contiguous() if ak else a), (b.t().contiguous() if bk else b)
     for nsplit in (1, 2):
-        c = ops.gemm_bf16(at.to(DEV), bt.to(DEV), None, ak, bk, nsplit, 1)
+        c = ops.gemm_bf16(at.to(DEV), bt.to(DEV), None, ak, bk, nsplit, 1, tile=tile)
         assert torch.equal(c.cpu(), a @ b.t())
 
 
