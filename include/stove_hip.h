@@ -126,6 +126,27 @@ int stove_scene_bwd(const StoveSpnTables* t, const float* frames, const float* z
 int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
                     int seq_stride, float overlap_beta, const float* saved, const float* dll, float* dz, StoveSpnTableGrads* g,
                     void* ws, void* stream, void* param_stream);
+/* ---- RatSpn.forward / backward of the OBJECT SPN for any glimpse size and vector widths (reference probabilistic_models.py:8-22
+ * with config.patch_width / patch_height / obj_spn_num_gauss / obj_spn_num_sums other than 10 / 10 / 10 / 10, config.py:99-100,
+ * 119-120; the entry points above are the tuned kernels of the default shape).  R replicas (children of the root sum), each the
+ * product of two sum vectors of S nodes over the G x G product of two Gaussian leaves; D dimensions, leaves of up to Lmax pixels.
+ *   lscope (R*4, Lmax) int32: pixels of leaf (r, 2 j + side), padded with -1;   slot (R, D) int32: l * Lmax + i of pixel p in replica r
+ *   coef (R*4, Lmax, G, 3) = (a, b, c) per pixel and component;  wsum (R*2, G*G, S) softmaxed over G*G;  wroot (R, S*S) softmaxed
+ * marg NULL = nothing marginalised.  saved: stove_objspn_saved_floats_any floats; ws: stove_objspn_bwd_ws_bytes_any bytes.
+ * d_inputs / d_marg may be NULL; g_* are overwritten.  Limits: R <= 8, G, S <= 16, D <= 1024. */
+size_t stove_objspn_saved_floats_any(int n, int R, int G, int S, int D, int Lmax);
+size_t stove_objspn_bwd_ws_bytes_any(int n, int R, int G, int S, int D, int Lmax);
+int stove_objspn_fwd_any(const float* inputs, const float* marg, const int* lscope, const float* coef, const float* wsum,
+                         const float* wroot, float* saved, float* out, int n, int R, int G, int S, int D, int Lmax, void* stream);
+int stove_objspn_bwd_any(const float* inputs, const float* marg, const int* lscope, const int* slot, const float* coef,
+                         const float* wsum, const float* wroot, const float* saved, const float* dout, float* d_inputs,
+                         float* d_marg, float* g_coef, float* g_wsum, float* g_wroot, void* ws, int n, int R, int G, int S, int D,
+                         int Lmax, void* stream);
+/* ---- the reference's fixed-Gaussian debug models (SimpleBG / SimpleObj, probabilistic_models.py:42-90; config.debug_bg_model /
+ * debug_obj_spn): out[r] = sum_p (1 - marg[r][p]) log Normal(mean, scale)(x[r][p]), marg unclamped as there; dx / dm may be NULL. */
+int stove_gauss_ll_fwd(const float* x, const float* marg, float* out, int n, int d, float mean, float scale, void* stream);
+int stove_gauss_ll_bwd(const float* x, const float* marg, const float* dout, float* dx, float* dm, int n, int d, float mean, float scale,
+                       void* stream);
 /* The same likelihood for any frame size and either sampling convention of the spatial transformer (reference supair.py:44-110 with
  * config width/height != 32 -- the reference's stock gravity / multibilliards data are 50 x 50, envs.py:771-773 -- or the
  * torch-1.0.1 convention align_corners=True its published runs used).  frames: rows of W*H floats (W = the size of the last

@@ -645,12 +645,70 @@ def g13_wide():
                  recon=rec.to(torch.float32), **props, **gnorm, **small)
 
 
+def g14_spn_shapes():
+    """Supair.likelihood with an object SPN of another shape: 8 x 12 glimpses, 7 Gaussians per leaf, 5 sums per inner region
+    (config.patch_width / patch_height / obj_spn_num_gauss / obj_spn_num_sums, reference config.py:99-100, 119-120), and the
+    RatSpn operator itself on random inputs with out-of-range marginalisation.  float64."""
+    dtype, tag = torch.float64, 'f64'
+    kw = dict(patch_width=8, patch_height=12, obj_spn_num_gauss=7, obj_spn_num_sums=5)
+    c = ref_config(dtype, num_obj=3, **kw)
+    c.debug = True
+    sup = Supair(c)
+    fill(sup, 'sup.')
+    g = torch.Generator().manual_seed(14)
+    # the operator
+    n, d = 37, 96
+    xin = torch.rand(n, d, generator=g, dtype=torch.float64).to(dtype).requires_grad_()
+    marg = (torch.rand(n, d, generator=g, dtype=torch.float64) * 1.4 - 0.2).to(dtype).requires_grad_()
+    out = sup.obj_spn.forward(xin, marg)
+    w = torch.linspace(0.5, 1.5, n, dtype=dtype)
+    (out[:, 0] * w).sum().backward()
+    og = {f'og_{k}': p.grad.clone() for k, p in sup.obj_spn.named_parameters() if p.grad is not None and p.numel() <= 2000}
+    ogn = {f'ogn_{k}': p.grad.norm() for k, p in sup.obj_spn.named_parameters() if p.grad is not None}
+    save(f'g14_objspn_8x12_{tag}', x=xin, marg=marg, out=out, w=w, gx=xin.grad, gmarg=marg.grad, **og, **ogn)
+    sup.zero_grad()
+    # the likelihood
+    n, t = 2, 3
+    x = (torch.rand(n, t, 1, 32, 32, generator=g, dtype=torch.float64) ** 3).to(dtype)
+    z = crafted_z(n * t, 3, g, dtype).flatten(end_dim=1).requires_grad_()
+    sup.step_counter = 0
+    lp, prop = sup.likelihood(x, z)
+    w = torch.linspace(0.5, 1.5, n * t, dtype=dtype)
+    (lp * w).sum().backward()
+    grads = {f'gn_{k}': p.grad.norm() for k, p in sup.named_parameters() if p.grad is not None}
+    small = {f'g_{k}': p.grad for k, p in sup.named_parameters() if p.grad is not None and p.numel() <= 700}
+    save(f'g14_likelihood_8x12_{tag}', x=x, z=z, log_p=lp, w=w, gz=z.grad, bg=prop['bg'], patch=prop['patch'],
+         overlap=prop['overlap'], **grads, **small)
+
+
+def g15_simple_models():
+    """Supair.likelihood with the reference's fixed-Gaussian debug models (config.debug_bg_model / debug_obj_spn,
+    supair.py:33-42, probabilistic_models.py:42-90): both on, and each on beside the other SPN.  float64."""
+    dtype, tag = torch.float64, 'f64'
+    for name, kw in (('both', dict(debug_bg_model=True, debug_obj_spn=True)), ('bg', dict(debug_bg_model=True)), ('obj', dict(debug_obj_spn=True))):
+        c = ref_config(dtype, num_obj=3, **kw)
+        c.debug = True
+        sup = Supair(c)
+        fill(sup, 'sup.')
+        g = torch.Generator().manual_seed(15)
+        n, t = 2, 3
+        x = (torch.rand(n, t, 1, 32, 32, generator=g, dtype=torch.float64) ** 3).to(dtype)
+        z = crafted_z(n * t, 3, g, dtype).flatten(end_dim=1).requires_grad_()
+        sup.step_counter = 0
+        lp, prop = sup.likelihood(x, z)
+        w = torch.linspace(0.5, 1.5, n * t, dtype=dtype)
+        (lp * w).sum().backward()
+        grads = {f'gn_{k}': p.grad.norm() for k, p in sup.named_parameters() if p.grad is not None}
+        save(f'g15_likelihood_simple_{name}_{tag}', x=x, z=z, log_p=lp, w=w, gz=z.grad, bg=prop['bg'], patch=prop['patch'],
+             overlap=prop['overlap'], **grads)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7', 'g6b', 'g11', 'g9', 'g12', 'g13']
+    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7', 'g6b', 'g11', 'g9', 'g12', 'g13', 'g14', 'g15']
     os.makedirs(OUT, exist_ok=True)
     table = {'g0': g0_envs, 'g1': g1_structures, 'g2': g2_ratspn, 'g3': g3_masks_glimpses,
              'g4': g4_likelihood, 'g5': g5_dynamics, 'g6': g6_matchers, 'g10': g10_units, 'g7': g7_g8_full,
-             'g6b': g6b_volatile, 'g11': g11_supair_only, 'g9': g9_optimiser_steps, 'g12': g12_reconstruct, 'g13': g13_wide}
+             'g6b': g6b_volatile, 'g11': g11_supair_only, 'g9': g9_optimiser_steps, 'g12': g12_reconstruct, 'g13': g13_wide, 'g14': g14_spn_shapes, 'g15': g15_simple_models}
     for k in which:
         torch.manual_seed(0)
         np.random.seed(0)

@@ -47,6 +47,7 @@ def default_config(**overrides):
         transition_lik_std=[0.01, 0.01, 0.01, 0.01],
         debug_latent_q_std=0.04, debug_nonlinear='relu',
         debug_fix_supair=True, debug_match_objects='3_only',
+        debug_bg_model=False, debug_obj_spn=False, debug_simple_bg_var=0.1, debug_simple_obj_var=0.2,
         debug_match_appearance=False, debug_core_appearance=False,
         debug_appearance_dim=3, debug_bw=True,
         action_conditioned=False, action_space=None,
@@ -329,16 +330,30 @@ def masks_from_z(c, z_img):
     return marg.flatten(0, 1), bg, overlap
 
 
+def simple_gauss(x, marg, mean, scale):
+    """SimpleBG / SimpleObj.forward, probabilistic_models.py:42-90: Normal(mean, scale).log_prob per pixel, weighted by
+    (1 - marg) as it comes (no clamp), summed per row -> (B, 1).  (`scale` is what the reference calls var.)"""
+    lp = -(x - mean) ** 2 / (2.0 * scale * scale) - math.log(scale) - 0.5 * LOG_2PI
+    return (lp * (1.0 - marg)).sum(1, keepdim=True)
+
+
 def scene_likelihood(c, params, structs, x, z_obj, parts=False):
-    """Supair.likelihood, supair.py:44-110.  x (n,T',ch,H,W), z_obj (n*T'*N,4) [sx,sy,x,y] -> (n*T',)."""
+    """Supair.likelihood, supair.py:44-110.  x (n,T',ch,H,W), z_obj (n*T'*N,4) [sx,sy,x,y] -> (n*T',).
+    config.debug_bg_model / debug_obj_spn (supair.py:33-42): the fixed-Gaussian models instead of the SPNs."""
     x_img = x.flatten(0, 1)
     z_img = z_obj.view(-1, c.num_obj, 4)
     marg_patch, marg_bg, overlap = masks_from_z(c, z_img)
-    bg_ll = spn_forward(structs['bg'], params, 'sup.bg_spn.', x_img.flatten(1), marg_bg.flatten(1),
-                        6, 3, c.bg_min_var, c.bg_max_var)[:, 0]
+    if getattr(c, 'debug_bg_model', False):
+        bg_ll = simple_gauss(x_img.flatten(1), marg_bg.flatten(1), 0.0, c.debug_simple_bg_var)[:, 0]
+    else:
+        bg_ll = spn_forward(structs['bg'], params, 'sup.bg_spn.', x_img.flatten(1), marg_bg.flatten(1),
+                            6, 3, c.bg_min_var, c.bg_max_var)[:, 0]
     patches = glimpses(c, x_img, z_obj)
-    p_ll = spn_forward(structs['obj'], params, 'sup.obj_spn.', patches.flatten(1), marg_patch.flatten(1),
-                       c.obj_spn_num_gauss, c.obj_spn_num_sums, c.obj_min_var, c.obj_max_var)[:, 0]
+    if getattr(c, 'debug_obj_spn', False):
+        p_ll = simple_gauss(patches.flatten(1), marg_patch.flatten(1), 0.8, c.debug_simple_obj_var)[:, 0]
+    else:
+        p_ll = spn_forward(structs['obj'], params, 'sup.obj_spn.', patches.flatten(1), marg_patch.flatten(1),
+                           c.obj_spn_num_gauss, c.obj_spn_num_sums, c.obj_min_var, c.obj_max_var)[:, 0]
     p_ll = (p_ll * z_obj[:, 0] * z_obj[:, 1]).view(-1, c.num_obj).sum(1)
     # Exponential(beta).log_prob(r) = log(beta) - beta r   (supair.py:84-85)
     ov_ll = (math.log(c.overlap_beta) - c.overlap_beta * overlap).sum(1)

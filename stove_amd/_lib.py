@@ -25,7 +25,7 @@ EXPORTS = [
     'stove_bw_transform_u8', 'stove_stream_after', 'stove_capture_begin', 'stove_capture_end', 'stove_graph_instantiate', 'stove_graph_launch', 'stove_graph_destroy',
     'stove_reward_head_param_floats', 'stove_reward_head_saved_floats', 'stove_reward_head_bwd_ws_floats', 'stove_reward_head_fwd',
     'stove_bgspn_saved_floats_d', 'stove_bgspn_fwd_d', 'stove_bgspn_bwd_ws_bytes_d', 'stove_bgspn_bwd_d', 'stove_noise_normal', 'stove_set_overlap', 'stove_set_tablegrad_placement', 'stove_event_list_begin', 'stove_event_list_end', 'stove_event_list_destroy', 'stove_fill_words',
-    'stove_reward_head_bwd', 'stove_small_linear', 'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_fwd_floats', 'stove_scene_saved_floats_any', 'stove_scene_bwd_ws_bytes_any', 'stove_scene_fwd_any', 'stove_scene_bwd_any', 'stove_scene_bwd_from', 'stove_dynloop_range_ok', 'stove_dynloop_fwd_range', 'stove_dynloop_bwd_range', 'stove_zall_fwd_range', 'stove_zall_bwd_range',
+    'stove_reward_head_bwd', 'stove_small_linear', 'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_fwd_floats', 'stove_gauss_ll_fwd', 'stove_gauss_ll_bwd', 'stove_objspn_saved_floats_any', 'stove_objspn_bwd_ws_bytes_any', 'stove_objspn_fwd_any', 'stove_objspn_bwd_any', 'stove_scene_saved_floats_any', 'stove_scene_bwd_ws_bytes_any', 'stove_scene_fwd_any', 'stove_scene_bwd_any', 'stove_scene_bwd_from', 'stove_dynloop_range_ok', 'stove_dynloop_fwd_range', 'stove_dynloop_bwd_range', 'stove_zall_fwd_range', 'stove_zall_bwd_range',
 ]
 
 
@@ -71,6 +71,12 @@ def _declare(lib):
         'stove_scene_bwd_ws_bytes': (S, [I, I]),
         'stove_scene_bwd': (I, [T, P, P, I, I, I, I, F, P, P, P, G, P, P]),
         'stove_scene_bwd_overlap': (I, [T, P, P, I, I, I, I, F, P, P, P, G, P, P, P]),
+        'stove_gauss_ll_fwd': (I, [P, P, P, I, I, F, F, P]),
+        'stove_gauss_ll_bwd': (I, [P, P, P, P, P, I, I, F, F, P]),
+        'stove_objspn_saved_floats_any': (S, [I, I, I, I, I, I]),
+        'stove_objspn_bwd_ws_bytes_any': (S, [I, I, I, I, I, I]),
+        'stove_objspn_fwd_any': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+        'stove_objspn_bwd_any': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
         'stove_scene_saved_floats_any': (S, [I, I, I, I]),
         'stove_scene_bwd_ws_bytes_any': (S, [I, I, I]),
         'stove_scene_fwd_any': (I, [T, P, P, I, I, I, I, I, I, I, F, P, P, P, P, I]),

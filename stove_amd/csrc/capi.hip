@@ -8,6 +8,7 @@
 #include <math.h>
 #include <atomic>
 #include "spn_obj.hip"
+#include "spn_obj_generic.hip"
 #include "spn_bg.hip"
 #include "spn_bg_generic.hip"
 #include "scene.hip"
@@ -412,6 +413,42 @@ int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const flo
     if (rc) return rc;
   }
   jp.dismiss();
+  return 0;
+}
+
+// ---------------------------------------------------------------- object RAT-SPN operator, any glimpse size / vector widths
+static ObjAnyShape obj_any_shape(int R, int G, int S, int D, int Lmax) {
+  ObjAnyShape sh;
+  sh.R = R; sh.G = G; sh.S = S; sh.D = D; sh.Lmax = Lmax;
+  return sh;
+}
+size_t stove_objspn_saved_floats_any(int n, int R, int G, int S, int D, int Lmax) { return objany_saved_floats(n, obj_any_shape(R, G, S, D, Lmax)); }
+size_t stove_objspn_bwd_ws_bytes_any(int n, int R, int G, int S, int D, int Lmax) { return objany_bwd_ws_floats(n, obj_any_shape(R, G, S, D, Lmax)) * sizeof(float); }
+int stove_objspn_fwd_any(const float* inputs, const float* marg, const int* lscope, const float* coef, const float* wsum, const float* wroot,
+                         float* saved, float* out, int n, int R, int G, int S, int D, int Lmax, void* stream) {
+  return objany_forward(inputs, marg, lscope, coef, wsum, wroot, saved, out, n, obj_any_shape(R, G, S, D, Lmax), (hipStream_t)stream);
+}
+int stove_objspn_bwd_any(const float* inputs, const float* marg, const int* lscope, const int* slot, const float* coef, const float* wsum,
+                         const float* wroot, const float* saved, const float* dout, float* d_inputs, float* d_marg, float* g_coef,
+                         float* g_wsum, float* g_wroot, void* ws, int n, int R, int G, int S, int D, int Lmax, void* stream) {
+  return objany_backward(inputs, marg, lscope, slot, coef, wsum, wroot, saved, dout, d_inputs, d_marg, g_coef, g_wsum, g_wroot, (float*)ws, n,
+                         obj_any_shape(R, G, S, D, Lmax), (hipStream_t)stream);
+}
+
+int stove_gauss_ll_fwd(const float* x, const float* marg, float* out, int n, int d, float mean, float scale, void* stream) {
+  if (n == 0) return 0;
+  if (d < 1 || !(scale > 0.0f) || x == nullptr || marg == nullptr || out == nullptr) return (int)hipErrorInvalidValue;
+  STOVE_LAUNCH(gauss_ll_fwd_k, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, marg, out, n, d, mean, scale);
+  STOVE_LAUNCH_CHECK();
+  return 0;
+}
+int stove_gauss_ll_bwd(const float* x, const float* marg, const float* dout, float* dx, float* dm, int n, int d, float mean, float scale,
+                       void* stream) {
+  if (n == 0) return 0;
+  if (d < 1 || !(scale > 0.0f) || x == nullptr || marg == nullptr || dout == nullptr) return (int)hipErrorInvalidValue;
+  const size_t tot = (size_t)n * d;
+  STOVE_LAUNCH(gauss_ll_bwd_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, marg, dout, dx, dm, n, d, mean, scale);
+  STOVE_LAUNCH_CHECK();
   return 0;
 }
 

@@ -289,6 +289,82 @@ class _SceneFn(torch.autograd.Function):
         return (None, dz, *grads) + (None,) * 9
 
 
+class _ObjSpnAnyFn(torch.autograd.Function):
+    """RatSpn.forward of the object SPN for any glimpse size / vector widths (csrc/spn_obj_generic.hip; reference
+    rat_torch.py:354-357 with probabilistic_models.py:8-22 at non-default config.patch_* / obj_spn_num_*)."""
+
+    @staticmethod
+    def forward(ctx, inputs, marg, coef, wsum, wroot, lscope, slot, shape):
+        lib = _lib.load()
+        inputs, marg = _f32(inputs), _f32(marg)
+        coef, wsum, wroot = _f32(coef), _f32(wsum), _f32(wroot)
+        R, G, S, D, lmax = shape
+        n, dev = inputs.shape[0], inputs.device
+        if inputs.shape[1] != D or coef.numel() != R * 4 * lmax * G * 3 or wsum.numel() != R * 2 * G * G * S or wroot.numel() != R * S * S:
+            raise ValueError('objspn_any: tables do not match the shape %s' % (shape,))
+        with torch.cuda.device(dev):
+            saved = torch.empty(lib.stove_objspn_saved_floats_any(n, R, G, S, D, lmax) + 1, dtype=torch.float32, device=dev)
+            out = torch.empty(n, dtype=torch.float32, device=dev)
+            check(lib.stove_objspn_fwd_any(ptr(inputs), ptr(marg), ptr(lscope), ptr(coef), ptr(wsum), ptr(wroot), ptr(saved), ptr(out),
+                                           n, R, G, S, D, lmax, stream()), 'stove_objspn_fwd_any')
+        ctx.save_for_backward(inputs, marg, coef, wsum, wroot, lscope, slot, saved)
+        ctx.shape = shape
+        return out.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        inputs, marg, coef, wsum, wroot, lscope, slot, saved = ctx.saved_tensors
+        R, G, S, D, lmax = ctx.shape
+        n, dev = inputs.shape[0], inputs.device
+        dout = _f32(dout.reshape(-1))
+        with torch.cuda.device(dev):
+            d_in = torch.empty_like(inputs) if ctx.needs_input_grad[0] else None
+            d_marg = torch.empty_like(marg) if (marg is not None and ctx.needs_input_grad[1]) else None
+            g_coef, g_wsum, g_wroot = torch.empty_like(coef), torch.empty_like(wsum), torch.empty_like(wroot)
+            ws = _ws(lib.stove_objspn_bwd_ws_bytes_any(n, R, G, S, D, lmax), dev)
+            check(lib.stove_objspn_bwd_any(ptr(inputs), ptr(marg), ptr(lscope), ptr(slot), ptr(coef), ptr(wsum), ptr(wroot), ptr(saved),
+                                           ptr(dout), ptr(d_in), ptr(d_marg), ptr(g_coef), ptr(g_wsum), ptr(g_wroot), ptr(ws),
+                                           n, R, G, S, D, lmax, stream()), 'stove_objspn_bwd_any')
+        return d_in, d_marg, g_coef, g_wsum, g_wroot, None, None, None
+
+
+class _GaussLlFn(torch.autograd.Function):
+    """SimpleBG / SimpleObj.forward (reference probabilistic_models.py:42-90): rows of pixels under one fixed Normal."""
+
+    @staticmethod
+    def forward(ctx, x, marg, mean, scale):
+        lib = _lib.load()
+        x, marg = _f32(x), _f32(marg)
+        n, d = x.shape
+        with torch.cuda.device(x.device):
+            out = torch.empty(n, dtype=torch.float32, device=x.device)
+            check(lib.stove_gauss_ll_fwd(ptr(x), ptr(marg), ptr(out), n, d, float(mean), float(scale), stream()), 'stove_gauss_ll_fwd')
+        ctx.save_for_backward(x, marg)
+        ctx.ms = (float(mean), float(scale))
+        return out.unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, marg = ctx.saved_tensors
+        n, d = x.shape
+        dout = _f32(dout.reshape(-1))
+        with torch.cuda.device(x.device):
+            dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            dm = torch.empty_like(marg) if ctx.needs_input_grad[1] else None
+            check(lib.stove_gauss_ll_bwd(ptr(x), ptr(marg), ptr(dout), ptr(dx), ptr(dm), n, d, ctx.ms[0], ctx.ms[1], stream()), 'stove_gauss_ll_bwd')
+        return dx, dm, None, None
+
+
+def gauss_ll(x, marg, mean, scale):
+    return _GaussLlFn.apply(x, marg, mean, scale)
+
+
+def objspn_any_apply(inputs, marg, coef, wsum, wroot, lscope, slot, shape):
+    return _ObjSpnAnyFn.apply(inputs, marg, coef, wsum, wroot, lscope, slot, tuple(int(v) for v in shape))
+
+
 def objspn_apply(inputs, marg, coef, wsum, wroot, scope, leaf_slot):
     return _ObjSpnFn.apply(inputs, marg, coef, wsum, wroot, scope, leaf_slot)
 

@@ -27,3 +27,29 @@ def _get_bg_spn(c, seed):
     args.gauss_min_sigma = c.bg_min_var
     args.gauss_max_sigma = c.bg_max_var
     return RatSpn(1, region_graph=rg, args=args, name='bg-spn')
+
+
+class _FixedGauss:
+    """The reference's fixed-Gaussian debug models (probabilistic_models.py:42-90): no parameters, every pixel scored under one
+    Normal and weighted by (1 - marg) as it comes; `_kind = 'simple'` sends Supair.likelihood through its composed path."""
+    _kind = 'simple'
+
+    def __init__(self, mean, var):
+        self.mean, self.var = float(mean), float(var)        # `var` is used as the scale of the Normal, as in the reference
+
+    def forward(self, img_flat, marg_flat):
+        """(n, d), (n, d) -> (n, 1) (csrc/spn_obj_generic.hip gauss_ll_fwd_k / _bwd_k)."""
+        from .. import ops
+        return ops.gauss_ll(img_flat, marg_flat, self.mean, self.var)
+
+    __call__ = forward
+
+
+def _get_simple_bg(c):
+    """SimpleBG (config.debug_bg_model): a black background, Normal(0, debug_simple_bg_var)."""
+    return _FixedGauss(0.0, c.debug_simple_bg_var)
+
+
+def _get_simple_obj(c):
+    """SimpleObj (config.debug_obj_spn): white objects, Normal(0.8, debug_simple_obj_var)."""
+    return _FixedGauss(0.8, c.debug_simple_obj_var)

@@ -239,11 +239,51 @@ class RatSpn(nn.Module):
         """Per row of inputs (B, D): the reconstruction along argmax_k(child_k + log w_k) of every sum node, clamped to
         [0, 1] (what Supair.spn_mpe builds from compute_activations(get_sum_child_acts=True) + reconstruct,
         supair.py:407-421).  Object-SPN shape only (one kernel, ops.objspn_mpe)."""
+        if self._kind == 'obj_any':
+            return self._mpe_any(inputs, return_pick)
         if self._kind != 'obj':
             raise NotImplementedError('RatSpn.mpe: gfx950 kernel exists for the object SPN shape only')
         coef, wsum, wroot, scope, leaf_slot = self.tables()
         mu = torch.stack([v.means for v in self.vector_list[0]])[self._plan(coef.device)['leaf_order']]
         return ops.objspn_mpe(inputs, mu.detach(), coef.detach(), wsum.detach(), wroot.detach(), scope, leaf_slot, return_pick)
+
+    @torch.no_grad()
+    def _mpe_any(self, inputs, return_pick=False):
+        """mpe() for the general-size object SPN: the upward pass on the HIP operator (its saved leaf / sum-node values), the
+        downward argmax walk as batched gathers on the device (plot-time only, not part of the training step)."""
+        coef, wsum, wroot, lscope, slot, (R, G, S, D, lmax) = self.tables()
+        lib = ops._lib.load()
+        x = inputs.float().contiguous()
+        n, dev = x.shape[0], x.device
+        with torch.cuda.device(dev):
+            saved = torch.empty(lib.stove_objspn_saved_floats_any(n, R, G, S, D, lmax) + 1, dtype=torch.float32, device=dev)
+            out = torch.empty(n, dtype=torch.float32, device=dev)
+            ops.check(lib.stove_objspn_fwd_any(ops.ptr(x), None, ops.ptr(lscope), ops.ptr(coef), ops.ptr(wsum), ops.ptr(wroot), ops.ptr(saved),
+                                               ops.ptr(out), n, R, G, S, D, lmax, ops.stream()), 'stove_objspn_fwd_any')
+        sv = saved[:n * (R * 4 * G + R * 2 * S + 1)].view(n, -1)
+        ell = sv[:, :R * 4 * G].view(n, R, 2, 2, G)                       # [b][r][j][side][g]
+        s_ = sv[:, R * 4 * G:R * 4 * G + R * 2 * S].view(n, R, 2, S)
+        top = (s_[:, :, 1, :, None] + s_[:, :, 0, None, :]).reshape(n, R * S * S) + torch.log(wroot).reshape(1, -1)      # node k1 * S + k0
+        pick = top.argmax(1)
+        r, k1, k0 = pick // (S * S), (pick % (S * S)) // S, pick % S
+        ar = torch.arange(n, device=dev)
+        rec = torch.zeros(n, D, dtype=torch.float32, device=dev)
+        mu = torch.cat([v.means for v in self.vector_list[0]])[self._plan(dev)['gidx']]                       # (R*4, Lmax, G)
+        picks = [r]
+        for j, k in ((0, k0), (1, k1)):
+            e = ell[ar, r, j]                                                  # (n, 2, G)
+            prod = (e[:, 1, :, None] + e[:, 0, None, :]).reshape(n, G * G)    # node g1 * G + g0
+            child = (prod + torch.log(wsum.view(R, 2, G * G, S)[r, j, :, k])).argmax(1)
+            g1, g0 = child // G, child % G
+            picks += [g0, g1]
+            for side, gsel in ((0, g0), (1, g1)):
+                q = r * 4 + j * 2 + side                                       # leaf row
+                px = lscope[q].long()                                          # (n, Lmax), -1 padded
+                val = mu[q, :, :].gather(2, gsel.view(n, 1, 1).expand(n, lmax, 1))[..., 0]
+                ok = px >= 0
+                rec[ar[:, None].expand_as(px)[ok], px[ok]] = val[ok]
+        rec = rec.clamp(0.0, 1.0)
+        return (rec, torch.stack(picks, 1).int()) if return_pick else rec
 
     # ------------------------------------------------------------------ kernel plan
     def _make_plan(self):
@@ -262,12 +302,13 @@ class RatSpn(nn.Module):
             return
         leaves = list(vl[0])
         leaf_idx = {id(v): i for i, v in enumerate(leaves)}
-        if len(vl) == 5 and self.num_dims == 100 and a.num_gauss == 10 and a.num_sums == 10:
+        tuned = (len(vl) == 5 and self.num_dims == 100 and a.num_gauss == 10 and a.num_sums == 10 and len(root.inputs) == 6
+                 and len(leaves) == 24 and len(vl[2]) == 12 and all(len(v.scope) == 25 for v in leaves)
+                 and not getattr(self, '_no_tuned', False))
+        if tuned:
             sums = list(vl[2])
             sum_idx = {id(v): i for i, v in enumerate(sums)}
             R = len(root.inputs)
-            if R != 6 or len(leaves) != 4 * R or len(sums) != 2 * R:
-                return
             leaf_order, sum_order = [], []
             for prod in root.inputs:                       # replica r = r-th child of the root sum
                 for s in prod.inputs:                      # (in1, in2) = sides 0, 1
@@ -287,6 +328,45 @@ class RatSpn(nn.Module):
             self._plan_cpu = {'scope': scope, 'leaf_slot': slot, 'leaf_order': torch.tensor(leaf_order),
                               'sum_order': torch.tensor(sum_order)}
             self._kind = 'obj'
+        elif len(vl) == 5 and a.num_gauss <= 16 and a.num_sums <= 16 and self.num_dims <= 1024 and len(root.inputs) <= 8:
+            # [amd] the object SPN's structure with any glimpse size / vector widths (config.patch_width / patch_height /
+            # obj_spn_num_gauss / obj_spn_num_sums, reference config.py:99-100, 119-120): the general-size operator of
+            # csrc/spn_obj_generic.hip.  Replica r = r-th child of the root; its leaves in (sum 0: leaf 0, leaf 1; sum 1: leaf 0, leaf 1) order
+            sums = list(vl[2])
+            sum_idx = {id(v): i for i, v in enumerate(sums)}
+            R, D = len(root.inputs), self.num_dims
+            start, off = {}, 0
+            for i, leaf in enumerate(leaves):
+                start[i] = off
+                off += len(leaf.scope)
+            leaf_lists, sum_order = [], []
+            for prod in root.inputs:
+                if len(prod.inputs) != 2:
+                    return
+                for s_ in prod.inputs:
+                    if not isinstance(s_, SumVector) or len(s_.inputs) != 1 or len(s_.inputs[0].inputs) != 2:
+                        return
+                    sum_order.append(sum_idx[id(s_)])
+                    for leaf in s_.inputs[0].inputs:
+                        if not isinstance(leaf, GaussVector):
+                            return
+                        leaf_lists.append(leaf_idx[id(leaf)])
+            lmax = max(len(leaves[i].scope) for i in leaf_lists)
+            lscope = torch.full((R * 4, lmax), -1, dtype=torch.int32)
+            gidx = torch.zeros(R * 4, lmax, dtype=torch.long)
+            slot = torch.full((R, D), -1, dtype=torch.int32)
+            for q, li in enumerate(leaf_lists):
+                r, l = q // 4, q % 4
+                for i, p in enumerate(leaves[li].scope):
+                    lscope[q, i] = p
+                    gidx[q, i] = start[li] + i
+                    slot[r, p] = l * lmax + i
+            if int(slot.min()) < 0:
+                return
+            self._plan_cpu = {'lscope': lscope, 'gidx': gidx, 'slot': slot, 'sum_order': torch.tensor(sum_order),
+                              'pad': (lscope < 0)}
+            self._any_shape = (R, a.num_gauss, a.num_sums, D, lmax)
+            self._kind = 'obj_any'
         elif len(vl) == 3 and a.num_gauss == 6:
             # background SPN over any number of dimensions D (c x w x h: probabilistic_models.py:25-39): three replicas, each a
             # product of two Gaussian leaves that split the D pixels between them (512 / 512 for 32 x 32 frames, 1250 / 1250 for
@@ -312,6 +392,11 @@ class RatSpn(nn.Module):
                 return
             self._plan_cpu = {'side': side, 'gidx': gidx}
             self._kind = 'bg'
+
+    def _force_general_plan(self):
+        """Tests: plan the default object-SPN shape onto the general-size operator instead of the tuned kernels."""
+        self._no_tuned = True
+        self._make_plan()
 
     def _leaf_coef(self, flat=False):
         """(n_leaves, S, G, 3) = (a, b, c) with leaf log-density sum_p w_p (a x^2 + b x + c); flat: leaves of different scope
@@ -339,6 +424,14 @@ class RatSpn(nn.Module):
             wsum = torch.softmax(w, 1)[pl['sum_order']]
             wroot = torch.softmax(self.output_vector.params, 0).view(6, 100)
             return (coef.contiguous(), wsum.contiguous(), wroot.contiguous(), pl['scope'], pl['leaf_slot'])
+        if self._kind == 'obj_any':
+            pl = self._plan(self.output_vector.params.device)
+            R, G, S, D, lmax = self._any_shape
+            coef = self._leaf_coef(flat=True)[pl['gidx']]                                # (R*4, Lmax, G, 3); padded rows: unused
+            w = torch.stack([v.params for v in self.vector_list[2]])                      # (2R, G*G, S)
+            wsum = torch.softmax(w, 1)[pl['sum_order']]
+            wroot = torch.softmax(self.output_vector.params, 0).view(R, S * S)
+            return (coef.contiguous(), wsum.contiguous(), wroot.contiguous(), pl['lscope'], pl['slot'], self._any_shape)
         if self._kind == 'bg':
             pl = self._plan(self.output_vector.params.device)
             coef = self._leaf_coef(flat=True)[pl['gidx']]                                # (3, D, 6, 3)
@@ -346,7 +439,7 @@ class RatSpn(nn.Module):
             return (coef.contiguous(), wroot.contiguous(), pl['side'])
         raise NotImplementedError(
             'RatSpn: no gfx950 kernel for this SPN shape (dims=%d); kernels exist for the STOVE '
-            'object (100-dim, 6x random_split(2,2)) and background (any dims, 3x random_split(2,1), 6 gaussians) SPNs'
+            'object (Nx random_split(2,2), up to 16 gaussians / sums, up to 1024 dims) and background (any dims, 3x random_split(2,1), 6 gaussians) SPNs'
             % self.num_dims)
 
     # ------------------------------------------------------------------ evaluation
@@ -356,6 +449,8 @@ class RatSpn(nn.Module):
         tabs = self.tables()
         if self._kind == 'obj':
             return ops.objspn_apply(inputs, marginalized, *tabs)
+        if self._kind == 'obj_any':
+            return ops.objspn_any_apply(inputs, marginalized, *tabs)
         return ops.bgspn_apply(inputs, marginalized, *tabs)
 
 

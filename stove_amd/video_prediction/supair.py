@@ -28,10 +28,9 @@ class Supair(nn.Module):
         self.step_counter = 0          # set by the calling trainer
         self.prop_dict = {}            # exported metrics
         self.encoder = encoder.RnnStates(self.c)
-        if self.c.debug_obj_spn or self.c.debug_bg_model:
-            raise NotImplementedError('the simple-Gaussian debug models have no gfx950 kernel')
-        self.obj_spn = prob._get_obj_spn(self.c, seed=self.c.random_seed)
-        self.bg_spn = prob._get_bg_spn(self.c, seed=self.c.random_seed)
+        # the fixed-Gaussian debug models of the reference (supair.py:33-42) are plain objects, not sub-modules, as there
+        self.obj_spn = prob._get_simple_obj(self.c) if self.c.debug_obj_spn else prob._get_obj_spn(self.c, seed=self.c.random_seed)
+        self.bg_spn = prob._get_simple_bg(self.c) if self.c.debug_bg_model else prob._get_bg_spn(self.c, seed=self.c.random_seed)
 
     # ------------------------------------------------------------------ likelihood
     def likelihood(self, x, z_obj, log_from=0):
@@ -42,8 +41,13 @@ class Supair(nn.Module):
                 + sum_k log Exponential(overlap_beta)(overlap_k)      (reference supair.py:44-110)
         `log_from` (build addition) restricts the logged part means to frames x[:, log_from:].
         """
-        if self.c.channels != 1 or self.c.patch_width != 10 or self.c.patch_height != 10:
-            raise NotImplementedError('SPN kernels are built for single-channel frames and 10x10 glimpses')
+        if self.c.channels != 1:
+            raise NotImplementedError('SPN kernels are built for single-channel frames')
+        if self.obj_spn._kind != 'obj' or self.bg_spn._kind != 'bg' or self.c.patch_width != 10 or self.c.patch_height != 10:
+            # [amd] other glimpse sizes / SPN vector widths (config.patch_width, patch_height, obj_spn_num_gauss, obj_spn_num_sums): the
+            # reference's op sequence with the general-size SPN operators (csrc/spn_obj_generic.hip, spn_bg_generic.hip); the fused
+            # scene pipeline is instantiated for 10 x 10 glimpses and the default 10 / 10 widths
+            return self._likelihood_general(x, z_obj, log_from)
         geom = None
         if x.shape[-1] != 32 or x.shape[-2] != 32 or bool(getattr(self.c, 'align_corners', False)):
             # [amd] any other frame size (the reference's stock gravity / multibilliards data are 50 x 50, envs.py:771-773, 841-844)
@@ -223,7 +227,7 @@ class Supair(nn.Module):
                 raise ValueError('Need x for reconstructions.')
             z_in, x_in = (z[:, 0], x) if single_image else (z.flatten(end_dim=1), x.flatten(end_dim=1))
             patches, per = self.spn_mpe(z_in, x_in, spn=self.obj_spn), (T if single_image else 1)
-        if (c.width, c.height) == (32, 32) and not bool(getattr(c, 'align_corners', False)):
+        if (c.width, c.height) == (32, 32) and (c.patch_width, c.patch_height) == (10, 10) and not bool(getattr(c, 'align_corners', False)):
             frames = ops.render_frames(bg.float(), patches.float(), per, z.reshape(-1, 4).float(), o)
             return frames.view(n, T, c.channels, c.width, c.height).type(c.dtype)
         # any other frame size / sampling convention: the reference's paste through the inverse transform (supair.py:480-498)

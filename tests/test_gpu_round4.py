@@ -288,3 +288,143 @@ def test_training_on_the_reference_default_gravity_data_50x50(tmp_path):
     assert torch.isfinite(trainer.bucket.data).all() and not torch.equal(before, trainer.bucket.data)
     out = trainer.long_rollout(idx=[0, 1], num=5)
     assert out['frames_rollout'].shape[-2:] == (50, 50) and np.isfinite(out['z_pred']).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# object SPNs of other shapes (VERDICT r03 "what's missing" 2): glimpse sizes and vector widths from the config
+# ---------------------------------------------------------------------------------------------------------------------
+SHAPE_8x12 = dict(patch_width=8, patch_height=12, obj_spn_num_gauss=7, obj_spn_num_sums=5)
+
+
+def test_object_spn_operator_of_another_shape_against_the_reference():
+    """csrc/spn_obj_generic.hip through RatSpn.forward against the reference's own numbers (g14): 96 dimensions in leaves of 24,
+    7 Gaussians, 5 sums; out-of-range marginalisation; every parameter gradient; two runs bit for bit."""
+    from stove_amd.spn import probabilistic_models as prob
+    g = load_golden('g14_objspn_8x12_f64')
+    c = _cfg(**SHAPE_8x12)
+    spn = fill_analytic(prob._get_obj_spn(c, 42), 'sup.obj_spn.').to(DEV)
+    assert spn._kind == 'obj_any' and spn.num_dims == 96
+    x = t_(g['x']).float().to(DEV).requires_grad_()
+    m = t_(g['marg']).float().to(DEV).requires_grad_()
+    out = spn(x, m)
+    check('objany.fwd', err(out, g['out']), 5e-6)
+    (out[:, 0] * t_(g['w']).float().to(DEV)).sum().backward()
+    check_grad('objany.dx', x.grad, g['gx'], 3e-4, 3e-4, 5e-3)
+    check_grad('objany.dmarg', m.grad, g['gmarg'], 3e-4, 3e-4, 5e-3)
+    params = dict(spn.named_parameters())
+    n = 0
+    for k, v in g.items():
+        if k.startswith('ogn_'):
+            check('objany.grad_norm', abs(float(params[k[4:]].grad.norm()) - float(v)) / (float(v) + 1e-9), 3e-4)
+            n += 1
+        elif k.startswith('og_'):
+            check_grad('objany.grad', params[k[3:]].grad, v, 3e-4, 3e-4, 1e-2)
+    assert n > 20
+    o1, o2 = spn(x.detach(), None), spn(x.detach(), None)
+    assert torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize('shape', [(10, 10, 10, 10, 300), (6, 6, 3, 2, 65), (12, 14, 16, 16, 33), (9, 7, 5, 9, 130)])
+def test_object_spn_operator_of_any_shape_against_the_oracle(shape):
+    """Glimpse sizes whose leaves have different lengths (9 x 7 = 63 dimensions), the widest vectors the kernels take (16 / 16) and the
+    default shape through the general operator, against the float64 oracle; with and without marginalisation."""
+    from stove_amd.spn import probabilistic_models as prob
+    pw, ph, G, S, n = shape
+    kw = dict(patch_width=pw, patch_height=ph, obj_spn_num_gauss=G, obj_spn_num_sums=S)
+    c, structs, params = oracle_setup(torch.float64, **kw)
+    spn = fill_analytic(prob._get_obj_spn(_cfg(**kw), 42), 'sup.obj_spn.').to(DEV)
+    if (pw, ph, G, S) == (10, 10, 10, 10):
+        assert spn._kind == 'obj'                        # the default shape keeps the tuned kernels ...
+        spn._force_general_plan()                        # ... and also runs through the general operator here
+    assert spn._kind == 'obj_any'
+    d = pw * ph
+    gen = torch.Generator().manual_seed(pw * 100 + ph)
+    x64 = torch.rand(n, d, generator=gen, dtype=torch.float64)
+    m64 = torch.rand(n, d, generator=gen, dtype=torch.float64) * 1.4 - 0.2
+    w64 = torch.linspace(0.5, 1.5, n, dtype=torch.float64)
+    xo, mo = x64.clone().requires_grad_(), m64.clone().requires_grad_()
+    ref = O.spn_forward(structs['obj'], params, 'sup.obj_spn.', xo, mo, G, S, c.obj_min_var, c.obj_max_var)
+    (ref[:, 0] * w64).sum().backward()
+    xd, md = x64.float().to(DEV).requires_grad_(), m64.float().to(DEV).requires_grad_()
+    out = spn(xd, md)
+    check('objany.oracle_fwd', err(out, ref), 5e-6)
+    (out[:, 0] * w64.float().to(DEV)).sum().backward()
+    check_grad('objany.oracle_dx', xd.grad, xo.grad, 3e-4, 3e-4, 5e-3)
+    check_grad('objany.oracle_dmarg', md.grad, mo.grad, 3e-4, 3e-4, 5e-3)
+    for k, p in spn.named_parameters():
+        r = params['sup.obj_spn.' + k].grad
+        if r is not None and float(r.abs().max()) > 0:
+            check_grad('objany.oracle_grad', p.grad, r, 3e-4, 3.5e-4, 1e-2)
+    check('objany.oracle_nomarg', err(spn(xd.detach(), None), O.spn_forward(structs['obj'], params, 'sup.obj_spn.', x64, None, G, S, c.obj_min_var, c.obj_max_var)), 5e-6)
+    # MPE reconstruction (Supair.spn_mpe's inner step): the oracle's argmax walk per sample; a fp32 / fp64 tie may flip a branch
+    with torch.no_grad():
+        rec = spn.mpe(xd.detach()[:24]).cpu().double()
+        _, kept = O.spn_forward(structs['obj'], params, 'sup.obj_spn.', x64[:24], None, G, S, c.obj_min_var, c.obj_max_var, child_values=True)
+    want = np.stack([np.clip(O.spn_decode(structs['obj'], params, 'sup.obj_spn.', {k: np.argmax(v[j].detach().numpy(), 0) for k, v in kept.items()}), 0, 1)
+                     for j in range(24)])
+    same = (np.abs(rec.numpy() - want).max(1) < 1e-5).mean()
+    assert same >= 0.9, same
+
+
+def test_likelihood_and_training_with_an_object_spn_of_another_shape(tmp_path):
+    """Supair.likelihood at 8 x 12 glimpses / 7 Gaussians / 5 sums against the reference's numbers (g14), then a few optimiser
+    steps of the whole model with that shape (eager and replayed): finite, and the ELBO moves."""
+    from stove_amd.video_prediction.supair import Supair
+    g = load_golden('g14_likelihood_8x12_f64')
+    sup = fill_analytic(Supair(_cfg(**SHAPE_8x12)), 'sup.').to(DEV)
+    sup.step_counter = 0
+    x = t_(g['x']).float().to(DEV)
+    z = t_(g['z']).float().to(DEV).requires_grad_()
+    lp, prop = sup.likelihood(x, z)
+    check('shape.log_p', err(lp, g['log_p']), 5e-6)
+    for k in ('bg', 'patch', 'overlap'):
+        check('shape.part_' + k, abs(float(prop[k]) - float(g[k])) / (abs(float(g[k])) + 1e-9), 5e-6)
+    (lp * t_(g['w']).float().to(DEV)).sum().backward()
+    check('shape.dz', err(z.grad, g['gz']), 3e-4)
+    params = dict(sup.named_parameters())
+    n = 0
+    for k, v in g.items():
+        if k.startswith('gn_'):
+            check('shape.grad_norm', abs(float(params[k[3:]].grad.norm()) - float(v)) / (float(v) + 1e-9), 3e-4)
+            n += 1
+        elif k.startswith('g_'):
+            check('shape.grad_tensor', err(params[k[2:]].grad, v), 3e-4)
+    assert n > 10
+    # the whole model trains with it
+    from stove_amd.envs import envs
+    from stove_amd.video_prediction.stove import Stove
+    torch.manual_seed(3)
+    st = Stove(_cfg(**SHAPE_8x12)).to(DEV)
+    opt = torch.optim.Adam(st.parameters(), lr=2e-3)
+    xs = torch.from_numpy(envs.synth_sequences('billiards', 8, 8, seed0=2)['X']).to(DEV)
+    vals = []
+    for _ in range(4):
+        opt.zero_grad()
+        elbo, _, _ = st(xs, 1)
+        (-elbo).backward()
+        opt.step()
+        vals.append(float(elbo))
+    assert all(np.isfinite(v) for v in vals) and vals[-1] != vals[0]
+
+
+@pytest.mark.parametrize('name', ['both', 'bg', 'obj'])
+def test_fixed_gaussian_debug_models_against_the_reference(name):
+    """config.debug_bg_model / debug_obj_spn (SimpleBG / SimpleObj of the reference, probabilistic_models.py:42-90) on the HIP row
+    kernels (csrc/spn_obj_generic.hip gauss_ll_*), through Supair.likelihood, against the reference's numbers (g15)."""
+    from stove_amd.video_prediction.supair import Supair
+    kw = {'both': dict(debug_bg_model=True, debug_obj_spn=True), 'bg': dict(debug_bg_model=True), 'obj': dict(debug_obj_spn=True)}[name]
+    g = load_golden(f'g15_likelihood_simple_{name}_f64')
+    sup = fill_analytic(Supair(_cfg(**kw)), 'sup.').to(DEV)
+    sup.step_counter = 0
+    x = t_(g['x']).float().to(DEV)
+    z = t_(g['z']).float().to(DEV).requires_grad_()
+    lp, prop = sup.likelihood(x, z)
+    check('simple.log_p', err(lp, g['log_p']), 5e-6)
+    for k in ('bg', 'patch', 'overlap'):
+        check('simple.part_' + k, abs(float(prop[k]) - float(g[k])) / (abs(float(g[k])) + 1e-9), 5e-6)
+    (lp * t_(g['w']).float().to(DEV)).sum().backward()
+    check('simple.dz', err(z.grad, g['gz']), 3e-4)
+    params = dict(sup.named_parameters())
+    for k, v in g.items():
+        if k.startswith('gn_') and float(v) > 0:
+            check('simple.grad_norm', abs(float(params[k[3:]].grad.norm()) - float(v)) / (float(v) + 1e-9), 3e-4)

@@ -304,3 +304,49 @@ def test_likelihood_and_forward_beyond_the_32x32_contract(name):
     with torch.no_grad():
         rec = O.reconstruct_from_z(c, params, structs, info['z'])
     assert rel_err(rec, g['recon']) < 1e-6
+
+
+SHAPE_8x12 = dict(patch_width=8, patch_height=12, obj_spn_num_gauss=7, obj_spn_num_sums=5)
+
+
+def test_object_spn_of_another_shape():
+    """g14: the reference with 8 x 12 glimpses, 7 Gaussians per leaf and 5 sums per region (config.py:99-100, 119-120), float64:
+    RatSpn.forward with out-of-range marginalisation and its gradients, then Supair.likelihood with that object SPN."""
+    dtype, tol = torch.float64, 1e-9
+    g = load_golden('g14_objspn_8x12_f64')
+    c, structs, params = oracle_setup(dtype, **SHAPE_8x12)
+    x, m, w = t_(g['x'], dtype).requires_grad_(), t_(g['marg'], dtype).requires_grad_(), t_(g['w'], dtype)
+    out = O.spn_forward(structs['obj'], params, 'sup.obj_spn.', x, m, 7, 5, c.obj_min_var, c.obj_max_var)
+    assert rel_err(out.detach(), g['out']) < tol
+    (out[:, 0] * w).sum().backward()
+    assert rel_err(x.grad, g['gx']) < tol * 100 and rel_err(m.grad, g['gmarg']) < tol * 100
+    n = 0
+    for k, v in g.items():
+        if k.startswith('ogn_'):
+            assert abs(float(params['sup.obj_spn.' + k[4:]].grad.norm()) - float(v)) <= 1e-6 * float(v) + 1e-12, k
+            n += 1
+    assert n > 20
+    g = load_golden('g14_likelihood_8x12_f64')
+    c, structs, params = oracle_setup(dtype, **SHAPE_8x12)
+    x, z, w = t_(g['x'], dtype), t_(g['z'], dtype).requires_grad_(), t_(g['w'], dtype)
+    lp, bg, pl, ol = O.scene_likelihood(c, params, structs, x, z, parts=True)
+    assert rel_err(lp.detach(), g['log_p']) < tol
+    (lp * w).sum().backward()
+    assert rel_err(z.grad, g['gz']) < tol * 100
+
+
+@pytest.mark.parametrize('name', ['both', 'bg', 'obj'])
+def test_fixed_gaussian_debug_models(name):
+    """g15: the reference with config.debug_bg_model / debug_obj_spn (SimpleBG / SimpleObj, probabilistic_models.py:42-90) in
+    place of one or both SPNs, float64: Supair.likelihood, its parts and the gradient with respect to z."""
+    dtype, tol = torch.float64, 1e-9
+    kw = {'both': dict(debug_bg_model=True, debug_obj_spn=True), 'bg': dict(debug_bg_model=True), 'obj': dict(debug_obj_spn=True)}[name]
+    g = load_golden(f'g15_likelihood_simple_{name}_f64')
+    c, structs, params = oracle_setup(dtype, **kw)
+    x, z, w = t_(g['x'], dtype), t_(g['z'], dtype).requires_grad_(), t_(g['w'], dtype)
+    lp, bg, pl, ol = O.scene_likelihood(c, params, structs, x, z, parts=True)
+    assert rel_err(lp.detach(), g['log_p']) < tol
+    assert abs(float(bg.mean().detach()) - float(g['bg'])) < tol * abs(float(g['bg'])) + 1e-9
+    assert abs(float(pl.mean().detach()) - float(g['patch'])) < tol * abs(float(g['patch'])) + 1e-9
+    (lp * w).sum().backward()
+    assert rel_err(z.grad, g['gz']) < tol * 100
