@@ -973,10 +973,14 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
                     int ldb, int ldc, int a_kmajor, int b_kmajor, int nsplit, int splitk, int tile, float* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (M == 0 || N == 0) return 0;
-  if (K <= 0 || splitk < 1 || (nsplit != 1 && nsplit != 2) || tile < 0 || (tile > 3 && tile != 11 && tile != 12)) return (int)hipErrorInvalidValue;
+  if (K <= 0 || splitk < 1 || (nsplit != 1 && nsplit != 2) || tile < 0 || (tile > 3 && (tile < 11 || tile > 15))) return (int)hipErrorInvalidValue;
   // tile 11 / 12: measurement variants of the 256 x 128 NT kernel (tools/gemm_bf16_bench.py): no loads in the loop / no MFMAs
   if (tile == 11 && !a_kmajor && !b_kmajor && nsplit == 2) return gemm_launch<false, false, 2, 256, 128, 1>(A, B, bias, add, C, M, N, K, lda, ldb, ldc, 1, st);
   if (tile == 12 && !a_kmajor && !b_kmajor && nsplit == 2) return gemm_launch<false, false, 2, 256, 128, 2>(A, B, bias, add, C, M, N, K, lda, ldb, ldc, 1, st);
+  // 13 / 14: the same two variants of the 256 x 256 tile
+  if (tile == 13 && !a_kmajor && !b_kmajor && nsplit == 2) return gemm_launch<false, false, 2, 256, 256, 1, false, 64, 128>(A, B, bias, add, C, M, N, K, lda, ldb, ldc, 1, st);
+  if (tile == 14 && !a_kmajor && !b_kmajor && nsplit == 2) return gemm_launch<false, false, 2, 256, 256, 2, false, 64, 128>(A, B, bias, add, C, M, N, K, lda, ldb, ldc, 1, st);
+  if (tile == 15 && !a_kmajor && !b_kmajor && nsplit == 2) return gemm_launch<false, false, 2, 256, 256, 3, false, 64, 128>(A, B, bias, add, C, M, N, K, lda, ldb, ldc, 1, st);
   if (tile > 3) tile = 1;
   // float4 granularity along the contiguous dimension of an operand / of C, or the element-wise slow path for it
   // (fc1 of the recognition network has 50 columns)

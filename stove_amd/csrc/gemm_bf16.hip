@@ -198,6 +198,8 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int r0, int lane) {
 // WTM x WTN: the wave tile.  64 x 64: eight waves on 256 x 128 or four on 128 x 128, 16 accumulator tiles per wave.  Larger
 // wave tiles (256 x 256 workgroup tile: 64 x 128 with eight waves, 128 x 128 with four): every fragment read from LDS feeds more
 // MFMAs and a workgroup moves 2/3 of the operand bytes per flop through L2.
+// (Measured and removed, round 4: the two waves of a SIMD half a k-step apart -- one in its MFMAs while the other stages, a barrier
+// between the halves -- 169 vs 164 us warm, 178 vs 186 cold on x W_ih^T: level.  DESIGN.md section 7.)
 template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT, int BM, int BN, int DEBUG = 0, bool A_SCALAR = false, int WTM = 64, int WTN = 64>
 __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                                                const float* __restrict__ add, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
   sb.init(B, ldb, n0, N, k_begin, tid);
   // Interior workgroups (the whole tile inside the matrices, K a whole number of k-steps, vector path) run the loop without the
   // edge predicates; the choice is uniform over the workgroup.
-  const bool full_tile = !A_SCALAR && DEBUG == 0 && m0 + kGemmBM <= M && n0 + kGemmBN <= N && (k_end - k_begin) % kGemmBK == 0 && nt > 0;
+  const bool full_tile = !A_SCALAR && m0 + kGemmBM <= M && n0 + kGemmBN <= N && (k_end - k_begin) % kGemmBK == 0 && nt > 0;
   auto run = [&](auto full_tag) {
     constexpr bool F = decltype(full_tag)::value;
     if (nt > 0) {
@@ -329,15 +331,15 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
         // MFMAs never share an accumulator.  One register set of staged fp32 pieces: behind the first TN / 2 column tiles the
         // pieces of k-tile t + 1 (requested half a step ago) are converted and written to the other LDS buffer, behind the last
         // TN / 2 the pieces of k-tile t + 2 are requested into the registers just freed.
+        constexpr int NA = decltype(la0)::NLD, NB = decltype(lb0)::NLD, H = TN / 2;
+        static_assert(NA % H == 0 && NB % H == 0, "pieces per half step");
+        const int k_far = k_begin + (t + 2) * kGemmBK;
         bf16x8 ah[TM], al[TM];
   #pragma unroll
         for (int i = 0; i < TM; ++i) {
           ah[i] = read_frag<kGemmBM, A_KMAJOR>(img(cur, 0), wm * WTM + i * 16, lane);
           if (NSPLIT == 2) al[i] = read_frag<kGemmBM, A_KMAJOR>(img(cur, 1), wm * WTM + i * 16, lane);
         }
-        constexpr int NA = decltype(la0)::NLD, NB = decltype(lb0)::NLD, H = TN / 2;
-        static_assert(NA % H == 0 && NB % H == 0, "pieces per half step");
-        const int k_far = k_begin + (t + 2) * kGemmBK;
   #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const bf16x8 bh = read_frag<kGemmBN, B_KMAJOR>(img(cur, 2), wn * WTN + j * 16, lane);
@@ -356,7 +358,13 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
   #pragma unroll
             for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[i], acc[i][j], 0, 0, 0);
           }
-          if (j < H) {
+          if (j < H && DEBUG == 3) {
+            // (measurement variant: the staged registers are only kept alive, not converted or written)
+  #pragma unroll
+            for (int q = 0; q < NA / H; ++q) asm volatile("" ::"v"(a_next.v[j * (NA / H) + q].x));
+  #pragma unroll
+            for (int q = 0; q < NB / H; ++q) asm volatile("" ::"v"(b_next.v[j * (NB / H) + q].x));
+          } else if (j < H) {
   #pragma unroll
             for (int q = 0; q < NA / H; ++q) a_next.template store_piece<NSPLIT, F>(j * (NA / H) + q, img(cur ^ 1, 0), img(cur ^ 1, 1), tid);
   #pragma unroll

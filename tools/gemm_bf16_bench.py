@@ -47,6 +47,7 @@ for name, mine, lib, flops in cases:
     print('%-52s split3 %7.1f us (%6.1f TF fp32-equiv, %6.1f TF bf16)   bf16 %7.1f us (%6.1f TF)   library fp32 %7.1f us (%5.1f TF)' % (
         name, t2, flops / t2 / 1e6, 3 * flops / t2 / 1e6, t1, flops / t1 / 1e6, tl, flops / tl / 1e6))
 if os.environ.get('GEMM_DEBUG'):
-    for tile, what in ((1, 'full'), (11, 'no loads in the loop (compute + staging of stale registers)'), (12, 'no MFMAs (loads + staging + LDS reads)')):
+    for tile, what in ((1, 'full'), (11, 'no loads in the loop (compute + staging of stale registers)'), (12, 'no MFMAs (loads + staging + LDS reads)'),
+                       (3, '256 x 256: full'), (13, '256 x 256: no loads in the loop'), (14, '256 x 256: no MFMAs'), (15, '256 x 256: no conversion / LDS writes (stale images)')):
         t = timeit(lambda: ops.gemm_bf16(x, w_ih, None, False, False, 2, 1, tile=tile))
         print('gx variant %-70s %7.1f us' % (what, t))
