@@ -1399,8 +1399,8 @@ int stove_elbo_fwd(const float* zs, const float* mean, const float* std_, const 
 int stove_elbo_bwd(const float* zs, const float* mean, const float* std_, const float* zdyn, const float* trans_std16, const float* g_out,
                    float* g_zs, float* g_mean, float* g_std, float* g_zdyn, float* g_lik, int n, int T, int o, int skip, void* stream) {
   if (n == 0) return 0;
-  const int M = n * (T - skip) * o + n * (T - 1);
-  STOVE_LAUNCH(elbo_bwd_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, zs, mean, std_, zdyn, trans_std(trans_std16), g_out,
+  const size_t M = (size_t)n * (T - skip) * o * 18 + (size_t)n * (T - 1);
+  STOVE_LAUNCH(elbo_bwd_k, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, zs, mean, std_, zdyn, trans_std(trans_std16), g_out,
                g_zs, g_mean, g_std, g_zdyn, g_lik, n, T, o, skip);
   STOVE_LAUNCH_CHECK();
   return 0;

@@ -1439,9 +1439,11 @@ class _EncoderLstmFn(torch.autograd.Function):
             if ns and gemm_ok(dy.shape[0]):
                 M_, N_, K_ = dy.shape[1], inp.shape[1], dy.shape[0]
                 wide_tiles = (M_ // 256) * (N_ // 256)
-                if GEMM_WIDE and M_ % 256 == 0 and N_ % 256 == 0 and 8 <= wide_tiles <= 128 and K_ // (256 // wide_tiles) >= 512:
+                if GEMM_WIDE_WGRAD and M_ % 256 == 0 and N_ % 256 == 0 and 8 <= wide_tiles <= 128 and K_ // (256 // wide_tiles) >= 512:
                     # dW_ih (1024 x 1024 over 25 600 frames): sixteen 256 x 256 tiles x 16 K-slices, 147 us from cold caches
-                    # against 192 for thirty-two 256 x 128 tiles x 8 (tools/gemm_tile_ab.py, GEMM_COLD=1)
+                    # against 192 for thirty-two 256 x 128 tiles x 8 (tools/gemm_tile_ab.py, GEMM_COLD=1) -- but OFF by default: a
+                    # workgroup of the wide tile holds every register of its CU (2 x 254 per SIMD lane), the bias sums on the
+                    # second stream then start only when it is done, and the step's tail is 18 us LONGER (r04 timeline)
                     return gemm_bf16(dy, inp, None, True, True, ns, splitk=256 // wide_tiles, out=out, tile=3)
                 return gemm_bf16(dy, inp, None, True, True, ns, out=out)
             return _splitk_tn(dy, inp)
@@ -1556,6 +1558,7 @@ def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=
     return c
 
 
+GEMM_WIDE_WGRAD = os.environ.get('STOVE_GEMM_WIDE_WGRAD', '0') == '1'
 GEMM_WIDE = os.environ.get('STOVE_GEMM_WIDE', '1') != '0'      # A/B switch of the 256 x 256 tile for the input projection
 
 
