@@ -451,6 +451,9 @@ int stove_colsum2(const float* a, float* out, float* out2, int accumulate, float
  * ws: stove_flat_adam_ws_bytes(nseg) bytes, zeroed once by the caller before the first call.  max_exp_avg_sq NULL = plain
  * Adam.  hyper_dev != NULL: f32[5] = lr, beta1, beta2, eps, max_norm in device memory override the by-value arguments
  * (captured hipGraphs: kernel arguments are frozen at capture, the learning-rate schedule is not). */
+/* clip: bit 0 = clip the gradient to max_norm; bit 1 = "strict zero gradients": a tensor that has once received a gradient keeps
+ * stepping while its gradient is all zero (torch.optim.Adam on zero-FILLED .grad tensors, the zero_grad() of the torch 1.0.1 the
+ * reference pins); default (bit clear): an all-zero gradient slice means `grad is None` (current torch's zero_grad(set_to_none=True)). */
 size_t stove_flat_adam_ws_bytes(int nseg);
 int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, size_t numel,
                     const int* seg_of4, const unsigned char* seg_trainable, float* seg_steps, int nseg, void* ws, float* grad_norm_out,

@@ -242,11 +242,13 @@ __global__ __launch_bounds__(256) void flat_adam_k(float* __restrict__ p, const 
   if (vmax != nullptr) reinterpret_cast<float4*>(vmax)[i] = x4;
 }
 
-__global__ void adam_tick_k(const unsigned char* __restrict__ trainable, float* __restrict__ steps, int* __restrict__ flags, int nseg) {
+// sticky: a segment that has once received a gradient keeps its flag (torch.optim.Adam on `.grad` tensors that zero_grad() filled
+// with zeros instead of dropping: the momentum keeps moving the parameter -- the torch 1.0.1 behaviour the reference pins)
+__global__ void adam_tick_k(const unsigned char* __restrict__ trainable, float* __restrict__ steps, int* __restrict__ flags, int nseg, int sticky) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nseg) return;
   if (trainable[s] != 0 && flags[s] != 0) steps[s] += 1.0f;
-  flags[s] = 0;
+  if (!sticky) flags[s] = 0;
 }
 
 // out[j] = sum_c part[c][j], fixed order; n4 = n / 4 (split-K partials of the batched weight-gradient GEMMs)

@@ -1266,8 +1266,8 @@ int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* ex
   int* flags = reinterpret_cast<int*>(part + ADAM_SCAN_BLOCKS);          // cleared by the caller once, by adam_tick_k ever after
   STOVE_LAUNCH(grad_scan_k, dim3(ADAM_SCAN_BLOCKS), dim3(256), 0, st, grads, seg_of4, flags, part, n4);
   STOVE_LAUNCH(flat_adam_k, dim3((n4 + 255) / 256), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq, seg_of4,
-               seg_trainable, (const float*)seg_steps, (const int*)flags, (const float*)part, grad_norm_out, hyper_dev, k, clip, n4);
-  STOVE_LAUNCH(adam_tick_k, dim3((nseg + 255) / 256), dim3(256), 0, st, seg_trainable, seg_steps, flags, nseg);
+               seg_trainable, (const float*)seg_steps, (const int*)flags, (const float*)part, grad_norm_out, hyper_dev, k, clip & 1, n4);
+  STOVE_LAUNCH(adam_tick_k, dim3((nseg + 255) / 256), dim3(256), 0, st, seg_trainable, seg_steps, flags, nseg, (clip >> 1) & 1);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -24,13 +24,17 @@ class FlatAdam(torch.optim.Optimizer):
     decay, no step-count tick).  torch.optim.Adam still steps a parameter whose `.grad` is a zero tensor (its momentum keeps
     moving it) -- the reference reaches that state only through `optimizer.zero_grad()` leaving zero tensors on parameters that
     then receive no gradient, which for its models means "never used" (dynamics cores 1-2) or "frozen by a training phase":
-    the cases listed above, where not moving is what torch does for `grad is None`.  tests/test_gpu_optim.py pins both readings."""
+    the cases listed above, where not moving is what torch does for `grad is None`.  `strict_zero_grad=True`
+    (`config.strict_adam_zero_grad`) gives the other reading: once a tensor has received a gradient it keeps stepping on zero
+    gradients, as torch.optim.Adam does on zero-filled `.grad` tensors.  tests/test_gpu_optim.py pins both readings."""
 
-    def __init__(self, arena, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, amsgrad=False):
+    def __init__(self, arena, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, amsgrad=False, strict_zero_grad=False):
         if arena.data.dtype != torch.float32 or not arena.data.is_cuda:
             raise RuntimeError('FlatAdam needs a float32 ParamArena on a GPU')
         super().__init__(arena.params, dict(lr=lr, betas=betas, eps=eps, amsgrad=amsgrad, weight_decay=0))
         self.arena = arena
+        # strict_zero_grad: a tensor that has once received a gradient keeps stepping on all-zero gradients (see the class docstring)
+        self.strict_zero_grad = bool(strict_zero_grad)
         self._steps = 0                     # calls of step(); the per-segment counts live on the device
         names = ['exp_avg', 'exp_avg_sq'] + (['max_exp_avg_sq'] if amsgrad else [])
         self._flat = {k: torch.zeros_like(arena.data) for k in names}
@@ -90,7 +94,7 @@ class FlatAdam(torch.optim.Optimizer):
                 self._seg_steps.data_ptr(), len(ar.params), self._ws.data_ptr(), self._norm.data_ptr(),
                 None if hyper_dev is None else hyper_dev.data_ptr(), float(group['lr']), float(group['betas'][0]),
                 float(group['betas'][1]), float(group['eps']), float(max_norm) if max_norm is not None else 0.0,
-                1 if max_norm is not None else 0, _lib.stream()), 'stove_flat_adam')
+                (1 if max_norm is not None else 0) | (2 if self.strict_zero_grad else 0), _lib.stream()), 'stove_flat_adam')
         return self._norm if max_norm is not None else None
 
     def count_step(self):

@@ -50,7 +50,8 @@ class AbstractTrainer:
         p0 = next(self.stove.parameters())
         if p0.is_cuda and p0.dtype == torch.float32:
             # same update rule and state-dict layout as the Adam above, one launch over the flat buffers
-            self.optimizer = FlatAdam(self.bucket, lr=self.c.learning_rate, amsgrad=self.c.debug_amsgrad)
+            self.optimizer = FlatAdam(self.bucket, lr=self.c.learning_rate, amsgrad=self.c.debug_amsgrad,
+                                      strict_zero_grad=bool(getattr(self.c, 'strict_adam_zero_grad', False)))
         self.epoch_start, self.step_start = 0, 0
         if self.c.checkpoint_path is not None:
             self.load()

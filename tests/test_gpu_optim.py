@@ -88,6 +88,39 @@ def test_flat_adam_matches_torch_adam_with_late_and_frozen_parameters(amsgrad):
         assert float((opt2._flat[k] - opt._flat[k]).abs().max()) < 1e-6
 
 
+def test_flat_adam_strict_zero_gradients_matches_torch_on_zero_filled_grads():
+    """FlatAdam(strict_zero_grad=True) (config.strict_adam_zero_grad): a tensor that has received a gradient keeps stepping on its
+    momentum while its gradient is all zero -- torch.optim.Adam with zero_grad(set_to_none=False), the zero_grad() of the torch 1.0.1
+    the reference pins; a tensor that never received one stays untouched in both.  Default mode: it stands still."""
+    from stove_amd.arena import ParamArena
+    from stove_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    ref = _Net().to(DEV)
+    nets = {False: copy.deepcopy(ref), True: copy.deepcopy(ref)}
+    arenas = {k: ParamArena(n, 1) for k, n in nets.items()}
+    opts = {k: FlatAdam(arenas[k], lr=1e-2, amsgrad=True, strict_zero_grad=k) for k in nets}
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2, amsgrad=True)
+    g = torch.Generator().manual_seed(2)
+    for step in range(6):
+        full = step < 3                                        # `b` trains for three steps, then drops out of the graph
+        x = torch.randn(32, 8, generator=g).to(DEV)
+        for k in nets:
+            arenas[k].zero_grad()
+            _loss(nets[k], x, full).backward()
+            opts[k].step()
+        ropt.zero_grad(set_to_none=False)                      # zero-filled .grad tensors
+        _loss(ref, x, full).backward()
+        ropt.step()
+        for (n, p), q in zip(nets[True].named_parameters(), ref.parameters()):
+            if q.grad is not None:                             # `unused` never had a gradient: None in torch, skipped in both
+                assert float((p - q).abs().max()) < 2e-6, (step, n)
+        if step == 2:
+            kept = nets[False].b.weight.detach().clone()
+    assert torch.equal(nets[False].b.weight, kept)             # default mode: no gradient, no step
+    assert not torch.equal(nets[True].b.weight, kept)          # strict mode: the momentum kept moving it
+    assert torch.equal(nets[True].unused.weight, ref.unused.weight)
+
+
 @pytest.mark.parametrize('rows,M,N', [(25088, 12, 9), (3000, 1, 8), (2048, 16, 16), (5, 3, 4), (0, 2, 2)])
 def test_small_tn_weight_gradient(rows, M, N):
     """a^T b for narrow operands over many rows (the action embedding's weight gradient): against float64, bit-reproducible."""
