@@ -460,7 +460,10 @@ int stove_gauss_ll_bwd(const float* x, const float* marg, const float* dout, flo
 struct SceneSavedAny {
   size_t xw, obj_ll, ovl, bg_out, bg_ell, mask, obj_scratch, total;
 };
-static SceneSavedAny scene_saved_layout_any(int nf, int n_obj, int n_pix, bool with_grad) {
+// frames up to kBgTabMax a side: the background kernels form the mask themselves from per-frame coverage tables (spn_bg_generic.hip), no
+// mask image is kept
+static bool scene_any_inline(int W, int H) { return W <= kBgTabMax && H <= kBgTabMax; }
+static SceneSavedAny scene_saved_layout_any(int nf, int n_obj, int n_pix, bool with_grad, bool inline_mask = false) {
   const size_t np = (size_t)nf * n_obj;
   SceneSavedAny s;
   s.xw = 0;
@@ -469,7 +472,7 @@ static SceneSavedAny scene_saved_layout_any(int nf, int n_obj, int n_pix, bool w
   s.bg_out = s.ovl + align64(np);
   s.bg_ell = s.bg_out + align64(nf);
   s.mask = s.bg_ell + align64(bgspn_any_saved_floats(nf, n_pix));
-  s.obj_scratch = s.mask + align64((size_t)nf * n_pix);
+  s.obj_scratch = s.mask + (inline_mask ? 0 : align64((size_t)nf * n_pix));
   s.total = s.obj_scratch + (with_grad ? align64(objspn_scratch_floats((int)np)) : 0);
   return s;
 }
@@ -501,7 +504,10 @@ int stove_scene_fwd_any(const StoveSpnTables* t, const float* frames, const floa
   if (frame_map(n_frames, seq_frames, seq_stride, &fm)) return (int)hipErrorInvalidValue;
   const int n_pix = W * H, np = n_frames * n_obj;
   const SceneGeom gm = scene_geom(W, H, align_corners);
-  const SceneSavedAny L = scene_saved_layout_any(n_frames, n_obj, n_pix, true);
+  const bool inl = scene_any_inline(W, H);
+  const SceneSavedAny L = scene_saved_layout_any(n_frames, n_obj, n_pix, true, inl);
+  SceneBoxes boxes;
+  boxes.z = inl ? z : nullptr; boxes.n_obj = n_obj; boxes.gm = gm;
   hipStream_t sb = scene_fork_stream(st);
   STOVE_TRY(stream_after(sb, st));
   JoinGuard jb(st, sb);
@@ -514,10 +520,13 @@ int stove_scene_fwd_any(const StoveSpnTables* t, const float* frames, const floa
   else
     rc = objspn_forward(saved + L.xw, t->obj_scope, t->obj_coef, t->obj_wsum, t->obj_wroot, saved + L.obj_ll, saved + L.ovl, np, st);
   if (rc) return rc;
-  const size_t tot = (size_t)n_frames * n_pix;
-  STOVE_LAUNCH(bg_mask_any_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, sb, z, saved + L.mask, n_frames, n_obj, gm);
-  STOVE_LAUNCH_CHECK();
-  rc = bgspn_any_forward(frames, saved + L.mask, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames, n_pix, sb, fm);
+  if (!inl) {
+    const size_t tot = (size_t)n_frames * n_pix;
+    STOVE_LAUNCH(bg_mask_any_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, sb, z, saved + L.mask, n_frames, n_obj, gm);
+    STOVE_LAUNCH_CHECK();
+  }
+  rc = bgspn_any_forward(frames, inl ? nullptr : saved + L.mask, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, n_frames,
+                         n_pix, sb, fm, boxes);
   if (rc) return rc;
   STOVE_TRY(jb.join());
   STOVE_LAUNCH(scene_assemble_fwd_k, dim3((n_frames + 255) / 256), dim3(256), 0, st, saved + L.bg_out, saved + L.obj_ll,
@@ -538,8 +547,11 @@ int stove_scene_bwd_any(const StoveSpnTables* t, const float* frames, const floa
   float* ws = (float*)ws_;
   const int n_pix = W * H, np = n_frames * n_obj;
   const SceneGeom gm = scene_geom(W, H, align_corners);
-  const SceneSavedAny L = scene_saved_layout_any(n_frames, n_obj, n_pix, true);
+  const bool inl = scene_any_inline(W, H);
+  const SceneSavedAny L = scene_saved_layout_any(n_frames, n_obj, n_pix, true, inl);
   const SceneWsAny Wl = scene_ws_layout_any(n_frames, n_obj, n_pix);
+  SceneBoxes boxes;
+  boxes.z = inl ? z : nullptr; boxes.n_obj = n_obj; boxes.gm = gm;
   STOVE_LAUNCH(scene_assemble_bwd_k, dim3((np + 255) / 256), dim3(256), 0, st, dll, z, ws + Wl.d_obj, ws + Wl.d_ovl, n_obj, np, overlap_beta);
   STOVE_LAUNCH_CHECK();
   hipStream_t sb = scene_fork_stream(st);
@@ -547,8 +559,8 @@ int stove_scene_bwd_any(const StoveSpnTables* t, const float* frames, const floa
   JoinGuard jb(st, sb);
   JoinGuard jp(st, sp);
   // background chain: operator backward (d mask, table gradients), then the mask's backward to z
-  int rc = bgspn_any_backward(frames, saved + L.mask, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, dll, nullptr,
-                              ws + Wl.d_mask, g->bg_coef, g->bg_wroot, ws + Wl.bg, n_frames, n_pix, sb, fm);
+  int rc = bgspn_any_backward(frames, inl ? nullptr : saved + L.mask, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, dll,
+                              nullptr, ws + Wl.d_mask, g->bg_coef, g->bg_wroot, ws + Wl.bg, n_frames, n_pix, sb, fm, boxes);
   if (rc) return rc;
   if (n_obj <= 3) STOVE_LAUNCH((bg_mask_bwd_any_k<3>), dim3(n_frames), dim3(256), 0, sb, z, (const float*)(ws + Wl.d_mask), ws + Wl.dz_bg, n_frames, n_obj, gm);
   else STOVE_LAUNCH((bg_mask_bwd_any_k<8>), dim3(n_frames), dim3(256), 0, sb, z, (const float*)(ws + Wl.d_mask), ws + Wl.dz_bg, n_frames, n_obj, gm);

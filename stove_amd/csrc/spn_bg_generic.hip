@@ -10,13 +10,53 @@
 
 namespace stove {
 
+// ---- the background's marginalisation mask of a scene and its backward, any frame size (Supair.masks_from_z, supair.py:304-356) -----
+// mask[f][Y][X] = min(1, sum_k cover_x,k(X) cover_y,k(Y)): a pasted unit box is separable and the sequential clamps collapse (scene.hip).
+// cover(q) is the bilinear sample of a ones image with zero padding at pixel coordinate q = (X - cx) / sx_k + cx - sxa x_k / sx_k.
+__device__ __forceinline__ float cover_n(float q, float n, float* dq) {
+  const float a = q + 1.0f, b = n - q;
+  const float m = fminf(a, b);
+  *dq = (m > 0.0f && m < 1.0f) ? (a < b ? 1.0f : -1.0f) : 0.0f;
+  return fminf(fmaxf(m, 0.0f), 1.0f);
+}
+// Scene mode of the two kernels below: the mask is not read from memory but formed per pixel from per-frame coverage TABLES -- a pasted box
+// is separable, so a frame needs (W + H) coverage values per object instead of two evaluations per (pixel, object) -- which the
+// workgroup fills into LDS one frame ahead (two buffers; the loop's barrier publishes them).  Frames up to kBgTabMax pixels a side.
+constexpr int kBgTabMax = 128, kBgTabObj = 8;
+struct SceneBoxes {
+  const float* z;      // (n_frames * n_obj, 4) = [sx, sy, x, y], or null: mask from `marg`
+  int n_obj;
+  SceneGeom gm;
+};
+__device__ __forceinline__ void bg_fill_tables(const SceneBoxes& sb, int f, float (*tx)[kBgTabMax], float (*ty)[kBgTabMax],
+                                               float (*dtx)[kBgTabMax], float (*dty)[kBgTabMax]) {
+  const int W = sb.gm.W, H = sb.gm.H, per = W + H;
+  for (int i = threadIdx.x; i < sb.n_obj * per; i += blockDim.x) {
+    const int k = i / per, c = i - k * per;
+    const float4 zk = *reinterpret_cast<const float4*>(sb.z + ((size_t)f * sb.n_obj + k) * 4);
+    float d;
+    if (c < W) {
+      const float isx = 1.0f / zk.x;
+      tx[k][c] = cover_n(fmaf(isx, (float)c - sb.gm.cx, fmaf(-sb.gm.sxa * zk.z, isx, sb.gm.cx)), (float)W, &d);
+      if (dtx != nullptr) dtx[k][c] = d;
+    } else {
+      const float isy = 1.0f / zk.y;
+      ty[k][c - W] = cover_n(fmaf(isy, (float)(c - W) - sb.gm.cy, fmaf(-sb.gm.sya * zk.w, isy, sb.gm.cy)), (float)H, &d);
+      if (dty != nullptr) dty[k][c - W] = d;
+    }
+  }
+}
+
 template <int R, int G>
 __global__ __launch_bounds__(kBgThreads) void bgspn_fwd_any_k(const float* __restrict__ inputs, const float* __restrict__ marg,
                                                               const int* __restrict__ side, const float* __restrict__ coef,
-                                                              float* __restrict__ ell_part, int n_frames, int n_pix, int halves, FrameMap fm) {
+                                                              float* __restrict__ ell_part, int n_frames, int n_pix, int halves, FrameMap fm,
+                                                              SceneBoxes sb) {
   constexpr int NO = R * 2 * G;
   constexpr int NW = kBgThreads / 64;
   __shared__ float part[2][NW * 4][NO];     // one partial per 16-lane row of every wave
+  __shared__ float tbx[2][kBgTabObj][kBgTabMax], tby[2][kBgTabObj][kBgTabMax];
+  const bool scene = sb.z != nullptr;
   const int half = blockIdx.x % halves;
   const int p = half * kBgThreads + threadIdx.x;
   const bool live = p < n_pix;
@@ -33,9 +73,21 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_fwd_any_k(const float* __res
       for (int k = 0; k < 3; ++k) cf[r][g][k] = coef[(((size_t)r * n_pix + pc) * G + g) * 3 + k];
   }
   int it = 0;
-  for (int f = blockIdx.x / halves; f < n_frames; f += gridDim.x / halves, ++it) {
+  const int fstep = gridDim.x / halves;
+  const int X = scene ? pc % sb.gm.W : 0, Y = scene ? pc / sb.gm.W : 0;
+  if (scene && (int)(blockIdx.x / halves) < n_frames) {
+    bg_fill_tables(sb, blockIdx.x / halves, tbx[0], tby[0], nullptr, nullptr);
+    __syncthreads();
+  }
+  for (int f = blockIdx.x / halves; f < n_frames; f += fstep, ++it) {
     const float x = inputs[fm.row(f) * n_pix + pc];
     float w = (marg != nullptr) ? 1.0f - fminf(fmaxf(marg[(size_t)f * n_pix + pc], 0.0f), 1.0f) : 1.0f;
+    if (scene) {
+      float run = 0.0f;
+      for (int k = 0; k < sb.n_obj; ++k) run = fmaf(tbx[it & 1][k][X], tby[it & 1][k][Y], run);
+      w = 1.0f - fminf(run, 1.0f);
+      if (f + fstep < n_frames) bg_fill_tables(sb, f + fstep, tbx[(it + 1) & 1], tby[(it + 1) & 1], nullptr, nullptr);
+    }
     if (!live) w = 0.0f;
     const float wx = w * x, wxx = wx * x;
     float* pp = part[it & 1][wv * 4 + (lane >> 4)];
@@ -71,8 +123,10 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_any_k(const float* __res
                                                               const int* __restrict__ side, const float* __restrict__ coef,
                                                               const float* __restrict__ dell, float* __restrict__ d_inputs,
                                                               float* __restrict__ d_marg, float* __restrict__ gcoef_part, int n_frames,
-                                                              int n_pix, int halves, FrameMap fm) {
+                                                              int n_pix, int halves, FrameMap fm, SceneBoxes sb) {
   constexpr int NO = R * 2 * G;
+  __shared__ float tbx[2][kBgTabObj][kBgTabMax], tby[2][kBgTabObj][kBgTabMax];
+  const bool scene = sb.z != nullptr;
   const int half = blockIdx.x % halves;
   const int p = half * kBgThreads + threadIdx.x;
   const bool live = p < n_pix;
@@ -90,12 +144,25 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_any_k(const float* __res
         gc[r][g][k] = 0.0f;
       }
   }
-  for (int f = blockIdx.x / halves; f < n_frames; f += gridDim.x / halves) {
+  const int fstep = gridDim.x / halves;
+  const int X = scene ? pc % sb.gm.W : 0, Y = scene ? pc / sb.gm.W : 0;
+  if (scene && (int)(blockIdx.x / halves) < n_frames) {
+    bg_fill_tables(sb, blockIdx.x / halves, tbx[0], tby[0], nullptr, nullptr);
+    __syncthreads();
+  }
+  int it = 0;
+  for (int f = blockIdx.x / halves; f < n_frames; f += fstep, ++it) {
     const float x = inputs[fm.row(f) * n_pix + pc];
     float mraw = 0.0f, w = 1.0f;
     if (marg != nullptr) {
       mraw = marg[(size_t)f * n_pix + pc];
       w = 1.0f - fminf(fmaxf(mraw, 0.0f), 1.0f);
+    }
+    if (scene) {
+      // mraw = the unclamped sum of the boxes: the gradient passes while it is <= 1 (min(1, .)); never negative
+      for (int k = 0; k < sb.n_obj; ++k) mraw = fmaf(tbx[it & 1][k][X], tby[it & 1][k][Y], mraw);
+      w = 1.0f - fminf(mraw, 1.0f);
+      if (f + fstep < n_frames) bg_fill_tables(sb, f + fstep, tbx[(it + 1) & 1], tby[(it + 1) & 1], nullptr, nullptr);
     }
     if (!live) w = 0.0f;
     const float wx = w * x, wxx = wx * x, x2 = x * x;
@@ -121,6 +188,7 @@ __global__ __launch_bounds__(kBgThreads) void bgspn_bwd_any_k(const float* __res
       if (d_marg != nullptr) d_marg[(size_t)f * n_pix + p] = (mraw >= 0.0f && mraw <= 1.0f) ? -dw : 0.0f;      // boundaries pass, as ATen's clamp
       if (d_inputs != nullptr) d_inputs[(size_t)f * n_pix + p] = dx * w;
     }
+    if (scene) __syncthreads();       // the next frame's tables are complete; this frame's may be overwritten
   }
   float* o = gcoef_part + ((size_t)blockIdx.x * R * kBgThreads) * G * 3;
 #pragma unroll
@@ -158,15 +226,6 @@ __global__ __launch_bounds__(256) void bgspn_coef_reduce_any_k(const float* __re
   }
 }
 
-// ---- the background's marginalisation mask of a scene and its backward, any frame size (Supair.masks_from_z, supair.py:304-356) -----
-// mask[f][Y][X] = min(1, sum_k cover_x,k(X) cover_y,k(Y)): a pasted unit box is separable and the sequential clamps collapse (scene.hip).
-// cover(q) is the bilinear sample of a ones image with zero padding at pixel coordinate q = (X - cx) / sx_k + cx - sxa x_k / sx_k.
-__device__ __forceinline__ float cover_n(float q, float n, float* dq) {
-  const float a = q + 1.0f, b = n - q;
-  const float m = fminf(a, b);
-  *dq = (m > 0.0f && m < 1.0f) ? (a < b ? 1.0f : -1.0f) : 0.0f;
-  return fminf(fmaxf(m, 0.0f), 1.0f);
-}
 __global__ __launch_bounds__(256) void bg_mask_any_k(const float* __restrict__ z, float* __restrict__ mask, int n_frames, int n_obj, SceneGeom gm) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int n_pix = gm.W * gm.H;
@@ -190,8 +249,16 @@ template <int NMAX>
 __global__ __launch_bounds__(256) void bg_mask_bwd_any_k(const float* __restrict__ z, const float* __restrict__ d_mask, float* __restrict__ dz_bg,
                                                          int n_frames, int n_obj, SceneGeom gm) {
   __shared__ float red[4][NMAX * 4];
+  __shared__ float tx[kBgTabObj][kBgTabMax], ty[kBgTabObj][kBgTabMax], dtx[kBgTabObj][kBgTabMax], dty[kBgTabObj][kBgTabMax];
   const int f = blockIdx.x;
   const int n_pix = gm.W * gm.H;
+  const bool tabs = gm.W <= kBgTabMax && gm.H <= kBgTabMax;      // workgroup-uniform: coverage from per-frame tables (see bg_fill_tables)
+  if (tabs) {
+    SceneBoxes sb;
+    sb.z = z; sb.n_obj = n_obj; sb.gm = gm;
+    bg_fill_tables(sb, f, tx, ty, dtx, dty);
+    __syncthreads();
+  }
   float isx[NMAX], isy[NMAX], ox[NMAX], oy[NMAX], zx[NMAX], zy[NMAX], acc[NMAX][4];
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
@@ -209,8 +276,13 @@ __global__ __launch_bounds__(256) void bg_mask_bwd_any_k(const float* __restrict
     float cxv[NMAX], cyv[NMAX], dcx[NMAX], dcy[NMAX], run = 0.0f;
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
-      cxv[k] = cover_n(fmaf(isx[k], X, ox[k]), (float)gm.W, &dcx[k]);
-      cyv[k] = cover_n(fmaf(isy[k], Y, oy[k]), (float)gm.H, &dcy[k]);
+      if (tabs) {
+        const int kk = k < n_obj ? k : 0;
+        cxv[k] = tx[kk][Xi]; dcx[k] = dtx[kk][Xi]; cyv[k] = ty[kk][Yi]; dcy[k] = dty[kk][Yi];
+      } else {
+        cxv[k] = cover_n(fmaf(isx[k], X, ox[k]), (float)gm.W, &dcx[k]);
+        cyv[k] = cover_n(fmaf(isy[k], Y, oy[k]), (float)gm.H, &dcy[k]);
+      }
       if (k < n_obj) run += cxv[k] * cyv[k];
     }
     const float d = run <= 1.0f ? d_mask[(size_t)f * n_pix + p] : 0.0f;        // min(1, .): the gradient passes while the sum is not clamped
@@ -250,12 +322,12 @@ size_t bgspn_any_bwd_ws_floats(int n_frames, int n_pix) {
 }
 
 int bgspn_any_forward(const float* inputs, const float* marg, const int* side, const float* coef, const float* wroot, float* ell_part,
-                      float* out, int n_frames, int n_pix, hipStream_t st, FrameMap fm = FrameMap{0, 0}) {
+                      float* out, int n_frames, int n_pix, hipStream_t st, FrameMap fm = FrameMap{0, 0}, SceneBoxes sb = SceneBoxes{nullptr, 0, SceneGeom{}}) {
   if (n_frames == 0) return 0;
   if (n_pix < 1) return (int)hipErrorInvalidValue;
   const int halves = bg_halves_any(n_pix);
   STOVE_LAUNCH((bgspn_fwd_any_k<kBgR, kBgG>), dim3(bg_grid_any(n_frames, n_pix)), dim3(kBgThreads), 0, st, inputs, marg, side, coef, ell_part,
-               n_frames, n_pix, halves, fm);
+               n_frames, n_pix, halves, fm, sb);
   STOVE_LAUNCH_CHECK();
   STOVE_LAUNCH((bgspn_root_fwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, n_frames, halves);
   STOVE_LAUNCH_CHECK();
@@ -265,7 +337,7 @@ int bgspn_any_forward(const float* inputs, const float* marg, const int* side, c
 // g_coef [R][n_pix][G][3], g_wroot [R*G*G] overwritten
 int bgspn_any_backward(const float* inputs, const float* marg, const int* side, const float* coef, const float* wroot, const float* ell_part,
                        const float* out, const float* dout, float* d_inputs, float* d_marg, float* g_coef, float* g_wroot, float* ws,
-                       int n_frames, int n_pix, hipStream_t st, FrameMap fm = FrameMap{0, 0}) {
+                       int n_frames, int n_pix, hipStream_t st, FrameMap fm = FrameMap{0, 0}, SceneBoxes sb = SceneBoxes{nullptr, 0, SceneGeom{}}) {
   if (n_pix < 1) return (int)hipErrorInvalidValue;
   if (n_frames == 0) {
     hipMemsetAsync(g_coef, 0, sizeof(float) * kBgR * (size_t)n_pix * kBgG * 3, st);
@@ -280,7 +352,7 @@ int bgspn_any_backward(const float* inputs, const float* marg, const int* side, 
   STOVE_LAUNCH((bgspn_root_bwd_k<kBgR, kBgG>), dim3((n_frames + 255) / 256), dim3(256), 0, st, ell_part, wroot, out, dout, dell, rsc, n_frames, halves);
   STOVE_LAUNCH_CHECK();
   STOVE_LAUNCH((bgspn_bwd_any_k<kBgR, kBgG>), dim3(grid), dim3(kBgThreads), 0, st, inputs, marg, side, coef, (const float*)dell, d_inputs, d_marg,
-               gpart, n_frames, n_pix, halves, fm);
+               gpart, n_frames, n_pix, halves, fm, sb);
   STOVE_LAUNCH_CHECK();
   const size_t nc = (size_t)kBgR * n_pix * kBgG * 3;
   STOVE_LAUNCH((bgspn_coef_reduce_any_k<kBgR, kBgG>), dim3((unsigned)((nc + 31) / 32)), dim3(256), 0, st, (const float*)gpart, g_coef, grid, n_pix, halves);

@@ -191,7 +191,8 @@ def test_likelihood_beyond_the_32x32_contract(name, composed, monkeypatch):
     assert n > 10
 
 
-@pytest.mark.parametrize('shape', [(50, 50, False, 3), (40, 28, False, 3), (28, 40, True, 5), (64, 64, True, 8), (32, 32, True, 6)])
+@pytest.mark.parametrize('shape', [(50, 50, False, 3), (40, 28, False, 3), (28, 40, True, 5), (64, 64, True, 8), (32, 32, True, 6),
+                                   (136, 24, False, 2)])      # the last: a side past the coverage tables' 128 entries (mask image kept)
 def test_fused_scene_of_any_geometry_against_the_oracle(shape):
     """Frames that are not square, more objects than the goldens hold, both conventions: the fused any-size pipeline against the
     float64 oracle on the same seeded inputs (the oracle itself is pinned on 50 x 50 / align_corners goldens of the reference,
