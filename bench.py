@@ -311,12 +311,18 @@ def main():
         step(0)                                   # capture (restores parameters / optimiser / generator: not a training step)
         torch.cuda.synchronize()
         log('step captured')
+    if a.warmup > 0 and not os.environ.get('STOVE_BENCH_NO_GC_SETTLE'):
+        # Host-side settling BEFORE the warm-up steps, not between them and the timed region: the collection takes tens of ms of host
+        # time with the device idle, the chip drops its clocks, and the first timed steps then ran 3.34 / 3.17 / 3.04 ms against 2.90
+        # steady (STOVE_BENCH_SERIES=1).  The warm-up steps now run straight into the timed region.
+        if a.step_mode != 'graph':
+            step(0)                               # eager mode: one step so that the long-lived objects exist (setup, as the capture is)
+        torch.cuda.synchronize()
+        from stove_amd.utils.utils import settle_host_gc
+        settle_host_gc()            # as the Trainer does after its first steps (train.py): see the function's note
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
-    if a.warmup > 0 and not os.environ.get('STOVE_BENCH_NO_GC_SETTLE'):
-        from stove_amd.utils.utils import settle_host_gc
-        settle_host_gc()            # as the Trainer does after its first steps (train.py): see the function's note
     log('warm-up done')
     if world > 1:
         dist.barrier()
@@ -398,6 +404,9 @@ def main():
         log('stalled step(s): device ms ' + ' '.join('%.2f' % v for v in series))
         log('                 host ms   ' + ' '.join('%.2f' % ((host_t[i + 1] - host_t[i]) * 1e3) for i in range(a.steps)))
     log('timed region done: %.1f ms/step' % (dt / a.steps * 1e3))
+    if os.environ.get('STOVE_BENCH_SERIES'):
+        log('device ms per step: ' + ' '.join('%.3f' % v for v in series))
+        log('host ms per step:   ' + ' '.join('%.3f' % ((host_t[i + 1] - host_t[i]) * 1e3) for i in range(a.steps)))
 
     # ---- per-kernel HIP-event timing of extra steps (profiling hooks off during the timed region)
     roofline = None
