@@ -1474,12 +1474,13 @@ int stove_enc_head_fwd(const float* h, const float* W1, const float* b1, const f
                        int H, int HID, int OUT, int frames, void* stream) {
   if (H != kEhH || HID < 1 || HID > kEhHid || OUT != kEhOut || frames < 0 || (frames > 0 && rows % frames != 0)) return (int)hipErrorInvalidValue;
   if (rows == 0) return 0;
+  static_assert(2 * kEhHid * kEhLdB == sizeof(float) * kEhHid * kEhLd, "the two bf16 images of W1 take the fp32 image's place");
   const size_t lds = sizeof(float) * kEhHid * kEhLd;
-  int rc = (int)hipFuncSetAttribute((const void*)enc_head_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int rc = (int)hipFuncSetAttribute((const void*)enc_head_fwd_k<kEhFc1Split>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (rc) return rc;
   const int tiles = (rows + 15) / 16;
   const int grid = (tiles + 3) / 4 < 512 ? (tiles + 3) / 4 : 512;
-  STOVE_LAUNCH(enc_head_fwd_k, dim3(grid), dim3(256), lds, (hipStream_t)stream, h, W1, b1, W2, b2, h1, codes, rows, HID, frames);
+  STOVE_LAUNCH((enc_head_fwd_k<kEhFc1Split>), dim3(grid), dim3(256), lds, (hipStream_t)stream, h, W1, b1, W2, b2, h1, codes, rows, HID, frames);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

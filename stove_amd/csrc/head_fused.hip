@@ -32,6 +32,13 @@ __device__ __forceinline__ size_t eh_orow(int row, int pn, int pk) { return pn >
 // the 16 float4 h[row c][16 q + 4 g], each a whole k-step quadruple (k = 16 q + 4 g + j for step 4 q + j): one load instruction
 // covers 64 contiguous bytes of each of the 16 rows (with k = 64 g + 4 q it touched 64 different lines for 16 B each), and
 // every byte of h crosses the memory system once.
+// SPLIT (round 4): fc1 -- 97 % of the kernel's flops -- as split-bf16 MFMAs (v_mfma_f32_16x16x32_bf16 on hi / lo pieces, three per product,
+// fp32 accumulate: the recognition network's GEMMs, gemm_bf16.hip) instead of v_mfma_f32_16x16x4_f32: 96 MFMAs of 16 cycles per 16-row
+// tile instead of 256 of 32.  The accumulator layout D[feature 4 g + r][row c] is the same for both instructions, so everything behind
+// fc1 is unchanged.  W1 sits in LDS as two bf16 images (rows of 528 bytes: conflict-free b128 fragment reads), h is split in registers.
+constexpr int kEhLdB = 528;
+constexpr bool kEhFc1Split = true;      // false: the fp32-MFMA fc1 of round 2 (A/B builds)
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void enc_head_fwd_k(const float* __restrict__ h, const float* __restrict__ W1, const float* __restrict__ b1,
                                                        const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ h1,
                                                        float* __restrict__ codes, int rows, int HID, int pn) {
@@ -68,15 +75,34 @@ __global__ __launch_bounds__(256, 2) void enc_head_fwd_k(const float* __restrict
   float4 hn[16];                 // the next tile's rows, fetched while the current tile is in the matrix pipe
   auto fetch = [&](int tt) {
     const int row = tt * 16 + c;
-    const float* hp = h + (size_t)(row < rows ? row : rows - 1) * kEhH + 4 * g;
+    if (SPLIT) {          // lane (c, g): the 8 consecutive k = 32 q + 8 g .. + 7 of row c per k-block (128 contiguous bytes per row and load pair)
+      const float* hp = h + (size_t)(row < rows ? row : rows - 1) * kEhH + 8 * g;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) hn[q] = ld4(hp + 16 * q);
+      for (int q = 0; q < 8; ++q) {
+        hn[2 * q] = ld4(hp + 32 * q);
+        hn[2 * q + 1] = ld4(hp + 32 * q + 4);
+      }
+    } else {
+      const float* hp = h + (size_t)(row < rows ? row : rows - 1) * kEhH + 4 * g;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) hn[q] = ld4(hp + 16 * q);
+    }
   };
   if (t < n_tiles) fetch(t);
+  char* img_hi = reinterpret_cast<char*>(eh_lds);
+  char* img_lo = img_hi + kEhHid * kEhLdB;
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
     const int i = tid + 256 * u, n = i / (kEhH / 4), k4 = i % (kEhH / 4);
-    st4(eh_lds + n * kEhLd + 4 * k4, n < HID ? wst[u] : float4{0.0f, 0.0f, 0.0f, 0.0f});
+    const float4 wv4 = n < HID ? wst[u] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (SPLIT) {
+      u32x2 hi, lo;
+      split4<2>(wv4, hi, lo);
+      *reinterpret_cast<u32x2*>(img_hi + n * kEhLdB + 8 * k4) = hi;
+      *reinterpret_cast<u32x2*>(img_lo + n * kEhLdB + 8 * k4) = lo;
+    } else {
+      st4(eh_lds + n * kEhLd + 4 * k4, wv4);
+    }
   }
   __syncthreads();
   const float* wrow = eh_lds + c * kEhLd + 4 * g;
@@ -90,24 +116,61 @@ __global__ __launch_bounds__(256, 2) void enc_head_fwd_k(const float* __restrict
     f32x4 acc[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) acc[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    // W1 fragments one quadruple of k-steps ahead of the MFMAs that use them (the scheduling barrier keeps the compiler from
-    // hoisting all 64 LDS reads to the top: 256 registers)
-    float4 a[4], an[4];
+    if constexpr (SPLIT) {
+      const char* fr = img_hi + c * kEhLdB + 16 * g;          // fragment of feature tile jt, k-block q: + 16 jt rows, + 64 q bytes
+      bf16x8 ahi[4], alo[4], nhi[4], nlo[4];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) a[jt] = ld4(wrow + 16 * jt * kEhLd);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      if (q + 1 < 16) {
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) an[jt] = ld4(wrow + 16 * jt * kEhLd + 16 * (q + 1));
+      for (int jt = 0; jt < 4; ++jt) {
+        ahi[jt] = *reinterpret_cast<const bf16x8*>(fr + 16 * jt * kEhLdB);
+        alo[jt] = *reinterpret_cast<const bf16x8*>(fr + kEhHid * kEhLdB + 16 * jt * kEhLdB);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int q = 0; q < 8; ++q) {
+        if (q + 1 < 8) {
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = eh_mfma(eh_comp(a[jt], j), eh_comp(hb[q], j), acc[jt]);
-      __builtin_amdgcn_sched_barrier(0);
+          for (int jt = 0; jt < 4; ++jt) {
+            nhi[jt] = *reinterpret_cast<const bf16x8*>(fr + 16 * jt * kEhLdB + 64 * (q + 1));
+            nlo[jt] = *reinterpret_cast<const bf16x8*>(fr + kEhHid * kEhLdB + 16 * jt * kEhLdB + 64 * (q + 1));
+          }
+        }
+        u32x2 h0, l0, h1_, l1;
+        split4<2>(hb[2 * q], h0, l0);
+        split4<2>(hb[2 * q + 1], h1_, l1);
+        const bf16x8 bhi = __builtin_bit_cast(bf16x8, u32x4{h0.x, h0.y, h1_.x, h1_.y});
+        const bf16x8 blo = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) a[jt] = an[jt];
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[jt], bhi, acc[jt], 0, 0, 0);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[jt], blo, acc[jt], 0, 0, 0);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[jt], bhi, acc[jt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          ahi[jt] = nhi[jt];
+          alo[jt] = nlo[jt];
+        }
+      }
+    } else {
+      // W1 fragments one quadruple of k-steps ahead of the MFMAs that use them (the scheduling barrier keeps the compiler from
+      // hoisting all 64 LDS reads to the top: 256 registers)
+      float4 a[4], an[4];
+  #pragma unroll
+      for (int jt = 0; jt < 4; ++jt) a[jt] = ld4(wrow + 16 * jt * kEhLd);
+  #pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if (q + 1 < 16) {
+  #pragma unroll
+          for (int jt = 0; jt < 4; ++jt) an[jt] = ld4(wrow + 16 * jt * kEhLd + 16 * (q + 1));
+        }
+  #pragma unroll
+        for (int j = 0; j < 4; ++j)
+  #pragma unroll
+          for (int jt = 0; jt < 4; ++jt) acc[jt] = eh_mfma(eh_comp(a[jt], j), eh_comp(hb[q], j), acc[jt]);
+        __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+        for (int jt = 0; jt < 4; ++jt) a[jt] = an[jt];
+      }
     }
     // h1 = sigmoid(a1 + b1): this lane holds h1[row c][16 jt + 4 g + r]; features >= HID are exact zeros (fc2 operand)
     float hv[4][4];
