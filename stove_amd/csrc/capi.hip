@@ -1502,9 +1502,13 @@ int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, con
     return 0;
   }
   const int groups = enc_head_groups(rows);
-  const size_t lds = sizeof(float) * kEhBwdLds;
+  const size_t lds = sizeof(float) * (kEhBwdSplit ? kEhBwdLdsS : kEhBwdLds);
   int rc;
-  if (HID <= 50) {
+  if (kEhBwdSplit) {
+    rc = (int)hipFuncSetAttribute((const void*)enc_head_bwd_k<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc) return rc;
+    STOVE_LAUNCH((enc_head_bwd_k<16, true>), dim3(groups * 5), dim3(256), lds, st, dcodes, h1, h, W1, W2, gh, ws, rows, HID, groups, frames);
+  } else if (HID <= 50) {
     rc = (int)hipFuncSetAttribute((const void*)enc_head_bwd_k<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc) return rc;
     STOVE_LAUNCH(enc_head_bwd_k<14>, dim3(groups * 5), dim3(256), lds, st, dcodes, h1, h, W1, W2, gh, ws, rows, HID, groups, frames);
