@@ -98,9 +98,18 @@ template <int K4>
 struct SmW {
   float4 w[K4];
 };
-template <int K4>
+// HK (round 4; kernels with ONE node row per wave, where the upper half-wave only mirrored the lower one): the two halves split K --
+// the lower half takes k < K / 2, the upper half k >= K / 2 (its own half of the weight row: half the LDS reads and half the registers
+// per layer) -- and sm_dotw adds the two partial sums across the halves with one v_permlane32_swap (new on gfx950).
+template <int K4, bool HK = false>
 __device__ __forceinline__ SmW<K4> sm_wload(const float* Wl, int OUT, int o, int k4_0 = 0) {
   SmW<K4> r;
+  if (HK) {
+    const int kh = k4_0 + (lane_id() >> 5) * (K4 / 2);
+#pragma unroll
+    for (int k4 = 0; k4 < K4 / 2; ++k4) r.w[k4] = *reinterpret_cast<const float4*>(Wl + ((kh + k4) * OUT + o) * 4);
+    return r;
+  }
 #pragma unroll
   for (int k4 = 0; k4 < K4; ++k4) r.w[k4] = *reinterpret_cast<const float4*>(Wl + ((k4_0 + k4) * OUT + o) * 4);
   return r;
@@ -116,11 +125,37 @@ __device__ __forceinline__ SmW<K4> sm_wload(const float* Wl, int OUT, int o, int
 // 32 v_readlane feeding the FMAs through SGPRs (every FMA then waits on the SGPR its readlane has just written).
 // Each HALF-wave is a row of its own: lane k of the half holds x[k], lane o gets y[o] of its half's row (both halves use the
 // same weight rows W[o]).  With one node row per wave the upper half mirrors the lower one and computes the same numbers.
-template <int K4>
+template <int K4, bool HK = false>
 __device__ __forceinline__ float sm_dotw(const SmW<K4>& W, float x) {
   __shared__ __attribute__((aligned(16))) float xb[kSmWaves][64];
   float* p = xb[wave_id()];
   p[lane_id()] = x;
+  if (HK) {
+    static_assert(K4 % 4 == 0, "two packed-FMA pairs per half");
+    // both halves read the LOWER half's copy of x (lanes 0..31 are the row; what the upper lanes hold is not relied on)
+    p += (lane_id() >> 5) * (2 * K4);              // the half's K / 2 = 2 K4 inputs
+    float4 xh[K4 / 2];
+#pragma unroll
+    for (int k4 = 0; k4 < K4 / 2; ++k4) xh[k4] = *reinterpret_cast<const float4*>(p + 4 * k4);
+    v2f a = {0.0f, 0.0f}, b = {0.0f, 0.0f}, c = {0.0f, 0.0f}, d = {0.0f, 0.0f};
+#pragma unroll
+    for (int k4 = 0; k4 < K4 / 2; k4 += 2) {
+      a = pk_fma(v2f{W.w[k4].x, W.w[k4].y}, v2f{xh[k4].x, xh[k4].y}, a);
+      b = pk_fma(v2f{W.w[k4].z, W.w[k4].w}, v2f{xh[k4].z, xh[k4].w}, b);
+      c = pk_fma(v2f{W.w[k4 + 1].x, W.w[k4 + 1].y}, v2f{xh[k4 + 1].x, xh[k4 + 1].y}, c);
+      d = pk_fma(v2f{W.w[k4 + 1].z, W.w[k4 + 1].w}, v2f{xh[k4 + 1].z, xh[k4 + 1].w}, d);
+    }
+    a += b;
+    c += d;
+    a += c;
+    // v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second: on two copies of the partial sum
+    // it leaves [lower | lower] and [upper | upper].  As inline asm on two registers: hipcc 7.2 returns the FIRST result for both
+    // members of __builtin_amdgcn_permlane32_swap's pair (tools/ubench/permlane32_swap.hip).
+    float lo = a.x + a.y, hi;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(hi) : "v"(lo));
+    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+    return lo + hi;
+  }
   p += lane_id() & 32;
   float4 xv[K4];
 #pragma unroll
@@ -478,6 +513,7 @@ template <bool SAVE, int NMX>
 __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float sinv, const SmAct& act, float& res_out, float& pred_out,
                                         const SmEdgeLane (&el)[SmShape<NMX>::ET]) {
   constexpr int RP = SmShape<NMX>::RP, ET = SmShape<NMX>::ET;
+  constexpr bool HK = RP == 1;                                      // one row per wave: the half-waves split K (sm_wload / sm_dotw)
   __shared__ __attribute__((aligned(16))) float sbuf[NMX][32];     // S back as broadcast float4 reads (see sm_dotw)
   __shared__ __attribute__((aligned(16))) float sdx[NMX][32];      // SD of every node row, from the self-dynamics wave
   const int wv = wave_id();
@@ -493,7 +529,7 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
   sm_stamp(cf, 0);
   // ---- P1: node rows: encoder, factorised first edge layer ------------------------------------------------------
   if (wv < N) {
-    wa = sm_wload<8>(L.W + W_ENC, 32, o);
+    wa = sm_wload<8, HK>(L.W + W_ENC, 32, o);
     const float benc = V[V_ENC + o];
     // first quarter of the edge-first weights (k4 = 0, 1; four column groups of 64) while the encoder computes; the other
     // quarters arrive one round ahead of their FMAs (two halves of 16 float4 held 128 registers of weights in a kernel that
@@ -504,13 +540,15 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
 #pragma unroll
       for (int g = 0; g < 4; ++g) ef[k4][g] = *reinterpret_cast<const float4*>(L.W + W_EF + (k4 * 256 + g * 64 + lane) * 4);
     float e;
-    if (cf.sin_dim <= 16) {
+    if (HK) {
+      e = sm_dotw<8, HK>(wa, sinv);          // (s_in is zero beyond sin_dim: the split form always takes the 32-wide dot, 8 packed FMAs a half)
+    } else if (cf.sin_dim <= 16) {
       SmW<4> w4;
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) w4.w[k4] = wa.w[k4];
       e = sm_dotw<4>(w4, sinv);
     } else {
-      e = sm_dotw<8>(wa, sinv);
+      e = sm_dotw<8, HK>(wa, sinv);
     }
     S = (o < cf.lim_enc) ? sinv : e + benc;
     if (own) {
@@ -580,31 +618,31 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
   // ---- P3: edges (i -> j, i != j) as the columns of the relation chain (wave 3) and the attention chain (wave 2); the
   // self-dynamics of all node rows as the columns of wave 1's
   sm_edge_phase_mfma<SAVE, ET>(L, cf, act, &sbuf[0][0], &sdx[0][0], el, pre);
-  if (wv < N) wa = sm_wload<8>(L.W + W_F0, 32, o);        // affector.0, in flight across the barrier
+  if (wv < N) wa = sm_wload<8, HK>(L.W + W_F0, 32, o);        // affector.0, in flight across the barrier
   sm_stamp(cf, 4);
   WG_SYNC();
   sm_stamp(cf, 5);
   // ---- P4: node rows: aggregation, affector, output ------------------------------------------------------------------
   if (wv < N) {
-    wb = sm_wload<8>(L.W + W_F1, 32, o);
+    wb = sm_wload<8, HK>(L.W + W_F1, 32, o);
     const float bf0 = V[V_F0 + o], bf1 = V[V_F1 + o], bf2 = V[V_F2 + o], bo0 = V[V_O0 + o], bo1 = V[V_O1 + o];
     float pred = sdx[rs][o];
     for (int j = 0; j < N; ++j)
       if (j != rs) pred = fmaf(L.R3[(rs * N + j) * 32 + o], L.ATT[rs * N + j], pred);
     sm_stamp(cf, 12);
-    const float F1 = fast_tanh(sm_dotw<8>(wa, pred) + bf0);
+    const float F1 = fast_tanh(sm_dotw<8, HK>(wa, pred) + bf0);
     sm_stamp(cf, 13);
-    wa = sm_wload<8>(L.W + W_F2, 32, o);
-    const float F2 = fast_tanh(sm_dotw<8>(wb, F1) + bf1) + F1;
-    wb = sm_wload<8>(L.W + W_O0, 32, o);
-    const float F3 = sm_dotw<8>(wa, F2) + bf2;
-    wa = sm_wload<8>(L.W + W_O0, 32, o, 8);
-    float t = sm_dotw<8>(wb, F3);
-    wb = sm_wload<8>(L.W + W_O1, 32, o);
-    t += sm_dotw<8>(wa, S);
+    wa = sm_wload<8, HK>(L.W + W_F2, 32, o);
+    const float F2 = fast_tanh(sm_dotw<8, HK>(wb, F1) + bf1) + F1;
+    wb = sm_wload<8, HK>(L.W + W_O0, 32, o);
+    const float F3 = sm_dotw<8, HK>(wa, F2) + bf2;
+    wa = sm_wload<8, HK>(L.W + W_O0, 32, o, 8);
+    float t = sm_dotw<8, HK>(wb, F3);
+    wb = sm_wload<8, HK>(L.W + W_O1, 32, o);
+    t += sm_dotw<8, HK>(wa, S);
     const float O1 = fast_tanh(t + bo0);
     sm_stamp(cf, 14);
-    const float RES = sm_dotw<8>(wb, O1) + bo1 + O1;
+    const float RES = sm_dotw<8, HK>(wb, O1) + bo1 + O1;
     sm_stamp(cf, 15);
     if (SAVE && own) {
       act.PRED[r * 32 + o] = pred;

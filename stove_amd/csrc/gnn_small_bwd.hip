@@ -238,6 +238,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
   // steps ts1-1 .. ts0 of the Ts the tensors are laid out for (see dyn_loop_fwd_small_k).  The gradient that flows from step ts0
   // into the state before it leaves through `carry` (B, N, 18; layout of dz1) when ts0 > 0 and enters there when ts1 < Ts.
   constexpr int RP = SmShape<NMX>::RP, ET = SmShape<NMX>::ET, NE4 = (SmShape<NMX>::NE + 3) & ~3;
+  constexpr bool HK = RP == 1;       // one node row per wave: the half-waves split K of the row-per-lane dots (gnn_small.hip sm_dotw)
   static_assert(NT <= NMX, "object count beyond what the kernel is built for");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // the chain is issue-latency bound: where another kernel's wave shares the SIMD (the table gradients that run underneath,
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     float dS_o0 = 0.0f, dSD = 0.0f, pc = 0.0f;
     // ---- Q4: node rows: epilogue, output and affector MLPs backwards ----------------------------------------------
     if (node) {
-      SmW<8> wa = sm_wload<8>(L.W + W_O1, 32, l), wb;
+      SmW<8> wa = sm_wload<8, HK>(L.W + W_O1, 32, l), wb;
       if (l < 2 && own) pos[r * 4 + l] = cur.S;
       // epilogue backward (dyn_loop_bwd_k of gnn.hip, per (row, q)): lane d < 16 owns q = d + 2, lanes 16/17 q = 0/1
       const float res_hi = sm_from_lane(cur.RES, (lane & 32) + ((l + 16) & 31));
@@ -346,23 +347,23 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
       const float dres = l < 16 ? lo : hi_from;
       sm_stamp(cf, 6);
       // b1. out.1
-      wb = sm_wload<8>(L.W + W_O0, 64, l);
-      const float db = (sm_dotw<8>(wa, dres) + dres) * (1.0f - cur.O1 * cur.O1);
+      wb = sm_wload<8, HK>(L.W + W_O0, 64, l);
+      const float db = (sm_dotw<8, HK>(wa, dres) + dres) * (1.0f - cur.O1 * cur.O1);
       // b2. out.0 on [F3 | S]
-      wa = sm_wload<8>(L.W + W_O0, 64, 32 + l);
-      const float dF3 = sm_dotw<8>(wb, db);
-      wb = sm_wload<8>(L.W + W_F2, 32, l);
-      dS_o0 = sm_dotw<8>(wa, db);
+      wa = sm_wload<8, HK>(L.W + W_O0, 64, 32 + l);
+      const float dF3 = sm_dotw<8, HK>(wb, db);
+      wb = sm_wload<8, HK>(L.W + W_F2, 32, l);
+      dS_o0 = sm_dotw<8, HK>(wa, db);
       // b3. affector.2
-      wa = sm_wload<8>(L.W + W_F1, 32, l);
-      const float dF2 = sm_dotw<8>(wb, dF3);
+      wa = sm_wload<8, HK>(L.W + W_F1, 32, l);
+      const float dF2 = sm_dotw<8, HK>(wb, dF3);
       const float th = cur.F2 - cur.F1;
       const float du = dF2 * (1.0f - th * th);
       // b4. affector.1
-      wb = sm_wload<8>(L.W + W_F0, 32, l);
-      const float dbf = (sm_dotw<8>(wa, du) + dF2) * (1.0f - cur.F1 * cur.F1);
+      wb = sm_wload<8, HK>(L.W + W_F0, 32, l);
+      const float dbf = (sm_dotw<8, HK>(wa, du) + dF2) * (1.0f - cur.F1 * cur.F1);
       // b5. affector.0
-      dSD = sm_dotw<8>(wb, dbf) + cur.dpred;
+      dSD = sm_dotw<8, HK>(wb, dbf) + cur.dpred;
       if (own) {
         L.DSD[r * 32 + l] = dSD;
         g.dRES[r * 32 + l] = dres;
@@ -431,13 +432,13 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
         if (RP == 1 || rq == h) dS_edge = de;           // element l of row rw: kept by the half-wave that carries the row
       }
       sm_stamp(cf, 8);
-      SmW<8> wa = sm_wload<8>(L.W + W_S1, 32, l);
+      SmW<8> wa = sm_wload<8, HK>(L.W + W_S1, 32, l);
       // b11. self.1:  SD = H1 W^T + b + H1
-      SmW<8> wb = sm_wload<8>(L.W + W_S0, 32, l);
-      const float dH1p = (sm_dotw<8>(wa, dSD) + dSD) * dphi_from_out(cur.H1, elu);
+      SmW<8> wb = sm_wload<8, HK>(L.W + W_S0, 32, l);
+      const float dH1p = (sm_dotw<8, HK>(wa, dSD) + dSD) * dphi_from_out(cur.H1, elu);
       // b12. self.0 ; total dS ; split into the encoder output part and the pass-through part
-      wa = sm_wload<8>(L.W + W_ENC, 32, l);
-      float tot = sm_dotw<8>(wb, dH1p) + dS_edge + dS_o0;
+      wa = sm_wload<8, HK>(L.W + W_ENC, 32, l);
+      float tot = sm_dotw<8, HK>(wb, dH1p) + dS_edge + dS_o0;
       if (l < 2) {
         float dd = 0.0f;
         for (int j = 0; j < N; ++j)
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
       const bool raw = l < lim_enc;
       const float dEnc = raw ? 0.0f : tot;
       // b13. encoder
-      const float dsin = sm_dotw<8>(wa, dEnc) + (raw ? tot : 0.0f);
+      const float dsin = sm_dotw<8, HK>(wa, dEnc) + (raw ? tot : 0.0f);
       if (own) {
         g.dH1p[r * 32 + l] = dH1p;
         g.dEnc[r * 32 + l] = dEnc;

@@ -7,6 +7,6 @@ for v in A B A B; do
   if [ $v = A ]; then cp stove_amd/$A stove_amd/libstove_hip.so; E="$STOVE_AB_ENV_A"; else cp /tmp/keep.so stove_amd/libstove_hip.so; [ "$B" != "-" ] && cp stove_amd/$B stove_amd/libstove_hip.so; E="$STOVE_AB_ENV_B"; fi
   env $E STOVE_BENCH_NO_PARITY=1 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-variants "$@" 2>/dev/null | tail -1 | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernels_ms_per_step']
-print('$v', round(d['ms_per_step'],4), round(d['ms_per_step_p50'],4), {n: k[n] for n in ('gemm_bf16_k','lstm_cell_fwd_k','lstm_cell_bwd_k','enc_head_fwd_k','gnn_dw_small_k') if n in k}, 'gemm launches', d['roofline'].get('launches'), 'avg', d['roofline'].get('avg_ms'))"
+print('$v', round(d['ms_per_step'],4), round(d['ms_per_step_p50'],4), {n: k[n] for n in ('gemm_bf16_k','dyn_loop_fwd_small_k','dyn_loop_bwd_small_k','objspn_tablegrad_under_k','enc_head_fwd_k','gnn_dw_small_k') if n in k}, 'gemm launches', d['roofline'].get('launches'), 'avg', d['roofline'].get('avg_ms'))"
 done
 cp /tmp/keep.so stove_amd/libstove_hip.so
