@@ -731,14 +731,16 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
       float zv;
       if (l < 16) {
         const int d = l;
-        const float m = 2.0f * sigmoidf_(res) - 1.0f;
-        const float sd = std_scale(d, kc) * sigmoidf_(res_s);
+        // v_rcp_f32 / v_rsq_f32 (1 ulp) for the two sigmoids' and the product-of-Gaussians' divisions: four IEEE divisions and a
+        // square root were ~40 instructions of the step's serial tail (the backward's epilogue has had them since round 2)
+        const float m = 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-res)) - 1.0f;
+        const float sd = std_scale(d, kc) * __builtin_amdgcn_rcpf(1.0f + __expf(-res_s));
         const float zd = m + (d < 2 ? sinv : 0.0f);
         float mu, sg;
         if (d < 4) {
           const float sd2 = sd * sd, ss2 = ss * ss, D = sd2 + ss2;
-          mu = (ss2 * zd + sd2 * ms) / D;
-          sg = sd * ss / sqrtf(D);
+          mu = (ss2 * zd + sd2 * ms) * __builtin_amdgcn_rcpf(D);
+          sg = sd * ss * __builtin_amdgcn_rsqf(D);
         } else {
           mu = zd;
           sg = sd;
