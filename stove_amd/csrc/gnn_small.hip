@@ -148,13 +148,8 @@ __device__ __forceinline__ float sm_dotw(const SmW<K4>& W, float x) {
     a += b;
     c += d;
     a += c;
-    // v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second: on two copies of the partial sum
-    // it leaves [lower | lower] and [upper | upper].  As inline asm on two registers: hipcc 7.2 returns the FIRST result for both
-    // members of __builtin_amdgcn_permlane32_swap's pair (tools/ubench/permlane32_swap.hip).
-    float lo = a.x + a.y, hi;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(hi) : "v"(lo));
-    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-    return lo + hi;
+    // the two halves' partial sums meet through one v_permlane32_swap (common.h sum_xor32)
+    return sum_xor32(a.x + a.y);
   }
   p += lane_id() & 32;
   float4 xv[K4];
@@ -450,8 +445,7 @@ __device__ __forceinline__ void sm_edge_chain(const SmLds& L, const SmCfg& cf, c
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) p = fmaf(pre.bl3[t][s2], a2[c][t][s2], p);
-      p += __shfl_xor(p, 16);
-      p += __shfl_xor(p, 32);
+      p = sum_xor32(sum_xor16(p));
       const float att = __expf(p + V[V_BA2]);
       if (el[c].valid) {
         if (SAVE) {
@@ -727,7 +721,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     sm_step<SAVE, NMX>(L, cf, sinv, a, res, prd, el);
     if (wv < N) {
       // epilogue (stove.py:103-170 + constrain_z_dyn): lane d < 16 owns state dim d, lanes 16/17 the two scale dims
-      const float res_s = sm_from_lane(res, (lane & 32) + ((l + 16) & 31));      // RES[16 + d] for d < 16
+      const float res_s = from_xor16(res);      // RES[16 + d] for d < 16
       float zv;
       if (l < 16) {
         const int d = l;
@@ -810,7 +804,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void rollout_fwd_small_k(const float
     float res = 0.0f, prd = 0.0f;
     sm_step<false, NMX>(L, cf, sinv, a, res, prd, el);
     if (wv < N) {
-      const float res_s = sm_from_lane(res, (lane & 32) + ((l + 16) & 31));
+      const float res_s = from_xor16(res);
       float zv;
       if (l < 16) {
         zv = 2.0f * sigmoidf_(res) - 1.0f + (l < 2 ? sinv : 0.0f);

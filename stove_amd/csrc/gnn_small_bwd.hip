@@ -160,8 +160,7 @@ __device__ __forceinline__ void smb_edge_phase_mfma(const SmBLds& L, const SmEdg
 #pragma unroll
       for (int e = 0; e < 4; ++e) pq = fmaf(dsd[c][t][e], in[c].r3[t][e], pq);
     }
-    pq += __shfl_xor(pq, 16);
-    pq += __shfl_xor(pq, 32);
+    pq = sum_xor32(sum_xor16(pq));
     dq[c] = pq * in[c].att;
   }
   if (h == 0) {
@@ -213,8 +212,7 @@ __device__ __forceinline__ void smb_edge_phase_mfma(const SmBLds& L, const SmEdg
 #pragma unroll
       for (int e = 0; e < 4; ++e) dd = fmaf(d1[c][u][e], wd[e], dd);
     }
-    dd += __shfl_xor(dd, 16);
-    dd += __shfl_xor(dd, 32);
+    dd = sum_xor32(sum_xor16(dd));
     if (el[c].valid) {
       float* eg = L.EG + el[c].e * 128 + 64 * h + 4 * gq;
       float* g1 = g.dR1p + (h ? g.dA1p - g.dR1p : (ptrdiff_t)0) + el[c].s64;      // (a select between the two pointers went through scratch memory)
@@ -307,7 +305,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
       SmW<8> wa = sm_wload<8, HK>(L.W + W_O1, 32, l), wb;
       if (l < 2 && own) pos[r * 4 + l] = cur.S;
       // epilogue backward (dyn_loop_bwd_k of gnn.hip, per (row, q)): lane d < 16 owns q = d + 2, lanes 16/17 q = 0/1
-      const float res_hi = sm_from_lane(cur.RES, (lane & 32) + ((l + 16) & 31));
+      const float res_hi = from_xor16(cur.RES);
       const float gz = cur.gz + (l < 16 ? car : 0.0f);
       const float gmu = gz + cur.gmu_in, gsg = gz * cur.ep + cur.gsg_in;
       float lo = 0.0f, hi = 0.0f;
@@ -343,7 +341,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
         dzsup[o * 6 + (l - 16)] = gmu;
         dzsstd[o * 6 + (l - 16)] = gsg;
       }
-      const float hi_from = sm_from_lane(hi, (lane & 32) + ((l + 16) & 31));      // lane l >= 16 takes hi of lane l - 16
+      const float hi_from = from_xor16(hi);      // lane l >= 16 takes hi of lane l - 16
       const float dres = l < 16 ? lo : hi_from;
       sm_stamp(cf, 6);
       // b1. out.1
@@ -428,7 +426,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
         }
         s0 += s1;
         float de = s0.x + s0.y;
-        de += sm_from_lane(de, lane ^ 32);
+        de = sum_xor32(de);
         if (RP == 1 || rq == h) dS_edge = de;           // element l of row rw: kept by the half-wave that carries the row
       }
       sm_stamp(cf, 8);

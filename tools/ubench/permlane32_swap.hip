@@ -17,16 +17,23 @@ __global__ void k(float* o) {
   asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
   o[256 + threadIdx.x] = lo;
   o[320 + threadIdx.x] = hi;
+  float a16 = v, b16;                                                            // v_permlane16_swap
+  asm volatile("v_mov_b32 %0, %1" : "=v"(b16) : "v"(a16));
+  asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a16), "+v"(b16));
+  o[384 + threadIdx.x] = a16;
+  o[448 + threadIdx.x] = b16;
 }
 int main() {
-  float* d; hipMalloc(&d, 384 * 4);
+  float* d; hipMalloc(&d, 512 * 4);
   k<<<1, 64>>>(d);
-  float h[384]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  float h[512]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
   printf("r0: lane0 %g lane31 %g lane32 %g lane63 %g\n", h[0], h[31], h[32], h[63]);
   printf("r1: lane0 %g lane31 %g lane32 %g lane63 %g\n", h[64], h[95], h[96], h[127]);
   printf("two registers:\nq0: lane0 %g lane31 %g lane32 %g lane63 %g\n", h[128], h[159], h[160], h[191]);
   printf("q1: lane0 %g lane31 %g lane32 %g lane63 %g\n", h[192], h[223], h[224], h[255]);
   printf("inline asm:\nlo: lane0 %g lane31 %g lane32 %g lane63 %g\n", h[256], h[287], h[288], h[319]);
   printf("hi: lane0 %g lane31 %g lane32 %g lane63 %g\n", h[320], h[351], h[352], h[383]);
+  printf("v_permlane16_swap:\na: lane0 %g lane16 %g lane32 %g lane48 %g\n", h[384], h[400], h[416], h[432]);
+  printf("b: lane0 %g lane16 %g lane32 %g lane48 %g\n", h[448], h[464], h[480], h[496]);
   return 0;
 }
