@@ -301,8 +301,10 @@ def test_pipelined_recursion_and_likelihood_equal_the_unpipelined_step(workload)
     e1, g1, p1 = run(1)
     for pieces in (2, 3):
         e, g, p = run(pieces)
-        # billiards: bit-identical forward; with action / appearance inputs the last bit of the ELBO may move (7e-8 relative seen)
-        assert (e == e1) if workload == 'billiards' else abs(e - e1) <= 5e-7 * abs(e1), (pieces, e, e1)
+        # the last bit of the ELBO may move (one ulp, 1.2e-7 relative, seen on billiards too once round 4 changed the values of z): the
+        # recursion's outputs and every logged mean are bit-identical, the ELBO is assembled from per-frame likelihoods that a piece
+        # computes in another grouping of frames
+        assert abs(e - e1) <= 5e-7 * abs(e1), (pieces, e, e1)
         assert float((g - g1).abs().max()) <= 2e-5 * float(g1.abs().max()), pieces
         for k in p1:
             a, b = p1[k], p[k]
