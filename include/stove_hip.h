@@ -487,6 +487,12 @@ int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, f
 int stove_lstm_cell_bwd(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
                         const float* dc_in, float* dg, float* dc_out, float* dgx_sum, const float* dg_more, int n_more, int n, int H,
                         int fast, void* stream);
+/* the same on a row range of the batch: every pointer already offset to the range's first row, n = rows of the range,
+ * more_stride = floats between dg_more[m] and dg_more[m + 1] (the whole batch's rows x 4H).  The recognition network's chain
+ * is row-wise independent; the host runs it in two row chunks on two streams (ops._EncoderLstmFn). */
+int stove_lstm_cell_bwd_rows(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
+                             const float* dc_in, float* dg, float* dc_out, float* dgx_sum, const float* dg_more, int n_more,
+                             size_t more_stride, int n, int H, int fast, void* stream);
 
 /* ---- output head of RnnStates behind fc1 (encoder.py:53-56: zps = fc2(sigmoid(fc1(output)))).  a1 (rows, H1) = fc1
  * pre-activations (library GEMM) -> h1 = sigmoid(a1) (rows, H1) and codes (rows, OUT) = h1 W2^T + b2; W2 (OUT, H1).

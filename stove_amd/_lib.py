@@ -18,7 +18,7 @@ EXPORTS = [
     'stove_scene_saved_floats', 'stove_scene_fwd', 'stove_scene_bwd_ws_bytes', 'stove_scene_bwd',
     'stove_scene_glimpses',
     'stove_gnn_param_floats', 'stove_gnn_grad_floats', 'stove_gnn_blocks', 'stove_gnn_fwd', 'stove_gnn_bwd_ws_bytes',
-    'stove_gnn_bwd', 'stove_dynloop_act_floats', 'stove_dynloop_fwd', 'stove_dynloop_bwd_ws_bytes', 'stove_dynloop_bwd', 'stove_rollout_fwd', 'stove_match_objects', 'stove_profile_enable', 'stove_profile_report', 'stove_gnn_debug_stamps', 'stove_lstm_cell_fwd', 'stove_lstm_cell_bwd',
+    'stove_gnn_bwd', 'stove_dynloop_act_floats', 'stove_dynloop_fwd', 'stove_dynloop_bwd_ws_bytes', 'stove_dynloop_bwd', 'stove_rollout_fwd', 'stove_match_objects', 'stove_profile_enable', 'stove_profile_report', 'stove_gnn_debug_stamps', 'stove_lstm_cell_fwd', 'stove_lstm_cell_bwd', 'stove_lstm_cell_bwd_rows',
     'stove_spn_bake', 'stove_spn_bake_bwd', 'stove_arena_gather', 'stove_arena_scatter_add', 'stove_debug_set_stamps',
     'stove_supair_state_fwd', 'stove_supair_state_bwd', 'stove_zall_fwd', 'stove_zall_bwd', 'stove_elbo_fwd', 'stove_elbo_bwd', 'stove_flat_adam', 'stove_flat_adam_ws_bytes', 'stove_gemm_bf16', 'stove_gemm_bf16_ws_floats', 'stove_sum_chunks', 'stove_colsum_ws_floats', 'stove_colsum', 'stove_bw_transform', 'stove_dynloop_bwd_ws_bytes_ts', 'stove_scene_bwd_overlap', 'stove_dynloop_bwd_overlap', 'stove_glimpse_mean', 'stove_objspn_mpe', 'stove_render_frames', 'stove_head_fwd', 'stove_head_bwd_ws_floats', 'stove_head_bwd',
     'stove_enc_head_fwd', 'stove_enc_head_bwd_ws_floats', 'stove_enc_head_bwd', 'stove_colsum2', 'stove_small_tn', 'stove_small_tn_ws_floats', 'stove_supair_state_fwd2', 'stove_supair_state_bwd2', 'stove_bg_dense', 'stove_bg_dense_floats',
@@ -98,6 +98,7 @@ def _declare(lib):
         'stove_profile_enable': (None, [I]),
         'stove_lstm_cell_fwd': (I, [P, P, P, P, P, I, I, I, P]),
         'stove_lstm_cell_bwd': (I, [P] * 10 + [I, I, I, I, P]),
+        'stove_lstm_cell_bwd_rows': (I, [P] * 10 + [I, S, I, I, I, P]),
         'stove_gnn_debug_stamps': (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
         'stove_profile_report': (S, [c_char_p, S]),
         'stove_spn_bake': (I, [P, A, P, P, P, P, P, P]),

@@ -1538,14 +1538,20 @@ int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, f
 int stove_lstm_cell_bwd(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
                         const float* dc_in, float* dg, float* dc_out, float* dgx_sum, const float* dg_more, int n_more, int n, int H,
                         int fast, void* stream) {
+  return stove_lstm_cell_bwd_rows(gx, gh, c_prev, c, dh, dc_in, dg, dc_out, dgx_sum, dg_more, n_more, (size_t)n * 4 * H, n, H, fast, stream);
+}
+
+int stove_lstm_cell_bwd_rows(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
+                             const float* dc_in, float* dg, float* dc_out, float* dgx_sum, const float* dg_more, int n_more,
+                             size_t more_stride, int n, int H, int fast, void* stream) {
   if (n == 0) return 0;
-  if (H % 4 || n_more < 0 || (n_more > 0 && dg_more == nullptr)) return (int)hipErrorInvalidValue;
+  if (H % 4 || n_more < 0 || (n_more > 0 && (dg_more == nullptr || more_stride < (size_t)n * 4 * H))) return (int)hipErrorInvalidValue;
   const size_t total = (size_t)n * (H / 4);
   const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   if (fast) STOVE_LAUNCH(lstm_cell_bwd_k<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gx, gh, c_prev, c, dh, dc_in, dg, dc_out, dgx_sum, dg_more,
-                         n_more, n, H);
+                         n_more, more_stride, n, H);
   else STOVE_LAUNCH(lstm_cell_bwd_k<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gx, gh, c_prev, c, dh, dc_in, dg, dc_out, dgx_sum, dg_more,
-                    n_more, n, H);
+                    n_more, more_stride, n, H);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -71,11 +71,12 @@ __global__ void lstm_cell_fwd_k(const float* __restrict__ gx, const float* __res
 //    dgx_sum (n,4H) or null: this step's dg + the dg of `n_more` other steps, dg_more[m][n][4H] -- the input projection is
 //    shared by all steps, so its gradient is the sum over the steps; it is formed ONCE, by the last backward step (step 0),
 //    from the stored gate gradients of the others, instead of a read-modify-write of a running sum in every step.
+//    more_stride: floats between dg_more[m] and dg_more[m + 1] (n * 4H, or more when the launch covers a row range of the batch).
 template <bool FAST>
 __global__ void lstm_cell_bwd_k(const float* __restrict__ gx, const float* __restrict__ gh, const float* __restrict__ c_prev,
                                 const float* __restrict__ c, const float* __restrict__ dh, const float* __restrict__ dc_in,
                                 float* __restrict__ dg, float* __restrict__ dc_out, float* __restrict__ dgx_sum,
-                                const float* __restrict__ dg_more, int n_more, int n, int H) {
+                                const float* __restrict__ dg_more, int n_more, size_t more_stride, int n, int H) {
   const int q = H / 4;
   const size_t total = (size_t)n * q;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -116,7 +117,7 @@ __global__ void lstm_cell_bwd_k(const float* __restrict__ gx, const float* __res
       if (dgx_sum != nullptr) {
         float4 a = v;
         for (int m = 0; m < n_more; ++m) {
-          const float4 p = ld4(dg_more + (size_t)m * n * 4 * H + go_ + k * H);
+          const float4 p = ld4(dg_more + (size_t)m * more_stride + go_ + k * H);
           a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
         }
         st4(dgx_sum + go_ + k * H, a);

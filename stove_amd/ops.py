@@ -1372,6 +1372,146 @@ class _blas:
 FAST_CELL = int(os.environ.get('STOVE_LSTM_FAST_CELL', '1') != '0')
 
 
+ENC_CHUNKS = int(os.environ.get('STOVE_ENC_CHUNKS', '2'))
+ENC_STAGGER = os.environ.get('STOVE_ENC_STAGGER', '0') != '0'
+ENC_SPLIT = os.environ.get('STOVE_ENC_SPLIT', '')          # shares of the rows per chunk, e.g. "64,36" (A/B; default: equal chunks)
+
+
+def _enc_chunks(n, D, H):
+    """Row chunks [r0, r1) of the recognition network's forward chain (every product and cell of it is row-wise independent), or
+    None for the unchunked chain: the 256 x 256 tile on whole tiles of every chunk, chunks big enough to fill most of the chip."""
+    c = ENC_CHUNKS
+    if not (c > 1 and GEMM_WIDE and os.environ.get('STOVE_NO_OVERLAP', '0') != '1' and n % 256 == 0 and n // c >= 4096
+            and (4 * H) % 256 == 0 and D % 32 == 0 and H % 32 == 0):
+        return None
+    tiles = n // 256
+    shares = [float(v) for v in ENC_SPLIT.split(',')] if ENC_SPLIT else [1.0] * c
+    bounds, acc = [0], 0.0
+    for v in shares[:-1]:
+        acc += v
+        bounds.append(int(round(tiles * acc / sum(shares))) * 256)
+    bounds.append(n)
+    if any(b1 - b0 < 2048 for b0, b1 in zip(bounds, bounds[1:])):
+        return None
+    return list(zip(bounds, bounds[1:]))
+
+
+def _encoder_lstm_fwd_chunked(lib, x, w_ih, w_hh, bias, hs, cs, num_steps, ns, chunks):
+    """The forward chain [x W_ih^T, then per step h W_hh^T + gx and the cell] over row chunks on two streams: while one chunk's
+    cell kernel streams its gates through HBM the other chunk's product keeps the matrix cores busy, and the workgroups of two
+    products fill the chip where one launch leaves a partial round of tiles.  Row-wise the same kernels on the same operands:
+    bit-identical to the unchunked chain.  -> [gs_0 (= gx), gs_1, ...]"""
+    n, D = x.shape
+    H = w_hh.shape[1]
+    dev = x.device
+    main, side = torch.cuda.current_stream(dev), _side_stream(dev, 'enc')
+    gss = [torch.empty(n, 4 * H, dtype=torch.float32, device=dev) for _ in range(num_steps)]
+
+    def chain(r0, r1, after_first=None):
+        rows = r1 - r0
+        st = stream()
+        check(lib.stove_gemm_bf16(ptr(x[r0:]), ptr(w_ih), ptr(bias), None, ptr(gss[0][r0:]), rows, 4 * H, D, x.stride(0), w_ih.stride(0), 4 * H,
+                                  0, 0, ns, 1, 3, None, st), 'stove_gemm_bf16')
+        if after_first is not None:
+            after_first()
+        for k in range(num_steps):
+            if k > 0:
+                check(lib.stove_gemm_bf16(ptr(hs[k - 1][r0:]), ptr(w_hh), None, ptr(gss[0][r0:]), ptr(gss[k][r0:]), rows, 4 * H, H, H, w_hh.stride(0),
+                                          4 * H, 0, 0, ns, 1, 3, None, st), 'stove_gemm_bf16')
+            check(lib.stove_lstm_cell_fwd(ptr(gss[k][r0:]), None, ptr(cs[k - 1][r0:]) if k > 0 else None, ptr(cs[k][r0:]), ptr(hs[k][r0:]),
+                                          rows, H, FAST_CELL, st), 'stove_lstm_cell_fwd')
+
+    side.wait_stream(main)
+    evs = []
+
+    def first_done():          # (A/B: the second stream's first chunk a product behind the first stream's)
+        if ENC_STAGGER:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            evs.append(ev)
+    for c, (r0, r1) in enumerate(chunks):
+        if c % 2 == 0:
+            chain(r0, r1, first_done if c == 0 else None)
+        else:
+            with torch.cuda.stream(side):
+                if c == 1 and evs:
+                    side.wait_event(evs[0])
+                chain(r0, r1)
+    main.wait_stream(side)
+    return gss
+
+
+# The backward chain in the same chunks: measured, OFF (same box, alternating: 2.85-2.88 ms against 2.81-2.82, six objects 5.39 against
+# 5.35-5.37) -- that phase already runs the recursion's weight gradients, dW_hh and the column sums beside the chain and is bound by
+# what all of them move through HBM; two chains of cells only add to the contention.  Kept as a tested switch.
+ENC_CHUNKS_BWD = os.environ.get('STOVE_ENC_CHUNKS_BWD', '0') != '0'
+
+
+def _encoder_lstm_bwd_chunked(lib, x, w_hh, gss, hs, cs, dhs, views, ns, chunks, wgrad):
+    """The backward chain [cell backward, dg W_hh + dh of the step before, ...] over the forward's row chunks, alternating between
+    the main stream and the 'enc' stream; the products that contract over the rows follow on the parameter stream (dW_hh, the bias
+    sums: once every chunk has written its gate gradients) and on the main stream (dW_ih: chunk by chunk into the arena's view,
+    the first chunk's while the other stream still runs its last cells).  Per row the same kernels as the unchunked chain;
+    dW_ih is the sum of per-chunk products (another summation order than one product over all rows)."""
+    K = len(gss)
+    n, H = x.shape[0], w_hh.shape[1]
+    dev = x.device
+    main, enc = torch.cuda.current_stream(dev), _side_stream(dev, 'enc')
+    dgx = torch.empty(n, 4 * H, dtype=torch.float32, device=dev)
+    dg_all = torch.empty(K - 1, n, 4 * H, dtype=torch.float32, device=dev)
+    dc = [torch.empty(n, H, dtype=torch.float32, device=dev) for _ in range(2)]
+    dhb = [torch.empty(n, H, dtype=torch.float32, device=dev) for _ in range(2)]
+    ws = torch.empty(lib.stove_colsum_ws_floats(n, 4 * H) + 1, dtype=torch.float32, device=dev)
+    last = len(chunks) - 1
+
+    def whh_grad():
+        wgrad(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H), out=views[1])
+
+    def bias_sums():
+        _side_keep(ws)
+        check(lib.stove_colsum2(ptr(dgx), ptr(views[2]), ptr(views[3]), 1, ptr(ws), n, 4 * H, stream()), 'stove_colsum2')
+
+    def chain(c, r0, r1):
+        rows = r1 - r0
+        st = stream()
+        dh = dhs[K - 1][r0:]
+        for k in range(K - 1, -1, -1):
+            dg = dg_all[k - 1][r0:] if k > 0 else None
+            check(lib.stove_lstm_cell_bwd_rows(ptr(gss[k][r0:]), None, ptr(cs[k - 1][r0:]) if k > 0 else None, ptr(cs[k][r0:]), ptr(dh),
+                                               ptr(dc[(k + 1) % 2][r0:]) if k < K - 1 else None, ptr(dg) if dg is not None else None,
+                                               ptr(dc[k % 2][r0:]), ptr(dgx[r0:]) if k == 0 else None, ptr(dg_all[0][r0:]) if k == 0 else None,
+                                               K - 1 if k == 0 else 0, n * 4 * H, rows, H, FAST_CELL, st), 'stove_lstm_cell_bwd_rows')
+            if k <= 1:
+                # the parameter stream waits for this chunk's gate gradients (k = 1: all that W_hh sees; k = 0: dgx); behind the last
+                # chunk's it runs the product / the sums
+                fn = whh_grad if k == 1 else bias_sums
+                if c == last:
+                    run_on_side(dev, fn, (dg_all, hs) if k == 1 else (dgx,))
+                else:
+                    check(lib.stove_stream_after(_side_stream(dev).cuda_stream, st), 'stove_stream_after')
+            if k > 0:
+                out = dhb[(k - 1) % 2][r0:]
+                check(lib.stove_gemm_bf16(ptr(dg), ptr(w_hh), None, ptr(dhs[k - 1][r0:]), ptr(out), rows, H, 4 * H, 4 * H, w_hh.stride(0), H,
+                                          0, 1, ns, 1, 1, None, st), 'stove_gemm_bf16')
+                dh = out
+
+    enc.wait_stream(main)
+    for c, (r0, r1) in enumerate(chunks):
+        if c % 2 == 0:
+            chain(c, r0, r1)
+        else:
+            with torch.cuda.stream(enc):
+                chain(c, r0, r1)
+    # dW_ih: the main stream's own chunks first, the other stream's behind the join
+    for c, (r0, r1) in enumerate(chunks):
+        if c % 2 == 0:
+            wgrad(dgx[r0:r1], x[r0:r1], out=views[0])
+    main.wait_stream(enc)
+    for c, (r0, r1) in enumerate(chunks):
+        if c % 2 == 1:
+            wgrad(dgx[r0:r1], x[r0:r1], out=views[0])
+
+
 class _EncoderLstmFn(torch.autograd.Function):
     """num_steps LSTM steps on the SAME input x (reference encoder.py:43-51): hs (n, num_steps, H).
 
@@ -1389,7 +1529,9 @@ class _EncoderLstmFn(torch.autograd.Function):
         if not gemm_ok(x.shape[1], H):
             ns = 0                               # odd sizes: library GEMMs
         with torch.cuda.device(dev):
-            if ns:
+            if ns and _enc_chunks(n, x.shape[1], H) is not None:
+                gx = None               # the chunked chains below make their own rows of it
+            elif ns:
                 gx = _gemm_rows_balanced(x, w_ih, _f32(b_ih + b_hh), ns)
             else:
                 with _blas('hipblas'):
@@ -1399,7 +1541,10 @@ class _EncoderLstmFn(torch.autograd.Function):
             # gs[k]: gate pre-activations of step k = gx + h_{k-1} W_hh^T (the recurrent GEMM adds gx in its epilogue, so the
             # cell kernels read ONE (n, 4H) tensor per step, forward and backward); gs[0] is gx itself
             gss = []
-            for k in range(num_steps):
+            if gx is None:
+                gss = _encoder_lstm_fwd_chunked(lib, x, w_ih, w_hh, _f32(b_ih + b_hh), hs, cs, num_steps, ns, _enc_chunks(n, x.shape[1], H))
+                gx = gss[0]
+            for k in range(num_steps if not gss else 0):
                 gs = gx
                 if k > 0 and ns:
                     # K = 256 (8 k-steps): the 128 x 128 tile (1600 workgroups) beats 256 x 128; the 256 x 256 tile is level with it
@@ -1453,6 +1598,12 @@ class _EncoderLstmFn(torch.autograd.Function):
                 run_on_side(dev, fn, bufs)
             else:
                 fn()
+        chunks = _enc_chunks(n, x.shape[1], H) if (fork and ENC_CHUNKS_BWD and K > 1) else None
+        if chunks is not None:
+            with torch.cuda.device(dev):
+                _encoder_lstm_bwd_chunked(lib, x, w_hh, gss, hs, cs, dhs, views, ns, chunks, wgrad)
+                join_side_after_backward(dev)
+            return None, None, None, None, None, None, None, None
         with torch.cuda.device(dev):
             dgx = torch.empty_like(gx)
             # gate gradients of steps 1..K-1 are kept ((K-1) x 105 MB at 25 600 frames): dW_hh is ONE GEMM over all of

@@ -429,3 +429,42 @@ def test_fixed_gaussian_debug_models_against_the_reference(name):
     for k, v in g.items():
         if k.startswith('gn_') and float(v) > 0:
             check('simple.grad_norm', abs(float(params[k[3:]].grad.norm()) - float(v)) / (float(v) + 1e-9), 3e-4)
+
+
+@pytest.mark.parametrize('n_obj', [3, 6])
+def test_recognition_network_in_row_chunks_equals_the_unchunked_chain(n_obj):
+    """ops._encoder_lstm_fwd_chunked / _bwd_chunked (reference encoder.py:43-57): the recognition network's chain over two row
+    chunks on two streams.  Forward: bit-identical to the unchunked chain (row-wise the same kernels).  Backward (with the
+    arena's gradient views, as the training step runs it): equal to the unchunked backward up to the summation order of the
+    products that contract over the rows (dW_ih is the sum of per-chunk products)."""
+    from stove_amd import ops
+    from stove_amd.arena import ParamArena
+    from stove_amd.video_prediction.encoder import RnnStates
+    from test_gpu_dynamics import make_cfg
+    n = 8192
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(n, 1, 32, 32, generator=g).to(DEV)
+    w = torch.randn(n, n_obj, 8, generator=g).to(DEV)
+    saved = ops.ENC_CHUNKS, ops.ENC_CHUNKS_BWD
+    res = {}
+    try:
+        for mode, (cf, cb) in (('plain', (1, False)), ('chunked', (2, True)), ('fwd_only', (2, False))):
+            ops.ENC_CHUNKS, ops.ENC_CHUNKS_BWD = cf, cb
+            torch.manual_seed(5)
+            enc = RnnStates(make_cfg(num_obj=n_obj)).to(DEV)
+            arena = ParamArena(enc)
+            assert (ops._enc_chunks(n, 1024, 256) is not None) == (cf > 1)
+            arena.zero()
+            out = enc(x)
+            (out * w).sum().backward()
+            torch.cuda.synchronize()
+            res[mode] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in enc.named_parameters()})
+    finally:
+        ops.ENC_CHUNKS, ops.ENC_CHUNKS_BWD = saved
+    for mode in ('chunked', 'fwd_only'):
+        assert torch.equal(res[mode][0], res['plain'][0]), mode
+    for k, gp in res['plain'][1].items():
+        assert torch.equal(res['fwd_only'][1][k], gp), k
+        # other summation orders: dW_ih per chunk, and at this size the unchunked dg W_hh splits K (ops.gemm_bf16's short-batch rule)
+        gc = res['chunked'][1][k]
+        assert float((gc - gp).abs().max()) <= 2e-6 * float(gp.abs().max()), (k, float((gc - gp).abs().max()), float(gp.abs().max()))
