@@ -1374,6 +1374,7 @@ FAST_CELL = int(os.environ.get('STOVE_LSTM_FAST_CELL', '1') != '0')
 
 ENC_CHUNKS = int(os.environ.get('STOVE_ENC_CHUNKS', '2'))
 ENC_STAGGER = os.environ.get('STOVE_ENC_STAGGER', '0') != '0'
+ENC_STREAMS = int(os.environ.get('STOVE_ENC_STREAMS', '2'))
 ENC_SPLIT = os.environ.get('STOVE_ENC_SPLIT', '')          # shares of the rows per chunk, e.g. "64,36" (A/B; default: equal chunks)
 
 
@@ -1404,7 +1405,7 @@ def _encoder_lstm_fwd_chunked(lib, x, w_ih, w_hh, bias, hs, cs, num_steps, ns, c
     n, D = x.shape
     H = w_hh.shape[1]
     dev = x.device
-    main, side = torch.cuda.current_stream(dev), _side_stream(dev, 'enc')
+    main = torch.cuda.current_stream(dev)
     gss = [torch.empty(n, 4 * H, dtype=torch.float32, device=dev) for _ in range(num_steps)]
 
     def chain(r0, r1, after_first=None):
@@ -1421,23 +1422,30 @@ def _encoder_lstm_fwd_chunked(lib, x, w_ih, w_hh, bias, hs, cs, num_steps, ns, c
             check(lib.stove_lstm_cell_fwd(ptr(gss[k][r0:]), None, ptr(cs[k - 1][r0:]) if k > 0 else None, ptr(cs[k][r0:]), ptr(hs[k][r0:]),
                                           rows, H, FAST_CELL, st), 'stove_lstm_cell_fwd')
 
-    side.wait_stream(main)
+    # chunk c on stream c mod ENC_STREAMS (the main stream first)
+    sides = [_side_stream(dev, 'enc' if i == 1 else 'enc%d' % i) for i in range(1, min(ENC_STREAMS, len(chunks)))]
+    for sd in sides:
+        sd.wait_stream(main)
     evs = []
 
-    def first_done():          # (A/B: the second stream's first chunk a product behind the first stream's)
+    def first_done():          # (A/B: the other streams' first chunk a product behind the main stream's)
         if ENC_STAGGER:
             ev = torch.cuda.Event()
             ev.record(main)
             evs.append(ev)
+    waited = set()
     for c, (r0, r1) in enumerate(chunks):
-        if c % 2 == 0:
+        i = c % (len(sides) + 1)
+        if i == 0:
             chain(r0, r1, first_done if c == 0 else None)
         else:
-            with torch.cuda.stream(side):
-                if c == 1 and evs:
-                    side.wait_event(evs[0])
+            with torch.cuda.stream(sides[i - 1]):
+                if evs and i not in waited:
+                    sides[i - 1].wait_event(evs[0])
+                    waited.add(i)
                 chain(r0, r1)
-    main.wait_stream(side)
+    for sd in sides:
+        main.wait_stream(sd)
     return gss
 
 
