@@ -518,7 +518,8 @@ int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, con
 
 /* ---- measurement hooks (bench.py): when enabled, every kernel launch of this library is bracketed by
  * two HIP events recorded on the launch stream.  stove_profile_report() synchronises them, writes
- * "kernel\ttotal_ms\tcount\n" lines into buf and clears the records; returns the bytes needed.
+ * "kernel\ttotal_ms\tcount\twall_ms\n" lines into buf (wall_ms: the time the kernel's launches cover -- less than their sum
+ * where launches on two streams overlap) and clears the records; returns the bytes needed.
  * This is the only process-global state of the library and it is off by default. */
 void stove_profile_enable(int on);
 size_t stove_profile_report(char* buf, size_t cap);

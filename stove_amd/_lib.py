@@ -9,7 +9,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libstove_hip.so')
 _lib = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = [
     'stove_abi_version', 'stove_error_string', 'stove_selftest_wave_sum',
@@ -234,15 +234,17 @@ def force_stream(handle):
     return prev
 
 
-def profile_report():
-    """{kernel name: (total ms, launches)} recorded since stove_profile_enable(1); clears the records."""
+def profile_report(wall=False):
+    """{kernel name: (total ms, launches)} recorded since stove_profile_enable(1); clears the records.
+    wall=True: (total ms, launches, ms covered by the launches' time spans -- less than the total where launches of the
+    kernel overlap on two streams)."""
     lib = load()
     buf = ctypes.create_string_buffer(1 << 16)
     lib.stove_profile_report(buf, len(buf))
     out = {}
     for line in buf.value.decode().splitlines():
-        name, ms, cnt = line.split('\t')
+        name, ms, cnt, cover = line.split('\t')
         name = name.strip('()').split('<')[0].split('::')[-1]
-        tot, c = out.get(name, (0.0, 0))
-        out[name] = (tot + float(ms), c + int(cnt))
-    return out
+        tot, c, w = out.get(name, (0.0, 0, 0.0))
+        out[name] = (tot + float(ms), c + int(cnt), w + float(cover))
+    return out if wall else {k: v[:2] for k, v in out.items()}

@@ -1,6 +1,7 @@
 // C ABI of libstove_hip.so (see include/stove_hip.h).  Single translation unit: the kernel
 // files are included here so every launch sees its kernel without relocatable device code.
 #include "../../include/stove_hip.h"
+#include <algorithm>
 
 #include "common.h"
 #include <string.h>
@@ -121,7 +122,7 @@ extern "C" {
 //    stove_gnn_param_floats() floats); the measurement switches are explicit setters (stove_set_overlap,
 //    stove_set_tablegrad_placement) instead of environment reads; cross-capture events are owned by the caller
 //    (stove_event_list_*).
-int stove_abi_version(void) { return 2; }
+int stove_abi_version(void) { return 3; }
 
 const char* stove_error_string(int code) { return hipGetErrorString((hipError_t)code); }
 
@@ -1563,29 +1564,60 @@ void stove_profile_enable(int on) {
 }
 
 // Synchronises every recorded event pair, aggregates by kernel name and writes lines
-// "name\ttotal_ms\tcount\n" into buf (at most cap bytes); returns the number of bytes needed.
+// "name\ttotal_ms\tcount\twall_ms\n" (wall_ms: the union of the launches' time spans) into buf (at most cap bytes); returns the
+// number of bytes needed.
 size_t stove_profile_report(char* buf, size_t cap) {
   std::lock_guard<std::mutex> g(prof_mu());
-  std::vector<std::pair<std::string, std::pair<double, long>>> agg;
-  for (auto& r : prof_recs()) {
-    (void)hipEventSynchronize(r.b);
-    float ms = 0.0f;
+  struct Agg {
+    std::string name;
+    double total = 0.0;
+    long count = 0;
+    std::vector<std::pair<double, double>> spans;      // [start, end) in ms since the first recorded launch
+  };
+  std::vector<Agg> agg;
+  auto& recs = prof_recs();
+  for (auto& r : recs) (void)hipEventSynchronize(r.b);
+  for (auto& r : recs) {
+    float ms = 0.0f, t0 = 0.0f;
     (void)hipEventElapsedTime(&ms, r.a, r.b);
-    (void)hipEventDestroy(r.a);
-    (void)hipEventDestroy(r.b);
-    bool found = false;
-    for (auto& e : agg)
-      if (e.first == r.name) {
-        e.second.first += ms;
-        e.second.second += 1;
-        found = true;
+    (void)hipEventElapsedTime(&t0, recs.front().a, r.a);
+    Agg* e = nullptr;
+    for (auto& x : agg)
+      if (x.name == r.name) {
+        e = &x;
         break;
       }
-    if (!found) agg.push_back({r.name, {ms, 1}});
+    if (e == nullptr) {
+      agg.push_back(Agg());
+      e = &agg.back();
+      e->name = r.name;
+    }
+    e->total += ms;
+    e->count += 1;
+    e->spans.push_back({(double)t0, (double)t0 + ms});
   }
-  prof_recs().clear();
+  for (auto& r : recs) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  recs.clear();
   std::string out;
-  for (auto& e : agg) out += e.first + "\t" + std::to_string(e.second.first) + "\t" + std::to_string(e.second.second) + "\n";
+  for (auto& e : agg) {
+    // launches of one kernel on two streams overlap in time (the recognition network's row chunks): the time they COVER
+    std::sort(e.spans.begin(), e.spans.end());
+    double wall = 0.0, lo = 0.0, hi = -1.0;
+    for (auto& sp : e.spans) {
+      if (hi < lo || sp.first > hi) {
+        if (hi >= lo) wall += hi - lo;
+        lo = sp.first;
+        hi = sp.second;
+      } else if (sp.second > hi) {
+        hi = sp.second;
+      }
+    }
+    if (hi >= lo) wall += hi - lo;
+    out += e.name + "\t" + std::to_string(e.total) + "\t" + std::to_string(e.count) + "\t" + std::to_string(wall) + "\n";
+  }
   if (buf != nullptr && cap > 0) {
     const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
     memcpy(buf, out.data(), n);

@@ -27,3 +27,23 @@ for n in ('bench', 'bench_store_f32', 'bench_store_u8', 'bench_onegraph', 'bench
     except Exception as e:
         print(n, 'failed', e)
 PY
+# every kernel of the median step (headline and six objects), the recursion's in-kernel stamps
+cd /tmp && export TMPDIR=/tmp
+export STOVE_BENCH_NO_PARITY=1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/all -o ks -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-variants --profile-steps 0 --step-mode graph > $OUT/all.log 2>&1
+python3 $R/tools/timeline.py $(find $OUT/all -name "*kernel_trace.csv" | head -1) 0 > $OUT/timeline_all.txt; rm -rf $OUT/all
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mb -o ks -- python3 $R/bench.py --workload multibilliards --steps 20 --warmup 3 --no-cpu-baseline --no-variants --profile-steps 0 --step-mode graph > $OUT/mb.log 2>&1
+python3 $R/tools/timeline.py $(find $OUT/mb -name "*kernel_trace.csv" | head -1) 0 > $OUT/timeline_multibilliards.txt; rm -rf $OUT/mb
+# the kernel statistics with the recognition network's forward chain on one stream: no two GEMM launches overlap (like for like with round 3)
+STOVE_ENC_CHUNKS=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/one_stream -o ks -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-variants --profile-steps 0 --step-mode graph > $OUT/one_stream.log 2>&1
+s1=$(find $OUT/one_stream -name "*kernel_stats.csv" | head -1); [ -n "$s1" ] && cp $s1 $OUT/kernel_stats_one_stream.csv; rm -rf $OUT/one_stream
+unset STOVE_BENCH_NO_PARITY
+cd $R
+timeout 200 python3 tools/loop_stamps.py > $OUT/loop_stamps.txt 2>&1
+# what profiles/ holds of this run
+for f in bench.json bench_avoidance.json bench_gravity.json bench_multibilliards.json bench_onegraph.json bench_store_f32.json bench_store_u8.json \
+         kernel_stats.csv kernel_stats_one_stream.csv kernel_times.txt loop_stamps.txt pmc_sq.json pmc_traffic.json timeline.txt timeline_all.txt timeline_eager.txt \
+         timeline_multibilliards.txt timeline_onegraph.txt; do
+  [ -s $OUT/$f ] && cp $OUT/$f $OUT/../${TAG}_final_$f
+done
+[ -s gpurun_out/parity_errors.json ] && cp gpurun_out/parity_errors.json $OUT/../${TAG}_final_parity_errors.json

@@ -19,6 +19,8 @@ s=$(find $OUT/ks -name "*kernel_stats.csv" | head -1); [ -n "$s" ] && cp $s $OUT
 python3 tools/pmc_summary.py $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $(find $OUT/write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json
 python3 tools/pmc_sq_summary.py $(find $OUT/sq -name "*counter_collection.csv" | head -1) $OUT/pmc_sq.json
 rm -rf $OUT/ks $OUT/fetch $OUT/write $OUT/sq
+# the bench line quotes roofline.traffic from profiles/*pmc_traffic.json (source-hash checked): make this run's summary the one it finds
+cp $OUT/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json
 unset STOVE_BENCH_NO_PARITY
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.log
 tail -c 900 $OUT/bench.json
