@@ -40,7 +40,9 @@ def main():
     # which sources the profiled library was built from: bench.py quotes these figures only for the same sources
     from stove_amd import build
     meta['_source_hash'] = build.source_hash()
-    meta['_steps_profiled'] = 3          # bench.py --steps 2 --warmup 1 --profile-steps 0 (tools/profile_round.sh)
+    # steps the passes held: the optimiser's kernel runs once per step (bench.py --steps 2 --warmup 1 plus the step that precedes the
+    # warm-up: four)
+    meta['_steps_profiled'] = res['flat_adam_k']['launches_profiled'] if 'flat_adam_k' in res else 3
     meta.update(res)
     json.dump(meta, open(out, 'w'), indent=1)
     print('wrote', out, len(res), 'kernels')
