@@ -468,3 +468,42 @@ def test_recognition_network_in_row_chunks_equals_the_unchunked_chain(n_obj):
         # other summation orders: dW_ih per chunk, and at this size the unchunked dg W_hh splits K (ops.gemm_bf16's short-batch rule)
         gc = res['chunked'][1][k]
         assert float((gc - gp).abs().max()) <= 2e-6 * float(gp.abs().max()), (k, float((gc - gp).abs().max()), float(gp.abs().max()))
+
+
+def test_profile_report_covered_time_of_overlapping_launches():
+    """stove_profile_report's fourth column (bench.py roofline.frac_covered): the time a kernel's launches COVER -- equal to their
+    summed time for launches in a row on one stream, less than it when two streams run them side by side."""
+    from stove_amd import _lib, ops
+    lib = _lib.load()
+    n = 25600
+    x = torch.rand(n, 1024, device=DEV)
+    w = torch.randn(1024, 1024, device=DEV) * 0.03
+    outs = [torch.empty(n // 2, 1024, device=DEV) for _ in range(2)]
+    side = torch.cuda.Stream(device=DEV)
+
+    def half(i):
+        _lib.check(lib.stove_gemm_bf16(_lib.ptr(x[i * (n // 2):]), _lib.ptr(w), None, None, _lib.ptr(outs[i]), n // 2, 1024, 1024, 1024, 1024, 1024,
+                                       0, 0, 2, 1, 3, None, _lib.stream()), 'stove_gemm_bf16')
+    for overlap in (False, True):
+        half(0); half(1)
+        torch.cuda.synchronize()
+        lib.stove_profile_enable(1)
+        try:
+            side.wait_stream(torch.cuda.current_stream(DEV))
+            half(0)
+            if overlap:
+                with torch.cuda.stream(side):
+                    half(1)
+                torch.cuda.current_stream(DEV).wait_stream(side)
+            else:
+                half(1)
+            torch.cuda.synchronize()
+            rep = _lib.profile_report(wall=True)
+        finally:
+            lib.stove_profile_enable(0)
+        total, count, covered = rep['gemm_bf16_k']
+        assert count == 2 and covered > 0.0
+        if overlap:
+            assert covered < 0.9 * total, (total, covered)          # two launches of 200 workgroups share the chip
+        else:
+            assert abs(covered - total) <= 0.02 * total, (total, covered)
