@@ -129,6 +129,24 @@ def test_replayed_step_equals_eager_step_bitwise(workload, poison):
     assert not torch.equal(ref[0][2], ref[-1][2])         # it trained
 
 
+def test_replayed_step_equals_eager_step_bitwise_with_the_forward_chain_in_row_chunks():
+    """The same at a batch big enough for the recognition network's forward to run as two row chunks on two streams
+    (ops._encoder_lstm_fwd_chunked: 8 192 frames per step), graph pools poisoned between the replays: a chunk stream that was
+    not ordered against the main one -- in the capture or in the eager step -- would read stale or poisoned rows."""
+    from stove_amd import ops
+    n_seq, T = 128, 64
+    assert ops._enc_chunks(n_seq * T, 1024, 256) is not None
+    batches = _batches('billiards', n_seq, T, 3)
+    ref, _ = _run('billiards', batches, graphed=False)
+    got, poisoned = _run('billiards', batches, graphed=True, poison=True)
+    assert poisoned > (1 << 20)
+    for i, ((e0, g0, p0, _), (e1, g1, p1, _)) in enumerate(zip(ref, got)):
+        assert torch.isfinite(e0) and float(g0.abs().max()) > 0
+        assert torch.equal(e0, e1), ('elbo', i, float(e0), float(e1))
+        assert torch.equal(g0, g1), ('gradient arena', i, float((g0 - g1).abs().max()))
+        assert torch.equal(p0, p1), ('parameters', i, float((p0 - p1).abs().max()))
+
+
 def test_replayed_step_equals_eager_step_bitwise_device_rng():
     """The same with the draws coming from the device generator inside the capture (torch's graph-safe Philox offsets): the
     replay consumes the generator exactly as the eager step does."""
