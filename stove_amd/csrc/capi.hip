@@ -122,6 +122,8 @@ extern "C" {
 //    stove_gnn_param_floats() floats); the measurement switches are explicit setters (stove_set_overlap,
 //    stove_set_tablegrad_placement) instead of environment reads; cross-capture events are owned by the caller
 //    (stove_event_list_*).
+// 3: stove_lstm_cell_bwd_rows (the cell backward on a row range of the batch); stove_profile_report lines carry a fourth column, the
+//    time the kernel's launches cover.
 int stove_abi_version(void) { return 3; }
 
 const char* stove_error_string(int code) { return hipGetErrorString((hipError_t)code); }
