@@ -11,4 +11,4 @@ import importlib.util as _u
 _spec = _u.spec_from_file_location('_golden_analytic_weights', os.path.join(_G, 'analytic_weights.py'))
 _m = _u.module_from_spec(_spec)
 _spec.loader.exec_module(_m)
-analytic_tensor, analytic_state_dict = _m.analytic_tensor, _m.analytic_state_dict
+analytic_tensor, analytic_state_dict, fan_ins, REGIMES = _m.analytic_tensor, _m.analytic_state_dict, _m.fan_ins, _m.REGIMES

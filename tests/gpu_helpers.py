@@ -2,13 +2,16 @@
 import numpy as np
 import torch
 
-from analytic_weights import analytic_tensor
+from analytic_weights import REGIMES, analytic_tensor, fan_ins  # noqa: F401
 
 
-def fill_analytic(module, prefix=''):
+def fill_analytic(module, prefix='', regime='analytic'):
+    """`regime`: one of analytic_weights.REGIMES (smooth mid-range / the reference's initial statistics / saturated)."""
     with torch.no_grad():
-        for name, p in module.named_parameters():
-            p.copy_(analytic_tensor(prefix + name, p.shape, torch.float64).to(p.dtype))
+        named = {prefix + name: p for name, p in module.named_parameters()}
+        fi = fan_ins({k: tuple(p.shape) for k, p in named.items()})
+        for name, p in named.items():
+            p.copy_(analytic_tensor(name, p.shape, torch.float64, regime, fi.get(name)).to(p.dtype))
     return module
 
 

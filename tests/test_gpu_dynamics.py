@@ -31,13 +31,21 @@ VARIANTS = {
 }
 
 
+def gname(stem, regime):
+    """fixture of a weight regime (tests/golden/analytic_weights.py): the round-1 'analytic' files carry no infix"""
+    return f'{stem}_f64' if regime == 'analytic' else f'{stem}_{regime}_f64'
+
+
+REGIME_ARENA = [('analytic', False), ('analytic', True), ('init', True), ('stress', True), ('stress', False)]
+
+
 @pytest.mark.parametrize('name', list(VARIANTS))
-@pytest.mark.parametrize('arena', [False, True])
-def test_dynamics_step(name, arena):
+@pytest.mark.parametrize('regime,arena', REGIME_ARENA)
+def test_dynamics_step(name, regime, arena):
     from stove_amd.arena import ParamArena
     from stove_amd.video_prediction.dynamics import Dynamics
-    gold = load_golden(f'g5_dynamics_{name}_f64')
-    dyn = fill_analytic(Dynamics(make_cfg(**VARIANTS[name])), 'dyn.').to(DEV)
+    gold = load_golden(gname(f'g5_dynamics_{name}', regime))
+    dyn = fill_analytic(Dynamics(make_cfg(**VARIANTS[name])), 'dyn.', regime).to(DEV)
     if arena:
         assert ParamArena(dyn).has_gnn
     s = t_(gold['s']).float().to(DEV).requires_grad_()
@@ -184,17 +192,21 @@ def _golden_noise(gold):
     return lambda kind, shape: table[kind].reshape(shape)
 
 
+REGIME_FUSED_ARENA = [('analytic', True, False), ('analytic', True, True), ('analytic', False, False), ('analytic', False, True),
+                      ('init', True, True), ('init', False, False), ('stress', True, True), ('stress', False, False)]
+
+
 @pytest.mark.parametrize('name', list(CASES))
-@pytest.mark.parametrize('fused', [True, False])
-@pytest.mark.parametrize('arena', [False, True])
-def test_stove_forward_elbo_and_grads(name, fused, arena):
+@pytest.mark.parametrize('regime,fused,arena', REGIME_FUSED_ARENA)
+def test_stove_forward_elbo_and_grads(name, regime, fused, arena):
     """`arena`: parameters / gradients as views into the flat ParamArena buffers, tables baked and gradients sunk
-    by the arena kernels -- must give the same numbers as the per-tensor autograd path."""
+    by the arena kernels -- must give the same numbers as the per-tensor autograd path.  `regime`: the weights the model is
+    filled with (smooth mid-range / the reference's initial statistics / saturated), each against the reference's own run."""
     from stove_amd.arena import ParamArena
     from stove_amd.video_prediction.stove import Stove
-    gold = load_golden(f'g7_stove_{name}_f64')
+    gold = load_golden(gname(f'g7_stove_{name}', regime))
     # fused=False: host time loop, PyTorch state chain and PyTorch ELBO assembly (the op-by-op restatement)
-    st = fill_analytic(Stove(make_cfg(fused_dynamics=fused, fused_state=fused, fused_elbo=fused, **CASES[name]))).to(DEV)
+    st = fill_analytic(Stove(make_cfg(fused_dynamics=fused, fused_state=fused, fused_elbo=fused, **CASES[name])), '', regime).to(DEV)
     if arena:
         ar = ParamArena(st)
         assert ar.has_spn and ar.has_gnn

@@ -104,24 +104,32 @@ def test_ratspn_bitwise_reproducible():
         assert torch.equal(a, b)
 
 
-def _supair_pair(n_obj, **extra):
+def _supair_pair(n_obj, regime='analytic', **extra):
     from stove_amd.video_prediction.supair import Supair
     from stove_amd.video_prediction.config import StoveConfig
-    c, structs, params = oracle_setup(torch.float64, num_obj=n_obj, **extra)
+    c, structs, params = oracle_setup(torch.float64, regime=regime, num_obj=n_obj, **extra)
     cfg = StoveConfig()
     cfg.num_obj, cfg.width, cfg.height = n_obj, 32, 32
     cfg.device, cfg.dtype, cfg.random_seed = torch.device(DEV), torch.float32, 42
     cfg.action_conditioned, cfg.action_space = False, None
     for k, v in extra.items():
         setattr(cfg, k, v)
-    sup = fill_analytic(Supair(cfg), 'sup.').to(DEV)
+    sup = fill_analytic(Supair(cfg), 'sup.', regime).to(DEV)
     return c, structs, params, sup
 
 
+def gname(stem, regime):
+    """fixture of a weight regime (tests/golden/analytic_weights.py): the round-1 'analytic' files carry no infix"""
+    return f'{stem}_f64' if regime == 'analytic' else f'{stem}_{regime}_f64'
+
+
 @pytest.mark.parametrize('n_obj,extra', [(3, {}), (6, {'overlap_beta': 100.0, 'max_obj_scale': 0.22})])
-def test_scene_likelihood_vs_reference_golden(n_obj, extra):
-    gold = load_golden(f'g4_likelihood_n{n_obj}_f64')
-    c, structs, params, sup = _supair_pair(n_obj, **extra)
+@pytest.mark.parametrize('regime', ['analytic', 'init', 'stress'])
+def test_scene_likelihood_vs_reference_golden(n_obj, extra, regime):
+    """Supair.likelihood against the reference's own numbers in three weight regimes: smooth mid-range weights, the reference's
+    initial statistics, and a saturated model (leaf variances at their bounds, near one-hot sum weights)."""
+    gold = load_golden(gname(f'g4_likelihood_n{n_obj}', regime))
+    c, structs, params, sup = _supair_pair(n_obj, regime, **extra)
     x = t_(gold['x']).float().to(DEV)
     z = t_(gold['z']).float().to(DEV).requires_grad_()
     sup.step_counter = 0

@@ -75,11 +75,20 @@ def test_masks_and_glimpses(n_obj):
 
 
 # ---------------------------------------------------------------- G4 likelihood
+# weight regimes (tests/golden/analytic_weights.py): the round-1 fixtures ('analytic', fp64 + fp32) and round 5's 'init' / 'stress' (fp64)
+REGIME_TAGS = [('analytic', 'f64', torch.float64), ('analytic', 'f32', torch.float32), ('init', 'f64', torch.float64), ('stress', 'f64', torch.float64)]
+
+
+def _gname(stem, regime, tag):
+    return f'{stem}_{tag}' if regime == 'analytic' else f'{stem}_{regime}_{tag}'
+
+
 @pytest.mark.parametrize('n_obj,extra', [(3, {}), (6, {'overlap_beta': 100.0, 'max_obj_scale': 0.22})])
-@pytest.mark.parametrize('tag,dtype,tol', [('f64', torch.float64, 1e-10), ('f32', torch.float32, 2e-5)])
-def test_scene_likelihood(n_obj, extra, tag, dtype, tol):
-    g = load_golden(f'g4_likelihood_n{n_obj}_{tag}')
-    c, structs, params = oracle_setup(dtype, num_obj=n_obj, **extra)
+@pytest.mark.parametrize('regime,tag,dtype', REGIME_TAGS)
+def test_scene_likelihood(n_obj, extra, regime, tag, dtype):
+    tol = 1e-10 if dtype == torch.float64 else 2e-5
+    g = load_golden(_gname(f'g4_likelihood_n{n_obj}', regime, tag))
+    c, structs, params = oracle_setup(dtype, regime=regime, num_obj=n_obj, **extra)
     x = t_(g['x'], dtype)
     z = t_(g['z'], dtype).requires_grad_()
     lp, bg, pl, ol = O.scene_likelihood(c, params, structs, x, z, parts=True)
@@ -99,10 +108,11 @@ def test_scene_likelihood(n_obj, extra, tag, dtype, tol):
     ('plain3', dict(num_obj=3)), ('plain6', dict(num_obj=6)),
     ('ac3', dict(num_obj=3, action_conditioned=True, action_space=9, debug_core_appearance=True)),
     ('lim4', dict(num_obj=3))])
-@pytest.mark.parametrize('tag,dtype,tol', [('f64', torch.float64, 1e-10), ('f32', torch.float32, 1e-4)])
-def test_dynamics(name, cfg, tag, dtype, tol):
-    g = load_golden(f'g5_dynamics_{name}_{tag}')
-    c, structs, params = oracle_setup(dtype, **cfg)
+@pytest.mark.parametrize('regime,tag,dtype', REGIME_TAGS)
+def test_dynamics(name, cfg, regime, tag, dtype):
+    tol = 1e-10 if dtype == torch.float64 else 1e-4
+    g = load_golden(_gname(f'g5_dynamics_{name}', regime, tag))
+    c, structs, params = oracle_setup(dtype, regime=regime, **cfg)
     s = t_(g['s'], dtype).requires_grad_()
     act = t_(g['actions'], dtype) if 'actions' in g else None
     app = t_(g['app'], dtype).requires_grad_() if 'app' in g else None
@@ -177,10 +187,11 @@ CASES = {
 
 
 @pytest.mark.parametrize('name', list(CASES))
-@pytest.mark.parametrize('tag,dtype,tol', [('f64', torch.float64, 1e-9), ('f32', torch.float32, 1e-4)])
-def test_stove_forward_and_rollout(name, tag, dtype, tol):
-    g = load_golden(f'g7_stove_{name}_{tag}')
-    c, structs, params = oracle_setup(dtype, **CASES[name])
+@pytest.mark.parametrize('regime,tag,dtype', REGIME_TAGS)
+def test_stove_forward_and_rollout(name, regime, tag, dtype):
+    tol = 1e-9 if dtype == torch.float64 else 1e-4
+    g = load_golden(_gname(f'g7_stove_{name}', regime, tag))
+    c, structs, params = oracle_setup(dtype, regime=regime, **CASES[name])
     x = t_(g['x'], dtype)
     eps = {'latent': t_(g['eps_lat'], dtype), 'std': t_(g['eps_std'], dtype),
            'steps': [t_(e, dtype) for e in g['eps_steps']]}
