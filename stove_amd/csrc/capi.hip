@@ -988,7 +988,7 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
                     int ldb, int ldc, int a_kmajor, int b_kmajor, int nsplit, int splitk, int tile, float* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (M == 0 || N == 0) return 0;
-  if (K <= 0 || splitk < 1 || (nsplit != 1 && nsplit != 2) || tile < 0 || (tile > 3 && (tile < 11 || tile > 15))) return (int)hipErrorInvalidValue;
+  if (K <= 0 || splitk < 1 || nsplit < 1 || nsplit > 3 || tile < 0 || (tile > 3 && (tile < 11 || tile > 15))) return (int)hipErrorInvalidValue;
   // tile 11 / 12: measurement variants of the 256 x 128 NT kernel (tools/gemm_bf16_bench.py): no loads in the loop / no MFMAs
   if (tile == 11 && !a_kmajor && !b_kmajor && nsplit == 2) return gemm_launch<false, false, 2, 256, 128, 1>(A, B, bias, add, C, M, N, K, lda, ldb, ldc, 1, st);
   if (tile == 12 && !a_kmajor && !b_kmajor && nsplit == 2) return gemm_launch<false, false, 2, 256, 128, 2>(A, B, bias, add, C, M, N, K, lda, ldb, ldc, 1, st);
@@ -1013,7 +1013,15 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
   const int ldo = splitk > 1 ? N : ldc;
   if (tile == 0) tile = 1;
   int rc;
-  if (scalar_bits & 1) {        // element-wise A: the two layouts fc1's backward needs (d_a1 W1 and d_a1^T h), 128 x 128 tile
+  if (nsplit == 3) {
+    // round 5: hi / lo pieces in IEEE half instead of bf16 (11 + 11 significant bits: the product is as good as an fp32 one) for
+    // operands inside half's range -- the forward products x W_ih^T, h W_hh^T of the recognition network.  K-contiguous,
+    // float4-addressable operands.
+    if (a_kmajor || b_kmajor || scalar_bits) return (int)hipErrorInvalidValue;
+    rc = tile == 3 ? gemm_launch<false, false, 2, 256, 256, 0, false, 64, 128, true>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits)
+       : tile == 1 ? gemm_launch<false, false, 2, 256, 128, 0, false, 64, 64, true>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits)
+                   : gemm_launch<false, false, 2, 128, 128, 0, false, 64, 64, true>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits);
+  } else if (scalar_bits & 1) {        // element-wise A: the two layouts fc1's backward needs (d_a1 W1 and d_a1^T h), 128 x 128 tile
     if (!b_kmajor) return (int)hipErrorInvalidValue;
     if (a_kmajor) rc = nsplit == 2 ? gemm_launch<true, true, 2, 128, 128, 0, true>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits)
                                    : gemm_launch<true, true, 1, 128, 128, 0, true>(A, B, bias, add, out, M, N, K, lda, ldb, ldo, splitk, st, scalar_bits);

@@ -42,25 +42,25 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Lane exchanges over 16 and 32 lanes with gfx950's v_permlane16_swap / v_permlane32_swap (one VALU instruction each on two
 // copies of the value; a ds_bpermute / __shfl_xor is an LDS round trip, ~100+ cycles on a one-wave-per-SIMD serial chain).
 // As inline asm: hipcc 7.2 hands back the first result of __builtin_amdgcn_permlane32_swap for both members of its pair
-// (tools/ubench/permlane32_swap.hip).  Every lane of the wave has to be active.
+// (tools/ubench/permlane32_swap.hip).  Every lane of the wave has to be active.  The copy, the wait states and the swap are ONE
+// asm block: a VGPR written by a VALU instruction needs two wait states before v_permlane*_swap reads it (the compiler emits
+// `s_nop 1` for its builtin), and the hazard recognizer does not look inside inline asm -- the v_mov is one wait state for the
+// value's producer, the s_nop covers the copy.
 //   v_permlane32_swap a, b: lanes 32..63 of a <-> lanes 0..31 of b      -> a = [lower | lower], b = [upper | upper]
 //   v_permlane16_swap a, b: odd 16-lane rows of a <-> even rows of b    -> a = [r0 r0 r2 r2],   b = [r1 r1 r3 r3]
 __device__ __forceinline__ float sum_xor32(float v) {          // v + (value of lane ^ 32)
   float a = v, b;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(b) : "v"(a));
-  asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
   return a + b;
 }
 __device__ __forceinline__ float sum_xor16(float v) {          // v + (value of lane ^ 16)
   float a = v, b;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(b) : "v"(a));
-  asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
   return a + b;
 }
 __device__ __forceinline__ float from_xor16(float v) {         // value of lane ^ 16
   float a = v, b;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(b) : "v"(a));
-  asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
   return (threadIdx.x & 16) ? a : b;
 }
 

@@ -46,17 +46,45 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   const bf16x2 v = {(__bf16)a, (__bf16)b};
   return __builtin_bit_cast(unsigned, v);
 }
-// hi / lo bf16 pieces of 4 floats: hi[2], lo[2] dwords
-template <int NSPLIT>
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+  const f16x2 v = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+// hi / lo 16-bit pieces of 4 floats: hi[2], lo[2] dwords.  F16 = false: bf16 pieces (8 + 8 significant bits, fp32's exponent range:
+// any operand, the gradients of the backward included).  F16 = true (round 5): IEEE half pieces, 11 + 11 significant bits -- the
+// two pieces carry 2^-22 of the value instead of 2^-18, i.e. the three-MFMA product is as good as an fp32 one -- for operands
+// inside half's range: the FORWARD products of the recognition network (frames in [0, 1], hidden states in (-1, 1), weights),
+// whose error the head's weights amplify into the codes (tests: the 'stress' weight regime).  Same MFMA rate, same images.
+template <int NSPLIT, bool F16 = false>
 __device__ __forceinline__ void split4(const float4 v, u32x2& hi, u32x2& lo) {
-  hi.x = pack_bf16(v.x, v.y);
-  hi.y = pack_bf16(v.z, v.w);
-  if (NSPLIT == 2) {
-    const float rx = v.x - __uint_as_float(hi.x << 16), ry = v.y - __uint_as_float(hi.x & 0xffff0000u);
-    const float rz = v.z - __uint_as_float(hi.y << 16), rw = v.w - __uint_as_float(hi.y & 0xffff0000u);
-    lo.x = pack_bf16(rx, ry);
-    lo.y = pack_bf16(rz, rw);
+  if constexpr (F16) {
+    // (element-wise conversions: with the residuals taken from the packed words -- bit_cast<f16x2>(hi.x), bit_cast<f16x2>(hi.y) --
+    // hipcc 7.2 -O3 subtracts the halves of hi.x from BOTH pairs; /tmp ISA check in round 5)
+    const _Float16 hx = (_Float16)v.x, hy = (_Float16)v.y, hz = (_Float16)v.z, hw = (_Float16)v.w;
+    hi.x = __builtin_bit_cast(unsigned, f16x2{hx, hy});
+    hi.y = __builtin_bit_cast(unsigned, f16x2{hz, hw});
+    if (NSPLIT == 2) {
+      lo.x = pack_f16(v.x - (float)hx, v.y - (float)hy);
+      lo.y = pack_f16(v.z - (float)hz, v.w - (float)hw);
+    }
+  } else {
+    hi.x = pack_bf16(v.x, v.y);
+    hi.y = pack_bf16(v.z, v.w);
+    if (NSPLIT == 2) {
+      const float rx = v.x - __uint_as_float(hi.x << 16), ry = v.y - __uint_as_float(hi.x & 0xffff0000u);
+      const float rz = v.z - __uint_as_float(hi.y << 16), rw = v.w - __uint_as_float(hi.y & 0xffff0000u);
+      lo.x = pack_bf16(rx, ry);
+      lo.y = pack_bf16(rz, rw);
+    }
   }
+}
+// one 16 x 16 x 32 MFMA on two fragments of 8 sixteen-bit pieces (held as bf16x8 whatever they are)
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 // Where one thread's NLD float4 pieces of an operand tile (ROWS x 32) come from: a running pointer per piece, advanced by one
@@ -151,12 +179,12 @@ struct TileLoad {
     v[j] = *reinterpret_cast<const float4*>(ok ? src.p(j) : src.safe);
     okmask = (okmask & ~(1u << j)) | (ok ? (1u << j) : 0u);
   }
-  template <int NSPLIT, bool FULLT = false>
+  template <int NSPLIT, bool FULLT = false, bool F16 = false>
   __device__ __forceinline__ void store(char* hi_img, char* lo_img, int tid) const {
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) store_piece<NSPLIT, FULLT>(j, hi_img, lo_img, tid);
+    for (int j = 0; j < NLD; ++j) store_piece<NSPLIT, FULLT, F16>(j, hi_img, lo_img, tid);
   }
-  template <int NSPLIT, bool FULLT = false>
+  template <int NSPLIT, bool FULLT = false, bool F16 = false>
   __device__ __forceinline__ void store_piece(int j, char* hi_img, char* lo_img, int tid) const {
     {
       const int f = tid + THREADS * j;
@@ -168,7 +196,7 @@ struct TileLoad {
         off = row * 64 + ((((kq & 3) << 4) | ((kq >> 2) << 3)) ^ (((row >> 3) & 1) << 5));
       }
       u32x2 hi, lo;
-      split4<NSPLIT>((FULLT || ((okmask >> j) & 1u)) ? v[j] : float4{0.0f, 0.0f, 0.0f, 0.0f}, hi, lo);
+      split4<NSPLIT, F16>((FULLT || ((okmask >> j) & 1u)) ? v[j] : float4{0.0f, 0.0f, 0.0f, 0.0f}, hi, lo);
       *reinterpret_cast<u32x2*>(hi_img + off) = hi;
       if (NSPLIT == 2) *reinterpret_cast<u32x2*>(lo_img + off) = lo;
     }
@@ -200,7 +228,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int r0, int lane) {
 // MFMAs and a workgroup moves 2/3 of the operand bytes per flop through L2.
 // (Measured and removed, round 4: the two waves of a SIMD half a k-step apart -- one in its MFMAs while the other stages, a barrier
 // between the halves -- 169 vs 164 us warm, 178 vs 186 cold on x W_ih^T: level.  DESIGN.md section 7.)
-template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT, int BM, int BN, int DEBUG = 0, bool A_SCALAR = false, int WTM = 64, int WTN = 64>
+template <bool A_KMAJOR, bool B_KMAJOR, int NSPLIT, int BM, int BN, int DEBUG = 0, bool A_SCALAR = false, int WTM = 64, int WTN = 64, bool F16 = false>
 __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                                                const float* __restrict__ add, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
                                                                int tiles_m, int tiles_n, int splitk, int k_per_slice, int scalar_bits) {
@@ -264,8 +292,8 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
           lb1.load(sb, k_begin + kGemmBK, k_end);
         }
       }
-      la0.template store<NSPLIT, F>(img(0, 0), img(0, 1), tid);
-      lb0.template store<NSPLIT, F>(img(0, 2), img(0, 3), tid);
+      la0.template store<NSPLIT, F, F16>(img(0, 0), img(0, 1), tid);
+      lb0.template store<NSPLIT, F, F16>(img(0, 2), img(0, 3), tid);
       if constexpr (!SQ64) {          // one register set: tile 1 follows tile 0 through it
         if constexpr (F) {
           la0.load_full(sa, nt > 2);
@@ -311,19 +339,19 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
               continue;
             }
             if (NSPLIT == 2) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+              acc[i][j] = mfma16<F16>(bl[j], ah[i], acc[i][j]);
+              acc[i][j] = mfma16<F16>(bh[j], al[i], acc[i][j]);
             }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16<F16>(bh[j], ah[i], acc[i][j]);
           }
           // a quarter of the next tile's staging behind every quarter of the MFMAs
           constexpr int NA = decltype(la0)::NLD, NB = decltype(lb0)::NLD;
     #pragma unroll
           for (int q = 0; q < NA; ++q)
-            if (q % 4 == i) a_next.template store_piece<NSPLIT, F>(q, img(cur ^ 1, 0), img(cur ^ 1, 1), tid);
+            if (q % 4 == i) a_next.template store_piece<NSPLIT, F, F16>(q, img(cur ^ 1, 0), img(cur ^ 1, 1), tid);
     #pragma unroll
           for (int q = 0; q < NB; ++q)
-            if ((q + 2) % 4 == i) b_next.template store_piece<NSPLIT, F>(q, img(cur ^ 1, 2), img(cur ^ 1, 3), tid);
+            if ((q + 2) % 4 == i) b_next.template store_piece<NSPLIT, F, F16>(q, img(cur ^ 1, 2), img(cur ^ 1, 3), tid);
         }
       } else {
         // Large wave tile: the A fragments of the step stay in registers, the B fragments come one column tile at a time; the MFMAs
@@ -351,12 +379,12 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
           } else {
             if (NSPLIT == 2) {
   #pragma unroll
-              for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[i], acc[i][j], 0, 0, 0);
+              for (int i = 0; i < TM; ++i) acc[i][j] = mfma16<F16>(bl, ah[i], acc[i][j]);
   #pragma unroll
-              for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[i], acc[i][j], 0, 0, 0);
+              for (int i = 0; i < TM; ++i) acc[i][j] = mfma16<F16>(bh, al[i], acc[i][j]);
             }
   #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i][j] = mfma16<F16>(bh, ah[i], acc[i][j]);
           }
           if (j < H && DEBUG == 3) {
             // (measurement variant: the staged registers are only kept alive, not converted or written)
@@ -366,9 +394,9 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
             for (int q = 0; q < NB / H; ++q) asm volatile("" ::"v"(b_next.v[j * (NB / H) + q].x));
           } else if (j < H) {
   #pragma unroll
-            for (int q = 0; q < NA / H; ++q) a_next.template store_piece<NSPLIT, F>(j * (NA / H) + q, img(cur ^ 1, 0), img(cur ^ 1, 1), tid);
+            for (int q = 0; q < NA / H; ++q) a_next.template store_piece<NSPLIT, F, F16>(j * (NA / H) + q, img(cur ^ 1, 0), img(cur ^ 1, 1), tid);
   #pragma unroll
-            for (int q = 0; q < NB / H; ++q) b_next.template store_piece<NSPLIT, F>(j * (NB / H) + q, img(cur ^ 1, 2), img(cur ^ 1, 3), tid);
+            for (int q = 0; q < NB / H; ++q) b_next.template store_piece<NSPLIT, F, F16>(j * (NB / H) + q, img(cur ^ 1, 2), img(cur ^ 1, 3), tid);
           } else if (DEBUG != 1) {
   #pragma unroll
             for (int q = 0; q < NA / H; ++q) {
@@ -439,15 +467,15 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
 // LDS bytes of the kernel
 constexpr int gemm_lds_bytes(int nsplit, int bm, int bn) { return 2 * nsplit * (gemm_part_bytes(bm) + gemm_part_bytes(bn)); }
 
-template <bool AK, bool BK_, int NS, int BM = 256, int BN = 128, int DEBUG = 0, bool A_SCALAR = false, int WTM = 64, int WTN = 64>
+template <bool AK, bool BK_, int NS, int BM = 256, int BN = 128, int DEBUG = 0, bool A_SCALAR = false, int WTM = 64, int WTN = 64, bool F16 = false>
 static int gemm_launch(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                        int splitk, hipStream_t st, int scalar_bits = 0) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   int kper = ((K + splitk - 1) / splitk + kGemmBK - 1) / kGemmBK * kGemmBK;
-  const void* fn = (const void*)gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR, WTM, WTN>;
+  const void* fn = (const void*)gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR, WTM, WTN, F16>;
   int rc = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(NS, BM, BN));
   if (rc) return rc;
-  STOVE_LAUNCH((gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR, WTM, WTN>), dim3(tiles_m * tiles_n * splitk), dim3(BM * BN / (WTM * WTN) * 64), gemm_lds_bytes(NS, BM, BN), st, A, B, bias, add, C,
+  STOVE_LAUNCH((gemm_bf16_k<AK, BK_, NS, BM, BN, DEBUG, A_SCALAR, WTM, WTN, F16>), dim3(tiles_m * tiles_n * splitk), dim3(BM * BN / (WTM * WTN) * 64), gemm_lds_bytes(NS, BM, BN), st, A, B, bias, add, C,
                M, N, K, lda, ldb, ldc, tiles_m, tiles_n, splitk, kper, scalar_bits);
   STOVE_LAUNCH_CHECK();
   return 0;

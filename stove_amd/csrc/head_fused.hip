@@ -32,7 +32,8 @@ __device__ __forceinline__ size_t eh_orow(int row, int pn, int pk) { return pn >
 // the 16 float4 h[row c][16 q + 4 g], each a whole k-step quadruple (k = 16 q + 4 g + j for step 4 q + j): one load instruction
 // covers 64 contiguous bytes of each of the 16 rows (with k = 64 g + 4 q it touched 64 different lines for 16 B each), and
 // every byte of h crosses the memory system once.
-// SPLIT (round 4): fc1 -- 97 % of the kernel's flops -- as split-bf16 MFMAs (v_mfma_f32_16x16x32_bf16 on hi / lo pieces, three per product,
+// SPLIT (round 4; round 5: the pieces are IEEE halves, v_mfma_f32_16x16x32_f16 -- gemm_bf16.hip split4<.., true>): fc1 -- 97 % of the
+// kernel's flops -- as split 16-bit MFMAs (hi / lo pieces, three per product,
 // fp32 accumulate: the recognition network's GEMMs, gemm_bf16.hip) instead of v_mfma_f32_16x16x4_f32: 96 MFMAs of 16 cycles per 16-row
 // tile instead of 256 of 32.  The accumulator layout D[feature 4 g + r][row c] is the same for both instructions, so everything behind
 // fc1 is unchanged.  W1 sits in LDS as two bf16 images (rows of 528 bytes: conflict-free b128 fragment reads), h is split in registers.
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void enc_head_fwd_k(const float* __restrict
     const float4 wv4 = n < HID ? wst[u] : float4{0.0f, 0.0f, 0.0f, 0.0f};
     if (SPLIT) {
       u32x2 hi, lo;
-      split4<2>(wv4, hi, lo);
+      split4<2, true>(wv4, hi, lo);         // half pieces (round 5: 2^-22 of the value instead of bf16's 2^-18; W1 and h sit inside half's range)
       *reinterpret_cast<u32x2*>(img_hi + n * kEhLdB + 8 * k4) = hi;
       *reinterpret_cast<u32x2*>(img_lo + n * kEhLdB + 8 * k4) = lo;
     } else {
@@ -134,16 +135,16 @@ __global__ __launch_bounds__(256, 2) void enc_head_fwd_k(const float* __restrict
           }
         }
         u32x2 h0, l0, h1_, l1;
-        split4<2>(hb[2 * q], h0, l0);
-        split4<2>(hb[2 * q + 1], h1_, l1);
+        split4<2, true>(hb[2 * q], h0, l0);
+        split4<2, true>(hb[2 * q + 1], h1_, l1);
         const bf16x8 bhi = __builtin_bit_cast(bf16x8, u32x4{h0.x, h0.y, h1_.x, h1_.y});
         const bf16x8 blo = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[jt], bhi, acc[jt], 0, 0, 0);
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = mfma16<true>(alo[jt], bhi, acc[jt]);
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[jt], blo, acc[jt], 0, 0, 0);
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = mfma16<true>(ahi[jt], blo, acc[jt]);
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[jt], bhi, acc[jt], 0, 0, 0);
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = mfma16<true>(ahi[jt], bhi, acc[jt]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {

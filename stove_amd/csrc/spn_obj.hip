@@ -134,17 +134,27 @@ __device__ __forceinline__ float root_pair_sum(const float (&EA)[K], const float
     for (int j1 = 0; j1 < K; ++j1) sr = fmaf(EA[j1] * EB[j2], wr[j2 * K + j1], sr);
   return sr;
 }
-// root log-density of the lane's sample from the R replicas' (max, sum) pairs in LDS
+// root of the lane's sample from the R replicas' (max, sum) pairs in LDS: log-density = M + log Z.  The backward takes a
+// replica's share of the root as exp(M_r - M) / Z from the SAME rounded M_r, M and Z (M_r - M is an exact subtraction), not as
+// exp(M_r - value): the value's rounding (6e-8 of a log-density of 10^2..10^4) would sit on every gradient of the sample as a
+// common relative error (round 5, 'stress' weight regime; spn_bg.hip bgspn_root_bwd_k has the numbers).
+struct RootMZ {
+  float M, Z;
+  __device__ __forceinline__ float value() const { return M + __logf(Z); }
+  __device__ __forceinline__ float share(float Mr) const { return __expf(Mr - M) / Z; }
+};
 template <int R>
-__device__ __forceinline__ float root_value(const float* part, int lane) {
+__device__ __forceinline__ RootMZ root_mz(const float* part, int lane) {
   float M = part[lane];
 #pragma unroll
   for (int q = 1; q < R; ++q) M = fmaxf(M, part[(q * 2) * 64 + lane]);
   float Z = 0.0f;
 #pragma unroll
   for (int q = 0; q < R; ++q) Z = fmaf(part[(q * 2 + 1) * 64 + lane], __expf(part[(q * 2) * 64 + lane] - M), Z);
-  return M + __logf(Z);
+  return RootMZ{M, Z};
 }
+template <int R>
+__device__ __forceinline__ float root_value(const float* part, int lane) { return root_mz<R>(part, lane).value(); }
 // mean over the pixels of (1 - w): the overlap statistic of the glimpse
 template <int D>
 __device__ __forceinline__ float tile_overlap(const float* __restrict__ tile, int lane) {
@@ -400,6 +410,7 @@ __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
     float* __restrict__ Dscr, float* __restrict__ Sscr, float* __restrict__ Rscr, int n_samples, int n_batches) {
   constexpr int D = 4 * S;
   __shared__ float xch[R * 2 * K * 64];
+  __shared__ float part[R * 2 * 64];
   const int lane = lane_id();
   const int wv = wave_id();
   const int r = wv >> 1, side = wv & 1;
@@ -427,9 +438,15 @@ __global__ __launch_bounds__(128 * R) void objspn_bwd_k(
     }
     const int smp = b * 64 + lane;
     const bool live = smp < n_samples;
-    const float rho = live ? dout[smp] * __expf(mO + mP - out[smp]) : 0.0f;
+    // the root's (M, Z) once more (as objspn_fwd_unit_k forms them) instead of the forward's saved value `out`: see RootMZ
+    if (side == 0) {
+      part[(r * 2) * 64 + lane] = mO + mP;
+      part[(r * 2 + 1) * 64 + lane] = root_pair_sum<K>(EO, EP, wroot + r * K * K);
+    }
+    __syncthreads();
+    const float rho = live ? dout[smp] * root_mz<R>(part, lane).share(mO + mP) : 0.0f;
     side_backward<R, S, G, K>(st, EO, EP, rho, b, r, side, lane, W, WR, Dscr, Sscr, Rscr);
-    __syncthreads();   // xch reuse
+    __syncthreads();   // xch / part reuse
   }
 }
 
@@ -484,9 +501,9 @@ __global__ __launch_bounds__(128 * R) void objspn_fwd_unit_k(
       if (live) ovl[smp] = v;
     }
     __syncthreads();      // (also orders this batch's xch reads before the next batch's xch writes)
-    const float ro = root_value<R>(part, lane);       // every wave for itself: the same arithmetic as wave 0's, no third barrier
-    if (wv == 0 && live) out[smp] = ro;
-    const float rho = live ? __expf(mO + mP - ro) : 0.0f;
+    const RootMZ rt = root_mz<R>(part, lane);         // every wave for itself: the same arithmetic as wave 0's, no third barrier
+    if (wv == 0 && live) out[smp] = rt.value();
+    const float rho = live ? rt.share(mO + mP) : 0.0f;
     side_backward<R, S, G, K>(st, EO, EP, rho, b, r, side, lane, W, WR, Dscr, Sscr, Rscr);
     // part: rewritten only after the next batch's first barrier, which every wave reaches after it has read part here
   }

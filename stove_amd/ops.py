@@ -1536,6 +1536,10 @@ class _EncoderLstmFn(torch.autograd.Function):
         ns = {'bf16x3': 2, 'bf16': 1, 'fp32': 0}[gemm]
         if not gemm_ok(x.shape[1], H):
             ns = 0                               # odd sizes: library GEMMs
+        ns_bwd = ns
+        # the forward products' hi / lo pieces are IEEE halves (nsplit 3: 2^-22 of the value in two pieces instead of bf16's 2^-18;
+        # frames, hidden states and weights sit inside half's range), the backward's stay bf16 (gradients need fp32's exponent range)
+        ns = 3 if ns == 2 else ns
         with torch.cuda.device(dev):
             if ns and _enc_chunks(n, x.shape[1], H) is not None:
                 gx = None               # the chunked chains below make their own rows of it
@@ -1567,7 +1571,7 @@ class _EncoderLstmFn(torch.autograd.Function):
         ctx.save_for_backward(x, w_ih, w_hh, gx, hs, cs, b_ih, b_hh, *gss[1:])
         ctx.num_steps = num_steps
         ctx.time_major = bool(time_major)
-        ctx.ns = ns
+        ctx.ns = ns_bwd
         return hs if time_major else hs.transpose(0, 1)
 
     @staticmethod

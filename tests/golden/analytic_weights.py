@@ -8,7 +8,8 @@ only inputs/outputs; the ~1.45 M model parameters are regenerated from a formula
 * ``'init'``      the statistics the reference starts training from (what `bench.py` times): SPN leaves and sum
                   weights ~ truncated normal(0, 0.1) cut at two sigma (reference `model/spn/rat_torch.py:11-18`,
                   `:111-118`, `:250-253` with `init_fn = truncated_normal_` of `:32`), `nn.Linear` weights and biases
-                  ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)), `nn.LSTM` ~ U(-1/sqrt(hidden), 1/sqrt(hidden)) -- drawn from
+                  ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)), `nn.LSTM` ~ U(-1/sqrt(hidden), 1/sqrt(hidden)), the recognition
+                  head xavier-uniform with biases 0.1 (`model/video_prediction/encoder.py:23-26`) -- drawn from
                   numpy's frozen legacy `RandomState(crc32(name))` stream, so only the rule is committed.
 * ``'stress'``    a trained / saturated model: leaf variance parameters rho = +-8 (variances AT `obj/bg_min/max_var`,
                   reference `config.py:102-106`), sum parameters x 20 (near one-hot mixtures), leaf means over the whole
@@ -67,6 +68,11 @@ def _init_values(name, shape, fan_in):
         return 0.1 * cand[np.arange(n), first]
     if '.rnn.' in name:
         bound = 1.0 / math.sqrt(shape[0] // 4)
+    elif 'encoder.fc' in name:
+        # the recognition network's head (reference encoder.py:23-26): xavier_uniform_ weights, biases = 0.1
+        if name.endswith('.bias'):
+            return np.full(n, 0.1)
+        bound = math.sqrt(6.0 / (shape[0] + shape[1]))
     else:
         if fan_in is None:
             fan_in = shape[-1] if len(shape) > 1 else 1
