@@ -386,16 +386,11 @@ int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void*
  * own that stream -- several models per device, its own capture discipline -- hands it over here: stream != NULL = use this one,
  * NULL = run the chain on the call's stream; restore_default != 0 = back to the library-owned stream.  Thread-safe; takes effect for
  * calls enqueued afterwards.
- * ---- process state.  Everything the library keeps between calls: the fork streams above; the two switches below (A/B
- * measurements; the Python binding sets them once from STOVE_NO_OVERLAP / STOVE_PARAMS_EARLY, the library itself never reads the
- * environment); the open event list (stove_event_list_*); the profiler at the end of this header. */
+ * ---- process state.  Everything the library keeps between calls: the fork streams above; the switch below (a measurement
+ * aid; the Python binding sets it once from STOVE_NO_OVERLAP, the library itself never reads the environment); the open event list (stove_event_list_*); the profiler at the end of this header. */
 int stove_set_fork_stream(int device, void* stream, int restore_default);
 /* on = 0: no internal fork stream, every chain of a scene call on the call's stream (default 1). */
 int stove_set_overlap(int on);
-/* late = 1 (default): stove_scene_bwd_overlap / _from with a parameter stream and n_obj <= 4 hold the object SPN's table
- * gradients back until dz is out (they then run underneath whatever the caller enqueues next); 0: right behind their producer. */
-int stove_set_tablegrad_placement(int late);
-
 /* ---- stream ordering and graph replay (no reference counterpart: the reference enqueues ~6000 ATen launches per step from Python,
  * train.py:443-473; here a step is ~70 launches that a trainer replays as captured hipGraphs, stove_amd/graphed.py).
  * stove_stream_after: everything enqueued on `to` from now on runs after everything enqueued on `from` so far.  Plain streams: an
@@ -463,7 +458,9 @@ int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* ex
  * GEMMs on the bf16 matrix cores:  C[m][n] = sum_k a(m,k) b(n,k) (+ bias[n]) (+ add[m*ldc + n]),  a(m,k) = A[m*lda + k], or A[k*lda + m] when
  * a_kmajor (the operand is stored K-major, as dg / x are in the weight-gradient products dW = dg^T x); b likewise.
  * nsplit = 2: every fp32 operand element is split on the fly into bf16 hi + lo and the product is three bf16 MFMAs with fp32
- * accumulation (~2^-16 relative per product); nsplit = 1: plain bf16 operands (2^-8), fp32 accumulate.  A, B, bias, C stay fp32.
+ * accumulation (~2^-18 relative per product); nsplit = 3: the same with IEEE-half pieces (~2^-22: an fp32-grade product) for
+ * operands inside half's range -- K-contiguous, float4-addressable operands only; nsplit = 1: plain bf16 operands (2^-8), fp32
+ * accumulate.  A, B, bias, C stay fp32.
  * splitk > 1: K is cut into `splitk` slices computed by different workgroups into ws (stove_gemm_bf16_ws_floats floats), then
  * summed in slice order into C (needs ldc == N, bias and add NULL): fills the chip when M x N is small and K huge (weight gradients).
  * tile: workgroup tile, 0 = chosen by the library, 1 = 256 x 128 (8 waves), 2 = 128 x 128 (4 waves), 3 = 256 x 256 (8 waves of
@@ -487,31 +484,16 @@ int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, f
 int stove_lstm_cell_bwd(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
                         const float* dc_in, float* dg, float* dc_out, float* dgx_sum, const float* dg_more, int n_more, int n, int H,
                         int fast, void* stream);
-/* the same on a row range of the batch: every pointer already offset to the range's first row, n = rows of the range,
- * more_stride = floats between dg_more[m] and dg_more[m + 1] (the whole batch's rows x 4H).  The recognition network's chain
- * is row-wise independent; the host runs it in two row chunks on two streams (ops._EncoderLstmFn). */
-int stove_lstm_cell_bwd_rows(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
-                             const float* dc_in, float* dg, float* dc_out, float* dgx_sum, const float* dg_more, int n_more,
-                             size_t more_stride, int n, int H, int fast, void* stream);
-
-/* ---- output head of RnnStates behind fc1 (encoder.py:53-56: zps = fc2(sigmoid(fc1(output)))).  a1 (rows, H1) = fc1
- * pre-activations (library GEMM) -> h1 = sigmoid(a1) (rows, H1) and codes (rows, OUT) = h1 W2^T + b2; W2 (OUT, H1).
- * bwd: dcodes (rows, OUT) -> d_a1 (rows, H1) = dL/d a1 and g_w2b1b2 = [dW2 (OUT*H1) | db1 (H1) | db2 (OUT)] (db1 = column sums
- * of d_a1, i.e. fc1's bias gradient); ws: stove_head_bwd_ws_floats floats.  H1 <= 64, OUT <= 8.  Fixed summation order. */
-int stove_head_fwd(const float* a1, const float* W2, const float* b2, float* h1, float* codes, int rows, int H1, int OUT, void* stream);
-size_t stove_head_bwd_ws_floats(int rows, int H1, int OUT);
-int stove_head_bwd(const float* dcodes, const float* h1, const float* W2, float* d_a1, float* g_w2b1b2, float* ws, int rows, int H1,
-                   int OUT, void* stream);
-
 /* ---- the whole output head of RnnStates in one kernel each way (encoder.py:53-56), csrc/head_fused.hip: fc1, sigmoid and fc2 on the
- * fp32 matrix-core instructions (fp32 operands and accumulation, nothing is rounded below fp32); H must be 256, HID <= 64, OUT 8.
+ * matrix cores; H must be 256, HID <= 64, OUT 8.  fc1_split != 0 (the default path): fc1's forward products as three MFMAs on IEEE-half
+ * hi / lo pieces (2^-22 of the value per product, as stove_gemm_bf16 nsplit = 3); 0: on the fp32 MFMA like everything else of the head.
  * fwd: h (rows, H) -> h1 = sigmoid(h W1^T + b1) (rows, HID) and codes (rows, OUT) = h1 W2^T + b2; W1 (HID, H), W2 (OUT, HID).
  * bwd: dcodes (rows, OUT), h1, h -> gh (rows, H) = dL/dh and the parameter gradients gW1 (HID, H), gb1 (HID), gW2 (OUT, HID),
  * gb2 (OUT); accumulate != 0: added to what the four tensors hold (gradient views of a flat arena).  ws:
  * stove_enc_head_bwd_ws_floats floats.  Fixed summation order.  frames > 0: h, h1, gh are step-major (row = step * frames + frame,
  * as the LSTM writes them) while codes / dcodes are frame-major (row = frame * steps + step, encoder.py:57); 0: same row order. */
 int stove_enc_head_fwd(const float* h, const float* W1, const float* b1, const float* W2, const float* b2, float* h1, float* codes, int rows,
-                       int H, int HID, int OUT, int frames, void* stream);
+                       int H, int HID, int OUT, int frames, int fc1_split, void* stream);
 size_t stove_enc_head_bwd_ws_floats(int rows, int HID);
 int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, const float* W1, const float* W2, float* gh, float* gW1,
                        float* gb1, float* gW2, float* gb2, int accumulate, float* ws, int rows, int H, int HID, int OUT, int frames, void* stream);

@@ -9,7 +9,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libstove_hip.so')
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = [
     'stove_abi_version', 'stove_error_string', 'stove_selftest_wave_sum',
@@ -18,13 +18,13 @@ EXPORTS = [
     'stove_scene_saved_floats', 'stove_scene_fwd', 'stove_scene_bwd_ws_bytes', 'stove_scene_bwd',
     'stove_scene_glimpses',
     'stove_gnn_param_floats', 'stove_gnn_grad_floats', 'stove_gnn_blocks', 'stove_gnn_fwd', 'stove_gnn_bwd_ws_bytes',
-    'stove_gnn_bwd', 'stove_dynloop_act_floats', 'stove_dynloop_fwd', 'stove_dynloop_bwd_ws_bytes', 'stove_dynloop_bwd', 'stove_rollout_fwd', 'stove_match_objects', 'stove_profile_enable', 'stove_profile_report', 'stove_gnn_debug_stamps', 'stove_lstm_cell_fwd', 'stove_lstm_cell_bwd', 'stove_lstm_cell_bwd_rows',
+    'stove_gnn_bwd', 'stove_dynloop_act_floats', 'stove_dynloop_fwd', 'stove_dynloop_bwd_ws_bytes', 'stove_dynloop_bwd', 'stove_rollout_fwd', 'stove_match_objects', 'stove_profile_enable', 'stove_profile_report', 'stove_gnn_debug_stamps', 'stove_lstm_cell_fwd', 'stove_lstm_cell_bwd',
     'stove_spn_bake', 'stove_spn_bake_bwd', 'stove_arena_gather', 'stove_arena_scatter_add', 'stove_debug_set_stamps',
-    'stove_supair_state_fwd', 'stove_supair_state_bwd', 'stove_zall_fwd', 'stove_zall_bwd', 'stove_elbo_fwd', 'stove_elbo_bwd', 'stove_flat_adam', 'stove_flat_adam_ws_bytes', 'stove_gemm_bf16', 'stove_gemm_bf16_ws_floats', 'stove_sum_chunks', 'stove_colsum_ws_floats', 'stove_colsum', 'stove_bw_transform', 'stove_dynloop_bwd_ws_bytes_ts', 'stove_scene_bwd_overlap', 'stove_dynloop_bwd_overlap', 'stove_glimpse_mean', 'stove_objspn_mpe', 'stove_render_frames', 'stove_head_fwd', 'stove_head_bwd_ws_floats', 'stove_head_bwd',
+    'stove_supair_state_fwd', 'stove_supair_state_bwd', 'stove_zall_fwd', 'stove_zall_bwd', 'stove_elbo_fwd', 'stove_elbo_bwd', 'stove_flat_adam', 'stove_flat_adam_ws_bytes', 'stove_gemm_bf16', 'stove_gemm_bf16_ws_floats', 'stove_sum_chunks', 'stove_colsum_ws_floats', 'stove_colsum', 'stove_bw_transform', 'stove_dynloop_bwd_ws_bytes_ts', 'stove_scene_bwd_overlap', 'stove_dynloop_bwd_overlap', 'stove_glimpse_mean', 'stove_objspn_mpe', 'stove_render_frames',
     'stove_enc_head_fwd', 'stove_enc_head_bwd_ws_floats', 'stove_enc_head_bwd', 'stove_colsum2', 'stove_small_tn', 'stove_small_tn_ws_floats', 'stove_supair_state_fwd2', 'stove_supair_state_bwd2', 'stove_bg_dense', 'stove_bg_dense_floats',
     'stove_bw_transform_u8', 'stove_stream_after', 'stove_capture_begin', 'stove_capture_end', 'stove_graph_instantiate', 'stove_graph_launch', 'stove_graph_destroy',
     'stove_reward_head_param_floats', 'stove_reward_head_saved_floats', 'stove_reward_head_bwd_ws_floats', 'stove_reward_head_fwd',
-    'stove_bgspn_saved_floats_d', 'stove_bgspn_fwd_d', 'stove_bgspn_bwd_ws_bytes_d', 'stove_bgspn_bwd_d', 'stove_noise_normal', 'stove_set_overlap', 'stove_set_tablegrad_placement', 'stove_event_list_begin', 'stove_event_list_end', 'stove_event_list_destroy', 'stove_fill_words',
+    'stove_bgspn_saved_floats_d', 'stove_bgspn_fwd_d', 'stove_bgspn_bwd_ws_bytes_d', 'stove_bgspn_bwd_d', 'stove_noise_normal', 'stove_set_overlap', 'stove_event_list_begin', 'stove_event_list_end', 'stove_event_list_destroy', 'stove_fill_words',
     'stove_reward_head_bwd', 'stove_small_linear', 'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_fwd_floats', 'stove_gauss_ll_fwd', 'stove_gauss_ll_bwd', 'stove_objspn_saved_floats_any', 'stove_objspn_bwd_ws_bytes_any', 'stove_objspn_fwd_any', 'stove_objspn_bwd_any', 'stove_scene_saved_floats_any', 'stove_scene_bwd_ws_bytes_any', 'stove_scene_fwd_any', 'stove_scene_bwd_any', 'stove_scene_bwd_from', 'stove_dynloop_range_ok', 'stove_dynloop_fwd_range', 'stove_dynloop_bwd_range', 'stove_zall_fwd_range', 'stove_zall_bwd_range',
 ]
 
@@ -98,7 +98,6 @@ def _declare(lib):
         'stove_profile_enable': (None, [I]),
         'stove_lstm_cell_fwd': (I, [P, P, P, P, P, I, I, I, P]),
         'stove_lstm_cell_bwd': (I, [P] * 10 + [I, I, I, I, P]),
-        'stove_lstm_cell_bwd_rows': (I, [P] * 10 + [I, S, I, I, I, P]),
         'stove_gnn_debug_stamps': (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
         'stove_profile_report': (S, [c_char_p, S]),
         'stove_spn_bake': (I, [P, A, P, P, P, P, P, P]),
@@ -107,10 +106,7 @@ def _declare(lib):
         'stove_glimpse_mean': (I, [P, P, P, I, I, I, P]),
         'stove_objspn_mpe': (I, [T, P, P, P, P, P, I, P]),
         'stove_render_frames': (I, [P, P, I, P, P, I, I, P]),
-        'stove_head_fwd': (I, [P, P, P, P, P, I, I, I, P]),
-        'stove_head_bwd_ws_floats': (S, [I, I, I]),
-        'stove_head_bwd': (I, [P, P, P, P, P, P, I, I, I, P]),
-        'stove_enc_head_fwd': (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+        'stove_enc_head_fwd': (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
         'stove_enc_head_bwd_ws_floats': (S, [I, I]),
         'stove_enc_head_bwd': (I, [P, P, P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
         'stove_colsum2': (I, [P, P, P, I, P, I, I, P]),
@@ -133,7 +129,6 @@ def _declare(lib):
         'stove_bgspn_bwd_ws_bytes_d': (S, [I, I]),
         'stove_bgspn_bwd_d': (I, [T, P, P, P, P, P, P, P, G, P, I, I, P]),
         'stove_set_overlap': (I, [I]),
-        'stove_set_tablegrad_placement': (I, [I]),
         'stove_event_list_begin': (P, []),
         'stove_event_list_end': (I, [P]),
         'stove_event_list_destroy': (I, [P]),
@@ -195,8 +190,8 @@ def load():
             raise RuntimeError(f'{LIB_PATH} has ABI version {lib.stove_abi_version()}, this binding needs {ABI_VERSION}: '
                                'rebuild it with `python -m stove_amd.build --force`')
         # the A/B measurement switches live in the binding, not in the library (which never reads the environment)
-        lib.stove_set_overlap(0 if os.environ.get('STOVE_NO_OVERLAP', '0') == '1' else 1)
-        lib.stove_set_tablegrad_placement(0 if os.environ.get('STOVE_PARAMS_EARLY', '0') == '1' else 1)
+        from . import settings
+        lib.stove_set_overlap(1 if settings.OVERLAP else 0)
         _lib = lib
     return _lib
 

@@ -18,12 +18,12 @@ Contract: build the arena AFTER the model is on its device / dtype, zero gradien
 kernels check that the views are intact and raise otherwise.
 """
 import ctypes
-import os
 
 import torch
 import torch.distributed as dist
 
 from . import _lib, ops
+from . import settings as _settings
 
 
 def _unique_params(module):
@@ -182,7 +182,7 @@ class ParamArena:
         """Bake the SPN tables and gather the GNN parameter image(s) on the second stream NOW (called at the top of
         Stove.forward): they depend on the parameters only, so their two small launches leave the critical path between the
         recognition network and the recursion / the scene likelihood.  Consumed once by spn_tables() / gnn_image()."""
-        if not self._on_gpu or os.environ.get('STOVE_NO_OVERLAP', '0') == '1':
+        if not self._on_gpu or not _settings.OVERLAP:
             return
         dev = self.data.device
         main, side = torch.cuda.current_stream(dev), ops._side_stream(dev, 'pre')      # its own stream: joined again inside the forward

@@ -120,11 +120,12 @@ extern "C" {
 
 // 2: the GNN parameter image carries the LDS-order weight sections ([W | W^T | vectors | W packed | W^T packed],
 //    stove_gnn_param_floats() floats); the measurement switches are explicit setters (stove_set_overlap,
-//    stove_set_tablegrad_placement) instead of environment reads; cross-capture events are owned by the caller
+//    ...) instead of environment reads; cross-capture events are owned by the caller
 //    (stove_event_list_*).
-// 3: stove_lstm_cell_bwd_rows (the cell backward on a row range of the batch); stove_profile_report lines carry a fourth column, the
-//    time the kernel's launches cover.
-int stove_abi_version(void) { return 3; }
+// 3: stove_profile_report lines carry a fourth column, the time the kernel's launches cover.
+// 4 (round 5): stove_gemm_bf16 takes nsplit = 3 (half pieces); the A/B entry points whose losing side is recorded are gone
+//    (stove_set_tablegrad_placement, stove_lstm_cell_bwd_rows).
+int stove_abi_version(void) { return 4; }
 
 const char* stove_error_string(int code) { return hipGetErrorString((hipError_t)code); }
 
@@ -223,7 +224,6 @@ static bool g_fork_user_set[16] = {false};
 static std::mutex g_fork_mu;
 
 static std::atomic<int> g_overlap{1};            // stove_set_overlap
-static std::atomic<int> g_tablegrad_late{1};     // stove_set_tablegrad_placement
 
 static hipStream_t scene_fork_stream(hipStream_t st) {
   static hipStream_t side[16] = {nullptr};
@@ -236,19 +236,12 @@ static hipStream_t scene_fork_stream(hipStream_t st) {
   return side[dev];
 }
 
-// Measurement switches (explicit state instead of environment reads; defaults 1 / 1).
+// Measurement switch (explicit state instead of an environment read; default 1).
 // overlap 0: the scene calls run their background-SPN chain on the call's stream (no internal fork at all).
 int stove_set_overlap(int on) {
   g_overlap.store(on != 0, std::memory_order_relaxed);
   return 0;
 }
-// late 1 (default): with a parameter stream and up to four objects the object SPN's table gradients are held back until dz is
-// out and run underneath what the caller enqueues next (objspn_tablegrad_under_k); 0: right behind their producer.
-int stove_set_tablegrad_placement(int late) {
-  g_tablegrad_late.store(late != 0, std::memory_order_relaxed);
-  return 0;
-}
-
 // The caller owns the fork stream of `device` from now on (the scene calls run their background-SPN chain on it, forked from and joined
 // into the call's stream): stream != NULL -- use this one; NULL -- no internal fork, everything on the call's stream.
 // restore_default != 0: back to the library-owned stream that is created on first use.
@@ -331,13 +324,11 @@ static SceneWs scene_ws_layout(int nf, int n_obj) {
 
 size_t stove_scene_bwd_ws_bytes(int n_frames, int n_obj) { return scene_ws_layout(n_frames, n_obj).total * sizeof(float); }
 
-// Where the object-SPN table gradients run when the caller gives a parameter stream.  Default: held back until dz is out, then
-// underneath the recursion's backward as objspn_tablegrad_under_k (one wave per SIMD in the registers and LDS that kernel
-// leaves free).  Measured (gpurun_out/late, B = 256): the SPN backward phase 600 -> 495 us without them, the recursion's
-// backward 470 -> 545 us with them on its SIMDs (MFMA pipe and L1 shared; raising the chain's wave priority changes
-// nothing), the step 3.273 -> 3.254 ms.  STOVE_PARAMS_EARLY=1: right behind their producer, next to pix / bgspn_bwd
-// (the round-1 placement, objspn_tablegrad_k).
-static int params_late() { return g_tablegrad_late.load(std::memory_order_relaxed); }
+// Where the object-SPN table gradients run when the caller gives a parameter stream: with up to four objects they are held back
+// until dz is out and then run underneath the recursion's backward as objspn_tablegrad_under_k (one wave per SIMD in the registers
+// and LDS that kernel leaves free).  Measured in round 2 (B = 256): the SPN backward phase 600 -> 495 us without them, the
+// recursion's backward 470 -> 545 us with them on its SIMDs, the step 3.273 -> 3.254 ms.  (The round-1 placement -- right behind
+// their producer, next to pix / bgspn_bwd -- was a switch until round 5.)
 
 size_t stove_bg_dense_floats(void) { return (size_t)kBgDenseF; }
 int stove_bg_dense(const int32_t* bg_side, const float* bg_coef, float* dense, void* stream) {
@@ -381,11 +372,11 @@ int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const flo
   // The object SPN's backward already ran, at unit upstream gradient, inside the forward (objspn_fwd_unit_k): what is left is to
   // apply d_obj[patch] where its scratch is consumed -- the tail below and the table gradients.
   int rc = 0;
-  // The object-SPN table gradients go to the parameter stream: once dz is out (underneath what the caller enqueues next,
-  // the recursion's backward), or (STOVE_PARAMS_EARLY=1) right behind their producer.
+  // The object-SPN table gradients go to the parameter stream once dz is out (underneath what the caller enqueues next, the
+  // recursion's backward) ...
   // ... for up to four objects: the small-graph recursion (gnn_small*.hip) is the latency-bound kernel with room beside it; the
   // six/eight-object recursion (gnn.hip) fills the matrix pipe itself and was stretched 2.49 -> 3.20 ms by a co-runner
-  const bool late = sp != st && params_late() && n_obj <= 4;
+  const bool late = sp != st && n_obj <= 4;
   if (!late) {
     STOVE_TRY(stream_after(sp, st));
     rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, saved + L.obj_scratch, ws + W.obj,
@@ -1431,48 +1422,6 @@ int stove_elbo_bwd(const float* zs, const float* mean, const float* std_, const 
 
 // ---------------------------------------------------------------- LSTM cell (recognition network)
 // ---------------------------------------------------------------- recognition-network head
-static inline int head_waves(int H1, bool bwd) {
-  const size_t per_wave = (size_t)(64 * (H1 | 1) + (bwd ? 64 * kHeadOut : 0)) * sizeof(float);
-  const int w = (int)((65536 - kHeadHid * kHeadOut * sizeof(float)) / per_wave);
-  return w > 4 ? 4 : w;
-}
-static inline int head_grid(int rows, int nw) {
-  const int tiles = (rows + 63) / 64, blocks = (tiles + nw - 1) / nw;
-  return blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048;
-}
-
-int stove_head_fwd(const float* a1, const float* W2, const float* b2, float* h1, float* codes, int rows, int H1, int OUT, void* stream) {
-  if (H1 < 1 || H1 > kHeadHid || OUT < 1 || OUT > kHeadOut) return (int)hipErrorInvalidValue;
-  if (rows == 0) return 0;
-  const int nw = head_waves(H1, false);
-  STOVE_LAUNCH(head_fwd_k, dim3(head_grid(rows, nw)), dim3(64 * nw), (size_t)(kHeadHid * kHeadOut + nw * 64 * (H1 | 1)) * sizeof(float), (hipStream_t)stream,
-               a1, W2, b2, h1, codes, rows, H1, OUT);
-  STOVE_LAUNCH_CHECK();
-  return 0;
-}
-
-size_t stove_head_bwd_ws_floats(int rows, int H1, int OUT) {
-  return (size_t)head_grid(rows, head_waves(H1, true)) * (OUT * H1 + H1 + OUT) + 4;
-}
-
-int stove_head_bwd(const float* dcodes, const float* h1, const float* W2, float* d_a1, float* g_w2b1b2, float* ws, int rows, int H1,
-                   int OUT, void* stream) {
-  if (H1 < 1 || H1 > kHeadHid || OUT < 1 || OUT > kHeadOut) return (int)hipErrorInvalidValue;
-  hipStream_t st = (hipStream_t)stream;
-  const int n_out = OUT * H1 + H1 + OUT;
-  if (rows == 0) {
-    hipMemsetAsync(g_w2b1b2, 0, sizeof(float) * n_out, st);
-    return 0;
-  }
-  const int nw = head_waves(H1, true), grid = head_grid(rows, nw);
-  STOVE_LAUNCH(head_bwd_k, dim3(grid), dim3(64 * nw), (size_t)(kHeadHid * kHeadOut + nw * (64 * (H1 | 1) + 64 * kHeadOut)) * sizeof(float), st,
-               dcodes, h1, W2, d_a1, ws, rows, H1, OUT);
-  STOVE_LAUNCH_CHECK();
-  STOVE_LAUNCH(reduce_chunks_k, dim3((n_out + 31) / 32), dim3(256), 0, st, ws, g_w2b1b2, n_out, grid, 0);
-  STOVE_LAUNCH_CHECK();
-  return 0;
-}
-
 // ---- fused output head (csrc/head_fused.hip): H = 256, HID <= 64, OUT = 8 ------------------------------------------------------
 static int enc_head_groups(int rows) {
   const int tiles = (rows + 15) / 16;
@@ -1482,16 +1431,23 @@ static int enc_head_groups(int rows) {
 }
 
 int stove_enc_head_fwd(const float* h, const float* W1, const float* b1, const float* W2, const float* b2, float* h1, float* codes, int rows,
-                       int H, int HID, int OUT, int frames, void* stream) {
+                       int H, int HID, int OUT, int frames, int fc1_split, void* stream) {
   if (H != kEhH || HID < 1 || HID > kEhHid || OUT != kEhOut || frames < 0 || (frames > 0 && rows % frames != 0)) return (int)hipErrorInvalidValue;
   if (rows == 0) return 0;
   static_assert(2 * kEhHid * kEhLdB == sizeof(float) * kEhHid * kEhLd, "the two bf16 images of W1 take the fp32 image's place");
   const size_t lds = sizeof(float) * kEhHid * kEhLd;
-  int rc = (int)hipFuncSetAttribute((const void*)enc_head_fwd_k<kEhFc1Split>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (rc) return rc;
   const int tiles = (rows + 15) / 16;
   const int grid = (tiles + 3) / 4 < 512 ? (tiles + 3) / 4 : 512;
-  STOVE_LAUNCH((enc_head_fwd_k<kEhFc1Split>), dim3(grid), dim3(256), lds, (hipStream_t)stream, h, W1, b1, W2, b2, h1, codes, rows, HID, frames);
+  int rc;
+  if (fc1_split) {       // fc1 as three half-piece MFMAs per product (the default); else on v_mfma_f32_16x16x4_f32 (encoder_gemm = 'fp32')
+    rc = (int)hipFuncSetAttribute((const void*)enc_head_fwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc) return rc;
+    STOVE_LAUNCH((enc_head_fwd_k<true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, h, W1, b1, W2, b2, h1, codes, rows, HID, frames);
+  } else {
+    rc = (int)hipFuncSetAttribute((const void*)enc_head_fwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc) return rc;
+    STOVE_LAUNCH((enc_head_fwd_k<false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, h, W1, b1, W2, b2, h1, codes, rows, HID, frames);
+  }
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -1513,13 +1469,9 @@ int stove_enc_head_bwd(const float* dcodes, const float* h1, const float* h, con
     return 0;
   }
   const int groups = enc_head_groups(rows);
-  const size_t lds = sizeof(float) * (kEhBwdSplit ? kEhBwdLdsS : kEhBwdLds);
+  const size_t lds = sizeof(float) * kEhBwdLds;
   int rc;
-  if (kEhBwdSplit) {
-    rc = (int)hipFuncSetAttribute((const void*)enc_head_bwd_k<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (rc) return rc;
-    STOVE_LAUNCH((enc_head_bwd_k<16, true>), dim3(groups * 5), dim3(256), lds, st, dcodes, h1, h, W1, W2, gh, ws, rows, HID, groups, frames);
-  } else if (HID <= 50) {
+  if (HID <= 50) {
     rc = (int)hipFuncSetAttribute((const void*)enc_head_bwd_k<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc) return rc;
     STOVE_LAUNCH(enc_head_bwd_k<14>, dim3(groups * 5), dim3(256), lds, st, dcodes, h1, h, W1, W2, gh, ws, rows, HID, groups, frames);
@@ -1549,14 +1501,9 @@ int stove_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, f
 int stove_lstm_cell_bwd(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
                         const float* dc_in, float* dg, float* dc_out, float* dgx_sum, const float* dg_more, int n_more, int n, int H,
                         int fast, void* stream) {
-  return stove_lstm_cell_bwd_rows(gx, gh, c_prev, c, dh, dc_in, dg, dc_out, dgx_sum, dg_more, n_more, (size_t)n * 4 * H, n, H, fast, stream);
-}
-
-int stove_lstm_cell_bwd_rows(const float* gx, const float* gh, const float* c_prev, const float* c, const float* dh,
-                             const float* dc_in, float* dg, float* dc_out, float* dgx_sum, const float* dg_more, int n_more,
-                             size_t more_stride, int n, int H, int fast, void* stream) {
   if (n == 0) return 0;
-  if (H % 4 || n_more < 0 || (n_more > 0 && (dg_more == nullptr || more_stride < (size_t)n * 4 * H))) return (int)hipErrorInvalidValue;
+  if (H % 4 || n_more < 0 || (n_more > 0 && dg_more == nullptr)) return (int)hipErrorInvalidValue;
+  const size_t more_stride = (size_t)n * 4 * H;
   const size_t total = (size_t)n * (H / 4);
   const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   if (fast) STOVE_LAUNCH(lstm_cell_bwd_k<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gx, gh, c_prev, c, dh, dc_in, dg, dc_out, dgx_sum, dg_more,

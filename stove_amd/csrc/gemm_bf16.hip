@@ -60,14 +60,20 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {
 template <int NSPLIT, bool F16 = false>
 __device__ __forceinline__ void split4(const float4 v, u32x2& hi, u32x2& lo) {
   if constexpr (F16) {
-    // (element-wise conversions: with the residuals taken from the packed words -- bit_cast<f16x2>(hi.x), bit_cast<f16x2>(hi.y) --
-    // hipcc 7.2 -O3 subtracts the halves of hi.x from BOTH pairs; /tmp ISA check in round 5)
-    const _Float16 hx = (_Float16)v.x, hy = (_Float16)v.y, hz = (_Float16)v.z, hw = (_Float16)v.w;
-    hi.x = __builtin_bit_cast(unsigned, f16x2{hx, hy});
-    hi.y = __builtin_bit_cast(unsigned, f16x2{hz, hw});
+    // hi = v_cvt_pk_f16_f32 (round to nearest even), residual x - (float)hi as ONE v_fma_mix_f32 per element (the half operand is
+    // converted inside the instruction: fma(hi_half, -1, x), exact), lo = v_cvt_pk_f16_f32 of the residuals: 8 instructions per
+    // float4 (the bf16 form below takes 12).  Inline asm: written in C++ with the residuals taken from the packed words, hipcc 7.2
+    // -O3 subtracts the halves of hi.x from BOTH pairs (a miscompile seen in round 5), and element-wise conversions cost 16.
+    hi.x = pack_f16(v.x, v.y);
+    hi.y = pack_f16(v.z, v.w);
     if (NSPLIT == 2) {
-      lo.x = pack_f16(v.x - (float)hx, v.y - (float)hy);
-      lo.y = pack_f16(v.z - (float)hz, v.w - (float)hw);
+      float rx, ry, rz, rw;
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rx) : "v"(hi.x), "v"(v.x));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ry) : "v"(hi.x), "v"(v.y));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rz) : "v"(hi.y), "v"(v.z));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rw) : "v"(hi.y), "v"(v.w));
+      lo.x = pack_f16(rx, ry);
+      lo.y = pack_f16(rz, rw);
     }
   } else {
     hi.x = pack_bf16(v.x, v.y);

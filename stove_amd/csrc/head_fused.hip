@@ -38,7 +38,6 @@ __device__ __forceinline__ size_t eh_orow(int row, int pn, int pk) { return pn >
 // tile instead of 256 of 32.  The accumulator layout D[feature 4 g + r][row c] is the same for both instructions, so everything behind
 // fc1 is unchanged.  W1 sits in LDS as two bf16 images (rows of 528 bytes: conflict-free b128 fragment reads), h is split in registers.
 constexpr int kEhLdB = 528;
-constexpr bool kEhFc1Split = true;      // false: the fp32-MFMA fc1 of round 2 (A/B builds)
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void enc_head_fwd_k(const float* __restrict__ h, const float* __restrict__ W1, const float* __restrict__ b1,
                                                        const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ h1,
@@ -220,20 +219,8 @@ __global__ __launch_bounds__(256, 2) void enc_head_fwd_k(const float* __restrict
 __host__ __device__ inline int eh_part_floats(int HID) { return (HID * kEhH + kEhOut * HID + HID + kEhOut + 3) / 4 * 4; }
 constexpr int kEhTLd = 17;      // d_a1 slice [feature][row]: odd stride -> the A-operand reads (feature c, row g + 4 s) are conflict-free
 constexpr int kEhBwdLds = 4 * 4 * 64 * 4 + 4 * kEhHid * kEhTLd + 256;      // floats: W1 fragment image | 4 slices (the reductions alias both)
-// SPLIT form of the column roles (round 4): products 3 and 4 as split-bf16 MFMAs (v_mfma_f32_16x16x32_bf16, three per product).
-//   3. gh^T (m x row): K = 64 features = two 32-blocks.  The d_a1 registers ARE the B operand again: k-slot (g, i) of block b is feature
-//      32 b + 4 g + i (i < 4, tile 2 b) or 32 b + 16 + 4 g + (i - 4) (tile 2 b + 1) -- a sum over k does not care about its order -- and
-//      the W1 fragment image in LDS is laid out in that order (bf16x8 per (m tile, block, lane), hi and lo planes).
-//   4. gw1 (feature x m): K = the tile's 16 rows in the k-slots i < 4 of every lane (row g + 4 i), the other half of the MFMA's K zero.
-//      (Pairs of tiles -- a full K of 32 rows -- need a 36 KB slice per workgroup: 54 KB of LDS in all, and then only one workgroup fits
-//      beside gnn_dw_small_k on the side stream: at six objects the kernel took 534 us instead of 274.)
-//   24 + 48 MFMAs of 16 cycles per 16 rows and role instead of up to 52 + 64 of 32; LDS as the fp32 form.
-constexpr int kEhBwdLdsS = kEhBwdLds;
-// Measured (same-box A/B, r04): in the three-object step the kernel goes 101 -> 72 us and the step does not move (the forward's split
-// form alone: -11 us; both: -9); at six objects the kernel takes 523 us instead of 274 -- it runs beside gnn_dw_small_k, which saturates HBM
-// there (2.5 GB in 445 us), and gets the smaller share -- and the step +55 us.  Capped at 192 registers (amdgpu_num_vgpr, so that it can
-// share a SIMD with that kernel: 154 used, no spills) it is no better.  OFF: the fp32 form stays the product path.
-constexpr bool kEhBwdSplit = false;
+// (Round 4 also wrote the column roles' products as split-bf16 MFMAs: 101 -> 72 us in the three-object step with the step unchanged, and
+// 274 -> 523 us at six objects next to gnn_dw_small_k, step + 55 us -- docs/history/r04.md; removed in round 5.)
 
 struct EhTileIn {      // what a column role fetches for one tile
   float gv[2];         // dcodes[row c][g + 4 s]
@@ -285,7 +272,7 @@ __device__ __forceinline__ void eh_da(const EhTileIn& x, const float (&a1)[4][2]
   }
 }
 
-template <int KS, bool SPLIT = false>               // k-steps of product 3 = feature quadruples (jt, s) with 16 jt + s < HID, in (jt, s) order
+template <int KS>               // k-steps of product 3 = feature quadruples (jt, s) with 16 jt + s < HID, in (jt, s) order
 __global__ __launch_bounds__(256, 2) void enc_head_bwd_k(const float* __restrict__ dcodes, const float* __restrict__ h1, const float* __restrict__ h,
                                                           const float* __restrict__ W1, const float* __restrict__ W2, float* __restrict__ gh,
                                                           float* __restrict__ part, int rows, int HID, int n_groups, int pn) {
@@ -382,128 +369,6 @@ __global__ __launch_bounds__(256, 2) void enc_head_bwd_k(const float* __restrict
   }
   // ---- roles 0..3: gh and gw1 of the column quarter -------------------------------------------------------------------------------
   const int m0 = 64 * w;
-  if constexpr (SPLIT) {
-    // W1 fragment image: entry (mt, b, lane) = 8 bf16 of W1[feature(g, i; b)][m0 + 16 mt + c], hi plane then lo plane
-    char* A3h = reinterpret_cast<char*>(eh_lds);
-    char* A3l = A3h + 4 * 2 * 64 * 16;
-    float* T = eh_lds + 4 * 4 * 64 * 4 + wv * (kEhHid * kEhTLd);
-    {
-      float v[2][8];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = tid + 256 * u, ln = e & 63, b = (e >> 6) & 1, mt = e >> 7;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int n = 32 * b + (i < 4 ? 0 : 16) + 4 * (ln >> 4) + (i & 3);
-          const float wv_ = W1[(size_t)(n < HID ? n : 0) * kEhH + m0 + 16 * mt + (ln & 15)];
-          v[u][i] = n < HID ? wv_ : 0.0f;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = tid + 256 * u;
-        u32x2 h0, l0, h1_, l1;
-        split4<2>(float4{v[u][0], v[u][1], v[u][2], v[u][3]}, h0, l0);
-        split4<2>(float4{v[u][4], v[u][5], v[u][6], v[u][7]}, h1_, l1);
-        *reinterpret_cast<u32x4*>(A3h + e * 16) = u32x4{h0.x, h0.y, h1_.x, h1_.y};
-        *reinterpret_cast<u32x4*>(A3l + e * 16) = u32x4{l0.x, l0.y, l1.x, l1.y};
-      }
-    }
-    f32x4 accw[4][4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) accw[nt][mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    __syncthreads();
-    for (int t = grp * 4 + wv; t < n_tiles; t += n_groups * 4) {
-      const int R0 = t * 16, row = R0 + c;
-      const bool live = row < rows;
-      EhTileIn x;
-      eh_fetch(x, dcodes, h1, h, t, rows, HID, m0, c, g, even, true, pn);
-      float gv[2], da[4][4];
-      eh_da(x, a1, live, g, HID, gv, da);
-      // 3. gh of this tile
-      bf16x8 bhi[2], blo[2];
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        u32x2 h0, l0, h1_, l1;
-        split4<2>(float4{da[2 * b][0], da[2 * b][1], da[2 * b][2], da[2 * b][3]}, h0, l0);
-        split4<2>(float4{da[2 * b + 1][0], da[2 * b + 1][1], da[2 * b + 1][2], da[2 * b + 1][3]}, h1_, l1);
-        bhi[b] = __builtin_bit_cast(bf16x8, u32x4{h0.x, h0.y, h1_.x, h1_.y});
-        blo[b] = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        f32x4 o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(A3h + ((mt * 2 + b) * 64 + lane) * 16);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(A3l + ((mt * 2 + b) * 64 + lane) * 16);
-          o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhi[b], o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blo[b], o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhi[b], o, 0, 0, 0);
-        }
-        if (live) st4(gh + (size_t)row * kEhH + m0 + 16 * mt + 4 * g, float4{o[0], o[1], o[2], o[3]});
-      }
-      // 4. gw1 += d_a1^T h over the tile's 16 rows: k-slots i < 4 of lane (c, g) are rows g + 4 i, slots i >= 4 are zero (half of each
-      //    MFMA's K is padding: 48 MFMAs of 16 cycles against 64 of 32, and no pairing of tiles: the LDS slice stays 64 x 17 floats)
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T[(16 * jt + 4 * g + r) * kEhTLd + c] = da[jt][r];
-      __builtin_amdgcn_wave_barrier();
-      bf16x8 a4h[4], a4l[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        float av[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) av[i] = T[(c + 16 * nt) * kEhTLd + g + 4 * i];
-        u32x2 h0, l0;
-        split4<2>(float4{av[0], av[1], av[2], av[3]}, h0, l0);
-        a4h[nt] = __builtin_bit_cast(bf16x8, u32x4{h0.x, h0.y, 0u, 0u});
-        a4l[nt] = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, 0u, 0u});
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        float hv4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) hv4[i] = (R0 + g + 4 * i < rows) ? x.hb[mt][i] : 0.0f;
-        u32x2 h0, l0;
-        split4<2>(float4{hv4[0], hv4[1], hv4[2], hv4[3]}, h0, l0);
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, u32x4{h0.x, h0.y, 0u, 0u});
-        const bf16x8 bl = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, 0u, 0u});
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) accw[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4l[nt], bh, accw[nt][mt], 0, 0, 0);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) accw[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4h[nt], bl, accw[nt][mt], 0, 0, 0);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) accw[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4h[nt], bh, accw[nt][mt], 0, 0, 0);
-      }
-    }
-    // ---- the four waves' sums, in wave order, two feature-tile pairs at a time (32 KB of LDS) ---------------------------------------
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();
-      float* R = eh_lds + wv * (32 * 64);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) R[((nt * 4 + mt) * 4 + r) * 64 + lane] = accw[2 * half + nt][mt][r];
-      __syncthreads();
-      for (int e = tid; e < 32 * 64; e += blockDim.x) {
-        const int reg = e >> 6, ln = e & 63;
-        const float v = ((eh_lds[e] + eh_lds[2048 + e]) + eh_lds[2 * 2048 + e]) + eh_lds[3 * 2048 + e];
-        const int nt = 2 * half + (reg >> 4), mt = (reg >> 2) & 3, r = reg & 3;
-        const int n = 16 * nt + 4 * (ln >> 4) + r, m = m0 + 16 * mt + (ln & 15);
-        if (n < HID) P[(size_t)n * kEhH + m] = v;
-      }
-    }
-    return;
-  }
   float* A3 = eh_lds;                                   // [mt][kq][lane][4]: W1[feature 16 kq + 4 g + j][m0 + 16 mt + c], zero beyond HID
   float* T = eh_lds + 4 * 4 * 64 * 4 + wv * (kEhHid * kEhTLd);
   {

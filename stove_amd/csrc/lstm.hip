@@ -127,224 +127,4 @@ __global__ void lstm_cell_bwd_k(const float* __restrict__ gx, const float* __res
   }
 }
 
-// ---- output head of the recognition network: zps = fc2(sigmoid(fc1(h)))  (encoder.py:53-56) ---------------------------------
-// fc1 (256 -> 50) stays a library GEMM; everything behind it is narrow (50 -> 8) and HBM-bound: as library calls the
-// backward is a (rows x 8)(8 x 50) GEMM on 16x16 tiles, an elementwise sigmoid', a split-K GEMM for the 8 x 50 weight
-// gradient and two column sums (~130 us for 76 800 rows); here it is one pass over h1 (15 MB) each way.
-// One wave owns a tile of 64 rows: the tile is staged in the wave's LDS slice (row stride odd -> conflict-free both by
-// row and by column), lane = row for the products along the features, lane = feature for the sums over rows.
-constexpr int kHeadOut = 8;      // max outputs (2 * z_size)
-constexpr int kHeadHid = 64;     // max hidden width
-
-__device__ __forceinline__ int head_stride(int H1) { return H1 | 1; }
-constexpr int kHeadV4 = 64 * kHeadHid / 4 / 64;      // float4 loads per lane that cover a 64 x kHeadHid tile
-
-// A tile = 64 consecutive rows = 64 * H1 consecutive floats (16-byte aligned since 64 * H1 * 4 is): float4 loads, scattered
-// into the LDS tile [row][stride].  The loads go out in batches of kHeadBatch before their first use -- with one tile per
-// wave a "load, use, load, use" loop was pure memory latency -- and the batches bound the registers, so the kernels fit next
-// to the register-heavy MFMA kernels they overlap with.  SIG: sigmoid on the way, result also stored to `dst`.
-constexpr int kHeadBatch = 4;
-template <bool SIG>
-__device__ __forceinline__ void head_stream(const float* __restrict__ src, float* __restrict__ dst, float* tile, int n_el, int H1,
-                                            int stride, int lane) {
-  int row = (lane * 4) / H1, col = (lane * 4) % H1;
-  const int dq = 256 / H1, dr = 256 % H1;
-  for (int i0 = 0; i0 < kHeadV4 && i0 * 256 < n_el; i0 += kHeadBatch) {
-    float4 q[kHeadBatch];
-#pragma unroll
-    for (int u = 0; u < kHeadBatch; ++u) {
-      const int e = ((i0 + u) * 64 + lane) * 4;
-      q[u] = float4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (e + 3 < n_el) {
-        q[u] = ld4(src + e);
-      } else if (e < n_el) {
-        q[u].x = src[e];
-        if (e + 1 < n_el) q[u].y = src[e + 1];
-        if (e + 2 < n_el) q[u].z = src[e + 2];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kHeadBatch; ++u) {
-      const int e = ((i0 + u) * 64 + lane) * 4;
-      float vv[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-      if (SIG) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vv[k] = sig_(vv[k]);
-        if (e + 3 < n_el) {
-          st4(dst + e, float4{vv[0], vv[1], vv[2], vv[3]});
-        } else if (e < n_el) {
-          dst[e] = vv[0];
-          if (e + 1 < n_el) dst[e + 1] = vv[1];
-          if (e + 2 < n_el) dst[e + 2] = vv[2];
-        }
-      }
-      int r = row, c = col;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (e + k < n_el) tile[r * stride + c] = vv[k];
-        if (++c == H1) { c = 0; ++r; }
-      }
-      row += dq;
-      col += dr;
-      if (col >= H1) { col -= H1; ++row; }
-    }
-  }
-}
-// W2 (OUT, H1) -> LDS w2t[j][kHeadOut] (zero padded): two broadcast float4 reads per feature
-__device__ __forceinline__ void head_stage_w2(const float* __restrict__ W2, float* w2t, int H1, int OUT) {
-  for (int i = threadIdx.x; i < H1 * kHeadOut; i += blockDim.x) {
-    const int j = i / kHeadOut, k = i % kHeadOut;
-    w2t[i] = k < OUT ? W2[k * H1 + j] : 0.0f;
-  }
-  __syncthreads();
-}
-
-// a1 (rows, H1) = fc1 pre-activations -> h1 = sigmoid(a1) (rows, H1), codes (rows, OUT) = h1 W2^T + b2;  W2 (OUT, H1)
-__global__ __launch_bounds__(256) void head_fwd_k(const float* __restrict__ a1, const float* __restrict__ W2, const float* __restrict__ b2,
-                           float* __restrict__ h1, float* __restrict__ codes, int rows, int H1, int OUT) {
-  extern __shared__ __attribute__((aligned(16))) float head_lds[];
-  const int lane = lane_id(), wv = wave_id(), nw = blockDim.x >> 6;
-  const int stride = head_stride(H1);
-  float* w2t = head_lds;
-  float* tile = head_lds + kHeadHid * kHeadOut + (size_t)wv * 64 * stride;
-  head_stage_w2(W2, w2t, H1, OUT);
-  const int n_tiles = (rows + 63) / 64;
-  for (int t = blockIdx.x * nw + wv; t < n_tiles; t += gridDim.x * nw) {
-    const size_t r0 = (size_t)t * 64;
-    const int live = rows - (int)r0 < 64 ? rows - (int)r0 : 64;
-    const int n_el = live * H1;
-    head_stream<true>(a1 + r0 * H1, h1 + r0 * H1, tile, n_el, H1, stride, lane);
-    if (lane < live) {
-      float acc[kHeadOut];
-#pragma unroll
-      for (int k = 0; k < kHeadOut; ++k) acc[k] = k < OUT ? b2[k] : 0.0f;
-      const float* hr = tile + lane * stride;
-      for (int j = 0; j < H1; ++j) {
-        const float h = hr[j];
-        const float4 wa = ld4(w2t + j * kHeadOut), wb = ld4(w2t + j * kHeadOut + 4);
-        acc[0] = fmaf(h, wa.x, acc[0]); acc[1] = fmaf(h, wa.y, acc[1]); acc[2] = fmaf(h, wa.z, acc[2]); acc[3] = fmaf(h, wa.w, acc[3]);
-        acc[4] = fmaf(h, wb.x, acc[4]); acc[5] = fmaf(h, wb.y, acc[5]); acc[6] = fmaf(h, wb.z, acc[6]); acc[7] = fmaf(h, wb.w, acc[7]);
-      }
-      float* o = codes + (r0 + lane) * OUT;
-      if (OUT == kHeadOut) {
-        st4(o, float4{acc[0], acc[1], acc[2], acc[3]});
-        st4(o + 4, float4{acc[4], acc[5], acc[6], acc[7]});
-      } else {
-#pragma unroll
-        for (int k = 0; k < kHeadOut; ++k)
-          if (k < OUT) o[k] = acc[k];
-      }
-    }
-  }
-}
-
-// dcodes (rows, OUT), h1 (rows, H1) -> d_a1 (rows, H1) = (dcodes W2) * h1 (1 - h1); per-block partial sums
-// part[block][OUT*H1 | H1 | OUT] = (dW2 = dcodes^T h1, db1 = colsum d_a1, db2 = colsum dcodes), waves added in order.
-__global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ dcodes, const float* __restrict__ h1, const float* __restrict__ W2,
-                           float* __restrict__ d_a1, float* __restrict__ part, int rows, int H1, int OUT) {
-  extern __shared__ __attribute__((aligned(16))) float head_lds[];
-  const int lane = lane_id(), wv = wave_id(), nw = blockDim.x >> 6;
-  const int stride = head_stride(H1);
-  const int slice = 64 * stride + 64 * kHeadOut;
-  float* w2t = head_lds;
-  float* tile = head_lds + kHeadHid * kHeadOut + (size_t)wv * slice;
-  float* gt = tile + 64 * stride;                 // [64][kHeadOut]
-  head_stage_w2(W2, w2t, H1, OUT);
-  float aw[kHeadOut], ab1 = 0.0f, ab2 = 0.0f;
-#pragma unroll
-  for (int k = 0; k < kHeadOut; ++k) aw[k] = 0.0f;
-  const int n_tiles = (rows + 63) / 64;
-  for (int t = blockIdx.x * nw + wv; t < n_tiles; t += gridDim.x * nw) {
-    const size_t r0 = (size_t)t * 64;
-    const int live = rows - (int)r0 < 64 ? rows - (int)r0 : 64;
-    const int n_el = live * H1;
-    head_stream<false>(h1 + r0 * H1, nullptr, tile, n_el, H1, stride, lane);
-    float g[kHeadOut];
-    if (OUT == kHeadOut && lane < live) {
-      const float4 ga = ld4(dcodes + (r0 + lane) * OUT), gb = ld4(dcodes + (r0 + lane) * OUT + 4);
-      g[0] = ga.x, g[1] = ga.y, g[2] = ga.z, g[3] = ga.w, g[4] = gb.x, g[5] = gb.y, g[6] = gb.z, g[7] = gb.w;
-    } else {
-#pragma unroll
-      for (int k = 0; k < kHeadOut; ++k) g[k] = (lane < live && k < OUT) ? dcodes[(r0 + lane) * OUT + k] : 0.0f;
-    }
-    st4(gt + lane * kHeadOut, float4{g[0], g[1], g[2], g[3]});
-    st4(gt + lane * kHeadOut + 4, float4{g[4], g[5], g[6], g[7]});
-    // sums over the tile's rows, lane = feature (h tile still intact)
-    if (lane < H1) {
-      for (int r = 0; r < live; ++r) {
-        const float hv = tile[r * stride + lane];
-        const float4 ga = ld4(gt + r * kHeadOut), gb = ld4(gt + r * kHeadOut + 4);
-        aw[0] = fmaf(ga.x, hv, aw[0]); aw[1] = fmaf(ga.y, hv, aw[1]); aw[2] = fmaf(ga.z, hv, aw[2]); aw[3] = fmaf(ga.w, hv, aw[3]);
-        aw[4] = fmaf(gb.x, hv, aw[4]); aw[5] = fmaf(gb.y, hv, aw[5]); aw[6] = fmaf(gb.z, hv, aw[6]); aw[7] = fmaf(gb.w, hv, aw[7]);
-      }
-    }
-    if (lane < OUT)
-      for (int r = 0; r < live; ++r) ab2 += gt[r * kHeadOut + lane];
-    // lane = row: d_a1 over the h tile
-    if (lane < live) {
-      float* hr = tile + lane * stride;
-      for (int j = 0; j < H1; ++j) {
-        const float4 wa = ld4(w2t + j * kHeadOut), wb = ld4(w2t + j * kHeadOut + 4);
-        float tsum = g[0] * wa.x;
-        tsum = fmaf(g[1], wa.y, tsum); tsum = fmaf(g[2], wa.z, tsum); tsum = fmaf(g[3], wa.w, tsum);
-        tsum = fmaf(g[4], wb.x, tsum); tsum = fmaf(g[5], wb.y, tsum); tsum = fmaf(g[6], wb.z, tsum); tsum = fmaf(g[7], wb.w, tsum);
-        const float h = hr[j];
-        hr[j] = tsum * h * (1.0f - h);
-      }
-    }
-    if (lane < H1)
-      for (int r = 0; r < live; ++r) ab1 += tile[r * stride + lane];
-    // back out in the global (row-major) order
-    {
-      int row = (lane * 4) / H1, col = (lane * 4) % H1;
-      const int dq = 256 / H1, dr = 256 % H1;
-      float* dst = d_a1 + r0 * H1;
-#pragma unroll 4
-      for (int i = 0; i < kHeadV4; ++i) {
-        const int e = (i * 64 + lane) * 4;
-        if (e >= n_el) break;
-        float vv[4];
-        int r = row, c = col;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          vv[k] = (e + k < n_el) ? tile[r * stride + c] : 0.0f;
-          if (++c == H1) { c = 0; ++r; }
-        }
-        if (e + 3 < n_el) {
-          st4(dst + e, float4{vv[0], vv[1], vv[2], vv[3]});
-        } else {
-          dst[e] = vv[0];
-          if (e + 1 < n_el) dst[e + 1] = vv[1];
-          if (e + 2 < n_el) dst[e + 2] = vv[2];
-        }
-        row += dq;
-        col += dr;
-        if (col >= H1) { col -= H1; ++row; }
-      }
-    }
-  }
-  // block partials: waves in fixed order through their own LDS slices
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < kHeadOut; ++k) tile[k * 64 + lane] = aw[k];
-  tile[kHeadOut * 64 + lane] = ab1;
-  tile[(kHeadOut + 1) * 64 + lane] = ab2;
-  __syncthreads();
-  if (wv == 0) {
-    const int n_out = OUT * H1 + H1 + OUT;
-    float* o = part + (size_t)blockIdx.x * n_out;
-    for (int q = 0; q < kHeadOut + 2; ++q) {
-      float s = 0.0f;
-      for (int w = 0; w < nw; ++w) s += head_lds[kHeadHid * kHeadOut + (size_t)w * slice + q * 64 + lane];
-      if (q < kHeadOut) {
-        if (q < OUT && lane < H1) o[q * H1 + lane] = s;
-      } else if (q == kHeadOut) {
-        if (lane < H1) o[OUT * H1 + lane] = s;
-      } else if (lane < OUT) {
-        o[OUT * H1 + H1 + lane] = s;
-      }
-    }
-  }
-}
-
 }  // namespace stove

@@ -280,3 +280,28 @@ def synth_sequences(preset, n_seq, t_len, seed0=0, with_actions=None, res=None):
         out['action'] = np.stack(A)
         out['reward'] = np.stack(R)
     return out
+
+
+def _synth_chunk(args):
+    preset, n, t_len, seed0, res = args
+    return synth_sequences(preset, n, t_len, seed0=seed0, res=res)
+
+
+def synth_sequences_parallel(preset, n_seq, t_len, seed0=0, res=None, workers=None):
+    """synth_sequences over a pool of forked workers (sequence i is its own environment with seed seed0 + i, so the result
+    does not depend on the split).  Fork-based: call it BEFORE the process initialises the GPU."""
+    import multiprocessing as mp
+    import os
+    if workers is None:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except AttributeError:
+            workers = os.cpu_count() or 1
+    workers = max(1, min(workers, n_seq))
+    if workers == 1:
+        return synth_sequences(preset, n_seq, t_len, seed0=seed0, res=res)
+    per = (n_seq + workers - 1) // workers
+    jobs = [(preset, min(per, n_seq - s), t_len, seed0 + s, res) for s in range(0, n_seq, per)]
+    with mp.get_context('fork').Pool(len(jobs)) as pool:
+        parts = pool.map(_synth_chunk, jobs)
+    return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}

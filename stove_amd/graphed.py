@@ -10,7 +10,7 @@ Captured once and replayed, a step is three launch calls and the host runs many 
   (join the side stream; data parallel: all-reduce of the flat gradient)
   g_opt   [ clip + Adam ]
 g_main and g_side are ordered against each other by event nodes (csrc/common.h: stream_after across two captures).  As branches
-of ONE graph (STOVE_GRAPH_ONE=1) the runtime queued the side chain behind the main chain: 3.6 instead of 3.1 ms per step.
+of ONE graph the runtime queued the side chain behind the main chain: 3.6 instead of 3.1 ms per step.
 
 What varies from step to step enters through device memory:
   * the batch: static input tensors (`alias_inputs=True` adopts the caller's tensors instead of copying into own ones: a
@@ -164,7 +164,7 @@ class GraphedTrainStep:
                                    'the source tree, not of an installed package' % so)
             gd = ctypes.CDLL(so)
         g1 = torch.cuda.CUDAGraph(keep_graph=True) if dump else torch.cuda.CUDAGraph()
-        split = os.environ.get('STOVE_GRAPH_ONE', '0') != '1'
+        split = True                              # (the one-graph capture of round 3 is gone: module docstring)
         torch.cuda.synchronize(dev)
         self.graphs = None                        # a re-capture (new batch shape): the previous graphs and their events go
         self._drop_side()
@@ -202,7 +202,10 @@ class GraphedTrainStep:
                     ops.SideMode.split = False
                     lib.stove_capture_end(self._side.cuda_stream, ctypes.byref(side_graph), ctypes.byref(side_nodes))
                     if side_graph.value:
-                        lib.stove_graph_instantiate(side_graph, ctypes.byref(ctypes.c_void_p()))      # consumes (destroys) the graph
+                        ex = ctypes.c_void_p()
+                        lib.stove_graph_instantiate(side_graph, ctypes.byref(ex))      # consumes (destroys) the graph ...
+                        if ex.value:
+                            lib.stove_graph_destroy(ex)                                # ... and the executable made from it goes too
                     ops.SideMode.keep = []
                 raise
             if split:

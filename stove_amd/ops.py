@@ -5,12 +5,12 @@ workspaces through PyTorch's caching allocator, and raises if the library is mis
 tensors are not on a GPU -- there is no CPU or eager fallback.
 """
 import ctypes
-import os
 import math
 
 import torch
 
 from . import _lib
+from . import settings as _settings
 from ._lib import SpnTableGrads, SpnTables, check, ptr, stream
 
 
@@ -255,7 +255,7 @@ class _SceneFn(torch.autograd.Function):
             if ctx.geom is not None:
                 W, H, ac = ctx.geom
                 ws = _ws(lib.stove_scene_bwd_ws_bytes_any(nf, n_obj, W * H), dev)
-                overlap = ctx.sink is not None and os.environ.get('STOVE_NO_OVERLAP', '0') != '1'
+                overlap = ctx.sink is not None and _settings.OVERLAP
                 main, side = torch.cuda.current_stream(dev), (_side_stream(dev) if overlap else None)
                 check(lib.stove_scene_bwd_any(ctypes.byref(t), frames.data_ptr(), ptr(z), nf, n_obj, seq_frames, seq_stride, W, H, int(ac),
                                               ctx.beta, ptr(saved), ptr(dll), ptr(dz), ctypes.byref(g), ptr(ws), main.cuda_stream,
@@ -269,7 +269,7 @@ class _SceneFn(torch.autograd.Function):
                     grads = [None] * 5
                 return (None, dz, *grads) + (None,) * 9
             ws = _ws(lib.stove_scene_bwd_ws_bytes(nf, n_obj), dev)
-            if ctx.sink is not None and os.environ.get('STOVE_NO_OVERLAP', '0') != '1':
+            if ctx.sink is not None and _settings.OVERLAP:
                 # Flat-arena path: the table gradients only feed the optimiser.  Their passes (and the arena sink) go to a
                 # second stream and overlap with what autograd enqueues next on this one: the recursion's backward,
                 # latency-bound with one sequence per CU.  The main stream waits for them at the end of the backward pass.
@@ -638,7 +638,7 @@ class _DynLoopFn(torch.autograd.Function):
             dextra = torch.empty_like(extra) if extra is not None else None
             g = torch.empty(lib.stove_gnn_grad_floats(), dtype=torch.float32, device=dev)
             ws = _ws(lib.stove_dynloop_bwd_ws_bytes_ts(B, Ts, N), dev)
-            if ctx.sink is not None and os.environ.get('STOVE_NO_OVERLAP', '0') != '1':
+            if ctx.sink is not None and _settings.OVERLAP:
                 # weight gradients (only the optimiser reads them) on the second stream, under the encoder's backward GEMMs
                 main, side = torch.cuda.current_stream(dev), _side_stream(dev)
                 check(lib.stove_dynloop_bwd_overlap(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z), ptr(act),
@@ -740,7 +740,7 @@ class _InferScoreFn(torch.autograd.Function):
         dev = z1.device
         consts = [float(c) for c in cfg['consts']]
         main, pipe, side = torch.cuda.current_stream(dev), _side_stream(dev, 'pipe'), _side_stream(dev)
-        overlap = os.environ.get('STOVE_NO_OVERLAP', '0') != '1'
+        overlap = _settings.OVERLAP
         sp = side.cuda_stream if overlap else None
 
         def up(g):
@@ -1168,9 +1168,9 @@ def linear(x, weight, bias):
 # That removes one AccumulateGrad `add_` launch per parameter from the critical path (8 per step) and lets the weight-gradient
 # GEMMs run on the second stream, since nothing on the main stream consumes their result before the optimiser.
 # The semantics are those of .backward() (accumulate into .grad); torch.autograd.grad() on arena-bound parameters must
-# switch it off (STOVE_DIRECT_GRADS=0 or ops.DIRECT_GRADS = False).
+# switch it off (ops.DIRECT_GRADS = False).
 # ------------------------------------------------------------------------------------------------
-DIRECT_GRADS = os.environ.get('STOVE_DIRECT_GRADS', '1') != '0'
+DIRECT_GRADS = True       # tests flip it to compare with autograd's AccumulateGrad path (bit-identical gradients)
 _GRAD_VIEWS = {}            # id(parameter) -> (weak reference to the parameter, its gradient view): dies with the parameter
 
 
@@ -1209,7 +1209,7 @@ def _grad_views(*params, needs=None):
                 return None
     except RuntimeError:
         return None
-    except AttributeError:          # an older torch without the query: .backward() semantics assumed (STOVE_DIRECT_GRADS=0 otherwise)
+    except AttributeError:          # an older torch without the query: .backward() semantics assumed (ops.DIRECT_GRADS = False otherwise)
         pass
     out = []
     for p in params:
@@ -1224,65 +1224,21 @@ def _grad_views(*params, needs=None):
     return out
 
 
-class _EncoderHeadFn(torch.autograd.Function):
-    """fc2(sigmoid(fc1(h))) of the recognition network (reference encoder.py:53-56) on (rows, 256) LSTM outputs: fc1 and its
-    two gradient products are GEMMs (the MFMA GEMM of csrc/gemm_bf16.hip, whose element-wise operand path takes fc1's 50
-    columns; `gemm` = 'fp32' uses the library), everything behind fc1 is one HIP pass each way (csrc/lstm.hip head_*_k)."""
-
-    @staticmethod
-    def forward(ctx, h, w1, b1, w2, b2, gemm):
-        lib = _lib.load()
-        rows, H1, OUT = h.shape[0], w1.shape[0], w2.shape[0]
-        ctx.ns = {'bf16x3': 2, 'bf16': 1, 'fp32': 0}[gemm]
-        if ctx.ns and h.shape[1] % 4 == 0:
-            a1 = gemm_bf16(h, w1, bias=b1, nsplit=ctx.ns, tile=2)
-        else:
-            ctx.ns = 0
-            a1 = torch.addmm(b1, h, w1.t())
-        h1 = torch.empty_like(a1)
-        codes = torch.empty(rows, OUT, dtype=torch.float32, device=h.device)
-        with torch.cuda.device(h.device):
-            check(lib.stove_head_fwd(ptr(a1), ptr(w2), ptr(b2), ptr(h1), ptr(codes), rows, H1, OUT, stream()), 'stove_head_fwd')
-        ctx.save_for_backward(h, w1, w2, h1)
-        return codes
-
-    @staticmethod
-    def backward(ctx, g):
-        lib = _lib.load()
-        h, w1, w2, h1 = ctx.saved_tensors
-        rows, H1, OUT = h.shape[0], w1.shape[0], w2.shape[0]
-        g = _f32(g)
-        d_a1 = torch.empty_like(h1)
-        small = torch.empty(OUT * H1 + H1 + OUT, dtype=torch.float32, device=h.device)
-        with torch.cuda.device(h.device):
-            ws = torch.empty(lib.stove_head_bwd_ws_floats(rows, H1, OUT), dtype=torch.float32, device=h.device)
-            check(lib.stove_head_bwd(ptr(g), ptr(h1), ptr(w2), ptr(d_a1), ptr(small), ptr(ws), rows, H1, OUT, stream()), 'stove_head_bwd')
-        gh = gw1 = None
-        if ctx.ns:
-            if ctx.needs_input_grad[0]:
-                gh = gemm_bf16(d_a1, w1, b_kmajor=True, nsplit=ctx.ns, splitk=1, tile=2)
-            if ctx.needs_input_grad[1]:
-                gw1 = gemm_bf16(d_a1, h, a_kmajor=True, b_kmajor=True, nsplit=ctx.ns, tile=2)
-        else:
-            gh = torch.mm(d_a1, w1) if ctx.needs_input_grad[0] else None
-            gw1 = _splitk_tn(d_a1, h) if ctx.needs_input_grad[1] else None
-        return gh, gw1, small[OUT * H1:OUT * H1 + H1], small[:OUT * H1].view(OUT, H1), small[OUT * H1 + H1:], None
-
-
 class _EncoderHeadFusedFn(torch.autograd.Function):
-    """The same head as ONE kernel each way (csrc/head_fused.hip): fc1, sigmoid and fc2 chained on the fp32 matrix-core
-    instructions, h read once; the backward returns dL/dh and all four parameter gradients.  H = 256, HID <= 64, OUT = 8."""
+    """fc2(sigmoid(fc1(h))) of the recognition network (reference encoder.py:53-56) as ONE kernel each way (csrc/head_fused.hip):
+    fc1, sigmoid and fc2 chained on the matrix cores, h read once; the backward returns dL/dh and all four parameter gradients.
+    H = 256, HID <= 64, OUT = 8.  split: fc1's forward as three half-piece MFMAs per product (default) or on the fp32 MFMA."""
 
     @staticmethod
-    def forward(ctx, h, w1, b1, w2, b2, frames):
+    def forward(ctx, h, w1, b1, w2, b2, frames, split=True):
         lib = _lib.load()
         rows, H, HID, OUT = h.shape[0], h.shape[1], w1.shape[0], w2.shape[0]
         ctx.frames = int(frames)
         h1 = torch.empty(rows, HID, dtype=torch.float32, device=h.device)
         codes = torch.empty(rows, OUT, dtype=torch.float32, device=h.device)
         with torch.cuda.device(h.device):
-            check(lib.stove_enc_head_fwd(ptr(h), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(h1), ptr(codes), rows, H, HID, OUT, ctx.frames, stream()),
-                  'stove_enc_head_fwd')
+            check(lib.stove_enc_head_fwd(ptr(h), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(h1), ptr(codes), rows, H, HID, OUT, ctx.frames,
+                                         int(bool(split)), stream()), 'stove_enc_head_fwd')
         ctx.save_for_backward(h, w1, b1, w2, b2, h1)
         return codes
 
@@ -1301,27 +1257,25 @@ class _EncoderHeadFusedFn(torch.autograd.Function):
             check(lib.stove_enc_head_bwd(ptr(g), ptr(h1), ptr(h), ptr(w1), ptr(w2), ptr(gh), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]),
                                          ptr(outs[3]), int(views is not None), ptr(ws), rows, H, HID, OUT, ctx.frames, stream()), 'stove_enc_head_bwd')
         if views is not None:
-            return gh, None, None, None, None, None
-        return (gh, *outs, None)
+            return gh, None, None, None, None, None, None
+        return (gh, *outs, None, None)
 
 
 def encoder_head(h, w1, b1, w2, b2, gemm='bf16x3', step_major=False):
-    """(..., 256) -> (..., 8): fc2(sigmoid(fc1(h))).  gemm: 'bf16x3' | 'bf16' | 'fp32' for the fc1 products (see encoder_lstm).
-    step_major: h is (steps, n, 256) as the LSTM kernels write it and the result is (n, steps, 8) -- the kernels write the
-    small output transposed instead of a permute + copy each way."""
+    """(..., 256) -> (..., 8): fc2(sigmoid(fc1(h))).  gemm: 'fp32' runs fc1's forward on the fp32 MFMA instead of three half-piece
+    MFMAs per product (see encoder_lstm).  step_major: h is (steps, n, 256) as the LSTM kernels write it and the result is
+    (n, steps, 8) -- the kernels write the small output transposed instead of a permute + copy each way."""
     shape = h.shape
-    fused = gemm != 'fp32' and shape[-1] == 256 and w2.shape[0] == 8 and w1.shape[0] <= 64
+    fused = shape[-1] == 256 and w2.shape[0] == 8 and w1.shape[0] <= 64
+    split = gemm != 'fp32'
     if step_major and h.dim() == 3 and fused:
-        out = _EncoderHeadFusedFn.apply(_f32(h.reshape(-1, 256)), _f32(w1), _f32(b1), _f32(w2), _f32(b2), shape[1])
+        out = _EncoderHeadFusedFn.apply(_f32(h.reshape(-1, 256)), _f32(w1), _f32(b1), _f32(w2), _f32(b2), shape[1], split)
         return out.view(shape[1], shape[0], 8)
     if step_major:
         return encoder_head(h, w1, b1, w2, b2, gemm).transpose(0, 1)
-    if w1.shape[0] > 64 or w2.shape[0] > 8:
+    if not fused:                   # other head shapes than RnnStates' 256 -> <= 64 -> 8: two plain linear layers
         return linear(torch.sigmoid(linear(h, w1, b1)), w2, b2)
-    if fused:       # the one-kernel head; 'fp32' keeps the library GEMMs + head_*_k pair
-        out = _EncoderHeadFusedFn.apply(_f32(h.reshape(-1, shape[-1])), _f32(w1), _f32(b1), _f32(w2), _f32(b2), 0)
-        return out.view(*shape[:-1], w2.shape[0])
-    out = _EncoderHeadFn.apply(_f32(h.reshape(-1, shape[-1])), _f32(w1), _f32(b1), _f32(w2), _f32(b2), gemm)
+    out = _EncoderHeadFusedFn.apply(_f32(h.reshape(-1, shape[-1])), _f32(w1), _f32(b1), _f32(w2), _f32(b2), 0, split)
     return out.view(*shape[:-1], w2.shape[0])
 
 
@@ -1368,30 +1322,23 @@ class _blas:
         return False
 
 
-# gate activations of the LSTM cell kernels on v_exp_f32 / v_rcp_f32 (absolute error ~1e-7; STOVE_LSTM_FAST_CELL=0: IEEE division + ocml tanhf)
-FAST_CELL = int(os.environ.get('STOVE_LSTM_FAST_CELL', '1') != '0')
+# gate activations of the LSTM cell kernels on v_exp_f32 / v_rcp_f32 (absolute error ~1e-7; 0: IEEE division + ocml tanhf)
+FAST_CELL = 1
 
 
-ENC_CHUNKS = int(os.environ.get('STOVE_ENC_CHUNKS', '2'))
-ENC_STAGGER = os.environ.get('STOVE_ENC_STAGGER', '0') != '0'
-ENC_STREAMS = int(os.environ.get('STOVE_ENC_STREAMS', '2'))
-ENC_SPLIT = os.environ.get('STOVE_ENC_SPLIT', '')          # shares of the rows per chunk, e.g. "64,36" (A/B; default: equal chunks)
+# Row chunks of the recognition network's forward chain (two: measured best, DESIGN.md section 3 "Streams"; 1 = the unchunked chain,
+# which the bench's one-stream kernel profile and the equality test select)
+ENC_CHUNKS = 2
 
 
 def _enc_chunks(n, D, H):
-    """Row chunks [r0, r1) of the recognition network's forward chain (every product and cell of it is row-wise independent), or
+    """Equal row chunks [r0, r1) of the recognition network's forward chain (every product and cell of it is row-wise independent), or
     None for the unchunked chain: the 256 x 256 tile on whole tiles of every chunk, chunks big enough to fill most of the chip."""
     c = ENC_CHUNKS
-    if not (c > 1 and GEMM_WIDE and os.environ.get('STOVE_NO_OVERLAP', '0') != '1' and n % 256 == 0 and n // c >= 4096
-            and (4 * H) % 256 == 0 and D % 32 == 0 and H % 32 == 0):
+    if not (c > 1 and _settings.OVERLAP and n % 256 == 0 and n // c >= 4096 and (4 * H) % 256 == 0 and D % 32 == 0 and H % 32 == 0):
         return None
     tiles = n // 256
-    shares = [float(v) for v in ENC_SPLIT.split(',')] if ENC_SPLIT else [1.0] * c
-    bounds, acc = [0], 0.0
-    for v in shares[:-1]:
-        acc += v
-        bounds.append(int(round(tiles * acc / sum(shares))) * 256)
-    bounds.append(n)
+    bounds = [int(round(tiles * i / c)) * 256 for i in range(c)] + [n]
     if any(b1 - b0 < 2048 for b0, b1 in zip(bounds, bounds[1:])):
         return None
     return list(zip(bounds, bounds[1:]))
@@ -1408,13 +1355,11 @@ def _encoder_lstm_fwd_chunked(lib, x, w_ih, w_hh, bias, hs, cs, num_steps, ns, c
     main = torch.cuda.current_stream(dev)
     gss = [torch.empty(n, 4 * H, dtype=torch.float32, device=dev) for _ in range(num_steps)]
 
-    def chain(r0, r1, after_first=None):
+    def chain(r0, r1):
         rows = r1 - r0
         st = stream()
         check(lib.stove_gemm_bf16(ptr(x[r0:]), ptr(w_ih), ptr(bias), None, ptr(gss[0][r0:]), rows, 4 * H, D, x.stride(0), w_ih.stride(0), 4 * H,
                                   0, 0, ns, 1, 3, None, st), 'stove_gemm_bf16')
-        if after_first is not None:
-            after_first()
         for k in range(num_steps):
             if k > 0:
                 check(lib.stove_gemm_bf16(ptr(hs[k - 1][r0:]), ptr(w_hh), None, ptr(gss[0][r0:]), ptr(gss[k][r0:]), rows, 4 * H, H, H, w_hh.stride(0),
@@ -1422,102 +1367,18 @@ def _encoder_lstm_fwd_chunked(lib, x, w_ih, w_hh, bias, hs, cs, num_steps, ns, c
             check(lib.stove_lstm_cell_fwd(ptr(gss[k][r0:]), None, ptr(cs[k - 1][r0:]) if k > 0 else None, ptr(cs[k][r0:]), ptr(hs[k][r0:]),
                                           rows, H, FAST_CELL, st), 'stove_lstm_cell_fwd')
 
-    # chunk c on stream c mod ENC_STREAMS (the main stream first)
-    sides = [_side_stream(dev, 'enc' if i == 1 else 'enc%d' % i) for i in range(1, min(ENC_STREAMS, len(chunks)))]
-    for sd in sides:
-        sd.wait_stream(main)
-    evs = []
-
-    def first_done():          # (A/B: the other streams' first chunk a product behind the main stream's)
-        if ENC_STAGGER:
-            ev = torch.cuda.Event()
-            ev.record(main)
-            evs.append(ev)
-    waited = set()
-    for c, (r0, r1) in enumerate(chunks):
-        i = c % (len(sides) + 1)
-        if i == 0:
-            chain(r0, r1, first_done if c == 0 else None)
-        else:
-            with torch.cuda.stream(sides[i - 1]):
-                if evs and i not in waited:
-                    sides[i - 1].wait_event(evs[0])
-                    waited.add(i)
-                chain(r0, r1)
-    for sd in sides:
-        main.wait_stream(sd)
-    return gss
-
-
-# The backward chain in the same chunks: measured, OFF (same box, alternating: 2.85-2.88 ms against 2.81-2.82, six objects 5.39 against
-# 5.35-5.37) -- that phase already runs the recursion's weight gradients, dW_hh and the column sums beside the chain and is bound by
-# what all of them move through HBM; two chains of cells only add to the contention.  Kept as a tested switch.
-ENC_CHUNKS_BWD = os.environ.get('STOVE_ENC_CHUNKS_BWD', '0') != '0'
-
-
-def _encoder_lstm_bwd_chunked(lib, x, w_hh, gss, hs, cs, dhs, views, ns, chunks, wgrad):
-    """The backward chain [cell backward, dg W_hh + dh of the step before, ...] over the forward's row chunks, alternating between
-    the main stream and the 'enc' stream; the products that contract over the rows follow on the parameter stream (dW_hh, the bias
-    sums: once every chunk has written its gate gradients) and on the main stream (dW_ih: chunk by chunk into the arena's view,
-    the first chunk's while the other stream still runs its last cells).  Per row the same kernels as the unchunked chain;
-    dW_ih is the sum of per-chunk products (another summation order than one product over all rows)."""
-    K = len(gss)
-    n, H = x.shape[0], w_hh.shape[1]
-    dev = x.device
-    main, enc = torch.cuda.current_stream(dev), _side_stream(dev, 'enc')
-    dgx = torch.empty(n, 4 * H, dtype=torch.float32, device=dev)
-    dg_all = torch.empty(K - 1, n, 4 * H, dtype=torch.float32, device=dev)
-    dc = [torch.empty(n, H, dtype=torch.float32, device=dev) for _ in range(2)]
-    dhb = [torch.empty(n, H, dtype=torch.float32, device=dev) for _ in range(2)]
-    ws = torch.empty(lib.stove_colsum_ws_floats(n, 4 * H) + 1, dtype=torch.float32, device=dev)
-    last = len(chunks) - 1
-
-    def whh_grad():
-        wgrad(dg_all.view(-1, 4 * H), hs[:K - 1].view(-1, H), out=views[1])
-
-    def bias_sums():
-        _side_keep(ws)
-        check(lib.stove_colsum2(ptr(dgx), ptr(views[2]), ptr(views[3]), 1, ptr(ws), n, 4 * H, stream()), 'stove_colsum2')
-
-    def chain(c, r0, r1):
-        rows = r1 - r0
-        st = stream()
-        dh = dhs[K - 1][r0:]
-        for k in range(K - 1, -1, -1):
-            dg = dg_all[k - 1][r0:] if k > 0 else None
-            check(lib.stove_lstm_cell_bwd_rows(ptr(gss[k][r0:]), None, ptr(cs[k - 1][r0:]) if k > 0 else None, ptr(cs[k][r0:]), ptr(dh),
-                                               ptr(dc[(k + 1) % 2][r0:]) if k < K - 1 else None, ptr(dg) if dg is not None else None,
-                                               ptr(dc[k % 2][r0:]), ptr(dgx[r0:]) if k == 0 else None, ptr(dg_all[0][r0:]) if k == 0 else None,
-                                               K - 1 if k == 0 else 0, n * 4 * H, rows, H, FAST_CELL, st), 'stove_lstm_cell_bwd_rows')
-            if k <= 1:
-                # the parameter stream waits for this chunk's gate gradients (k = 1: all that W_hh sees; k = 0: dgx); behind the last
-                # chunk's it runs the product / the sums
-                fn = whh_grad if k == 1 else bias_sums
-                if c == last:
-                    run_on_side(dev, fn, (dg_all, hs) if k == 1 else (dgx,))
-                else:
-                    check(lib.stove_stream_after(_side_stream(dev).cuda_stream, st), 'stove_stream_after')
-            if k > 0:
-                out = dhb[(k - 1) % 2][r0:]
-                check(lib.stove_gemm_bf16(ptr(dg), ptr(w_hh), None, ptr(dhs[k - 1][r0:]), ptr(out), rows, H, 4 * H, 4 * H, w_hh.stride(0), H,
-                                          0, 1, ns, 1, 1, None, st), 'stove_gemm_bf16')
-                dh = out
-
+    # even chunks on the main stream, odd chunks on the 'enc' stream forked from it (more than two concurrently active capture
+    # streams cost the graph replay more than they hide: DESIGN.md)
+    enc = _side_stream(dev, 'enc')
     enc.wait_stream(main)
     for c, (r0, r1) in enumerate(chunks):
         if c % 2 == 0:
-            chain(c, r0, r1)
+            chain(r0, r1)
         else:
             with torch.cuda.stream(enc):
-                chain(c, r0, r1)
-    # dW_ih: the main stream's own chunks first, the other stream's behind the join
-    for c, (r0, r1) in enumerate(chunks):
-        if c % 2 == 0:
-            wgrad(dgx[r0:r1], x[r0:r1], out=views[0])
+                chain(r0, r1)
     main.wait_stream(enc)
-    for c, (r0, r1) in enumerate(chunks):
-        if c % 2 == 1:
-            wgrad(dgx[r0:r1], x[r0:r1], out=views[0])
+    return gss
 
 
 class _EncoderLstmFn(torch.autograd.Function):
@@ -1561,7 +1422,7 @@ class _EncoderLstmFn(torch.autograd.Function):
                 if k > 0 and ns:
                     # K = 256 (8 k-steps): the 128 x 128 tile (1600 workgroups) beats 256 x 128; the 256 x 256 tile is level with it
                     # warm and 5 % ahead from cold caches
-                    gs = gemm_bf16(hs[k - 1], w_hh, nsplit=ns, splitk=1, add=gx, tile=3 if (GEMM_WIDE and (4 * H) % 256 == 0) else 2)
+                    gs = gemm_bf16(hs[k - 1], w_hh, nsplit=ns, splitk=1, add=gx, tile=3 if (4 * H) % 256 == 0 else 2)
                 elif k > 0:
                     with _blas('hipblas'):
                         gs = torch.addmm(gx, hs[k - 1], w_hh.t())
@@ -1587,21 +1448,15 @@ class _EncoderLstmFn(torch.autograd.Function):
         # Parameter gradients straight into the arena's views (see _grad_views): no AccumulateGrad launches, and the two
         # weight-gradient GEMMs run on the second stream next to the rest of this backward -- only the optimiser reads them.
         views = _grad_views(w_ih, w_hh, b_ih, b_hh, needs=ctx.needs_input_grad[1:5]) if (ns and gemm_ok(n) and not ctx.needs_input_grad[0]) else None
-        fork = views is not None and os.environ.get('STOVE_NO_OVERLAP', '0') != '1'
+        fork = views is not None and _settings.OVERLAP
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if fork else main
 
         def wgrad(dy, inp, out=None):
             """dy^T @ inp over all rows: both operands are stored K-major for this product."""
             if ns and gemm_ok(dy.shape[0]):
-                M_, N_, K_ = dy.shape[1], inp.shape[1], dy.shape[0]
-                wide_tiles = (M_ // 256) * (N_ // 256)
-                if GEMM_WIDE_WGRAD and M_ % 256 == 0 and N_ % 256 == 0 and 8 <= wide_tiles <= 128 and K_ // (256 // wide_tiles) >= 512:
-                    # dW_ih (1024 x 1024 over 25 600 frames): sixteen 256 x 256 tiles x 16 K-slices, 147 us from cold caches
-                    # against 192 for thirty-two 256 x 128 tiles x 8 (tools/gemm_tile_ab.py, GEMM_COLD=1) -- but OFF by default: a
-                    # workgroup of the wide tile holds every register of its CU (2 x 254 per SIMD lane), the bias sums on the
-                    # second stream then start only when it is done, and the step's tail is 18 us LONGER (r04 timeline)
-                    return gemm_bf16(dy, inp, None, True, True, ns, splitk=256 // wide_tiles, out=out, tile=3)
+                # (the 256 x 256 tile for dW_ih is 45 us shorter alone and 11 us LONGER in the step: it holds every register of its CUs
+                # and the bias sums on the second stream wait for it -- DESIGN.md)
                 return gemm_bf16(dy, inp, None, True, True, ns, out=out)
             return _splitk_tn(dy, inp)
 
@@ -1610,12 +1465,6 @@ class _EncoderLstmFn(torch.autograd.Function):
                 run_on_side(dev, fn, bufs)
             else:
                 fn()
-        chunks = _enc_chunks(n, x.shape[1], H) if (fork and ENC_CHUNKS_BWD and K > 1) else None
-        if chunks is not None:
-            with torch.cuda.device(dev):
-                _encoder_lstm_bwd_chunked(lib, x, w_hh, gss, hs, cs, dhs, views, ns, chunks, wgrad)
-                join_side_after_backward(dev)
-            return None, None, None, None, None, None, None, None
         with torch.cuda.device(dev):
             dgx = torch.empty_like(gx)
             # gate gradients of steps 1..K-1 are kept ((K-1) x 105 MB at 25 600 frames): dW_hh is ONE GEMM over all of
@@ -1692,7 +1541,7 @@ def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=
     if splitk is None:
         splitk = gemm_splitk(M, N, K) if bias is None and add is None else 1
     if (splitk == 1 and out is None and not a_kmajor and (bias is not None or add is not None) and K >= 512 and K % 256 == 0
-            and M * N % 4 == 0 and os.environ.get('STOVE_GEMM_AUTO', '1') != '0'):
+            and M * N % 4 == 0):
         # Short activations x weights products (the reference's default training shape has 2 048 frames per step: 16-64 workgroups of
         # the tile, each walking all of K at ~1.5 us per k-step): split K so that every CU gets a workgroup.  The add term becomes
         # the initial value of C (split-K accumulates into C when add == C), a bias rides the slice sum (fewer than 16 slices).
@@ -1721,16 +1570,12 @@ def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=
     return c
 
 
-GEMM_WIDE_WGRAD = os.environ.get('STOVE_GEMM_WIDE_WGRAD', '0') == '1'
-GEMM_WIDE = os.environ.get('STOVE_GEMM_WIDE', '1') != '0'      # A/B switch of the 256 x 256 tile for the input projection
-
-
 def _gemm_rows_balanced(x, w, bias, ns):
     """x W^T + bias for a tall x on the 256 x 128 tile.  The tile count is rarely a multiple of the CU count (25 600 frames:
     800 tiles on 256 CUs = three full rounds and 32 tiles that keep an eighth of the chip busy for a fourth); the rows of the
     incomplete round go through a second launch that splits K eight ways instead (256 short workgroups)."""
     M, N = x.shape[0], w.shape[0]
-    if GEMM_WIDE and N % 256 == 0 and M >= 4096 and x.shape[1] >= 512:
+    if N % 256 == 0 and M >= 4096 and x.shape[1] >= 512:
         # 256 x 256 workgroup tile (eight waves of 64 x 128): 2/3 of the operand bytes per flop through L2 and LDS, half the
         # barriers; 25 600 x 1024 x 1024 isolated 183 us against 229 (256 x 128) / 211 (128 x 128), profiles/r04_gemm_tiles.txt
         return gemm_bf16(x, w, bias=bias, nsplit=ns, splitk=1, tile=3)

@@ -17,13 +17,13 @@ tests inject the reference's draws: 'latent' (n,o,12), 'std' (n,o,12), 'steps' (
 otherwise they come from the device generator.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
 from torch.distributions import Normal
 
 from .. import ops
+from .. import settings as _settings
 from ..utils.utils import bw_transform
 from .dynamics import Dynamics
 from .supair import Supair
@@ -75,7 +75,7 @@ class Stove(nn.Module):
         if src is None or src.device != dev:
             src = self._noise_source = ops.NoiseSource(dev)
         main, side = torch.cuda.current_stream(dev), ops._side_stream(dev, 'pre')
-        if os.environ.get('STOVE_NO_OVERLAP', '0') == '1':
+        if not _settings.OVERLAP:
             return src.normal(numel), None
         side.wait_stream(main)                   # allocator order (the block may have been in use on `main`); nothing of this step is on `main` yet
         with torch.cuda.stream(side):
@@ -202,7 +202,7 @@ class Stove(nn.Module):
         fused_state = bool(getattr(c, 'fused_state', True)) and not c.debug_match_appearance
         if pooled_ev is not None:
             torch.cuda.current_stream(x.device).wait_event(pooled_ev)
-        elif draw:
+        elif draw and pooled is None:                              # (no overlap: _draw_ahead already drew on this stream, no event to wait for)
             pooled = self._noise('pooled', (n_pool,), codes)      # [latent | std | steps]
         if fused_state:
             zfix, zsup_loop, zsstd_loop, init6, idx = ops.supair_state(
@@ -258,7 +258,7 @@ class Stove(nn.Module):
             lik_all = None
             pieces = int(getattr(c, 'pipeline_pieces', 1))
             if (pieces > 1 and fused_state and sink is not None and arena is not None and arena.has_spn and Ts >= 2 * pieces
-                    and os.environ.get('STOVE_NO_OVERLAP', '0') != '1' and ops.dynloop_range_ok(o) and x.is_cuda
+                    and _settings.OVERLAP and ops.dynloop_range_ok(o) and x.is_cuda
                     and x.dtype == torch.float32 and c.channels == 1 and tuple(x.shape[-2:]) == (32, 32)
                     and c.patch_width == 10 and c.patch_height == 10 and not bool(getattr(c, 'align_corners', False))):
                 # [amd] recursion and image likelihood as ONE pipelined node (ops._InferScoreFn): the likelihood of the frames a

@@ -8,7 +8,6 @@ every SPN parameter.  The stand-alone `patches_from_z` / `masks_from_z` API meth
 plots, appearance embedding; not on the hot path) stay PyTorch-ROCm host code.
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -52,9 +51,9 @@ class Supair(nn.Module):
         if x.shape[-1] != 32 or x.shape[-2] != 32 or bool(getattr(self.c, 'align_corners', False)):
             # [amd] any other frame size (the reference's stock gravity / multibilliards data are 50 x 50, envs.py:771-773, 841-844)
             # and the torch-1.0.1 sampling convention (align_corners=True): the same fused pipeline with the geometry at run time and
-            # the general-size background operator (stove_scene_fwd_any).  STOVE_SCENE_COMPOSED=1: the reference's own op sequence
+            # the general-size background operator (stove_scene_fwd_any).  config.scene_composed = True: the reference's own op sequence
             # on ATen's sampler instead (_likelihood_general, the cross-check of the tests; ~10x slower).
-            if os.environ.get('STOVE_SCENE_COMPOSED', '0') == '1':
+            if getattr(self.c, 'scene_composed', False):
                 return self._likelihood_general(x, z_obj, log_from)
             geom = (int(x.shape[-1]), int(x.shape[-2]), bool(getattr(self.c, 'align_corners', False)))
         frames = x.flatten(start_dim=2)                 # (n, T', 1024) view: a time-slice of longer clips is NOT copied (ops._SceneFn)

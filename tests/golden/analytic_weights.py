@@ -88,12 +88,16 @@ def _stress_values(name, shape):
         return _sine(name, shape, 0.5, 0.5)
     if name.endswith('.params'):
         return _sine(name, shape, 20.0, 0.0)
+    # (recognition network: amplitudes chosen so that the objects' codes stay DISTINCT -- with a stronger recurrence the LSTM runs into
+    # a fixed point after three steps, objects 4-6 of the six-object cases get the same code to 1e-7, and the matcher's argmin
+    # between them is decided below float32 resolution: a fixture no float32 implementation can be held to.  tools/fixture_robustness.py
+    # checks that 3e-5 of noise on the codes leaves every matching decision of the stress fixtures unchanged.)
     if 'encoder.rnn.weight_ih' in name:
-        return _sine(name, shape, 0.3, 0.0)
+        return _sine(name, shape, 0.2, 0.0)
     if 'encoder.rnn.weight_hh' in name:
-        return _sine(name, shape, 0.4, 0.0)
+        return _sine(name, shape, 0.2, 0.0)
     if 'encoder.fc1.weight' in name:
-        return _sine(name, shape, 0.3, 0.0)
+        return _sine(name, shape, 0.4, 0.0)
     if 'encoder.fc2.weight' in name:
         return _sine(name, shape, 8.0, 0.0)
     if 'encoder.fc2.bias' in name:

@@ -48,6 +48,33 @@ def check_grad(key, a, b, bar_max, bar_l2, bar_small):
     check(key + '.small', err_small(a, b), bar_small)
 
 
+_GAPS = None
+
+
+def ref_gap(case, *path, default=0.0):
+    """What the REFERENCE's own float32 run differs from its float64 run by on a round-5 regime fixture (tests/golden/
+    g16_reference_fp32_gap.json, written by oracle/fp32_gap.py), e.g. ref_gap('g7_n3_stress', 'prop', 'z').  0 for fixtures without a
+    record (the 'analytic' regime: its bars are pinned at ~3x what the kernels achieve)."""
+    global _GAPS
+    if _GAPS is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g16_reference_fp32_gap.json')) as f:
+            _GAPS = json.load(f)['gaps']
+    v = _GAPS.get(case)
+    for k in path:
+        if not isinstance(v, dict) or k not in v:
+            return default
+        v = v[k]
+    return float(v) if v is not None else default
+
+
+def regime_bar(bar, gap, mult=4.0):
+    """The tolerance of a quantity in a weight regime: the 'analytic' bar, or -- where a saturated model amplifies float32 rounding
+    beyond it -- `mult` times the reference's own float32-vs-float64 gap on the same fixture, whichever is larger."""
+    return max(float(bar), mult * float(gap))
+
+
 _WORST = {}
 
 

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import stove_oracle as O
-from gpu_helpers import check, check_grad, err, fill_analytic
+from gpu_helpers import check, check_grad, err, fill_analytic, ref_gap, regime_bar
 from helpers import load_golden, oracle_setup, t_
 
 pytestmark = pytest.mark.gpu
@@ -66,7 +66,10 @@ def test_dynamics_step(name, regime, arena):
     for k, v in gold.items():
         if k.startswith('g_'):
             assert params[k[2:]].grad is not None, k
-            check_grad('dyn_step.grad_param', params[k[2:]].grad, v, 2.5e-5, 2e-5, 1e-3)
+            # ('stress': the entry-wise bar follows the reference's own float32 run, whose small entries are 1.7e-3 off its float64 ones)
+            gp = lambda m: ref_gap(f'g5_{name}_{regime}', 'grad_param', m)
+            check_grad('dyn_step.grad_param' + ('' if regime == 'analytic' else '.' + regime), params[k[2:]].grad, v,
+                       regime_bar(2.5e-5, gp('max')), regime_bar(2e-5, gp('l2')), regime_bar(1e-3, gp('small')))
             n += 1
     assert n >= 26
 
@@ -214,26 +217,33 @@ def test_stove_forward_elbo_and_grads(name, regime, fused, arena):
     x = t_(gold['x']).float().to(DEV)
     actions = t_(gold['actions']).float().to(DEV) if 'actions' in gold else None
     elbo, prop, rewards = st(x, 0, actions)
+    # Bars: the 'analytic' ones (pinned at ~3x what the kernels achieve there) or, in the other regimes, 4x the REFERENCE's own
+    # float32-vs-float64 gap on the same fixture (tests/golden/g16_reference_fp32_gap.json) where that is larger: a saturated model
+    # amplifies float32 rounding (z of the 'stress' fixtures: 1.2e-5 in the reference's own float32 run).  The ELBO bar stays.
+    case = f'g7_{name}_{regime}'
+    tag = '' if regime == 'analytic' else '.' + regime
     rel = abs(float(elbo) - float(gold['elbo'])) / abs(float(gold['elbo']))
-    check('stove.elbo_rel', rel, 1.5e-6)                       # the north-star bar is 1e-4; achieved 2.5e-7
+    check('stove.elbo_rel' + tag, rel, 1.5e-6)                 # the north-star bar is 1e-4; achieved 2.5e-7
     for k in ('z', 'z_dyn', 'z_sup', 'z_std', 'z_sup_std', 'log_q', 'translik', 'bg', 'patch', 'overlap'):
-        check('stove.prop_' + k, err(prop[k], gold['p_' + k]), 8e-6 if k == 'z_sup' else 3e-6)
-    check('stove.prop_z_dyn_std', err(prop['z_dyn_std'][2:], gold['p_z_dyn_std'][2:]), 1e-6)
+        check('stove.prop_' + k + tag, err(prop[k], gold['p_' + k]), regime_bar(8e-6 if k == 'z_sup' else 3e-6, ref_gap(case, 'prop', k)))
+    check('stove.prop_z_dyn_std' + tag, err(prop['z_dyn_std'][2:], gold['p_z_dyn_std'][2:]), 1e-6)
     loss = -elbo
     if actions is not None:
-        check('stove.rewards', err(rewards, gold['rewards']), 1e-6)
+        check('stove.rewards' + tag, err(rewards, gold['rewards']), 1e-6)
         loss = loss + 3.0 * (rewards ** 2).sum()
     loss.backward()
     params = dict(st.named_parameters())
     n = 0
+    gt = lambda m: ref_gap(case, 'grad_tensor', m)
     for k, v in gold.items():
         if k.startswith('gn_'):
             p = params[k[3:]]
             assert p.grad is not None, k
-            check('stove.grad_norm', abs(float(p.grad.norm()) - float(v)) / (float(v) + 1e-9), 1.5e-4)
+            check('stove.grad_norm' + tag, abs(float(p.grad.norm()) - float(v)) / (float(v) + 1e-9), regime_bar(1.5e-4, ref_gap(case, 'grad_norm_rel_max')))
             n += 1
         elif k.startswith('g_'):
-            check_grad('stove.grad_tensor', params[k[2:]].grad, v, 3e-4, 3.5e-4, 4e-3)     # the reference's own fp32-vs-fp64 gap is 3.3e-4 (max-norm)
+            # the reference's own fp32-vs-fp64 gap is 3.3e-4 (max-norm) on the analytic fixtures
+            check_grad('stove.grad_tensor' + tag, params[k[2:]].grad, v, regime_bar(3e-4, gt('max')), regime_bar(3.5e-4, gt('l2')), regime_bar(4e-3, gt('small')))
     assert n > 50
     if arena:                                                  # cores 1-2 are never used: their gradients stay zero
         assert float(params['dyn.self_cores.1.0.weight'].grad.abs().max()) == 0.0
@@ -244,7 +254,7 @@ def test_stove_forward_elbo_and_grads(name, regime, fused, arena):
         fut = actions[:, :5] if actions is not None else None
         app = prop['obj_appearances'][:, -1] if actions is not None else None
         zp, rp = st.rollout(z_last, num=gold['roll_z'].shape[1], actions=fut, appearance=app)
-    check('stove.rollout_z', err(zp, gold['roll_z']), 3e-6)
+    check('stove.rollout_z' + tag, err(zp, gold['roll_z']), regime_bar(3e-6, ref_gap(case, 'rollout_z')))
     if actions is not None:
         check('stove.rollout_rewards', err(rp, gold['roll_rewards']), 1e-6)
     if 'eps_roll' in gold:

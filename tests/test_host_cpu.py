@@ -156,19 +156,17 @@ def test_recognition_network_row_chunks_cover_the_batch_in_whole_tiles():
     """ops._enc_chunks (host logic of the chunked forward chain, reference encoder.py:43-51): the chunks partition the rows, every
     boundary on a 256-row tile, and shapes the 256 x 256 tile cannot take whole (or that are too small to fill the chip) stay unchunked."""
     from stove_amd import ops
-    saved = ops.ENC_CHUNKS, ops.ENC_SPLIT
+    saved = ops.ENC_CHUNKS
     try:
-        ops.ENC_CHUNKS, ops.ENC_SPLIT = 2, ''
+        ops.ENC_CHUNKS = 2
         assert ops._enc_chunks(25600, 1024, 256) == [(0, 12800), (12800, 25600)]
         assert ops._enc_chunks(2048, 1024, 256) is None            # the reference's default training shape: 256 clips x 8 frames
         assert ops._enc_chunks(25600, 2500, 256) is None           # 50 x 50 frames: K is not a whole number of k-steps
         assert ops._enc_chunks(25601, 1024, 256) is None
-        ops.ENC_SPLIT = '64,36'
-        assert ops._enc_chunks(25600, 1024, 256) == [(0, 16384), (16384, 25600)]
-        ops.ENC_CHUNKS, ops.ENC_SPLIT = 3, ''
+        ops.ENC_CHUNKS = 3
         ch = ops._enc_chunks(25600, 1024, 256)
         assert ch[0][0] == 0 and ch[-1][1] == 25600 and all(a[1] == b[0] for a, b in zip(ch, ch[1:])) and all(r0 % 256 == 0 for r0, _ in ch)
         ops.ENC_CHUNKS = 1
         assert ops._enc_chunks(25600, 1024, 256) is None
     finally:
-        ops.ENC_CHUNKS, ops.ENC_SPLIT = saved
+        ops.ENC_CHUNKS = saved
