@@ -603,6 +603,11 @@ def main():
     a = parse()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(launch_ranks(a))
+    # stdout carries ONE line, the JSON record: everything else that writes to file descriptor 1 (RCCL prints a version banner from
+    # C when a communicator is made) goes to stderr; the record is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != a.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
@@ -828,7 +833,7 @@ def main():
             'roofline': roofline, 'cpu_baseline': cpu, 'variants': variants,
             'elbo_rel_vs_reference': parity.get('elbo_rel_vs_reference') if parity else None, 'reference_parity': parity, 'comm': comm,
         }
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -611,13 +611,18 @@ def object_embedding(c, z, x_color):
     return pat.mean((-1, -2)).view(*z.shape[:-1], 3)
 
 
-def stove_forward(c, params, structs, x_color, eps, actions=None, detail=False):
-    """Stove.forward -> stove_forward.  x_color (B,T,3,H,W) in [0,1]; eps from draw_eps."""
+def stove_forward(c, params, structs, x_color, eps, actions=None, detail=False, code_values=None):
+    """Stove.forward -> stove_forward.  x_color (B,T,3,H,W) in [0,1]; eps from draw_eps.
+    code_values (BT, N, 8): evaluate everything behind the recognition network AT these codes (the gradient still flows into the
+    recognition network as usual) -- the reference's numbers at another implementation's float32 codes, for fixtures whose
+    gradients amplify a 1e-5 difference of the codes a thousandfold (tests: the 'stress' weight regime)."""
     x = bw_transform(x_color) if c.debug_bw else x_color
     B, T = x.shape[:2]
     N, cl, skip = c.num_obj, c.cl, c.skip
 
     code = encoder_forward(c, params, x.flatten(0, 1))              # (BT, N, 8)
+    if code_values is not None:
+        code = code + (code_values.to(code.dtype).view_as(code) - code.detach())
     zs, zs_std = constrain_zp(c, code.flatten(0, 1))
     zs, zs_std = zs.view(B, T, N, 4), zs_std.view(B, T, N, 4)
 

@@ -17,6 +17,7 @@
 //   * the workgroup synchronises exactly twice per step (before the edge phase, before the aggregation).
 // All forward weights (90 KB) sit in LDS for the whole launch.
 #include "common.h"
+#include "split16.h"
 
 namespace stove {
 
@@ -275,6 +276,77 @@ __device__ __forceinline__ void sm_mfma_layer_t(const float* Wl, const smf4 (&x)
       }
   }
 }
+// ---- the edge chains' dense layers on half-piece MFMAs (round 5) --------------------------------------------------------------------
+// A 32-wide layer of the relation / attention chain as v_mfma_f32_16x16x32_f16 on IEEE-half hi / lo pieces (split16.h: three MFMAs per
+// product, 2^-22 of the value per product -- an fp32-grade result) instead of v_mfma_f32_16x16x4_f32: a 64 -> 32 layer is 12
+// MFMAs of 16 cycles on six independent accumulators instead of 32 dependent-chain MFMAs of 32 cycles (measured in place: 52
+// cycles each), 32 -> 32 is 6 instead of 16.  The accumulator of a layer is still the B operand of the next: k-slot j of lane
+// (column, g) in k-block b is feature 32 b + 4 g + j (j < 4) or 32 b + 16 + 4 g + (j - 4) -- the two accumulator tiles 2 b, 2 b + 1 the
+// lane holds -- a sum over k does not care about the order as long as the weights use the same one.  The weight fragments (A
+// operands, hi and lo) are built ONCE per launch from the fp32 LDS image and stay in registers over all time steps.
+// Forward only: activations and weights sit inside half's range; the backward's gradients do not (gnn_small_bwd.hip keeps fp32 MFMAs).
+struct SmChainW {
+  bf16x8 h2[2][2], l2[2][2];      // second layer (64 -> 32): [k-block b][output tile u], hi and lo pieces
+  bf16x8 h3[2], l3[2];            // third layer (32 -> 32) of the relation chain: [output tile u]
+};
+__device__ __forceinline__ void sm_frag_split(const float4 a, const float4 b, bf16x8& hi, bf16x8& lo) {
+  u32x2 h0, l0, h1, l1;
+  split4<2, true>(a, h0, l0);
+  split4<2, true>(b, h1, l1);
+  hi = __builtin_bit_cast(bf16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
+  lo = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
+}
+// fragments of the [K/4][32][4] LDS weight image Wl of a layer with KB k-blocks of 32 inputs
+template <int KB>
+__device__ __forceinline__ void sm_chain_wfrag(const float* Wl, int lane, bf16x8 (*h)[2], bf16x8 (*l)[2]) {
+  const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int b = 0; b < KB; ++b)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      sm_frag_split(*reinterpret_cast<const float4*>(Wl + ((8 * b + g) * 32 + 16 * u + i) * 4),
+                    *reinterpret_cast<const float4*>(Wl + ((8 * b + 4 + g) * 32 + 16 * u + i) * 4), h[b][u], l[b][u]);
+}
+__device__ __forceinline__ void sm_chain_wbuild(const SmLds& L, SmChainW& cw) {
+  const int wv = wave_id(), lane = lane_id();
+  if (wv < 2) return;
+  const int h = wv == 2 ? 1 : 0;
+  sm_chain_wfrag<2>(L.W + (h ? W_A1 : W_R1), lane, cw.h2, cw.l2);
+  if (h == 0) {
+    bf16x8 h3[1][2], l3[1][2];
+    sm_chain_wfrag<1>(L.W + W_R2, lane, h3, l3);
+    cw.h3[0] = h3[0][0]; cw.h3[1] = h3[0][1];
+    cw.l3[0] = l3[0][0]; cw.l3[1] = l3[0][1];
+  }
+}
+__device__ __forceinline__ float4 sm_f4(smf4 v) { return float4{v[0], v[1], v[2], v[3]}; }
+// acc[c][u] += W x for ET column tiles, KB k-blocks: x[c][2 b], x[c][2 b + 1] are the accumulator tiles of the previous layer
+template <int KB, int ET>
+__device__ __forceinline__ void sm_split_layer_tiles(const bf16x8 (*wh)[2], const bf16x8 (*wl)[2], const smf4 (&x)[ET][2 * KB], smf4 (&acc)[ET][2]) {
+  f32x4 p[ET][2], q[ET][2];          // the two cross terms on accumulators of their own (six independent chains per column tile)
+#pragma unroll
+  for (int c = 0; c < ET; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) p[c][u] = q[c][u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int b = 0; b < KB; ++b)
+#pragma unroll
+    for (int c = 0; c < ET; ++c) {
+      bf16x8 xh, xl;
+      sm_frag_split(sm_f4(x[c][2 * b]), sm_f4(x[c][2 * b + 1]), xh, xl);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        p[c][u] = mfma16<true>(wl[b][u], xh, p[c][u]);
+        q[c][u] = mfma16<true>(wh[b][u], xl, q[c][u]);
+        acc[c][u] = mfma16<true>(wh[b][u], xh, acc[c][u]);
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < ET; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[c][u] += p[c][u] + q[c][u];
+}
+
 // d phi / d pre-activation from the activation's OUTPUT, four values
 __device__ __forceinline__ smf4 sm_dphi4(smf4 y, int elu) {
   smf4 r;
@@ -341,8 +413,7 @@ __device__ __forceinline__ SmEdgeLane sm_edge_lane(int N, int compact_streams, i
 // bias / distance vectors -- is read from LDS BEFORE the first barrier of the step (wave 3 idles there for ~6 000 cycles, the
 // others issue the reads behind their node work), so the chain starts on the barrier's release with its operands in registers.
 struct SmEdgePre {
-  SmMW<4> w1;            // chains: first 64 -> 32 layer;  self-dynamics wave: w1.w[0..1] = layer 0, w1.w[2..3] = layer 1
-  SmMW<2> w2;            // relation chain: 32 -> 32 layer
+  SmMW<4> w1;            // self-dynamics wave: w1.w[0..1] = layer 0, w1.w[2..3] = layer 1
   smf4 wd[4], b0[4];     // chains: distance weights and biases of the factorised first layer
   smf4 bl2[2], bl3[2];   // biases of the wave's second / third layer (self-dynamics: layer 0 / layer 1)
 };
@@ -359,9 +430,7 @@ __device__ __forceinline__ void sm_edge_prefetch(const SmLds& L, SmEdgePre& pre)
       pre.bl3[t] = sm_ld4(V + V_S1 + 16 * t + 4 * g);
     }
   } else if (wv >= 2) {
-    const int h = wv == 2 ? 1 : 0;
-    pre.w1 = sm_mfma_wload<4>(L.W + (h ? W_A1 : W_R1), lane);
-    if (h == 0) pre.w2 = sm_mfma_wload<2>(L.W + W_R2, lane);
+    const int h = wv == 2 ? 1 : 0;       // (the chain's weights are the half-piece fragments of SmChainW, resident since the launch began)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       pre.wd[t] = sm_ld4(V + (h ? V_WDA : V_WDR) + 16 * t + 4 * g);
@@ -379,7 +448,7 @@ __device__ __forceinline__ void sm_edge_prefetch(const SmLds& L, SmEdgePre& pre)
 // through every layer together (a kernel built for ET tiles is only used where the last tile has edges in it)
 template <bool SAVE, int ET>
 __device__ __forceinline__ void sm_edge_chain(const SmLds& L, const SmCfg& cf, const SmAct& act, const SmEdgeLane (&el)[ET],
-                                              const SmEdgePre& pre, int h) {
+                                              const SmEdgePre& pre, const SmChainW& cw, int h) {
   const int g = lane_id() >> 4;
   const float* V = L.V;
   float* s1p = h ? act.A1 : act.R1;
@@ -402,7 +471,7 @@ __device__ __forceinline__ void sm_edge_chain(const SmLds& L, const SmCfg& cf, c
   for (int c = 0; c < ET; ++c)
 #pragma unroll
     for (int t = 0; t < 2; ++t) acc[c][t] = pre.bl2[t];
-  sm_mfma_layer_tiles<4, ET>(pre.w1, x1, acc);
+  sm_split_layer_tiles<2, ET>(cw.h2, cw.l2, x1, acc);
   if (SAVE) {          // the stores of the layer input go out behind the MFMAs that consumed it
 #pragma unroll
     for (int c = 0; c < ET; ++c)
@@ -422,7 +491,10 @@ __device__ __forceinline__ void sm_edge_chain(const SmLds& L, const SmCfg& cf, c
     for (int c = 0; c < ET; ++c)
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[c][t] = pre.bl3[t];
-    sm_mfma_layer_tiles<2, ET>(pre.w2, a2, acc);
+    {
+      const bf16x8 wh[1][2] = {{cw.h3[0], cw.h3[1]}}, wl[1][2] = {{cw.l3[0], cw.l3[1]}};
+      sm_split_layer_tiles<1, ET>(wh, wl, a2, acc);
+    }
     sm_stamp(cf, 11);
 #pragma unroll
     for (int c = 0; c < ET; ++c)
@@ -467,7 +539,7 @@ __device__ __forceinline__ void sm_edge_chain(const SmLds& L, const SmCfg& cf, c
 // sbuf [NMX][32]: encoder outputs S of the node rows (written in P1); sdx [NMX][32]: SD of the node rows (read in P4)
 template <bool SAVE, int ET>
 __device__ __forceinline__ void sm_edge_phase_mfma(const SmLds& L, const SmCfg& cf, const SmAct& act, const float* sbuf, float* sdx,
-                                                   const SmEdgeLane (&el)[ET], const SmEdgePre& pre) {
+                                                   const SmEdgeLane (&el)[ET], const SmEdgePre& pre, const SmChainW& cw) {
   const int wv = wave_id();
   if (wv == 1) {
     // ---- self-dynamics, columns = node rows (at most 16: one tile)
@@ -497,7 +569,7 @@ __device__ __forceinline__ void sm_edge_phase_mfma(const SmLds& L, const SmCfg& 
     return;
   }
   if ((wv != 2 && wv != 3) || cf.N < 2) return;
-  sm_edge_chain<SAVE, ET>(L, cf, act, el, pre, wv == 2 ? 1 : 0);
+  sm_edge_chain<SAVE, ET>(L, cf, act, el, pre, cw, wv == 2 ? 1 : 0);
 }
 
 // One GNN step.  The lane's node row is r = wave (+ 4 for the upper half-wave of a two-rows-per-wave kernel); lane k of the half
@@ -505,7 +577,7 @@ __device__ __forceinline__ void sm_edge_phase_mfma(const SmLds& L, const SmCfg& 
 // the upper half mirrors the lower.  SAVE: write the activation block (act.* valid).
 template <bool SAVE, int NMX>
 __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float sinv, const SmAct& act, float& res_out, float& pred_out,
-                                        const SmEdgeLane (&el)[SmShape<NMX>::ET]) {
+                                        const SmEdgeLane (&el)[SmShape<NMX>::ET], const SmChainW& cw) {
   constexpr int RP = SmShape<NMX>::RP, ET = SmShape<NMX>::ET;
   constexpr bool HK = RP == 1;                                      // one row per wave: the half-waves split K (sm_wload / sm_dotw)
   __shared__ __attribute__((aligned(16))) float sbuf[NMX][32];     // S back as broadcast float4 reads (see sm_dotw)
@@ -611,7 +683,7 @@ __device__ __forceinline__ void sm_step(const SmLds& L, const SmCfg& cf, float s
   if (wv < N) sm_edge_prefetch(L, pre);
   // ---- P3: edges (i -> j, i != j) as the columns of the relation chain (wave 3) and the attention chain (wave 2); the
   // self-dynamics of all node rows as the columns of wave 1's
-  sm_edge_phase_mfma<SAVE, ET>(L, cf, act, &sbuf[0][0], &sdx[0][0], el, pre);
+  sm_edge_phase_mfma<SAVE, ET>(L, cf, act, &sbuf[0][0], &sdx[0][0], el, pre, cw);
   if (wv < N) wa = sm_wload<8, HK>(L.W + W_F0, 32, o);        // affector.0, in flight across the barrier
   sm_stamp(cf, 4);
   WG_SYNC();
@@ -698,6 +770,8 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     else if (l < sin_dim) sinv = extra[(((size_t)b * Ts + ts0) * N + r) * E + (l - 16)];
   }
   WG_SYNC();
+  SmChainW cw;
+  sm_chain_wbuild(L, cw);       // the edge chains' weight fragments: registers, for all time steps
   for (int ts = ts0; ts < ts1; ++ts) {
     const size_t o = ((size_t)b * Ts + ts) * N + r;
     // this step's epilogue inputs and the next step's extra inputs: issued now, consumed ~2 us later
@@ -718,7 +792,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_fwd_small_k(
     if (SAVE) a = sm_act2(act + (size_t)b * sm_act2_floats(N, Ts), N, Ts, ts);
     cf.stamps = (ts == ts1 - 1) ? stamps : nullptr;
     float res = 0.0f, prd = 0.0f;
-    sm_step<SAVE, NMX>(L, cf, sinv, a, res, prd, el);
+    sm_step<SAVE, NMX>(L, cf, sinv, a, res, prd, el, cw);
     if (wv < N) {
       // epilogue (stove.py:103-170 + constrain_z_dyn): lane d < 16 owns state dim d, lanes 16/17 the two scale dims
       const float res_s = from_xor16(res);      // RES[16 + d] for d < 16
@@ -796,13 +870,15 @@ __global__ __launch_bounds__(64 * kSmWaves) void rollout_fwd_small_k(const float
     if (l >= 16 && l < 18) scale = z_last[((size_t)b * N + r) * 18 + (l - 16)];       // sx, sy stay constant
   }
   WG_SYNC();
+  SmChainW cw;
+  sm_chain_wbuild(L, cw);
   for (int t = 0; t < num; ++t) {
     const size_t o = ((size_t)b * num + t) * N + r;
     float xnext = 0.0f;
     if (row && l >= 16 && l < sin_dim && t + 1 < num) xnext = extra[(((size_t)b * A + ((t + 1) % A)) * N + r) * E + (l - 16)];
     SmAct a{};
     float res = 0.0f, prd = 0.0f;
-    sm_step<false, NMX>(L, cf, sinv, a, res, prd, el);
+    sm_step<false, NMX>(L, cf, sinv, a, res, prd, el, cw);
     if (wv < N) {
       const float res_s = from_xor16(res);
       float zv;

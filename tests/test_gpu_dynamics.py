@@ -6,7 +6,7 @@ import torch
 
 import stove_oracle as O
 from gpu_helpers import check, check_grad, err, fill_analytic, ref_gap, regime_bar
-from helpers import load_golden, oracle_setup, t_
+from helpers import load_golden, oracle_setup, reference_at_codes, t_
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -217,7 +217,21 @@ def test_stove_forward_elbo_and_grads(name, regime, fused, arena):
     x = t_(gold['x']).float().to(DEV)
     actions = t_(gold['actions']).float().to(DEV) if 'actions' in gold else None
     elbo, prop, rewards = st(x, 0, actions)
-    # Bars: the 'analytic' ones (pinned at ~3x what the kernels achieve there) or, in the other regimes, 4x the REFERENCE's own
+    gold_at_codes = None
+    if regime == 'stress':
+        # The saturated model is chaotic: swapping this implementation's float32 codes (1e-6 of the largest code off the reference's)
+        # into the float64 REFERENCE moves its z by 8e-5 and its dynamics gradients by up to 1.5e-2 (tools/regime_probe.py, round 5).
+        # So the recognition network is held to the reference's codes, and everything behind it to the reference evaluated at the
+        # same codes (helpers.reference_at_codes: the oracle, pinned to the reference on this very fixture) with the tight bars;
+        # against the fixture itself the forward quantities keep the regime bars below.
+        from stove_amd.utils.utils import bw_transform
+        c_o, structs_o, params_o = oracle_setup(torch.float64, requires_grad=False, regime=regime, **CASES[name])
+        with torch.no_grad():
+            codes = st.sup.encoder(bw_transform(x).flatten(end_dim=1))
+            codes_ref = O.encoder_forward(c_o, params_o, O.bw_transform(t_(gold['x'])).flatten(0, 1))
+        check('encoder.codes.stress', err(codes, codes_ref), 5e-6)          # achieved 1.6e-6 (fp32 library GEMMs: 1.1e-6)
+        gold_at_codes = reference_at_codes(gold, regime, CASES[name], codes)
+    # Bars: the 'analytic' ones (pinned at ~3x what the kernels achieve there) or, in the other regimes, 6x the REFERENCE's own
     # float32-vs-float64 gap on the same fixture (tests/golden/g16_reference_fp32_gap.json) where that is larger: a saturated model
     # amplifies float32 rounding (z of the 'stress' fixtures: 1.2e-5 in the reference's own float32 run).  The ELBO bar stays.
     case = f'g7_{name}_{regime}'
@@ -227,6 +241,15 @@ def test_stove_forward_elbo_and_grads(name, regime, fused, arena):
     for k in ('z', 'z_dyn', 'z_sup', 'z_std', 'z_sup_std', 'log_q', 'translik', 'bg', 'patch', 'overlap'):
         check('stove.prop_' + k + tag, err(prop[k], gold['p_' + k]), regime_bar(8e-6 if k == 'z_sup' else 3e-6, ref_gap(case, 'prop', k)))
     check('stove.prop_z_dyn_std' + tag, err(prop['z_dyn_std'][2:], gold['p_z_dyn_std'][2:]), 1e-6)
+    if gold_at_codes is not None:
+        gold, tag = gold_at_codes, tag + '.at_codes'          # from here on: the reference at this implementation's codes
+        check('stove.elbo_rel' + tag, abs(float(elbo) - float(gold['elbo'])) / abs(float(gold['elbo'])), 1.5e-6)
+        for k in ('z', 'z_dyn', 'z_sup', 'z_std', 'z_sup_std', 'log_q', 'translik'):
+            # (log q = -((z - mean) / std)^2 / 2 - log std with z = mean + std eps: for the stress model's stds of 1e-7 the float32
+            # difference z - mean is mostly rounding -- in the reference's own float32 run exactly as here: 1.78e-5 / 3.71e-5 / 8.4e-6
+            # on n3 / ac3 / grav3 in BOTH -- so log q keeps the regime bar)
+            bar = regime_bar(3e-6, ref_gap(case, 'prop', k)) if k == 'log_q' else (8e-6 if k == 'z_sup' else 3e-6)
+            check('stove.prop_' + k + tag, err(prop[k], gold['p_' + k]), bar)
     loss = -elbo
     if actions is not None:
         check('stove.rewards' + tag, err(rewards, gold['rewards']), 1e-6)
@@ -266,8 +289,8 @@ def test_stove_forward_elbo_and_grads(name, regime, fused, arena):
         with torch.no_grad():
             zs, lq, _ = st.rollout(z_last, num=len(eps_roll), sample=True)
         st.noise_fn = saved
-        check('stove.rollout_sample_z', err(zs, gold['roll_s_z']), 2e-6)
-        check('stove.rollout_sample_logq', err(lq, gold['roll_s_logq']), 1.5e-5)
+        check('stove.rollout_sample_z' + tag, err(zs, gold['roll_s_z']), regime_bar(2e-6, ref_gap(case, 'rollout_z')))
+        check('stove.rollout_sample_logq' + tag, err(lq, gold['roll_s_logq']), regime_bar(1.5e-5, ref_gap(case, 'prop', 'log_q')))
 
 
 def test_rollout_std_and_sampling_api():
