@@ -478,7 +478,7 @@ def attach_traffic(roofline, workload, batch, frames):
 def workload_variant(dev, workload, data, a):
     """One of BASELINE.json's other configurations (a per-GPU shard of it) through the same replayed step, with its own model:
     ms / step, frames/s, roofline block from its own kernel profile, ELBO difference against the reference on its golden fixture."""
-    job = Job(workload, dev, data, a.encoder_gemm, 'auto', 1)
+    job = Job(workload, dev, data, a.encoder_gemm, a.frame_store, 1)       # the headline's frame store (colour fp32 by default)
     job.step(0)                                   # capture
     ms, ms_max, last = job.median_ms(a.steps)
     out = {'workload': f'{workload} {job.cfg.num_obj}-object 32x32 T={job.frames} batch={job.batch}', 'what': WORKLOADS[workload]['label'], 'ms_per_step': ms,
@@ -831,6 +831,7 @@ def main():
                        'elbo_last_step': elbo_val,
                        'host_gc': 'collector enabled; long-lived objects frozen after warm-up (gc.collect + gc.freeze, as train.py does)'},
             'roofline': roofline, 'cpu_baseline': cpu, 'variants': variants,
+            'all_reduce_in_graph': bool(getattr(job.graphed, 'reduce_captured', False)) if world > 1 else None,
             'elbo_rel_vs_reference': parity.get('elbo_rel_vs_reference') if parity else None, 'reference_parity': parity, 'comm': comm,
         }
         os.write(json_fd, (json.dumps(out) + '\n').encode())

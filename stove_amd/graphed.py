@@ -34,7 +34,7 @@ NHYPER = 8          # floats per slot: lr, beta1, beta2, eps, max_norm, reward w
 
 class GraphedTrainStep:
     def __init__(self, stove, arena, optimizer, clip, supair_only=False, warmup=3, world_size=1, reward_loss=None,
-                 alias_inputs=False, force_reduce=False):
+                 alias_inputs=False, force_reduce=False, capture_reduce=True):
         """reward_loss: callable(pred, target) -> scalar for action-conditioned models (train.py:452-465); the loss is then
         -ELBO + w * reward_loss(rewards, targets) with the host-computed weight w (factor x ramp) passed per step."""
         self.stove, self.arena, self.opt, self.clip = stove, arena, optimizer, clip
@@ -43,6 +43,8 @@ class GraphedTrainStep:
         self.reward_loss = reward_loss
         self.alias_inputs = alias_inputs
         self.force_reduce = force_reduce          # send a single rank's gradient through the collective anyway (the 1-GPU RCCL test)
+        self.capture_reduce = capture_reduce      # data parallel: the all-reduce as a node of the optimiser graph (False: eager, between the graphs)
+        self.reduce_captured = False
         self.graphs = None
         self.key = None
         self.reward_value = None
@@ -226,9 +228,30 @@ class GraphedTrainStep:
             gd.graph_dump(ctypes.c_void_p(g1.raw_cuda_graph()), dump.encode())
             g1.instantiate()
         if split or self.world_size > 1 or self.force_reduce:
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, stream=s, pool=g1.pool()):
-                self._update()
+            # g_opt.  Data parallel: the gradient all-reduce is captured INTO it (RCCL collectives are capturable: the communicator
+            # exists since the warm-up steps), so a replayed step is three graph launches and no host-issued collective in between.
+            # If the capture of the collective fails on this stack, the all-reduce stays an eager call between the graphs.
+            self.reduce_captured = False
+            g2 = None
+            import torch.distributed as dist
+            # (only RCCL's collectives can be captured: gloo's all-reduce of a device tensor goes through the host, which invalidates
+            # the capture and leaves the stream in a state the fallback cannot recover from)
+            if (self.world_size > 1 or self.force_reduce) and self.capture_reduce and dist.is_initialized() and dist.get_backend() == 'nccl':
+                try:
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2, stream=s, pool=g1.pool()):
+                        self._reduce()
+                        self._update()
+                    self.reduce_captured = True
+                except Exception as exc:          # keep the two-graph form with the collective between them
+                    import warnings
+                    warnings.warn('GraphedTrainStep: the gradient all-reduce could not be captured (%r); it stays an eager call between the graphs' % (exc,))
+                    g2 = None
+                    torch.cuda.synchronize(self.x.device)
+            if g2 is None:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=s, pool=g1.pool()):
+                    self._update()
             self.graphs = (g1, g2)
         else:
             self.graphs = (g1,)
@@ -270,7 +293,8 @@ class GraphedTrainStep:
             _lib.check(lib.stove_graph_launch(self._side_exec, self._side.cuda_stream), 'stove_graph_launch')
             _lib.check(lib.stove_stream_after(main, self._side.cuda_stream), 'stove_stream_after')      # the optimiser reads what it wrote
         if len(self.graphs) > 1:
-            self._reduce()
+            if not self.reduce_captured:
+                self._reduce()
             self.graphs[1].replay()
         self._slot_events[slot].record()
         self._n += 1

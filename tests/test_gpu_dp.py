@@ -258,13 +258,27 @@ def _rccl_graph_worker(rank, port, out):
     opt = FlatAdam(arena, lr=cfg.learning_rate, amsgrad=True)
     x = torch.from_numpy(envs.synth_sequences('billiards', 8, 10, seed0=3)['X']).to('cuda:0').contiguous()
     # the process group (and its watchdog thread) is alive while the step is captured; every replay sends the flat gradient
-    # through RCCL between the two graphs, as a data-parallel run does
-    step = GraphedTrainStep(model, arena, opt, clip=1.0, force_reduce=True)
-    before = arena.data.clone()
-    elbos = [float(step(x)) for _ in range(4)]
-    torch.cuda.synchronize()
-    ok = all(np.isfinite(elbos)) and not torch.equal(before, arena.data) and len(step.graphs) == 2 and opt._steps == 4
-    torch.save({'ok': bool(ok), 'elbos': elbos}, out)
+    # through RCCL, as a data-parallel run does: as a node of the optimiser graph (the default) and as an eager call between the
+    # graphs (capture_reduce=False, the fallback) -- the same parameters after four steps either way
+    snap = (arena.data.clone(), {k: v.clone() for k, v in opt._flat.items()}, opt._seg_steps.clone(), torch.cuda.get_rng_state(0))
+    res = {}
+    for captured in (True, False):
+        with torch.no_grad():
+            arena.data.copy_(snap[0])
+            for k, v in snap[1].items():
+                opt._flat[k].copy_(v)
+            opt._seg_steps.copy_(snap[2])
+        opt._steps = 0
+        torch.cuda.set_rng_state(snap[3], 0)
+        step = GraphedTrainStep(model, arena, opt, clip=1.0, force_reduce=True, capture_reduce=captured)
+        elbos = [float(step(x)) for _ in range(4)]
+        torch.cuda.synchronize()
+        res[captured] = dict(elbos=elbos, data=arena.data.clone(), graphs=len(step.graphs), reduce_captured=step.reduce_captured, steps=opt._steps)
+        del step
+    ok = (all(np.isfinite(res[k]['elbos']).all() for k in res) and not torch.equal(snap[0], res[True]['data']) and res[True]['graphs'] == 2
+          and res[True]['steps'] == 4 and torch.equal(res[True]['data'], res[False]['data']) and res[True]['elbos'] == res[False]['elbos']
+          and res[False]['reduce_captured'] is False)
+    torch.save({'ok': bool(ok), 'elbos': res[True]['elbos'], 'reduce_captured': bool(res[True]['reduce_captured'])}, out)
     dist.destroy_process_group()
 
 
@@ -277,5 +291,52 @@ def test_graph_replay_with_rccl_between_the_graphs(tmp_path):
     s.close()
     out = str(tmp_path / 'rccl_graph.pt')
     mp.spawn(_rccl_graph_worker, args=(port, out), nprocs=1, join=True)
+    got = torch.load(out)
+    assert got['ok'], got
+    assert got['reduce_captured'], 'the all-reduce was not captured into the optimiser graph (fell back to the eager call)'
+
+
+def _nccl2_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    dev = torch.device('cuda', rank)
+    dist.init_process_group('nccl', rank=rank, world_size=2, device_id=dev)
+    from stove_amd.arena import ParamArena
+    from stove_amd.envs import envs
+    from stove_amd.graphed import GraphedTrainStep
+    from stove_amd.optim import FlatAdam
+    from stove_amd.video_prediction.stove import Stove
+    cfg = _cfg()
+    cfg.device = dev
+    cfg.print_every, cfg.plot_every = 10 ** 9, 1e19
+    torch.manual_seed(rank)                      # different initialisations: sync() has to make them one
+    model = Stove(cfg).to(dev)
+    arena = ParamArena(model, 2)
+    arena.sync(0)
+    opt = FlatAdam(arena, lr=cfg.learning_rate, amsgrad=True)
+    x = torch.from_numpy(envs.synth_sequences('billiards', 8, 10, seed0=3 + 8 * rank)['X']).to(dev).contiguous()
+    torch.manual_seed(100 + rank)
+    step = GraphedTrainStep(model, arena, opt, clip=1.0, world_size=2)
+    elbos = [float(step(x)) for _ in range(3)]
+    torch.cuda.synchronize()
+    mine = arena.data.clone()
+    other = [torch.empty_like(mine) for _ in range(2)]
+    dist.all_gather(other, mine)
+    same = torch.equal(other[0], other[1])
+    if rank == 0:
+        torch.save({'ok': bool(same and np.isfinite(elbos).all()), 'reduce_captured': bool(step.reduce_captured), 'elbos': elbos}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (the driver\'s multi-GPU box); the one-rank RCCL tests above run everywhere')
+def test_two_ranks_on_rccl_replayed_step(tmp_path):
+    """Two processes, two GPUs, RCCL over xGMI: three replayed data-parallel steps (all-reduce captured into the optimiser graph)
+    leave bit-identical parameters on both ranks."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'nccl2.pt')
+    mp.spawn(_nccl2_worker, args=(port, out), nprocs=2, join=True)
     got = torch.load(out)
     assert got['ok'], got
