@@ -58,6 +58,16 @@ __device__ __forceinline__ float sum_xor16(float v) {          // v + (value of 
   asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
   return a + b;
 }
+__device__ __forceinline__ float max_xor32(float v) {          // max(v, value of lane ^ 32)
+  float a = v, b;
+  asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float max_xor16(float v) {          // max(v, value of lane ^ 16)
+  float a = v, b;
+  asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
+  return fmaxf(a, b);
+}
 __device__ __forceinline__ float from_xor16(float v) {         // value of lane ^ 16
   float a = v, b;
   asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "=&v"(b));

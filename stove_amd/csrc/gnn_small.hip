@@ -347,6 +347,51 @@ __device__ __forceinline__ void sm_split_layer_tiles(const bf16x8 (*wh)[2], cons
     for (int u = 0; u < 2; ++u) acc[c][u] += p[c][u] + q[c][u];
 }
 
+// The same for operands of ANY magnitude (the backward's gradient vectors): every column is scaled by a power of two that brings
+// its largest entry into [1, 2) before it is split into half pieces, and the result is scaled back -- exact, and the pieces of every
+// entry down to 2^-14 of the column's largest keep their 22 bits (smaller ones add less than 2^-24 of the result).  The column's
+// eight values per lane group and its four lane groups (lane ^ 16, lane ^ 32) meet through two v_permlane swaps.
+__device__ __forceinline__ void sm_col_scale(const smf4 (&x)[2], float& s, float& inv) {
+  float m = fmaxf(fmaxf(fmaxf(fabsf(x[0][0]), fabsf(x[0][1])), fmaxf(fabsf(x[0][2]), fabsf(x[0][3]))),
+                  fmaxf(fmaxf(fabsf(x[1][0]), fabsf(x[1][1])), fmaxf(fabsf(x[1][2]), fabsf(x[1][3]))));
+  m = max_xor32(max_xor16(m));
+  unsigned e = (__float_as_uint(m) >> 23) & 0xffu;
+  e = e < 1u ? 1u : (e > 253u ? 253u : e);
+  s = __uint_as_float((254u - e) << 23);
+  inv = __uint_as_float(e << 23);
+}
+// acc[c][u] += W^T x for OT output tiles of a layer with 32 inputs (ONE k-block: x[c][0], x[c][1] are the two accumulator tiles of
+// the column), x column-normalised; wh / wl: the [OT] hi / lo fragments of the transposed weight image
+template <int OT, int ET>
+__device__ __forceinline__ void sm_split_layer_t_norm(const bf16x8 (&wh)[OT], const bf16x8 (&wl)[OT], const smf4 (&x)[ET][2], smf4 (&acc)[ET][OT]) {
+#pragma unroll
+  for (int c = 0; c < ET; ++c) {
+    float s, inv;
+    sm_col_scale(x[c], s, inv);
+    bf16x8 xh, xl;
+    sm_frag_split(sm_f4(x[c][0] * s), sm_f4(x[c][1] * s), xh, xl);
+    f32x4 p[OT], q[OT], r[OT];
+#pragma unroll
+    for (int u = 0; u < OT; ++u) {
+      const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+      p[u] = mfma16<true>(wl[u], xh, z);
+      q[u] = mfma16<true>(wh[u], xl, z);
+      r[u] = mfma16<true>(wh[u], xh, z);
+    }
+#pragma unroll
+    for (int u = 0; u < OT; ++u) acc[c][u] += (r[u] + (p[u] + q[u])) * inv;
+  }
+}
+// [OT] fragments of a transposed [32 inputs / 4][16 OT][4] LDS image
+template <int OT>
+__device__ __forceinline__ void sm_chain_wfrag_t(const float* Wl, int lane, bf16x8 (&h)[OT], bf16x8 (&l)[OT]) {
+  const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int u = 0; u < OT; ++u)
+    sm_frag_split(*reinterpret_cast<const float4*>(Wl + (g * (16 * OT) + 16 * u + i) * 4),
+                  *reinterpret_cast<const float4*>(Wl + ((4 + g) * (16 * OT) + 16 * u + i) * 4), h[u], l[u]);
+}
+
 // d phi / d pre-activation from the activation's OUTPUT, four values
 __device__ __forceinline__ smf4 sm_dphi4(smf4 y, int elu) {
   smf4 r;

@@ -142,9 +142,23 @@ __device__ __forceinline__ void smb_mfma_layer_t(const float* Wl, const smf4 (&x
       }
   }
 }
+// Round 5: the two transposed layers of each chain on half-piece MFMAs with column-normalised operands (gnn_small.hip
+// sm_split_layer_t_norm: 6 + 12 MFMAs of 16 cycles instead of 16 + 32 fp32 MFMAs that ran at ~50 cycles each in their dependent
+// chains); the hi / lo fragments of the transposed weights are built once per launch and stay in registers.
+struct SmBChainW {
+  bf16x8 h1[4], l1[4];      // W_R1^T (relation chain) / W_A1^T (attention chain): 32 -> 64
+  bf16x8 h2[2], l2[2];      // W_R2^T: 32 -> 32 (relation chain)
+};
+__device__ __forceinline__ void smb_chain_wbuild(const SmBLds& L, SmBChainW& cw) {
+  const int wv = wave_id(), lane = lane_id();
+  if (wv < 2) return;
+  const int h = wv == 2 ? 1 : 0;
+  sm_chain_wfrag_t<4>(L.W + (h ? W_A1 : W_R1), lane, cw.h1, cw.l1);
+  if (h == 0) sm_chain_wfrag_t<2>(L.W + W_R2, lane, cw.h2, cw.l2);
+}
 template <int ET>
 __device__ __forceinline__ void smb_edge_phase_mfma(const SmBLds& L, const SmEdgeLane (&el)[ET], const SmBEdgeIn (&in)[ET], const SmDy& g,
-                                                    int elu, int dd_stride) {
+                                                    int elu, int dd_stride, const SmBChainW& cw) {
   const int wv = wave_id(), lane = lane_id(), gq = lane >> 4;
   if (wv < 2) return;
   const int h = wv == 2 ? 1 : 0;
@@ -172,7 +186,7 @@ __device__ __forceinline__ void smb_edge_phase_mfma(const SmBLds& L, const SmEdg
         dr3[c][t] = dsd[c][t] * in[c].att;
         acc[c][t] = smf4{0.0f, 0.0f, 0.0f, 0.0f};
       }
-    smb_mfma_layer_t<2, 2, ET>(L.W + W_R2, dr3, acc, lane);
+    sm_split_layer_t_norm<2, ET>(cw.h2, cw.l2, dr3, acc);
 #pragma unroll
     for (int c = 0; c < ET; ++c) {
 #pragma unroll
@@ -201,7 +215,7 @@ __device__ __forceinline__ void smb_edge_phase_mfma(const SmBLds& L, const SmEdg
   for (int c = 0; c < ET; ++c)
 #pragma unroll
     for (int u = 0; u < 4; ++u) d1[c][u] = smf4{0.0f, 0.0f, 0.0f, 0.0f};
-  smb_mfma_layer_t<2, 4, ET>(L.W + (h ? W_A1 : W_R1), y, d1, lane);
+  sm_split_layer_t_norm<4, ET>(cw.h1, cw.l1, y, d1);
 #pragma unroll
   for (int c = 0; c < ET; ++c) {
     float dd = 0.0f;
@@ -281,6 +295,8 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     if (ts1 < Ts && l < 16) car = carry[((size_t)b * N + r) * 18 + 2 + l];
   }
   WG_SYNC();
+  SmBChainW cw;
+  smb_chain_wbuild(L, cw);      // the edge chains' transposed weights as half-piece fragments: registers, for all time steps
   for (int ts = ts1 - 1; ts >= ts0; --ts) {
     cf.stamps = (ts == ts0 + 1 && stamps != nullptr) ? stamps + 64 : nullptr;       // second half of the debug buffer
     sm_stamp(cf, 0);
@@ -376,7 +392,7 @@ __global__ __launch_bounds__(64 * kSmWaves) void dyn_loop_bwd_small_k(
     WG_SYNC();
     sm_stamp(cf, 2);
     // ---- Q3: edges as the columns of the relation chain (wave 3) / the attention chain (wave 2), all column tiles together
-    smb_edge_phase_mfma<ET>(L, el, ein, g, elu, NE4);
+    smb_edge_phase_mfma<ET>(L, el, ein, g, elu, NE4, cw);
     sm_stamp(cf, 3);
     WG_SYNC();
     sm_stamp(cf, 4);
