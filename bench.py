@@ -64,6 +64,7 @@ def parse():
                    help="how the resident frames are kept (config.frame_store of the Trainer's DeviceClipLoader): f32 (default) = colour fp32 "
                         "frames, bw_transform inside every step -- the reference's own step; bw32 = the bw plane made once at upload (the "
                         "Trainer's 'auto' choice for models that only consume bw frames; reported under variants); u8 = 8-bit colour frames")
+    p.add_argument('--enc-chunks', type=int, default=0, help='row chunks of the recognition network\'s forward chain (0 = the default, 2; 1 = the chain on one stream: a profiling aid)')
     p.add_argument('--step-mode', default='graph', choices=['graph', 'eager'],
                    help='graph (default): the step replayed as captured hipGraph(s), as Trainer.train runs its non-logging steps '
                         '(stove_amd/graphed.py); eager: every launch enqueued by the host (reported as a variant)')
@@ -652,6 +653,9 @@ def main():
             dist.init_process_group(backend)
 
     from stove_amd import _lib
+    if a.enc_chunks > 0:
+        from stove_amd import ops as _ops0
+        _ops0.ENC_CHUNKS = a.enc_chunks
     job = Job(a.workload, dev, data, a.encoder_gemm, a.frame_store, world, a.res, a.step_mode)
     cfg, model, bucket = job.cfg, job.model, job.bucket
     fs = job.fs

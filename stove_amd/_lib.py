@@ -7,7 +7,9 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_voi
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libstove_hip.so')
+from . import settings as _settings
+
+LIB_PATH = _settings.LIB_OVERRIDE or os.path.join(_HERE, 'libstove_hip.so')
 _lib = None
 ABI_VERSION = 4
 

@@ -8,3 +8,6 @@ STOVE_DIST_BACKEND (main.py, bench.py) picks the torch.distributed backend for t
 import os
 
 OVERLAP = os.environ.get('STOVE_NO_OVERLAP', '0') != '1'
+# STOVE_LIB=/path/to/another/libstove_hip.so: load that build instead of the installed one (tools/ab_lib.sh alternates builds on one
+# box without ever overwriting the installed file); its ABI version is checked like the installed library's.
+LIB_OVERRIDE = os.environ.get('STOVE_LIB') or None
