@@ -1513,8 +1513,9 @@ class _EncoderLstmFn(torch.autograd.Function):
 def encoder_lstm(x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major=False, gemm='bf16x3'):
     """-> hs (n, num_steps, H), or (num_steps, n, H) with time_major=True: the layout the kernels produce; the row-wise
     head can run on it directly, which saves two 78 MB transposes per step (only its 8-wide output is permuted).
-    gemm: 'bf16x3' = fp32 products as three bf16 MFMAs on hi/lo-split operands (csrc/gemm_bf16.hip, ~2^-17 relative),
-    'fp32' = library fp32 GEMMs, 'bf16' = plain bf16 operands with fp32 accumulation (the reported, never default, variant)."""
+    gemm: 'bf16x3' = fp32 products as three sixteen-bit MFMAs on hi/lo-split operands (csrc/gemm_bf16.hip, split16.h): IEEE-half
+    pieces in the forward products (2^-22 of the value per product), bf16 pieces in the gradient products (2^-18; fp32's exponent
+    range); 'fp32' = library fp32 GEMMs, 'bf16' = plain bf16 operands with fp32 accumulation (the reported, never default, variant)."""
     return _EncoderLstmFn.apply(x, w_ih, w_hh, b_ih, b_hh, num_steps, time_major, gemm)
 
 

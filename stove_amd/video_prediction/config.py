@@ -56,7 +56,7 @@ _DEFAULTS = dict(
     device_dataset=True,     # Trainer: training set resident on the GPU, batches gathered there (load_data.DeviceClipLoader)
     device_dataset_gb=64.0,  # ... when it needs at most this much HBM
     device_noise='philox', strict_adam_zero_grad=False,   # [amd] reparameterisation draws on the GPU: 'philox' = the library's counter-based generator (device-resident state, drawn ahead on the parameter stream), 'torch' = torch.randn
-    encoder_gemm='bf16x3',   # recognition-network GEMMs: 'bf16x3' (fp32 as 3 bf16 MFMAs on hi/lo-split operands), 'fp32' (library), 'bf16'
+    encoder_gemm='bf16x3',   # recognition-network GEMMs: 'bf16x3' (fp32 products as 3 sixteen-bit MFMAs on hi/lo pieces: IEEE-half pieces forward, bf16 pieces backward), 'fp32' (library), 'bf16'
 )
 
 
