@@ -790,6 +790,15 @@ def main():
             return {'dtype': 'default path, every launch enqueued by the host (no graph replay)', 'ms_per_step': ms, 'ms_per_step_max': ms_max,
                     'value': a.batch * a.frames / ms * 1e3, 'unit': 'frames/s'}
         guarded('eager', eager_variant)
+        def short_clip_variant():
+            """the reference's DEFAULT training shape (config.py: batch 256, 8 visible frames per clip, train.py:431-473): the same step"""
+            short = {k: (v[:, :8] if isinstance(v, np.ndarray) and v.ndim >= 2 and v.shape[1] == a.frames else v) for k, v in data.items()}
+            j8 = Job(a.workload, dev, short, a.encoder_gemm, fs, 1)
+            j8.step(0)
+            ms, ms_max, _ = j8.median_ms(max(a.steps, 30))
+            return {'what': 'the reference\'s default training shape: %d clips x 8 frames per step, same model and step (launch-latency bound: ~70 kernels in < 1 ms)' % j8.batch,
+                    'ms_per_step': ms, 'ms_per_step_max': ms_max, 'value': j8.batch * 8 / ms * 1e3, 'unit': 'frames/s', 'steps_per_s': 1e3 / ms}
+        guarded('default_training_shape', short_clip_variant)
         guarded('rollout', lambda: rollout_variant(job, a))
         guarded('cfg1_eval', lambda: cfg1_eval_variant(dev, a))
         for w in side_data:
