@@ -327,8 +327,12 @@ __global__ __launch_bounds__(256) void gauss_ll_bwd_k(const float* __restrict__ 
 }
 
 static inline bool oa_shape_ok(const ObjAnyShape& sh) {
-  return sh.R >= 1 && sh.R <= kOaMaxR && sh.G >= 1 && sh.G <= kOaMaxG && sh.S >= 1 && sh.S <= kOaMaxS && sh.D >= 4 && sh.D <= kOaMaxD &&
-         sh.Lmax >= 1 && sh.Lmax <= sh.D;
+  if (!(sh.R >= 1 && sh.R <= kOaMaxR && sh.G >= 1 && sh.G <= kOaMaxG && sh.S >= 1 && sh.S <= kOaMaxS && sh.D >= 4 && sh.D <= kOaMaxD &&
+        sh.Lmax >= 1 && sh.Lmax <= sh.D))
+    return false;
+  // the table-gradient kernel stages kOaGroup samples in LDS: a shape whose backward cannot run is refused by the forward already
+  // (before round 5 the forward ran and the first backward failed with hipErrorInvalidValue after objany_bwd_k had been launched)
+  return sizeof(float) * (size_t)kOaGroup * (2 * sh.n_ell() + 2 * sh.n_s() + 2 + 2 * (size_t)sh.D) <= 160u * 1024u;
 }
 static inline int oa_chunks(int n) {
   const int c = (n + kOaGroup - 1) / kOaGroup;

@@ -328,7 +328,9 @@ class RatSpn(nn.Module):
             self._plan_cpu = {'scope': scope, 'leaf_slot': slot, 'leaf_order': torch.tensor(leaf_order),
                               'sum_order': torch.tensor(sum_order)}
             self._kind = 'obj'
-        elif len(vl) == 5 and a.num_gauss <= 16 and a.num_sums <= 16 and self.num_dims <= 1024 and len(root.inputs) <= 8:
+        elif (len(vl) == 5 and a.num_gauss <= 16 and a.num_sums <= 16 and self.num_dims <= 1024 and len(root.inputs) <= 8
+              # the table-gradient kernel stages groups of 16 samples in LDS (csrc/spn_obj_generic.hip oa_shape_ok): 160 KiB
+              and 2 * len(root.inputs) * (4 * a.num_gauss + 2 * a.num_sums) + 2 + 2 * self.num_dims <= 2560):
             # [amd] the object SPN's structure with any glimpse size / vector widths (config.patch_width / patch_height /
             # obj_spn_num_gauss / obj_spn_num_sums, reference config.py:99-100, 119-120): the general-size operator of
             # csrc/spn_obj_generic.hip.  Replica r = r-th child of the root; its leaves in (sum 0: leaf 0, leaf 1; sum 1: leaf 0, leaf 1) order
@@ -439,7 +441,7 @@ class RatSpn(nn.Module):
             return (coef.contiguous(), wroot.contiguous(), pl['side'])
         raise NotImplementedError(
             'RatSpn: no gfx950 kernel for this SPN shape (dims=%d); kernels exist for the STOVE '
-            'object (Nx random_split(2,2), up to 16 gaussians / sums, up to 1024 dims) and background (any dims, 3x random_split(2,1), 6 gaussians) SPNs'
+            'object (Nx random_split(2,2), up to 16 gaussians / sums, up to 1024 dims within the 160 KiB LDS budget of the table gradients: 2 R (4 G + 2 S) + 2 D <= 2558) and background (any dims, 3x random_split(2,1), 6 gaussians) SPNs'
             % self.num_dims)
 
     # ------------------------------------------------------------------ evaluation
