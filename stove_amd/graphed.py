@@ -243,11 +243,18 @@ class GraphedTrainStep:
                         self._reduce()
                         self._update()
                     self.reduce_captured = True
-                except Exception as exc:          # keep the two-graph form with the collective between them
+                except Exception as exc:
+                    # A capture that failed half-way may leave the stream unable to begin another one (seen with a backend whose
+                    # collective synchronises with the host): no second attempt at a graph -- the all-reduce AND the optimiser's three
+                    # launches stay eager calls behind the two backward graphs.
                     import warnings
-                    warnings.warn('GraphedTrainStep: the gradient all-reduce could not be captured (%r); it stays an eager call between the graphs' % (exc,))
-                    g2 = None
-                    torch.cuda.synchronize(self.x.device)
+                    warnings.warn('GraphedTrainStep: the gradient all-reduce could not be captured (%r); all-reduce and optimiser '
+                                  'run eagerly behind the backward graphs' % (exc,))
+                    g2 = 'eager'
+                    try:
+                        torch.cuda.synchronize(self.x.device)
+                    except Exception:
+                        pass
             if g2 is None:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, stream=s, pool=g1.pool()):
@@ -295,7 +302,10 @@ class GraphedTrainStep:
         if len(self.graphs) > 1:
             if not self.reduce_captured:
                 self._reduce()
-            self.graphs[1].replay()
+            if self.graphs[1] == 'eager':
+                self._update()
+            else:
+                self.graphs[1].replay()
         self._slot_events[slot].record()
         self._n += 1
         self.opt.count_step()
