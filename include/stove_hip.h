@@ -459,8 +459,9 @@ int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* ex
  * a_kmajor (the operand is stored K-major, as dg / x are in the weight-gradient products dW = dg^T x); b likewise.
  * nsplit = 2: every fp32 operand element is split on the fly into bf16 hi + lo and the product is three bf16 MFMAs with fp32
  * accumulation (~2^-18 relative per product); nsplit = 3: the same with IEEE-half pieces (~2^-22: an fp32-grade product) for
- * operands inside half's range -- K-contiguous, float4-addressable operands only; nsplit = 1: plain bf16 operands (2^-8), fp32
- * accumulate.  A, B, bias, C stay fp32.
+ * operands inside half's range -- an element keeps max(2^-22 |x|, 2^-25) and must stay below 65504; B, the weights of the forward
+ * products, is cut as 2^8 B (floor 2^-33, ceiling 256) and the epilogue shifts back -- K-contiguous, float4-addressable operands
+ * only; nsplit = 1: plain bf16 operands (2^-8), fp32 accumulate.  A, B, bias, C stay fp32.
  * splitk > 1: K is cut into `splitk` slices computed by different workgroups into ws (stove_gemm_bf16_ws_floats floats), then
  * summed in slice order into C (needs ldc == N, bias and add NULL): fills the chip when M x N is small and K huge (weight gradients).
  * tile: workgroup tile, 0 = chosen by the library, 1 = 256 x 128 (8 waves), 2 = 128 x 128 (4 waves), 3 = 256 x 256 (8 waves of

@@ -128,12 +128,13 @@ struct TileLoad {
     v[j] = *reinterpret_cast<const float4*>(ok ? src.p(j) : src.safe);
     okmask = (okmask & ~(1u << j)) | (ok ? (1u << j) : 0u);
   }
-  template <int NSPLIT, bool FULLT = false, bool F16 = false>
+  // SH: the operand is multiplied by 2^SH before it is cut into pieces (exact; the epilogue takes it out again) -- see kGemmHalfShift
+  template <int NSPLIT, bool FULLT = false, bool F16 = false, int SH = 0>
   __device__ __forceinline__ void store(char* hi_img, char* lo_img, int tid) const {
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) store_piece<NSPLIT, FULLT, F16>(j, hi_img, lo_img, tid);
+    for (int j = 0; j < NLD; ++j) store_piece<NSPLIT, FULLT, F16, SH>(j, hi_img, lo_img, tid);
   }
-  template <int NSPLIT, bool FULLT = false, bool F16 = false>
+  template <int NSPLIT, bool FULLT = false, bool F16 = false, int SH = 0>
   __device__ __forceinline__ void store_piece(int j, char* hi_img, char* lo_img, int tid) const {
     {
       const int f = tid + THREADS * j;
@@ -145,7 +146,12 @@ struct TileLoad {
         off = row * 64 + ((((kq & 3) << 4) | ((kq >> 2) << 3)) ^ (((row >> 3) & 1) << 5));
       }
       u32x2 hi, lo;
-      split4<NSPLIT, F16>((FULLT || ((okmask >> j) & 1u)) ? v[j] : float4{0.0f, 0.0f, 0.0f, 0.0f}, hi, lo);
+      float4 x = (FULLT || ((okmask >> j) & 1u)) ? v[j] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+      if constexpr (SH != 0) {
+        constexpr float s = (float)(1 << SH);
+        x.x *= s; x.y *= s; x.z *= s; x.w *= s;
+      }
+      split4<NSPLIT, F16>(x, hi, lo);
       *reinterpret_cast<u32x2*>(hi_img + off) = hi;
       if (NSPLIT == 2) *reinterpret_cast<u32x2*>(lo_img + off) = lo;
     }
@@ -185,6 +191,11 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
   constexpr int kGemmBM = BM, kGemmBN = BN, THREADS = BM * BN / (WTM * WTN) * 64;      // one wave per WTM x WTN of the tile
   constexpr int TM = WTM / 16, TN = WTN / 16;                                            // MFMA tiles along the sides of the wave tile
   constexpr bool SQ64 = WTM == 64 && WTN == 64;
+  // Half pieces: B (the weights of the forward products) is cut as 2^8 B.  The lo piece of x is below 2^-11 |x| and lies in half's
+  // subnormals -- absolute error 2^-25 instead of a relative 2^-22 -- once |x| < 1/4, so a weight matrix of scale 0.003 would fall
+  // back to bf16-piece accuracy (measured 6e-6 vs 4e-7 of the largest entry); shifted, every |w| >= 2^-10 keeps its 22 bits and
+  // |w| < 256 stays inside half's range.  A (frames in [0, 1], hidden states in (-1, 1)) is taken as it is.
+  constexpr int BSH = F16 ? kGemmHalfShift : 0;
   constexpr int kGemmAPart = gemm_part_bytes(BM), kGemmBPart = gemm_part_bytes(BN);
   constexpr int STAGE = NSPLIT * (kGemmAPart + kGemmBPart);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
         }
       }
       la0.template store<NSPLIT, F, F16>(img(0, 0), img(0, 1), tid);
-      lb0.template store<NSPLIT, F, F16>(img(0, 2), img(0, 3), tid);
+      lb0.template store<NSPLIT, F, F16, BSH>(img(0, 2), img(0, 3), tid);
       if constexpr (!SQ64) {          // one register set: tile 1 follows tile 0 through it
         if constexpr (F) {
           la0.load_full(sa, nt > 2);
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
             if (q % 4 == i) a_next.template store_piece<NSPLIT, F, F16>(q, img(cur ^ 1, 0), img(cur ^ 1, 1), tid);
     #pragma unroll
           for (int q = 0; q < NB; ++q)
-            if ((q + 2) % 4 == i) b_next.template store_piece<NSPLIT, F, F16>(q, img(cur ^ 1, 2), img(cur ^ 1, 3), tid);
+            if ((q + 2) % 4 == i) b_next.template store_piece<NSPLIT, F, F16, BSH>(q, img(cur ^ 1, 2), img(cur ^ 1, 3), tid);
         }
       } else {
         // Large wave tile: the A fragments of the step stay in registers, the B fragments come one column tile at a time; the MFMAs
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
   #pragma unroll
             for (int q = 0; q < NA / H; ++q) a_next.template store_piece<NSPLIT, F, F16>(j * (NA / H) + q, img(cur ^ 1, 0), img(cur ^ 1, 1), tid);
   #pragma unroll
-            for (int q = 0; q < NB / H; ++q) b_next.template store_piece<NSPLIT, F, F16>(j * (NB / H) + q, img(cur ^ 1, 2), img(cur ^ 1, 3), tid);
+            for (int q = 0; q < NB / H; ++q) b_next.template store_piece<NSPLIT, F, F16, BSH>(j * (NB / H) + q, img(cur ^ 1, 2), img(cur ^ 1, 3), tid);
           } else if (DEBUG != 1) {
   #pragma unroll
             for (int q = 0; q < NA / H; ++q) {
@@ -387,6 +398,7 @@ __global__ __launch_bounds__(BM * BN / (WTM * WTN) * 64) void gemm_bf16_k(const 
       const int n = n0 + wn * WTN + j * 16 + 4 * (lane >> 4);
       if (m < M && n < N) {
         f32x4 v = acc[i][j];
+        if constexpr (BSH != 0) v *= 1.0f / (float)(1 << BSH);
         if (!(scalar_bits & 4)) {
           if (bias != nullptr && splitk == 1) {
             const float4 b4 = *reinterpret_cast<const float4*>(bias + n);

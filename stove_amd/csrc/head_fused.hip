@@ -97,7 +97,10 @@ __global__ __launch_bounds__(256, 2) void enc_head_fwd_k(const float* __restrict
     const float4 wv4 = n < HID ? wst[u] : float4{0.0f, 0.0f, 0.0f, 0.0f};
     if (SPLIT) {
       u32x2 hi, lo;
-      split4<2, true>(wv4, hi, lo);         // half pieces (round 5: 2^-22 of the value instead of bf16's 2^-18; W1 and h sit inside half's range)
+      // half pieces (round 5: 2^-22 of the value instead of bf16's 2^-18) of 2^8 W1 -- shifted so that the lo piece of a small weight
+      // stays out of half's subnormals (gemm_bf16.hip, kGemmHalfShift); the sigmoid's argument takes the shift out again
+      constexpr float ws = (float)(1 << kGemmHalfShift);
+      split4<2, true>(float4{wv4.x * ws, wv4.y * ws, wv4.z * ws, wv4.w * ws}, hi, lo);
       *reinterpret_cast<u32x2*>(img_hi + n * kEhLdB + 8 * k4) = hi;
       *reinterpret_cast<u32x2*>(img_lo + n * kEhLdB + 8 * k4) = lo;
     } else {
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void enc_head_fwd_k(const float* __restrict
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) hv[jt][r] = (16 * jt + 4 * g + r < HID) ? sig_(acc[jt][r] + bias1[jt][r]) : 0.0f;
+      for (int r = 0; r < 4; ++r) hv[jt][r] = (16 * jt + 4 * g + r < HID) ? sig_(acc[jt][r] * (SPLIT ? 1.0f / (float)(1 << kGemmHalfShift) : 1.0f) + bias1[jt][r]) : 0.0f;
     if (live) {
       float* o = h1 + (size_t)row * HID + 4 * g;
 #pragma unroll

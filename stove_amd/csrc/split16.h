@@ -27,6 +27,11 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {
 // two pieces carry 2^-22 of the value instead of 2^-18, i.e. the three-MFMA product is as good as an fp32 one -- for operands
 // inside half's range: the FORWARD products of the recognition network (frames in [0, 1], hidden states in (-1, 1), weights),
 // whose error the head's weights amplify into the codes (tests: the 'stress' weight regime).  Same MFMA rate, same images.
+// Range of the half pieces: hi is a normal half for 2^-14 <= |x| < 65504; lo, at most 2^-11 |x|, is a normal half only for |x| >= 1/4 and
+// a subnormal below (granularity 2^-24): an element keeps max(2^-22 |x|, 2^-25).  Operands whose scale is known to be small -- the
+// weights of the forward products -- are therefore cut as 2^kGemmHalfShift x (exact; the product's epilogue shifts back): every
+// |w| >= 2^-10 keeps its 22 bits, |w| < 256 stays in range.
+constexpr int kGemmHalfShift = 8;
 template <int NSPLIT, bool F16 = false>
 __device__ __forceinline__ void split4(const float4 v, u32x2& hi, u32x2& lo) {
   if constexpr (F16) {

@@ -1530,7 +1530,9 @@ def gemm_splitk(M, N, K):
 
 def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=None, add=None, tile=0, out=None):
     """C (M, N) = sum_k a(m,k) b(n,k) (+ bias) (+ add) on the bf16 matrix cores with fp32 in / out (csrc/gemm_bf16.hip).
-    a: (M, K), or (K, M) when a_kmajor; b: (N, K), or (K, N) when b_kmajor.  nsplit 2 = hi+lo split (3 MFMAs), 1 = plain bf16.
+    a: (M, K), or (K, M) when a_kmajor; b: (N, K), or (K, N) when b_kmajor.  nsplit 2 = hi+lo bf16 pieces (3 MFMAs, 4.5e-6 of the largest
+    entry), 1 = plain bf16, 3 = hi+lo IEEE-half pieces (3 MFMAs, 1-4e-7; row-major a and b only; operands must lie inside half's
+    range: |x| < 65504, and entries below 2^-14 keep an absolute error of 2^-25 instead of a relative one).
     splitk None = chosen from the shape (only without bias / add).  out: a contiguous (M, N) tensor the product is ADDED to
     (a gradient view; returned)."""
     def rows_ok(t):          # a row-strided view (padded leading dimension) is taken as it lies

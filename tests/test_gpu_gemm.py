@@ -49,6 +49,58 @@ def test_gemm_exact_on_small_integers(ak, bk, tile):
         assert torch.equal(c.cpu(), a @ b.t())
 
 
+@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+@pytest.mark.parametrize('M,N,K,splitk', [(256, 128, 32, 1), (300, 132, 100, 1), (20, 1024, 1024, 1), (1024, 256, 3000, 8), (3200, 1024, 1024, None)])
+def test_gemm_half_pieces(M, N, K, splitk, tile):
+    """nsplit 3 (csrc/split16.h): IEEE-half hi + lo pieces carry 22 bits of each operand; the product is fp32-grade -- here held to
+    1e-6 of the largest entry (measured 1-4e-7), an order below the bf16 pieces' 4.5e-6 -- with the same tiles, ragged edges and split-K."""
+    from stove_amd import ops
+    g = torch.Generator().manual_seed(M + N * 5 + K * 3)
+    a = torch.randn(M, K, generator=g).to(DEV)
+    b = torch.randn(N, K, generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV) if splitk == 1 else None
+    ref = _ref(a, b, bias, False, False)
+    c = ops.gemm_bf16(a, b, bias, False, False, 3, splitk, tile=tile)
+    err = float((c.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-6, err
+
+
+def test_gemm_half_pieces_exact_integers_and_layout_refusal():
+    """Integers below 2048 are exact in one half piece: any wrong lane / k map shows as a non-zero difference.  The half pieces exist for
+    row-major operands only; the other layouts are refused, not silently computed on bf16."""
+    from stove_amd import ops
+    M, N, K = 272, 132, 72
+    m, n, k = torch.arange(M).view(-1, 1), torch.arange(N).view(-1, 1), torch.arange(K).view(1, -1)
+    a = ((m * 3 + k * 5) % 17 - 8).float()
+    b = ((n * 7 + k * 11 + (n * k) % 5) % 13 - 6).float()
+    for tile in (1, 2, 3):
+        assert torch.equal(ops.gemm_bf16(a.to(DEV), b.to(DEV), None, False, False, 3, 1, tile=tile).cpu(), a @ b.t())
+    for ak, bk in ((True, False), (False, True), (True, True)):
+        with pytest.raises(RuntimeError):
+            ops.gemm_bf16((a.t().contiguous() if ak else a).to(DEV), (b.t().contiguous() if bk else b).to(DEV), None, ak, bk, 3, 1)
+
+
+@pytest.mark.parametrize('scale_a,scale_b', [(1.0, 1.0), (1.0, 3e-2), (1.0, 3e-3), (1.0, 1e-4), (0.1, 0.1), (1e-2, 1.0), (1e-3, 1.0), (50.0, 50.0), (1e3, 1e-3)])
+def test_gemm_half_pieces_range(scale_a, scale_b):
+    """The domain of nsplit 3, written down (csrc/split16.h): an element keeps max(2^-22 |x|, 2^-25) -- the lo piece, at most 2^-11 |x|,
+    is a subnormal half once |x| < 1/4 -- and must stay below 65504.  B (the weights of the forward products) is cut as 2^8 B, so
+    its floor is 2^-33 and its ceiling 256; A (frames in [0, 1], hidden states in (-1, 1)) is taken as it is.  Bound: 1e-6 of the
+    largest entry (fp32 accumulation included) plus the floors' sums, sqrt(K) x floor x the other operand's largest element."""
+    from stove_amd import ops
+    M, N, K = 512, 256, 1024
+    g = torch.Generator().manual_seed(11)
+    a = (torch.randn(M, K, generator=g) * scale_a).to(DEV)
+    b = (torch.randn(N, K, generator=g) * scale_b).to(DEV)
+    ref = _ref(a, b, None, False, False)
+    c = ops.gemm_bf16(a, b, None, False, False, 3, 1)
+    assert bool(torch.isfinite(c).all())
+    err = float((c.double() - ref).abs().max())
+    floor = K ** 0.5 * (2.0 ** -25 * float(b.abs().max()) + 2.0 ** -33 * float(a.abs().max()))
+    assert err < 1e-6 * float(ref.abs().max()) + floor, (err, float(ref.abs().max()), floor)
+    if scale_a >= 1.0:          # A at O(1), B anywhere above its (shifted) floor: fp32-grade whatever the weights' scale
+        assert err < 1e-6 * float(ref.abs().max()), (err, float(ref.abs().max()))
+
+
 def test_gemm_encoder_shapes_accuracy():
     """The headline shapes (25 600 frames): input projection x W_ih^T and its weight gradient dgx^T x; error of the 3-MFMA
     split against fp64, next to the fp32 library GEMM's own error."""
