@@ -374,8 +374,11 @@ int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const flo
   int rc = 0;
   // The object-SPN table gradients go to the parameter stream once dz is out (underneath what the caller enqueues next, the
   // recursion's backward) ...
-  // ... for up to four objects: the small-graph recursion (gnn_small*.hip) is the latency-bound kernel with room beside it; the
-  // six/eight-object recursion (gnn.hip) fills the matrix pipe itself and was stretched 2.49 -> 3.20 ms by a co-runner
+  // ... for up to four objects: that recursion (dyn_loop_bwd_small_k<4, ..>: 253 + 58 registers, one wave per SIMD on every CU at
+  // B = 256) is the latency-bound kernel with room beside it.  The five / six-object instantiation holds 256 + 192 of a SIMD lane's
+  // 512 registers (hipcc -Rpass-analysis=kernel-resource-usage, round 5), so nothing wider than 64 registers can run beside it --
+  // the 150-register table-gradient kernel would queue up behind it instead of under it -- and the seven / eight-object recursion
+  // (gnn.hip) fills the matrix pipe itself (stretched 2.49 -> 3.20 ms by a co-runner, round 2)
   const bool late = sp != st && n_obj <= 4;
   if (!late) {
     STOVE_TRY(stream_after(sp, st));
