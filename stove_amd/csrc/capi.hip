@@ -97,11 +97,11 @@ template <int NMAX>
 static int scene_bwd_tail(const float* frames, const float* z, const float* xw, const float* Dscr, const int* leaf_slot,
                           const float* coef, const float* d_ovl, float* dzc, const float* dll, const float* obj_ll,
                           const float* dz_bg, float* dz, int n_obj, int np, hipStream_t st, hipStream_t bg_stream, FrameMap fm,
-                          const float* d_obj) {      // Dscr is at unit upstream gradient: times d_obj[patch] as it is staged
+                          const float* d_obj, int bg_parts) {      // Dscr is at unit upstream gradient: times d_obj[patch] as it is staged
   int rc = scene_pixtile_bwd<NMAX>(frames, z, xw, Dscr, leaf_slot, coef, d_ovl, dzc, n_obj, np, st, fm, d_obj);
   if (rc) return rc;
   STOVE_TRY(stream_after(st, bg_stream));       // join: only the last kernel needs the background chain's dz_bg
-  STOVE_LAUNCH((scene_finalize_bwd_k<NMAX>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, obj_ll, dz_bg, dzc, dz, n_obj, np);
+  STOVE_LAUNCH((scene_finalize_bwd_k<NMAX>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, obj_ll, dz_bg, dzc, dz, n_obj, np, bg_parts);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
@@ -386,19 +386,21 @@ int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const flo
                                 ws + W.d_obj, np, sp);
     if (rc) return rc;
   }
+  // (dz = null: the per-half partial images of dz_bg stay where bgspn_bwd_k wrote them; the tail's last kernel sums them)
   rc = bgspn_backward(frames, nullptr, z, n_obj, t->bg_side, t->bg_coef, t->bg_wroot, saved + L.bg_ell, saved + L.bg_out, dll,
-                      nullptr, nullptr, ws + W.dz_bg, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, sb, sp == st ? sb : sp, fm, saved + L.cover);
+                      nullptr, nullptr, nullptr, g->bg_coef, g->bg_wroot, ws + W.bg, n_frames, sb, sp == st ? sb : sp, fm, saved + L.cover);
   if (rc) return rc;
+  const float* dz_bg_parts = bgspn_dz_parts(ws + W.bg, n_frames);
   // the tail joins `sb` before its last kernel (dz_bg; without a parameter stream also the bg table grads)
   if (n_obj <= 3)
     rc = scene_bwd_tail<3>(frames, z, saved + L.xw, saved + L.obj_scratch, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
-                           ws + W.dz_bg, dz, n_obj, np, st, sb, fm, ws + W.d_obj);
+                           dz_bg_parts, dz, n_obj, np, st, sb, fm, ws + W.d_obj, kBgHalves);
   else if (n_obj <= 6)
     rc = scene_bwd_tail<6>(frames, z, saved + L.xw, saved + L.obj_scratch, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
-                           ws + W.dz_bg, dz, n_obj, np, st, sb, fm, ws + W.d_obj);
+                           dz_bg_parts, dz, n_obj, np, st, sb, fm, ws + W.d_obj, kBgHalves);
   else if (n_obj <= 8)
     rc = scene_bwd_tail<8>(frames, z, saved + L.xw, saved + L.obj_scratch, t->obj_leaf_slot, t->obj_coef, ws + W.d_ovl, ws + W.dzc, dll, saved + L.obj_ll,
-                           ws + W.dz_bg, dz, n_obj, np, st, sb, fm, ws + W.d_obj);
+                           dz_bg_parts, dz, n_obj, np, st, sb, fm, ws + W.d_obj, kBgHalves);
   else
     rc = (int)hipErrorInvalidValue;
   if (rc) return rc;
@@ -572,9 +574,9 @@ int stove_scene_bwd_any(const StoveSpnTables* t, const float* frames, const floa
     rc = scene_pixtile_bwd<8, true>(frames, z, saved + L.xw, saved + L.obj_scratch, t->obj_leaf_slot, t->obj_coef, ws + Wl.d_ovl, ws + Wl.dzc, n_obj, np, st, fm, d_obj, gm);
   if (rc) return rc;
   STOVE_TRY(jb.join());
-  if (n_obj <= 3) STOVE_LAUNCH((scene_finalize_bwd_k<3>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, saved + L.obj_ll, ws + Wl.dz_bg, ws + Wl.dzc, dz, n_obj, np);
-  else if (n_obj <= 6) STOVE_LAUNCH((scene_finalize_bwd_k<6>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, saved + L.obj_ll, ws + Wl.dz_bg, ws + Wl.dzc, dz, n_obj, np);
-  else STOVE_LAUNCH((scene_finalize_bwd_k<8>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, saved + L.obj_ll, ws + Wl.dz_bg, ws + Wl.dzc, dz, n_obj, np);
+  if (n_obj <= 3) STOVE_LAUNCH((scene_finalize_bwd_k<3>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, saved + L.obj_ll, ws + Wl.dz_bg, ws + Wl.dzc, dz, n_obj, np, 1);
+  else if (n_obj <= 6) STOVE_LAUNCH((scene_finalize_bwd_k<6>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, saved + L.obj_ll, ws + Wl.dz_bg, ws + Wl.dzc, dz, n_obj, np, 1);
+  else STOVE_LAUNCH((scene_finalize_bwd_k<8>), dim3((np + 255) / 256), dim3(256), 0, st, dll, z, saved + L.obj_ll, ws + Wl.dz_bg, ws + Wl.dzc, dz, n_obj, np, 1);
   STOVE_LAUNCH_CHECK();
   // table gradients of the object SPN on the parameter stream (the background's are complete in `st` order: ordered into it as well)
   STOVE_TRY(stream_after(sp, st));

@@ -179,16 +179,28 @@ __global__ void scene_assemble_bwd_k(const float* __restrict__ dll, const float*
 }
 
 // dz[frame*n_obj + j][4] = bg part + sum_{k>=j} dzc[frame*n_obj+k][j] + direct scale terms
+// bg_parts == 1: dz_bg [patch][4] is the background's whole share; > 1: the per-frame partial images the background SPN's backward
+// leaves ([frame][bg_parts][n_obj * 4], one per half-frame workgroup), summed here in part order -- the sum was a launch of its own
+// (bg_dz_halves_k) on the step's critical path until round 5.
 template <int NMAX>
 __global__ void scene_finalize_bwd_k(const float* __restrict__ dll, const float* __restrict__ z,
                                      const float* __restrict__ obj_ll, const float* __restrict__ dz_bg,
-                                     const float* __restrict__ dzc, float* __restrict__ dz, int n_obj, int n_patches) {
+                                     const float* __restrict__ dzc, float* __restrict__ dz, int n_obj, int n_patches, int bg_parts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_patches) return;
   const int f = i / n_obj, j = i % n_obj;
   float s[4];
+  if (bg_parts == 1) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) s[e] = dz_bg[(size_t)i * 4 + e];
+    for (int e = 0; e < 4; ++e) s[e] = dz_bg[(size_t)i * 4 + e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = 0.0f;
+    for (int h = 0; h < bg_parts; ++h) {
+      const float4 p = *reinterpret_cast<const float4*>(dz_bg + (((size_t)f * bg_parts + h) * n_obj + j) * 4);
+      s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
+    }
+  }
   for (int k = j; k < n_obj; ++k) {
     const float* c = dzc + (((size_t)f * n_obj + k) * NMAX + j) * 4;
 #pragma unroll

@@ -650,7 +650,12 @@ __global__ void bg_dz_halves_k(const float* __restrict__ dz_part, float* __restr
   dz[j] = s;
 }
 
-// dz (SCENE): [n_frames][n_obj][4] overwritten.  g_coef [R][1024][G][3], g_wroot [R*G*G] overwritten.
+// the per-half partial images of dz inside bgspn_backward's workspace: [n_frames][kBgHalves][n_obj * 4]
+static inline float* bgspn_dz_parts(float* ws, int n_frames) {
+  return ws + (size_t)n_frames * kBgNO + (size_t)n_frames * kBgR * (1 + 2 * kBgG);
+}
+// dz (SCENE): [n_frames][n_obj][4] overwritten, or null: the caller sums the partial images (bgspn_dz_parts) itself.
+// g_coef [R][1024][G][3], g_wroot [R*G*G] overwritten.
 int bgspn_backward(const float* frames, const float* marg, const float* z, int n_obj, const int* side, const float* coef,
                    const float* wroot, const float* ell_part, const float* out, const float* dout,
                    float* d_inputs, float* d_marg, float* dz, float* g_coef, float* g_wroot, float* ws,
@@ -667,7 +672,7 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
   const int grid = n_frames < 128 ? bg_grid(n_frames) : 128 * kBgHalves;
   float* dell = ws;
   float* rsc = dell + (size_t)n_frames * kBgNO;
-  float* dz_part = rsc + (size_t)n_frames * kBgR * (1 + 2 * kBgG);
+  float* dz_part = bgspn_dz_parts(ws, n_frames);
   float* gpart = dz_part + (size_t)n_frames * kBgHalves * 8 * 4;
   float* rpart = gpart + (size_t)grid * kBgR * kBgThreads * kBgG * 3;
   float* T = rpart + (size_t)kBgRootChunks * kBgR * kBgG * kBgG;            // scene mode only (ws sized with n_obj)
@@ -691,7 +696,7 @@ int bgspn_backward(const float* frames, const float* marg, const float* z, int n
     rc = bg_bwd_launch<8>(scene, grid, st, frames, marg, z, n_obj, side, coef, dell, d_inputs, d_marg, dz_part, gpart, n_frames, T, fm);
   if (rc) return rc;
   STOVE_TRY(stream_after(st_par, st));         // gcoef_part of bgspn_bwd_k, rsc of bgspn_root_bwd_k
-  if (scene) {
+  if (scene && dz != nullptr) {
     const int n = n_frames * n_obj * 4;
     STOVE_LAUNCH(bg_dz_halves_k, dim3((n + 255) / 256), dim3(256), 0, st, dz_part, dz, n_frames, n_obj * 4);
     STOVE_LAUNCH_CHECK();
