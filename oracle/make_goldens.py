@@ -409,13 +409,16 @@ def billiards_frames(n_seq, t_len, n=3, r=1.2):
 
 
 # ------------------------------------------------------------------ G7/G8 full model
-def g7_g8_full(regime='analytic', dtypes=((torch.float64, 'f64'), (torch.float32, 'f32'))):
+def g7_g8_full(regime='analytic', dtypes=((torch.float64, 'f64'), (torch.float32, 'f32')), shape=None, prefix='g7_stove', roll_all=None):
+    """`shape` = (B, T) for every case instead of the short per-case ones; `roll_all`: rollout length for every case (g17)."""
     cases = [
         ('n3', dict(num_obj=3), 4, 8),
         ('n6', dict(num_obj=6, debug_match_objects='greedy', overlap_beta=100.0, max_obj_scale=0.22), 2, 6),
         ('ac3', dict(num_obj=3, action_conditioned=True, action_space=9, debug_core_appearance=True), 3, 6),
         ('grav3', dict(num_obj=3), 4, 8),
     ]
+    if shape is not None:
+        cases = [(n, kw, shape[0], shape[1]) for n, kw, _, _ in cases]
     only = os.environ.get('G7_ONLY')          # regenerate a subset without touching the other fixtures
     if only:
         cases = [c for c in cases if c[0] in only.split(',')]
@@ -468,7 +471,7 @@ def g7_g8_full(regime='analytic', dtypes=((torch.float64, 'f64'), (torch.float32
                 if c.action_conditioned:
                     fut = actions[:, :5]
                     app = prop['obj_appearances'][:, -1]
-                z_pred, r_pred = st.rollout(z_last, num=92 if name == 'n3' else 12, actions=fut, appearance=app)
+                z_pred, r_pred = st.rollout(z_last, num=roll_all or (92 if name == 'n3' else 12), actions=fut, appearance=app)
             extra['roll_z'] = z_pred
             if name in ('n3', 'grav3'):
                 # sampling rollout (stove.py:833-838; the reference only runs it with return_std=True, see z_dyn_stds)
@@ -480,7 +483,7 @@ def g7_g8_full(regime='analytic', dtypes=((torch.float64, 'f64'), (torch.float32
                 extra.update(eps_roll=torch.stack(eps_roll, 0), roll_s_z=zs, roll_s_logq=lq)
             if c.action_conditioned:
                 extra['roll_rewards'] = r_pred
-            save(f'g7_stove_{name}{_rs(regime)}_{tag}', x=x.to(torch.float32), eps_lat=lat, eps_std=sd, eps_steps=torch.stack(steps, 0),
+            save(f'{prefix}_{name}{_rs(regime)}_{tag}', x=x.to(torch.float32), eps_lat=lat, eps_std=sd, eps_steps=torch.stack(steps, 0),
                  elbo=elbo, **props, **gnorm, **small, **extra)
 
 
@@ -730,12 +733,23 @@ def g16_regimes():
         g7_g8_full(regime)
 
 
+def g17_full_length():
+    """Round 6: Stove.forward + backward at the length every BASELINE config runs -- B = 2, T = 100 (98 dependent steps of the
+    inference recursion, stove.py:696-713) -- for the four workloads in the three weight regimes, each followed by a 92-step
+    rollout (stove.py:823-846).  float64 fixtures are committed; the float32 runs feed oracle/fp32_gap.py and are deleted."""
+    only = os.environ.get('G17_ONLY')
+    for regime in ('analytic', 'init', 'stress'):
+        if only and regime not in only.split(','):
+            continue
+        g7_g8_full(regime, shape=(2, 100), prefix='g17_stove_T100', roll_all=92)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7', 'g6b', 'g11', 'g9', 'g12', 'g13', 'g14', 'g15', 'g16']
+    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7', 'g6b', 'g11', 'g9', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17']
     os.makedirs(OUT, exist_ok=True)
     table = {'g0': g0_envs, 'g1': g1_structures, 'g2': g2_ratspn, 'g3': g3_masks_glimpses,
              'g4': g4_likelihood, 'g5': g5_dynamics, 'g6': g6_matchers, 'g10': g10_units, 'g7': g7_g8_full,
-             'g6b': g6b_volatile, 'g11': g11_supair_only, 'g9': g9_optimiser_steps, 'g12': g12_reconstruct, 'g13': g13_wide, 'g14': g14_spn_shapes, 'g15': g15_simple_models, 'g16': g16_regimes}
+             'g6b': g6b_volatile, 'g11': g11_supair_only, 'g9': g9_optimiser_steps, 'g12': g12_reconstruct, 'g13': g13_wide, 'g14': g14_spn_shapes, 'g15': g15_simple_models, 'g16': g16_regimes, 'g17': g17_full_length}
     for k in which:
         torch.manual_seed(0)
         np.random.seed(0)

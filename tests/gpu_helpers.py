@@ -61,10 +61,18 @@ def ref_gap(case, *path, default=0.0):
         import os
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g16_reference_fp32_gap.json')) as f:
             _GAPS = json.load(f)['gaps']
-    v = _GAPS.get(case)
+    if case not in _GAPS:
+        # only the round-1 'analytic' fixtures (g4 / g5 / g7) have no record; a missing record of any other case is a typo in the
+        # case name or a fixture whose float32 run was never measured -- either would quietly put the analytic bar in force
+        if not case.endswith('_analytic') or case.startswith('g17'):
+            raise KeyError('no float32-gap record for ' + case)
+        return default
+    v = _GAPS[case]
     for k in path:
         if not isinstance(v, dict) or k not in v:
-            return default
+            if k == 'z_dyn_std':          # (nan-padded in the fixture: never recorded)
+                return default
+            raise KeyError('no float32-gap record %s of %s' % ('/'.join(path), case))
         v = v[k]
     return float(v) if v is not None else default
 

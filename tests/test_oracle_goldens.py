@@ -189,8 +189,21 @@ CASES = {
 @pytest.mark.parametrize('name', list(CASES))
 @pytest.mark.parametrize('regime,tag,dtype', REGIME_TAGS)
 def test_stove_forward_and_rollout(name, regime, tag, dtype):
+    _full_model_against(load_golden(_gname(f'g7_stove_{name}', regime, tag)), name, regime, dtype)
+
+
+@pytest.mark.parametrize('name', list(CASES))
+@pytest.mark.parametrize('regime', ['analytic', 'init', 'stress'])
+def test_stove_forward_full_length(name, regime):
+    """Round 6 (g17): B = 2, T = 100 -- the 98 dependent steps of the inference recursion every BASELINE config runs
+    (stove.py:696-713), backward through all of them, then a 92-step rollout (stove.py:823-846), for the four workloads."""
+    g = load_golden(_gname(f'g17_stove_T100_{name}', regime, 'f64'))
+    assert g['x'].shape[:2] == (2, 100) and g['p_z'].shape[1] == 98 and g['roll_z'].shape[1] == 92
+    _full_model_against(g, name, regime, torch.float64)
+
+
+def _full_model_against(g, name, regime, dtype):
     tol = 1e-9 if dtype == torch.float64 else 1e-4
-    g = load_golden(_gname(f'g7_stove_{name}', regime, tag))
     c, structs, params = oracle_setup(dtype, regime=regime, **CASES[name])
     x = t_(g['x'], dtype)
     eps = {'latent': t_(g['eps_lat'], dtype), 'std': t_(g['eps_std'], dtype),
