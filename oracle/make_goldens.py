@@ -249,6 +249,37 @@ def g5_dynamics(regime='analytic', dtypes=((torch.float64, 'f64'), (torch.float3
 
 
 # ------------------------------------------------------------------ G6 matchers + fix_supair, G10 units
+def source_index(z, zm):
+    """The permutation the reference's matcher applied, recovered from its output: idx[b, t, slot] = k with zm[b, t, slot] == z[b, t, k]
+    to 1e-12 (the matchers gather rows or multiply by a 0/1 matrix; the reference maps positions to [0, 1] and back around it, stove.py:
+    216-219 / 322-325, so values return one ulp off; the crafted rows differ by O(0.1))."""
+    eq = ((zm.unsqueeze(3) - z.unsqueeze(2)).abs() < 1e-12).all(-1)   # (n, t, slot, k)
+    assert bool((eq.sum(-1) == 1).all()), 'a matched row is not exactly one source row'
+    return eq.long().argmax(-1)
+
+
+def source_matrix(z, zm):
+    """As source_index for the 'volatile' matcher, whose 0/1 matrix need not be a permutation: perm[b, t, slot, k] in {0, 1} with
+    zm[b, t, slot] == sum_k perm * z[b, t, k] to 1e-12."""
+    n, t, o, _ = z.shape
+    perm = torch.zeros(n, t, o, o, dtype=torch.long)
+    for b in range(n):
+        for tt in range(t):
+            for slot in range(o):
+                hits = []
+                for mask in range(1 << o):
+                    acc = torch.zeros_like(z[b, tt, 0])
+                    for k in range(o):
+                        if mask >> k & 1:
+                            acc = acc + z[b, tt, k]
+                    if float((acc - zm[b, tt, slot]).abs().max()) < 1e-12:
+                        hits.append(mask)
+                assert len(hits) == 1, (b, tt, slot, hits)
+                for k in range(o):
+                    perm[b, tt, slot, k] = hits[0] >> k & 1
+    return perm
+
+
 def g6_matchers():
     g = torch.Generator().manual_seed(6)
     # 3_only: mostly smooth tracks + injected swaps + an ambiguous (fault) case
@@ -270,7 +301,8 @@ def g6_matchers():
     zm_a, zsm_a, app_m = st._3_only_match_objects(z.clone(), zstd.clone(), app.clone())
     c.debug_match_appearance = False
     save('g6_match_3only', z=z, zstd=zstd, z_matched=zm, zstd_matched=zsm,
-         app=app, z_matched_app=zm_a, zstd_matched_app=zsm_a, app_matched=app_m)
+         app=app, z_matched_app=zm_a, zstd_matched_app=zsm_a, app_matched=app_m,
+         idx=source_index(z, zm), idx_app=source_index(z, zm_a))
 
     c6 = ref_config(num_obj=6, debug_match_objects='greedy')
     st6 = Stove(c6)
@@ -282,7 +314,7 @@ def g6_matchers():
             z6[b, tt] = z6[b, tt][perm]
     z6std = torch.rand(n, t, 6, 4, generator=g, dtype=torch.float64) * 0.3
     zm6, zsm6, _ = st6._greedy_match_objects(z6.clone(), z6std.clone(), None)
-    save('g6_match_greedy', z=z6, zstd=z6std, z_matched=zm6, zstd_matched=zsm6)
+    save('g6_match_greedy', z=z6, zstd=z6std, z_matched=zm6, zstd_matched=zsm6, idx=source_index(z6, zm6))
 
     # fix_supair: glitches on scale dims (0,1) trigger, on position dims do not
     zf = base[:, :, :3] + torch.cumsum(0.01 * torch.randn(n, t, 3, 4, generator=g, dtype=torch.float64), 1)
@@ -500,7 +532,7 @@ def g6b_volatile():
     z[4, 4, :, 2:] = z[4, 3, 0:1, 2:]              # all current objects collapse onto one previous slot
     zstd = torch.rand(n, t, 3, 4, generator=g, dtype=torch.float64) * 0.3
     zm, zsm, _ = st._volatile_match_objects(z.clone(), zstd.clone(), None)
-    save('g6_match_volatile', z=z, zstd=zstd, z_matched=zm, zstd_matched=zsm)
+    save('g6_match_volatile', z=z, zstd=zstd, z_matched=zm, zstd_matched=zsm, perm=source_matrix(z, zm))
 
 
 def g11_supair_only():

@@ -8,6 +8,14 @@
 #include <stdlib.h>
 #include <math.h>
 #include <atomic>
+#include "validate.h"
+// argument checks shared with the sanitizer-built host driver (csrc/validate.h, tests/abi/validate_driver.cpp)
+static_assert(stove_validate::kStoveInvalidValue == (int)hipErrorInvalidValue, "validate.h returns hipErrorInvalidValue");
+#define STOVE_VALIDATE(expr)                      \
+  do {                                            \
+    const int v__ = stove_validate::expr;         \
+    if (v__) return v__;                          \
+  } while (0)
 #include "spn_obj.hip"
 #include "spn_obj_generic.hip"
 #include "spn_bg.hip"
@@ -141,6 +149,8 @@ size_t stove_objspn_tile_floats(int n) { return (size_t)((n + 63) / 64) * kObjX;
 
 int stove_objspn_fwd(const StoveSpnTables* t, const float* inputs, const float* marg, float* xw, float* out, int n,
                      void* stream) {
+  STOVE_VALIDATE(objspn_fwd(t, inputs, xw, out, n));
+  if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int rc = objspn_tile_from_arrays(inputs, marg, xw, n, st);
   if (rc) return rc;
@@ -151,6 +161,7 @@ size_t stove_objspn_bwd_ws_bytes(int n) { return (objspn_bwd_ws_floats(n) + stov
 
 int stove_objspn_bwd(const StoveSpnTables* t, const float* marg, const float* xw, const float* out, const float* dout,
                      float* d_inputs, float* d_marg, StoveSpnTableGrads* g, void* ws, int n, void* stream) {
+  STOVE_VALIDATE(objspn_bwd(t, marg, xw, out, dout, d_marg, g, ws, n));
   hipStream_t st = (hipStream_t)stream;
   float* dxw = (float*)ws;
   float* rest = dxw + stove_objspn_tile_floats(n);
@@ -167,6 +178,8 @@ size_t stove_bgspn_saved_floats(int n) { return bgspn_fwd_ws_floats(n); }
 
 int stove_bgspn_fwd(const StoveSpnTables* t, const float* inputs, const float* marg, float* ell, float* out, int n,
                     void* stream) {
+  STOVE_VALIDATE(bgspn_fwd(t, inputs, ell, out, n, 1024));
+  if (n == 0) return 0;
   return bgspn_forward(inputs, marg, nullptr, 0, t->bg_side, t->bg_coef, t->bg_wroot, ell, out, n, (hipStream_t)stream);
 }
 
@@ -175,7 +188,7 @@ size_t stove_bgspn_bwd_ws_bytes(int n) { return bgspn_bwd_ws_floats(n) * sizeof(
 int stove_bgspn_bwd(const StoveSpnTables* t, const float* inputs, const float* marg, const float* ell, const float* out,
                     const float* dout, float* d_inputs, float* d_marg, StoveSpnTableGrads* g, void* ws, int n,
                     void* stream) {
-  if (d_marg != nullptr && marg == nullptr) return (int)hipErrorInvalidValue;
+  STOVE_VALIDATE(bgspn_bwd(t, inputs, marg, ell, out, dout, d_marg, g, ws, n, 1024));
   return bgspn_backward(inputs, marg, nullptr, 0, t->bg_side, t->bg_coef, t->bg_wroot, ell, out, dout, d_inputs, d_marg,
                         nullptr, g->bg_coef, g->bg_wroot, (float*)ws, n, (hipStream_t)stream);
 }
@@ -183,12 +196,14 @@ int stove_bgspn_bwd(const StoveSpnTables* t, const float* inputs, const float* m
 // the same operator for any number of input dimensions (frame sizes other than 32 x 32): csrc/spn_bg_generic.hip
 size_t stove_bgspn_saved_floats_d(int n, int n_pix) { return bgspn_any_saved_floats(n, n_pix); }
 int stove_bgspn_fwd_d(const StoveSpnTables* t, const float* inputs, const float* marg, float* ell, float* out, int n, int n_pix, void* stream) {
+  STOVE_VALIDATE(bgspn_fwd(t, inputs, ell, out, n, n_pix));
+  if (n == 0) return 0;
   return bgspn_any_forward(inputs, marg, t->bg_side, t->bg_coef, t->bg_wroot, ell, out, n, n_pix, (hipStream_t)stream);
 }
 size_t stove_bgspn_bwd_ws_bytes_d(int n, int n_pix) { return bgspn_any_bwd_ws_floats(n, n_pix) * sizeof(float); }
 int stove_bgspn_bwd_d(const StoveSpnTables* t, const float* inputs, const float* marg, const float* ell, const float* out, const float* dout,
                       float* d_inputs, float* d_marg, StoveSpnTableGrads* g, void* ws, int n, int n_pix, void* stream) {
-  if (d_marg != nullptr && marg == nullptr) return (int)hipErrorInvalidValue;
+  STOVE_VALIDATE(bgspn_bwd(t, inputs, marg, ell, out, dout, d_marg, g, ws, n, n_pix));
   return bgspn_any_backward(inputs, marg, t->bg_side, t->bg_coef, t->bg_wroot, ell, out, dout, d_inputs, d_marg, g->bg_coef, g->bg_wroot,
                             (float*)ws, n, n_pix, (hipStream_t)stream);
 }
@@ -276,6 +291,7 @@ int stove_scene_fwd(const StoveSpnTables* t, const float* frames, const float* z
 int stove_scene_fwd_from(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
                          int seq_stride, float overlap_beta, float* ll, float* parts, float* saved, void* stream, void* fork_from,
                          int with_grad) {
+  STOVE_VALIDATE(scene_fwd(t, frames, z, n_frames, n_obj, seq_frames, seq_stride, ll, saved));
   hipStream_t st = (hipStream_t)stream;
   hipStream_t root = fork_from != nullptr ? (hipStream_t)fork_from : st;
   if (n_frames == 0) return 0;
@@ -353,6 +369,7 @@ int stove_scene_bwd_overlap(const StoveSpnTables* t, const float* frames, const 
 int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames,
                          int seq_stride, float overlap_beta, const float* saved, const float* dll, float* dz,
                          StoveSpnTableGrads* g, void* ws_, void* stream, void* param_stream, void* fork_from) {
+  STOVE_VALIDATE(scene_bwd(t, frames, z, n_frames, n_obj, seq_frames, seq_stride, saved, dll, dz, g, ws_));
   hipStream_t st = (hipStream_t)stream;
   hipStream_t root = fork_from != nullptr ? (hipStream_t)fork_from : st;
   hipStream_t sp = param_stream != nullptr ? (hipStream_t)param_stream : st;
@@ -496,6 +513,7 @@ size_t stove_scene_bwd_ws_bytes_any(int n_frames, int n_obj, int n_pix) { return
 
 int stove_scene_fwd_any(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames, int seq_stride,
                         int W, int H, int align_corners, float overlap_beta, float* ll, float* parts, float* saved, void* stream, int with_grad) {
+  STOVE_VALIDATE(scene_fwd(t, frames, z, n_frames, n_obj, seq_frames, seq_stride, ll, saved));
   hipStream_t st = (hipStream_t)stream;
   if (n_frames == 0) return 0;
   if (W < 2 || H < 2 || n_obj < 1 || n_obj > 8) return (int)hipErrorInvalidValue;
@@ -537,6 +555,7 @@ int stove_scene_fwd_any(const StoveSpnTables* t, const float* frames, const floa
 int stove_scene_bwd_any(const StoveSpnTables* t, const float* frames, const float* z, int n_frames, int n_obj, int seq_frames, int seq_stride,
                         int W, int H, int align_corners, float overlap_beta, const float* saved, const float* dll, float* dz,
                         StoveSpnTableGrads* g, void* ws_, void* stream, void* param_stream) {
+  STOVE_VALIDATE(scene_bwd(t, frames, z, n_frames, n_obj, seq_frames, seq_stride, saved, dll, dz, g, ws_));
   hipStream_t st = (hipStream_t)stream;
   hipStream_t sp = param_stream != nullptr ? (hipStream_t)param_stream : st;
   if (n_frames == 0) return 0;
@@ -642,8 +661,8 @@ int stove_gnn_blocks(int B, int N) {
 
 int stove_gnn_fwd(const float* s_in, const float* params, float* result, float* pred, int B, int N, int sin_dim,
                   int lim_enc, int elu, void* stream) {
+  STOVE_VALIDATE(gnn_fwd(s_in, params, result, B, N, sin_dim));
   if (B == 0) return 0;
-  if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32) return (int)hipErrorInvalidValue;
   int rc = gnn_lds_attr((const void*)gnn_step_fwd_k);
   if (rc) return rc;
   STOVE_LAUNCH(gnn_step_fwd_k, dim3(stove_gnn_blocks(B, N)), dim3(256), kGnnLdsFloats * sizeof(float), (hipStream_t)stream,
@@ -657,6 +676,8 @@ size_t stove_gnn_bwd_ws_bytes(int B, int N) { return (size_t)stove_gnn_blocks(B,
 int stove_gnn_bwd(const float* s_in, const float* params, const float* d_result, const float* d_pred, float* d_s_in,
                   float* g_params, void* ws, int B, int N, int sin_dim, int lim_enc, int elu, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (g_params == nullptr) return (int)hipErrorInvalidValue;
+  STOVE_VALIDATE(gnn_bwd(s_in, params, d_result, d_s_in, g_params, ws, B, N, sin_dim));
   if (B == 0) {
     hipMemsetAsync(g_params, 0, kGnnGrads * sizeof(float), st);
     return 0;
@@ -716,6 +737,7 @@ int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zss
                             const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred, float* act,
                             int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
                             int ts0, int ts1, void* stream) {
+  STOVE_VALIDATE(dynloop_fwd(z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, B, Ts, N, sin_dim));
   if (B == 0 || Ts == 0) return 0;
   if (ts0 < 0 || ts1 > Ts || ts0 >= ts1) return (int)hipErrorInvalidValue;
   if ((ts0 != 0 || ts1 != Ts) && !small_graph(N)) return (int)hipErrorInvalidValue;      // pieces: small-graph kernels only
@@ -814,6 +836,7 @@ int stove_dynloop_bwd_range(const float* z1, const float* zsup, const float* zss
                             const float* dmean, const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd,
                             float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
                             float pos_var, float vel_std, float lat_std, int ts0, int ts1, float* carry, void* stream, void* param_stream) {
+  STOVE_VALIDATE(dynloop_bwd(z1, zsup, zsstd, eps, extra, params, z, dz1, dzsup, dzsstd, dextra, g_params, ws, B, Ts, N, sin_dim));
   hipStream_t st = (hipStream_t)stream;
   if (ts0 < 0 || ts1 > Ts || ts0 >= ts1) return (int)hipErrorInvalidValue;
   const bool whole = ts0 == 0 && ts1 == Ts;
@@ -894,6 +917,7 @@ int stove_dynloop_bwd_range(const float* z1, const float* zsup, const float* zss
 int stove_rollout_fwd(const float* z_last, const float* extra, const float* params, float* z_pred, float* zstd, float* pred,
                       int B, int num, int A, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std,
                       float lat_std, void* stream) {
+  STOVE_VALIDATE(rollout_fwd(z_last, extra, params, z_pred, B, num, A, N, sin_dim));
   if (B == 0 || num == 0) return 0;
   if (N < 1 || N > 8 || sin_dim < 16 || sin_dim > 32 || (sin_dim > 16 && (extra == nullptr || A < 1))) return (int)hipErrorInvalidValue;
   LoopConst kc{pos_var, vel_std, lat_std};
@@ -983,6 +1007,7 @@ size_t stove_gemm_bf16_ws_floats(int M, int N, int splitk) { return splitk > 1 ?
 int stove_gemm_bf16(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda,
                     int ldb, int ldc, int a_kmajor, int b_kmajor, int nsplit, int splitk, int tile, float* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  STOVE_VALIDATE(gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, nsplit, splitk, ws));
   if (M == 0 || N == 0) return 0;
   if (K <= 0 || splitk < 1 || nsplit < 1 || nsplit > 3 || tile < 0 || (tile > 3 && (tile < 11 || tile > 15))) return (int)hipErrorInvalidValue;
   // tile 11 / 12: measurement variants of the 256 x 128 NT kernel (tools/gemm_bf16_bench.py): no loads in the loop / no MFMAs

@@ -79,3 +79,12 @@ def reference_at_codes(gold, regime, cfg, codes):
             zs, lq, _ = O.rollout(c, params, z_last, gold['roll_s_z'].shape[1], eps=[t_(e, dtype) for e in gold['eps_roll']])
             out['roll_s_z'], out['roll_s_logq'] = zs.numpy(), lq.numpy()
     return out
+
+
+def source_index(z, zm, tol=1e-6):
+    """idx[b, t, slot] = k with zm[b, t, slot] == z[b, t, k] (to `tol`): the permutation a matcher applied, recovered from its
+    output; every matched row must be exactly one source row (rows of the test tracks differ in their first two columns)."""
+    z, zm = torch.as_tensor(z).double().cpu(), torch.as_tensor(zm).double().cpu()
+    eq = ((zm.unsqueeze(3) - z.unsqueeze(2)).abs() < tol).all(-1)
+    assert bool((eq.sum(-1) == 1).all()), 'a matched row is not exactly one source row'
+    return eq.long().argmax(-1)

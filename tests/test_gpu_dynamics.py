@@ -6,7 +6,7 @@ import torch
 
 import stove_oracle as O
 from gpu_helpers import check, check_grad, err, fill_analytic, ref_gap, regime_bar
-from helpers import load_golden, oracle_setup, reference_at_codes, t_
+from helpers import load_golden, oracle_setup, reference_at_codes, source_index, t_
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -101,11 +101,23 @@ def test_dynamics_step_ragged_batches_and_reproducible():
             assert torch.equal(a, b)
 
 
+def _gold_idx(a):
+    return torch.from_numpy(np.asarray(a)).long().to(DEV)
+
+
 def test_match_3only():
+    """Index work is held bit-exact: the int64 permutation stove_match_objects returns == the reference's own (recovered from its
+    matched output by oracle/make_goldens.py source_index), incl. the repair branch (stove.py:273-316) and appearance features."""
+    from stove_amd import ops
     from stove_amd.video_prediction.stove import Stove
     g = load_golden('g6_match_3only')
     st = Stove(make_cfg())
     z, zs = t_(g['z']).float().to(DEV), t_(g['zstd']).float().to(DEV)
+    app = t_(g['app']).float().to(DEV)
+    for mode in ('3_only', '3_only_serial'):
+        assert torch.equal(ops.match_objects(z[..., 2:4].contiguous(), mode)[0], _gold_idx(g['idx'])), mode
+        assert torch.equal(ops.match_objects(torch.cat([z[..., 2:4], 2 * app - 1], -1), mode)[0], _gold_idx(g['idx_app'])), mode
+    assert not np.array_equal(g['idx'], np.broadcast_to(np.arange(3), g['idx'].shape))            # the fixture does permute
     zm, zsm, _ = st._3_only_match_objects(z, zs, None)
     assert err(zm, g['z_matched']) < 1e-6 and err(zsm, g['zstd_matched']) < 1e-6
     st.c.debug_match_appearance = True
@@ -140,6 +152,9 @@ def test_match_3only_collisions_and_ties(T):
         assert err(zm, zo) < 1e-6 and err(zsm, zso) < 1e-6, (T, use_app)
         if use_app:
             assert err(am, ao) < 1e-6
+        # ... and as indices, bit-exact (rows of zs are distinct random vectors: the oracle's permutation can be read off its output)
+        feat0 = torch.cat([z[..., 2:4]] + ([2 * app - 1] if use_app else []), -1).to(DEV)
+        assert torch.equal(ops.match_objects(feat0, '3_only')[0].cpu(), source_index(zs, zso)), (T, use_app)
         # and against the frame-by-frame walk of lane 0 (same arithmetic, so also on the continuous half of the batch, bit for bit)
         feat = torch.cat([z[..., 2:4]] + ([2 * app - 1] if use_app else []), -1).to(DEV)
         assert torch.equal(ops.match_objects(feat, '3_only')[0], ops.match_objects(feat, '3_only_serial')[0])
@@ -152,6 +167,10 @@ def test_match_greedy():
     st = Stove(make_cfg(num_obj=6, debug_match_objects='greedy'))
     zm, zsm, _ = st._greedy_match_objects(t_(g['z']).float().to(DEV), t_(g['zstd']).float().to(DEV), None)
     assert err(zm, g['z_matched']) < 1e-6 and err(zsm, g['zstd_matched']) < 1e-6
+    from stove_amd import ops
+    idx = ops.match_objects(t_(g['z']).float().to(DEV)[..., 2:4].contiguous(), 'greedy')[0]
+    assert torch.equal(idx, _gold_idx(g['idx']))                       # the reference's permutation, bit-exact
+    assert bool((idx.sort(-1).values == torch.arange(6, device=DEV)).all())
 
 
 def test_fix_supair_stage_on_reference_fixture():
@@ -342,6 +361,11 @@ def test_match_volatile():
     st = Stove(make_cfg(debug_match_objects='volatile'))
     zm, zsm, _ = st._volatile_match_objects(t_(g['z']).float().to(DEV), t_(g['zstd']).float().to(DEV), None)
     assert err(zm, g['z_matched']) < 1e-6 and err(zsm, g['zstd_matched']) < 1e-6
+    from stove_amd import ops
+    idx, _ = ops.match_objects(t_(g['z']).float().to(DEV)[..., 2:4].contiguous(), 'volatile')
+    gp = _gold_idx(g['perm'])                  # the reference's 0/1 matrix: one 1 per row (stove.py:405-411), not a permutation at [4, 4]
+    assert bool((gp.sum(-1) == 1).all()) and int(gp[4, 4].sum(0).max()) == 3
+    assert torch.equal(idx, gp.argmax(-1))     # bit-exact
 
 
 def test_supair_only_elbo():

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import stove_oracle as O
-from helpers import GOLDEN, load_golden, oracle_setup, rel_err, t_
+from helpers import GOLDEN, load_golden, oracle_setup, rel_err, source_index, t_
 
 F64 = torch.float64
 
@@ -138,8 +138,10 @@ def test_match_3only():
     zm, zs, _ = O.match_3only(c, t_(g['z']), t_(g['zstd']), None)
     assert np.array_equal(zm.numpy(), g['z_matched']) or rel_err(zm, g['z_matched']) < 1e-15
     assert rel_err(zs, g['zstd_matched']) < 1e-15
+    assert np.array_equal(source_index(g['zstd'], zs, 1e-12).numpy(), g['idx'])          # the permutation itself, exact
     c.debug_match_appearance = True
     zm, zs, am = O.match_3only(c, t_(g['z']), t_(g['zstd']), t_(g['app']))
+    assert np.array_equal(source_index(g['zstd'], zs, 1e-12).numpy(), g['idx_app'])
     assert rel_err(zm, g['z_matched_app']) < 1e-15
     assert rel_err(zs, g['zstd_matched_app']) < 1e-15
     assert rel_err(am, g['app_matched']) < 1e-15
@@ -151,6 +153,7 @@ def test_match_greedy():
     zm, zs, _ = O.match_greedy(c, t_(g['z']), t_(g['zstd']), None)
     assert rel_err(zm, g['z_matched']) < 1e-15
     assert rel_err(zs, g['zstd_matched']) < 1e-15
+    assert np.array_equal(source_index(g['zstd'], zs, 1e-12).numpy(), g['idx'])
 
 
 def test_fix_supair():
@@ -250,6 +253,8 @@ def test_match_volatile():
     c = O.default_config(debug_match_objects='volatile')
     zm, zs, _ = O.match_volatile(c, t_(g['z']), t_(g['zstd']), None)
     assert rel_err(zm, g['z_matched']) < 1e-14 and rel_err(zs, g['zstd_matched']) < 1e-14
+    assert (g['perm'].sum(-1) == 1).all()                                               # one source per slot: a gather
+    assert np.array_equal(source_index(g['zstd'], zs, 1e-12).numpy(), g['perm'].argmax(-1))
 
 
 def test_supair_only_elbo():
