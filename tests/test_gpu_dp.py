@@ -340,3 +340,30 @@ def test_two_ranks_on_rccl_replayed_step(tmp_path):
     mp.spawn(_nccl2_worker, args=(port, out), nprocs=2, join=True)
     got = torch.load(out)
     assert got['ok'], got
+
+
+def test_bench_eight_ranks_over_gloo_on_one_gpu():
+    """The driver's multi-GPU invocation shape -- `bench.py --gpus 8` -> torch.distributed.run, 8 ranks, rendezvous on 127.0.0.1 --
+    on the one-GPU box: STOVE_DIST_BACKEND=gloo, the ranks share cuda:0 (16 sequences each).  Everything that is not the wire runs:
+    launch_ranks, the wait for rank 0's library build, per-rank data generation with cores // 8 workers, one seed / one parameter
+    set on all ranks, the captured step with the eager all-reduce fallback between its graphs, barrier + max-over-ranks timing, and
+    ONE JSON line from rank 0 with the whole-job aggregate at N = 8.  No scaling number comes out of it (one GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STOVE_DIST_BACKEND='gloo', STOVE_BENCH_NO_PARITY='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--batch', '16', '--steps', '4', '--warmup', '2',
+           '--no-variants', '--no-cpu-baseline', '--profile-steps', '0']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['steps'] == 4 and d['scaling'] == 'weak'
+    assert d['config']['global_batch'] == 8 * 16 and d['config']['parallelism'] == 'dp8'
+    assert abs(d['value'] - 8 * 16 * 100 / d['ms_per_step'] * 1e3) < 1e-6 * d['value']          # whole-job frames / max-over-ranks time
+    assert d['all_reduce_in_graph'] is False                                                    # gloo: the eager all-reduce between the graphs
+    assert np.isfinite(d['config']['elbo_last_step'])
+    assert d['comm'] is not None and d['comm']['world_size_reported'] == 8 and d['comm']['backend'] == 'gloo', d['comm']

@@ -106,6 +106,28 @@ def test_two_rank_arena_replicas_agree(tmp_path):
     assert not torch.equal(r0['epochs'][0], r0['epochs'][1])
 
 
+def test_eight_rank_replicas_agree(tmp_path):
+    """The same contract at the world size the driver scales to (8 ranks, gloo on this host): one seed, one SPN structure, one set of
+    parameters, the mean of eight gradient buffers on every rank, eight disjoint clip shards of equal length."""
+    world = 8
+    out = str(tmp_path / 'r')
+    mp.spawn(_arena_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    rs = [torch.load(out + str(r)) for r in range(world)]
+    assert all(r['seed'] == 7 for r in rs) and len({r['drawn'] for r in rs}) == 1
+    n = rs[0]['grad'].numel()
+    mean = sum(_fake_grad(n, r) for r in range(world)) / world
+    for r in rs:
+        assert torch.equal(r['scope'], rs[0]['scope']) and torch.equal(r['data'], rs[0]['own'])
+        assert torch.equal(r['grad'], rs[0]['grad'])
+    nz = rs[0]['grad'] != 0
+    assert torch.allclose(rs[0]['grad'][nz], mean[nz], rtol=0, atol=2e-7)
+    assert all(r['len'] == (4 * 8 // world) // 3 for r in rs)
+    for e in range(2):
+        sets = [set(r['epochs'][e].flatten().tolist()) for r in rs]
+        assert all(len(s_) == rs[0]['len'] * 3 for s_ in sets)
+        assert len(set().union(*sets)) == sum(len(s_) for s_ in sets)          # pairwise disjoint
+
+
 def test_shard_order_is_a_partition():
     order = torch.randperm(103)
     parts = [shard_order(order, r, 4, 5) for r in range(4)]
