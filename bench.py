@@ -86,7 +86,8 @@ def build_config(workload, device, res=32):
 
 
 def _cache_path(workload, n_seq, T, seed0, res):
-    return os.path.join('/tmp', f'stove_bench_{workload}_{n_seq}_{T}_{seed0}' + ('' if res == 32 else f'_r{res}') + '.npz')
+    from stove_amd.envs import envs
+    return os.path.join('/tmp', f'stove_bench_v{envs.SIMULATOR_VERSION}_{workload}_{n_seq}_{T}_{seed0}' + ('' if res == 32 else f'_r{res}') + '.npz')
 
 
 def make_batch(workload, n_seq, T, seed0, res=32, workers=1):

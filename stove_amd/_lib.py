@@ -194,6 +194,9 @@ def load():
         # the A/B measurement switches live in the binding, not in the library (which never reads the environment)
         from . import settings
         lib.stove_set_overlap(1 if settings.OVERLAP else 0)
+        if settings.LIB_OVERRIDE:             # an A/B run: say which build this process measured
+            import sys
+            sys.stderr.write('[stove_amd] STOVE_LIB: loaded %s\n' % LIB_PATH)
         _lib = lib
     return _lib
 

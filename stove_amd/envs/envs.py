@@ -283,15 +283,23 @@ def synth_sequences(preset, n_seq, t_len, seed0=0, with_actions=None, res=None):
 
 
 def _synth_chunk(args):
-    preset, n, t_len, seed0, res = args
-    return synth_sequences(preset, n, t_len, seed0=seed0, res=res)
+    preset, n, t_len, seed0, res, with_actions = args
+    return synth_sequences(preset, n, t_len, seed0=seed0, with_actions=with_actions, res=res)
 
 
-def synth_sequences_parallel(preset, n_seq, t_len, seed0=0, res=None, workers=None):
+# bump when the simulators change what they draw: part of the name of every cache file of generated sequences (bench.py)
+SIMULATOR_VERSION = 2
+
+
+def synth_sequences_parallel(preset, n_seq, t_len, seed0=0, res=None, workers=None, with_actions=None):
     """synth_sequences over a pool of forked workers (sequence i is its own environment with seed seed0 + i, so the result
-    does not depend on the split).  Fork-based: call it BEFORE the process initialises the GPU."""
+    does not depend on the split).  Fork-based: it refuses to run once the process has initialised the GPU (a forked child of
+    such a process must not touch HIP, and the parent's runtime threads do not survive the fork); the workers are pure numpy."""
     import multiprocessing as mp
     import os
+    import sys
+    if 'torch' in sys.modules and sys.modules['torch'].cuda.is_initialized():
+        raise RuntimeError('synth_sequences_parallel forks: call it before the process touches the GPU (or use synth_sequences)')
     if workers is None:
         try:
             workers = len(os.sched_getaffinity(0))
@@ -299,9 +307,9 @@ def synth_sequences_parallel(preset, n_seq, t_len, seed0=0, res=None, workers=No
             workers = os.cpu_count() or 1
     workers = max(1, min(workers, n_seq))
     if workers == 1:
-        return synth_sequences(preset, n_seq, t_len, seed0=seed0, res=res)
+        return synth_sequences(preset, n_seq, t_len, seed0=seed0, with_actions=with_actions, res=res)
     per = (n_seq + workers - 1) // workers
-    jobs = [(preset, min(per, n_seq - s), t_len, seed0 + s, res) for s in range(0, n_seq, per)]
+    jobs = [(preset, min(per, n_seq - s), t_len, seed0 + s, res, with_actions) for s in range(0, n_seq, per)]
     with mp.get_context('fork').Pool(len(jobs)) as pool:
         parts = pool.map(_synth_chunk, jobs)
     return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}

@@ -32,6 +32,21 @@ SLOTS = 32          # how many steps the host may run ahead of the device
 NHYPER = 8          # floats per slot: lr, beta1, beta2, eps, max_norm, reward weight, (2 spare)
 
 
+def _cuda_backend():
+    """The torch.distributed backend that serves CUDA (HIP) tensors in the default group: 'nccl' (= RCCL), 'gloo', ...  A group
+    made with the default or a composite backend string reports 'undefined' / 'cpu:gloo,cuda:nccl' from get_backend(); the
+    per-device map is what decides whether the gradient all-reduce can be captured."""
+    import torch.distributed as dist
+    try:
+        cfg = str(dist.get_backend_config())
+    except Exception:
+        cfg = str(dist.get_backend())
+    if ':' in cfg:
+        table = dict(part.split(':', 1) for part in cfg.split(',') if ':' in part)
+        return table.get('cuda')
+    return cfg
+
+
 class GraphedTrainStep:
     def __init__(self, stove, arena, optimizer, clip, supair_only=False, warmup=3, world_size=1, reward_loss=None,
                  alias_inputs=False, force_reduce=False, capture_reduce=True):
@@ -45,6 +60,7 @@ class GraphedTrainStep:
         self.force_reduce = force_reduce          # send a single rank's gradient through the collective anyway (the 1-GPU RCCL test)
         self.capture_reduce = capture_reduce      # data parallel: the all-reduce as a node of the optimiser graph (False: eager, between the graphs)
         self.reduce_captured = False
+        self.update_eager = False          # the optimiser's launches as eager calls (only after a failed capture of the all-reduce)
         self.graphs = None
         self.key = None
         self.reward_value = None
@@ -232,11 +248,12 @@ class GraphedTrainStep:
             # exists since the warm-up steps), so a replayed step is three graph launches and no host-issued collective in between.
             # If the capture of the collective fails on this stack, the all-reduce stays an eager call between the graphs.
             self.reduce_captured = False
+            self.update_eager = False
             g2 = None
             import torch.distributed as dist
             # (only RCCL's collectives can be captured: gloo's all-reduce of a device tensor goes through the host, which invalidates
             # the capture and leaves the stream in a state the fallback cannot recover from)
-            if (self.world_size > 1 or self.force_reduce) and self.capture_reduce and dist.is_initialized() and dist.get_backend() == 'nccl':
+            if (self.world_size > 1 or self.force_reduce) and self.capture_reduce and dist.is_initialized() and _cuda_backend() == 'nccl':
                 try:
                     g2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g2, stream=s, pool=g1.pool()):
@@ -246,19 +263,34 @@ class GraphedTrainStep:
                 except Exception as exc:
                     # A capture that failed half-way may leave the stream unable to begin another one (seen with a backend whose
                     # collective synchronises with the host): no second attempt at a graph -- the all-reduce AND the optimiser's three
-                    # launches stay eager calls behind the two backward graphs.
+                    # launches stay eager calls behind the two backward graphs, after the stream and the communicator have been
+                    # checked (a stream still capturing, or a collective that no longer completes, is an error, not a slow path).
                     import warnings
                     warnings.warn('GraphedTrainStep: the gradient all-reduce could not be captured (%r); all-reduce and optimiser '
                                   'run eagerly behind the backward graphs' % (exc,))
-                    g2 = 'eager'
-                    try:
-                        torch.cuda.synchronize(self.x.device)
-                    except Exception:
-                        pass
-            if g2 is None:
+                    g2 = None
+                    self.update_eager = True
+                    torch.cuda.synchronize(self.x.device)
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError('GraphedTrainStep: the stream is still capturing after the failed capture of the all-reduce') from exc
+                    probe = torch.ones(1, device=self.x.device)
+                    dist.all_reduce(probe)
+                    torch.cuda.synchronize(self.x.device)
+                    if float(probe) != float(dist.get_world_size()):
+                        raise RuntimeError('GraphedTrainStep: the communicator does not reduce correctly after the failed capture') from exc
+            if g2 is None and not self.update_eager:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, stream=s, pool=g1.pool()):
                     self._update()
+            if self.world_size > 1 and dist.is_initialized():
+                # every rank issues one all-reduce per step either way, but the ranks should agree on HOW (a mixed job is a sign of
+                # a broken stack on some rank): say so once
+                took = torch.tensor([1.0 if self.reduce_captured else 0.0], device=self.x.device)
+                dist.all_reduce(took)
+                if 0.0 < float(took) < float(dist.get_world_size()):
+                    import warnings
+                    warnings.warn('GraphedTrainStep: %d of %d ranks captured the all-reduce into the optimiser graph, the others call it eagerly'
+                                  % (int(float(took)), dist.get_world_size()))
             self.graphs = (g1, g2)
         else:
             self.graphs = (g1,)
@@ -302,7 +334,7 @@ class GraphedTrainStep:
         if len(self.graphs) > 1:
             if not self.reduce_captured:
                 self._reduce()
-            if self.graphs[1] == 'eager':
+            if self.update_eager:
                 self._update()
             else:
                 self.graphs[1].replay()

@@ -264,6 +264,7 @@ def full_model_against_golden(gold, name, regime, fused, arena, case, key):
     for k in ('z', 'z_dyn', 'z_sup', 'z_std', 'z_sup_std', 'log_q', 'translik', 'bg', 'patch', 'overlap'):
         check(key + '.prop_' + k + tag, err(prop[k], gold['p_' + k]), regime_bar(8e-6 if k == 'z_sup' else 3e-6, ref_gap(case, 'prop', k)))
     check(key + '.prop_z_dyn_std' + tag, err(prop['z_dyn_std'][2:], gold['p_z_dyn_std'][2:]), 1e-6)
+    gold_fixture = gold
     if gold_at_codes is not None:
         gold, tag = gold_at_codes, tag + '.at_codes'          # from here on: the reference at this implementation's codes
         check(key + '.elbo_rel' + tag, abs(float(elbo) - float(gold['elbo'])) / abs(float(gold['elbo'])), 1.5e-6)
@@ -282,15 +283,24 @@ def full_model_against_golden(gold, name, regime, fused, arena, case, key):
     params = dict(st.named_parameters())
     n = 0
     gt = lambda m: ref_gap(case, 'grad_tensor', m)
+    # at the reference's own codes (`gold` is the at-codes oracle here in the stress regime) the gradients keep the tight ANALYTIC bars
+    # -- chaos was taken out by evaluating at equal codes; achieved 4.4e-5 / 2.9e-5 / 3.2e-4 (g7), 2.7e-5 / 2.4e-5 / 1.4e-3 (g17) --
+    # and the regime bars (6 x the reference's float32 gap) only apply against the committed fixture itself
+    at_codes = gold_at_codes is not None
+    gbar = (lambda bar, gap: bar) if at_codes else regime_bar
     for k, v in gold.items():
         if k.startswith('gn_'):
             p = params[k[3:]]
             assert p.grad is not None, k
-            check(key + '.grad_norm' + tag, abs(float(p.grad.norm()) - float(v)) / (float(v) + 1e-9), regime_bar(1.5e-4, ref_gap(case, 'grad_norm_rel_max')))
+            check(key + '.grad_norm' + tag, abs(float(p.grad.norm()) - float(v)) / (float(v) + 1e-9), gbar(1.5e-4, ref_gap(case, 'grad_norm_rel_max')))
+            if at_codes:       # ... and, loosely, against the committed fixture: the golden's own gradients stay exercised (the model is
+                # chaotic in its codes: 1.6e-6 on them moves the dynamics' gradients by up to 1.5e-2, tools/regime_probe.py)
+                v0 = float(gold_fixture[k])
+                check(key + '.grad_norm.stress.vs_fixture', abs(float(p.grad.norm()) - v0) / (v0 + 1e-9), 5e-2)
             n += 1
         elif k.startswith('g_'):
             # the reference's own fp32-vs-fp64 gap is 3.3e-4 (max-norm) on the analytic fixtures
-            check_grad(key + '.grad_tensor' + tag, params[k[2:]].grad, v, regime_bar(3e-4, gt('max')), regime_bar(3.5e-4, gt('l2')), regime_bar(4e-3, gt('small')))
+            check_grad(key + '.grad_tensor' + tag, params[k[2:]].grad, v, gbar(3e-4, gt('max')), gbar(3.5e-4, gt('l2')), gbar(4e-3, gt('small')))
     assert n > 50
     if arena:                                                  # cores 1-2 are never used: their gradients stay zero
         assert float(params['dyn.self_cores.1.0.weight'].grad.abs().max()) == 0.0
