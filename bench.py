@@ -276,8 +276,6 @@ class Job:
         self.workload, self.dev, self.world, self.step_mode = workload, dev, world, step_mode
         cfg = build_config(workload, dev, res)
         cfg.encoder_gemm = encoder_gemm
-        if os.environ.get('STOVE_PIECES'):
-            cfg.pipeline_pieces = int(os.environ['STOVE_PIECES'])
         torch.manual_seed(0)
         self.cfg = cfg
         self.model = Stove(cfg).to(dev)

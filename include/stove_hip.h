@@ -225,7 +225,13 @@ int stove_gnn_debug_stamps(const float* s_in, const float* params, const float* 
  * t=skip..T-1; eps (B,Ts,N,18) standard-normal draws; extra (B,Ts,N,sin_dim-16) or NULL.
  * outputs (B,Ts,N,.): z 18, zdyn 16, zdstd 16, mean 18, std 18, pred 32 (NULL to skip). */
 /* act: saved activations (stove_dynloop_act_floats() floats, ~9 KB per sequence-step at N=3), written by the forward and
- * read by the backward.  With 2 <= N <= 6 objects the small-graph kernels run (csrc/gnn_small*.hip: one wave per node row up to
+ * read by the backward.
+ * DOMAIN (2 <= N <= 6, forward and rollout): layers 2 and 3 of the relation / attention chains multiply on IEEE-half hi / lo pieces
+ * (three v_mfma_f32_16x16x32_f16 per product): their input activations must stay below 65 504 in magnitude (beyond it the pieces are
+ * inf and the outputs inf / NaN -- never finite garbage); an operand keeps max(2^-22 |x|, 2^-25) of absolute precision, i.e. weights
+ * below 1/4 lose relative, not absolute, accuracy (tests/test_gpu_dynamics.py::test_recursion_forward_chains_domain_*).
+ * The backward normalises every gradient column by a power of two first and has no such bound.
+ * With 2 <= N <= 6 objects the small-graph kernels run (csrc/gnn_small*.hip: one wave per node row up to
  * four objects, one HALF-wave per node row and two tiles of edge columns for five and six): act is then REQUIRED by the backward
  * (the layout is a set of per-sequence streams), and the backward consists of a T-serial data-gradient launch plus a
  * weight-gradient launch over the streams; its workspace is sized by stove_dynloop_bwd_ws_bytes_ts.  For N > 6 (MFMA kernels of
@@ -252,23 +258,6 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
                               float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
                               float pos_var, float vel_std, float lat_std, void* stream, void* param_stream);
 
-/* ---- the recursion in PIECES (pipelining it against the scene likelihood of the frames already inferred; the loop of stove.py:696-713
- * is T-serial and latency-bound with one sequence per CU, the likelihood of frame t only needs z_t, stove.py:731-736).  All tensors
- * keep their full (B, Ts, ...) layout; a call runs the steps [ts0, ts1).  Forward: a piece with ts0 > 0 starts from the state the
- * previous piece left in z.  Backward: pieces are called from the last to the first; the gradient that flows from step ts0 into the
- * state before it goes through `carry` (B, N, 18 floats, written when ts0 > 0, read when ts1 < Ts); dz1 is written by the piece with
- * ts0 == 0, which also runs the weight-gradient pass (g_params, on param_stream) over the streams of ALL steps.  Small-graph kernels
- * only (stove_dynloop_range_ok(N) != 0: 2 <= N <= 6 and the streamed backward enabled); otherwise only the whole range is accepted. */
-int stove_dynloop_range_ok(int N);
-int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
-                            const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred, float* act,
-                            int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
-                            int ts0, int ts1, void* stream);
-int stove_dynloop_bwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
-                            const float* params, const float* z, const float* act, const float* dz, const float* dzdyn,
-                            const float* dmean, const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd,
-                            float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
-                            float pos_var, float vel_std, float lat_std, int ts0, int ts1, float* carry, void* stream, void* param_stream);
 
 /* ---- reward head of the action-conditioned dynamics model (dynamics.py:62-70, 254-263):
  *   reward = sigmoid(head1(sum over objects of head0(dynamic_pred))),  head0 = Linear(32,32) ReLU Linear(32,32),
@@ -337,12 +326,6 @@ int stove_supair_state_bwd2(const float* zc, const long long* idx, const unsigne
 int stove_zall_fwd(const float* zfix, const float* zs, float* zall, int n, int T, int o, int skip, void* stream);
 int stove_zall_bwd(const float* zfix, const float* zs, const float* g_zall, float* g_zfix, float* g_zs, int n, int T, int o, int skip,
                    void* stream);
-/* the same for the scored frames [f0, f1) of the T-1 only (zall (n, f1-f0, o, 4) dense): the likelihood in pieces.  The backward
- * of a piece writes dz_tot = dz_in (NULL = 0) + the likelihood's part for ALL 18 dims of the piece's sampled steps (layout of zs) --
- * the total gradient the recursion's backward consumes -- and, for the piece with f0 == 0, every element of g_zfix (n, T, o, 8). */
-int stove_zall_fwd_range(const float* zfix, const float* zs, float* zall, int n, int T, int o, int skip, int f0, int f1, void* stream);
-int stove_zall_bwd_range(const float* zfix, const float* zs, const float* g_zall, const float* dz_in, float* g_zfix, float* dz_tot,
-                         int n, int T, int o, int skip, int f0, int f1, void* stream);
 int stove_elbo_fwd(const float* zs, const float* mean, const float* std_, const float* zdyn, const float* lik, const float* trans_std16,
                    float* part_ws, float* out3, int n, int T, int o, int skip, void* stream);
 int stove_elbo_bwd(const float* zs, const float* mean, const float* std_, const float* zdyn, const float* trans_std16, const float* g_out,

@@ -441,9 +441,10 @@ def billiards_frames(n_seq, t_len, n=3, r=1.2):
 
 
 # ------------------------------------------------------------------ G7/G8 full model
-def g7_g8_full(regime='analytic', dtypes=((torch.float64, 'f64'), (torch.float32, 'f32')), shape=None, prefix='g7_stove', roll_all=None):
-    """`shape` = (B, T) for every case instead of the short per-case ones; `roll_all`: rollout length for every case (g17)."""
-    cases = [
+def g7_g8_full(regime='analytic', dtypes=((torch.float64, 'f64'), (torch.float32, 'f32')), shape=None, prefix='g7_stove', roll_all=None, cases=None):
+    """`shape` = (B, T) for every case instead of the short per-case ones; `roll_all`: rollout length for every case (g17);
+    `cases`: another list of (name, config overrides, B, T) (g19)."""
+    cases = cases or [
         ('n3', dict(num_obj=3), 4, 8),
         ('n6', dict(num_obj=6, debug_match_objects='greedy', overlap_beta=100.0, max_obj_scale=0.22), 2, 6),
         ('ac3', dict(num_obj=3, action_conditioned=True, action_space=9, debug_core_appearance=True), 3, 6),
@@ -473,7 +474,7 @@ def g7_g8_full(regime='analytic', dtypes=((torch.float64, 'f64'), (torch.float32
             g = torch.Generator().manual_seed(123)
             lat = torch.randn(B, N, 12, 1, generator=g, dtype=torch.float64)
             sd = torch.randn(B, N, 12, 1, generator=g, dtype=torch.float64)
-            steps = [torch.randn(B, N, 18, generator=g, dtype=torch.float64) for _ in range(2, T)]
+            steps = [torch.randn(B, N, 6 if kw.get('debug_no_latents') else 18, generator=g, dtype=torch.float64) for _ in range(2, T)]
             actions = None
             if c.action_conditioned:
                 actions = torch.zeros(B, T, 9, dtype=dtype)
@@ -505,7 +506,7 @@ def g7_g8_full(regime='analytic', dtypes=((torch.float64, 'f64'), (torch.float32
                     app = prop['obj_appearances'][:, -1]
                 z_pred, r_pred = st.rollout(z_last, num=roll_all or (92 if name == 'n3' else 12), actions=fut, appearance=app)
             extra['roll_z'] = z_pred
-            if name in ('n3', 'grav3'):
+            if name in ('n3', 'grav3', 'novel', 'nolat', 'noreuse'):
                 # sampling rollout (stove.py:833-838; the reference only runs it with return_std=True, see z_dyn_stds)
                 eps_roll = [torch.randn(B, N, 16, generator=g, dtype=torch.float64) for _ in range(10)]
                 tdn._standard_normal = EpsFeeder(eps_roll)
@@ -677,7 +678,7 @@ def g13_wide():
             g = torch.Generator().manual_seed(123)
             lat = torch.randn(B, N, 12, 1, generator=g, dtype=torch.float64)
             sd = torch.randn(B, N, 12, 1, generator=g, dtype=torch.float64)
-            steps = [torch.randn(B, N, 18, generator=g, dtype=torch.float64) for _ in range(2, T)]
+            steps = [torch.randn(B, N, 6 if kw.get('debug_no_latents') else 18, generator=g, dtype=torch.float64) for _ in range(2, T)]
             saved = tdn._standard_normal
             tdn._standard_normal = EpsFeeder([lat, sd] + steps)
             elbo, prop, _ = st(x, 0, None)
@@ -765,6 +766,16 @@ def g16_regimes():
         g7_g8_full(regime)
 
 
+def g19_ablations():
+    """Round 6: the full_state ablations (stove.py:140-160; config.py:79,132,134) -- debug_no_velocity, debug_no_latents (q(z) over six
+    dimensions, six noise values per object and step) and debug_no_reuse (overwritten inside the reference's full_state: == the
+    default model) -- Stove.forward + backward + rollout, B = 2, T = 6, float64."""
+    g7_g8_full('analytic', dtypes=((torch.float64, 'f64'),), prefix='g19_stove', cases=[
+        ('novel', dict(num_obj=3, debug_no_velocity=True), 2, 6),
+        ('nolat', dict(num_obj=3, debug_no_latents=True), 2, 6),
+        ('noreuse', dict(num_obj=3, debug_no_reuse=True), 2, 6)])
+
+
 def g17_full_length():
     """Round 6: Stove.forward + backward at the length every BASELINE config runs -- B = 2, T = 100 (98 dependent steps of the
     inference recursion, stove.py:696-713) -- for the four workloads in the three weight regimes, each followed by a 92-step
@@ -777,11 +788,11 @@ def g17_full_length():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7', 'g6b', 'g11', 'g9', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17']
+    which = sys.argv[1:] or ['g0', 'g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g10', 'g7', 'g6b', 'g11', 'g9', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g19']
     os.makedirs(OUT, exist_ok=True)
     table = {'g0': g0_envs, 'g1': g1_structures, 'g2': g2_ratspn, 'g3': g3_masks_glimpses,
              'g4': g4_likelihood, 'g5': g5_dynamics, 'g6': g6_matchers, 'g10': g10_units, 'g7': g7_g8_full,
-             'g6b': g6b_volatile, 'g11': g11_supair_only, 'g9': g9_optimiser_steps, 'g12': g12_reconstruct, 'g13': g13_wide, 'g14': g14_spn_shapes, 'g15': g15_simple_models, 'g16': g16_regimes, 'g17': g17_full_length}
+             'g6b': g6b_volatile, 'g11': g11_supair_only, 'g9': g9_optimiser_steps, 'g12': g12_reconstruct, 'g13': g13_wide, 'g14': g14_spn_shapes, 'g15': g15_simple_models, 'g16': g16_regimes, 'g17': g17_full_length, 'g19': g19_ablations}
     for k in which:
         torch.manual_seed(0)
         np.random.seed(0)

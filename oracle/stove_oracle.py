@@ -50,6 +50,7 @@ def default_config(**overrides):
         debug_bg_model=False, debug_obj_spn=False, debug_simple_bg_var=0.1, debug_simple_obj_var=0.2,
         debug_match_appearance=False, debug_core_appearance=False,
         debug_appearance_dim=3, debug_bw=True,
+        debug_no_latents=False, debug_no_reuse=False, debug_no_velocity=False,      # full_state ablations, stove.py:140-163
         action_conditioned=False, action_space=None,
         random_seed=42,
         align_corners=False,     # the runnable reference (torch >= 1.3); True = the torch 1.0.1 convention the reference was written for
@@ -658,12 +659,22 @@ def stove_forward(c, params, structs, x_color, eps, actions=None, detail=False, 
         s_d, s_s = sd[..., :4], ss[..., 2:6]
         mean_xv = (s_s ** 2 * zdyn[..., :4] + s_d ** 2 * ms[..., 2:6]) / (s_d ** 2 + s_s ** 2)
         std_xv = s_d * s_s / torch.sqrt(s_d ** 2 + s_s ** 2)
-        mean = torch.cat([ms[..., :2], mean_xv, zdyn[..., 4:]], -1)
-        std = torch.cat([ss[..., :2], std_xv, sd[..., 4:]], -1)
-        zt = mean + std * eps['steps'][t - skip]
+        if c.debug_no_latents:                 # stove.py:140-148: q(z) over the six SuPAIR dimensions only, latents are zeros
+            mean = torch.cat([ms[..., :2], mean_xv], -1)
+            std = torch.cat([ss[..., :2], std_xv], -1)
+        elif c.debug_no_velocity:              # stove.py:154-160: velocities ~ N(0, 1) instead of the fused estimate
+            mean = torch.cat([ms[..., :2], mean_xv[..., :2], torch.zeros_like(mean_xv[..., 2:]), zdyn[..., 4:]], -1)
+            std = torch.cat([ss[..., :2], std_xv[..., :2], torch.ones_like(std_xv[..., 2:]), sd[..., 4:]], -1)
+        else:                                  # (debug_no_reuse, stove.py:151-153, is overwritten by the if / else that follows it
+            mean = torch.cat([ms[..., :2], mean_xv, zdyn[..., 4:]], -1)          # in the reference: the flag changes nothing)
+            std = torch.cat([ss[..., :2], std_xv, sd[..., 4:]], -1)
+        zt = mean + std * eps['steps'][t - skip][..., :mean.shape[-1]]
+        lq_t = normal_log_prob(zt, mean, std)
+        if c.debug_no_latents:
+            zt = torch.cat([zt, torch.zeros_like(zdyn[..., 4:])], -1)
         z[t] = zt
         z_l.append(zt); zdyn_l.append(zdyn); zdyn_std_l.append(sd); zstd_l.append(std)
-        logq_l.append(normal_log_prob(zt, mean, std))
+        logq_l.append(lq_t)
 
     z_s = torch.stack(z_l, 1)                                       # (B,T-2,N,18)
     zdyn_s = torch.stack(zdyn_l, 1)

@@ -11,7 +11,7 @@ from . import settings as _settings
 
 LIB_PATH = _settings.LIB_OVERRIDE or os.path.join(_HERE, 'libstove_hip.so')
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = [
     'stove_abi_version', 'stove_error_string', 'stove_selftest_wave_sum',
@@ -27,7 +27,7 @@ EXPORTS = [
     'stove_bw_transform_u8', 'stove_stream_after', 'stove_capture_begin', 'stove_capture_end', 'stove_graph_instantiate', 'stove_graph_launch', 'stove_graph_destroy',
     'stove_reward_head_param_floats', 'stove_reward_head_saved_floats', 'stove_reward_head_bwd_ws_floats', 'stove_reward_head_fwd',
     'stove_bgspn_saved_floats_d', 'stove_bgspn_fwd_d', 'stove_bgspn_bwd_ws_bytes_d', 'stove_bgspn_bwd_d', 'stove_noise_normal', 'stove_set_overlap', 'stove_event_list_begin', 'stove_event_list_end', 'stove_event_list_destroy', 'stove_fill_words',
-    'stove_reward_head_bwd', 'stove_small_linear', 'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_fwd_floats', 'stove_gauss_ll_fwd', 'stove_gauss_ll_bwd', 'stove_objspn_saved_floats_any', 'stove_objspn_bwd_ws_bytes_any', 'stove_objspn_fwd_any', 'stove_objspn_bwd_any', 'stove_scene_saved_floats_any', 'stove_scene_bwd_ws_bytes_any', 'stove_scene_fwd_any', 'stove_scene_bwd_any', 'stove_scene_bwd_from', 'stove_dynloop_range_ok', 'stove_dynloop_fwd_range', 'stove_dynloop_bwd_range', 'stove_zall_fwd_range', 'stove_zall_bwd_range',
+    'stove_reward_head_bwd', 'stove_small_linear', 'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_fwd_floats', 'stove_gauss_ll_fwd', 'stove_gauss_ll_bwd', 'stove_objspn_saved_floats_any', 'stove_objspn_bwd_ws_bytes_any', 'stove_objspn_fwd_any', 'stove_objspn_bwd_any', 'stove_scene_saved_floats_any', 'stove_scene_bwd_ws_bytes_any', 'stove_scene_fwd_any', 'stove_scene_bwd_any', 'stove_scene_bwd_from',
 ]
 
 
@@ -135,11 +135,6 @@ def _declare(lib):
         'stove_event_list_end': (I, [P]),
         'stove_event_list_destroy': (I, [P]),
         'stove_fill_words': (I, [P, ctypes.c_uint32, S, P]),
-        'stove_dynloop_range_ok': (I, [I]),
-        'stove_dynloop_fwd_range': (I, [P] * 13 + [I] * 6 + [F] * 3 + [I, I, P]),
-        'stove_dynloop_bwd_range': (I, [P] * 19 + [I] * 6 + [F] * 3 + [I, I, P, P, P]),
-        'stove_zall_fwd_range': (I, [P, P, P, I, I, I, I, I, I, P]),
-        'stove_zall_bwd_range': (I, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
         'stove_capture_begin': (I, [P]),
         'stove_capture_end': (I, [P, POINTER(c_void_p), POINTER(c_int)]),
         'stove_graph_instantiate': (I, [P, POINTER(c_void_p)]),

@@ -133,7 +133,7 @@ extern "C" {
 // 3: stove_profile_report lines carry a fourth column, the time the kernel's launches cover.
 // 4 (round 5): stove_gemm_bf16 takes nsplit = 3 (half pieces); the A/B entry points whose losing side is recorded are gone
 //    (stove_set_tablegrad_placement, stove_lstm_cell_bwd_rows).
-int stove_abi_version(void) { return 4; }
+int stove_abi_version(void) { return 5; }
 
 const char* stove_error_string(int code) { return hipGetErrorString((hipError_t)code); }
 
@@ -723,17 +723,27 @@ size_t stove_dynloop_act_floats(int B, int Ts, int N) {
   return blockwise;
 }
 
+// the recursion over the steps [ts0, ts1) (the whole range from the entry points; the kernels keep the piece interface of the
+// round-3 pipelining experiment, docs/experiments/r06_pipeline_pieces_removed.patch)
+static int dynloop_fwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+                            const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred, float* act,
+                            int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
+                            int ts0, int ts1, void* stream);
+static int dynloop_bwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+                            const float* params, const float* z, const float* act, const float* dz, const float* dzdyn,
+                            const float* dmean, const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd,
+                            float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
+                            float pos_var, float vel_std, float lat_std, int ts0, int ts1, float* carry, void* stream, void* param_stream);
 int stove_dynloop_fwd(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                       const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred, float* act,
                       int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
                       void* stream) {
-  return stove_dynloop_fwd_range(z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu,
+  return dynloop_fwd_range(z1, zsup, zsstd, eps, extra, params, z, zdyn, zdstd, mean, std_, pred, act, B, Ts, N, sin_dim, lim_enc, elu,
                                  pos_var, vel_std, lat_std, 0, Ts, stream);
 }
 
-int stove_dynloop_range_ok(int N) { return small_graph(N) ? 1 : 0; }
 
-int stove_dynloop_fwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+static int dynloop_fwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                             const float* params, float* z, float* zdyn, float* zdstd, float* mean, float* std_, float* pred, float* act,
                             int B, int Ts, int N, int sin_dim, int lim_enc, int elu, float pos_var, float vel_std, float lat_std,
                             int ts0, int ts1, void* stream) {
@@ -827,11 +837,11 @@ int stove_dynloop_bwd_overlap(const float* z1, const float* zsup, const float* z
                               const float* dmean, const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd,
                               float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
                               float pos_var, float vel_std, float lat_std, void* stream, void* param_stream) {
-  return stove_dynloop_bwd_range(z1, zsup, zsstd, eps, extra, params, z, act, dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra,
+  return dynloop_bwd_range(z1, zsup, zsstd, eps, extra, params, z, act, dz, dzdyn, dmean, dstd, dpred, dz1, dzsup, dzsstd, dextra,
                                  g_params, ws, B, Ts, N, sin_dim, lim_enc, elu, pos_var, vel_std, lat_std, 0, Ts, nullptr, stream, param_stream);
 }
 
-int stove_dynloop_bwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
+static int dynloop_bwd_range(const float* z1, const float* zsup, const float* zsstd, const float* eps, const float* extra,
                             const float* params, const float* z, const float* act, const float* dz, const float* dzdyn,
                             const float* dmean, const float* dstd, const float* dpred, float* dz1, float* dzsup, float* dzsstd,
                             float* dextra, float* g_params, void* ws, int B, int Ts, int N, int sin_dim, int lim_enc, int elu,
@@ -1397,28 +1407,6 @@ int stove_zall_bwd(const float* zfix, const float* zs, const float* g_zall, floa
   if (n == 0) return 0;
   const int M = n * T * o + n * (T - skip) * o;
   STOVE_LAUNCH(zall_bwd_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, zfix, zs, g_zall, g_zfix, g_zs, n, T, o, skip);
-  STOVE_LAUNCH_CHECK();
-  return 0;
-}
-
-int stove_zall_fwd_range(const float* zfix, const float* zs, float* zall, int n, int T, int o, int skip, int f0, int f1, void* stream) {
-  if (n == 0) return 0;
-  if (f0 < 0 || f1 > T - 1 || f0 >= f1 || skip < 1) return (int)hipErrorInvalidValue;
-  const int M = n * (f1 - f0) * o;
-  STOVE_LAUNCH(zall_fwd_range_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, zfix, zs, zall, n, T, o, skip, f0, f1);
-  STOVE_LAUNCH_CHECK();
-  return 0;
-}
-
-int stove_zall_bwd_range(const float* zfix, const float* zs, const float* g_zall, const float* dz_in, float* g_zfix, float* dz_tot,
-                         int n, int T, int o, int skip, int f0, int f1, void* stream) {
-  if (n == 0) return 0;
-  if (f0 < 0 || f1 > T - 1 || f0 >= f1 || skip < 1) return (int)hipErrorInvalidValue;
-  const int s0 = (f0 > skip - 1 ? f0 : skip - 1) - (skip - 1), s1 = f1 - (skip - 1);
-  const int M = (f0 == 0 ? n * T * o : 0) + n * (s1 > s0 ? s1 - s0 : 0) * o;
-  if (M == 0) return 0;
-  STOVE_LAUNCH(zall_bwd_range_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, zfix, zs, g_zall, dz_in, g_zfix, dz_tot, n, T, o,
-               skip, f0, f1);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

@@ -196,62 +196,6 @@ __global__ void zall_fwd_k(const float* __restrict__ zfix, const float* __restri
   zall[(size_t)i * 4 + 2] = src[2];
   zall[(size_t)i * 4 + 3] = src[3];
 }
-// The same for the frames [f0, f1) of the T-1 scored frames only (a caller that scores the clip in pieces, pipelined against the
-// recursion): zall (n, f1-f0, o, 4) dense.
-__global__ void zall_fwd_range_k(const float* __restrict__ zfix, const float* __restrict__ zs, float* __restrict__ zall, int n, int T, int o,
-                                 int skip, int f0, int f1) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int F = f1 - f0;
-  if (i >= n * F * o) return;
-  const int k = i % o, j = f0 + (i / o) % F, b = i / (o * F);
-  const float* src = (j < skip - 1) ? zfix + (((size_t)b * T + 1 + j) * o + k) * 8 : zs + (((size_t)b * (T - skip) + (j - (skip - 1))) * o + k) * 18;
-  const float sx = src[0];
-  zall[(size_t)i * 4] = sx;
-  zall[(size_t)i * 4 + 1] = sx * src[1];
-  zall[(size_t)i * 4 + 2] = src[2];
-  zall[(size_t)i * 4 + 3] = src[3];
-}
-// Backward of the piece [f0, f1): g_zall (n, f1-f0, o, 4).  For the sampled frames it writes the TOTAL gradient of z,
-// dz_tot = dz_in (from the ELBO terms; NULL = 0) + the likelihood's part, all 18 dims of the piece's steps -- the recursion's
-// backward reads dz_tot, so no separate addition pass.  The piece with f0 == 0 also writes EVERY element of g_zfix (n, T, o, 8).
-__global__ void zall_bwd_range_k(const float* __restrict__ zfix, const float* __restrict__ zs, const float* __restrict__ g_zall,
-                                 const float* __restrict__ dz_in, float* __restrict__ g_zfix, float* __restrict__ dz_tot, int n, int T, int o,
-                                 int skip, int f0, int f1) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int F = f1 - f0;
-  const int s0 = (f0 > skip - 1 ? f0 : skip - 1) - (skip - 1), s1 = f1 - (skip - 1);       // sampled steps of the piece
-  const int S = s1 > s0 ? s1 - s0 : 0;
-  const int nfix = f0 == 0 ? n * T * o : 0, nzs = n * S * o;
-  if (i < nfix) {
-    const int k = i % o, t = (i / o) % T, b = i / (o * T);
-    float g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (t >= 1 && t < skip && t - 1 < f1) {
-      const size_t a = (((size_t)b * F + (t - 1 - f0)) * o + k) * 4;
-      const float* src = zfix + (size_t)i * 8;
-      g[0] = g_zall[a] + g_zall[a + 1] * src[1];
-      g[1] = g_zall[a + 1] * src[0];
-      g[2] = g_zall[a + 2];
-      g[3] = g_zall[a + 3];
-    }
-#pragma unroll
-    for (int d = 0; d < 8; ++d) g_zfix[(size_t)i * 8 + d] = g[d];
-  } else if (i < nfix + nzs) {
-    const int q = i - nfix;
-    const int k = q % o, ts = s0 + (q / o) % S, b = q / (o * S);
-    const size_t row = ((size_t)b * (T - skip) + ts) * o + k;
-    const size_t a = (((size_t)b * F + (skip - 1 + ts - f0)) * o + k) * 4;
-    const float* src = zs + row * 18;
-    float* g = dz_tot + row * 18;
-    const float* gin = dz_in != nullptr ? dz_in + row * 18 : nullptr;
-    float v[4];
-    v[0] = g_zall[a] + g_zall[a + 1] * src[1];
-    v[1] = g_zall[a + 1] * src[0];
-    v[2] = g_zall[a + 2];
-    v[3] = g_zall[a + 3];
-#pragma unroll
-    for (int d = 0; d < 18; ++d) g[d] = (gin != nullptr ? gin[d] : 0.0f) + (d < 4 ? v[d] : 0.0f);
-  }
-}
 // writes EVERY element of g_zfix (n,T,o,8) and g_zs (n,Ts,o,18): no memset needed
 __global__ void zall_bwd_k(const float* __restrict__ zfix, const float* __restrict__ zs, const float* __restrict__ g_zall,
                            float* __restrict__ g_zfix, float* __restrict__ g_zs, int n, int T, int o, int skip) {

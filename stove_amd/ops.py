@@ -659,170 +659,6 @@ class _DynLoopFn(torch.autograd.Function):
         return (dz1, dzsup, dzsstd, None, dextra, g[:GNN_W_FLOATS], g[GNN_W_FLOATS:], None, None, None, None, None, None)
 
 
-class _InferScoreFn(torch.autograd.Function):
-    """The inference recursion (stove.py:696-713) and the image likelihood of every frame (stove.py:731-736, supair.py:44-110) as ONE
-    node, pipelined: the recursion is T-serial and latency-bound (one sequence per CU, one wave per SIMD), the likelihood of frame
-    t needs nothing but z_t.  The steps are cut into `pieces`; while the recursion runs piece i on the main stream, the likelihood
-    of piece i-1's frames runs underneath it on the 'pipe' stream (its background-SPN chain on the library's fork stream).  The
-    backward mirrors it: likelihood backward of piece i-1 underneath the recursion's backward of piece i; the SPN table gradients
-    and the recursion's weight gradients go to the side stream as before and reach the arena through the sinks.
-    Arena path only (both sinks given); the small-graph recursion kernels (stove_dynloop_range_ok)."""
-
-    @staticmethod
-    def forward(ctx, z1, zsup, zsstd, eps, extra, params, x, zfix, oc, ow, orr, bc, bw, osc, ols, bs, dense, cfg):
-        lib = _lib.load()
-        z1, zsup, zsstd, eps, extra, zfix = _f32(z1), _f32(zsup), _f32(zsstd), _f32(eps), _f32(extra), _f32(zfix)
-        tabs = [_f32(t) for t in (oc, ow, orr, bc, bw)]
-        B, Ts, N = zsup.shape[:3]
-        skip, pieces = cfg['skip'], cfg['pieces']
-        T = Ts + skip
-        sd = 16 + (extra.shape[-1] if extra is not None else 0)
-        dev = z1.device
-        x = _f32(x.reshape(B, T, -1))
-        assert x.shape[2] == 1024 and zfix.shape == (B, T, N, 8)
-        grad = any(ctx.needs_input_grad)
-        consts = [float(c) for c in cfg['consts']]
-        bounds = [(i * Ts) // pieces for i in range(pieces + 1)]
-        steps = [(a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
-        frames = [((0 if i == 0 else skip - 1 + a), skip - 1 + b) for i, (a, b) in enumerate(steps)]
-        main, pipe = torch.cuda.current_stream(dev), _side_stream(dev, 'pipe')
-        tab = _tables(obj=(osc, ols, tabs[0], tabs[1], tabs[2]), bg=(bs, tabs[3], tabs[4]), bg_dense=dense)
-        with torch.cuda.device(dev):
-            def out(d):
-                return torch.empty(B, Ts, N, d, dtype=torch.float32, device=dev)
-            z, zdyn, zdstd, mean, std = out(18), out(16), out(16), out(18), out(18)
-            pred = out(32) if cfg['want_pred'] else None
-            act = torch.empty(lib.stove_dynloop_act_floats(B, Ts, N) + 1, dtype=torch.float32, device=dev) if grad else None
-            zalls, lls, partss, saveds = [], [], [], []
-            for (f0, f1) in frames:
-                nf = B * (f1 - f0)
-                zalls.append(torch.empty(nf * N, 4, dtype=torch.float32, device=dev))
-                lls.append(torch.empty(B, f1 - f0, dtype=torch.float32, device=dev))
-                partss.append(torch.empty(B, f1 - f0, 3, dtype=torch.float32, device=dev))
-                saveds.append(torch.empty(lib.stove_scene_fwd_floats(nf, N, int(grad)) + 1, dtype=torch.float32, device=dev))
-            for i, ((a, b), (f0, f1)) in enumerate(zip(steps, frames)):
-                check(lib.stove_dynloop_fwd_range(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z), ptr(zdyn),
-                                                  ptr(zdstd), ptr(mean), ptr(std), ptr(pred), ptr(act), B, Ts, N, sd, int(cfg['lim_enc']),
-                                                  int(cfg['elu']), *consts, a, b, main.cuda_stream), 'stove_dynloop_fwd_range')
-                nf = B * (f1 - f0)
-                # z of the piece's frames on the main stream: the likelihood's object chain runs on `pipe`, its background chain on the
-                # library's fork stream, and BOTH fork from the main stream (see stove_scene_fwd_from: no fork of a fork under capture)
-                check(lib.stove_zall_fwd_range(ptr(zfix), ptr(z), ptr(zalls[i]), B, T, N, skip, f0, f1, main.cuda_stream), 'stove_zall_fwd_range')
-                check(lib.stove_stream_after(pipe.cuda_stream, main.cuda_stream), 'stove_stream_after')
-                check(lib.stove_scene_fwd_from(ctypes.byref(tab), x.data_ptr() + (1 + f0) * 1024 * 4, ptr(zalls[i]), nf, N, f1 - f0, T,
-                                               float(cfg['beta']), ptr(lls[i]), ptr(partss[i]), ptr(saveds[i]), pipe.cuda_stream,
-                                               main.cuda_stream, int(grad)), 'stove_scene_fwd_from')
-            check(lib.stove_stream_after(main.cuda_stream, pipe.cuda_stream), 'stove_stream_after')
-            ll = torch.cat(lls, 1) if len(lls) > 1 else lls[0]
-            parts = torch.cat(partss, 1) if len(partss) > 1 else partss[0]
-        ctx.save_for_backward(z1, zsup, zsstd, eps, extra, params, x, zfix, *tabs, osc, ols, bs, z, act, *zalls, *saveds)
-        ctx.cfg, ctx.steps, ctx.frames, ctx.sd = cfg, steps, frames, sd
-        ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(zdstd, parts)
-        if pred is None:
-            pred = z.new_zeros(0)
-            ctx.mark_non_differentiable(pred)
-        return z, zdyn, zdstd, mean, std, pred, ll, parts
-
-    @staticmethod
-    def backward(ctx, dz, dzdyn, _dzdstd, dmean, dstd, dpred, dll, _dparts):
-        lib = _lib.load()
-        sv = ctx.saved_tensors
-        z1, zsup, zsstd, eps, extra, params, x, zfix = sv[:8]
-        tabs = sv[8:13]
-        osc, ols, bs, z, act = sv[13:18]
-        K = len(ctx.steps)
-        zalls, saveds = sv[18:18 + K], sv[18 + K:18 + 2 * K]
-        cfg, sd = ctx.cfg, ctx.sd
-        B, Ts, N = zsup.shape[:3]
-        skip = cfg['skip']
-        T = Ts + skip
-        dev = z1.device
-        consts = [float(c) for c in cfg['consts']]
-        main, pipe, side = torch.cuda.current_stream(dev), _side_stream(dev, 'pipe'), _side_stream(dev)
-        overlap = _settings.OVERLAP
-        sp = side.cuda_stream if overlap else None
-
-        def up(g):
-            return None if g is None or g.numel() == 0 else _f32(g)
-        dz, dzdyn, dmean, dstd, dpred = up(dz), up(dzdyn), up(dmean), up(dstd), up(dpred)
-        tab = _tables(obj=(osc, ols, tabs[0], tabs[1], tabs[2]), bg=(bs, tabs[3], tabs[4]))
-        with torch.cuda.device(dev):
-            dz_tot = torch.empty_like(z)
-            g_zfix = torch.empty_like(zfix)
-            carry = torch.empty(B, N, 18, dtype=torch.float32, device=dev)
-            dz1 = torch.empty_like(z1)
-            dzsup, dzsstd = torch.empty_like(zsup), torch.empty_like(zsstd)
-            dextra = torch.empty_like(extra) if extra is not None else None
-            g = torch.empty(lib.stove_gnn_grad_floats(), dtype=torch.float32, device=dev)
-            ws = _ws(lib.stove_dynloop_bwd_ws_bytes_ts(B, Ts, N), dev)
-            if dll is None:
-                dll = torch.zeros(B, T - 1, dtype=torch.float32, device=dev)
-            dlls = [dll[:, f0:f1].contiguous() for (f0, f1) in ctx.frames]
-            check(lib.stove_stream_after(pipe.cuda_stream, main.cuda_stream), 'stove_stream_after')
-            keep = []
-
-            def scene_piece_bwd(i):
-                """likelihood backward of piece i on `pipe` (background chain on the fork stream, table gradients on the side stream)
-                and the total dz of its steps"""
-                (f0, f1) = ctx.frames[i]
-                nf = B * (f1 - f0)
-                dzall = torch.empty_like(zalls[i])
-                grads = [torch.empty_like(t) for t in tabs]
-                tg = SpnTableGrads()
-                tg.obj_coef, tg.obj_wsum, tg.obj_wroot, tg.bg_coef, tg.bg_wroot = [ptr(t) for t in grads]
-                sws = _ws(lib.stove_scene_bwd_ws_bytes(nf, N), dev)
-                check(lib.stove_scene_bwd_from(ctypes.byref(tab), x.data_ptr() + (1 + f0) * 1024 * 4, ptr(zalls[i]), nf, N, f1 - f0, T,
-                                               float(cfg['beta']), ptr(saveds[i]), ptr(dlls[i]), ptr(dzall), ctypes.byref(tg), ptr(sws),
-                                               pipe.cuda_stream, sp if sp is not None else pipe.cuda_stream, main.cuda_stream),
-                      'stove_scene_bwd_from')
-                check(lib.stove_zall_bwd_range(ptr(zfix), ptr(z), ptr(dzall), ptr(dz), ptr(g_zfix), ptr(dz_tot), B, T, N, skip, f0, f1,
-                                               pipe.cuda_stream), 'stove_zall_bwd_range')
-                if sp is not None:
-                    run_on_side(dev, lambda gr=grads: cfg['spn_sink'](gr), (sws, saveds[i], *grads), after_main=False)
-                else:
-                    prev = _lib.force_stream(pipe.cuda_stream)
-                    try:
-                        cfg['spn_sink'](grads)
-                    finally:
-                        _lib.force_stream(prev)
-                keep.extend([dzall, sws, *grads])
-            scene_piece_bwd(K - 1)
-            for i in range(K - 1, -1, -1):
-                (a, b) = ctx.steps[i]
-                check(lib.stove_stream_after(main.cuda_stream, pipe.cuda_stream), 'stove_stream_after')      # dz_tot of piece i is complete
-                if i > 0:
-                    scene_piece_bwd(i - 1)           # enqueued BEFORE the recursion piece: its chains fork from the main stream as it is now
-                check(lib.stove_dynloop_bwd_range(ptr(z1), ptr(zsup), ptr(zsstd), ptr(eps), ptr(extra), ptr(params), ptr(z), ptr(act),
-                                                  ptr(dz_tot), ptr(dzdyn), ptr(dmean), ptr(dstd), ptr(dpred), ptr(dz1), ptr(dzsup), ptr(dzsstd),
-                                                  ptr(dextra), ptr(g), ptr(ws), B, Ts, N, sd, int(cfg['lim_enc']), int(cfg['elu']), *consts,
-                                                  a, b, ptr(carry), main.cuda_stream, sp if sp is not None else main.cuda_stream),
-                      'stove_dynloop_bwd_range')
-            # g_zfix was written by piece 0's likelihood backward on `pipe`: whoever consumes it runs on the main stream
-            check(lib.stove_stream_after(main.cuda_stream, pipe.cuda_stream), 'stove_stream_after')
-            if sp is not None:
-                run_on_side(dev, lambda: cfg['gnn_sink'](g), (ws, g, act), after_main=False)
-                join_side_after_backward(dev)
-            else:
-                cfg['gnn_sink'](g)
-            for t in keep:                      # used on the pipe stream, owned by this (main-stream) scope
-                t.record_stream(pipe)
-        return (dz1, dzsup, dzsstd, None, dextra, None, None, g_zfix) + (None,) * 10
-
-
-def infer_and_score(z1, zsup, zsstd, eps, extra, image, x, zfix, obj_tabs, bg_tabs, cfg):
-    """See _InferScoreFn.  image: the prebuilt GNN parameter image; obj_tabs / bg_tabs as in scene_likelihood (bg_tabs with the dense
-    operand image); cfg: dict(lim_enc, elu, consts, want_pred, beta, skip, pieces, spn_sink, gnn_sink)."""
-    oc, ow, orr, osc, ols = obj_tabs
-    bc, bw, bs = bg_tabs[:3]
-    dense = bg_tabs[3] if len(bg_tabs) > 3 else None
-    return _InferScoreFn.apply(_sunk(z1, cfg['gnn_sink']), zsup, zsstd, eps, extra, image, x, zfix, oc, ow, orr, bc, bw, osc, ols, bs, dense, cfg)
-
-
-def dynloop_range_ok(n_obj):
-    return bool(_lib.load().stove_dynloop_range_ok(int(n_obj)))
-
-
 def _sunk(t, sink):
     """With a gradient sink the parameters are not autograd inputs: make sure the backward still runs."""
     if sink is not None and not t.requires_grad and torch.is_grad_enabled():

@@ -47,7 +47,6 @@ _DEFAULTS = dict(
     align_corners=False,     # spatial-transformer convention; False = what the runnable reference computes
     fused_dynamics=True,     # run the inference recursion in the persistent HIP time-loop kernel
     fused_state=True,        # constrain_zp / matching / fix_supair / velocities as the fused state pipeline (csrc/state.hip)
-    pipeline_pieces=1,       # > 1: the recursion in pieces with the likelihood of the frames already inferred underneath it (ops._InferScoreFn; measured SLOWER on MI355X: DESIGN.md section 7)
     fused_reward_head=True,  # action-conditioned model: the reward head as one HIP kernel each way (csrc/reward_head.hip) instead of ten library launches
     fused_elbo=True,         # log q, transition likelihood and the ELBO means in two launches
     graph_step=True,         # Trainer: replay the non-logging training steps as captured hipGraph(s) (stove_amd/graphed.py)

@@ -100,14 +100,23 @@ class Stove(nn.Module):
     def full_state(self, z_dyn, std_dyn, z_sup, std_sup):
         """q(z_t): scales from SuPAIR, (x, v) as the product of the dynamics and SuPAIR Gaussians,
         latents from the dynamics.  Returns a reparameterised sample, its log-density, mean, std."""
-        if self.c.debug_no_latents or self.c.debug_no_reuse or self.c.debug_no_velocity:
-            raise NotImplementedError('ablation switches debug_no_latents/no_reuse/no_velocity are out of scope')
         s_d, s_s = std_dyn[..., :4], std_sup[..., 2:6]
         var = s_d ** 2 + s_s ** 2
         mean_xv = (s_s ** 2 * z_dyn[..., :4] + s_d ** 2 * z_sup[..., 2:6]) / var
         std_xv = s_d * s_s / torch.sqrt(var)
-        mean = torch.cat([z_sup[..., :2], mean_xv, z_dyn[..., 4:]], -1)
-        std = torch.cat([std_sup[..., :2], std_xv, std_dyn[..., 4:]], -1)
+        c = self.c
+        if c.debug_no_latents:                  # reference stove.py:140-148: sample the six SuPAIR dimensions only, latents are zeros
+            mean = torch.cat([z_sup[..., :2], mean_xv], -1)
+            std = torch.cat([std_sup[..., :2], std_xv], -1)
+            z_s = mean + std * self._noise('step', mean.shape, mean)
+            log_q = _normal_log_prob(z_s, mean, std)
+            return torch.cat([z_s, torch.zeros_like(z_dyn[..., 4:])], -1), log_q, mean, std
+        if c.debug_no_velocity:                 # :154-160: velocities ~ N(0, 1) instead of the fused estimate
+            mean = torch.cat([z_sup[..., :2], mean_xv[..., :2], torch.zeros_like(mean_xv[..., 2:]), z_dyn[..., 4:]], -1)
+            std = torch.cat([std_sup[..., :2], std_xv[..., :2], torch.ones_like(std_xv[..., 2:]), std_dyn[..., 4:]], -1)
+        else:                                   # (debug_no_reuse, :151-153, is overwritten by the if / else behind it in the reference:
+            mean = torch.cat([z_sup[..., :2], mean_xv, z_dyn[..., 4:]], -1)       # the flag changes nothing there, and nothing here)
+            std = torch.cat([std_sup[..., :2], std_xv, std_dyn[..., 4:]], -1)
         z_s = mean + std * self._noise('step', mean.shape, mean)
         return z_s, _normal_log_prob(z_s, mean, std), mean, std
 
@@ -180,8 +189,14 @@ class Stove(nn.Module):
         n, T = x.shape[:2]
         o, skip, cl = c.num_obj, c.skip, c.cl
 
+        # [amd] the full_state ablations (reference stove.py:140-160, config.py:79,132,134) change what q(z) is made of: they run on
+        # the op-by-op chain (host time loop over the GNN step kernel, full_state and the ELBO terms in PyTorch), not in the fused
+        # recursion / ELBO kernels, which implement the default q(z)
+        ablated = bool(c.debug_no_latents or c.debug_no_velocity)
+        fused_dyn = bool(getattr(c, 'fused_dynamics', True)) and not ablated
+        fused_elbo = bool(getattr(c, 'fused_elbo', True)) and not ablated
         arena = getattr(self.dyn, '_arena', None)
-        if arena is not None and torch.is_grad_enabled() and getattr(c, 'fused_dynamics', True):
+        if arena is not None and torch.is_grad_enabled() and fused_dyn:
             arena.prefetch_images()          # parameter-only launches, off the critical path (second stream)
 
         # 1. SuPAIR states for every frame, consistent object order, smoothing, velocities.
@@ -195,7 +210,7 @@ class Stove(nn.Module):
         pooled = init_full = pooled_ev = None
         nl = n * o * (cl // 2 - 4)
         n_pool = 2 * nl + n * Ts * o * (cl // 2 + 2)
-        draw = self.noise_fn is None and getattr(c, 'fused_dynamics', True)
+        draw = self.noise_fn is None and fused_dyn
         if draw and x.is_cuda and getattr(c, 'device_noise', 'philox') == 'philox':
             pooled, pooled_ev = self._draw_ahead(n_pool, x.device)
         codes = self.sup.encoder(x.flatten(end_dim=1))
@@ -241,8 +256,7 @@ class Stove(nn.Module):
                 _ = 0.1 + 0.01 * self._noise('std', (n, o, cl // 2 - 4), z_sup)     # drawn as in the reference, unused
             init_z = torch.cat([init6, lat0], -1)
         use_app = bool(c.debug_core_appearance)
-        lik_all = None
-        if getattr(c, 'fused_dynamics', True):
+        if fused_dyn:
             extra = []
             if actions is not None:
                 emb = self.dyn.embed_actions(actions[:, skip - 1:T - 1])
@@ -255,30 +269,13 @@ class Stove(nn.Module):
             else:
                 eps = self._noise('steps', (n, Ts, o, cl // 2 + 2), z_sup)
             image, sink = self.dyn.kernel_params(0)
-            lik_all = None
-            pieces = int(getattr(c, 'pipeline_pieces', 1))
-            if (pieces > 1 and fused_state and sink is not None and arena is not None and arena.has_spn and Ts >= 2 * pieces
-                    and _settings.OVERLAP and ops.dynloop_range_ok(o) and x.is_cuda
-                    and x.dtype == torch.float32 and c.channels == 1 and tuple(x.shape[-2:]) == (32, 32)
-                    and c.patch_width == 10 and c.patch_height == 10 and not bool(getattr(c, 'align_corners', False))):
-                # [amd] recursion and image likelihood as ONE pipelined node (ops._InferScoreFn): the likelihood of the frames a
-                # piece of the recursion has produced runs underneath the next piece (forward and backward)
-                obj_tabs, bg_tabs = arena.spn_tables()
-                cfg = dict(lim_enc=2, elu=self.dyn.use_elu, consts=self.dyn.loop_consts(), want_pred=bool(c.action_conditioned),
-                           beta=c.overlap_beta, skip=skip, pieces=pieces, spn_sink=arena.spn_sink, gnn_sink=sink)
-                z_s, z_dyn_s, z_dyn_std_s, mean_s, z_std_s, pred, lik_all, parts = ops.infer_and_score(
-                    init_z, zsup_loop, zsstd_loop, eps, extra, image[0], x, zfix, obj_tabs, bg_tabs, cfg)
-                if ((self.step_counter % c.print_every == 0) or (self.step_counter % c.plot_every == 0)) and c.debug:
-                    m = parts[:, skip - 1:].mean((0, 1))
-                    self.prop_dict['bg'], self.prop_dict['patch'], self.prop_dict['overlap'] = m[0], m[1], m[2]
-            else:
-                z_s, z_dyn_s, z_dyn_std_s, mean_s, z_std_s, pred = ops.dyn_loop(
-                    init_z, zsup_loop, zsstd_loop, eps, extra, image,
-                    2, self.dyn.use_elu, self.dyn.loop_consts(), want_pred=bool(c.action_conditioned), sink=sink)
+            z_s, z_dyn_s, z_dyn_std_s, mean_s, z_std_s, pred = ops.dyn_loop(
+                init_z, zsup_loop, zsstd_loop, eps, extra, image,
+                2, self.dyn.use_elu, self.dyn.loop_consts(), want_pred=bool(c.action_conditioned), sink=sink)
             rewards = self.dyn.reward_from_pred(pred) if c.action_conditioned else torch.zeros(Ts)
         else:
             z_prev, zs, zd, zds, zm, zst, rew = init_z, [], [], [], [], [], []
-            eps_all = self._noise('steps', (n, Ts, o, cl // 2 + 2), z_sup)
+            eps_all = self._noise('steps', (n, Ts, o, 6 if c.debug_no_latents else cl // 2 + 2), z_sup)
             saved_fn = self.noise_fn
             for t in range(skip, T):
                 tmp, reward = self.dyn(z_prev[..., 2:], 0, actions[:, t - 1] if actions is not None else None,
@@ -297,22 +294,21 @@ class Stove(nn.Module):
         # 3. ELBO: image likelihood (SPNs), q(z|x) and the generative transition likelihood.
         # The reference scores frames skip..T-1 (sampled z) and frame 1..skip-1 (SuPAIR mean) in two
         # likelihood calls (stove.py:731-736); here both go through ONE fused scene launch.
-        if lik_all is None:
-            if fused_state:
-                z_all = ops.zall(zfix, z_s, n, T, o, skip)
-            else:
-                z_all = torch.cat([z_sup[:, 1:skip], z_s[..., :4]], 1)             # (n, T-1, o, 4) [sx, sy/sx, x, y]
-                z_all = self.sup.sy_from_quotient(z_all.flatten(end_dim=2))
-            lik_all, sup_prop = self.sup.likelihood(x[:, 1:], z_all, log_from=skip - 1)
-            self.prop_dict.update(sup_prop)
+        if fused_state:
+            z_all = ops.zall(zfix, z_s, n, T, o, skip)
+        else:
+            z_all = torch.cat([z_sup[:, 1:skip], z_s[..., :4]], 1)             # (n, T-1, o, 4) [sx, sy/sx, x, y]
+            z_all = self.sup.sy_from_quotient(z_all.flatten(end_dim=2))
+        lik_all, sup_prop = self.sup.likelihood(x[:, 1:], z_all, log_from=skip - 1)
+        self.prop_dict.update(sup_prop)
         lik_all = lik_all.view(n, T - 1)
-        if getattr(c, 'fused_elbo', True):
+        if fused_elbo:
             # log q(z), the transition likelihood and all the means in two launches (csrc/state.hip)
             average_elbo, stats = ops.elbo(z_s, mean_s, z_std_s, z_dyn_s, lik_all,
                                            self.dyn.transition_lik_std_host, n, T, o, skip)
             trans_mean, logq_mean = stats[0], stats[1]
         else:
-            log_z_s = _normal_log_prob(z_s, mean_s, z_std_s)
+            log_z_s = _normal_log_prob(z_s[..., :mean_s.shape[-1]], mean_s, z_std_s)          # (six dims under debug_no_latents)
             img_lik = lik_all[:, skip - 1:].reshape(-1)
             img_lik_sup = lik_all[:, :skip - 1].reshape(-1)
             log_z_f = log_z_s.sum((-2, -1)).flatten()

@@ -64,7 +64,7 @@ def ref_gap(case, *path, default=0.0):
     if case not in _GAPS:
         # only the round-1 'analytic' fixtures (g4 / g5 / g7) have no record; a missing record of any other case is a typo in the
         # case name or a fixture whose float32 run was never measured -- either would quietly put the analytic bar in force
-        if not case.endswith('_analytic') or case.startswith('g17'):
+        if not case.endswith('_analytic') or case.startswith('g17'):            # (g4 / g5 / g7 / g19 analytic: no float32 run recorded)
             raise KeyError('no float32-gap record for ' + case)
         return default
     v = _GAPS[case]

@@ -227,13 +227,14 @@ def test_stove_forward_elbo_and_grads(name, regime, fused, arena):
     full_model_against_golden(load_golden(gname(f'g7_stove_{name}', regime)), name, regime, fused, arena, f'g7_{name}_{regime}', 'stove')
 
 
-def full_model_against_golden(gold, name, regime, fused, arena, case, key):
+def full_model_against_golden(gold, name, regime, fused, arena, case, key, cfg=None):
     """Stove.forward + backward + rollout on a reference-generated full-model fixture (g7: T <= 8; g17: T = 100).  `case`: the
     fixture's record in g16_reference_fp32_gap.json; `key`: prefix of the recorded parity errors."""
     from stove_amd.arena import ParamArena
     from stove_amd.video_prediction.stove import Stove
+    cfg = CASES[name] if cfg is None else cfg
     # fused=False: host time loop, PyTorch state chain and PyTorch ELBO assembly (the op-by-op restatement)
-    st = fill_analytic(Stove(make_cfg(fused_dynamics=fused, fused_state=fused, fused_elbo=fused, **CASES[name])), '', regime).to(DEV)
+    st = fill_analytic(Stove(make_cfg(fused_dynamics=fused, fused_state=fused, fused_elbo=fused, **cfg)), '', regime).to(DEV)
     if arena:
         ar = ParamArena(st)
         assert ar.has_spn and ar.has_gnn
@@ -249,12 +250,12 @@ def full_model_against_golden(gold, name, regime, fused, arena, case, key):
         # same codes (helpers.reference_at_codes: the oracle, pinned to the reference on this very fixture) with the tight bars;
         # against the fixture itself the forward quantities keep the regime bars below.
         from stove_amd.utils.utils import bw_transform
-        c_o, structs_o, params_o = oracle_setup(torch.float64, requires_grad=False, regime=regime, **CASES[name])
+        c_o, structs_o, params_o = oracle_setup(torch.float64, requires_grad=False, regime=regime, **cfg)
         with torch.no_grad():
             codes = st.sup.encoder(bw_transform(x).flatten(end_dim=1))
             codes_ref = O.encoder_forward(c_o, params_o, O.bw_transform(t_(gold['x'])).flatten(0, 1))
         check('encoder.codes.stress', err(codes, codes_ref), 5e-6)          # achieved 1.6e-6 (fp32 library GEMMs: 1.1e-6)
-        gold_at_codes = reference_at_codes(gold, regime, CASES[name], codes)
+        gold_at_codes = reference_at_codes(gold, regime, cfg, codes)
     # Bars: the 'analytic' ones (pinned at ~3x what the kernels achieve there) or, in the other regimes, 6x the REFERENCE's own
     # float32-vs-float64 gap on the same fixture (tests/golden/g16_reference_fp32_gap.json) where that is larger: a saturated model
     # amplifies float32 rounding (z of the 'stress' fixtures: 1.2e-5 in the reference's own float32 run).  The ELBO bar stays.
@@ -533,9 +534,7 @@ def test_small_graph_recursion_matches_step_kernels(n_obj, ac, nonlinear):
     run two node rows per wave and two tiles of edge columns).  N = 7, 8: the workgroup-wide MFMA loops of csrc/gnn.hip
     (dyn_loop_fwd_k / dyn_loop_bwd_k / rollout_fwd_k), which no BASELINE configuration reaches since six objects moved to the
     small-graph path -- this test is what keeps them honest.  `ac`: action-conditioned, 23 inputs per node and the reward head."""
-    from stove_amd import _lib
     from stove_amd.video_prediction.stove import Stove
-    assert _lib.load().stove_dynloop_range_ok(n_obj) == int(n_obj <= 6)          # the kernels under test are the ones that run
     n, T = 3, 6
     g = torch.Generator(device='cpu').manual_seed(11)
     x = (torch.rand(n, T, 3, 32, 32, generator=g) < 0.04).float().to(DEV)
@@ -650,3 +649,54 @@ def test_encoder_gemm_variants_elbo_delta(mode, bar):
     elbo, prop, _ = st(t_(gold['x']).float().to(DEV), 0, None)
     check('stove.elbo_rel_encoder_' + mode, abs(float(elbo) - float(gold['elbo'])) / abs(float(gold['elbo'])), bar)
     check('stove.z_sup_encoder_' + mode, err(prop['z_sup'], gold['p_z_sup']), 5e-4 if mode == 'bf16' else 3e-6)
+
+
+@pytest.mark.parametrize('n_obj', [3, 6])
+def test_recursion_forward_chains_domain_large_activations_small_weights(n_obj):
+    """The forward edge chains of the small-graph recursion kernels (csrc/gnn_small.hip sm_split_layer_tiles: relation / attention
+    layers 2 and 3 as three v_mfma_f32_16x16x32_f16 on IEEE-half hi / lo pieces) at the edge of their stated domain (stove_hip.h,
+    stove_dynloop_fwd / stove_rollout_fwd): first-layer weights x 300 drive the chains' input activations to O(10^3), second-layer
+    weights x 1/300 put every lo piece of a weight into half's subnormals.  Inside the domain (|activation| < 65 504) the 12-step
+    rollout stays within 2e-5 of the float64 oracle (2e-6 at ordinary magnitudes: the subnormal lo pieces keep 2^-25 absolute, not
+    2^-22 relative); beyond it the documented failure is inf / NaN, not a silently wrong number."""
+    from stove_amd.video_prediction.stove import Stove
+    kw = dict(num_obj=n_obj, debug_match_objects='3_only' if n_obj == 3 else 'greedy')
+    c, structs, params = oracle_setup(torch.float64, requires_grad=False, **kw)
+    st = fill_analytic(Stove(make_cfg(**kw)))
+    scale = {'dyn.rel_cores.0.0.weight': 300.0, 'dyn.rel_cores.0.0.bias': 300.0, 'dyn.att_net.0.0.weight': 300.0, 'dyn.att_net.0.0.bias': 300.0,
+             'dyn.rel_cores.0.1.weight': 1.0 / 300.0, 'dyn.att_net.0.1.weight': 1.0 / 300.0}
+    named = dict(st.named_parameters())
+    with torch.no_grad():
+        for k, f in scale.items():
+            named[k].mul_(f)
+            params[k] = params[k] * f
+    st = st.to(DEV)
+    g = torch.Generator().manual_seed(n_obj)
+    z_last = torch.cat([torch.rand(5, n_obj, 2, generator=g) * 0.3 + 0.2, torch.rand(5, n_obj, 16, generator=g) * 1.6 - 0.8], -1)
+    with torch.no_grad():
+        zo, _ = O.rollout(c, params, z_last.double(), 12)
+        # the chains' inputs really are large: first relation layer of the oracle on the first state
+        s0 = z_last[..., 2:].double()
+        zp, _ = st.rollout(z_last.to(DEV), num=12)
+    assert torch.isfinite(zp).all()
+    check('dyn_loop.domain_edge.rollout_z', err(zp, zo), 2e-5)
+    # beyond the domain: activations past half's range overflow to inf in the pieces; the kernel must not return finite garbage
+    with torch.no_grad():
+        for k in ('dyn.rel_cores.0.0.weight', 'dyn.rel_cores.0.0.bias'):
+            named[k].mul_(1e4)
+        zbad, _ = st.rollout(z_last.to(DEV), num=2)
+    assert not torch.isfinite(zbad).all()
+
+
+ABLATIONS = {'novel': dict(num_obj=3, debug_no_velocity=True), 'nolat': dict(num_obj=3, debug_no_latents=True),
+             'noreuse': dict(num_obj=3, debug_no_reuse=True)}
+
+
+@pytest.mark.parametrize('name', list(ABLATIONS))
+@pytest.mark.parametrize('arena', [False, True])
+def test_stove_forward_full_state_ablations(name, arena):
+    """config.debug_no_velocity / debug_no_latents / debug_no_reuse (reference stove.py:140-160) against the reference's own runs (g19):
+    ELBO, every prop_dict entry, gradients, rollout.  The first two run q(z) on the op-by-op chain (the GNN step kernel in a host time
+    loop), the third is the default model (the reference overwrites what the flag sets) and stays on the fused recursion."""
+    gold = load_golden(f'g19_stove_{name}_f64')
+    full_model_against_golden(gold, name, 'analytic', True, arena, f'g19_{name}_analytic', 'stove_ablation', ABLATIONS[name])

@@ -205,9 +205,29 @@ def test_stove_forward_full_length(name, regime):
     _full_model_against(g, name, regime, torch.float64)
 
 
-def _full_model_against(g, name, regime, dtype):
+ABLATIONS = {          # full_state ablations (stove.py:140-160): g19
+    'novel': dict(num_obj=3, debug_no_velocity=True),
+    'nolat': dict(num_obj=3, debug_no_latents=True),
+    'noreuse': dict(num_obj=3, debug_no_reuse=True),
+}
+
+
+@pytest.mark.parametrize('name', list(ABLATIONS))
+def test_stove_forward_ablations(name):
+    g = load_golden(f'g19_stove_{name}_f64')
+    assert g['eps_steps'].shape[-1] == (6 if name == 'nolat' else 18)
+    _full_model_against(g, name, 'analytic', torch.float64, ABLATIONS[name])
+    if name == 'noreuse':          # the reference's full_state overwrites what debug_no_reuse sets (stove.py:151-163): the default model
+        c, structs, params = oracle_setup(torch.float64, num_obj=3)
+        eps = {'latent': t_(g['eps_lat']), 'std': t_(g['eps_std']), 'steps': [t_(e) for e in g['eps_steps']]}
+        elbo, _ = O.stove_forward(c, params, structs, t_(g['x']), eps)
+        assert abs(float(elbo) - float(g['elbo'])) < 1e-9 * abs(float(g['elbo']))
+
+
+def _full_model_against(g, name, regime, dtype, cfg=None):
     tol = 1e-9 if dtype == torch.float64 else 1e-4
-    c, structs, params = oracle_setup(dtype, regime=regime, **CASES[name])
+    cfg = CASES[name] if cfg is None else cfg
+    c, structs, params = oracle_setup(dtype, regime=regime, **cfg)
     x = t_(g['x'], dtype)
     eps = {'latent': t_(g['eps_lat'], dtype), 'std': t_(g['eps_std'], dtype),
            'steps': [t_(e, dtype) for e in g['eps_steps']]}
