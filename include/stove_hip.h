@@ -451,7 +451,8 @@ int stove_flat_adam(float* params, const float* grads, float* exp_avg, float* ex
  * 64 x 128; needs 136 KB of LDS: one workgroup per CU).
  * Operands / outputs whose leading dimension, contiguous extent or base address is not a multiple of 4 floats (fc1 of the
  * recognition network: 50 columns) are handled element-wise (slow path, meant for small operands); split-K needs an aligned C and
- * takes no add, except add == C: the product is accumulated into C (a gradient view); a bias is allowed with 2..15 slices (added by
+ * takes no add, except add == C (the product is accumulated into C, a gradient view) or, with 2..15 slices, a dense 16-byte aligned
+ * M x N add term (added by the slice sum); a bias is allowed with 2..15 slices (added by
  * the slice sum). */
 size_t stove_gemm_bf16_ws_floats(int M, int N, int splitk);
 int stove_gemm_bf16(const float* A, const float* B, const float* bias, const float* add, float* C, int M, int N, int K, int lda, int ldb, int ldc,

@@ -252,12 +252,17 @@ __global__ void adam_tick_k(const unsigned char* __restrict__ trainable, float* 
 }
 
 // out[j] = sum_c part[c][j], fixed order; n4 = n / 4 (split-K partials of the batched weight-gradient GEMMs)
-// bias4 / cols4: a row bias (cols4 float4 per output row) added to the sum -- the epilogue of a split-K GEMM
+// bias4 / cols4: a row bias (cols4 float4 per output row) added to the sum; add4: an element-wise term (same shape as out, another
+// tensor) -- the epilogue terms of a split-K GEMM
 __global__ void sum_chunks4_k(const float* __restrict__ part, float* __restrict__ out, int n4, int chunks, int accumulate = 0,
-                              const float* __restrict__ bias4 = nullptr, int cols4 = 0) {
+                              const float* __restrict__ bias4 = nullptr, int cols4 = 0, const float* __restrict__ add4 = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   float4 a = reinterpret_cast<const float4*>(part)[i];
+  if (add4 != nullptr) {
+    const float4 b = reinterpret_cast<const float4*>(add4)[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
   if (bias4 != nullptr) {
     const float4 b = reinterpret_cast<const float4*>(bias4)[i % cols4];
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;

@@ -340,6 +340,7 @@ static SceneWs scene_ws_layout(int nf, int n_obj) {
 
 size_t stove_scene_bwd_ws_bytes(int n_frames, int n_obj) { return scene_ws_layout(n_frames, n_obj).total * sizeof(float); }
 
+constexpr int kLateTableGradGlimpses = 16384;
 // Where the object-SPN table gradients run when the caller gives a parameter stream: with up to four objects they are held back
 // until dz is out and then run underneath the recursion's backward as objspn_tablegrad_under_k (one wave per SIMD in the registers
 // and LDS that kernel leaves free).  Measured in round 2 (B = 256): the SPN backward phase 600 -> 495 us without them, the
@@ -396,7 +397,10 @@ int stove_scene_bwd_from(const StoveSpnTables* t, const float* frames, const flo
   // 512 registers (hipcc -Rpass-analysis=kernel-resource-usage, round 5), so nothing wider than 64 registers can run beside it --
   // the 150-register table-gradient kernel would queue up behind it instead of under it -- and the seven / eight-object recursion
   // (gnn.hip) fills the matrix pipe itself (stretched 2.49 -> 3.20 ms by a co-runner, round 2)
-  const bool late = sp != st && n_obj <= 4;
+  // ... and for a batch large enough that the recursion's backward is long (98 steps): at the reference's default training shape
+  // (256 clips x 8 frames: 6 912 glimpses, a 35 us recursion) the held-back table gradients would be the head of a 260 us chain of
+  // small launches on the parameter stream that outlasts the main stream by 110 us -- there they start at once, beside the data half
+  const bool late = sp != st && n_obj <= 4 && np >= kLateTableGradGlimpses;
   if (!late) {
     STOVE_TRY(stream_after(sp, st));
     rc = objspn_backward_params(saved + L.xw, t->obj_scope, g->obj_coef, g->obj_wsum, g->obj_wroot, saved + L.obj_scratch, ws + W.obj,
@@ -1036,6 +1040,9 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
   // split-K: no epilogue terms, except add == C (accumulate into C, e.g. a gradient view), applied by the slice sum
   const bool acc_c = splitk > 1 && add != nullptr && add == C;
   if (acc_c) add = nullptr;
+  // ... or a dense (M x N, float4-addressable) add term of fewer than 16 slices: added by the slice sum, like the bias
+  const float* sum_add = (splitk > 1 && splitk < 16 && add != nullptr && (((uintptr_t)add & 15) == 0)) ? add : nullptr;
+  if (sum_add != nullptr) add = nullptr;
   const float* sum_bias = splitk > 1 ? bias : nullptr;      // split-K: the bias is added by the slice sum (fewer than 16 slices)
   if (splitk > 1 && splitk < 16) bias = nullptr;
   if (splitk > 1 && (ws == nullptr || bias != nullptr || add != nullptr || ldc != N || (scalar_bits & 4))) return (int)hipErrorInvalidValue;
@@ -1084,7 +1091,7 @@ int stove_gemm_bf16(const float* A, const float* B, const float* bias, const flo
     if (splitk >= 16)
       STOVE_LAUNCH(sum_chunks4_par_k, dim3((n4 + 63) / 64), dim3(256), 0, st, (const float*)ws, C, n4, splitk, acc_c ? 1 : 0);
     else
-      STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, st, (const float*)ws, C, n4, splitk, acc_c ? 1 : 0, sum_bias, N / 4);
+      STOVE_LAUNCH(sum_chunks4_k, dim3((n4 + 255) / 256), dim3(256), 0, st, (const float*)ws, C, n4, splitk, acc_c ? 1 : 0, sum_bias, N / 4, sum_add);
     STOVE_LAUNCH_CHECK();
   }
   return 0;

@@ -1158,6 +1158,10 @@ class _blas:
         return False
 
 
+# rows below which the recurrent products of the recognition network leave the 256 x 256 tile, and the tile they take then
+SMALL_M_ROWS = 4096
+SMALL_M_TILE = 2
+
 # gate activations of the LSTM cell kernels on v_exp_f32 / v_rcp_f32 (absolute error ~1e-7; 0: IEEE division + ocml tanhf)
 FAST_CELL = 1
 
@@ -1258,7 +1262,9 @@ class _EncoderLstmFn(torch.autograd.Function):
                 if k > 0 and ns:
                     # K = 256 (8 k-steps): the 128 x 128 tile (1600 workgroups) beats 256 x 128; the 256 x 256 tile is level with it
                     # warm and 5 % ahead from cold caches
-                    gs = gemm_bf16(hs[k - 1], w_hh, nsplit=ns, splitk=1, add=gx, tile=3 if (4 * H) % 256 == 0 else 2)
+                    # (fewer than 4 096 rows -- the reference's default training shape has 2 048 -- are 32 workgroups of the wide tile:
+                    # the 128 x 128 tile gives every second CU one)
+                    gs = gemm_bf16(hs[k - 1], w_hh, nsplit=ns, splitk=1, add=gx, tile=3 if ((4 * H) % 256 == 0 and n >= SMALL_M_ROWS) else SMALL_M_TILE)
                 elif k > 0:
                     with _blas('hipblas'):
                         gs = torch.addmm(gx, hs[k - 1], w_hh.t())
@@ -1391,8 +1397,8 @@ def gemm_bf16(a, b, bias=None, a_kmajor=False, b_kmajor=False, nsplit=2, splitk=
             sk *= 2
         if sk > 1 and not (bias is not None and add is not None):
             splitk = sk
-            if add is not None:
-                out, add = _f32(add).clone(), None
+            if add is not None and not (add.is_contiguous() and tuple(add.shape) == (M, N) and add.dtype == torch.float32 and add.data_ptr() % 16 == 0):
+                out, add = _f32(add).clone(), None          # (a dense add term rides the slice sum; anything else becomes C's initial value)
     lib = _lib.load()
     if out is not None:
         if add is not None or bias is not None or out.shape != (M, N) or not out.is_contiguous() or out.dtype != torch.float32:
