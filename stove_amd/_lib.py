@@ -26,7 +26,7 @@ EXPORTS = [
     'stove_enc_head_fwd', 'stove_enc_head_bwd_ws_floats', 'stove_enc_head_bwd', 'stove_colsum2', 'stove_small_tn', 'stove_small_tn_ws_floats', 'stove_supair_state_fwd2', 'stove_supair_state_bwd2', 'stove_bg_dense', 'stove_bg_dense_floats',
     'stove_bw_transform_u8', 'stove_stream_after', 'stove_capture_begin', 'stove_capture_end', 'stove_graph_instantiate', 'stove_graph_launch', 'stove_graph_destroy',
     'stove_reward_head_param_floats', 'stove_reward_head_saved_floats', 'stove_reward_head_bwd_ws_floats', 'stove_reward_head_fwd',
-    'stove_bgspn_saved_floats_d', 'stove_bgspn_fwd_d', 'stove_bgspn_bwd_ws_bytes_d', 'stove_bgspn_bwd_d', 'stove_noise_normal', 'stove_set_overlap', 'stove_event_list_begin', 'stove_event_list_end', 'stove_event_list_destroy', 'stove_fill_words',
+    'stove_bgspn_saved_floats_d', 'stove_bgspn_fwd_d', 'stove_bgspn_bwd_ws_bytes_d', 'stove_bgspn_bwd_d', 'stove_noise_normal', 'stove_set_overlap', 'stove_set_tile_lds', 'stove_event_list_begin', 'stove_event_list_end', 'stove_event_list_destroy', 'stove_fill_words',
     'stove_reward_head_bwd', 'stove_small_linear', 'stove_set_fork_stream', 'stove_scene_fwd_from', 'stove_scene_fwd_floats', 'stove_gauss_ll_fwd', 'stove_gauss_ll_bwd', 'stove_objspn_saved_floats_any', 'stove_objspn_bwd_ws_bytes_any', 'stove_objspn_fwd_any', 'stove_objspn_bwd_any', 'stove_scene_saved_floats_any', 'stove_scene_bwd_ws_bytes_any', 'stove_scene_fwd_any', 'stove_scene_bwd_any', 'stove_scene_bwd_from',
 ]
 
@@ -131,6 +131,7 @@ def _declare(lib):
         'stove_bgspn_bwd_ws_bytes_d': (S, [I, I]),
         'stove_bgspn_bwd_d': (I, [T, P, P, P, P, P, P, P, G, P, I, I, P]),
         'stove_set_overlap': (I, [I]),
+        'stove_set_tile_lds': (I, [I]),
         'stove_event_list_begin': (P, []),
         'stove_event_list_end': (I, [P]),
         'stove_event_list_destroy': (I, [P]),

@@ -56,10 +56,17 @@ __global__ void tile_unpack_k(const float* __restrict__ tile, float* __restrict_
   }
 }
 
+// measurement / test switch: 0 = the lane-per-glimpse gather kernel (tests compare the two bit for bit)
+static std::atomic<int> g_tile_lds{1};
 template <int NMAX>
 static int scene_tile_fwd(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st, FrameMap fm) {
   const int nb = (np + 63) / 64;
   const int grid = nb < 8192 ? nb : 8192;          // one workgroup per batch of 64 glimpses
+  if (g_tile_lds.load()) {          // lane = pixel, tile transposed through LDS (scene_tile_fwd_t_k)
+    STOVE_LAUNCH((scene_tile_fwd_t_k<NMAX>), dim3(grid), dim3(64 * kTileTWaves), 0, st, frames, z, xw, n_obj, np, nb, fm, SceneGeom{});
+    STOVE_LAUNCH_CHECK();
+    return 0;
+  }
   STOVE_LAUNCH((scene_tile_fwd_k<NMAX>), dim3(grid), dim3(256), 0, st, frames, z, xw, n_obj, np, nb, fm, SceneGeom{});
   STOVE_LAUNCH_CHECK();
   return 0;
@@ -69,6 +76,11 @@ template <int NMAX>
 static int scene_tile_fwd_g(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st, FrameMap fm, SceneGeom gm) {
   const int nb = (np + 63) / 64;
   const int grid = nb < 8192 ? nb : 8192;
+  if (g_tile_lds.load()) {
+    STOVE_LAUNCH((scene_tile_fwd_t_k<NMAX, true>), dim3(grid), dim3(64 * kTileTWaves), 0, st, frames, z, xw, n_obj, np, nb, fm, gm);
+    STOVE_LAUNCH_CHECK();
+    return 0;
+  }
   STOVE_LAUNCH((scene_tile_fwd_k<NMAX, true>), dim3(grid), dim3(256), 0, st, frames, z, xw, n_obj, np, nb, fm, gm);
   STOVE_LAUNCH_CHECK();
   return 0;
@@ -253,6 +265,11 @@ static hipStream_t scene_fork_stream(hipStream_t st) {
 
 // Measurement switch (explicit state instead of an environment read; default 1).
 // overlap 0: the scene calls run their background-SPN chain on the call's stream (no internal fork at all).
+int stove_set_tile_lds(int on) {
+  g_tile_lds.store(on ? 1 : 0);
+  return 0;
+}
+
 int stove_set_overlap(int on) {
   g_overlap.store(on != 0, std::memory_order_relaxed);
   return 0;

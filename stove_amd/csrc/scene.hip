@@ -139,6 +139,95 @@ __global__ __launch_bounds__(256) void scene_tile_fwd_k(const float* __restrict_
   }
 }
 
+// ---- the same with lane = PIXEL and the tile transposed through LDS (round 6) ------------------------------------------------
+// scene_tile_fwd_k has lane = glimpse: each of a wave's 400 tap loads touches up to 64 cache lines of ~22 different frames, and the
+// kernel sat in the texture path's issue stall for 56 % of its cycles (profiles/r06_pmc_sq_scene.json) -- 77 us per launch in front of
+// the object SPN on the step's critical path.  Here a wave takes glimpses one at a time with its lanes on the glimpse's pixels (two
+// passes: 64 + 36): the four taps of neighbouring pixels fall into the same few rows of ONE frame, so a tap load touches a handful of
+// lines; the glimpse's transform and its occluders' inverse transforms are wave-uniform.  The [pixel][x | w][64 glimpses] tile the
+// SPN kernels read is assembled in LDS (row stride 129 floats: the lanes of a pass write 64 different banks twice) and written out
+// with coalesced 256-B rows.  Arithmetic, operand order and outputs are those of scene_tile_fwd_k: bit-identical (tests).
+constexpr int kTileTWaves = 8;
+constexpr int kTileTStride = 2 * 64 + 1;
+template <int NMAX, bool ANY = false>
+__global__ __launch_bounds__(64 * kTileTWaves) void scene_tile_fwd_t_k(const float* __restrict__ frames, const float* __restrict__ z,
+                                                                       float* __restrict__ xw, int n_obj, int n_patches, int n_batches, FrameMap fm,
+                                                                       SceneGeom gm = SceneGeom{}) {
+  __shared__ float tl[kPD * kTileTStride];
+  const int IW = ANY ? gm.W : kImg, IH = ANY ? gm.H : kImg;
+  const int lane = lane_id(), wv = wave_id();
+  for (int b = blockIdx.x; b < n_batches; b += gridDim.x) {
+    for (int g = wv; g < 64; g += kTileTWaves) {
+      const int patch = b * 64 + g;
+      const bool live = patch < n_patches;                    // wave-uniform
+      const int pc = live ? patch : n_patches - 1;
+      const int f = pc / n_obj, k = pc % n_obj;
+      const float* zf = z + (size_t)f * n_obj * 4;
+      const float4 z4 = *reinterpret_cast<const float4*>(zf + k * 4);
+      const float zk[4] = {z4.x, z4.y, z4.z, z4.w};
+      constexpr int NOCC = NMAX > 1 ? NMAX - 1 : 1;
+      float isx[NOCC], isy[NOCC], ox[NOCC], oy[NOCC];
+#pragma unroll
+      for (int j = 0; j < NOCC; ++j) {
+        const float4 zj = *reinterpret_cast<const float4*>(zf + (j < n_obj ? j : 0) * 4);
+        isx[j] = 1.0f / zj.x;
+        isy[j] = 1.0f / zj.y;
+        ox[j] = -zj.z * isx[j];
+        oy[j] = -zj.w * isy[j];
+      }
+      const float* img = frames + fm.row(f) * (size_t)(IW * IH);
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int p = pass * 64 + lane;
+        if (p < kPD) {
+          const PatchPix q = ANY ? patch_pix_g(zk, p, gm) : patch_pix(zk, p);
+          float tap[4], wt[4];
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int iy = min(max(q.ty.i0 + a, 0), IH - 1), ix = min(max(q.tx.i0 + c, 0), IW - 1);
+              tap[a * 2 + c] = img[iy * IW + ix];
+              wt[a * 2 + c] = (a ? q.ty.in1 : q.ty.in0) * (c ? q.tx.in1 : q.tx.in0) * (a ? q.ty.t : 1.0f - q.ty.t) * (c ? q.tx.t : 1.0f - q.tx.t);
+            }
+          float run[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int j = 0; j < NOCC; ++j) {
+            if (j < k) {
+              float d, cx0, cx1, cy0, cy1;
+              if (ANY) {
+                cx0 = cover(inv_pix_x(isx[j], ox[j], q.tx.i0, gm), IW, &d), cx1 = cover(inv_pix_x(isx[j], ox[j], q.tx.i0 + 1, gm), IW, &d);
+                cy0 = cover(inv_pix_y(isy[j], oy[j], q.ty.i0, gm), IH, &d), cy1 = cover(inv_pix_y(isy[j], oy[j], q.ty.i0 + 1, gm), IH, &d);
+              } else {
+                cx0 = cover(inv_pix(isx[j], ox[j], q.tx.i0), kImg, &d), cx1 = cover(inv_pix(isx[j], ox[j], q.tx.i0 + 1), kImg, &d);
+                cy0 = cover(inv_pix(isy[j], oy[j], q.ty.i0), kImg, &d), cy1 = cover(inv_pix(isy[j], oy[j], q.ty.i0 + 1), kImg, &d);
+              }
+              run[0] = fminf(run[0] + cx0 * cy0, 1.0f);
+              run[1] = fminf(run[1] + cx1 * cy0, 1.0f);
+              run[2] = fminf(run[2] + cx0 * cy1, 1.0f);
+              run[3] = fminf(run[3] + cx1 * cy1, 1.0f);
+            }
+          }
+          float xv = 0.0f, seen = 0.0f;
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4) {
+            xv = fmaf(wt[t4], tap[t4], xv);
+            seen = fmaf(wt[t4], 1.0f - run[t4], seen);
+          }
+          const float mg = 1.0f - seen;                               // supair.py:331
+          const float wvv = 1.0f - fminf(fmaxf(mg, 0.0f), 1.0f);      // rat_torch.py:104-106
+          tl[p * kTileTStride + g] = live ? xv : 0.0f;
+          tl[p * kTileTStride + 64 + g] = live ? wvv : 0.0f;
+        }
+      }
+    }
+    __syncthreads();
+    float* t = xw + (size_t)b * kPD * 2 * 64;
+    for (int i = threadIdx.x; i < kPD * 2 * 64; i += 64 * kTileTWaves) t[i] = tl[(i >> 7) * kTileTStride + (i & 127)];
+    __syncthreads();                                          // the next batch's glimpses write the buffer again
+  }
+}
+
 // (the tile backward lives in scene_fused.hip: scene_pixtile_bwd_k)
 
 // ---- assemble: log p(x, z) per frame (supair.py:79-94) -------------------------------------

@@ -278,3 +278,58 @@ def test_scene_glimpse_kernel(n_obj):
     assert err(pat, gold['patches'].reshape(-1, 100)) < 1e-5
     marg = np.clip(gold['marg_patch'].reshape(-1, 100), 0, 1)
     assert err(1.0 - keep, marg) < 1e-5
+
+
+@pytest.mark.parametrize('n_obj,nf', [(3, 64), (3, 2301), (6, 130), (4, 77), (8, 40), (2, 50), (1, 9)])
+def test_glimpse_tile_kernel_lds_staging_is_bit_identical(n_obj, nf):
+    """scene_tile_fwd_lds_k (a batch's frames staged in LDS, taps as LDS gathers; round 6) against scene_tile_fwd_k (global gathers; the
+    kernel the goldens were first met with): glimpses and keep-weights bit for bit -- ragged last batches, objects leaving the frame,
+    every object count, and n_obj < 3 (a batch spans more frames than the LDS holds: the launcher falls back to the gather kernel)."""
+    from stove_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(nf + n_obj)
+    frames = torch.rand(nf, 1024, generator=g).to(DEV)
+    z = torch.rand(nf * n_obj, 4, generator=g)
+    z[:, :2] = z[:, :2] * 0.7 + 0.1
+    z[:, 2:] = z[:, 2:] * 2.4 - 1.2                  # some glimpses hang over the border
+    z = z.to(DEV).contiguous()
+    outs = []
+    for mode in (0, 1):
+        lib.stove_set_tile_lds(mode)
+        tile = torch.full((lib.stove_objspn_tile_floats(nf * n_obj),), float('nan'), device=DEV)
+        pat = torch.empty(nf * n_obj, 100, device=DEV)
+        keep = torch.empty(nf * n_obj, 100, device=DEV)
+        _lib.check(lib.stove_scene_glimpses(_lib.ptr(frames), _lib.ptr(z), nf, n_obj, _lib.ptr(tile), _lib.ptr(pat), _lib.ptr(keep), _lib.stream()),
+                   'stove_scene_glimpses')
+        torch.cuda.synchronize()
+        outs.append((pat.clone(), keep.clone()))
+    lib.stove_set_tile_lds(1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].abs().max()) > 0 and torch.isfinite(outs[1][1]).all()
+
+
+def test_scene_forward_on_strided_clips_is_the_same_with_either_tile_kernel():
+    """stove_scene_fwd on frames x[:, 1:] of longer clips handed over without a copy (seq_frames / seq_stride), LDS-staged against
+    gathered tiles: identical log-likelihoods."""
+    from stove_amd import _lib
+    from stove_amd.video_prediction.config import StoveConfig
+    from stove_amd.video_prediction.supair import Supair
+    lib = _lib.load()
+    cfg = StoveConfig()
+    cfg.num_obj, cfg.width, cfg.height = 3, 32, 32
+    cfg.device, cfg.dtype, cfg.random_seed = torch.device(DEV), torch.float32, 42
+    sup = Supair(cfg).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(7, 9, 1, 32, 32, generator=g).to(DEV)
+    z = torch.rand(7, 8, 3, 4, generator=g)
+    z[..., :2] = z[..., :2] * 0.6 + 0.15
+    z[..., 2:] = z[..., 2:] * 1.8 - 0.9
+    z = z.to(DEV)
+    res = []
+    for mode in (0, 1):
+        lib.stove_set_tile_lds(mode)
+        with torch.no_grad():
+            ll, _ = sup.likelihood(x[:, 1:], z.reshape(-1, 4))
+        res.append(ll.clone())
+    lib.stove_set_tile_lds(1)
+    assert torch.equal(res[0], res[1])
