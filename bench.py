@@ -65,7 +65,7 @@ def parse():
                         "frames, bw_transform inside every step -- the reference's own step; bw32 = the bw plane made once at upload (the "
                         "Trainer's 'auto' choice for models that only consume bw frames; reported under variants); u8 = 8-bit colour frames")
     p.add_argument('--enc-chunks', type=int, default=0, help='row chunks of the recognition network\'s forward chain (0 = the default, 2; 1 = the chain on one stream: a profiling aid)')
-    p.add_argument('--tile-gather', action='store_true', help='A/B: the glimpse-tile kernel of the scene forward with global gathers (stove_set_tile_lds(0)) instead of LDS-staged frames')
+    p.add_argument('--tile-gather', action='store_true', help='A/B: the glimpse-tile kernel of the scene forward with one lane per glimpse (stove_set_tile_lds(0)) whatever the object count')
     p.add_argument('--step-mode', default='graph', choices=['graph', 'eager'],
                    help='graph (default): the step replayed as captured hipGraph(s), as Trainer.train runs its non-logging steps '
                         '(stove_amd/graphed.py); eager: every launch enqueued by the host (reported as a variant)')

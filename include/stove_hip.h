@@ -374,9 +374,10 @@ int stove_sum_chunks(const float* parts, float* out, size_t n, int chunks, void*
 int stove_set_fork_stream(int device, void* stream, int restore_default);
 /* on = 0: no internal fork stream, every chain of a scene call on the call's stream (default 1). */
 int stove_set_overlap(int on);
-/* process state, test / measurement switch: 0 = the glimpse-tile kernel of the scene forward with one lane per glimpse (the round-5
- * kernel); 1 (default) = one lane per glimpse PIXEL, the tile transposed through LDS.  Same numbers bit for bit. */
-int stove_set_tile_lds(int on);
+/* process state, test / measurement switch: which glimpse-tile kernel the scene forward runs -- 1 (default): one lane per glimpse PIXEL with
+ * the tile transposed through LDS for up to three objects, one lane per glimpse (the round-5 kernel) beyond; 0: lane per glimpse always;
+ * 2: lane per pixel always.  Same numbers bit for bit. */
+int stove_set_tile_lds(int mode);
 /* ---- stream ordering and graph replay (no reference counterpart: the reference enqueues ~6000 ATen launches per step from Python,
  * train.py:443-473; here a step is ~70 launches that a trainer replays as captured hipGraphs, stove_amd/graphed.py).
  * stove_stream_after: everything enqueued on `to` from now on runs after everything enqueued on `from` so far.  Plain streams: an

@@ -56,13 +56,20 @@ __global__ void tile_unpack_k(const float* __restrict__ tile, float* __restrict_
   }
 }
 
-// measurement / test switch: 0 = the lane-per-glimpse gather kernel (tests compare the two bit for bit)
+// which glimpse-tile kernel the scene forward runs: 1 (default) = lane per PIXEL with the tile transposed through LDS up to three
+// objects, lane per glimpse beyond (28 % more VALU instructions in the transposing kernel -- 36 of 64 lanes idle in its second pass --
+// which the VALU-bound six-object scene phase pays for: 5.45 against 5.42 ms per step); 0 = lane per glimpse always; 2 = lane per
+// pixel always (the tests compare the two bit for bit at every object count)
 static std::atomic<int> g_tile_lds{1};
+static inline bool tile_transposed(int n_obj) {
+  const int m = g_tile_lds.load();
+  return m == 2 || (m == 1 && n_obj <= 3);
+}
 template <int NMAX>
 static int scene_tile_fwd(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st, FrameMap fm) {
   const int nb = (np + 63) / 64;
   const int grid = nb < 8192 ? nb : 8192;          // one workgroup per batch of 64 glimpses
-  if (g_tile_lds.load()) {          // lane = pixel, tile transposed through LDS (scene_tile_fwd_t_k)
+  if (tile_transposed(n_obj)) {          // lane = pixel, tile transposed through LDS (scene_tile_fwd_t_k)
     STOVE_LAUNCH((scene_tile_fwd_t_k<NMAX>), dim3(grid), dim3(64 * kTileTWaves), 0, st, frames, z, xw, n_obj, np, nb, fm, SceneGeom{});
     STOVE_LAUNCH_CHECK();
     return 0;
@@ -76,7 +83,7 @@ template <int NMAX>
 static int scene_tile_fwd_g(const float* frames, const float* z, float* xw, int n_obj, int np, hipStream_t st, FrameMap fm, SceneGeom gm) {
   const int nb = (np + 63) / 64;
   const int grid = nb < 8192 ? nb : 8192;
-  if (g_tile_lds.load()) {
+  if (tile_transposed(n_obj)) {
     STOVE_LAUNCH((scene_tile_fwd_t_k<NMAX, true>), dim3(grid), dim3(64 * kTileTWaves), 0, st, frames, z, xw, n_obj, np, nb, fm, gm);
     STOVE_LAUNCH_CHECK();
     return 0;
@@ -265,8 +272,9 @@ static hipStream_t scene_fork_stream(hipStream_t st) {
 
 // Measurement switch (explicit state instead of an environment read; default 1).
 // overlap 0: the scene calls run their background-SPN chain on the call's stream (no internal fork at all).
-int stove_set_tile_lds(int on) {
-  g_tile_lds.store(on ? 1 : 0);
+int stove_set_tile_lds(int mode) {
+  if (mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
+  g_tile_lds.store(mode);
   return 0;
 }
 

@@ -294,7 +294,7 @@ def test_glimpse_tile_kernel_lds_staging_is_bit_identical(n_obj, nf):
     z[:, 2:] = z[:, 2:] * 2.4 - 1.2                  # some glimpses hang over the border
     z = z.to(DEV).contiguous()
     outs = []
-    for mode in (0, 1):
+    for mode in (0, 2):
         lib.stove_set_tile_lds(mode)
         tile = torch.full((lib.stove_objspn_tile_floats(nf * n_obj),), float('nan'), device=DEV)
         pat = torch.empty(nf * n_obj, 100, device=DEV)
@@ -326,7 +326,7 @@ def test_scene_forward_on_strided_clips_is_the_same_with_either_tile_kernel():
     z[..., 2:] = z[..., 2:] * 1.8 - 0.9
     z = z.to(DEV)
     res = []
-    for mode in (0, 1):
+    for mode in (0, 2):
         lib.stove_set_tile_lds(mode)
         with torch.no_grad():
             ll, _ = sup.likelihood(x[:, 1:], z.reshape(-1, 4))
