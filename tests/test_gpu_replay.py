@@ -265,3 +265,46 @@ def test_data_parallel_replay_equals_eager_bitwise(tmp_path):
     for i in range(len(r[0][True])):                       # replicas: same reduced gradient, same parameters, different ELBOs
         assert torch.equal(r[0][True][i][1], r[1][True][i][1]) and torch.equal(r[0][True][i][2], r[1][True][i][2])
         assert not torch.equal(r[0][True][i][0], r[1][True][i][0])
+
+
+def test_set_overlap_switch_after_import_changes_the_schedule_not_the_numbers():
+    """settings.set_overlap: the one measurement switch can be flipped in a process that has already imported the package
+    -- the Python-side flag the ops read and the library's own, together.  One stream or five: the same ELBO bit for bit (the forward
+    runs the same kernels on the same operands) and the same gradients up to the summation order of the table-gradient partials
+    (held-back vs immediate placement use two kernels)."""
+    import torch
+    from stove_amd import settings
+    from stove_amd.arena import ParamArena
+    from stove_amd.envs import envs
+    from stove_amd.video_prediction.config import StoveConfig
+    from stove_amd.video_prediction.stove import Stove
+    dev = torch.device('cuda:0')
+    cfg = StoveConfig()
+    cfg.num_obj, cfg.width, cfg.height, cfg.random_seed = 3, 32, 32, 42
+    cfg.device, cfg.dtype, cfg.action_conditioned, cfg.action_space = dev, torch.float32, False, None
+    torch.manual_seed(0)
+    model = Stove(cfg).to(dev)
+    arena = ParamArena(model, 1)
+    B, T = 192, 100                                    # 19 200 encoder rows: the chunked forward chain and the held-back table gradients are on
+    x = torch.from_numpy(envs.synth_sequences('billiards', 24, T, seed0=3)['X']).repeat(8, 1, 1, 1, 1).to(dev).contiguous()
+    g = torch.Generator().manual_seed(9)
+    noise = {'latent': torch.randn(B, 3, 12, generator=g).to(dev), 'std': torch.randn(B, 3, 12, generator=g).to(dev),
+             'steps': torch.randn(B, T - 2, 3, 18, generator=g).to(dev)}
+    model.noise_fn = lambda kind, shape: noise[kind].reshape(shape)
+    res = {}
+    prev = settings.OVERLAP
+    try:
+        for on in (True, False, True):
+            assert settings.set_overlap(on) in (True, False) and settings.OVERLAP is on
+            arena.zero_grad()
+            elbo, _, _ = model(x, 1, None)
+            (-elbo).backward()
+            torch.cuda.synchronize()
+            res.setdefault(on, []).append((float(elbo), arena.grad.clone()))
+    finally:
+        settings.set_overlap(prev)
+    (e1, g1), (e3, g3) = res[True]
+    (e2, g2), = res[False]
+    assert e1 == e3 and torch.equal(g1, g3)                           # back on: the same schedule, the same bits
+    assert e1 == e2
+    assert float((g1 - g2).abs().max()) <= 2e-6 * float(g1.abs().max())
