@@ -13,10 +13,11 @@ from stove_amd import ops  # noqa: E402
 
 dev = torch.device('cuda:0')
 T = int(os.environ.get('T8_FRAMES', '8'))
-data = bench.make_batch('billiards', 256, T, 0)
+WL = os.environ.get('T8_WORKLOAD', 'billiards')
+data = bench.make_batch(WL, 256, T, 0)
 names = [s.split('=')[0] for s in switches]
 values = [[int(v) for v in s.split('=')[1].split(',')] for s in switches]
-for rep in range(3):
+for rep in range(int(os.environ.get('T8_REPS', '3'))):
     for combo in itertools.product(*values):
         for n, v in zip(names, combo):
             if n == 'OVERLAP':
@@ -24,7 +25,7 @@ for rep in range(3):
                 settings.set_overlap(bool(v))
             else:
                 setattr(ops, n, v)
-        job = bench.Job('billiards', dev, data, 'bf16x3', 'f32', 1)
+        job = bench.Job(WL, dev, data, 'bf16x3', 'f32', 1)
         job.step(0)
         ms, ms_max, _ = job.median_ms(60)
         print(dict(zip(names, combo)), 'ms/step %.4f (max %.4f)' % (ms, ms_max), flush=True)
