@@ -201,3 +201,41 @@ def test_library_entry_points_call_the_validation_layer():
         used = set(re.findall(r'STOVE_VALIDATE\((\w+)\(', f.read()))
     helpers = {'obj_tables', 'bg_tables', 'table_grads', 'frame_map', 'gnn_shape'}
     assert checks - helpers == used, (sorted(checks - helpers - used), sorted(used - checks))
+
+
+def test_product_path_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under stove_amd/ or model/ (the product) may import, load or name it, and nothing
+    there may reach for /root/reference; bench.py may only import it inside cpu_baseline() (after the timed region) and
+    __graft_entry__.py only inside smoke()."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    for top in ('stove_amd', 'model'):
+        for dirpath, _, files in os.walk(os.path.join(root, top)):
+            for fn in files:
+                if not fn.endswith(('.py', '.hip', '.h')):
+                    continue
+                with open(os.path.join(dirpath, fn), errors='replace') as f:
+                    text = f.read()
+                if re.search(r'stove_oracle|/root/reference|import oracle|from oracle', text):
+                    offenders.append(os.path.join(dirpath, fn))
+    assert not offenders, offenders
+
+    def importers(path):
+        """names of the functions whose bodies import stove_oracle (module level = '<module>')"""
+        with open(path) as f:
+            tree = ast.parse(f.read())
+        found = []
+
+        def visit(node, fn):
+            for child in ast.iter_child_nodes(node):
+                name = child.name if isinstance(child, (ast.FunctionDef, ast.AsyncFunctionDef)) else fn
+                if isinstance(child, (ast.Import, ast.ImportFrom)):
+                    mods = [a.name for a in child.names] + ([child.module] if isinstance(child, ast.ImportFrom) and child.module else [])
+                    if any(m and 'stove_oracle' in m for m in mods):
+                        found.append(fn)
+                visit(child, name)
+        visit(tree, '<module>')
+        return found
+    assert importers(os.path.join(root, 'bench.py')) == ['cpu_baseline']
+    assert importers(os.path.join(root, '__graft_entry__.py')) == ['smoke']
