@@ -196,6 +196,7 @@ def cpu_baseline(workload, T, n_seq, data_small, data_full, full_batch):
         times[threads].append(one(x, nb))
     med = lambda v: sorted(v)[0] if len(v) == 1 else 0.5 * (sorted(v)[0] + sorted(v)[1])
     fps = lambda k: nb * T / med(times[k])
+    best = max((counts[0], best), key=fps)          # of the two counts timed twice, by their medians (host timings of one step scatter)
     torch.set_num_threads(best)
     cores = best
     desc = f'{workload} B={nb} T={T} fp32 fwd+bwd' + (f' (a {nb}-sequence sample of the quoted batch of 256)' if nb < 256 else '')
