@@ -1312,8 +1312,7 @@ int stove_colsum2(const float* a, float* out, float* out2, int accumulate, float
     STOVE_LAUNCH_CHECK();
     src = ws2;
   }
-  STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, src, out, cols, used, accumulate);
-  if (out2 != nullptr) STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, src, out2, cols, used, accumulate);
+  STOVE_LAUNCH(reduce_chunks_k, dim3((cols + 31) / 32), dim3(256), 0, st, src, out, cols, used, accumulate, out2);      // both outputs in one launch
   STOVE_LAUNCH_CHECK();
   return 0;
 }

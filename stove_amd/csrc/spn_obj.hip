@@ -961,7 +961,8 @@ __global__ void objspn_tile_to_arrays_k(const float* __restrict__ dxw, const flo
 // out[j] = sum_c part[c][j]  (fixed order -> bitwise reproducible).
 // 256 threads = 32 elements x 8 chunk slices: slice q adds chunks q, q+8, ...; the 8 slice sums are then
 // added in slice order.  (One thread per element walking all chunks serially was latency-bound.)
-__global__ __launch_bounds__(256) void reduce_chunks_k(const float* __restrict__ part, float* __restrict__ out, int n, int n_chunks, int accumulate) {
+__global__ __launch_bounds__(256) void reduce_chunks_k(const float* __restrict__ part, float* __restrict__ out, int n, int n_chunks, int accumulate,
+                                                       float* __restrict__ out2 = nullptr) {      // out2: a second destination of the same sums
   __shared__ float red[8][32];
   const int e = threadIdx.x & 31, q = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + e;
@@ -975,6 +976,44 @@ __global__ __launch_bounds__(256) void reduce_chunks_k(const float* __restrict__
 #pragma unroll
     for (int k = 1; k < 8; ++k) t += red[k][e];
     out[j] = accumulate ? out[j] + t : t;
+    if (out2 != nullptr) out2[j] = accumulate ? out2[j] + t : t;
+  }
+}
+
+// Three such reductions as ONE launch (the object SPN's coefficient, sum-weight and root-weight partials share their chunk count): a
+// launch costs 5-8 us whatever it does, and these sit in a row on the parameter stream.  Block ranges [0, nb0), [nb0, nb0 + nb1), ...
+// take the three arrays; per element the same slices in the same order as reduce_chunks_k: identical sums.
+struct Reduce3 {
+  const float* part[3];
+  float* out[3];
+  int n[3];
+};
+__global__ __launch_bounds__(256) void reduce_chunks3_k(Reduce3 a, int n_chunks) {
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, q = threadIdx.x >> 5;
+  int blk = blockIdx.x, seg = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int nbk = (a.n[k] + 31) / 32;
+    if (seg == k && blk >= nbk) {
+      blk -= nbk;
+      seg = k + 1;
+    }
+  }
+  const float* __restrict__ part = seg == 0 ? a.part[0] : (seg == 1 ? a.part[1] : a.part[2]);
+  float* __restrict__ out = seg == 0 ? a.out[0] : (seg == 1 ? a.out[1] : a.out[2]);
+  const int n = seg == 0 ? a.n[0] : (seg == 1 ? a.n[1] : a.n[2]);
+  const int j = blk * 32 + e;
+  float s = 0.0f;
+  if (j < n)
+    for (int c = q; c < n_chunks; c += 8) s += part[(size_t)c * n + j];
+  red[q][e] = s;
+  __syncthreads();
+  if (q == 0 && j < n) {
+    float t = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][e];
+    out[j] = t;
   }
 }
 
@@ -1105,9 +1144,11 @@ int objspn_backward_params(const float* xw, const int* scope, float* g_coef, flo
     STOVE_LAUNCH((objspn_tablegrad_k<6, 25, 10, 10>), dim3(chunks), dim3(768), kTgLds, st, xw, Dscr, Sscr, Rscr, scope, pc, pw, pr, nb, chunks, scale);
     STOVE_LAUNCH_CHECK();
   }
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjCoefN + 31) / 32), dim3(256), 0, st, pc, g_coef, (int)kObjCoefN, chunks, 0);
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjWN + 31) / 32), dim3(256), 0, st, pw, g_wsum, (int)kObjWN, chunks, 0);
-  STOVE_LAUNCH(reduce_chunks_k, dim3((kObjRootN + 31) / 32), dim3(256), 0, st, pr, g_wroot, (int)kObjRootN, chunks, 0);
+  Reduce3 r3;
+  r3.part[0] = pc; r3.part[1] = pw; r3.part[2] = pr;
+  r3.out[0] = g_coef; r3.out[1] = g_wsum; r3.out[2] = g_wroot;
+  r3.n[0] = (int)kObjCoefN; r3.n[1] = (int)kObjWN; r3.n[2] = (int)kObjRootN;
+  STOVE_LAUNCH(reduce_chunks3_k, dim3((kObjCoefN + 31) / 32 + (kObjWN + 31) / 32 + (kObjRootN + 31) / 32), dim3(256), 0, st, r3, chunks);
   STOVE_LAUNCH_CHECK();
   return 0;
 }
