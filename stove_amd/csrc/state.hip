@@ -116,16 +116,13 @@ __device__ __forceinline__ void g6_at(const float* __restrict__ g_zl, const floa
   }
 }
 
-// step 1 of the backward, thread (b, t, k): gradient w.r.t. the smoothed state zfix[b, t, k, :]
-__global__ void supair_state_bwd1_k(const float* __restrict__ zfix, const float* __restrict__ g_zfix, const float* __restrict__ g_zl,
-                                    const float* __restrict__ g_sl, const float* __restrict__ g_init6, float* __restrict__ gfix,
-                                    int n, int T, int o, int skip, int init_ld) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * T * o) return;
-  const int k = i % o, t = (i / o) % T, b = i / (o * T);
-  float g[8];
+// gradient w.r.t. the smoothed state zfix[b, t, k, :] = element i of the (n, T, o) grid -> g[8]
+__device__ __forceinline__ void supair_gfix(const float* __restrict__ zfix, const float* __restrict__ g_zfix, const float* __restrict__ g_zl,
+                                            const float* __restrict__ g_sl, const float* __restrict__ g_init6, size_t i, int T, int o, int skip,
+                                            int init_ld, float (&g)[8]) {
+  const int k = (int)(i % o), t = (int)((i / o) % T), b = (int)(i / ((size_t)o * T));
 #pragma unroll
-  for (int d = 0; d < 8; ++d) g[d] = g_zfix != nullptr ? g_zfix[(size_t)i * 8 + d] : 0.0f;
+  for (int d = 0; d < 8; ++d) g[d] = g_zfix != nullptr ? g_zfix[i * 8 + d] : 0.0f;
   float gz[6], gs[6], gzn[6], gsn[6];
   g6_at(g_zl, g_sl, g_init6, b, t, k, T, o, skip, gz, gs, init_ld);
   g6_at(g_zl, g_sl, g_init6, b, t + 1, k, T, o, skip, gzn, gsn, init_ld);
@@ -135,28 +132,30 @@ __global__ void supair_state_bwd1_k(const float* __restrict__ zfix, const float*
     g[4 + d] += gs[d];
   }
   float cur[8];
-  load8(zfix + (size_t)i * 8, cur);
+  load8(zfix + i * 8, cur);
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     g[2 + a] += gz[4 + a] - gzn[4 + a];                  // v[t] = x[t] - x[t-1],  v[t+1] = x[t+1] - x[t]
     if (gs[4 + a] != 0.0f) {                             // vstd[t] = sqrt(s[t]^2 + s[t-1]^2)
-      const float p = zfix[((size_t)i - o) * 8 + 6 + a];
+      const float p = zfix[(i - o) * 8 + 6 + a];
       g[6 + a] += gs[4 + a] * cur[6 + a] / sqrtf(cur[6 + a] * cur[6 + a] + p * p);
     }
     if (gsn[4 + a] != 0.0f) {                            // vstd[t+1] = sqrt(s[t+1]^2 + s[t]^2)
-      const float q = zfix[((size_t)i + o) * 8 + 6 + a];
+      const float q = zfix[(i + o) * 8 + 6 + a];
       g[6 + a] += gsn[4 + a] * cur[6 + a] / sqrtf(q * q + cur[6 + a] * cur[6 + a]);
     }
   }
-#pragma unroll
-  for (int d = 0; d < 8; ++d) gfix[(size_t)i * 8 + d] = g[d];
 }
 
-// step 2, thread (b, t, j) with j the PRE-matching object index: undo the smoothing stencil and the gather
-// (as a gather over the slots k with idx[k] == j: no atomics, also right for the non-permutation 'volatile' mode),
-// then the sigmoid constraint -> g_codes (M, 8)
-__global__ void supair_state_bwd2_k(const float* __restrict__ zc, const long long* __restrict__ idx, const unsigned char* __restrict__ hits,
-                                    const float* __restrict__ gfix, ZpConst kc, float* __restrict__ g_codes, int n, int T, int o) {
+// The backward in ONE launch (round 6), thread (b, t, j) with j the PRE-matching object index: undo the smoothing stencil and the
+// gather (as a gather over the slots k with idx[k] == j: no atomics, also right for the non-permutation 'volatile' mode), then the
+// sigmoid constraint -> g_codes (M, 8).  The gradient of the smoothed state at (t, k) -- and, where fix_supair fired, at its time
+// neighbours -- is formed on the fly by supair_gfix (until round 5 a first launch wrote it for all (t, k) and a second one read it
+// back: two sub-10-us kernels on the step's serial chain); the same expressions in the same order: identical gradients.
+__global__ void supair_state_bwd_k(const float* __restrict__ zc, const long long* __restrict__ idx, const unsigned char* __restrict__ hits,
+                                   const float* __restrict__ zfix, const float* __restrict__ g_zfix, const float* __restrict__ g_zl,
+                                   const float* __restrict__ g_sl, const float* __restrict__ g_init6, ZpConst kc, float* __restrict__ g_codes,
+                                   int n, int T, int o, int skip, int init_ld) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * T * o) return;
   const int j = i % o, t = (i / o) % T, b = i / (o * T);
@@ -167,12 +166,16 @@ __global__ void supair_state_bwd2_k(const float* __restrict__ zc, const long lon
     const size_t e = row * o + k;
     const int h0 = hits[e];
     const int hp = (t >= 1) ? hits[e - o] : 0, hn = (t <= T - 2) ? hits[e + o] : 0;
+    float g0[8], gp[8], gn[8];
+    supair_gfix(zfix, g_zfix, g_zl, g_sl, g_init6, e, T, o, skip, init_ld, g0);
+    if (hp) supair_gfix(zfix, g_zfix, g_zl, g_sl, g_init6, e - o, T, o, skip, init_ld, gp);
+    if (hn) supair_gfix(zfix, g_zfix, g_zl, g_sl, g_init6, e + o, T, o, skip, init_ld, gn);
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
       const int bit = 1 << (d & 1);
-      float v = (h0 & bit) ? 0.0f : gfix[e * 8 + d];
-      if (hp & bit) v += 0.5f * gfix[(e - o) * 8 + d];
-      if (hn & bit) v += 0.5f * gfix[(e + o) * 8 + d];
+      float v = (h0 & bit) ? 0.0f : g0[d];
+      if (hp & bit) v += 0.5f * gp[d];
+      if (hn & bit) v += 0.5f * gn[d];
       acc[d] += v;
     }
   }
