@@ -324,8 +324,10 @@ int stove_supair_state_bwd2(const float* zc, const long long* idx, const unsigne
                             const float* g_zl, const float* g_sl, const float* g_init6, int init_ld, const float* span_low, float* gfix_ws,
                             float* g_codes, int n, int T, int o, int skip, void* stream);
 int stove_zall_fwd(const float* zfix, const float* zs, float* zall, int n, int T, int o, int skip, void* stream);
-int stove_zall_bwd(const float* zfix, const float* zs, const float* g_zall, float* g_zfix, float* g_zs, int n, int T, int o, int skip,
-                   void* stream);
+/* dz_in (NULL = none): the gradient zs receives from its other consumers (the ELBO's log q and transition terms; layout of zs): g_zs = the
+ * likelihood's part + dz_in, so that the caller needs no separate accumulation pass. */
+int stove_zall_bwd(const float* zfix, const float* zs, const float* g_zall, const float* dz_in, float* g_zfix, float* g_zs, int n, int T, int o,
+                   int skip, void* stream);
 int stove_elbo_fwd(const float* zs, const float* mean, const float* std_, const float* zdyn, const float* lik, const float* trans_std16,
                    float* part_ws, float* out3, int n, int T, int o, int skip, void* stream);
 int stove_elbo_bwd(const float* zs, const float* mean, const float* std_, const float* zdyn, const float* trans_std16, const float* g_out,

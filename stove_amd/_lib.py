@@ -155,7 +155,7 @@ def _declare(lib):
         'stove_supair_state_fwd2': (I, [P] * 10 + [I, P, I] + [I] * 6 + [P]),
         'stove_supair_state_bwd2': (I, [P] * 8 + [I] + [P] * 3 + [I] * 4 + [P]),
         'stove_zall_fwd': (I, [P, P, P, I, I, I, I, P]),
-        'stove_zall_bwd': (I, [P, P, P, P, P, I, I, I, I, P]),
+        'stove_zall_bwd': (I, [P, P, P, P, P, P, I, I, I, I, P]),
         'stove_elbo_fwd': (I, [P] * 8 + [I] * 4 + [P]),
         'stove_elbo_bwd': (I, [P] * 11 + [I] * 4 + [P]),
         'stove_arena_gather': (I, [P, P, P, I, P]),

@@ -1432,11 +1432,11 @@ int stove_zall_fwd(const float* zfix, const float* zs, float* zall, int n, int T
   return 0;
 }
 
-int stove_zall_bwd(const float* zfix, const float* zs, const float* g_zall, float* g_zfix, float* g_zs, int n, int T, int o, int skip,
-                   void* stream) {
+int stove_zall_bwd(const float* zfix, const float* zs, const float* g_zall, const float* dz_in, float* g_zfix, float* g_zs, int n, int T, int o,
+                   int skip, void* stream) {
   if (n == 0) return 0;
   const int M = n * T * o + n * (T - skip) * o;
-  STOVE_LAUNCH(zall_bwd_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, zfix, zs, g_zall, g_zfix, g_zs, n, T, o, skip);
+  STOVE_LAUNCH(zall_bwd_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, zfix, zs, g_zall, dz_in, g_zfix, g_zs, n, T, o, skip);
   STOVE_LAUNCH_CHECK();
   return 0;
 }

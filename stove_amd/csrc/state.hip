@@ -200,8 +200,10 @@ __global__ void zall_fwd_k(const float* __restrict__ zfix, const float* __restri
   zall[(size_t)i * 4 + 3] = src[3];
 }
 // writes EVERY element of g_zfix (n,T,o,8) and g_zs (n,Ts,o,18): no memset needed
+// dz_in (NULL = none): what the OTHER consumers of zs contribute to its gradient (the ELBO's log q and transition terms), same
+// layout as g_zs -- added here instead of by a separate elementwise launch behind this one
 __global__ void zall_bwd_k(const float* __restrict__ zfix, const float* __restrict__ zs, const float* __restrict__ g_zall,
-                           float* __restrict__ g_zfix, float* __restrict__ g_zs, int n, int T, int o, int skip) {
+                           const float* __restrict__ dz_in, float* __restrict__ g_zfix, float* __restrict__ g_zs, int n, int T, int o, int skip) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int nfix = n * T * o, nzs = n * (T - skip) * o;
   if (i < nfix) {
@@ -223,12 +225,19 @@ __global__ void zall_bwd_k(const float* __restrict__ zfix, const float* __restri
     const size_t a = (((size_t)b * (T - 1) + (skip - 1 + ts)) * o + k) * 4;
     const float* src = zs + (size_t)q * 18;
     float* g = g_zs + (size_t)q * 18;
-    g[0] = g_zall[a] + g_zall[a + 1] * src[1];
-    g[1] = g_zall[a + 1] * src[0];
-    g[2] = g_zall[a + 2];
-    g[3] = g_zall[a + 3];
+    float v[4];
+    v[0] = g_zall[a] + g_zall[a + 1] * src[1];
+    v[1] = g_zall[a + 1] * src[0];
+    v[2] = g_zall[a + 2];
+    v[3] = g_zall[a + 3];
+    if (dz_in == nullptr) {
 #pragma unroll
-    for (int d = 4; d < 18; ++d) g[d] = 0.0f;
+      for (int d = 0; d < 18; ++d) g[d] = d < 4 ? v[d] : 0.0f;
+    } else {
+      const float* gi = dz_in + (size_t)q * 18;
+#pragma unroll
+      for (int d = 0; d < 18; ++d) g[d] = d < 4 ? v[d] + gi[d] : gi[d];
+    }
   }
 }
 

@@ -773,7 +773,9 @@ class _SupairStateFn(torch.autograd.Function):
 
 
 class _ZallFn(torch.autograd.Function):
-    """z of the scene likelihood for frames 1..T-1 (reference stove.py:731-736 + sy_from_quotient) -> (n*(T-1)*o, 4)."""
+    """z of the scene likelihood for frames 1..T-1 (reference stove.py:731-736 + sy_from_quotient) -> (n*(T-1)*o, 4), and zs handed
+    through: the caller gives the SECOND output to the other consumers of zs (the ELBO terms), so that their gradient arrives here
+    and is added by the backward kernel instead of by an accumulation launch of its own between this backward and the recursion's."""
 
     @staticmethod
     def forward(ctx, zfix, zs, n, T, o, skip):
@@ -785,17 +787,20 @@ class _ZallFn(torch.autograd.Function):
             check(lib.stove_zall_fwd(ptr(zfix), ptr(zs), ptr(zall), n, T, o, skip, stream()), 'stove_zall_fwd')
         ctx.save_for_backward(zfix, zs)
         ctx.cfg = (n, T, o, skip)
-        return zall
+        ctx.set_materialize_grads(False)
+        return zall, zs.view_as(zs)
 
     @staticmethod
-    def backward(ctx, g_zall):
+    def backward(ctx, g_zall, g_pass):
         lib = _lib.load()
         zfix, zs = ctx.saved_tensors
         n, T, o, skip = ctx.cfg
+        if g_zall is None:
+            return None, g_pass, None, None, None, None
         with torch.cuda.device(zfix.device):
             g_zfix, g_zs = torch.empty_like(zfix), torch.empty_like(zs)
-            check(lib.stove_zall_bwd(ptr(zfix), ptr(zs), ptr(_f32(g_zall)), ptr(g_zfix), ptr(g_zs), n, T, o, skip, stream()),
-                  'stove_zall_bwd')
+            check(lib.stove_zall_bwd(ptr(zfix), ptr(zs), ptr(_f32(g_zall)), ptr(_f32(g_pass)) if g_pass is not None else None, ptr(g_zfix), ptr(g_zs),
+                                     n, T, o, skip, stream()), 'stove_zall_bwd')
         return g_zfix, g_zs, None, None, None, None
 
 
@@ -846,6 +851,7 @@ def supair_state(codes, span_low, n, T, o, skip, fix, mode, lat_noise=None):
 
 
 def zall(zfix, zs, n, T, o, skip):
+    """-> (z_all, zs handed through): use the second value wherever zs is differentiated next (see _ZallFn)."""
     return _ZallFn.apply(zfix, zs, int(n), int(T), int(o), int(skip))
 
 

@@ -295,7 +295,7 @@ class Stove(nn.Module):
         # The reference scores frames skip..T-1 (sampled z) and frame 1..skip-1 (SuPAIR mean) in two
         # likelihood calls (stove.py:731-736); here both go through ONE fused scene launch.
         if fused_state:
-            z_all = ops.zall(zfix, z_s, n, T, o, skip)
+            z_all, z_s = ops.zall(zfix, z_s, n, T, o, skip)        # (z_s handed through: its ELBO gradient is added by zall's backward kernel)
         else:
             z_all = torch.cat([z_sup[:, 1:skip], z_s[..., :4]], 1)             # (n, T-1, o, 4) [sx, sy/sx, x, y]
             z_all = self.sup.sy_from_quotient(z_all.flatten(end_dim=2))
