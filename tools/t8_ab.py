@@ -9,7 +9,7 @@ sys.argv, switches = [sys.argv[0]], sys.argv[1:]
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from stove_amd import ops  # noqa: E402
+from stove_amd import graphed, ops  # noqa: E402
 
 dev = torch.device('cuda:0')
 T = int(os.environ.get('T8_FRAMES', '8'))
@@ -23,6 +23,8 @@ for rep in range(int(os.environ.get('T8_REPS', '3'))):
             if n == 'OVERLAP':
                 from stove_amd import settings
                 settings.set_overlap(bool(v))
+            elif hasattr(graphed, n):
+                setattr(graphed, n, v)
             else:
                 setattr(ops, n, v)
         job = bench.Job(WL, dev, data, 'bf16x3', 'f32', 1)
